@@ -1,0 +1,155 @@
+"""Dispatch of binary layers onto the HIP XNOR/popcount path.
+
+A layer takes the HIP path when ALL of the following hold (otherwise the torch composition in
+``layers/*.py`` — the reference's own formulation — runs):
+
+* hooks are exactly ``BasicInputBinarizer`` / ``XNORWeightBinarizer`` / (``Identity`` or a
+  per-output-channel ``BasicScaleBinarizer``)      (reference: ``examples/cifar10.py:65-69``,
+  ``test/test_layers.py:17-21``)
+* input and weight are float32 on the same HIP device
+* autograd is not recording (``torch.no_grad()`` / inference) — the kernels have no backward
+* ``groups == 1``, ``padding_mode == 'zeros'``, numeric padding
+
+When those hold and ``libbnn_hip.so`` cannot be loaded the call raises ``NativeError``: there is
+no CPU or eager stand-in for the GPU path.
+
+Packed weights (1 bit + 1 mask bit per weight, alpha per channel) are derived data: they are
+cached on the layer, keyed on the weight's storage pointer and version counter, and rebuilt after
+``load_state_dict`` / ``.to()`` / optimiser steps.  The fp32 ``weight`` Parameter stays the source
+of truth (reference: ``bnn/layers/conv.py:111-112`` shares it with the float module).
+"""
+from __future__ import annotations
+
+import threading
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import hipops, native, ops
+from .bconfig import Identity
+
+_stats_lock = threading.Lock()
+_stats = {"conv2d": 0, "conv1d": 0, "linear": 0, "weight_packs": 0}
+
+
+def stats() -> dict:
+    """Counters of HIP-path invocations (tests use them to prove which path ran)."""
+    with _stats_lock:
+        return dict(_stats)
+
+
+def _bump(key: str) -> None:
+    with _stats_lock:
+        _stats[key] += 1
+
+
+@dataclass
+class Plan:
+    center: bool
+    compute_alpha: bool
+    scale: Optional[torch.Tensor]  # BasicScaleBinarizer.alpha or None
+
+
+def _recognise(layer: nn.Module, out_channels: int) -> Optional[Plan]:
+    pre = layer.activation_pre_process
+    wpre = layer.weight_pre_process
+    post = layer.activation_post_process
+    if type(pre) is not ops.BasicInputBinarizer or type(wpre) is not ops.XNORWeightBinarizer:
+        return None
+    if type(post) is Identity:
+        scale = None
+    elif type(post) is ops.BasicScaleBinarizer and post.alpha.numel() == out_channels \
+            and post.alpha.dim() >= 2 and post.alpha.shape[1] == out_channels:
+        scale = post.alpha
+    else:
+        return None
+    return Plan(bool(wpre.center_weights), bool(wpre.compute_alpha), scale)
+
+
+def _eligible(layer: nn.Module, x: torch.Tensor, plan: Plan) -> bool:
+    w = layer.weight
+    if not (x.is_cuda and w.is_cuda and x.device == w.device):
+        return False
+    if x.dtype != torch.float32 or w.dtype != torch.float32:
+        return False
+    if torch.is_grad_enabled():
+        needs = x.requires_grad or w.requires_grad
+        needs = needs or (layer.bias is not None and layer.bias.requires_grad)
+        needs = needs or (plan.scale is not None and plan.scale.requires_grad)
+        if needs:
+            return False
+    return True
+
+
+def _numeric_padding(layer) -> bool:
+    return not isinstance(layer.padding, str) and layer.padding_mode == "zeros" and layer.groups == 1
+
+
+def plan_conv2d(layer, x: torch.Tensor) -> Optional[Plan]:
+    if x.dim() != 4 or not _numeric_padding(layer):
+        return None
+    plan = _recognise(layer, layer.out_channels)
+    return plan if plan is not None and _eligible(layer, x, plan) else None
+
+
+def plan_conv1d(layer, x: torch.Tensor) -> Optional[Plan]:
+    if x.dim() != 3 or not _numeric_padding(layer):
+        return None
+    plan = _recognise(layer, layer.out_channels)
+    return plan if plan is not None and _eligible(layer, x, plan) else None
+
+
+def plan_linear(layer, x: torch.Tensor) -> Optional[Plan]:
+    if x.dim() < 1:
+        return None
+    plan = _recognise(layer, layer.out_features)
+    return plan if plan is not None and _eligible(layer, x, plan) else None
+
+
+def packed_weight(layer, plan: Plan) -> hipops.PackedWeight:
+    """Cached ``XNORWeightBinarizer`` output for ``layer.weight`` (rebuilt when it changes)."""
+    w = layer.weight
+    key = (w.data_ptr(), w._version, str(w.device), tuple(w.shape), plan.center, plan.compute_alpha)
+    cached = layer.__dict__.get("_bnn_packed")
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    pw = hipops.pack_weight(w, plan.center, plan.compute_alpha)
+    layer.__dict__["_bnn_packed"] = (key, pw)
+    _bump("weight_packs")
+    return pw
+
+
+def conv2d(layer, x: torch.Tensor, plan: Plan) -> torch.Tensor:
+    """HIP evaluation of ``bnn.layers.Conv2d.forward`` (bnn/layers/conv.py:90-97)."""
+    native.require()
+    pw = packed_weight(layer, plan)
+    act = hipops.pack_act(x)
+    out = hipops.bconv2d(act, pw, layer.bias, plan.scale, layer.stride, layer.padding,
+                         layer.dilation)
+    _bump("conv2d")
+    return out
+
+
+def conv1d(layer, x: torch.Tensor, plan: Plan) -> torch.Tensor:
+    """``Conv1d`` as an ``H == 1`` 2-D convolution (bnn/layers/conv.py:36-43)."""
+    native.require()
+    pw = packed_weight(layer, plan)
+    act = hipops.pack_act(x.unsqueeze(2))
+    out = hipops.bconv2d(act, pw, layer.bias, plan.scale, (1, layer.stride[0]),
+                         (0, layer.padding[0]), (1, layer.dilation[0]))
+    _bump("conv1d")
+    return out.squeeze(2)
+
+
+def linear(layer, x: torch.Tensor, plan: Plan) -> torch.Tensor:
+    """``Linear`` as a 1x1 convolution over 1x1 images (bnn/layers/linear.py:22-27)."""
+    native.require()
+    pw = packed_weight(layer, plan)
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    act = hipops.pack_act(x2[:, :, None, None])
+    out = hipops.bconv2d(act, pw, layer.bias, plan.scale)
+    _bump("linear")
+    return out.reshape(*lead, layer.out_features)

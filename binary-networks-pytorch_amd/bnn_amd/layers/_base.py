@@ -1,0 +1,54 @@
+"""Behaviour shared by the binary Conv1d / Conv2d / Linear layers.
+
+Reference template (identical in ``bnn/layers/conv.py:10-117`` and ``bnn/layers/linear.py:9-44``):
+
+    forward(x) = post( F.op( pre(x), wpre(weight), bias ), x )
+
+with ``pre``/``post``/``wpre`` instantiated from the layer's ``BConfig`` at construction and
+registered as sub-modules (so they appear in ``state_dict()`` and ``repr``).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch.nn as nn
+
+from ..bconfig import BConfig
+from .helpers import copy_paramters
+
+
+class BinaryLayerMixin:
+    """Hook construction + ``from_module`` for classes that also derive from a float layer."""
+
+    _FLOAT_MODULE: type = nn.Module
+
+    def _init_hooks(self, bconfig: Optional[BConfig]) -> None:
+        assert bconfig, "bconfig is required for a binarized module"
+        self.bconfig = bconfig
+        self.activation_pre_process = bconfig.activation_pre_process()
+        self.activation_post_process = bconfig.activation_post_process(self)
+        self.weight_pre_process = bconfig.weight_pre_process()
+
+    @classmethod
+    def _ctor_kwargs(cls, mod: nn.Module) -> dict:  # pragma: no cover - overridden
+        raise NotImplementedError
+
+    @classmethod
+    def from_module(cls, mod: nn.Module, bconfig: Optional[BConfig] = None, update: bool = False):
+        """Build a binary twin of ``mod`` that SHARES its ``weight``/``bias`` Parameters.
+
+        Accepts the float class or an already-binary instance of ``cls`` (re-binarisation with
+        a new recipe), exactly as ``bnn/layers/conv.py:99-117``.
+        """
+        assert type(mod) == cls._FLOAT_MODULE or type(mod) == cls, (
+            "bnn." + cls.__name__ + ".from_float only works for " + cls._FLOAT_MODULE.__name__)
+        if not bconfig:
+            assert hasattr(mod, "bconfig"), "The input modele requires a predifined bconfig"
+            assert mod.bconfig, "The input modele bconfig is invalid"
+            bconfig = mod.bconfig
+        twin = cls(**cls._ctor_kwargs(mod), bconfig=bconfig)
+        twin.weight = mod.weight
+        twin.bias = mod.bias
+        if update:
+            copy_paramters(mod, twin, bconfig)
+        return twin

@@ -1,0 +1,72 @@
+// bnn_dev.h — device-side helpers shared by the gfx950 kernels.
+// Hand-written for CDNA4 (wave64, v_bitop3_b32, v_bcnt_u32_b32); no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bnn_hip.h"
+
+namespace bnn {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kOCB = BNN_HIP_OCB;  // output channels per weight block
+
+// Disagreement word of 32 ternary activations against 32 binary weights.
+//   w bit = 1 (weight +1): disagree where the activation is negative  -> take M
+//   w bit = 0 (weight -1): disagree where the activation is positive  -> take P
+// The expression is matched by hipcc to ONE v_bitop3_b32 (truth table 0xe4) on gfx950.
+__device__ __forceinline__ uint32_t disagree(uint32_t w, uint32_t m, uint32_t p) {
+  return (w & m) | (~w & p);
+}
+
+// v_cmp_class_f32 masks: bit0 sNaN,1 qNaN,2 -inf,3 -normal,4 -denorm,5 -0,6 +0,7 +denorm,8 +normal,9 +inf.
+// Using the class test (not a float compare) makes the planes independent of the
+// kernel's denormal mode and maps NaN to "zero", exactly like torch.sign on CPU.
+constexpr int kClassPos = 0x380;  // +denorm | +normal | +inf
+constexpr int kClassNeg = 0x01C;  // -inf | -normal | -denorm
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ bool is_pos(float x) { return __builtin_amdgcn_classf(x, kClassPos); }
+__device__ __forceinline__ bool is_neg(float x) { return __builtin_amdgcn_classf(x, kClassNeg); }
+#else  // host pass of hipcc only parses these; the amdgcn builtin does not exist for x86
+__device__ __forceinline__ bool is_pos(float) { return false; }
+__device__ __forceinline__ bool is_neg(float) { return false; }
+#endif
+
+template <int N>
+struct WordVec;
+template <>
+struct WordVec<1> { using type = uint32_t; };
+template <>
+struct WordVec<2> { using type = uint2; };
+template <>
+struct WordVec<4> { using type = uint4; };
+
+// Everything one binary-convolution launch needs (device pointers + geometry).
+struct ConvP {
+  const uint32_t* P;
+  const uint32_t* M;
+  const uint16_t* nzc;
+  const uint32_t* W;
+  const uint32_t* Z;
+  const float* alpha;
+  const float* bias;
+  const float* scale;
+  void* out;
+  int N, H, Wd, Ho, Wo, O;
+  int KH, KW, sh, sw, ph, pw, dh, dw;
+  int cw32, cwc, nchunk;
+  int npix;  // N*Ho*Wo
+};
+
+// host-side launchers (one per .hip file); return a bnn_hip_status
+int choose_cwc(int cw32, int KH, int KW);
+int launch_pack_act(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
+                    uint16_t* nzc, hipStream_t stream);
+int launch_pack_weight(const float* w, int O, int C, int KH, int KW, int center, int compute_alpha,
+                       const bnn_hip_wlayout& L, uint32_t* wbits, uint32_t* wnz, float* alpha,
+                       int32_t* zero_flag, hipStream_t stream);
+int launch_bconv(const ConvP& p, int flags, bool raw, hipStream_t s);
+int launch_probe_int_alu(int iters, double* lane_ops_per_s, double* elapsed_ms, hipStream_t s);
+
+}  // namespace bnn

@@ -1,0 +1,196 @@
+// capi.hip — the extern "C" boundary declared in include/bnn_hip.h.
+// Argument validation, geometry, workspace carving and launch bookkeeping live here;
+// kernels live in pack_act.hip / pack_weight.hip / bconv.hip.
+#include <atomic>
+#include <cstring>
+
+#include "bnn_dev.h"
+
+namespace {
+
+std::atomic<uint64_t> g_launches{0};
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+constexpr long long kMaxElems = (1LL << 31) - 1;
+
+int out_dim(int in, int k, int s, int p, int d) { return (in + 2 * p - d * (k - 1) - 1) / s + 1; }
+
+int check_desc(const bnn_hip_conv_desc* d, int* Ho, int* Wo) {
+  if (!d) return BNN_HIP_ERR_INVALID_ARG;
+  if (d->N <= 0 || d->C <= 0 || d->H <= 0 || d->W <= 0 || d->O <= 0 || d->KH <= 0 || d->KW <= 0)
+    return BNN_HIP_ERR_INVALID_ARG;
+  if (d->stride_h <= 0 || d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0 || d->dil_h <= 0 ||
+      d->dil_w <= 0)
+    return BNN_HIP_ERR_INVALID_ARG;
+  if (d->C > 65535) return BNN_HIP_ERR_UNSUPPORTED;  // nzc is uint16
+  const int ho = out_dim(d->H, d->KH, d->stride_h, d->pad_h, d->dil_h);
+  const int wo = out_dim(d->W, d->KW, d->stride_w, d->pad_w, d->dil_w);
+  if (ho <= 0 || wo <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if ((long long)d->N * d->H * d->W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if ((long long)d->N * d->O * ho * wo > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  *Ho = ho;
+  *Wo = wo;
+  return BNN_HIP_OK;
+}
+
+int run_conv(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M, const uint16_t* nzc,
+             const uint32_t* wbits, const uint32_t* wnz, const float* alpha, const float* bias,
+             const float* post_scale, void* out, bool raw, void* stream) {
+  int Ho = 0, Wo = 0;
+  const int st = check_desc(d, &Ho, &Wo);
+  if (st != BNN_HIP_OK) return st;
+  if (!P || !M || !nzc || !wbits || !out || (!raw && !alpha)) return BNN_HIP_ERR_INVALID_ARG;
+  if ((d->flags & BNN_HIP_FLAG_WEIGHT_ZEROS) && !wnz) return BNN_HIP_ERR_INVALID_ARG;
+  if (!aligned(P, 16) || !aligned(M, 16) || !aligned(wbits, 16)) return BNN_HIP_ERR_INVALID_ARG;
+  bnn_hip_wlayout L;
+  bnn_hip_weight_layout(d->O, d->C, d->KH, d->KW, &L);
+  bnn::ConvP p;
+  p.P = reinterpret_cast<const uint32_t*>(P);
+  p.M = reinterpret_cast<const uint32_t*>(M);
+  p.nzc = nzc;
+  p.W = wbits;
+  p.Z = wnz;
+  p.alpha = alpha;
+  p.bias = bias;
+  p.scale = post_scale;
+  p.out = out;
+  p.N = d->N; p.H = d->H; p.Wd = d->W; p.Ho = Ho; p.Wo = Wo; p.O = d->O;
+  p.KH = d->KH; p.KW = d->KW; p.sh = d->stride_h; p.sw = d->stride_w;
+  p.ph = d->pad_h; p.pw = d->pad_w; p.dh = d->dil_h; p.dw = d->dil_w;
+  p.cw32 = L.cw32; p.cwc = L.cwc; p.nchunk = L.nchunk;
+  p.npix = d->N * Ho * Wo;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  return bnn::launch_bconv(p, d->flags, raw, static_cast<hipStream_t>(stream));
+}
+
+}  // namespace
+
+extern "C" {
+
+int bnn_hip_abi_version(void) { return BNN_HIP_ABI_VERSION; }
+
+const char* bnn_hip_status_string(int status) {
+  switch (status) {
+    case BNN_HIP_OK: return "ok";
+    case BNN_HIP_ERR_INVALID_ARG: return "invalid argument (null/misaligned pointer or non-positive size)";
+    case BNN_HIP_ERR_UNSUPPORTED: return "unsupported shape";
+    case BNN_HIP_ERR_LAUNCH: return "HIP kernel launch failed";
+    case BNN_HIP_ERR_TOO_LARGE: return "tensor exceeds 2^31-1 elements per launch; split the batch";
+    case BNN_HIP_ERR_NO_DEVICE: return "no usable HIP device";
+    default: return "unknown status";
+  }
+}
+
+uint64_t bnn_hip_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
+
+int bnn_hip_device_info(int device, bnn_hip_devinfo* out) {
+  if (!out) return BNN_HIP_ERR_INVALID_ARG;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return BNN_HIP_ERR_NO_DEVICE;
+  std::memset(out, 0, sizeof(*out));
+  std::strncpy(out->name, prop.name, sizeof(out->name) - 1);
+  std::strncpy(out->arch, prop.gcnArchName, sizeof(out->arch) - 1);
+  out->compute_units = prop.multiProcessorCount;
+  out->clock_khz = prop.clockRate;
+  out->mem_clock_khz = prop.memoryClockRate;
+  out->mem_bus_bits = prop.memoryBusWidth;
+  out->wavefront = prop.warpSize;
+  out->lds_bytes_per_block = (int32_t)prop.sharedMemPerBlock;
+  out->total_mem_bytes = (int64_t)prop.totalGlobalMem;
+  out->l2_bytes = prop.l2CacheSize;
+  return BNN_HIP_OK;
+}
+
+int bnn_hip_act_words(int C) { return C > 0 ? (C + 63) / 64 : BNN_HIP_ERR_INVALID_ARG; }
+
+int bnn_hip_weight_layout(int O, int C, int KH, int KW, bnn_hip_wlayout* out) {
+  if (!out || O <= 0 || C <= 0 || KH <= 0 || KW <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  out->cw32 = 2 * ((C + 63) / 64);
+  out->cwc = bnn::choose_cwc(out->cw32, KH, KW);
+  out->nchunk = out->cw32 / out->cwc;
+  out->taps = KH * KW;
+  out->o_pad = (O + BNN_HIP_OCB - 1) / BNN_HIP_OCB * BNN_HIP_OCB;
+  out->reserved = 0;
+  out->n_words = (int64_t)out->o_pad * out->taps * out->cw32;
+  return BNN_HIP_OK;
+}
+
+int bnn_hip_pack_act_f32(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
+                         uint16_t* nzc, void* stream) {
+  if (!x || !P || !M || !nzc || N <= 0 || C <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (C > 65535) return BNN_HIP_ERR_UNSUPPORTED;
+  if ((long long)N * C * H * W > kMaxElems * 4LL) return BNN_HIP_ERR_TOO_LARGE;
+  if (!aligned(P, 8) || !aligned(M, 8) || !aligned(x, 4)) return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  return bnn::launch_pack_act(x, N, C, H, W, P, M, nzc, static_cast<hipStream_t>(stream));
+}
+
+int bnn_hip_pack_weight_f32(const float* w, int O, int C, int KH, int KW, int center,
+                            int compute_alpha, uint32_t* wbits, uint32_t* wnz, float* alpha,
+                            int32_t* zero_flag, void* stream) {
+  if (!w || !wbits || !wnz || !alpha || !zero_flag) return BNN_HIP_ERR_INVALID_ARG;
+  bnn_hip_wlayout L;
+  const int st = bnn_hip_weight_layout(O, C, KH, KW, &L);
+  if (st != BNN_HIP_OK) return st;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  return bnn::launch_pack_weight(w, O, C, KH, KW, center, compute_alpha, L, wbits, wnz, alpha,
+                                 zero_flag, static_cast<hipStream_t>(stream));
+}
+
+int bnn_hip_bconv2d(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M,
+                    const uint16_t* nzc, const uint32_t* wbits, const uint32_t* wnz,
+                    const float* alpha, const float* bias, const float* post_scale, float* out,
+                    void* stream) {
+  return run_conv(d, P, M, nzc, wbits, wnz, alpha, bias, post_scale, out, false, stream);
+}
+
+int bnn_hip_bconv2d_dot(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M,
+                        const uint16_t* nzc, const uint32_t* wbits, const uint32_t* wnz,
+                        int32_t* dot, void* stream) {
+  return run_conv(d, P, M, nzc, wbits, wnz, nullptr, nullptr, nullptr, dot, true, stream);
+}
+
+int bnn_hip_blinear(int B, int F, int O, const uint64_t* P, const uint64_t* M, const uint16_t* nzc,
+                    const uint32_t* wbits, const uint32_t* wnz, int weight_zeros, const float* alpha,
+                    const float* bias, const float* post_scale, float* out, void* stream) {
+  bnn_hip_conv_desc d;
+  std::memset(&d, 0, sizeof(d));
+  d.N = B; d.C = F; d.H = 1; d.W = 1; d.O = O; d.KH = 1; d.KW = 1;
+  d.stride_h = d.stride_w = 1; d.dil_h = d.dil_w = 1;
+  d.flags = weight_zeros ? BNN_HIP_FLAG_WEIGHT_ZEROS : 0;
+  return run_conv(&d, P, M, nzc, wbits, wnz, alpha, bias, post_scale, out, false, stream);
+}
+
+size_t bnn_hip_conv_workspace_bytes(const bnn_hip_conv_desc* d) {
+  if (!d || d->N <= 0 || d->C <= 0 || d->H <= 0 || d->W <= 0) return 0;
+  const size_t npix = (size_t)d->N * d->H * d->W;
+  const size_t plane = align_up(npix * ((d->C + 63) / 64) * sizeof(uint64_t), 256);
+  return 2 * plane + align_up(npix * sizeof(uint16_t), 256);
+}
+
+int bnn_hip_bconv2d_f32(const bnn_hip_conv_desc* d, const float* x, const uint32_t* wbits,
+                        const uint32_t* wnz, const float* alpha, const float* bias,
+                        const float* post_scale, float* out, void* workspace, void* stream) {
+  if (!d || !x || !workspace || !aligned(workspace, 16)) return BNN_HIP_ERR_INVALID_ARG;
+  int Ho, Wo;
+  int st = check_desc(d, &Ho, &Wo);
+  if (st != BNN_HIP_OK) return st;
+  const size_t npix = (size_t)d->N * d->H * d->W;
+  const size_t plane = align_up(npix * ((d->C + 63) / 64) * sizeof(uint64_t), 256);
+  char* ws = static_cast<char*>(workspace);
+  uint64_t* P = reinterpret_cast<uint64_t*>(ws);
+  uint64_t* M = reinterpret_cast<uint64_t*>(ws + plane);
+  uint16_t* nzc = reinterpret_cast<uint16_t*>(ws + 2 * plane);
+  st = bnn_hip_pack_act_f32(x, d->N, d->C, d->H, d->W, P, M, nzc, stream);
+  if (st != BNN_HIP_OK) return st;
+  return run_conv(d, P, M, nzc, wbits, wnz, alpha, bias, post_scale, out, false, stream);
+}
+
+int bnn_hip_probe_int_alu(int iters, double* lane_ops_per_s, double* elapsed_ms, void* stream) {
+  if (iters <= 0 || !lane_ops_per_s) return BNN_HIP_ERR_INVALID_ARG;
+  return bnn::launch_probe_int_alu(iters, lane_ops_per_s, elapsed_ms, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,308 @@
+/*
+ * bnn_oracle.c — CPU restatement of the reference's binary Conv2d / Linear forward.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under binary-networks-pytorch_amd/ may import, link
+ * or call this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do,
+ * and there only as the checker.
+ *
+ * Parity status: PINNED — see oracle/README.md.  This restatement is checked (tests/
+ * test_oracle_cpu.py) against (a) the three known-answer vectors of the reference's own
+ * test/test_layers.py:30-67 and (b) fixtures produced by importing the reference package
+ * in the build container (tests/golden/make_golden.py -> tests/golden/*.npz).
+ *
+ * Each function cites the reference lines it follows (paths relative to the reference root).
+ * Two independent routes to the same numbers are provided on purpose:
+ *   route F (float):  sign -> sign(W)*alpha -> float conv          (what the reference does)
+ *   route I (integer): bit planes -> popcount dot -> fmaf epilogue (what the HIP path does)
+ * Route I must equal route F up to float rounding, and the HIP kernels must equal route I
+ * bit-for-bit.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define OCB 32 /* output-channel block of the packed weight layout (== BNN_HIP_OCB) */
+
+/* ------------------------------------------------------------------------------------ */
+/* torch.sign semantics: bnn/ops.py:63-66 (`input.sign()`).  NaN -> 0, -0 -> 0,         */
+/* denormals keep their sign.                                                           */
+/* ------------------------------------------------------------------------------------ */
+static inline int sgn(float v) { return (v > 0.0f) - (v < 0.0f); }
+
+void orc_sign_f32(const float* x, float* y, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) y[i] = (float)sgn(x[i]);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Deterministic reduction shared with the HIP pack_weight kernel (csrc/pack_weight.hip): */
+/* 64 strided partial sums in double, xor-butterfly 32..1, result in slot 0.             */
+/* ------------------------------------------------------------------------------------ */
+static double butterfly64(double part[64]) {
+  double tmp[64];
+  for (int s = 32; s >= 1; s >>= 1) {
+    for (int i = 0; i < 64; ++i) tmp[i] = part[i] + part[i ^ s];
+    memcpy(part, tmp, sizeof(tmp));
+  }
+  return part[0];
+}
+
+/* XNORWeightBinarizer.forward, bnn/ops.py:129-140, and _compute_alpha, bnn/ops.py:116-127.
+ *   center:  mean over input channels per (o, tap)     (ops.py:131  x.mean(1, keepdim=True))
+ *   v     :  w - mean                                  (ops.py:132  x.sub(mean))
+ *   alpha :  sum|v| / n, n = C*KH*KW                   (ops.py:117-123)
+ *   wsign :  sign(v) in {-1,0,+1}                      (ops.py:136/138 SignActivation.apply)
+ *   what  :  sign(v)*alpha                             (ops.py:136 .mul_(alpha))
+ * w is [O][C][taps] (taps = KH*KW, 1 for Linear).  Any of wsign/what/alpha may be NULL.   */
+void orc_xnor_weight(const float* w, int O, int C, int taps, int center, int compute_alpha,
+                     float* wsign, float* what, float* alpha, float* centered) {
+  float* mean = (float*)malloc(sizeof(float) * (size_t)taps);
+  for (int o = 0; o < O; ++o) {
+    const float* wo = w + (size_t)o * C * taps;
+    for (int t = 0; t < taps; ++t) {
+      float m = 0.0f;
+      if (center) {
+        double part[64] = {0};
+        for (int c = 0; c < C; ++c) part[c & 63] += (double)wo[(size_t)c * taps + t];
+        m = (float)(butterfly64(part) / (double)C);
+      }
+      mean[t] = m;
+    }
+    const int K = C * taps;
+    float a = 1.0f;
+    if (compute_alpha) {
+      double part[64] = {0};
+      for (int k = 0; k < K; ++k) {
+        const float v = wo[k] - mean[k % taps];
+        part[k & 63] += (double)fabsf(v);
+      }
+      a = (float)(butterfly64(part) / (double)K);
+    }
+    if (alpha) alpha[o] = a;
+    for (int k = 0; k < K; ++k) {
+      const float v = wo[k] - mean[k % taps];
+      const float s = (float)sgn(v);
+      if (centered) centered[(size_t)o * K + k] = v;
+      if (wsign) wsign[(size_t)o * K + k] = s;
+      if (what) what[(size_t)o * K + k] = s * a;
+    }
+  }
+  free(mean);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Route F: nn.Conv2d._conv_forward as called from bnn/layers/conv.py:92 with            */
+/* padding_mode='zeros', groups=1: zero padding applied AFTER the activation binariser.   */
+/* Accumulates in double (the reference's oneDNN accumulation order is not reproducible;  */
+/* double is the order-free limit both agree with to ~1e-6).                              */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t N, C, H, W, O, KH, KW, sh, sw, ph, pw, dh, dw;
+} orc_geom;
+
+static int odim(int in, int k, int s, int p, int d) { return (in + 2 * p - d * (k - 1) - 1) / s + 1; }
+int orc_out_h(const orc_geom* g) { return odim(g->H, g->KH, g->sh, g->ph, g->dh); }
+int orc_out_w(const orc_geom* g) { return odim(g->W, g->KW, g->sw, g->pw, g->dw); }
+
+void orc_conv2d_f32(const orc_geom* g, const float* xin, const float* wgt, const float* bias,
+                    float* out) {
+  const int Ho = orc_out_h(g), Wo = orc_out_w(g);
+  for (int n = 0; n < g->N; ++n)
+    for (int o = 0; o < g->O; ++o)
+      for (int oy = 0; oy < Ho; ++oy)
+        for (int ox = 0; ox < Wo; ++ox) {
+          double acc = 0.0;
+          for (int c = 0; c < g->C; ++c)
+            for (int ky = 0; ky < g->KH; ++ky) {
+              const int iy = oy * g->sh - g->ph + ky * g->dh;
+              if (iy < 0 || iy >= g->H) continue;
+              for (int kx = 0; kx < g->KW; ++kx) {
+                const int ix = ox * g->sw - g->pw + kx * g->dw;
+                if (ix < 0 || ix >= g->W) continue;
+                acc += (double)xin[(((size_t)n * g->C + c) * g->H + iy) * g->W + ix] *
+                       (double)wgt[(((size_t)o * g->C + c) * g->KH + ky) * g->KW + kx];
+              }
+            }
+          if (bias) acc += (double)bias[o];
+          out[(((size_t)n * g->O + o) * Ho + oy) * Wo + ox] = (float)acc;
+        }
+}
+
+/* Whole reference forward, route F: bnn/layers/conv.py:90-97 with
+ * pre = BasicInputBinarizer (ops.py:151-152), wpre = XNORWeightBinarizer (ops.py:129-140),
+ * post = Identity (bconfig.py:6-8) or BasicScaleBinarizer (ops.py:200-202: out.mul_(alpha)). */
+void orc_binary_conv2d_float(const orc_geom* g, const float* x, const float* w, const float* bias,
+                             const float* post_scale, int center, int compute_alpha, float* out) {
+  const size_t nx = (size_t)g->N * g->C * g->H * g->W;
+  const size_t nw = (size_t)g->O * g->C * g->KH * g->KW;
+  float* xs = (float*)malloc(sizeof(float) * nx);
+  float* wh = (float*)malloc(sizeof(float) * nw);
+  orc_sign_f32(x, xs, (int64_t)nx);
+  orc_xnor_weight(w, g->O, g->C, g->KH * g->KW, center, compute_alpha, NULL, wh, NULL, NULL);
+  orc_conv2d_f32(g, xs, wh, bias, out);
+  if (post_scale) {
+    const int Ho = orc_out_h(g), Wo = orc_out_w(g);
+    for (int n = 0; n < g->N; ++n)
+      for (int o = 0; o < g->O; ++o)
+        for (int i = 0; i < Ho * Wo; ++i) out[((size_t)n * g->O + o) * Ho * Wo + i] *= post_scale[o];
+  }
+  free(xs);
+  free(wh);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Route I, step 1: activation bit planes (format of include/bnn_hip.h).                  */
+/* ------------------------------------------------------------------------------------ */
+void orc_pack_act(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
+                  uint16_t* nzc) {
+  const int cw64 = (C + 63) / 64;
+  const size_t HW = (size_t)H * W;
+  memset(P, 0, sizeof(uint64_t) * (size_t)N * HW * cw64);
+  memset(M, 0, sizeof(uint64_t) * (size_t)N * HW * cw64);
+  for (int n = 0; n < N; ++n)
+    for (size_t r = 0; r < HW; ++r) {
+      const size_t pix = (size_t)n * HW + r;
+      int cnt = 0;
+      for (int c = 0; c < C; ++c) {
+        const int s = sgn(x[((size_t)n * C + c) * HW + r]);
+        if (s > 0) P[pix * cw64 + c / 64] |= (uint64_t)1 << (c % 64);
+        if (s < 0) M[pix * cw64 + c / 64] |= (uint64_t)1 << (c % 64);
+        cnt += (s != 0);
+      }
+      nzc[pix] = (uint16_t)cnt;
+    }
+}
+
+/* Chunk width: must equal bnn::choose_cwc (csrc/bconv.hip). */
+int orc_choose_cwc(int cw32, int KH, int KW) {
+  if (KH == 3 && KW == 3) return (cw32 % 4 == 0) ? 4 : 2;
+  if (KH == 1 && KW == 1) {
+    if (cw32 % 16 == 0) return 16;
+    if (cw32 % 8 == 0) return 8;
+    if (cw32 % 4 == 0) return 4;
+    return 2;
+  }
+  return 2;
+}
+
+int64_t orc_weight_words(int O, int C, int KH, int KW) {
+  const int cw32 = 2 * ((C + 63) / 64);
+  const int opad = (O + OCB - 1) / OCB * OCB;
+  return (int64_t)opad * KH * KW * cw32;
+}
+
+/* Route I, step 2: weight bits in the kernel-facing layout wbits[ob][chunk][j][tap][cwc].
+ * Returns 1 when some in-range sign(w) == 0 (the HIP kernel raises zero_flag).           */
+int orc_pack_weight(const float* w, int O, int C, int KH, int KW, int center, int compute_alpha,
+                    uint32_t* wbits, uint32_t* wnz, float* alpha /* [o_pad] */) {
+  const int taps = KH * KW;
+  const int cw32 = 2 * ((C + 63) / 64);
+  const int cwc = orc_choose_cwc(cw32, KH, KW);
+  const int nchunk = cw32 / cwc;
+  const int opad = (O + OCB - 1) / OCB * OCB;
+  const size_t K = (size_t)C * taps;
+  float* ws = (float*)malloc(sizeof(float) * (size_t)O * K);
+  float* al = (float*)malloc(sizeof(float) * (size_t)O);
+  float* cen = (float*)malloc(sizeof(float) * (size_t)O * K);
+  orc_xnor_weight(w, O, C, taps, center, compute_alpha, ws, NULL, al, cen);
+  memset(wbits, 0, sizeof(uint32_t) * (size_t)opad * taps * cw32);
+  memset(wnz, 0, sizeof(uint32_t) * (size_t)opad * taps * cw32);
+  int any_zero = 0;
+  for (int o = 0; o < opad; ++o) {
+    alpha[o] = o < O ? al[o] : 0.0f;
+    if (o >= O) continue;
+    const int ob = o / OCB, j = o % OCB;
+    for (int c = 0; c < C; ++c)
+      for (int t = 0; t < taps; ++t) {
+        const float s = ws[(size_t)o * K + (size_t)c * taps + t];
+        const int word = c / 32, bit = c % 32;
+        const int ch = word / cwc, cw = word % cwc;
+        const size_t idx = (((size_t)ob * nchunk + ch) * OCB + j) * ((size_t)taps * cwc) +
+                           (size_t)t * cwc + cw;
+        if (s > 0) wbits[idx] |= 1u << bit;
+        if (s != 0) wnz[idx] |= 1u << bit; else any_zero = 1;
+      }
+  }
+  free(ws); free(al); free(cen);
+  return any_zero;
+}
+
+/* Route I, step 3: the popcount dot on packed operands (emulated integer path).
+ *   D   = popcount((W & M) | (~W & P))  [& Z when use_wnz]
+ *   dot = popcount(P|M [& Z]) - 2 D                                                     */
+void orc_bconv_dot(const orc_geom* g, const uint64_t* P, const uint64_t* M, const uint32_t* wbits,
+                   const uint32_t* wnz, int use_wnz, int32_t* dot) {
+  const int Ho = orc_out_h(g), Wo = orc_out_w(g);
+  const int taps = g->KH * g->KW;
+  const int cw32 = 2 * ((g->C + 63) / 64);
+  const int cwc = orc_choose_cwc(cw32, g->KH, g->KW);
+  const int nchunk = cw32 / cwc;
+  const uint32_t* P32 = (const uint32_t*)P;
+  const uint32_t* M32 = (const uint32_t*)M;
+  for (int n = 0; n < g->N; ++n)
+    for (int o = 0; o < g->O; ++o) {
+      const int ob = o / OCB, j = o % OCB;
+      for (int oy = 0; oy < Ho; ++oy)
+        for (int ox = 0; ox < Wo; ++ox) {
+          int nz = 0, D = 0;
+          for (int t = 0; t < taps; ++t) {
+            const int ky = t / g->KW, kx = t % g->KW;
+            const int iy = oy * g->sh - g->ph + ky * g->dh;
+            const int ix = ox * g->sw - g->pw + kx * g->dw;
+            if (iy < 0 || iy >= g->H || ix < 0 || ix >= g->W) continue;
+            const size_t pix = ((size_t)n * g->H + iy) * g->W + ix;
+            for (int word = 0; word < cw32; ++word) {
+              const uint32_t p = P32[pix * cw32 + word], m = M32[pix * cw32 + word];
+              const int ch = word / cwc, cw = word % cwc;
+              const size_t idx = (((size_t)ob * nchunk + ch) * OCB + j) * ((size_t)taps * cwc) +
+                                 (size_t)t * cwc + cw;
+              const uint32_t wv = wbits[idx];
+              uint32_t d = (wv & m) | (~wv & p);
+              uint32_t z = p | m;
+              if (use_wnz) { d &= wnz[idx]; z &= wnz[idx]; }
+              D += __builtin_popcount(d);
+              nz += __builtin_popcount(z);
+            }
+          }
+          dot[(((size_t)n * g->O + o) * Ho + oy) * Wo + ox] = nz - 2 * D;
+        }
+    }
+}
+
+/* Independent integer route (no packing): dot = sum sign(x)*sign(w - mean) directly from
+ * the float tensors — cross-checks orc_pack_* + orc_bconv_dot against each other.        */
+void orc_ternary_dot(const orc_geom* g, const float* x, const float* wsign, int32_t* dot) {
+  const int Ho = orc_out_h(g), Wo = orc_out_w(g);
+  for (int n = 0; n < g->N; ++n)
+    for (int o = 0; o < g->O; ++o)
+      for (int oy = 0; oy < Ho; ++oy)
+        for (int ox = 0; ox < Wo; ++ox) {
+          int acc = 0;
+          for (int c = 0; c < g->C; ++c)
+            for (int ky = 0; ky < g->KH; ++ky) {
+              const int iy = oy * g->sh - g->ph + ky * g->dh;
+              if (iy < 0 || iy >= g->H) continue;
+              for (int kx = 0; kx < g->KW; ++kx) {
+                const int ix = ox * g->sw - g->pw + kx * g->dw;
+                if (ix < 0 || ix >= g->W) continue;
+                acc += sgn(x[(((size_t)n * g->C + c) * g->H + iy) * g->W + ix]) *
+                       (int)wsign[(((size_t)o * g->C + c) * g->KH + ky) * g->KW + kx];
+              }
+            }
+          dot[(((size_t)n * g->O + o) * Ho + oy) * Wo + ox] = acc;
+        }
+}
+
+/* Route I, step 4: float epilogue, identical formula to csrc/bconv.hip store_result():
+ *   out = fmaf(alpha[o], (float)dot, bias[o]) ; optional out *= post_scale[o]            */
+void orc_epilogue(const int32_t* dot, int N, int O, int HoWo, const float* alpha, const float* bias,
+                  const float* post_scale, float* out) {
+  for (int n = 0; n < N; ++n)
+    for (int o = 0; o < O; ++o)
+      for (int i = 0; i < HoWo; ++i) {
+        const size_t idx = ((size_t)n * O + o) * HoWo + i;
+        float v = fmaf(alpha[o], (float)dot[idx], bias ? bias[o] : 0.0f);
+        if (post_scale) v *= post_scale[o];
+        out[idx] = v;
+      }
+}
