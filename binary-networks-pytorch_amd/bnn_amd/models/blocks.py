@@ -1,0 +1,195 @@
+"""Residual blocks that CALL the binary-conv hot path.
+
+These are plain float ``nn.Module`` graphs; their ``nn.Conv2d`` leaves become binary layers only
+after ``prepare_binary_model``.  Attribute names and forward order equal the reference's
+(``bnn/models/layers/res_block.py``, ``hierarchical_block.py``), so ``state_dict`` keys are
+interchangeable and outputs can be pinned against fixtures generated from the reference.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+
+
+def conv3x3(cin: int, cout: int, stride: int = 1, groups: int = 1, dilation: int = 1) -> nn.Conv2d:
+    return nn.Conv2d(cin, cout, 3, stride=stride, padding=dilation, groups=groups, bias=False,
+                     dilation=dilation)
+
+
+def conv1x1(cin: int, cout: int, stride: int = 1) -> nn.Conv2d:
+    return nn.Conv2d(cin, cout, 1, stride=stride, bias=False)
+
+
+def _act(activation, channels: int) -> nn.Module:
+    """``nn.ReLU(inplace=True)`` or a per-channel parametric activation (``nn.PReLU``)."""
+    return activation(inplace=True) if activation == nn.ReLU else activation(num_parameters=channels)
+
+
+class _Residual(nn.Module):
+    expansion = 1
+
+    def _shortcut(self, x: torch.Tensor) -> torch.Tensor:
+        return x if self.downsample is None else self.downsample(x)
+
+
+class BasicBlock(_Residual):
+    """conv-BN-act-conv-BN-(+id)-act   (reference: ``res_block.py:8-56``)."""
+    expansion = 1
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1,
+                 downsample: Optional[nn.Module] = None, groups: int = 1, base_width: int = 64,
+                 dilation: int = 1, norm_layer: Optional[Callable[..., nn.Module]] = None,
+                 activation=nn.ReLU) -> None:
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        if groups != 1 or base_width != 64:
+            raise ValueError("BasicBlock only supports groups=1 and base_width=64")
+        if dilation > 1:
+            raise NotImplementedError("Dilation > 1 not supported in BasicBlock")
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = norm_layer(planes)
+        self.act1 = _act(activation, planes)
+        self.act2 = _act(activation, planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = self.act1(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        y += self._shortcut(x)
+        return self.act2(y)
+
+
+class PreBasicBlock(_Residual):
+    """BN-conv-act-BN-conv-act-(+id)   (reference: ``res_block.py:121-167``)."""
+    expansion = 1
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1,
+                 downsample: Optional[nn.Module] = None, groups: int = 1, base_width: int = 64,
+                 dilation: int = 1, norm_layer: Optional[Callable[..., nn.Module]] = None,
+                 activation=nn.ReLU) -> None:
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        if groups != 1 or base_width != 64:
+            raise ValueError("BasicBlock only supports groups=1 and base_width=64")
+        if dilation > 1:
+            raise NotImplementedError("Dilation > 1 not supported in BasicBlock")
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = norm_layer(inplanes)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = norm_layer(planes)
+        self.act1 = _act(activation, planes)
+        self.act2 = _act(activation, planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = self.act1(self.conv1(self.bn1(x)))
+        y = self.act2(self.conv2(self.bn2(y)))
+        y += self._shortcut(x)
+        return y
+
+
+class Bottleneck(_Residual):
+    """1x1-BN-act-3x3(stride)-BN-act-1x1-BN-(+id)-act   (reference: ``res_block.py:59-118``)."""
+    expansion = 4
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1,
+                 downsample: Optional[nn.Module] = None, groups: int = 1, base_width: int = 64,
+                 dilation: int = 1, norm_layer: Optional[Callable[..., nn.Module]] = None,
+                 activation=nn.ReLU) -> None:
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        width = int(planes * (base_width / 64.0)) * groups
+        self.conv1 = conv1x1(inplanes, width)
+        self.bn1 = norm_layer(width)
+        self.conv2 = conv3x3(width, width, stride, groups, dilation)
+        self.bn2 = norm_layer(width)
+        self.conv3 = conv1x1(width, planes * self.expansion)
+        self.bn3 = norm_layer(planes * self.expansion)
+        self.act1 = _act(activation, width)
+        self.act2 = _act(activation, width)
+        self.act3 = _act(activation, planes * self.expansion)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = self.act1(self.bn1(self.conv1(x)))
+        y = self.act2(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        y += self._shortcut(x)
+        return self.act3(y)
+
+
+class PreBottleneck(_Residual):
+    """BN-1x1-act-BN-3x3-act-BN-1x1-act-(+id)   (reference: ``res_block.py:170-229``)."""
+    expansion = 4
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1,
+                 downsample: Optional[nn.Module] = None, groups: int = 1, base_width: int = 64,
+                 dilation: int = 1, norm_layer: Optional[Callable[..., nn.Module]] = None,
+                 activation=nn.ReLU) -> None:
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        width = int(planes * (base_width / 64.0)) * groups
+        self.conv1 = conv1x1(inplanes, width)
+        self.bn1 = norm_layer(inplanes)
+        self.conv2 = conv3x3(width, width, stride, groups, dilation)
+        self.bn2 = norm_layer(width)
+        self.conv3 = conv1x1(width, planes * self.expansion)
+        self.bn3 = norm_layer(width)
+        self.act1 = _act(activation, width)
+        self.act2 = _act(activation, width)
+        self.act3 = _act(activation, planes * self.expansion)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = self.act1(self.conv1(self.bn1(x)))
+        y = self.act2(self.conv2(self.bn2(y)))
+        y = self.act3(self.conv3(self.bn3(y)))
+        y += self._shortcut(x)
+        return y
+
+
+class HBlock(_Residual):
+    """Hierarchical block: three BN-act-3x3 stages of widths C/2, C/4, C/4, concatenated, + id.
+
+    Reference: ``bnn/models/layers/hierarchical_block.py:8-60`` (stride/dilation > 1 rejected
+    there too).  ``expansion = 1`` is added so the block can be placed in :class:`ResNet`.
+    """
+    expansion = 1
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1,
+                 downsample: Optional[nn.Module] = None, groups: int = 1, base_width: int = 64,
+                 dilation: int = 1, norm_layer: Optional[Callable[..., nn.Module]] = None,
+                 activation=nn.ReLU) -> None:
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        if dilation > 1:
+            raise NotImplementedError("Dilation > 1 not supported in HBlock")
+        if stride > 1:
+            raise NotImplementedError("Stride > 1 not supported in HBlock")
+        half, quarter = int(planes / 2), int(planes / 4)
+        self.bn1 = norm_layer(inplanes)
+        self.conv1 = conv3x3(inplanes, half, groups=groups)
+        self.bn2 = norm_layer(half)
+        self.conv2 = conv3x3(half, quarter, groups=groups)
+        self.bn3 = norm_layer(quarter)
+        self.conv3 = conv3x3(quarter, quarter, groups=groups)
+        self.act1 = _act(activation, half)
+        self.act2 = _act(activation, half)
+        self.act3 = _act(activation, quarter)
+        self.downsample = downsample
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        o1 = self.conv1(self.act1(self.bn1(x)))
+        o2 = self.conv2(self.act2(self.bn2(o1)))
+        o3 = self.conv3(self.act3(self.bn3(o2)))
+        y = torch.cat((o1, o2, o3), 1)
+        y += self._shortcut(x)
+        return y

@@ -1,0 +1,40 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_DIR = os.path.join(ROOT, "binary-networks-pytorch_amd")
+for p in (ROOT, PKG_DIR):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU-marked tests are skipped (not failed) when no HIP device is visible."""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:  # pragma: no cover
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def golden_layers(golden_dir):
+    import numpy as np
+    return np.load(os.path.join(golden_dir, "layers.npz"))

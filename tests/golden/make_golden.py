@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures by running the REFERENCE implementation.
+
+Runs only in the build container (needs /root/reference); the GPU box and the test-suite use the
+committed ``*.npz`` / ``*.json`` outputs.  Nothing of the reference's source is stored — only
+inputs' generator parameters (tests/golden/cases.py, gen.py) and the reference's numeric outputs.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = os.environ.get("BNN_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REFERENCE)
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+import bnn  # the reference package  # noqa: E402
+from bnn.ops import BasicInputBinarizer, BasicScaleBinarizer, XNORWeightBinarizer  # noqa: E402
+from bnn.models.resnet import resnet18 as ref_resnet18  # noqa: E402
+from bnn.models.layers import Bottleneck as RefBottleneck, HBlock as RefHBlock, PreBasicBlock as RefPreBasicBlock  # noqa: E402
+
+from tests.golden import gen  # noqa: E402
+from tests.golden.cases import LAYER_CASES, LINEAR_CASES  # noqa: E402
+
+assert os.path.realpath(bnn.__file__).startswith(os.path.realpath(REFERENCE)), bnn.__file__
+torch.set_num_threads(8)
+
+
+def t(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a))
+
+
+def ref_layer_forward(case):
+    """One reference bnn.layers.Conv2d forward (bnn/layers/conv.py:90-97) for a LayerCase."""
+    x, w, b, sc = case.tensors()
+    conv = nn.Conv2d(case.C, case.O, case.k, stride=case.stride, padding=case.pad,
+                     dilation=case.dilation, bias=case.bias)
+    conv.weight.data.copy_(t(w))
+    if b is not None:
+        conv.bias.data.copy_(t(b))
+    cfg = bnn.BConfig(
+        activation_pre_process=BasicInputBinarizer,
+        activation_post_process=BasicScaleBinarizer if case.post == "scale" else bnn.Identity,
+        weight_pre_process=XNORWeightBinarizer.with_args(compute_alpha=case.compute_alpha,
+                                                         center_weights=case.center))
+    layer = bnn.prepare_binary_model(conv, cfg)
+    assert type(layer) is bnn.layers.Conv2d
+    if sc is not None:
+        layer.activation_post_process.alpha.data.copy_(t(sc).view(1, -1, 1, 1))
+    with torch.no_grad():
+        out = layer(t(x)).numpy().copy()
+        # the integer dot straight from the reference's own ops: conv(sign(x), sign(W - mean))
+        xs = layer.activation_pre_process(t(x))
+        wsgn = XNORWeightBinarizer(compute_alpha=False, center_weights=case.center)(layer.weight)
+        dot = torch.nn.functional.conv2d(xs.double(), wsgn.double(), None, case.stride, case.pad,
+                                         case.dilation).numpy()
+    assert np.array_equal(dot, np.round(dot)) or np.isnan(dot).any()
+    return out, dot.astype(np.int32)
+
+
+def make_layers():
+    blob = {}
+    for case in LAYER_CASES:
+        out, dot = ref_layer_forward(case)
+        blob[case.name + "/out"] = out
+        blob[case.name + "/dot"] = dot.astype(np.int16)
+        print(f"layer {case.name:22s} out{out.shape} |max|={np.nanmax(np.abs(out)):.4f}")
+    for case in LINEAR_CASES:
+        x, w, b, sc = case.tensors()
+        lin = nn.Linear(case.F, case.O, bias=case.bias)
+        lin.weight.data.copy_(t(w))
+        if b is not None:
+            lin.bias.data.copy_(t(b))
+        cfg = bnn.BConfig(
+            activation_pre_process=BasicInputBinarizer,
+            activation_post_process=BasicScaleBinarizer if case.post == "scale" else bnn.Identity,
+            weight_pre_process=XNORWeightBinarizer.with_args(center_weights=case.center))
+        layer = bnn.prepare_binary_model(lin, cfg)
+        if sc is not None:
+            layer.activation_post_process.alpha.data.copy_(t(sc).view(1, -1))
+        with torch.no_grad():
+            blob["linear/" + case.name + "/out"] = layer(t(x)).numpy().copy()
+        print(f"linear {case.name}")
+    np.savez_compressed(os.path.join(HERE, "layers.npz"), **blob)
+
+
+def make_ref_test_layers():
+    """G1: the reference's own known-answer vectors (test/test_layers.py:22-25, :37, :47-49, :59-66),
+    re-evaluated through the reference so that expected == what its CI asserts (atol 1e-4)."""
+    data = np.array([-0.05263, -0.05068, -0.03849, 0.03104, 0.0772, 0.03038, -0.06640, 0.05894,
+                     0.13059, 0.03433, -0.25811, 0.13785], np.float32).reshape(1, 3, 2, 2)
+    weights = np.array([-0.0252, 0.0084, -0.0676, 0.0891, -0.0010, 0.0518, 0.0380, 0.2866, -0.0050],
+                       np.float32)
+    cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer,
+                      activation_post_process=BasicScaleBinarizer,
+                      weight_pre_process=XNORWeightBinarizer)
+    lin = nn.Linear(3, 3, bias=False); lin.weight.data.copy_(t(weights).view(3, 3))
+    c1 = nn.Conv1d(3, 3, 1, bias=False); c1.weight.data.copy_(t(weights).view(3, 3, 1))
+    c2 = nn.Conv2d(3, 3, 1, bias=False); c2.weight.data.copy_(t(weights).view(3, 3, 1, 1))
+    with torch.no_grad():
+        o_lin = bnn.prepare_binary_model(lin, cfg)(t(data)[:, :, 0, 0].reshape(1, 3)).numpy()
+        o_c1 = bnn.prepare_binary_model(c1, cfg)(t(data)[:, :, :, 0].reshape(1, 3, 2)).numpy()
+        o_c2 = bnn.prepare_binary_model(c2, cfg)(t(data)).numpy()
+    # the literals asserted by the reference's test file
+    exp_lin = np.array([[0.0337, -0.0473, -0.1099]], np.float32)
+    exp_c1 = np.array([[[0.0337, 0.0337], [-0.0473, -0.0473], [-0.1099, -0.1099]]], np.float32)
+    exp_c2 = np.array([[[[0.0337, 0.0337], [0.0337, -0.0337]], [[-0.0473, -0.0473], [-0.0473, 0.0473]],
+                        [[-0.1099, -0.1099], [-0.1099, 0.1099]]]], np.float32)
+    assert np.allclose(o_lin, exp_lin, atol=1e-4) and np.allclose(o_c1, exp_c1, atol=1e-4) \
+        and np.allclose(o_c2, exp_c2, atol=1e-4)
+    np.savez_compressed(os.path.join(HERE, "ref_test_layers.npz"), data=data, weights=weights,
+                        linear=o_lin, conv1d=o_c1, conv2d=o_c2, lit_linear=exp_lin, lit_conv1d=exp_c1,
+                        lit_conv2d=exp_c2)
+    print("ref_test_layers ok")
+
+
+def load_state(model, seed):
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    st = gen.model_state(shapes, seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    return model
+
+
+def xnor_cfg():
+    return bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
+                       weight_pre_process=XNORWeightBinarizer)
+
+
+def make_resnet18():
+    """G4: examples/cifar10.py:61-71 model (resnet18 + XNOR BConfig, conv1/fc real-valued)."""
+    net = ref_resnet18()
+    net = bnn.prepare_binary_model(net, xnor_cfg(), custom_config_layers_name={"conv1": bnn.BConfig(),
+                                                                               "fc": bnn.BConfig()})
+    load_state(net, seed=1)
+    net.eval()
+    blob = {}
+    for tag, shape in (("32", (4, 3, 32, 32)), ("64", (2, 3, 64, 64)), ("224", (2, 3, 224, 224))):
+        x = gen.normal(gen.seed_of("r18", tag), shape)
+        with torch.no_grad():
+            y = net(t(x)).numpy()
+        blob["logits_" + tag] = y
+        print("resnet18", tag, y.shape, float(np.abs(y).max()))
+    blob["state_keys"] = np.array(list(net.state_dict().keys()))
+    blob["module_types"] = np.array([f"{n}:{type(m).__name__}" for n, m in net.named_modules()])
+    np.savez_compressed(os.path.join(HERE, "resnet18.npz"), **blob)
+
+
+def make_blocks():
+    """G5: module-level outputs of the blocks that call the hot path (config 5 building blocks)."""
+    blob = {}
+    specs = {
+        "hblock_256": (lambda: RefHBlock(256, 256, norm_layer=nn.BatchNorm2d), (2, 256, 8, 8)),
+        "bottleneck_256_64": (lambda: RefBottleneck(256, 64), (2, 256, 8, 8)),
+        "prebasic_64": (lambda: RefPreBasicBlock(64, 64), (2, 64, 10, 10)),
+        "prebasic_64_prelu": (lambda: RefPreBasicBlock(64, 64, activation=nn.PReLU), (2, 64, 10, 10)),
+    }
+    for name, (ctor, shape) in specs.items():
+        blk = bnn.prepare_binary_model(ctor(), xnor_cfg())
+        load_state(blk, seed=gen.seed_of("block", name))
+        blk.eval()
+        x = gen.normal(gen.seed_of("blockx", name), shape)
+        with torch.no_grad():
+            blob[name] = blk(t(x)).numpy()
+        print("block", name, blob[name].shape)
+    np.savez_compressed(os.path.join(HERE, "blocks.npz"), **blob)
+
+
+def make_convert():
+    """G6: conversion behaviour of prepare_binary_model incl. the crossed _first_/_last_ words."""
+    def small():
+        return nn.Sequential(nn.Conv2d(3, 16, 1, 1), nn.BatchNorm2d(16), nn.ReLU(inplace=True),
+                             nn.Conv2d(16, 16, 1, 1), nn.BatchNorm2d(16), nn.ReLU(inplace=True),
+                             nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten(), nn.Linear(16, 3))
+    cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer,
+                      activation_post_process=BasicScaleBinarizer, weight_pre_process=XNORWeightBinarizer)
+
+    def describe(m):
+        return {n: [type(c).__module__.split(".")[0] == "bnn", type(c).__name__,
+                    type(getattr(c, "activation_pre_process", None)).__name__]
+                for n, c in m.named_modules() if isinstance(c, (nn.Conv2d, nn.Linear))}
+    out = {}
+    out["plain"] = describe(bnn.prepare_binary_model(small(), cfg))
+    out["ignore_first_word"] = describe(bnn.prepare_binary_model(small(), cfg, ignore_layers_name=["_first_"]))
+    out["ignore_last_word"] = describe(bnn.prepare_binary_model(small(), cfg, ignore_layers_name=["_last_"]))
+    out["ignore_regex"] = describe(bnn.prepare_binary_model(small(), cfg, ignore_layers_name=["$^[03]$$"]))
+    out["ignore_literal"] = describe(bnn.prepare_binary_model(small(), cfg, ignore_layers_name=["8"]))
+    fp32 = bnn.BConfig(activation_pre_process=nn.Identity, activation_post_process=nn.Identity,
+                       weight_pre_process=nn.Identity)
+    out["custom_fp32_8"] = describe(bnn.prepare_binary_model(small(), cfg, custom_config_layers_name={"8": fp32}))
+    out["state_keys"] = list(bnn.prepare_binary_model(small(), cfg).state_dict().keys())
+    with open(os.path.join(HERE, "convert.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("convert ok")
+
+
+if __name__ == "__main__":
+    make_ref_test_layers()
+    make_layers()
+    make_resnet18()
+    make_blocks()
+    make_convert()

@@ -1,0 +1,76 @@
+"""The C-ABI library loads on a GPU-less machine and exports every symbol include/bnn_hip.h
+declares.  No kernel is launched here (host-only entry points are exercised)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import oracle
+from bnn_amd import native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "bnn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bnn_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(native.lib_path()), "build with __graft_entry__.build() first"
+    lib = ctypes.CDLL(native.lib_path())
+    syms = header_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/bnn_hip.h but not exported"
+    assert set(native.EXPORTED_SYMBOLS) == set(syms)
+
+
+def test_require_loads_and_reports_abi():
+    lib = native.require()
+    assert lib.bnn_hip_abi_version() == 1
+    assert lib.bnn_hip_status_string(0) == b"ok"
+    assert b"invalid" in lib.bnn_hip_status_string(-1)
+    assert isinstance(native.launch_count(), int)
+
+
+def test_host_only_entry_points():
+    lib = native.require()
+    assert lib.bnn_hip_act_words(1) == 1 and lib.bnn_hip_act_words(64) == 1
+    assert lib.bnn_hip_act_words(65) == 2 and lib.bnn_hip_act_words(0) < 0
+    for (O, C, k) in [(64, 64, 3), (128, 128, 3), (5, 200, 3), (128, 64, 1), (64, 1024, 1),
+                      (8, 32, 5), (1000, 512, 1), (3, 3, 1), (512, 512, 3)]:
+        L = native.weight_layout(O, C, k, k)
+        ref = oracle.weight_layout(O, C, k, k)
+        got = {f: getattr(L, f) for f in ("cw32", "cwc", "nchunk", "taps", "o_pad", "n_words")}
+        assert got == ref
+    bad = native.WLayout()
+    assert lib.bnn_hip_weight_layout(0, 3, 1, 1, ctypes.byref(bad)) == -1
+    assert lib.bnn_hip_weight_layout(3, 3, 1, 1, None) == -1
+
+
+def test_argument_validation_without_touching_the_gpu():
+    lib = native.require()
+    d = native.ConvDesc(1, 64, 8, 8, 32, 3, 3, 1, 1, 1, 1, 1, 1, 0)
+    # null pointers are rejected before any launch
+    assert lib.bnn_hip_bconv2d(ctypes.byref(d), None, None, None, None, None, None, None, None, None, None) == -1
+    assert lib.bnn_hip_pack_act_f32(None, 1, 1, 1, 1, None, None, None, None) == -1
+    assert lib.bnn_hip_pack_weight_f32(None, 1, 1, 1, 1, 0, 1, None, None, None, None, None) == -1
+    assert lib.bnn_hip_conv_workspace_bytes(ctypes.byref(d)) >= 2 * 64 * 8 + 128
+    d.N = 0
+    assert lib.bnn_hip_bconv2d(ctypes.byref(d), 16, 16, 16, 16, 16, 16, None, None, 16, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import importlib
+    monkeypatch.setenv("BNN_AMD_LIB", str(tmp_path / "nope.so"))
+    fresh = importlib.reload(native)
+    try:
+        assert not fresh.available()
+        with pytest.raises(fresh.NativeError, match="does not fall back"):
+            fresh.require()
+    finally:
+        monkeypatch.delenv("BNN_AMD_LIB")
+        importlib.reload(native)

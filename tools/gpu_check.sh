@@ -1,0 +1,23 @@
+#!/bin/bash
+# One GPU-box visit: smoke -> parity tests -> bench -> rocprofv3 kernel stats.
+# Usage (from the build container):  gpurun --timeout 1500 -- 'bash tools/gpu_check.sh'
+set -u
+R="${GRAFT_REPO_ROOT:-$(pwd)}"
+OUT="$R/gpurun_out"
+mkdir -p "$OUT"
+cd "$R"
+export TMPDIR=/tmp
+{
+  echo "== rocminfo (clocks/CUs)"; rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock|Wavefront Size|gfx" | head -12
+  echo "== host"; nproc; lscpu | grep -E "Model name|Socket|Core|Thread" | head -6
+} > "$OUT/box.txt" 2>&1
+
+echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5
+echo "== pytest -m gpu"; timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 | tee "$OUT/pytest_gpu.txt"
+echo "== bench"; timeout 600 python bench.py --steps 10 --warmup 3 2>&1 | tail -3 | tee "$OUT/bench.json"
+echo "== rocprof"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o r01 -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/prof_run.log" 2>&1
+ls -R "$OUT/prof" | head -20
+f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && head -25 "$f"
