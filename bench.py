@@ -108,7 +108,7 @@ def conv_c2_roofline(device, info, batch=256, iters=20, act_kind="relu"):
     }
 
 
-def cpu_baseline(sample_batch=32, iters=2):
+def cpu_baseline(sample_batch=64, iters=6):
     """Reference op sequence (torch CPU: sign -> sign(W)*alpha -> conv2d) on the host cores."""
     from oracle import torch_ref  # checker / baseline only
     shapes = torch_ref.resnet18_state_shapes()
@@ -199,9 +199,9 @@ def main():
             rec["roofline"] = conv_c2_roofline(device, info, act_kind="relu")
             rec["roofline_normal_input"] = {k: v for k, v in conv_c2_roofline(device, info, act_kind="normal").items()
                                             if k in ("achieved", "frac", "avg_kernel_us")}
-            probe = hipops.probe_int_alu(4096, device)
-            rec["int_alu_probe"] = {"measured_Tlane_ops": probe["lane_ops_per_s"] / 1e12,
-                                    "frac_of_peak": probe["lane_ops_per_s"] / int_alu_peak(info)}
+            rec["int_alu_probe_Tlane_ops"] = {
+                name: round(hipops.probe_int_alu(4096, device, mode)["lane_ops_per_s"] / 1e12, 2)
+                for mode, name in hipops.PROBE_MODES.items()}
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec), flush=True)

@@ -40,13 +40,24 @@ def _require_cuda_f32(t: torch.Tensor, what: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def _per_channel(t: Optional[torch.Tensor], n: int, what: str) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    t = _require_cuda_f32(t.detach(), what).reshape(-1)
+    if t.numel() != n:
+        raise native.NativeError(f"bnn_amd: {what} must have one entry per output channel ({n})")
+    return t
+
+
 @dataclass
 class PackedAct:
-    """sign(x) as bit planes: ``P``/``M`` int64 ``[N,H,W,cw64]``, ``nzc`` int16 ``[N,H,W]``."""
+    """sign(x) as bit planes: ``P``/``M`` int64 ``[N,cw64,H,W]`` (format: include/bnn_hip.h)."""
     P: torch.Tensor
     M: torch.Tensor
-    nzc: torch.Tensor
     shape: Tuple[int, int, int, int]  # logical (N, C, H, W)
+
+    def batch_slice(self, n0: int, n1: int) -> "PackedAct":
+        return PackedAct(self.P[n0:n1], self.M[n0:n1], (n1 - n0,) + tuple(self.shape[1:]))
 
 
 @dataclass
@@ -59,6 +70,12 @@ class PackedWeight:
     shape: Tuple[int, int, int, int]  # logical (O, C, KH, KW)
 
 
+def empty_packed(N: int, C: int, H: int, W: int, device) -> PackedAct:
+    cw64 = (C + 63) // 64
+    return PackedAct(torch.empty((N, cw64, H, W), dtype=torch.int64, device=device),
+                     torch.empty((N, cw64, H, W), dtype=torch.int64, device=device), (N, C, H, W))
+
+
 def pack_act(x: torch.Tensor) -> PackedAct:
     """``BasicInputBinarizer`` on device: fp32 NCHW -> bit planes (bnn/ops.py:151-152)."""
     x = _require_cuda_f32(x, "activation")
@@ -66,15 +83,27 @@ def pack_act(x: torch.Tensor) -> PackedAct:
         raise native.NativeError(f"bnn_amd: pack_act expects NCHW, got shape {tuple(x.shape)}")
     lib = native.require()
     N, C, H, W = x.shape
-    cw64 = (C + 63) // 64
     with torch.cuda.device(x.device):
-        P = torch.empty((N, H, W, cw64), dtype=torch.int64, device=x.device)
-        M = torch.empty((N, H, W, cw64), dtype=torch.int64, device=x.device)
-        nzc = torch.empty((N, H, W), dtype=torch.int16, device=x.device)
-        native.check(lib.bnn_hip_pack_act_f32(x.data_ptr(), N, C, H, W, P.data_ptr(), M.data_ptr(),
-                                              nzc.data_ptr(), _stream(x.device)),
+        a = empty_packed(N, C, H, W, x.device)
+        native.check(lib.bnn_hip_pack_act_f32(x.data_ptr(), N, C, H, W, a.P.data_ptr(),
+                                              a.M.data_ptr(), _stream(x.device)),
                      "bnn_hip_pack_act_f32")
-    return PackedAct(P, M, nzc, (N, C, H, W))
+    return a
+
+
+def avgpool_pack(x: torch.Tensor, k: int) -> PackedAct:
+    """``AvgPool2d(k, k, ceil_mode=True, count_include_pad=False)`` + sign, fused
+    (shortcut branch of bnn/models/resnet.py:128-133)."""
+    x = _require_cuda_f32(x, "activation")
+    lib = native.require()
+    N, C, H, W = x.shape
+    ho, wo = (H + k - 1) // k, (W + k - 1) // k
+    with torch.cuda.device(x.device):
+        a = empty_packed(N, C, ho, wo, x.device)
+        native.check(lib.bnn_hip_avgpool_pack_f32(x.data_ptr(), N, C, H, W, k, a.P.data_ptr(),
+                                                  a.M.data_ptr(), _stream(x.device)),
+                     "bnn_hip_avgpool_pack_f32")
+    return a
 
 
 def pack_weight(w: torch.Tensor, center: bool = False, compute_alpha: bool = True) -> PackedWeight:
@@ -123,22 +152,29 @@ def _desc(act_shape, w_shape, stride, padding, dilation, flags) -> native.ConvDe
     return native.ConvDesc(N, C, H, W, O, KH, KW, sh, sw, ph, pw, dh, dw, flags)
 
 
+def _flags(w: PackedWeight, force_generic: bool, weights: Optional[str]) -> int:
+    f = (native.FLAG_FORCE_GENERIC if force_generic else 0) | \
+        (native.FLAG_WEIGHT_ZEROS if w.has_zero else 0)
+    if weights == "sgpr":
+        f |= native.FLAG_WEIGHTS_SGPR
+    elif weights == "lds":
+        f |= native.FLAG_WEIGHTS_LDS
+    elif weights is not None:
+        raise ValueError("weights must be None, 'sgpr' or 'lds'")
+    return f
+
+
 def bconv2d(a: PackedAct, w: PackedWeight, bias: Optional[torch.Tensor] = None,
             post_scale: Optional[torch.Tensor] = None, stride=1, padding=0, dilation=1,
-            force_generic: bool = False, raw_dot: bool = False) -> torch.Tensor:
+            force_generic: bool = False, raw_dot: bool = False,
+            weights: Optional[str] = None) -> torch.Tensor:
     """Binary convolution on packed operands -> fp32 NCHW (or int32 dot when ``raw_dot``)."""
     lib = native.require()
-    flags = (native.FLAG_FORCE_GENERIC if force_generic else 0) | \
-            (native.FLAG_WEIGHT_ZEROS if w.has_zero else 0)
-    d = _desc(a.shape, w.shape, stride, padding, dilation, flags)
+    d = _desc(a.shape, w.shape, stride, padding, dilation, _flags(w, force_generic, weights))
     ho, wo = conv_out_hw(d.H, d.W, d.KH, d.KW, stride, padding, dilation)
     dev = a.P.device
-    if bias is not None:
-        bias = _require_cuda_f32(bias.detach(), "bias")
-    if post_scale is not None:
-        post_scale = _require_cuda_f32(post_scale.detach(), "post_scale").reshape(-1)
-        if post_scale.numel() != d.O:
-            raise native.NativeError("bnn_amd: post_scale must have one entry per output channel")
+    bias = _per_channel(bias, d.O, "bias")
+    post_scale = _per_channel(post_scale, d.O, "post_scale")
     with torch.cuda.device(dev):
         out = torch.empty((d.N, d.O, ho, wo), dtype=torch.int32 if raw_dot else torch.float32,
                           device=dev)
@@ -150,7 +186,7 @@ def bconv2d(a: PackedAct, w: PackedWeight, bias: Optional[torch.Tensor] = None,
             dd = native.ConvDesc.from_buffer_copy(d)
             dd.N = n1 - n0
             args = (ctypes.byref(dd), a.P[n0:n1].data_ptr(), a.M[n0:n1].data_ptr(),
-                    a.nzc[n0:n1].data_ptr(), w.wbits.data_ptr(), w.wnz.data_ptr())
+                    w.wbits.data_ptr(), w.wnz.data_ptr())
             if raw_dot:
                 st = lib.bnn_hip_bconv2d_dot(*args, out[n0:n1].data_ptr(), _stream(dev))
             else:
@@ -160,13 +196,52 @@ def bconv2d(a: PackedAct, w: PackedWeight, bias: Optional[torch.Tensor] = None,
     return out
 
 
-def probe_int_alu(iters: int = 4096, device: Optional[torch.device] = None) -> dict:
-    """Sustained v_bitop3+v_bcnt lane-ops/s of the current device (roofline calibration)."""
+def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, bn_scale=None,
+                  bn_shift=None, residual=None, prelu=None, relu=False, out_f32=True,
+                  out_packed=False, stride=1, padding=0, dilation=1, force_generic=False,
+                  weights: Optional[str] = None):
+    """Binary convolution + fused epilogue (see ``bnn_hip_epilogue``): returns
+    ``(y_fp32 | None, PackedAct(sign(y)) | None)``."""
+    lib = native.require()
+    d = _desc(a.shape, w.shape, stride, padding, dilation, _flags(w, force_generic, weights))
+    ho, wo = conv_out_hw(d.H, d.W, d.KH, d.KW, stride, padding, dilation)
+    if d.N * max(d.O * ho * wo, d.H * d.W) > _MAX_ELEMS:
+        raise native.NativeError("bnn_amd: bconv2d_fused: split the batch (tensor > 2^31-1 elements)")
+    dev = a.P.device
+    bias = _per_channel(bias, d.O, "bias")
+    post_scale = _per_channel(post_scale, d.O, "post_scale")
+    bn_scale = _per_channel(bn_scale, d.O, "bn_scale")
+    bn_shift = _per_channel(bn_shift, d.O, "bn_shift")
+    prelu = _per_channel(prelu, d.O, "prelu")
+    if residual is not None:
+        residual = _require_cuda_f32(residual, "residual")
+        if tuple(residual.shape) != (d.N, d.O, ho, wo):
+            raise native.NativeError(f"bnn_amd: residual shape {tuple(residual.shape)} != output")
+    with torch.cuda.device(dev):
+        y = torch.empty((d.N, d.O, ho, wo), dtype=torch.float32, device=dev) if out_f32 else None
+        pk = empty_packed(d.N, d.O, ho, wo, dev) if out_packed else None
+        e = native.Epilogue(w.alpha.data_ptr(), _ptr(bias), _ptr(post_scale), _ptr(bn_scale),
+                            _ptr(bn_shift), _ptr(residual), _ptr(prelu), int(bool(relu)), 0,
+                            _ptr(y), None if pk is None else pk.P.data_ptr(),
+                            None if pk is None else pk.M.data_ptr())
+        native.check(lib.bnn_hip_bconv2d_fused(ctypes.byref(d), a.P.data_ptr(), a.M.data_ptr(),
+                                               w.wbits.data_ptr(), w.wnz.data_ptr(),
+                                               ctypes.byref(e), _stream(dev)),
+                     "bnn_hip_bconv2d_fused")
+    return y, pk
+
+
+PROBE_MODES = {0: "bitop3+bcnt", 1: "xor+bcnt", 2: "bcnt", 3: "bitop3", 4: "xor", 5: "fma_f32",
+               6: "add_u32"}
+
+
+def probe_int_alu(iters: int = 4096, device: Optional[torch.device] = None, mode: int = 0) -> dict:
+    """Sustained lane-ops/s of a register-only instruction stream (roofline calibration)."""
     lib = native.require()
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     rate = ctypes.c_double()
     ms = ctypes.c_double()
     with torch.cuda.device(dev):
-        native.check(lib.bnn_hip_probe_int_alu(iters, ctypes.byref(rate), ctypes.byref(ms),
+        native.check(lib.bnn_hip_probe_int_alu(mode, iters, ctypes.byref(rate), ctypes.byref(ms),
                                                _stream(dev)), "bnn_hip_probe_int_alu")
     return {"lane_ops_per_s": rate.value, "elapsed_ms": ms.value}

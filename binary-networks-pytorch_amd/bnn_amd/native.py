@@ -18,12 +18,16 @@ DEFAULT_LIB_PATH = os.path.join(_HERE, "_lib", LIB_BASENAME)
 OCB = 32
 FLAG_FORCE_GENERIC = 1
 FLAG_WEIGHT_ZEROS = 2
+FLAG_WEIGHTS_SGPR = 4
+FLAG_WEIGHTS_LDS = 8
+ABI_VERSION = 2
 
 # every symbol include/bnn_hip.h declares (tests assert the .so exports all of them)
 EXPORTED_SYMBOLS = (
     "bnn_hip_abi_version", "bnn_hip_status_string", "bnn_hip_launch_count", "bnn_hip_device_info",
     "bnn_hip_act_words", "bnn_hip_weight_layout", "bnn_hip_pack_act_f32",
-    "bnn_hip_pack_weight_f32", "bnn_hip_bconv2d", "bnn_hip_bconv2d_dot", "bnn_hip_blinear",
+    "bnn_hip_avgpool_pack_f32", "bnn_hip_pack_weight_f32", "bnn_hip_bconv2d",
+    "bnn_hip_bconv2d_fused", "bnn_hip_bconv2d_dot", "bnn_hip_blinear",
     "bnn_hip_conv_workspace_bytes", "bnn_hip_bconv2d_f32", "bnn_hip_probe_int_alu",
 )
 
@@ -52,6 +56,15 @@ class DevInfo(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
+class Epilogue(ctypes.Structure):
+    """``bnn_hip_epilogue``"""
+    _fields_ = [("alpha", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("post_scale", ctypes.c_void_p),
+                ("bn_scale", ctypes.c_void_p), ("bn_shift", ctypes.c_void_p),
+                ("residual", ctypes.c_void_p), ("prelu", ctypes.c_void_p),
+                ("relu", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("out_f32", ctypes.c_void_p), ("out_P", ctypes.c_void_p), ("out_M", ctypes.c_void_p)]
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -76,15 +89,18 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_device_info.argtypes = [_i, ctypes.POINTER(DevInfo)]
     lib.bnn_hip_act_words.argtypes = [_i]
     lib.bnn_hip_weight_layout.argtypes = [_i, _i, _i, _i, ctypes.POINTER(WLayout)]
-    lib.bnn_hip_pack_act_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]
+    lib.bnn_hip_pack_act_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _vp]
+    lib.bnn_hip_avgpool_pack_f32.argtypes = [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]
     lib.bnn_hip_pack_weight_f32.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
-    lib.bnn_hip_bconv2d.argtypes = [ctypes.POINTER(ConvDesc)] + [_vp] * 10
-    lib.bnn_hip_bconv2d_dot.argtypes = [ctypes.POINTER(ConvDesc)] + [_vp] * 7
-    lib.bnn_hip_blinear.argtypes = [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]
+    lib.bnn_hip_bconv2d.argtypes = [ctypes.POINTER(ConvDesc)] + [_vp] * 9
+    lib.bnn_hip_bconv2d_fused.argtypes = [ctypes.POINTER(ConvDesc)] + [_vp] * 4 + \
+        [ctypes.POINTER(Epilogue), _vp]
+    lib.bnn_hip_bconv2d_dot.argtypes = [ctypes.POINTER(ConvDesc)] + [_vp] * 6
+    lib.bnn_hip_blinear.argtypes = [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]
     lib.bnn_hip_conv_workspace_bytes.restype = ctypes.c_size_t
     lib.bnn_hip_conv_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.bnn_hip_bconv2d_f32.argtypes = [ctypes.POINTER(ConvDesc)] + [_vp] * 9
-    lib.bnn_hip_probe_int_alu.argtypes = [_i, ctypes.POINTER(ctypes.c_double),
+    lib.bnn_hip_probe_int_alu.argtypes = [_i, _i, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), _vp]
 
 
@@ -100,8 +116,8 @@ def load() -> Optional[ctypes.CDLL]:
             for name in EXPORTED_SYMBOLS:
                 getattr(lib, name)
             _declare(lib)
-            if lib.bnn_hip_abi_version() != 1:
-                raise OSError(f"ABI version mismatch: {lib.bnn_hip_abi_version()} != 1")
+            if lib.bnn_hip_abi_version() != ABI_VERSION:
+                raise OSError(f"ABI version mismatch: {lib.bnn_hip_abi_version()} != {ABI_VERSION}")
             _lib = lib
         except (OSError, AttributeError) as exc:  # missing file, missing libamdhip64, missing symbol
             _load_error = f"{path}: {exc}"

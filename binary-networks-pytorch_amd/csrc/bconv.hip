@@ -17,32 +17,83 @@
 //     (s_load_dwordx16) and feed v_bitop3_b32 directly as its scalar operand, so
 //     the vector ALU executes nothing but bitop3 + bcnt in the main loop
 //   * zero padding / ragged edges: out-of-image taps load P = M = 0, which contribute
-//     nothing to D nor to nzc — no per-tap masks in the inner loop.
+//     nothing to D nor to the non-zero count — no per-tap masks in the inner loop.
+#include <type_traits>
+#include <utility>
+
 #include "bnn_dev.h"
 
 namespace bnn {
 
-// Geometry only (pointers travel as separate __restrict__ kernel arguments so that the
-// compiler may keep wave-uniform reads on the scalar path).
+// Geometry + epilogue switches.  Pointers travel as separate __restrict__ kernel arguments so
+// that the compiler keeps wave-uniform reads (weights, per-channel constants) on the scalar path.
 struct Geo {
   int N, H, Wd, Ho, Wo, O;
   int KH, KW, sh, sw, ph, pw, dh, dw;
   int cw32, cwc, nchunk;
-  int npix;
-  int has_bias, has_scale;
+  int npix;      // N*Ho*Wo
+  int flags;     // EF_*
+  int cw32_out;  // words per pixel per plane of the packed OUTPUT (EF_PACK)
 };
 
-template <bool RAW>
-__device__ __forceinline__ void store_result(void* __restrict__ out, size_t idx, int dot, float a,
-                                             float b, float sc, bool has_scale) {
-  if (RAW) {
-    static_cast<int32_t*>(out)[idx] = dot;
-  } else {
-    float v = fmaf(a, (float)dot, b);
-    if (has_scale) v *= sc;
-    static_cast<float*>(out)[idx] = v;
-  }
+enum : int {
+  EF_RAW = 1,      // store the int32 dot, nothing else
+  EF_BIAS = 2,
+  EF_SCALE = 4,    // BasicScaleBinarizer (ops.py:200-202)
+  EF_BN = 8,       // folded eval-mode BatchNorm: y = fmaf(y, bn_a, bn_b)
+  EF_RES = 16,     // y += residual (fp32 NCHW)
+  EF_RELU = 32,
+  EF_PRELU = 64,
+  EF_OUTF = 128,   // write y as fp32 NCHW
+  EF_PACK = 256,   // write sign(y) as bit planes for the next binary layer
+};
+
+struct EpiArgs {
+  const float* alpha;
+  const float* bias;
+  const float* scale;
+  const float* bn_a;
+  const float* bn_b;
+  const float* prelu;
+  const float* res;
+  void* out;
+  uint32_t* outP;
+  uint32_t* outM;
+};
+
+#ifndef BNN_TILED_MIN_WAVES  // waves per SIMD the tiled kernels are register-allocated for
+#define BNN_TILED_MIN_WAVES 1
+#endif
+
+// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).
+// Used where every index must be a constant (register arrays, SGPR blocks) — `#pragma unroll`
+// is only a hint and hipcc falls back to runtime-indexed code when it declines.
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
 }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+// popcount(x) + acc in ONE instruction.  Written as asm because hipcc's reassociation otherwise
+// splits long accumulation chains into v_bcnt(x, 0) + v_add3 trees (+25 % VALU in the hot loop).
+__device__ __forceinline__ int popc_acc(uint32_t x, int acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+#else
+  return acc + __builtin_popcount(x);
+#endif
+}
+
+// WB consecutive weight words, loaded with one s_load_dwordx16.
+template <int WB>
+struct alignas(64) WBlock {
+  uint32_t v[WB];
+};
 
 template <int LV>
 __device__ __forceinline__ void load_words(const uint32_t* __restrict__ src, size_t word_off,
@@ -55,176 +106,351 @@ __device__ __forceinline__ void load_words(const uint32_t* __restrict__ src, siz
   for (int i = 0; i < LV; ++i) dst[i] = e[i];
 }
 
-// ---------------------------------------------------------------------------------
-// Tiled kernel: KH x KW taps, CWC words per chunk, dilation 1, no zero weights.
-// ---------------------------------------------------------------------------------
-template <int KH, int KW, int CWC, bool RAW>
-__global__ __launch_bounds__(64) void bconv_tiled_kernel(
-    const uint32_t* __restrict__ P, const uint32_t* __restrict__ M,
-    const uint16_t* __restrict__ nzc, const uint32_t* __restrict__ W,
-    const float* __restrict__ alpha, const float* __restrict__ bias,
-    const float* __restrict__ scale, void* __restrict__ out, const Geo g) {
-  constexpr int T = KH * KW;
-  constexpr int NW = T * CWC;             // words per (o, chunk)
-  constexpr int LV = CWC >= 4 ? 4 : CWC;  // words per vector load
+// Output pixel of this lane.
+struct Pix {
+  int q, n, r, oy, ox;
+  bool live;
+};
 
-  int q = blockIdx.x * kWave + threadIdx.x;
-  const bool live = q < g.npix;
-  if (!live) q = g.npix - 1;
+__device__ __forceinline__ Pix decode_pixel(const Geo& g, int q) {
+  Pix p;
+  p.live = q < g.npix;
+  p.q = p.live ? q : g.npix - 1;
   const int hw = g.Ho * g.Wo;
-  const int n = q / hw;
-  const int r = q - n * hw;
-  const int oy = r / g.Wo;
-  const int ox = r - oy * g.Wo;
-  const int ob = blockIdx.y;
+  p.n = p.q / hw;
+  p.r = p.q - p.n * hw;
+  p.oy = p.r / g.Wo;
+  p.ox = p.r - p.oy * g.Wo;
+  return p;
+}
 
-  // receptive field: pixel index per tap (or -1 when the tap falls into the zero padding)
-  int off[T];
-  int nz = 0;
+// Receptive field of one chunk: T taps x CWC words x 2 planes into registers.  Taps that fall
+// into the zero padding yield P = M = 0 (padding is applied after sign(): conv.py:91-92).
+template <int KH, int KW, int CWC>
+__device__ __forceinline__ void load_field(const Geo& g, const Pix& px, int ch,
+                                           const uint32_t* __restrict__ P,
+                                           const uint32_t* __restrict__ M,
+                                           uint32_t (&pr)[KH * KW * CWC],
+                                           uint32_t (&mr)[KH * KW * CWC]) {
+  // Planes are stored channel-group planar, [n][group of 64 channels][y][x] uint64: the 64
+  // lanes of a wave (consecutive pixels) read 512 contiguous bytes per load whatever C is.
+  constexpr int GC = CWC / 2;  // 64-channel groups per chunk
+  const int cw64 = g.cw32 >> 1;
+  const int plane = g.H * g.Wd;
+  const size_t img = ((size_t)px.n * cw64 + (size_t)ch * GC) * plane;
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const int iy = oy * g.sh - g.ph + t / KW;
-    const int ix = ox * g.sw - g.pw + t % KW;
+  for (int t = 0; t < KH * KW; ++t) {
+    const int iy = px.oy * g.sh - g.ph + t / KW;
+    const int ix = px.ox * g.sw - g.pw + t % KW;
     const bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.Wd;
-    const int pix = (n * g.H + iy) * g.Wd + ix;
-    off[t] = ok ? pix : -1;
-    nz += ok ? (int)nzc[ok ? pix : 0] : 0;
-  }
-
-  int acc[kOCB];
+    const int pix = ok ? iy * g.Wd + ix : 0;
 #pragma unroll
-  for (int j = 0; j < kOCB; ++j) acc[j] = 0;
-
-  const uint32_t* wblk = W + (size_t)ob * g.nchunk * (kOCB * NW);
-
-  for (int ch = 0; ch < g.nchunk; ++ch) {
-    uint32_t pr[NW], mr[NW];
+    for (int gi = 0; gi < GC; ++gi) {
+      uint32_t pv[2], mv[2];
+      const size_t w = (img + (size_t)gi * plane + pix) * 2;
+      load_words<2>(P, w, pv);
+      load_words<2>(M, w, mv);
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const bool ok = off[t] >= 0;
-      const size_t base = (size_t)(ok ? off[t] : 0) * g.cw32 + (size_t)ch * CWC;
-#pragma unroll
-      for (int c = 0; c < CWC; c += LV) {
-        uint32_t pv[LV], mv[LV];
-        load_words<LV>(P, base + c, pv);
-        load_words<LV>(M, base + c, mv);
-#pragma unroll
-        for (int e = 0; e < LV; ++e) {
-          pr[t * CWC + c + e] = ok ? pv[e] : 0u;
-          mr[t * CWC + c + e] = ok ? mv[e] : 0u;
-        }
-      }
-    }
-    const uint32_t* wch = wblk + (size_t)ch * (kOCB * NW);
-#pragma unroll
-    for (int j = 0; j < kOCB; ++j) {
-      const uint32_t* w = wch + j * NW;  // wave-uniform -> scalar loads
-      int a0 = 0, a1 = 0;
-#pragma unroll
-      for (int i = 0; i + 1 < NW; i += 2) {
-        a0 += __builtin_popcount(disagree(w[i], mr[i], pr[i]));
-        a1 += __builtin_popcount(disagree(w[i + 1], mr[i + 1], pr[i + 1]));
-      }
-      if (NW & 1) a0 += __builtin_popcount(disagree(w[NW - 1], mr[NW - 1], pr[NW - 1]));
-      acc[j] += a0 + a1;
-    }
-  }
-
-  if (!live) return;
-  const size_t obase = ((size_t)n * g.O) * hw + r;
-  const int o0 = ob * kOCB;
-  if (o0 + kOCB <= g.O) {  // full block: no per-channel bounds checks
-#pragma unroll
-    for (int j = 0; j < kOCB; ++j) {
-      const int o = o0 + j;
-      const float a = RAW ? 0.f : alpha[o];
-      const float b = (!RAW && g.has_bias) ? bias[o] : 0.f;
-      const float sc = (!RAW && g.has_scale) ? scale[o] : 1.f;
-      store_result<RAW>(out, obase + (size_t)o * hw, nz - 2 * acc[j], a, b, sc, g.has_scale);
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < kOCB; ++j) {
-      const int o = o0 + j;
-      if (o < g.O) {
-        const float a = RAW ? 0.f : alpha[o];
-        const float b = (!RAW && g.has_bias) ? bias[o] : 0.f;
-        const float sc = (!RAW && g.has_scale) ? scale[o] : 1.f;
-        store_result<RAW>(out, obase + (size_t)o * hw, nz - 2 * acc[j], a, b, sc, g.has_scale);
+      for (int e = 0; e < 2; ++e) {
+        pr[t * CWC + gi * 2 + e] = ok ? pv[e] : 0u;
+        mr[t * CWC + gi * 2 + e] = ok ? mv[e] : 0u;
       }
     }
   }
 }
 
-// ---------------------------------------------------------------------------------
-// Generic kernel: any KH/KW/stride/pad/dilation/cwc, optional zero-weight mask.
-// One lane = one output pixel, one wave = 64 pixels x OG output channels.
-// ---------------------------------------------------------------------------------
-constexpr int kOG = 8;
+template <int NW>
+__device__ __forceinline__ int count_nonzero(const uint32_t (&pr)[NW], const uint32_t (&mr)[NW],
+                                             int nz) {
+  int a = nz, b = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    if (i & 1) b = popc_acc(pr[i] | mr[i], b);
+    else a = popc_acc(pr[i] | mr[i], a);
+  }
+  return a + b;
+}
 
-template <bool WZ, bool RAW>
-__global__ __launch_bounds__(64) void bconv_generic_kernel(
-    const uint32_t* __restrict__ P, const uint32_t* __restrict__ M,
-    const uint16_t* __restrict__ nzc, const uint32_t* __restrict__ W,
-    const uint32_t* __restrict__ Z, const float* __restrict__ alpha,
-    const float* __restrict__ bias, const float* __restrict__ scale, void* __restrict__ out,
-    const Geo g) {
-  int q = blockIdx.x * kWave + threadIdx.x;
-  const bool live = q < g.npix;
-  if (!live) q = g.npix - 1;
+// Epilogue of one wave: 64 pixels x up to 32 output channels of block `ob`.
+//   y = fmaf(alpha, dot, bias) [* scale] ; [y = fmaf(y, bn_a, bn_b)] ; [y += res] ; [relu|prelu]
+// then fp32 NCHW store and/or sign(y) re-packed for the next binary layer.
+//
+// Addressing: the per-lane part of every NCHW address (n*O*hw + r) is ONE 32-bit offset computed
+// once; the per-channel part (o*hw) is wave-uniform and stays in SGPRs, so each store/load is a
+// `global_* v_off, v_data, s[base]` with no per-channel vector address arithmetic.
+template <int NACC, bool FUSED>
+__device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
+                                         const int (&dot)[NACC], const EpiArgs& e) {
   const int hw = g.Ho * g.Wo;
-  const int n = q / hw;
-  const int r = q - n * hw;
-  const int oy = r / g.Wo;
-  const int ox = r - oy * g.Wo;
-  const int o0 = blockIdx.y * kOG;
-  const int ob = o0 / kOCB, j0 = o0 % kOCB;
-  const int taps = g.KH * g.KW;
-  const int per_o = taps * g.cwc;
-
-  int acc[kOG], nzw[kOG];
+  const unsigned lane_off = (unsigned)(px.n * g.O * hw + px.r);  // host keeps N*O*hw < 2^30
+  const int f = g.flags;
+  const bool full = o0 + NACC <= g.O;
+  if (f & EF_RAW) {
+    if (px.live) {
+      int32_t* o32 = static_cast<int32_t*>(e.out);
 #pragma unroll
-  for (int k = 0; k < kOG; ++k) { acc[k] = 0; nzw[k] = 0; }
-  int nz = 0;
-
-  for (int t = 0; t < taps; ++t) {
-    const int ky = t / g.KW, kx = t - ky * g.KW;
-    const int iy = oy * g.sh - g.ph + ky * g.dh;
-    const int ix = ox * g.sw - g.pw + kx * g.dw;
-    const bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.Wd;
-    const int pix = ok ? (n * g.H + iy) * g.Wd + ix : 0;
-    if (!WZ) nz += ok ? (int)nzc[pix] : 0;
-    for (int cw = 0; cw < g.cw32; ++cw) {
-      const uint32_t pw = ok ? P[(size_t)pix * g.cw32 + cw] : 0u;
-      const uint32_t mw = ok ? M[(size_t)pix * g.cw32 + cw] : 0u;
-      const int ch = cw / g.cwc, c = cw - ch * g.cwc;
-      const size_t wbase = ((size_t)(ob * g.nchunk + ch) * kOCB + j0) * per_o + t * g.cwc + c;
+      for (int j = 0; j < NACC; ++j)
+        if (full || o0 + j < g.O) (o32 + (size_t)(o0 + j) * hw)[lane_off] = dot[j];
+    }
+    return;
+  }
+  float* outf = static_cast<float*>(e.out);
+  if (!FUSED) {  // alpha, optional bias / post-scale, fp32 store: the drop-in Conv2d.forward
+    const bool hb = (f & EF_BIAS) != 0, hs = (f & EF_SCALE) != 0;
 #pragma unroll
-      for (int k = 0; k < kOG; ++k) {
-        const uint32_t w = W[wbase + (size_t)k * per_o];
-        uint32_t d = disagree(w, mw, pw);
-        if (WZ) {
-          const uint32_t z = Z[wbase + (size_t)k * per_o];
-          d &= z;
-          nzw[k] += __builtin_popcount((pw | mw) & z);
-        }
-        acc[k] += __builtin_popcount(d);
+    for (int j = 0; j < NACC; ++j) {
+      const int o = o0 + j;
+      if (full || o < g.O) {
+        float y = fmaf(e.alpha[o], (float)dot[j], hb ? e.bias[o] : 0.0f);
+        if (hs) y *= e.scale[o];
+        if (px.live) (outf + (size_t)o * hw)[lane_off] = y;
+      }
+    }
+    return;
+  }
+  uint32_t pbits = 0u, mbits = 0u;
+#pragma unroll
+  for (int j = 0; j < NACC; ++j) {
+    const int o = o0 + j;
+    if (full || o < g.O) {  // wave-uniform
+      float y = fmaf(e.alpha[o], (float)dot[j], (f & EF_BIAS) ? e.bias[o] : 0.0f);
+      if (f & EF_SCALE) y *= e.scale[o];
+      if (f & EF_BN) y = fmaf(y, e.bn_a[o], e.bn_b[o]);
+      if (f & EF_RES) y += px.live ? (e.res + (size_t)o * hw)[lane_off] : 0.0f;
+      if (f & EF_RELU) y = (y < 0.0f) ? 0.0f : y;  // keeps NaN, like torch.relu
+      if (f & EF_PRELU) y = (y >= 0.0f) ? y : e.prelu[o] * y;
+      if ((f & EF_OUTF) && px.live) (outf + (size_t)o * hw)[lane_off] = y;
+      if (f & EF_PACK) {
+        pbits |= (is_pos(y) ? 1u : 0u) << (j & 31);
+        mbits |= (is_neg(y) ? 1u : 0u) << (j & 31);
       }
     }
   }
-  if (!live) return;
-  const size_t obase = ((size_t)n * g.O) * hw + r;
+  if ((f & EF_PACK) && px.live) {
+    // output planes [n][group][y][x] uint64; this block of 32 channels is one half of a word
+    const int ob = o0 >> 5;
+    const size_t w = ((((size_t)px.n * (g.cw32_out >> 1) + (ob >> 1)) * hw + px.r) << 1) + (ob & 1);
+    e.outP[w] = pbits;
+    e.outM[w] = mbits;
+  }
+}
+
+#define BNN_EPI_PARAMS                                                                          \
+  const float *__restrict__ alpha, const float *__restrict__ bias, const float *__restrict__ scale, \
+      const float *__restrict__ bn_a, const float *__restrict__ bn_b,                           \
+      const float *__restrict__ prelu, const float *__restrict__ res, void *__restrict__ out,   \
+      uint32_t *__restrict__ outP, uint32_t *__restrict__ outM
+#define BNN_EPI_INIT \
+  EpiArgs epi{alpha, bias, scale, bn_a, bn_b, prelu, res, out, outP, outM}
+
+// ---------------------------------------------------------------------------------
+// Tiled kernel, weights streamed through SGPRs (scalar cache).  Best when all waves in
+// flight share one small weight block (large images, few output channels): BASELINE config 2.
+// ---------------------------------------------------------------------------------
+template <int KH, int KW, int CWC, bool FUSED>
+__global__ __launch_bounds__(64, BNN_TILED_MIN_WAVES) void bconv_sgpr_kernel(
+    const uint32_t* __restrict__ P, const uint32_t* __restrict__ M, const uint32_t* __restrict__ W,
+    BNN_EPI_PARAMS, const Geo g) {
+  constexpr int T = KH * KW;
+  constexpr int NW = T * CWC;  // words per (o, chunk)
+  BNN_EPI_INIT;
+  const Pix px = decode_pixel(g, blockIdx.x * kWave + threadIdx.x);
+  const int ob = blockIdx.y;
+
+  int acc[kOCB];
 #pragma unroll
-  for (int k = 0; k < kOG; ++k) {
-    const int o = o0 + k;
-    if (o < g.O) {
-      const float a = RAW ? 0.f : alpha[o];
-      const float b = (!RAW && g.has_bias) ? bias[o] : 0.f;
-      const float sc = (!RAW && g.has_scale) ? scale[o] : 1.f;
-      store_result<RAW>(out, obase + (size_t)o * hw, (WZ ? nzw[k] : nz) - 2 * acc[k], a, b, sc,
-                        g.has_scale);
+  for (int j = 0; j < kOCB; ++j) acc[j] = 0;
+  int nz = 0;
+
+  if (ob * kOCB < g.O) {
+    const uint32_t* wblk = W + (size_t)ob * g.nchunk * (kOCB * NW);
+    for (int ch = 0; ch < g.nchunk; ++ch) {
+      uint32_t pr[NW], mr[NW];
+      load_field<KH, KW, CWC>(g, px, ch, P, M, pr, mr);
+      nz = count_nonzero<NW>(pr, mr, nz);
+      const uint32_t* wch = wblk + (size_t)ch * (kOCB * NW);
+      // The 32 x NW weight words of this (ob, chunk) are one contiguous, wave-uniform stream.
+      // Walk it in blocks of WB words through two SGPR buffers.  SMEM returns out of order, so
+      // the only usable wait is lgkmcnt(0): touch `cur` first so that this wait lands BEFORE
+      // block b+1 is requested; b+1 then has the whole VALU block below (2*WB instructions)
+      // to arrive.
+      constexpr int WB = 16;
+      constexpr int NB = kOCB * NW / WB;
+      static_assert((kOCB * NW) % WB == 0, "weight stream must be a whole number of blocks");
+      const WBlock<WB>* wq = reinterpret_cast<const WBlock<WB>*>(wch);
+      WBlock<WB> cur = wq[0];
+      int t0 = 0, t1 = 0;  // two accumulation chains per channel (even / odd words)
+      static_for<NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::"s"(cur.v[0]), "s"(cur.v[WB - 1]));
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        WBlock<WB> nxt;
+        if constexpr (b + 1 < NB) nxt = wq[b + 1];
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<WB>([&](auto ec) {
+          constexpr int e = decltype(ec)::value;
+          constexpr int f = b * WB + e;
+          constexpr int j = f / NW, i = f % NW;
+          const uint32_t d = disagree(cur.v[e], mr[i], pr[i]);
+          // the first word of each chain uses the inline-constant form (v_bcnt d, 0): no v_mov
+          if constexpr (i == 0) t0 = __builtin_popcount(d);
+          else if constexpr (i == 1) t1 = __builtin_popcount(d);
+          else if constexpr (i & 1) t1 = popc_acc(d, t1);
+          else t0 = popc_acc(d, t0);
+          if constexpr (i == NW - 1) acc[j] += t0 + (NW > 1 ? t1 : 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (b + 1 < NB) cur = nxt;
+      });
     }
   }
+#pragma unroll
+  for (int j = 0; j < kOCB; ++j) acc[j] = nz - 2 * acc[j];  // dot = non-zero count - 2 * disagreements
+  epilogue<kOCB, FUSED>(g, px, ob * kOCB, acc, epi);
+}
+
+// ---------------------------------------------------------------------------------
+// Tiled kernel, weights staged in LDS.  A workgroup = 4 waves = 256 pixels sharing one
+// (ob, chunk) weight tile; every wave reads the tile with wave-uniform (broadcast)
+// ds_read_b128.  Best when many output-channel blocks are in flight at once (small images,
+// wide layers: ResNet layer3/layer4), where the scalar cache thrashes and every s_load pays
+// an L2 round trip.
+// ---------------------------------------------------------------------------------
+constexpr int kLdsWaves = 4;
+
+template <int KH, int KW, int CWC>
+__global__ __launch_bounds__(kLdsWaves* kWave) void bconv_lds_kernel(
+    const uint32_t* __restrict__ P, const uint32_t* __restrict__ M, const uint32_t* __restrict__ W,
+    BNN_EPI_PARAMS, const Geo g) {
+  constexpr int T = KH * KW;
+  constexpr int NW = T * CWC;
+  constexpr int TILE = kOCB * NW;          // words per (ob, chunk) weight tile
+  constexpr int NV = (TILE + 3) / 4;       // uint4 pieces
+  constexpr int NT = kLdsWaves * kWave;    // threads
+  constexpr int PER = (NV + NT - 1) / NT;  // pieces per thread
+  __shared__ __attribute__((aligned(16))) uint32_t wl[2][NV * 4];
+  BNN_EPI_INIT;
+  const Pix px = decode_pixel(g, blockIdx.x * NT + threadIdx.x);
+  const int ob = blockIdx.y;
+  const bool active = ob * kOCB < g.O;
+
+  int acc[kOCB];
+#pragma unroll
+  for (int j = 0; j < kOCB; ++j) acc[j] = 0;
+  int nz = 0;
+
+  if (active) {
+    const uint4* wsrc = reinterpret_cast<const uint4*>(W + (size_t)ob * g.nchunk * TILE);
+    uint4 stage[PER];
+    auto fetch = [&](int ch) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int v = threadIdx.x + k * NT;
+        if (v < NV) stage[k] = wsrc[(size_t)ch * NV + v];
+      }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int v = threadIdx.x + k * NT;
+        if (v < NV) reinterpret_cast<uint4*>(wl[buf])[v] = stage[k];
+      }
+    };
+    fetch(0);
+    commit(0);
+    for (int ch = 0; ch < g.nchunk; ++ch) {
+      const int buf = ch & 1;
+      __syncthreads();  // tile `ch` is in wl[buf]; everyone is done reading wl[buf^1]
+      if (ch + 1 < g.nchunk) fetch(ch + 1);  // global -> registers, lands during the VALU work
+      uint32_t pr[NW], mr[NW];
+      load_field<KH, KW, CWC>(g, px, ch, P, M, pr, mr);
+      nz = count_nonzero<NW>(pr, mr, nz);
+      const uint32_t* wt = wl[buf];
+#pragma unroll
+      for (int j = 0; j < kOCB; ++j) {
+        int t0 = 0, t1 = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+          const uint32_t d = disagree(wt[j * NW + i], mr[i], pr[i]);  // uniform address: broadcast
+          if (i & 1) t1 = popc_acc(d, t1);
+          else t0 = popc_acc(d, t0);
+        }
+        acc[j] += t0 + t1;
+      }
+      if (ch + 1 < g.nchunk) commit(buf ^ 1);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kOCB; ++j) acc[j] = nz - 2 * acc[j];  // dot = non-zero count - 2 * disagreements
+  epilogue<kOCB, true>(g, px, ob * kOCB, acc, epi);
+}
+
+// ---------------------------------------------------------------------------------
+// Generic kernel: any KH/KW/stride/pad/dilation/cwc, optional zero-weight mask.
+// One lane = one output pixel, one wave = 64 pixels x 32 output channels in 4 passes of 8.
+// ---------------------------------------------------------------------------------
+constexpr int kOG = 8;
+
+template <bool WZ>
+__global__ __launch_bounds__(64) void bconv_generic_kernel(
+    const uint32_t* __restrict__ P, const uint32_t* __restrict__ M, const uint32_t* __restrict__ W,
+    const uint32_t* __restrict__ Z, BNN_EPI_PARAMS, const Geo g) {
+  BNN_EPI_INIT;
+  const Pix px = decode_pixel(g, blockIdx.x * kWave + threadIdx.x);
+  const int ob = blockIdx.y;
+  const int taps = g.KH * g.KW;
+  const int per_o = taps * g.cwc;
+
+  int dotv[kOCB];
+#pragma unroll
+  for (int j = 0; j < kOCB; ++j) dotv[j] = 0;
+
+  if (ob * kOCB < g.O) {
+#pragma unroll
+    for (int pass = 0; pass < kOCB / kOG; ++pass) {
+      const int j0 = pass * kOG;
+      int acc[kOG], nzw[kOG];
+#pragma unroll
+      for (int k = 0; k < kOG; ++k) { acc[k] = 0; nzw[k] = 0; }
+      int nz = 0;
+      if (ob * kOCB + j0 < g.O) {
+        for (int t = 0; t < taps; ++t) {
+          const int ky = t / g.KW, kx = t - ky * g.KW;
+          const int iy = px.oy * g.sh - g.ph + ky * g.dh;
+          const int ix = px.ox * g.sw - g.pw + kx * g.dw;
+          const bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.Wd;
+          const int pix = ok ? iy * g.Wd + ix : 0;
+          for (int cw = 0; cw < g.cw32; ++cw) {
+            // word cw of the pixel lives in plane (cw >> 1), half (cw & 1)
+            const size_t aw =
+                ((((size_t)px.n * (g.cw32 >> 1) + (cw >> 1)) * g.H * g.Wd + pix) << 1) + (cw & 1);
+            const uint32_t pw = ok ? P[aw] : 0u;
+            const uint32_t mw = ok ? M[aw] : 0u;
+            if (!WZ) nz += __builtin_popcount(pw | mw);
+            const int ch = cw / g.cwc, c = cw - ch * g.cwc;
+            const size_t wbase =
+                ((size_t)(ob * g.nchunk + ch) * kOCB + j0) * per_o + t * g.cwc + c;
+#pragma unroll
+            for (int k = 0; k < kOG; ++k) {
+              const uint32_t w = W[wbase + (size_t)k * per_o];
+              uint32_t d = disagree(w, mw, pw);
+              if (WZ) {
+                const uint32_t z = Z[wbase + (size_t)k * per_o];
+                d &= z;
+                nzw[k] += __builtin_popcount((pw | mw) & z);
+              }
+              acc[k] += __builtin_popcount(d);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kOG; ++k) dotv[j0 + k] = (WZ ? nzw[k] : nz) - 2 * acc[k];
+    }
+  }
+  epilogue<kOCB, true>(g, px, ob * kOCB, dotv, epi);
 }
 
 // ---------------------------------------------------------------------------------
@@ -236,38 +462,59 @@ static Geo make_geo(const ConvP& p) {
   g.KH = p.KH; g.KW = p.KW; g.sh = p.sh; g.sw = p.sw; g.ph = p.ph; g.pw = p.pw;
   g.dh = p.dh; g.dw = p.dw; g.cw32 = p.cw32; g.cwc = p.cwc; g.nchunk = p.nchunk;
   g.npix = p.npix;
-  g.has_bias = p.bias != nullptr;
-  g.has_scale = p.scale != nullptr;
+  g.cw32_out = 2 * ((p.O + 63) / 64);
+  int f = 0;
+  if (p.raw) f |= EF_RAW;
+  if (p.bias) f |= EF_BIAS;
+  if (p.scale) f |= EF_SCALE;
+  if (p.bn_a && p.bn_b) f |= EF_BN;
+  if (p.res) f |= EF_RES;
+  if (p.relu) f |= EF_RELU;
+  if (p.prelu) f |= EF_PRELU;
+  if (p.out) f |= EF_OUTF;
+  if (p.outP && p.outM) f |= EF_PACK;
+  g.flags = f;
   return g;
 }
 
+#define BNN_EPI_ACTUALS p.alpha, p.bias, p.scale, p.bn_a, p.bn_b, p.prelu, p.res, p.out, p.outP, p.outM
+
+// grid.y: one block per 32 output channels; in pack mode also the (all-zero) tail words of the
+// packed output row so that every word of the next layer's input is written.
+static unsigned oblocks(const ConvP& p) {
+  const unsigned nb = (p.O + kOCB - 1) / kOCB;
+  return (p.outP && p.outM) ? (unsigned)(2 * ((p.O + 63) / 64)) : nb;
+}
+
 template <int KH, int KW, int CWC>
-static void launch_tiled(const ConvP& p, bool raw, hipStream_t s) {
-  const dim3 grid((p.npix + kWave - 1) / kWave, (p.O + kOCB - 1) / kOCB);
+static void launch_sgpr(const ConvP& p, hipStream_t s) {
+  const dim3 grid((p.npix + kWave - 1) / kWave, oblocks(p));
   const Geo g = make_geo(p);
-  if (raw)
-    hipLaunchKernelGGL((bconv_tiled_kernel<KH, KW, CWC, true>), grid, dim3(kWave), 0, s, p.P, p.M,
-                       p.nzc, p.W, p.alpha, p.bias, p.scale, p.out, g);
+  const bool fused = (g.flags & (EF_BN | EF_RES | EF_RELU | EF_PRELU | EF_PACK)) != 0;
+  if (fused)
+    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, true>), grid, dim3(kWave), 0, s, p.P, p.M,
+                       p.W, BNN_EPI_ACTUALS, g);
   else
-    hipLaunchKernelGGL((bconv_tiled_kernel<KH, KW, CWC, false>), grid, dim3(kWave), 0, s, p.P, p.M,
-                       p.nzc, p.W, p.alpha, p.bias, p.scale, p.out, g);
+    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, false>), grid, dim3(kWave), 0, s, p.P, p.M,
+                       p.W, BNN_EPI_ACTUALS, g);
 }
 
-template <bool WZ, bool RAW>
-static void launch_generic_t(const ConvP& p, hipStream_t s) {
-  const dim3 grid((p.npix + kWave - 1) / kWave, (p.O + kOG - 1) / kOG);
-  hipLaunchKernelGGL((bconv_generic_kernel<WZ, RAW>), grid, dim3(kWave), 0, s, p.P, p.M, p.nzc, p.W,
-                     p.Z, p.alpha, p.bias, p.scale, p.out, make_geo(p));
+template <int KH, int KW, int CWC>
+static void launch_lds(const ConvP& p, hipStream_t s) {
+  constexpr int NT = kLdsWaves * kWave;
+  const dim3 grid((p.npix + NT - 1) / NT, oblocks(p));
+  hipLaunchKernelGGL((bconv_lds_kernel<KH, KW, CWC>), grid, dim3(NT), 0, s, p.P, p.M, p.W,
+                     BNN_EPI_ACTUALS, make_geo(p));
 }
 
-static void launch_generic(const ConvP& p, bool wz, bool raw, hipStream_t s) {
-  if (wz) {
-    if (raw) launch_generic_t<true, true>(p, s);
-    else launch_generic_t<true, false>(p, s);
-  } else {
-    if (raw) launch_generic_t<false, true>(p, s);
-    else launch_generic_t<false, false>(p, s);
-  }
+static void launch_generic(const ConvP& p, bool wz, hipStream_t s) {
+  const dim3 grid((p.npix + kWave - 1) / kWave, oblocks(p));
+  if (wz)
+    hipLaunchKernelGGL((bconv_generic_kernel<true>), grid, dim3(kWave), 0, s, p.P, p.M, p.W, p.Z,
+                       BNN_EPI_ACTUALS, make_geo(p));
+  else
+    hipLaunchKernelGGL((bconv_generic_kernel<false>), grid, dim3(kWave), 0, s, p.P, p.M, p.W, p.Z,
+                       BNN_EPI_ACTUALS, make_geo(p));
 }
 
 // Chunk width is a pure function of the weight geometry (shared with pack_weight).
@@ -282,21 +529,28 @@ int choose_cwc(int cw32, int KH, int KW) {
   return 2;
 }
 
-int launch_bconv(const ConvP& p, int flags, bool raw, hipStream_t s) {
+// Weight source.  Measured on MI355X (tools/bench_conv.py, tools/exp_l4.py): the SGPR stream
+// beats the LDS-staged tile on every ResNet-18 shape (e.g. 512->512 7x7 b256: 140 vs 216 us),
+// so LDS is only taken on request.
+static bool prefer_lds(const ConvP&, int flags) { return (flags & BNN_HIP_FLAG_WEIGHTS_LDS) != 0; }
+
+int launch_bconv(const ConvP& p, int flags, hipStream_t s) {
   const bool wz = (flags & BNN_HIP_FLAG_WEIGHT_ZEROS) != 0;
   const bool generic = (flags & BNN_HIP_FLAG_FORCE_GENERIC) || wz || p.dh != 1 || p.dw != 1;
   bool done = false;
   if (!generic) {
+    const bool lds = prefer_lds(p, flags);
     done = true;
-    if (p.KH == 3 && p.KW == 3 && p.cwc == 4) launch_tiled<3, 3, 4>(p, raw, s);
-    else if (p.KH == 3 && p.KW == 3 && p.cwc == 2) launch_tiled<3, 3, 2>(p, raw, s);
-    else if (p.KH == 1 && p.KW == 1 && p.cwc == 16) launch_tiled<1, 1, 16>(p, raw, s);
-    else if (p.KH == 1 && p.KW == 1 && p.cwc == 8) launch_tiled<1, 1, 8>(p, raw, s);
-    else if (p.KH == 1 && p.KW == 1 && p.cwc == 4) launch_tiled<1, 1, 4>(p, raw, s);
-    else if (p.KH == 1 && p.KW == 1 && p.cwc == 2) launch_tiled<1, 1, 2>(p, raw, s);
-    else done = false;
+#define BNN_PICK(KH_, KW_, C_)                                  \
+  if (p.KH == KH_ && p.KW == KW_ && p.cwc == C_) {              \
+    if (lds) launch_lds<KH_, KW_, C_>(p, s);                    \
+    else launch_sgpr<KH_, KW_, C_>(p, s);                       \
+  } else
+    BNN_PICK(3, 3, 4) BNN_PICK(3, 3, 2) BNN_PICK(1, 1, 16) BNN_PICK(1, 1, 8) BNN_PICK(1, 1, 4)
+    BNN_PICK(1, 1, 2) { done = false; }
+#undef BNN_PICK
   }
-  if (!done) launch_generic(p, wz, raw, s);
+  if (!done) launch_generic(p, wz, s);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 

@@ -42,17 +42,25 @@ struct WordVec<2> { using type = uint2; };
 template <>
 struct WordVec<4> { using type = uint4; };
 
-// Everything one binary-convolution launch needs (device pointers + geometry).
+// Everything one binary-convolution launch needs (device pointers + geometry + epilogue).
 struct ConvP {
   const uint32_t* P;
   const uint32_t* M;
-  const uint16_t* nzc;
   const uint32_t* W;
   const uint32_t* Z;
+  // epilogue (see bnn_hip_epilogue in include/bnn_hip.h)
   const float* alpha;
   const float* bias;
   const float* scale;
-  void* out;
+  const float* bn_a;
+  const float* bn_b;
+  const float* prelu;
+  const float* res;
+  void* out;       // fp32 NCHW, or int32 NCHW when raw
+  uint32_t* outP;  // packed sign planes of the output, or null
+  uint32_t* outM;
+  bool raw;
+  bool relu;
   int N, H, Wd, Ho, Wo, O;
   int KH, KW, sh, sw, ph, pw, dh, dw;
   int cw32, cwc, nchunk;
@@ -62,11 +70,13 @@ struct ConvP {
 // host-side launchers (one per .hip file); return a bnn_hip_status
 int choose_cwc(int cw32, int KH, int KW);
 int launch_pack_act(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
-                    uint16_t* nzc, hipStream_t stream);
+                    hipStream_t stream);
+int launch_avgpool_pack(const float* x, int N, int C, int H, int W, int k, uint64_t* P, uint64_t* M,
+                        hipStream_t stream);
 int launch_pack_weight(const float* w, int O, int C, int KH, int KW, int center, int compute_alpha,
                        const bnn_hip_wlayout& L, uint32_t* wbits, uint32_t* wnz, float* alpha,
                        int32_t* zero_flag, hipStream_t stream);
-int launch_bconv(const ConvP& p, int flags, bool raw, hipStream_t s);
-int launch_probe_int_alu(int iters, double* lane_ops_per_s, double* elapsed_ms, hipStream_t s);
+int launch_bconv(const ConvP& p, int flags, hipStream_t s);
+int launch_probe_int_alu(int mode, int iters, double* lane_ops_per_s, double* elapsed_ms, hipStream_t s);
 
 }  // namespace bnn

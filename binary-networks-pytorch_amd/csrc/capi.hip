@@ -24,7 +24,6 @@ int check_desc(const bnn_hip_conv_desc* d, int* Ho, int* Wo) {
   if (d->stride_h <= 0 || d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0 || d->dil_h <= 0 ||
       d->dil_w <= 0)
     return BNN_HIP_ERR_INVALID_ARG;
-  if (d->C > 65535) return BNN_HIP_ERR_UNSUPPORTED;  // nzc is uint16
   const int ho = out_dim(d->H, d->KH, d->stride_h, d->pad_h, d->dil_h);
   const int wo = out_dim(d->W, d->KW, d->stride_w, d->pad_w, d->dil_w);
   if (ho <= 0 || wo <= 0) return BNN_HIP_ERR_INVALID_ARG;
@@ -35,34 +34,39 @@ int check_desc(const bnn_hip_conv_desc* d, int* Ho, int* Wo) {
   return BNN_HIP_OK;
 }
 
-int run_conv(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M, const uint16_t* nzc,
-             const uint32_t* wbits, const uint32_t* wnz, const float* alpha, const float* bias,
-             const float* post_scale, void* out, bool raw, void* stream) {
+// Shared tail of every conv entry point: fills the geometry part of `p` and launches.
+int run_conv(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M, const uint32_t* wbits,
+             const uint32_t* wnz, bnn::ConvP p, void* stream) {
   int Ho = 0, Wo = 0;
   const int st = check_desc(d, &Ho, &Wo);
   if (st != BNN_HIP_OK) return st;
-  if (!P || !M || !nzc || !wbits || !out || (!raw && !alpha)) return BNN_HIP_ERR_INVALID_ARG;
+  if (!P || !M || !wbits) return BNN_HIP_ERR_INVALID_ARG;
+  if (!p.out && !(p.outP && p.outM)) return BNN_HIP_ERR_INVALID_ARG;
+  if (!p.raw && !p.alpha) return BNN_HIP_ERR_INVALID_ARG;
+  if ((p.bn_a == nullptr) != (p.bn_b == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
+  if ((p.outP == nullptr) != (p.outM == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
   if ((d->flags & BNN_HIP_FLAG_WEIGHT_ZEROS) && !wnz) return BNN_HIP_ERR_INVALID_ARG;
   if (!aligned(P, 16) || !aligned(M, 16) || !aligned(wbits, 16)) return BNN_HIP_ERR_INVALID_ARG;
+  if (p.outP && (!aligned(p.outP, 8) || !aligned(p.outM, 8))) return BNN_HIP_ERR_INVALID_ARG;
   bnn_hip_wlayout L;
   bnn_hip_weight_layout(d->O, d->C, d->KH, d->KW, &L);
-  bnn::ConvP p;
   p.P = reinterpret_cast<const uint32_t*>(P);
   p.M = reinterpret_cast<const uint32_t*>(M);
-  p.nzc = nzc;
   p.W = wbits;
   p.Z = wnz;
-  p.alpha = alpha;
-  p.bias = bias;
-  p.scale = post_scale;
-  p.out = out;
   p.N = d->N; p.H = d->H; p.Wd = d->W; p.Ho = Ho; p.Wo = Wo; p.O = d->O;
   p.KH = d->KH; p.KW = d->KW; p.sh = d->stride_h; p.sw = d->stride_w;
   p.ph = d->pad_h; p.pw = d->pad_w; p.dh = d->dil_h; p.dw = d->dil_w;
   p.cw32 = L.cw32; p.cwc = L.cwc; p.nchunk = L.nchunk;
   p.npix = d->N * Ho * Wo;
   g_launches.fetch_add(1, std::memory_order_relaxed);
-  return bnn::launch_bconv(p, d->flags, raw, static_cast<hipStream_t>(stream));
+  return bnn::launch_bconv(p, d->flags, static_cast<hipStream_t>(stream));
+}
+
+bnn::ConvP empty_convp() {
+  bnn::ConvP p;
+  std::memset(&p, 0, sizeof(p));
+  return p;
 }
 
 }  // namespace
@@ -118,13 +122,23 @@ int bnn_hip_weight_layout(int O, int C, int KH, int KW, bnn_hip_wlayout* out) {
 }
 
 int bnn_hip_pack_act_f32(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
-                         uint16_t* nzc, void* stream) {
-  if (!x || !P || !M || !nzc || N <= 0 || C <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
-  if (C > 65535) return BNN_HIP_ERR_UNSUPPORTED;
-  if ((long long)N * C * H * W > kMaxElems * 4LL) return BNN_HIP_ERR_TOO_LARGE;
+                         void* stream) {
+  if (!x || !P || !M || N <= 0 || C <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if ((long long)N * H * W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if ((C + 63) / 64 > 65535) return BNN_HIP_ERR_UNSUPPORTED;  // grid.y limit
   if (!aligned(P, 8) || !aligned(M, 8) || !aligned(x, 4)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
-  return bnn::launch_pack_act(x, N, C, H, W, P, M, nzc, static_cast<hipStream_t>(stream));
+  return bnn::launch_pack_act(x, N, C, H, W, P, M, static_cast<hipStream_t>(stream));
+}
+
+int bnn_hip_avgpool_pack_f32(const float* x, int N, int C, int H, int W, int k, uint64_t* P,
+                             uint64_t* M, void* stream) {
+  if (!x || !P || !M || N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if ((long long)N * H * W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (2 * ((C + 63) / 64) > 65535) return BNN_HIP_ERR_UNSUPPORTED;
+  if (!aligned(P, 8) || !aligned(M, 8)) return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  return bnn::launch_avgpool_pack(x, N, C, H, W, k, P, M, static_cast<hipStream_t>(stream));
 }
 
 int bnn_hip_pack_weight_f32(const float* w, int O, int C, int KH, int KW, int center,
@@ -140,34 +154,49 @@ int bnn_hip_pack_weight_f32(const float* w, int O, int C, int KH, int KW, int ce
 }
 
 int bnn_hip_bconv2d(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M,
-                    const uint16_t* nzc, const uint32_t* wbits, const uint32_t* wnz,
-                    const float* alpha, const float* bias, const float* post_scale, float* out,
-                    void* stream) {
-  return run_conv(d, P, M, nzc, wbits, wnz, alpha, bias, post_scale, out, false, stream);
+                    const uint32_t* wbits, const uint32_t* wnz, const float* alpha,
+                    const float* bias, const float* post_scale, float* out, void* stream) {
+  bnn::ConvP p = empty_convp();
+  p.alpha = alpha; p.bias = bias; p.scale = post_scale; p.out = out;
+  return run_conv(d, P, M, wbits, wnz, p, stream);
+}
+
+int bnn_hip_bconv2d_fused(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M,
+                          const uint32_t* wbits, const uint32_t* wnz, const bnn_hip_epilogue* e,
+                          void* stream) {
+  if (!e) return BNN_HIP_ERR_INVALID_ARG;
+  bnn::ConvP p = empty_convp();
+  p.alpha = e->alpha; p.bias = e->bias; p.scale = e->post_scale;
+  p.bn_a = e->bn_scale; p.bn_b = e->bn_shift; p.res = e->residual; p.prelu = e->prelu;
+  p.relu = e->relu != 0;
+  p.out = e->out_f32;
+  p.outP = reinterpret_cast<uint32_t*>(e->out_P);
+  p.outM = reinterpret_cast<uint32_t*>(e->out_M);
+  return run_conv(d, P, M, wbits, wnz, p, stream);
 }
 
 int bnn_hip_bconv2d_dot(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M,
-                        const uint16_t* nzc, const uint32_t* wbits, const uint32_t* wnz,
-                        int32_t* dot, void* stream) {
-  return run_conv(d, P, M, nzc, wbits, wnz, nullptr, nullptr, nullptr, dot, true, stream);
+                        const uint32_t* wbits, const uint32_t* wnz, int32_t* dot, void* stream) {
+  bnn::ConvP p = empty_convp();
+  p.raw = true; p.out = dot;
+  return run_conv(d, P, M, wbits, wnz, p, stream);
 }
 
-int bnn_hip_blinear(int B, int F, int O, const uint64_t* P, const uint64_t* M, const uint16_t* nzc,
-                    const uint32_t* wbits, const uint32_t* wnz, int weight_zeros, const float* alpha,
-                    const float* bias, const float* post_scale, float* out, void* stream) {
+int bnn_hip_blinear(int B, int F, int O, const uint64_t* P, const uint64_t* M, const uint32_t* wbits,
+                    const uint32_t* wnz, int weight_zeros, const float* alpha, const float* bias,
+                    const float* post_scale, float* out, void* stream) {
   bnn_hip_conv_desc d;
   std::memset(&d, 0, sizeof(d));
   d.N = B; d.C = F; d.H = 1; d.W = 1; d.O = O; d.KH = 1; d.KW = 1;
   d.stride_h = d.stride_w = 1; d.dil_h = d.dil_w = 1;
   d.flags = weight_zeros ? BNN_HIP_FLAG_WEIGHT_ZEROS : 0;
-  return run_conv(&d, P, M, nzc, wbits, wnz, alpha, bias, post_scale, out, false, stream);
+  return bnn_hip_bconv2d(&d, P, M, wbits, wnz, alpha, bias, post_scale, out, stream);
 }
 
 size_t bnn_hip_conv_workspace_bytes(const bnn_hip_conv_desc* d) {
   if (!d || d->N <= 0 || d->C <= 0 || d->H <= 0 || d->W <= 0) return 0;
   const size_t npix = (size_t)d->N * d->H * d->W;
-  const size_t plane = align_up(npix * ((d->C + 63) / 64) * sizeof(uint64_t), 256);
-  return 2 * plane + align_up(npix * sizeof(uint16_t), 256);
+  return 2 * align_up(npix * ((d->C + 63) / 64) * sizeof(uint64_t), 256);
 }
 
 int bnn_hip_bconv2d_f32(const bnn_hip_conv_desc* d, const float* x, const uint32_t* wbits,
@@ -182,15 +211,16 @@ int bnn_hip_bconv2d_f32(const bnn_hip_conv_desc* d, const float* x, const uint32
   char* ws = static_cast<char*>(workspace);
   uint64_t* P = reinterpret_cast<uint64_t*>(ws);
   uint64_t* M = reinterpret_cast<uint64_t*>(ws + plane);
-  uint16_t* nzc = reinterpret_cast<uint16_t*>(ws + 2 * plane);
-  st = bnn_hip_pack_act_f32(x, d->N, d->C, d->H, d->W, P, M, nzc, stream);
+  st = bnn_hip_pack_act_f32(x, d->N, d->C, d->H, d->W, P, M, stream);
   if (st != BNN_HIP_OK) return st;
-  return run_conv(d, P, M, nzc, wbits, wnz, alpha, bias, post_scale, out, false, stream);
+  return bnn_hip_bconv2d(d, P, M, wbits, wnz, alpha, bias, post_scale, out, stream);
 }
 
-int bnn_hip_probe_int_alu(int iters, double* lane_ops_per_s, double* elapsed_ms, void* stream) {
+int bnn_hip_probe_int_alu(int mode, int iters, double* lane_ops_per_s, double* elapsed_ms,
+                          void* stream) {
   if (iters <= 0 || !lane_ops_per_s) return BNN_HIP_ERR_INVALID_ARG;
-  return bnn::launch_probe_int_alu(iters, lane_ops_per_s, elapsed_ms, static_cast<hipStream_t>(stream));
+  return bnn::launch_probe_int_alu(mode, iters, lane_ops_per_s, elapsed_ms,
+                                   static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

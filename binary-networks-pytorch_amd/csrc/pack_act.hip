@@ -5,10 +5,12 @@
 // fp32 tensor of {-1,0,+1}; here the same information is 2 bits per element:
 //   P bit = x > 0, M bit = x < 0, neither = 0 / -0 / NaN  (torch.sign semantics).
 //
-// HBM-bound: reads 4 B/element, writes 2 bits/element (+2 B/pixel of nzc).
-// Mapping: one thread owns VP consecutive pixels of one image and walks all channels,
-// so every global load is a coalesced 4*VP-byte-per-lane row segment of one channel
-// plane, and every store is a whole uint64 word of a pixel.
+// HBM-bound: reads 4 B/element, writes 2 bits/element.
+// Mapping: one thread owns VP consecutive pixels of one image and ONE 64-channel group
+// (blockIdx.y), so every global load is a coalesced 4*VP-byte-per-lane row segment of one
+// channel plane, every store is VP contiguous uint64 words of the [n][group][y][x] output
+// plane, and small images with many channels still fill the chip (parallelism = pixels/VP x
+// channel groups).
 #include "bnn_dev.h"
 
 namespace bnn {
@@ -26,84 +28,121 @@ template <int VP>
 __global__ __launch_bounds__(256) void pack_act_kernel(const float* __restrict__ x, int C, int HW,
                                                        long long npix, int cw64,
                                                        uint64_t* __restrict__ P,
-                                                       uint64_t* __restrict__ M,
-                                                       uint16_t* __restrict__ nzc) {
+                                                       uint64_t* __restrict__ M) {
   using V = typename PixVec<VP>::type;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long pix0 = t * VP;
   if (pix0 >= npix) return;
+  const int g = blockIdx.y;
   const int n = (int)(pix0 / HW);
   const int r = (int)(pix0 - (long long)n * HW);
   const float* xb = x + ((size_t)n * C) * HW + r;
 
-  int cnt[VP];
+  uint32_t pw[2][VP], mw[2][VP];
 #pragma unroll
-  for (int v = 0; v < VP; ++v) cnt[v] = 0;
-
-  for (int g = 0; g < cw64; ++g) {
-    uint32_t pw[2][VP], mw[2][VP];
+  for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int v = 0; v < VP; ++v) { pw[h][v] = 0u; mw[h][v] = 0u; }
+    const int c0 = g * 64 + h * 32;
+    if (c0 + 32 <= C) {
+      // full 32-channel word: walk channels high -> low so that shifting left leaves
+      // channel c0+b in bit b.
+#pragma unroll 16
+      for (int b = 31; b >= 0; --b) {
+        const V xv = *reinterpret_cast<const V*>(xb + (size_t)(c0 + b) * HW);
+        const float* xs = reinterpret_cast<const float*>(&xv);
 #pragma unroll
-      for (int v = 0; v < VP; ++v) { pw[h][v] = 0u; mw[h][v] = 0u; }
-      const int c0 = g * 64 + h * 32;
-      if (c0 + 32 <= C) {
-        // full 32-channel word: walk channels high -> low so that shifting left leaves
-        // channel c0+b in bit b.
-#pragma unroll 8
-        for (int b = 31; b >= 0; --b) {
-          const V xv = *reinterpret_cast<const V*>(xb + (size_t)(c0 + b) * HW);
-          const float* xs = reinterpret_cast<const float*>(&xv);
-#pragma unroll
-          for (int v = 0; v < VP; ++v) {
-            pw[h][v] = (pw[h][v] << 1) | (is_pos(xs[v]) ? 1u : 0u);
-            mw[h][v] = (mw[h][v] << 1) | (is_neg(xs[v]) ? 1u : 0u);
-          }
+        for (int v = 0; v < VP; ++v) {
+          pw[h][v] = (pw[h][v] << 1) | (is_pos(xs[v]) ? 1u : 0u);
+          mw[h][v] = (mw[h][v] << 1) | (is_neg(xs[v]) ? 1u : 0u);
         }
-      } else {
-        for (int b = 0; b < 32 && c0 + b < C; ++b) {
-          const V xv = *reinterpret_cast<const V*>(xb + (size_t)(c0 + b) * HW);
-          const float* xs = reinterpret_cast<const float*>(&xv);
+      }
+    } else {
+      for (int b = 0; b < 32 && c0 + b < C; ++b) {
+        const V xv = *reinterpret_cast<const V*>(xb + (size_t)(c0 + b) * HW);
+        const float* xs = reinterpret_cast<const float*>(&xv);
 #pragma unroll
-          for (int v = 0; v < VP; ++v) {
-            pw[h][v] |= (is_pos(xs[v]) ? 1u : 0u) << b;
-            mw[h][v] |= (is_neg(xs[v]) ? 1u : 0u) << b;
-          }
+        for (int v = 0; v < VP; ++v) {
+          pw[h][v] |= (is_pos(xs[v]) ? 1u : 0u) << b;
+          mw[h][v] |= (is_neg(xs[v]) ? 1u : 0u) << b;
         }
       }
     }
-#pragma unroll
-    for (int v = 0; v < VP; ++v) {
-      const uint64_t pq = (uint64_t)pw[0][v] | ((uint64_t)pw[1][v] << 32);
-      const uint64_t mq = (uint64_t)mw[0][v] | ((uint64_t)mw[1][v] << 32);
-      P[(size_t)(pix0 + v) * cw64 + g] = pq;
-      M[(size_t)(pix0 + v) * cw64 + g] = mq;
-      cnt[v] += __builtin_popcountll(pq | mq);
-    }
   }
+  // planes are [n][group][y][x] uint64: the VP words of this thread are contiguous
+  const size_t o = ((size_t)n * cw64 + g) * HW + r;
 #pragma unroll
-  for (int v = 0; v < VP; ++v) nzc[pix0 + v] = (uint16_t)cnt[v];
+  for (int v = 0; v < VP; ++v) {
+    P[o + v] = (uint64_t)pw[0][v] | ((uint64_t)pw[1][v] << 32);
+    M[o + v] = (uint64_t)mw[0][v] | ((uint64_t)mw[1][v] << 32);
+  }
 }
 
 int launch_pack_act(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
-                    uint16_t* nzc, hipStream_t stream) {
+                    hipStream_t stream) {
   const int HW = H * W;
   const long long npix = (long long)N * HW;
   const int cw64 = (C + 63) / 64;
   const bool a16 = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
   const bool a8 = (reinterpret_cast<uintptr_t>(x) & 7u) == 0;
-  if (HW % 4 == 0 && a16) {
-    const long long nthr = npix / 4;
-    hipLaunchKernelGGL(pack_act_kernel<4>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0,
-                       stream, x, C, HW, npix, cw64, P, M, nzc);
-  } else if (HW % 2 == 0 && a8) {
-    const long long nthr = npix / 2;
-    hipLaunchKernelGGL(pack_act_kernel<2>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0,
-                       stream, x, C, HW, npix, cw64, P, M, nzc);
-  } else {
-    hipLaunchKernelGGL(pack_act_kernel<1>, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0,
-                       stream, x, C, HW, npix, cw64, P, M, nzc);
+  auto grid = [&](long long nthr) { return dim3((unsigned)((nthr + 255) / 256), (unsigned)cw64); };
+  if (HW % 4 == 0 && a16)
+    hipLaunchKernelGGL(pack_act_kernel<4>, grid(npix / 4), dim3(256), 0, stream, x, C, HW, npix, cw64, P, M);
+  else if (HW % 2 == 0 && a8)
+    hipLaunchKernelGGL(pack_act_kernel<2>, grid(npix / 2), dim3(256), 0, stream, x, C, HW, npix, cw64, P, M);
+  else
+    hipLaunchKernelGGL(pack_act_kernel<1>, grid(npix), dim3(256), 0, stream, x, C, HW, npix, cw64, P, M);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+// AvgPool2d(k, stride=k, ceil_mode=True, count_include_pad=False) + sign() in one pass: the
+// shortcut branch of a down-sampling stage (bnn/models/resnet.py:128-133).  The sign of an
+// average is the sign of the sum, so the divisor never matters and clipped windows at the
+// ragged edge need no special case beyond skipping out-of-image taps.
+// One thread = one output pixel x one 32-channel word.
+__global__ __launch_bounds__(256) void avgpool_pack_kernel(const float* __restrict__ x, int C,
+                                                           int H, int W, int k, int Ho, int Wo,
+                                                           long long npix_out, int cw32,
+                                                           uint32_t* __restrict__ P,
+                                                           uint32_t* __restrict__ M) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= npix_out) return;
+  const int word = blockIdx.y;
+  const int hw = Ho * Wo;
+  const int n = (int)(q / hw);
+  const int r = (int)(q - (long long)n * hw);
+  const int oy = r / Wo, ox = r - oy * Wo;
+  uint32_t pw = 0u, mw = 0u;
+  for (int b = 0; b < 32; ++b) {
+    const int c = word * 32 + b;
+    if (c >= C) break;
+    const float* xc = x + ((size_t)n * C + c) * H * W;
+    float s = 0.0f;
+    for (int dy = 0; dy < k; ++dy) {
+      const int iy = oy * k + dy;
+      if (iy >= H) break;
+      for (int dx = 0; dx < k; ++dx) {
+        const int ix = ox * k + dx;
+        if (ix >= W) break;
+        s += xc[(size_t)iy * W + ix];
+      }
+    }
+    pw |= (is_pos(s) ? 1u : 0u) << b;
+    mw |= (is_neg(s) ? 1u : 0u) << b;
   }
+  const size_t o = ((((size_t)n * (cw32 >> 1) + (word >> 1)) * hw + r) << 1) + (word & 1);
+  P[o] = pw;
+  M[o] = mw;
+}
+
+int launch_avgpool_pack(const float* x, int N, int C, int H, int W, int k, uint64_t* P, uint64_t* M,
+                        hipStream_t stream) {
+  const int Ho = (H + k - 1) / k, Wo = (W + k - 1) / k;
+  const long long npix = (long long)N * Ho * Wo;
+  const int cw32 = 2 * ((C + 63) / 64);
+  hipLaunchKernelGGL(avgpool_pack_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)cw32),
+                     dim3(256), 0, stream, x, C, H, W, k, Ho, Wo, npix, cw32,
+                     reinterpret_cast<uint32_t*>(P), reinterpret_cast<uint32_t*>(M));
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 

@@ -1,39 +1,89 @@
 // probe.hip — integer-ALU roofline calibration for the bconv main loop.
-// Runs the exact instruction pair of the hot loop (v_bitop3_b32 with a scalar weight
-// operand + accumulating v_bcnt_u32_b32) from registers only, on every CU, and reports
-// sustained 32-bit lane-ops/s.  bench.py prints this next to the theoretical peak
-// (CUs x 4 SIMD x 32 lanes x clock) so the roofline denominator is evidenced, not assumed.
+// Register-only instruction streams (inline asm, so the compiler can neither fold nor
+// re-associate them) run on every CU at full occupancy; the sustained 32-bit lane-ops/s is
+// what bench.py prints next to the theoretical peak, so the roofline denominator is
+// evidenced, not assumed.
+//
+//   mode 0  v_bitop3_b32 (scalar weight operand) + v_bcnt_u32_b32   <- the hot loop's pair
+//   mode 1  v_xor_b32 (scalar operand)           + v_bcnt_u32_b32   <- plain XNOR pair
+//   mode 2  v_bcnt_u32_b32 only
+//   mode 3  v_bitop3_b32 only
+//   mode 4  v_xor_b32 only
+//   mode 5  v_fma_f32 only (reference point: the guide's 2-cycle wave64 FMA)
+//   mode 6  v_add_u32 only
 #include "bnn_dev.h"
 
 namespace bnn {
 
 constexpr int kProbeRegs = 16;
 
-__global__ __launch_bounds__(256) void probe_int_alu_kernel(int iters, uint32_t seed,
-                                                            uint32_t* __restrict__ sink) {
-  uint32_t p[kProbeRegs], m[kProbeRegs];
-  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+template <int MODE>
+__global__ __launch_bounds__(256) void probe_kernel(int iters, uint32_t seed,
+                                                    uint32_t* __restrict__ sink) {
+  uint32_t p[kProbeRegs], m[kProbeRegs], a[8], t[8];
+  const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
 #pragma unroll
   for (int i = 0; i < kProbeRegs; ++i) {
-    p[i] = (t * 2654435761u) ^ (0x9e3779b9u * (i + 1));
-    m[i] = ~p[i] & ((t + i) * 40503u);
+    p[i] = (tid * 2654435761u) ^ (0x9e3779b9u * (i + 1));
+    m[i] = ~p[i] & ((tid + i) * 40503u);
   }
-  uint32_t w = seed;  // wave-uniform -> lives in an SGPR, like a streamed weight word
-  int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = i; t[i] = tid + i; }
+  uint32_t w = seed;  // wave-uniform -> SGPR, like a streamed weight word
+#if defined(__HIP_DEVICE_COMPILE__)  // gfx950 asm: the x86 host pass must not see the constraints
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < kProbeRegs; i += 4) {
-      a0 += __builtin_popcount(disagree(w, m[i], p[i]));
-      a1 += __builtin_popcount(disagree(w, m[i + 1], p[i + 1]));
-      a2 += __builtin_popcount(disagree(w, m[i + 2], p[i + 2]));
-      a3 += __builtin_popcount(disagree(w, m[i + 3], p[i + 3]));
+    for (int i = 0; i < kProbeRegs; ++i) {
+      const int k = i & 7;
+      if (MODE == 0) {
+        asm volatile("v_bitop3_b32 %0, %2, %3, %4 bitop3:0xe4\n\tv_bcnt_u32_b32 %1, %0, %1"
+                     : "=&v"(t[k]), "+v"(a[k]) : "v"(m[i]), "v"(p[i]), "s"(w));
+      } else if (MODE == 1) {
+        asm volatile("v_xor_b32 %0, %3, %2\n\tv_bcnt_u32_b32 %1, %0, %1"
+                     : "=&v"(t[k]), "+v"(a[k]) : "v"(p[i]), "s"(w));
+      } else if (MODE == 2) {
+        asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[k]) : "v"(p[i]));
+      } else if (MODE == 3) {
+        asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(t[k]) : "v"(m[i]), "v"(p[i]), "s"(w));
+      } else if (MODE == 4) {
+        asm volatile("v_xor_b32 %0, %2, %1" : "=v"(t[k]) : "v"(p[i]), "s"(w));
+      } else if (MODE == 5) {
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[k]) : "v"(p[i]), "v"(m[i]));
+      } else {
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(a[k]) : "v"(p[i]));
+      }
     }
     w = w * 1664525u + 1013904223u;
   }
-  sink[t] = (uint32_t)(a0 + a1 + a2 + a3);
+#endif
+  uint32_t r = w;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r += a[i] + t[i];
+  sink[tid] = r;
 }
 
-int launch_probe_int_alu(int iters, double* lane_ops_per_s, double* elapsed_ms, hipStream_t s) {
+template <int MODE>
+static void launch_mode(int blocks, int iters, uint32_t seed, uint32_t* sink, hipStream_t s) {
+  hipLaunchKernelGGL(probe_kernel<MODE>, dim3(blocks), dim3(256), 0, s, iters, seed, sink);
+}
+
+static void launch_any(int mode, int blocks, int iters, uint32_t seed, uint32_t* sink, hipStream_t s) {
+  switch (mode) {
+    case 0: launch_mode<0>(blocks, iters, seed, sink, s); break;
+    case 1: launch_mode<1>(blocks, iters, seed, sink, s); break;
+    case 2: launch_mode<2>(blocks, iters, seed, sink, s); break;
+    case 3: launch_mode<3>(blocks, iters, seed, sink, s); break;
+    case 4: launch_mode<4>(blocks, iters, seed, sink, s); break;
+    case 5: launch_mode<5>(blocks, iters, seed, sink, s); break;
+    default: launch_mode<6>(blocks, iters, seed, sink, s); break;
+  }
+}
+
+// ops per lane per loop step for each mode
+static int ops_per_step(int mode) { return (mode == 0 || mode == 1) ? 2 : 1; }
+
+int launch_probe_int_alu(int mode, int iters, double* lane_ops_per_s, double* elapsed_ms, hipStream_t s) {
+  if (mode < 0 || mode > 6) return BNN_HIP_ERR_INVALID_ARG;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return BNN_HIP_ERR_NO_DEVICE;
   hipDeviceProp_t prop;
@@ -44,9 +94,9 @@ int launch_probe_int_alu(int iters, double* lane_ops_per_s, double* elapsed_ms, 
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL(probe_int_alu_kernel, dim3(blocks), dim3(256), 0, s, 8, 1u, sink);  // warm-up
+  launch_any(mode, blocks, 8, 1u, sink, s);  // warm-up
   (void)hipEventRecord(e0, s);
-  hipLaunchKernelGGL(probe_int_alu_kernel, dim3(blocks), dim3(256), 0, s, iters, 12345u, sink);
+  launch_any(mode, blocks, iters, 12345u, sink, s);
   (void)hipEventRecord(e1, s);
   (void)hipEventSynchronize(e1);
   float ms = 0.f;
@@ -55,7 +105,7 @@ int launch_probe_int_alu(int iters, double* lane_ops_per_s, double* elapsed_ms, 
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   (void)hipFree(sink);
-  const double ops = 2.0 * kProbeRegs * (double)iters * (double)blocks * 256.0;
+  const double ops = (double)ops_per_step(mode) * kProbeRegs * (double)iters * (double)blocks * 256.0;
   *lane_ops_per_s = ops / (ms * 1e-3);
   if (elapsed_ms) *elapsed_ms = ms;
   return st;

@@ -30,12 +30,13 @@
  * Data formats
  *   Activations are ternary {-1,0,+1} because the reference's sign(0) == 0 and its
  *   zero padding is applied AFTER binarisation (bnn/layers/conv.py:91-92).  They are
- *   stored as two bit-planes, pixel-major ("NHWC of words"):
- *       P[n][y][x][cw64]  bit c%64 of word c/64 set  <=>  x[n][c][y][x] > 0
- *       M[n][y][x][cw64]  bit c%64 of word c/64 set  <=>  x[n][c][y][x] < 0
- *   with cw64 = ceil(C/64) uint64 words per pixel; pad bits are 0 in both planes.
+ *   stored as two bit-planes, channel-group planar ("N C/64 H W" of uint64 words):
+ *       P[n][g][y][x]  bit b set  <=>  x[n][64*g + b][y][x] > 0
+ *       M[n][g][y][x]  bit b set  <=>  x[n][64*g + b][y][x] < 0
+ *   with g < cw64 = ceil(C/64); pad bits are 0 in both planes.  (Consecutive pixels of one
+ *   group are contiguous, so a wavefront whose lanes are pixels reads 512 contiguous bytes
+ *   per load for any C; a pixel-major layout wastes 3/4 of every cache line at C = 512.)
  *   NaN -> neither plane (torch.sign(nan) == 0), denormals keep their sign.
- *   nzc[n][y][x] (uint16) = popcount(P|M) over the pixel = number of non-zero channels.
  *
  *   Weights are one bit-plane (+1 -> 1, -1 -> 0) plus a non-zero mask, in the
  *   kernel-facing layout  wbits[ob][chunk][j][tap][cwc]  (uint32 words) where
@@ -46,7 +47,7 @@
  *
  *   Integer dot product per output element (exact):
  *       D   = popcount( (W & M) | (~W & P) )       disagreeing non-zero positions
- *       dot = nzc_window - 2*D                      (= sum of sign(x)*sign(w))
+ *       dot = popcount(P | M) - 2*D                 (= sum of sign(x)*sign(w)), over the window
  *   and the float result  out = fmaf(alpha[o], (float)dot, bias[o]) [* post_scale[o]].
  */
 #ifndef BNN_HIP_H_
@@ -59,7 +60,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 1
+#define BNN_HIP_ABI_VERSION 2
 #define BNN_HIP_OCB 32 /* output channels per weight block (padding granularity of O) */
 
 typedef enum bnn_hip_status {
@@ -84,6 +85,33 @@ typedef struct bnn_hip_conv_desc {
 
 #define BNN_HIP_FLAG_FORCE_GENERIC 1 /* use the shape-generic kernel even if a tiled one exists */
 #define BNN_HIP_FLAG_WEIGHT_ZEROS 2  /* some sign(W) == 0: honour the wnz mask (slower kernel)  */
+#define BNN_HIP_FLAG_WEIGHTS_SGPR 4  /* tiled kernel: force the scalar-cache weight stream       */
+#define BNN_HIP_FLAG_WEIGHTS_LDS 8   /* tiled kernel: force the LDS-staged weight tile           */
+
+/* Everything that happens to the integer dot after the popcount loop, fused into the conv
+ * kernel so that activations can stay bit-packed between binary layers (callers:
+ * bnn/models/layers/res_block.py:40-56, conv -> BN -> ReLU -> conv -> BN -> +identity -> ReLU):
+ *     y = fmaf(alpha[o], dot, bias[o])                 XNOR scale + conv bias   (required)
+ *     y = y * post_scale[o]                            BasicScaleBinarizer      (optional)
+ *     y = fmaf(y, bn_scale[o], bn_shift[o])            eval-mode BatchNorm      (optional)
+ *     y = y + residual[n,o,y,x]                        shortcut                 (optional)
+ *     y = relu(y)  |  y = y >= 0 ? y : prelu[o]*y      activation               (optional)
+ * Outputs: out_f32 (fp32 NCHW) and/or out_P/out_M (sign(y) as bit planes, format above, with
+ * C := O; every word is written, pad bits 0).  At least one output is required. */
+typedef struct bnn_hip_epilogue {
+  const float* alpha;      /* [o_pad]                                   */
+  const float* bias;       /* [O] or NULL                               */
+  const float* post_scale; /* [O] or NULL                               */
+  const float* bn_scale;   /* [O] or NULL  gamma / sqrt(var + eps)      */
+  const float* bn_shift;   /* [O] or NULL  beta - mean * bn_scale       */
+  const float* residual;   /* [N,O,Ho,Wo] or NULL                       */
+  const float* prelu;      /* [O] or NULL                               */
+  int32_t relu;            /* non-zero: clamp at 0 after the residual   */
+  int32_t reserved;
+  float* out_f32;          /* [N,O,Ho,Wo] or NULL                       */
+  uint64_t* out_P;         /* [N,ceil(O/64),Ho,Wo] or NULL              */
+  uint64_t* out_M;
+} bnn_hip_epilogue;
 
 typedef struct bnn_hip_wlayout {
   int32_t cw32;     /* 32-bit words per pixel per plane (= 2*ceil(C/64))          */
@@ -122,10 +150,17 @@ int bnn_hip_act_words(int C);
 /* HOST: weight layout for a [O,C,KH,KW] weight.                                   */
 int bnn_hip_weight_layout(int O, int C, int KH, int KW, bnn_hip_wlayout* out);
 
-/* sign(x) as two bit planes.  x: float32 NCHW contiguous.  P, M: N*H*W*ceil(C/64)
- * uint64 each, 16-byte aligned.  nzc: N*H*W uint16 (C <= 65535).                  */
+/* sign(x) as two bit planes.  x: float32 NCHW contiguous.  P, M: [N,ceil(C/64),H,W]
+ * uint64 each, 16-byte aligned.                                                    */
 int bnn_hip_pack_act_f32(const float* x, int N, int C, int H, int W,
-                         uint64_t* P, uint64_t* M, uint16_t* nzc, void* stream);
+                         uint64_t* P, uint64_t* M, void* stream);
+
+/* AvgPool2d(kernel=k, stride=k, ceil_mode=True, count_include_pad=False) followed by
+ * sign(): the shortcut branch of a down-sampling residual stage
+ * (bnn/models/resnet.py:128-133: AvgPool2d -> binary conv1x1 -> BN).  Output planes have
+ * ceil(H/k) x ceil(W/k) pixels.                                                    */
+int bnn_hip_avgpool_pack_f32(const float* x, int N, int C, int H, int W, int k,
+                             uint64_t* P, uint64_t* M, void* stream);
 
 /* XNOR-Net weight binarisation.  w: float32 [O,C,KH,KW] contiguous.
  *   center        != 0: subtract the mean over C per (o,ky,kx) first  (ops.py:130-132)
@@ -143,22 +178,28 @@ int bnn_hip_pack_weight_f32(const float* w, int O, int C, int KH, int KW,
  *   out[n,o,y,x] = fmaf(alpha[o], dot, bias ? bias[o] : 0) * (post_scale ? post_scale[o] : 1)
  * wnz may be NULL unless BNN_HIP_FLAG_WEIGHT_ZEROS is set.                         */
 int bnn_hip_bconv2d(const bnn_hip_conv_desc* d,
-                    const uint64_t* P, const uint64_t* M, const uint16_t* nzc,
+                    const uint64_t* P, const uint64_t* M,
                     const uint32_t* wbits, const uint32_t* wnz,
                     const float* alpha, const float* bias, const float* post_scale,
                     float* out, void* stream);
 
+/* Binary convolution with the fused epilogue described at bnn_hip_epilogue.        */
+int bnn_hip_bconv2d_fused(const bnn_hip_conv_desc* d,
+                          const uint64_t* P, const uint64_t* M,
+                          const uint32_t* wbits, const uint32_t* wnz,
+                          const bnn_hip_epilogue* epi, void* stream);
+
 /* Same traversal, raw integer result: dot[n,o,y,x] (int32) — the bit-exact target
  * of the popcount path against the emulated-integer oracle.                        */
 int bnn_hip_bconv2d_dot(const bnn_hip_conv_desc* d,
-                        const uint64_t* P, const uint64_t* M, const uint16_t* nzc,
+                        const uint64_t* P, const uint64_t* M,
                         const uint32_t* wbits, const uint32_t* wnz,
                         int32_t* dot, void* stream);
 
 /* Binary fully-connected layer: x packed as [B][ceil(F/64)] planes (pack_act with
- * H=W=1), weight packed with KH=KW=1.  out: float32 [B,O].                         */
+ * H=W=1, i.e. [B][ceil(F/64)] words), weight packed with KH=KW=1.  out: float32 [B,O].                         */
 int bnn_hip_blinear(int B, int F, int O,
-                    const uint64_t* P, const uint64_t* M, const uint16_t* nzc,
+                    const uint64_t* P, const uint64_t* M,
                     const uint32_t* wbits, const uint32_t* wnz, int weight_zeros,
                     const float* alpha, const float* bias, const float* post_scale,
                     float* out, void* stream);
@@ -171,10 +212,13 @@ int bnn_hip_bconv2d_f32(const bnn_hip_conv_desc* d, const float* x,
                         const float* alpha, const float* bias, const float* post_scale,
                         float* out, void* workspace, void* stream);
 
-/* Roofline calibration: runs a register-only v_bitop3_b32 + v_bcnt_u32_b32 chain on
- * every CU and reports the sustained 32-bit lane-ops/s (two ops per loop step).
- * Synchronous (uses hipEvents on `stream`); not part of the inference path.        */
-int bnn_hip_probe_int_alu(int iters, double* lane_ops_per_s, double* elapsed_ms, void* stream);
+/* Roofline calibration: runs a register-only instruction stream on every CU at full
+ * occupancy and reports the sustained 32-bit lane-ops/s.  mode: 0 = v_bitop3_b32 +
+ * v_bcnt_u32_b32 (the hot loop's pair), 1 = v_xor_b32 + v_bcnt_u32_b32, 2 = bcnt only,
+ * 3 = bitop3 only, 4 = xor only, 5 = v_fma_f32 only, 6 = v_add_u32 only.
+ * Synchronous (hipEvents on `stream`, temporary hipMalloc); not part of the inference path. */
+int bnn_hip_probe_int_alu(int mode, int iters, double* lane_ops_per_s, double* elapsed_ms,
+                          void* stream);
 
 #ifdef __cplusplus
 }

@@ -153,23 +153,19 @@ void orc_binary_conv2d_float(const orc_geom* g, const float* x, const float* w, 
 /* ------------------------------------------------------------------------------------ */
 /* Route I, step 1: activation bit planes (format of include/bnn_hip.h).                  */
 /* ------------------------------------------------------------------------------------ */
-void orc_pack_act(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
-                  uint16_t* nzc) {
+void orc_pack_act(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M) {
   const int cw64 = (C + 63) / 64;
   const size_t HW = (size_t)H * W;
   memset(P, 0, sizeof(uint64_t) * (size_t)N * HW * cw64);
   memset(M, 0, sizeof(uint64_t) * (size_t)N * HW * cw64);
   for (int n = 0; n < N; ++n)
     for (size_t r = 0; r < HW; ++r) {
-      const size_t pix = (size_t)n * HW + r;
-      int cnt = 0;
-      for (int c = 0; c < C; ++c) {
+      for (int c = 0; c < C; ++c) { /* planes are [n][c/64][y][x] */
         const int s = sgn(x[((size_t)n * C + c) * HW + r]);
-        if (s > 0) P[pix * cw64 + c / 64] |= (uint64_t)1 << (c % 64);
-        if (s < 0) M[pix * cw64 + c / 64] |= (uint64_t)1 << (c % 64);
-        cnt += (s != 0);
+        const size_t w = ((size_t)n * cw64 + c / 64) * HW + r;
+        if (s > 0) P[w] |= (uint64_t)1 << (c % 64);
+        if (s < 0) M[w] |= (uint64_t)1 << (c % 64);
       }
-      nzc[pix] = (uint16_t)cnt;
     }
 }
 
@@ -250,9 +246,10 @@ void orc_bconv_dot(const orc_geom* g, const uint64_t* P, const uint64_t* M, cons
             const int iy = oy * g->sh - g->ph + ky * g->dh;
             const int ix = ox * g->sw - g->pw + kx * g->dw;
             if (iy < 0 || iy >= g->H || ix < 0 || ix >= g->W) continue;
-            const size_t pix = ((size_t)n * g->H + iy) * g->W + ix;
+            const size_t pix = (size_t)iy * g->W + ix;
             for (int word = 0; word < cw32; ++word) {
-              const uint32_t p = P32[pix * cw32 + word], m = M32[pix * cw32 + word];
+              const size_t aw = ((((size_t)n * (cw32 / 2) + word / 2) * g->H * g->W + pix) * 2) + word % 2;
+              const uint32_t p = P32[aw], m = M32[aw];
               const int ch = word / cwc, cw = word % cwc;
               const size_t idx = (((size_t)ob * nchunk + ch) * OCB + j) * ((size_t)taps * cwc) +
                                  (size_t)t * cwc + cw;
@@ -291,6 +288,48 @@ void orc_ternary_dot(const orc_geom* g, const float* x, const float* wsign, int3
             }
           dot[(((size_t)n * g->O + o) * Ho + oy) * Wo + ox] = acc;
         }
+}
+
+/* Fused epilogue of the HIP conv kernel (csrc/bconv.hip epilogue(), include/bnn_hip.h
+ * bnn_hip_epilogue), restated op for op so the result is bit-identical:
+ *   y = fmaf(alpha, dot, bias) ; y *= scale ; y = fmaf(y, bn_a, bn_b) ; y += res ;
+ *   relu: y = y < 0 ? 0 : y ; prelu: y = y >= 0 ? y : slope*y
+ * It stands for the caller-side sequence conv -> BN(eval) -> (+identity) -> ReLU of
+ * bnn/models/layers/res_block.py:40-56 with BN folded to one multiply-add per channel.    */
+void orc_fused_epilogue(const int32_t* dot, int N, int O, int HoWo, const float* alpha,
+                        const float* bias, const float* post_scale, const float* bn_a,
+                        const float* bn_b, const float* res, const float* prelu, int relu,
+                        float* out) {
+  for (int n = 0; n < N; ++n)
+    for (int o = 0; o < O; ++o)
+      for (int i = 0; i < HoWo; ++i) {
+        const size_t idx = ((size_t)n * O + o) * HoWo + i;
+        float y = fmaf(alpha[o], (float)dot[idx], bias ? bias[o] : 0.0f);
+        if (post_scale) y *= post_scale[o];
+        if (bn_a) y = fmaf(y, bn_a[o], bn_b[o]);
+        if (res) y += res[idx];
+        if (relu) y = (y < 0.0f) ? 0.0f : y;
+        if (prelu) y = (y >= 0.0f) ? y : prelu[o] * y;
+        out[idx] = y;
+      }
+}
+
+/* AvgPool2d(k, stride k, ceil_mode=True, count_include_pad=False) as used by the shortcut of
+ * bnn/models/resnet.py:128-133; sums taps in (dy, dx) order in float like the HIP kernel.   */
+void orc_avgpool_ceil(const float* x, int N, int C, int H, int W, int k, float* out) {
+  const int Ho = (H + k - 1) / k, Wo = (W + k - 1) / k;
+  for (int nc = 0; nc < N * C; ++nc)
+    for (int oy = 0; oy < Ho; ++oy)
+      for (int ox = 0; ox < Wo; ++ox) {
+        float s = 0.0f;
+        int cnt = 0;
+        for (int dy = 0; dy < k && oy * k + dy < H; ++dy)
+          for (int dx = 0; dx < k && ox * k + dx < W; ++dx) {
+            s += x[((size_t)nc * H + oy * k + dy) * W + ox * k + dx];
+            ++cnt;
+          }
+        out[((size_t)nc * Ho + oy) * Wo + ox] = s / (float)cnt;
+      }
 }
 
 /* Route I, step 4: float epilogue, identical formula to csrc/bconv.hip store_result():

@@ -45,7 +45,9 @@ def normal(seed: int, shape) -> np.ndarray:
         for k in range(4):
             h = _splitmix64(base + np.uint64(k))
             acc += (h >> np.uint64(40)).astype(np.float64) / float(1 << 24)
-    return ((acc - 2.0) * np.sqrt(3.0)).astype(np.float32).reshape(shape)
+    # + 2^-25: half a grid step, so that no value is exactly 0.0 (zeros are injected explicitly
+    # by the "sparse"/"relu"/"withzeros" kinds, never by accident)
+    return ((acc - 2.0 + 2.0 ** -25) * np.sqrt(3.0)).astype(np.float32).reshape(shape)
 
 
 def activation(kind: str, seed: int, shape) -> np.ndarray:

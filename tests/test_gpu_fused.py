@@ -1,0 +1,117 @@
+"""GPU parity of the fused pieces (epilogue, avgpool+pack, weight-source variants): bit-exact
+against the CPU oracle's op-for-op restatement, through the C-ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from bnn_amd import hipops
+from tests.golden import gen
+from tests.golden.cases import LAYER_CASES, LAYER_CASES_BY_NAME
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def u64(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+TILED = [c for c in LAYER_CASES if c.k in (1, 3) and c.dilation == 1 and c.winit != "withzeros"]
+
+
+@pytest.mark.parametrize("weights", ["sgpr", "lds"])
+@pytest.mark.parametrize("case", TILED, ids=lambda c: c.name)
+def test_weight_source_variants_bit_exact(case, weights):
+    """Scalar-cache weight stream and LDS-staged weight tile compute the same integers."""
+    x, w, b, sc = case.tensors()
+    act = hipops.pack_act(dev(x))
+    pw = hipops.pack_weight(dev(w), case.center, case.compute_alpha)
+    dot = hipops.bconv2d(act, pw, stride=case.stride, padding=case.pad, raw_dot=True,
+                         weights=weights).cpu().numpy()
+    _, ref_dot = oracle.binary_conv2d_int(x, w, None, None, case.stride, case.pad, case.dilation,
+                                          case.center, case.compute_alpha)
+    assert np.array_equal(dot, ref_dot)
+
+
+EPI_CASES = [
+    # name of layer case, dict of epilogue switches
+    ("c2_relu", dict(bn=True, relu=True, res=False, prelu=False)),
+    ("c2_relu", dict(bn=True, relu=True, res=True, prelu=False)),
+    ("l4_512x7", dict(bn=True, relu=True, res=True, prelu=False)),
+    ("l2_0_c1_s2", dict(bn=True, relu=True, res=False, prelu=False)),
+    ("l3_ds_1x1", dict(bn=True, relu=False, res=False, prelu=False)),
+    ("tail_c96", dict(bn=True, relu=False, res=True, prelu=True)),       # O=40: ragged channel block
+    ("tail_c200_o5", dict(bn=False, relu=True, res=True, prelu=False)),  # O=5
+    ("center_bias_scale", dict(bn=True, relu=True, res=True, prelu=False)),
+    ("k5_generic", dict(bn=True, relu=True, res=True, prelu=False)),     # generic kernel epilogue
+    ("special_vals", dict(bn=True, relu=False, res=False, prelu=True)),
+]
+
+
+@pytest.mark.parametrize("name,sw", EPI_CASES, ids=[f"{n}-{i}" for i, (n, _) in enumerate(EPI_CASES)])
+def test_fused_epilogue_bit_exact(name, sw):
+    case = LAYER_CASES_BY_NAME[name]
+    x, w, b, sc = case.tensors()
+    act = hipops.pack_act(dev(x))
+    pw = hipops.pack_weight(dev(w), case.center, case.compute_alpha)
+    _, dot = oracle.binary_conv2d_int(x, w, None, None, case.stride, case.pad, case.dilation,
+                                      case.center, case.compute_alpha)
+    O = case.O
+    s = gen.seed_of("epi", name)
+    bn_a = (0.5 + gen.uniform(s, (O,))).astype(np.float32) if sw["bn"] else None
+    bn_b = (0.3 * gen.normal(s + 1, (O,))).astype(np.float32) if sw["bn"] else None
+    res = gen.normal(s + 2, dot.shape) if sw["res"] else None
+    pre = (0.25 * gen.uniform(s + 3, (O,))).astype(np.float32) if sw["prelu"] else None
+    alpha = pw.alpha.cpu().numpy()[:O]
+    ref = oracle.fused_epilogue(dot, alpha, b, sc, bn_a, bn_b, res, pre, sw["relu"])
+    opt = lambda a: None if a is None else dev(a)  # noqa: E731
+    y, pk = hipops.bconv2d_fused(act, pw, bias=opt(b), post_scale=opt(sc), bn_scale=opt(bn_a),
+                                 bn_shift=opt(bn_b), residual=opt(res), prelu=opt(pre),
+                                 relu=sw["relu"], out_f32=True, out_packed=True,
+                                 stride=case.stride, padding=case.pad, dilation=case.dilation)
+    assert np.array_equal(y.cpu().numpy(), ref)
+    P, M = oracle.pack_act(ref)                       # sign(y) re-packed for the next layer
+    assert np.array_equal(u64(pk.P), P) and np.array_equal(u64(pk.M), M)
+    # packed-only output (no fp32 store) produces the same planes
+    _, pk2 = hipops.bconv2d_fused(act, pw, bias=opt(b), post_scale=opt(sc), bn_scale=opt(bn_a),
+                                  bn_shift=opt(bn_b), residual=opt(res), prelu=opt(pre),
+                                  relu=sw["relu"], out_f32=False, out_packed=True,
+                                  stride=case.stride, padding=case.pad, dilation=case.dilation)
+    assert torch.equal(pk2.P, pk.P) and torch.equal(pk2.M, pk.M)
+
+
+def test_two_fused_layers_equal_unfused_chain():
+    """conv -> BN -> ReLU -> (packed) -> conv: packed hand-over == fp32 round trip."""
+    c1, c2 = LAYER_CASES_BY_NAME["l2_128x28"], LAYER_CASES_BY_NAME["c2_relu"]
+    x, w1, _, _ = c1.tensors()
+    _, w2, _, _ = c2.tensors()
+    pw1, pw2 = hipops.pack_weight(dev(w1)), hipops.pack_weight(dev(w2))
+    bn_a = dev((0.5 + gen.uniform(5, (128,))).astype(np.float32))
+    bn_b = dev((0.3 * gen.normal(6, (128,))).astype(np.float32))
+    act = hipops.pack_act(dev(x))
+    y, pk = hipops.bconv2d_fused(act, pw1, bn_scale=bn_a, bn_shift=bn_b, relu=True, out_f32=True,
+                                 out_packed=True, stride=1, padding=1)
+    a = hipops.bconv2d(pk, pw2, stride=1, padding=1)
+    b = hipops.bconv2d(hipops.pack_act(y), pw2, stride=1, padding=1)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape,k", [((2, 64, 56, 56), 2), ((3, 128, 7, 7), 2), ((2, 70, 9, 5), 2),
+                                     ((1, 256, 14, 14), 2), ((2, 32, 6, 6), 3)])
+def test_avgpool_pack_matches_torch_pool_then_sign(shape, k):
+    x = gen.activation("relu", gen.seed_of("ap", shape), shape)
+    x[0, 0] = -x[0, 0]  # some negative windows too
+    pk = hipops.avgpool_pack(dev(x), k)
+    pooled = oracle.avgpool_ceil(x, k)
+    t = F.avg_pool2d(torch.from_numpy(x), k, k, ceil_mode=True, count_include_pad=False).numpy()
+    assert np.allclose(pooled, t, rtol=1e-6, atol=1e-7)     # the oracle restates the reference op
+    P, M = oracle.pack_act(pooled)
+    assert np.array_equal(u64(pk.P), P) and np.array_equal(u64(pk.M), M)
+    P2, M2 = oracle.pack_act(t)                              # and sign(torch's pool) is identical
+    assert np.array_equal(P, P2) and np.array_equal(M, M2)

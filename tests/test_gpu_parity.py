@@ -50,9 +50,8 @@ def u64(t):
 def test_pack_act_bit_exact(shape, kind):
     x = gen.activation(kind, gen.seed_of("pack", shape, kind), shape)
     act = hipops.pack_act(dev(x))
-    P, M, nzc = oracle.pack_act(x)
+    P, M = oracle.pack_act(x)
     assert np.array_equal(u64(act.P), P) and np.array_equal(u64(act.M), M)
-    assert np.array_equal(act.nzc.cpu().numpy().view(np.uint16), nzc)
 
 
 def test_pack_act_sign_semantics_on_device():
@@ -106,7 +105,7 @@ def test_linear_through_c_abi(case, golden_layers):
     st = None if sc is None else dev(sc)
     lib = native.require()
     native.check(lib.bnn_hip_blinear(case.B, case.F, case.O, act.P.data_ptr(), act.M.data_ptr(),
-                                     act.nzc.data_ptr(), pw.wbits.data_ptr(), pw.wnz.data_ptr(),
+                                     pw.wbits.data_ptr(), pw.wnz.data_ptr(),
                                      int(pw.has_zero), pw.alpha.data_ptr(),
                                      None if bt is None else bt.data_ptr(),
                                      None if st is None else st.data_ptr(), out.data_ptr(),
@@ -297,11 +296,11 @@ def test_c2_full_size_properties(c2_full):
     # determinism: integer kernel -> run-to-run bit-exact
     assert torch.equal(out, hipops.bconv2d(act, pw, stride=1, padding=1))
     # tiled kernel == shape-generic kernel on a batch slice
-    sl = hipops.PackedAct(act.P[:32], act.M[:32], act.nzc[:32], (32,) + act.shape[1:])
+    sl = act.batch_slice(0, 32)
     assert torch.equal(out[:32], hipops.bconv2d(sl, pw, stride=1, padding=1, force_generic=True))
     # images are independent units: a batch of one gives the same image
     for n in (0, 100, 255):
-        one = hipops.PackedAct(act.P[n:n + 1], act.M[n:n + 1], act.nzc[n:n + 1], (1,) + act.shape[1:])
+        one = act.batch_slice(n, n + 1)
         assert torch.equal(out[n:n + 1], hipops.bconv2d(one, pw, stride=1, padding=1))
     # antisymmetry: negating the weights (or the input) negates every output exactly
     assert torch.equal(hipops.bconv2d(act, hipops.pack_weight(-w), stride=1, padding=1), -out)

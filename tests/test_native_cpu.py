@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert os.path.exists(native.lib_path()), "build with __graft_entry__.build() first"
     lib = ctypes.CDLL(native.lib_path())
     syms = header_symbols()
-    assert len(syms) >= 14
+    assert len(syms) >= 16
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/bnn_hip.h but not exported"
     assert set(native.EXPORTED_SYMBOLS) == set(syms)
@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_require_loads_and_reports_abi():
     lib = native.require()
-    assert lib.bnn_hip_abi_version() == 1
+    assert lib.bnn_hip_abi_version() == native.ABI_VERSION == 2
     assert lib.bnn_hip_status_string(0) == b"ok"
     assert b"invalid" in lib.bnn_hip_status_string(-1)
     assert isinstance(native.launch_count(), int)
@@ -55,12 +55,14 @@ def test_argument_validation_without_touching_the_gpu():
     lib = native.require()
     d = native.ConvDesc(1, 64, 8, 8, 32, 3, 3, 1, 1, 1, 1, 1, 1, 0)
     # null pointers are rejected before any launch
-    assert lib.bnn_hip_bconv2d(ctypes.byref(d), None, None, None, None, None, None, None, None, None, None) == -1
-    assert lib.bnn_hip_pack_act_f32(None, 1, 1, 1, 1, None, None, None, None) == -1
+    assert lib.bnn_hip_bconv2d(ctypes.byref(d), None, None, None, None, None, None, None, None, None) == -1
+    assert lib.bnn_hip_bconv2d_fused(ctypes.byref(d), 16, 16, 16, 16, None, None) == -1
+    assert lib.bnn_hip_pack_act_f32(None, 1, 1, 1, 1, None, None, None) == -1
+    assert lib.bnn_hip_avgpool_pack_f32(None, 1, 1, 1, 1, 2, None, None, None) == -1
     assert lib.bnn_hip_pack_weight_f32(None, 1, 1, 1, 1, 0, 1, None, None, None, None, None) == -1
-    assert lib.bnn_hip_conv_workspace_bytes(ctypes.byref(d)) >= 2 * 64 * 8 + 128
+    assert lib.bnn_hip_conv_workspace_bytes(ctypes.byref(d)) >= 2 * 64 * 8
     d.N = 0
-    assert lib.bnn_hip_bconv2d(ctypes.byref(d), 16, 16, 16, 16, 16, 16, None, None, 16, None) == -1
+    assert lib.bnn_hip_bconv2d(ctypes.byref(d), 16, 16, 16, 16, 16, None, None, 16, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Build differently-configured libraries (in the container):   bash tools/conv_variants.sh build
+# ... and time them on the GPU box:     gpurun -- 'bash tools/conv_variants.sh run'
+set -u
+R="$(cd "$(dirname "$0")/.." && pwd)"
+V="$R/binary-networks-pytorch_amd/bnn_amd/_lib/variants"
+declare -A CFG=(
+  [w1]="-DBNN_TILED_MIN_WAVES=1"
+  [w4]="-DBNN_TILED_MIN_WAVES=4"
+)
+if [ "${1:-build}" = "build" ]; then
+  rm -rf "$V"; mkdir -p "$V"
+  for k in "${!CFG[@]}"; do
+    ( make -s -C "$R/binary-networks-pytorch_amd/csrc" OUTDIR="$V/$k" EXTRA="${CFG[$k]}" 2>&1 | grep -E "error" ) &
+  done
+  wait
+  ls "$V"/*/
+else
+  for k in "${!CFG[@]}"; do
+    echo "=== $k (${CFG[$k]})"
+    BNN_AMD_LIB="$V/$k/libbnn_hip.so" ONLY="${ONLY:-}" timeout 300 python "$R/tools/bench_conv.py" 2>&1 | grep -v amdgpu.ids
+  done
+fi

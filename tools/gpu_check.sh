@@ -17,7 +17,7 @@ echo "== pytest -m gpu"; timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | 
 echo "== bench"; timeout 600 python bench.py --steps 10 --warmup 3 2>&1 | tail -3 | tee "$OUT/bench.json"
 echo "== rocprof"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o r01 -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/prof_run.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o r01 -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/prof_run.log" 2>&1
 ls -R "$OUT/prof" | head -20
 f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && head -25 "$f"
+[ -n "$f" ] && head -40 "$f" | cut -c1-200
