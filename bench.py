@@ -32,6 +32,7 @@ import torch.nn as nn  # noqa: E402
 
 import bnn_amd as bnn  # noqa: E402
 from bnn_amd import fastpath, hipops, native  # noqa: E402
+from bnn_amd.inference import FusedResNet  # noqa: E402
 from bnn_amd.models import resnet18  # noqa: E402
 from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer  # noqa: E402
 from bnn_amd.parallel import ShardedInference  # noqa: E402
@@ -59,7 +60,17 @@ def build_model(device):
 
 
 def int_alu_peak(info) -> float:
-    """gfx950 CU = 4 SIMD x 32 lanes, one 32-bit VALU lane-op per lane per clock."""
+    """Roofline denominator of BASELINE.md §4: CUs x 64 lanes x f_clk 32-bit lane-ops/s.
+
+    This is also the measured issue limit of the two instructions the path is made of: on gfx950
+    v_bitop3_b32 / v_xor_b32 and v_bcnt_u32_b32 each issue once per 4 cycles per wave64
+    (bench field ``int_alu_probe_Tlane_ops``: the register-only pair sustains 39.2 T at 2.4 GHz),
+    unlike v_add_u32 / v_fma_f32 which run at the SIMD-32 rate of one per 2 cycles."""
+    return info["compute_units"] * 64 * info["clock_khz"] * 1e3
+
+
+def simd32_peak(info) -> float:
+    """Full-rate VALU bound (4 SIMD x 32 lanes): what a 2-cycle op such as v_add_u32 reaches."""
     return info["compute_units"] * 4 * 32 * info["clock_khz"] * 1e3
 
 
@@ -95,7 +106,7 @@ def conv_c2_roofline(device, info, batch=256, iters=20, act_kind="relu"):
     out_bytes = N * O * H * W * 4
     del out
     return {
-        "bound": "int_alu", "kernel": "bconv_tiled_kernel<3,3,4>", "workload": "conv3x3 128->128 56x56 b256",
+        "bound": "int_alu", "kernel": "bconv_sgpr_kernel<3,3,4>", "workload": "conv3x3 128->128 56x56 b256",
         "achieved": lane_ops / t_conv / 1e12, "peak": peak / 1e12, "unit": "Tlane-op/s",
         "frac": lane_ops / t_conv / peak, "traffic": None,
         "avg_kernel_us": t_conv * 1e6, "images_per_s_kernel": N / t_conv,
@@ -103,7 +114,9 @@ def conv_c2_roofline(device, info, batch=256, iters=20, act_kind="relu"):
         "hbm": {"conv_GBps": (in_bytes + out_bytes) / t_conv / 1e9,
                 "pack_us": t_pack * 1e6, "pack_GBps": (N * C * H * W * 4 + in_bytes) / t_pack / 1e9,
                 "peak_GBps": 8000.0},
-        "peak_basis": f"{info['compute_units']} CU x 4 SIMD x 32 lanes x {info['clock_khz'] / 1e6:.2f} GHz",
+        "peak_basis": f"{info['compute_units']} CU x 64 lanes x {info['clock_khz'] / 1e6:.2f} GHz "
+                      "(BASELINE.md §4; = issue rate of v_bitop3/v_bcnt, 4 cycles per wave64)",
+        "frac_of_simd32_peak": lane_ops / t_conv / simd32_peak(info),
         "act": act_kind,
     }
 
@@ -132,6 +145,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--engine", choices=("graph", "fused", "layerwise"), default="graph",
+                    help="graph: fused executor replayed as a HIP graph (default); fused: same, eager "
+                         "launches; layerwise: the drop-in per-layer path (pack -> conv -> torch BN/ReLU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -150,10 +166,17 @@ def main():
 
     native.require()
     info = native.device_info(local_rank)
-    model = ShardedInference(build_model(device))
+    net = build_model(device)
     B = args.batch
     x = torch.from_numpy(gen.normal(100 + rank, (8, 3, 224, 224))).to(device).repeat(B // 8, 1, 1, 1)
     x = x + 0.01 * torch.arange(B, device=device, dtype=torch.float32).view(B, 1, 1, 1)  # distinct images
+    if args.engine == "layerwise":
+        engine = net
+    else:
+        engine = FusedResNet(net)
+        if args.engine == "graph":
+            engine.capture(x)
+    model = ShardedInference(engine)
 
     def barrier():
         if world > 1:
@@ -190,6 +213,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "binary ResNet-18 (bnn.models resnet18, XNOR recipe of examples/cifar10.py, "
                                    "conv1+fc real-valued) 224x224 full forward, batch 256 per GPU",
+                       "engine": args.engine,
                        "global_batch": world * B, "parallelism": f"dp{world} (batch shards, RCCL all-gather of logits)",
                        "hip_kernel_launches_per_step": hip_launches // max(args.steps + args.warmup, 1)},
             "device": {k: info[k] for k in ("name", "arch", "compute_units", "clock_khz")},

@@ -106,6 +106,26 @@ def avgpool_pack(x: torch.Tensor, k: int) -> PackedAct:
     return a
 
 
+def bn_relu_maxpool_pack(x: torch.Tensor, bn_scale=None, bn_shift=None, relu: bool = True, k: int = 3,
+                         stride: int = 2, pad: int = 1, out_f32: bool = True, out_packed: bool = True):
+    """Stem tail in one pass: folded BN -> MaxPool2d(k, stride, pad) -> ReLU, written as fp32
+    and/or sign planes (bnn/models/resnet.py:150-153 + the first binary conv's binarizer)."""
+    x = _require_cuda_f32(x, "activation")
+    lib = native.require()
+    N, C, H, W = x.shape
+    ho, wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    bn_scale = _per_channel(bn_scale, C, "bn_scale")
+    bn_shift = _per_channel(bn_shift, C, "bn_shift")
+    with torch.cuda.device(x.device):
+        y = torch.empty((N, C, ho, wo), dtype=torch.float32, device=x.device) if out_f32 else None
+        pk = empty_packed(N, C, ho, wo, x.device) if out_packed else None
+        native.check(lib.bnn_hip_bn_relu_maxpool_pack_f32(
+            x.data_ptr(), N, C, H, W, _ptr(bn_scale), _ptr(bn_shift), int(bool(relu)), k, stride, pad,
+            _ptr(y), None if pk is None else pk.P.data_ptr(), None if pk is None else pk.M.data_ptr(),
+            _stream(x.device)), "bnn_hip_bn_relu_maxpool_pack_f32")
+    return y, pk
+
+
 def pack_weight(w: torch.Tensor, center: bool = False, compute_alpha: bool = True) -> PackedWeight:
     """``XNORWeightBinarizer`` on device (bnn/ops.py:116-140).  Synchronises once to read the
     zero-weight flag — call it when the weight changes, not per forward."""

@@ -1,0 +1,192 @@
+"""Fused inference executor for binary ResNets.
+
+The drop-in path (``prepare_binary_model`` + ``model(x)``) evaluates every binary conv as
+pack -> XNOR/popcount -> fp32 NCHW and leaves BatchNorm / ReLU / residual adds to torch: each of
+those is a full fp32 round trip through HBM.  For the block structure of the reference's ResNets
+(``bnn/models/layers/res_block.py:40-56``: conv-BN-ReLU-conv-BN-(+identity)-ReLU) all of that
+folds into the conv kernel's epilogue (``bnn_hip_epilogue``), so activations travel between
+binary layers as bit planes and only the residual stream is ever written in fp32:
+
+    conv1 -> BN1 -> ReLU            -> packed only                (no fp32 tensor at all)
+    conv2 -> BN2 -> +identity -> ReLU -> fp32 (next identity) + packed (next conv1 input)
+    shortcut: AvgPool(ceil) -> sign  fused into one kernel; 1x1 binary conv -> BN -> fp32
+
+``FusedResNet`` shares the weights of the model it wraps; packed weights and folded BN constants
+are derived once (call ``refresh()`` after changing parameters).  Eval mode only.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import fastpath, hipops, native
+from .layers import Conv2d as BinaryConv2d
+from .models.blocks import BasicBlock
+from .models.resnet import ResNet
+
+
+class FusionError(RuntimeError):
+    """The model (or a layer's recipe) is outside what the fused executor covers."""
+
+
+def fold_bn(bn: nn.BatchNorm2d):
+    """Eval-mode BatchNorm as one multiply-add per channel: y = x*scale + shift."""
+    if not isinstance(bn, nn.BatchNorm2d) or bn.running_mean is None:
+        raise FusionError(f"cannot fold {type(bn).__name__} (needs BatchNorm2d with running stats)")
+    var = bn.running_var.detach().double()
+    mean = bn.running_mean.detach().double()
+    gamma = bn.weight.detach().double() if bn.weight is not None else torch.ones_like(var)
+    beta = bn.bias.detach().double() if bn.bias is not None else torch.zeros_like(var)
+    scale = gamma / torch.sqrt(var + bn.eps)
+    shift = beta - mean * scale
+    return scale.float().contiguous(), shift.float().contiguous()
+
+
+@dataclass
+class _Conv:
+    layer: BinaryConv2d
+    plan: fastpath.Plan
+    weight: hipops.PackedWeight
+    bn_scale: torch.Tensor
+    bn_shift: torch.Tensor
+    relu: bool
+    prelu: Optional[torch.Tensor]
+
+    def run(self, act: hipops.PackedAct, *, residual=None, out_f32: bool, out_packed: bool):
+        lay = self.layer
+        return hipops.bconv2d_fused(
+            act, self.weight, bias=lay.bias, post_scale=self.plan.scale, bn_scale=self.bn_scale,
+            bn_shift=self.bn_shift, residual=residual, prelu=self.prelu, relu=self.relu,
+            out_f32=out_f32, out_packed=out_packed, stride=lay.stride, padding=lay.padding,
+            dilation=lay.dilation)
+
+
+def _plan_of(conv: nn.Module) -> fastpath.Plan:
+    if not isinstance(conv, BinaryConv2d):
+        raise FusionError(f"{type(conv).__name__} is not a binary Conv2d (run prepare_binary_model first)")
+    plan = fastpath._recognise(conv, conv.out_channels)
+    if plan is None or not fastpath._numeric_padding(conv):
+        raise FusionError("layer recipe is not BasicInputBinarizer + XNORWeightBinarizer "
+                          "(+ Identity | BasicScaleBinarizer)")
+    return plan
+
+
+def _activation(act: nn.Module):
+    if isinstance(act, nn.ReLU):
+        return True, None
+    if isinstance(act, nn.PReLU):
+        return False, act.weight.detach().float().contiguous()
+    raise FusionError(f"unsupported activation {type(act).__name__}")
+
+
+class FusedResNet(nn.Module):
+    """Inference executor for ``bnn_amd.models.ResNet`` built from ``BasicBlock`` (ResNet-18/34)."""
+
+    def __init__(self, model: ResNet) -> None:
+        super().__init__()
+        if not isinstance(model, ResNet) or model.stem_type != "basic":
+            raise FusionError("FusedResNet covers bnn_amd.models.ResNet with the 'basic' stem")
+        self.model = model
+        self._blocks: List[dict] = []
+        self._graph = None
+        self.refresh()
+
+    def _conv(self, conv, bn, act) -> _Conv:
+        plan = _plan_of(conv)
+        relu, prelu = (False, None) if act is None else _activation(act)
+        if prelu is not None and prelu.numel() != conv.out_channels:
+            prelu = prelu.expand(conv.out_channels).contiguous()
+        scale, shift = fold_bn(bn)
+        return _Conv(conv, plan, fastpath.packed_weight(conv, plan), scale, shift, relu, prelu)
+
+    def refresh(self) -> None:
+        """(Re)derive packed weights and folded BN constants from the wrapped model."""
+        native.require()
+        m = self.model
+        if m.training:
+            raise FusionError("FusedResNet is inference-only: call model.eval() first")
+        dev = m.fc.weight.device
+        if dev.type != "cuda":
+            raise FusionError("FusedResNet needs the model on a HIP device")
+        self._blocks = []
+        self._stem = None
+        mp = m.maxpool
+        if isinstance(mp, nn.MaxPool2d) and isinstance(m.bn1, nn.BatchNorm2d) and mp.dilation in (1, (1, 1)) \
+                and not mp.ceil_mode and isinstance(mp.kernel_size, int) and isinstance(mp.stride, int) \
+                and isinstance(mp.padding, int):
+            self._stem = (*fold_bn(m.bn1), (mp.kernel_size, mp.stride, mp.padding))
+        for stage in (m.layer1, m.layer2, m.layer3, m.layer4):
+            for blk in stage:
+                if not isinstance(blk, BasicBlock):
+                    raise FusionError(f"unsupported block {type(blk).__name__}")
+                entry = {"c1": self._conv(blk.conv1, blk.bn1, blk.act1),
+                         "c2": self._conv(blk.conv2, blk.bn2, blk.act2), "ds": None, "pool": 0}
+                if blk.downsample is not None:
+                    pool, conv, bn = blk.downsample[0], blk.downsample[1], blk.downsample[2]
+                    k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
+                    if not (isinstance(pool, nn.AvgPool2d) and pool.ceil_mode and not pool.count_include_pad
+                            and pool.padding in (0, (0, 0))):
+                        raise FusionError("shortcut pooling must be AvgPool2d(k, k, ceil_mode=True, "
+                                          "count_include_pad=False)")
+                    entry["ds"] = self._conv(conv, bn, None)
+                    entry["pool"] = k
+                self._blocks.append(entry)
+        self._graph = None
+
+    @torch.no_grad()
+    def _forward_impl(self, x: torch.Tensor) -> torch.Tensor:
+        m = self.model
+        # real-valued stem (first layer stays float: examples/cifar10.py:71): the conv runs in the
+        # vendor library (MFMA), its BN -> ReLU -> MaxPool -> sign tail in one HBM pass
+        t = m.conv1(x)
+        if self._stem is not None:
+            t, packed = hipops.bn_relu_maxpool_pack(t, self._stem[0], self._stem[1], True, *self._stem[2])
+        else:
+            t = m.maxpool(m.relu(m.bn1(t)))
+            packed = hipops.pack_act(t)
+        last = len(self._blocks) - 1
+        for i, b in enumerate(self._blocks):
+            if b["ds"] is not None:
+                sc_in = hipops.avgpool_pack(t, b["pool"]) if b["pool"] > 1 else packed
+                idn, _ = b["ds"].run(sc_in, out_f32=True, out_packed=False)
+            else:
+                idn = t
+            _, p1 = b["c1"].run(packed, out_f32=False, out_packed=True)
+            t, packed = b["c2"].run(p1, residual=idn, out_f32=True, out_packed=i != last)
+        # real-valued head (last layer stays float)
+        return m.fc(torch.flatten(m.avgpool(t), 1))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._graph is not None and x.shape == self._gx.shape:
+            self._gx.copy_(x, non_blocking=True)
+            self._graph.replay()
+            return self._gy
+        return self._forward_impl(x)
+
+    def capture(self, example: torch.Tensor) -> "FusedResNet":
+        """Record the whole forward (for this input shape) into a HIP graph; later calls with the
+        same shape replay it — no per-kernel launch cost on the host."""
+        self._graph = None
+        self._gx = example.clone()
+        side = torch.cuda.Stream(device=example.device)
+        side.wait_stream(torch.cuda.current_stream(example.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._forward_impl(self._gx)
+        torch.cuda.current_stream(example.device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._gy = self._forward_impl(self._gx)
+        self._graph = g
+        return self
+
+
+def optimize_for_inference(model: nn.Module) -> nn.Module:
+    """Return the fused executor for ``model`` when it is covered, else ``model`` unchanged."""
+    try:
+        return FusedResNet(model)
+    except FusionError:
+        return model

@@ -209,6 +209,14 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
     return;
   }
   uint32_t pbits = 0u, mbits = 0u;
+  // All residual loads of the wave are issued back to back BEFORE the per-channel arithmetic:
+  // one exposed memory latency per wave instead of one per channel.
+  float resv[NACC];
+  if (f & EF_RES) {
+#pragma unroll
+    for (int j = 0; j < NACC; ++j)
+      resv[j] = (px.live && (full || o0 + j < g.O)) ? (e.res + (size_t)(o0 + j) * hw)[lane_off] : 0.0f;
+  }
 #pragma unroll
   for (int j = 0; j < NACC; ++j) {
     const int o = o0 + j;
@@ -216,7 +224,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
       float y = fmaf(e.alpha[o], (float)dot[j], (f & EF_BIAS) ? e.bias[o] : 0.0f);
       if (f & EF_SCALE) y *= e.scale[o];
       if (f & EF_BN) y = fmaf(y, e.bn_a[o], e.bn_b[o]);
-      if (f & EF_RES) y += px.live ? (e.res + (size_t)o * hw)[lane_off] : 0.0f;
+      if (f & EF_RES) y += resv[j];
       if (f & EF_RELU) y = (y < 0.0f) ? 0.0f : y;  // keeps NaN, like torch.relu
       if (f & EF_PRELU) y = (y >= 0.0f) ? y : e.prelu[o] * y;
       if ((f & EF_OUTF) && px.live) (outf + (size_t)o * hw)[lane_off] = y;

@@ -141,6 +141,23 @@ int bnn_hip_avgpool_pack_f32(const float* x, int N, int C, int H, int W, int k, 
   return bnn::launch_avgpool_pack(x, N, C, H, W, k, P, M, static_cast<hipStream_t>(stream));
 }
 
+int bnn_hip_bn_relu_maxpool_pack_f32(const float* x, int N, int C, int H, int W,
+                                     const float* bn_scale, const float* bn_shift, int relu, int k,
+                                     int stride, int pad, float* out_f32, uint64_t* P, uint64_t* M,
+                                     void* stream) {
+  if (!x || N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || stride <= 0 || pad < 0)
+    return BNN_HIP_ERR_INVALID_ARG;
+  if (!out_f32 && !P) return BNN_HIP_ERR_INVALID_ARG;
+  if ((P == nullptr) != (M == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
+  if ((bn_scale == nullptr) != (bn_shift == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
+  if (2 * pad > k || H + 2 * pad < k || W + 2 * pad < k) return BNN_HIP_ERR_INVALID_ARG;
+  if ((long long)N * C * H * W > 4 * kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (P && (!aligned(P, 8) || !aligned(M, 8))) return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  return bnn::launch_bn_relu_maxpool_pack(x, N, C, H, W, bn_scale, bn_shift, relu, k, stride, pad,
+                                          out_f32, P, M, static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_pack_weight_f32(const float* w, int O, int C, int KH, int KW, int center,
                             int compute_alpha, uint32_t* wbits, uint32_t* wnz, float* alpha,
                             int32_t* zero_flag, void* stream) {

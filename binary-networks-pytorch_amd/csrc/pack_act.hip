@@ -146,4 +146,67 @@ int launch_avgpool_pack(const float* x, int N, int C, int H, int W, int k, uint6
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
+// Tail of the real-valued stem in ONE pass over the stem conv's output
+// (bnn/models/resnet.py:150-153: bn1 -> relu -> maxpool, then the first binary conv's sign()):
+//     v = fma(x, bn_a[c], bn_b[c])   eval-mode BatchNorm (optional)
+//     m = max over the k x k window (padding taps ignored, like nn.MaxPool2d)
+//     y = relu(m)                    relu and max commute, so ReLU runs once per output
+//     out_f32 = y ; P/M = sign(y)
+// Reads the big tensor once (HBM-bound) instead of four times (BN, ReLU, pool, pack).
+// One thread = one output pixel x one 32-channel word; consecutive lanes = consecutive ox, so
+// fp32 stores are coalesced and the stride-2 window reads of neighbouring lanes share lines.
+__global__ __launch_bounds__(256) void bn_relu_maxpool_pack_kernel(
+    const float* __restrict__ x, int C, int H, int W, const float* __restrict__ bn_a,
+    const float* __restrict__ bn_b, int relu, int k, int stride, int pad, int Ho, int Wo,
+    long long npix_out, int cw32, float* __restrict__ out, uint32_t* __restrict__ P,
+    uint32_t* __restrict__ M) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= npix_out) return;
+  const int word = blockIdx.y;
+  const int hw = Ho * Wo;
+  const int n = (int)(q / hw);
+  const int r = (int)(q - (long long)n * hw);
+  const int oy = r / Wo, ox = r - oy * Wo;
+  const int y0 = oy * stride - pad, x0 = ox * stride - pad;
+  uint32_t pw = 0u, mw = 0u;
+  for (int b = 0; b < 32; ++b) {
+    const int c = word * 32 + b;
+    if (c >= C) break;
+    const float* xc = x + ((size_t)n * C + c) * H * W;
+    const float a = bn_a ? bn_a[c] : 1.0f, sh = bn_b ? bn_b[c] : 0.0f;
+    float m = -INFINITY;
+    for (int dy = 0; dy < k; ++dy) {
+      const int iy = y0 + dy;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int dx = 0; dx < k; ++dx) {
+        const int ix = x0 + dx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        m = fmaxf(m, fmaf(xc[(size_t)iy * W + ix], a, sh));
+      }
+    }
+    if (relu) m = fmaxf(m, 0.0f);
+    if (out) out[((size_t)n * C + c) * hw + r] = m;
+    pw |= (is_pos(m) ? 1u : 0u) << b;
+    mw |= (is_neg(m) ? 1u : 0u) << b;
+  }
+  if (P) {
+    const size_t o = ((((size_t)n * (cw32 >> 1) + (word >> 1)) * hw + r) << 1) + (word & 1);
+    P[o] = pw;
+    M[o] = mw;
+  }
+}
+
+int launch_bn_relu_maxpool_pack(const float* x, int N, int C, int H, int W, const float* bn_a,
+                                const float* bn_b, int relu, int k, int stride, int pad, float* out,
+                                uint64_t* P, uint64_t* M, hipStream_t stream) {
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const long long npix = (long long)N * Ho * Wo;
+  const int cw32 = 2 * ((C + 63) / 64);
+  hipLaunchKernelGGL(bn_relu_maxpool_pack_kernel,
+                     dim3((unsigned)((npix + 255) / 256), (unsigned)cw32), dim3(256), 0, stream, x, C,
+                     H, W, bn_a, bn_b, relu, k, stride, pad, Ho, Wo, npix, cw32, out,
+                     reinterpret_cast<uint32_t*>(P), reinterpret_cast<uint32_t*>(M));
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
 }  // namespace bnn

@@ -162,6 +162,16 @@ int bnn_hip_pack_act_f32(const float* x, int N, int C, int H, int W,
 int bnn_hip_avgpool_pack_f32(const float* x, int N, int C, int H, int W, int k,
                              uint64_t* P, uint64_t* M, void* stream);
 
+/* Tail of the real-valued stem, one pass over the stem conv's fp32 NCHW output
+ * (bnn/models/resnet.py:150-153: bn1 -> relu -> maxpool, then the sign() of the first binary
+ * conv):  v = fma(x, bn_scale[c], bn_shift[c]) (both NULL = no BN);  m = max over the k x k
+ * window with stride/pad of nn.MaxPool2d;  y = relu ? max(m,0) : m.
+ * Outputs (either may be NULL): out_f32 [N,C,Ho,Wo] and sign(y) as planes P, M.     */
+int bnn_hip_bn_relu_maxpool_pack_f32(const float* x, int N, int C, int H, int W,
+                                     const float* bn_scale, const float* bn_shift, int relu,
+                                     int k, int stride, int pad,
+                                     float* out_f32, uint64_t* P, uint64_t* M, void* stream);
+
 /* XNOR-Net weight binarisation.  w: float32 [O,C,KH,KW] contiguous.
  *   center        != 0: subtract the mean over C per (o,ky,kx) first  (ops.py:130-132)
  *   compute_alpha != 0: alpha[o] = mean |w[o]| (after centering)      (ops.py:116-127)

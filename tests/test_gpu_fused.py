@@ -115,3 +115,91 @@ def test_avgpool_pack_matches_torch_pool_then_sign(shape, k):
     assert np.array_equal(u64(pk.P), P) and np.array_equal(u64(pk.M), M)
     P2, M2 = oracle.pack_act(t)                              # and sign(torch's pool) is identical
     assert np.array_equal(P, P2) and np.array_equal(M, M2)
+
+
+# ----------------------------------------------------------------------- whole-network executor
+import os  # noqa: E402
+
+import torch.nn as nn  # noqa: E402
+
+import bnn_amd as bnn  # noqa: E402
+from bnn_amd import fastpath  # noqa: E402
+from bnn_amd.inference import FusedResNet, FusionError, optimize_for_inference  # noqa: E402
+from bnn_amd.models import resnet18, resnet50  # noqa: E402
+from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer  # noqa: E402
+
+
+def _r18(activation=None):
+    cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
+                      weight_pre_process=XNORWeightBinarizer)
+    kw = {} if activation is None else {"activation": activation}
+    net = bnn.prepare_binary_model(resnet18(**kw), cfg, custom_config_layers_name={
+        "conv1": bnn.BConfig(), "fc": bnn.BConfig()})
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in gen.model_state(shapes, 1).items()})
+    return net.to(DEV).eval()
+
+
+@pytest.mark.parametrize("tag,shape", [("32", (4, 3, 32, 32)), ("64", (2, 3, 64, 64)), ("224", (2, 3, 224, 224))])
+def test_fused_resnet18_matches_reference_logits(tag, shape):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "resnet18.npz"))
+    net = _r18()
+    fused = FusedResNet(net)
+    x = dev(gen.normal(gen.seed_of("r18", tag), shape))
+    before = fastpath.stats()["conv2d"]
+    y = fused(x).cpu().numpy()
+    assert fastpath.stats()["conv2d"] == before       # the fused path bypasses the per-layer path
+    ref = g["logits_" + tag]
+    assert np.allclose(y, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+    assert (y.argmax(1) == ref.argmax(1)).all()
+    with torch.no_grad():
+        y_layerwise = net(x).cpu().numpy()
+    assert np.allclose(y, y_layerwise, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+
+
+def test_fused_resnet18_graph_replay_is_bit_identical():
+    net = _r18()
+    fused = FusedResNet(net)
+    x = dev(gen.normal(5, (8, 3, 64, 64)))
+    y0 = fused(x).clone()
+    fused.capture(x)
+    y1 = fused(x).clone()
+    y2 = fused(dev(gen.normal(6, (8, 3, 64, 64)))).clone()
+    assert torch.equal(y0, y1) and not torch.equal(y1, y2)
+    assert torch.equal(fused(x), y0)
+
+
+def test_fused_resnet18_prelu_variant():
+    net = _r18(activation=nn.PReLU)
+    fused = FusedResNet(net)
+    x = dev(gen.normal(9, (2, 3, 64, 64)))
+    with torch.no_grad():
+        ref = net(x)
+    assert torch.allclose(fused(x), ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()))
+
+
+def test_unsupported_models_are_left_alone():
+    cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
+                      weight_pre_process=XNORWeightBinarizer)
+    r50 = bnn.prepare_binary_model(resnet50(), cfg).to(DEV).eval()
+    assert optimize_for_inference(r50) is r50
+    with pytest.raises(FusionError):
+        FusedResNet(_r18().train())
+    with pytest.raises(FusionError):
+        FusedResNet(resnet18().to(DEV).eval())          # not binarised
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16), (1, 70, 11, 9), (3, 32, 7, 7)])
+def test_stem_tail_matches_torch_sequence(shape):
+    """BN(eval) -> ReLU -> MaxPool(3,2,1) -> sign, fused, vs the torch ops the reference runs."""
+    C = shape[1]
+    x = dev(gen.normal(gen.seed_of("stem", shape), shape) * 3)
+    a = dev((0.5 + gen.uniform(1, (C,))).astype(np.float32) * np.where(np.arange(C) % 5 == 0, -1, 1).astype(np.float32))
+    b = dev((0.3 * gen.normal(2, (C,))).astype(np.float32))
+    y, pk = hipops.bn_relu_maxpool_pack(x, a, b, True, 3, 2, 1)
+    ref = F.max_pool2d(F.relu(x * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)), 3, 2, 1)
+    assert torch.allclose(y, ref, rtol=1e-6, atol=1e-6)
+    P, M = oracle.pack_act(y.cpu().numpy())
+    assert np.array_equal(u64(pk.P), P) and np.array_equal(u64(pk.M), M)
+    y2, _ = hipops.bn_relu_maxpool_pack(x, None, None, False, 2, 2, 0, out_packed=False)
+    assert torch.equal(y2, F.max_pool2d(x, 2, 2, 0))
