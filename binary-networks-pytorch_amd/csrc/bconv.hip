@@ -178,12 +178,26 @@ __device__ __forceinline__ int count_nonzero(const uint32_t (&pr)[NW], const uin
 // Addressing: the per-lane part of every NCHW address (n*O*hw + r) is ONE 32-bit offset computed
 // once; the per-channel part (o*hw) is wave-uniform and stays in SGPRs, so each store/load is a
 // `global_* v_off, v_data, s[base]` with no per-channel vector address arithmetic.
-template <int NACC, bool FUSED>
+//
+// Epilogue profiles: the switches are wave-uniform run-time flags, but the two combinations a
+// residual block issues on every conv are also compiled with the flags as constants, which
+// removes ~1/3 of the epilogue's instructions (and all its scalar branches).
+enum : int {
+  EP_PLAIN = 0,    // alpha [, bias] [, post-scale] -> fp32 : the drop-in Conv2d.forward
+  EP_RUNTIME = 1,  // anything, decided at run time
+  EP_MID = 2,      // BN + ReLU -> packed only            (conv1 of a BasicBlock)
+  EP_OUT = 3,      // BN + residual + ReLU -> fp32 + packed (conv2 of a BasicBlock)
+};
+constexpr int kFlagsMid = EF_BN | EF_RELU | EF_PACK;
+constexpr int kFlagsOut = EF_BN | EF_RES | EF_RELU | EF_OUTF | EF_PACK;
+
+template <int NACC, int EP>
 __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
                                          const int (&dot)[NACC], const EpiArgs& e) {
+  constexpr bool FUSED = EP != EP_PLAIN;
   const int hw = g.Ho * g.Wo;
   const unsigned lane_off = (unsigned)(px.n * g.O * hw + px.r);  // host keeps N*O*hw < 2^30
-  const int f = g.flags;
+  const int f = EP == EP_MID ? kFlagsMid : EP == EP_OUT ? kFlagsOut : g.flags;
   const bool full = o0 + NACC <= g.O;
   if (f & EF_RAW) {
     if (px.live) {
@@ -230,7 +244,8 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
       if ((f & EF_OUTF) && px.live) (outf + (size_t)o * hw)[lane_off] = y;
       if (f & EF_PACK) {
         pbits |= (is_pos(y) ? 1u : 0u) << (j & 31);
-        mbits |= (is_neg(y) ? 1u : 0u) << (j & 31);
+        // after a ReLU nothing is negative: the M plane of this block stays 0
+        if (!(f & EF_RELU)) mbits |= (is_neg(y) ? 1u : 0u) << (j & 31);
       }
     }
   }
@@ -255,8 +270,8 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
 // Tiled kernel, weights streamed through SGPRs (scalar cache).  Best when all waves in
 // flight share one small weight block (large images, few output channels): BASELINE config 2.
 // ---------------------------------------------------------------------------------
-template <int KH, int KW, int CWC, bool FUSED>
-__global__ __launch_bounds__(64, BNN_TILED_MIN_WAVES) void bconv_sgpr_kernel(
+template <int KH, int KW, int CWC, int EP, int MINW>
+__global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
     const uint32_t* __restrict__ P, const uint32_t* __restrict__ M, const uint32_t* __restrict__ W,
     BNN_EPI_PARAMS, const Geo g) {
   constexpr int T = KH * KW;
@@ -316,7 +331,7 @@ __global__ __launch_bounds__(64, BNN_TILED_MIN_WAVES) void bconv_sgpr_kernel(
   }
 #pragma unroll
   for (int j = 0; j < kOCB; ++j) acc[j] = nz - 2 * acc[j];  // dot = non-zero count - 2 * disagreements
-  epilogue<kOCB, FUSED>(g, px, ob * kOCB, acc, epi);
+  epilogue<kOCB, EP>(g, px, ob * kOCB, acc, epi);
 }
 
 // ---------------------------------------------------------------------------------
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(kLdsWaves* kWave) void bconv_lds_kernel(
   }
 #pragma unroll
   for (int j = 0; j < kOCB; ++j) acc[j] = nz - 2 * acc[j];  // dot = non-zero count - 2 * disagreements
-  epilogue<kOCB, true>(g, px, ob * kOCB, acc, epi);
+  epilogue<kOCB, EP_RUNTIME>(g, px, ob * kOCB, acc, epi);
 }
 
 // ---------------------------------------------------------------------------------
@@ -458,7 +473,7 @@ __global__ __launch_bounds__(64) void bconv_generic_kernel(
       for (int k = 0; k < kOG; ++k) dotv[j0 + k] = (WZ ? nzw[k] : nz) - 2 * acc[k];
     }
   }
-  epilogue<kOCB, true>(g, px, ob * kOCB, dotv, epi);
+  epilogue<kOCB, EP_RUNTIME>(g, px, ob * kOCB, dotv, epi);
 }
 
 // ---------------------------------------------------------------------------------
@@ -494,17 +509,41 @@ static unsigned oblocks(const ConvP& p) {
   return (p.outP && p.outM) ? (unsigned)(2 * ((p.O + 63) / 64)) : nb;
 }
 
-template <int KH, int KW, int CWC>
-static void launch_sgpr(const ConvP& p, hipStream_t s) {
+template <int KH, int KW, int CWC, int EP, int MINW>
+static void launch_sgpr_t(const ConvP& p, const Geo& g, hipStream_t s) {
   const dim3 grid((p.npix + kWave - 1) / kWave, oblocks(p));
+  hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MINW>), grid, dim3(kWave), 0, s, p.P, p.M,
+                     p.W, BNN_EPI_ACTUALS, g);
+}
+
+// MINW: waves per SIMD the kernel is register-allocated for.  One-chunk layers (C <= 128) run
+// best unconstrained (166 VGPRs, 3 waves); multi-chunk layers re-load their field per chunk and
+// gain from the 4th wave (128 VGPRs) — measured on MI355X with tools/conv_variants.sh.
+// PROFILES: whether the compile-time epilogue profiles exist for this shape (3x3 only).
+template <int KH, int KW, int CWC, bool PROFILES>
+static void launch_sgpr(const ConvP& p, hipStream_t s) {
   const Geo g = make_geo(p);
   const bool fused = (g.flags & (EF_BN | EF_RES | EF_RELU | EF_PRELU | EF_PACK)) != 0;
-  if (fused)
-    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, true>), grid, dim3(kWave), 0, s, p.P, p.M,
-                       p.W, BNN_EPI_ACTUALS, g);
-  else
-    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, false>), grid, dim3(kWave), 0, s, p.P, p.M,
-                       p.W, BNN_EPI_ACTUALS, g);
+  const bool multi = p.nchunk > 1 && KH * KW * CWC >= 36;
+  if constexpr (PROFILES) {
+    if (g.flags == kFlagsMid) {
+      if (multi) launch_sgpr_t<KH, KW, CWC, EP_MID, 4>(p, g, s);
+      else launch_sgpr_t<KH, KW, CWC, EP_MID, 1>(p, g, s);
+      return;
+    }
+    if (g.flags == kFlagsOut) {
+      if (multi) launch_sgpr_t<KH, KW, CWC, EP_OUT, 4>(p, g, s);
+      else launch_sgpr_t<KH, KW, CWC, EP_OUT, 1>(p, g, s);
+      return;
+    }
+    if (multi) {
+      if (fused) launch_sgpr_t<KH, KW, CWC, EP_RUNTIME, 4>(p, g, s);
+      else launch_sgpr_t<KH, KW, CWC, EP_PLAIN, 4>(p, g, s);
+      return;
+    }
+  }
+  if (fused) launch_sgpr_t<KH, KW, CWC, EP_RUNTIME, 1>(p, g, s);
+  else launch_sgpr_t<KH, KW, CWC, EP_PLAIN, 1>(p, g, s);
 }
 
 template <int KH, int KW, int CWC>
@@ -549,13 +588,13 @@ int launch_bconv(const ConvP& p, int flags, hipStream_t s) {
   if (!generic) {
     const bool lds = prefer_lds(p, flags);
     done = true;
-#define BNN_PICK(KH_, KW_, C_)                                  \
+#define BNN_PICK(KH_, KW_, C_, PROF_)                           \
   if (p.KH == KH_ && p.KW == KW_ && p.cwc == C_) {              \
-    if (lds) launch_lds<KH_, KW_, C_>(p, s);                    \
-    else launch_sgpr<KH_, KW_, C_>(p, s);                       \
+    if (lds && PROF_) launch_lds<KH_, KW_, C_>(p, s);           \
+    else launch_sgpr<KH_, KW_, C_, PROF_>(p, s);                \
   } else
-    BNN_PICK(3, 3, 4) BNN_PICK(3, 3, 2) BNN_PICK(1, 1, 16) BNN_PICK(1, 1, 8) BNN_PICK(1, 1, 4)
-    BNN_PICK(1, 1, 2) { done = false; }
+    BNN_PICK(3, 3, 4, true) BNN_PICK(3, 3, 2, true) BNN_PICK(1, 1, 16, false)
+    BNN_PICK(1, 1, 8, false) BNN_PICK(1, 1, 4, false) BNN_PICK(1, 1, 2, false) { done = false; }
 #undef BNN_PICK
   }
   if (!done) launch_generic(p, wz, s);

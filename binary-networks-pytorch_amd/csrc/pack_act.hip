@@ -135,11 +135,53 @@ __global__ __launch_bounds__(256) void avgpool_pack_kernel(const float* __restri
   M[o] = mw;
 }
 
+// k == 2 on even images with W % 4 == 0 (every ResNet stage transition): one thread produces two
+// adjacent outputs from one aligned float4 per input row.  Same tap order as the scalar kernel.
+__global__ __launch_bounds__(256) void avgpool2_pack_kernel(const float* __restrict__ x, int C,
+                                                            int H, int W, int Ho, int Wo,
+                                                            long long npairs, int cw32,
+                                                            uint32_t* __restrict__ P,
+                                                            uint32_t* __restrict__ M) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;  // (n, oy, ox/2)
+  if (q >= npairs) return;
+  const int word = blockIdx.y;
+  const int wp = Wo >> 1;
+  const int n = (int)(q / ((long long)Ho * wp));
+  const int rr = (int)(q - (long long)n * Ho * wp);
+  const int oy = rr / wp, t = rr - oy * wp;
+  const int hw = Ho * Wo;
+  const int r = oy * Wo + 2 * t;
+  uint32_t pw0 = 0u, mw0 = 0u, pw1 = 0u, mw1 = 0u;
+  for (int b = 0; b < 32; ++b) {
+    const int c = word * 32 + b;
+    if (c >= C) break;
+    const float* row = x + (((size_t)n * C + c) * H + 2 * oy) * W + 4 * t;
+    const float4 u = *reinterpret_cast<const float4*>(row);
+    const float4 v = *reinterpret_cast<const float4*>(row + W);
+    const float s0 = ((u.x + u.y) + v.x) + v.y;
+    const float s1 = ((u.z + u.w) + v.z) + v.w;
+    pw0 |= (is_pos(s0) ? 1u : 0u) << b;
+    mw0 |= (is_neg(s0) ? 1u : 0u) << b;
+    pw1 |= (is_pos(s1) ? 1u : 0u) << b;
+    mw1 |= (is_neg(s1) ? 1u : 0u) << b;
+  }
+  const size_t o = ((((size_t)n * (cw32 >> 1) + (word >> 1)) * hw + r) << 1) + (word & 1);
+  P[o] = pw0; M[o] = mw0;
+  P[o + 2] = pw1; M[o + 2] = mw1;
+}
+
 int launch_avgpool_pack(const float* x, int N, int C, int H, int W, int k, uint64_t* P, uint64_t* M,
                         hipStream_t stream) {
   const int Ho = (H + k - 1) / k, Wo = (W + k - 1) / k;
   const long long npix = (long long)N * Ho * Wo;
   const int cw32 = 2 * ((C + 63) / 64);
+  if (k == 2 && H % 2 == 0 && W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+    const long long npairs = npix / 2;
+    hipLaunchKernelGGL(avgpool2_pack_kernel, dim3((unsigned)((npairs + 255) / 256), (unsigned)cw32),
+                       dim3(256), 0, stream, x, C, H, W, Ho, Wo, npairs, cw32,
+                       reinterpret_cast<uint32_t*>(P), reinterpret_cast<uint32_t*>(M));
+    return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(avgpool_pack_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)cw32),
                      dim3(256), 0, stream, x, C, H, W, k, Ho, Wo, npix, cw32,
                      reinterpret_cast<uint32_t*>(P), reinterpret_cast<uint32_t*>(M));
@@ -196,12 +238,72 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_pack_kernel(
   }
 }
 
+// The ResNet stem's geometry (3x3 window, stride 2, pad 1, W % 4 == 0) with vector loads: one
+// thread produces TWO horizontally adjacent outputs from one aligned float4 + one scalar per
+// input row, i.e. 6 loads per channel for 2 outputs instead of 18 stride-2 dword loads.
+__global__ __launch_bounds__(256) void bn_relu_maxpool3s2_pack_kernel(
+    const float* __restrict__ x, int C, int H, int W, const float* __restrict__ bn_a,
+    const float* __restrict__ bn_b, int relu, int Ho, int Wo, long long npairs, int cw32,
+    float* __restrict__ out, uint32_t* __restrict__ P, uint32_t* __restrict__ M) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;  // (n, oy, ox/2)
+  if (q >= npairs) return;
+  const int word = blockIdx.y;
+  const int wp = Wo >> 1;
+  const int n = (int)(q / ((long long)Ho * wp));
+  const int rr = (int)(q - (long long)n * Ho * wp);
+  const int oy = rr / wp, t = rr - oy * wp;
+  const int hw = Ho * Wo;
+  const int r = oy * Wo + 2 * t;
+  uint32_t pw0 = 0u, mw0 = 0u, pw1 = 0u, mw1 = 0u;
+  for (int b = 0; b < 32; ++b) {
+    const int c = word * 32 + b;
+    if (c >= C) break;
+    const float* xc = x + ((size_t)n * C + c) * H * W;
+    const float a = bn_a ? bn_a[c] : 1.0f, sh = bn_b ? bn_b[c] : 0.0f;
+    float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = 2 * oy - 1 + dy;
+      if ((unsigned)iy < (unsigned)H) {
+        const float* row = xc + (size_t)iy * W + 4 * t;
+        const float4 v = *reinterpret_cast<const float4*>(row);
+        const float e = t > 0 ? fmaf(row[-1], a, sh) : -INFINITY;
+        const float v0 = fmaf(v.x, a, sh), v1 = fmaf(v.y, a, sh), v2 = fmaf(v.z, a, sh),
+                    v3 = fmaf(v.w, a, sh);
+        m0 = fmaxf(m0, fmaxf(e, fmaxf(v0, v1)));
+        m1 = fmaxf(m1, fmaxf(v1, fmaxf(v2, v3)));
+      }
+    }
+    if (relu) { m0 = fmaxf(m0, 0.0f); m1 = fmaxf(m1, 0.0f); }
+    if (out) *reinterpret_cast<float2*>(out + ((size_t)n * C + c) * hw + r) = make_float2(m0, m1);
+    pw0 |= (is_pos(m0) ? 1u : 0u) << b;
+    mw0 |= (is_neg(m0) ? 1u : 0u) << b;
+    pw1 |= (is_pos(m1) ? 1u : 0u) << b;
+    mw1 |= (is_neg(m1) ? 1u : 0u) << b;
+  }
+  if (P) {
+    const size_t o = ((((size_t)n * (cw32 >> 1) + (word >> 1)) * hw + r) << 1) + (word & 1);
+    P[o] = pw0; M[o] = mw0;
+    P[o + 2] = pw1; M[o + 2] = mw1;
+  }
+}
+
 int launch_bn_relu_maxpool_pack(const float* x, int N, int C, int H, int W, const float* bn_a,
                                 const float* bn_b, int relu, int k, int stride, int pad, float* out,
                                 uint64_t* P, uint64_t* M, hipStream_t stream) {
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   const long long npix = (long long)N * Ho * Wo;
   const int cw32 = 2 * ((C + 63) / 64);
+  if (k == 3 && stride == 2 && pad == 1 && W % 4 == 0 && Wo == W / 2 &&
+      (reinterpret_cast<uintptr_t>(x) & 15u) == 0 &&
+      (!out || (reinterpret_cast<uintptr_t>(out) & 7u) == 0)) {
+    const long long npairs = npix / 2;
+    hipLaunchKernelGGL(bn_relu_maxpool3s2_pack_kernel,
+                       dim3((unsigned)((npairs + 255) / 256), (unsigned)cw32), dim3(256), 0, stream, x,
+                       C, H, W, bn_a, bn_b, relu, Ho, Wo, npairs, cw32, out,
+                       reinterpret_cast<uint32_t*>(P), reinterpret_cast<uint32_t*>(M));
+    return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(bn_relu_maxpool_pack_kernel,
                      dim3((unsigned)((npix + 255) / 256), (unsigned)cw32), dim3(256), 0, stream, x, C,
                      H, W, bn_a, bn_b, relu, k, stride, pad, Ho, Wo, npix, cw32, out,
