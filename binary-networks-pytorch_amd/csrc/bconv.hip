@@ -91,7 +91,7 @@ __device__ __forceinline__ int popc_acc(uint32_t x, int acc) {
 
 // WB consecutive weight words, loaded with one s_load_dwordx16.
 template <int WB>
-struct alignas(64) WBlock {
+struct alignas(WB * 4) WBlock {
   uint32_t v[WB];
 };
 
@@ -193,7 +193,8 @@ constexpr int kFlagsOut = EF_BN | EF_RES | EF_RELU | EF_OUTF | EF_PACK;
 
 template <int NACC, int EP>
 __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
-                                         const int (&dot)[NACC], const EpiArgs& e) {
+                                         const int (&dot)[NACC], const EpiArgs& e, uint32_t& pbits,
+                                         uint32_t& mbits) {
   constexpr bool FUSED = EP != EP_PLAIN;
   const int hw = g.Ho * g.Wo;
   const unsigned lane_off = (unsigned)(px.n * g.O * hw + px.r);  // host keeps N*O*hw < 2^30
@@ -222,7 +223,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
     }
     return;
   }
-  uint32_t pbits = 0u, mbits = 0u;
+  const int bit0 = o0 & 31;  // position of channel o0 inside its 32-channel output word
   // All residual loads of the wave are issued back to back BEFORE the per-channel arithmetic:
   // one exposed memory latency per wave instead of one per channel.
   float resv[NACC];
@@ -243,19 +244,22 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
       if (f & EF_PRELU) y = (y >= 0.0f) ? y : e.prelu[o] * y;
       if ((f & EF_OUTF) && px.live) (outf + (size_t)o * hw)[lane_off] = y;
       if (f & EF_PACK) {
-        pbits |= (is_pos(y) ? 1u : 0u) << (j & 31);
+        pbits |= (is_pos(y) ? 1u : 0u) << (bit0 + j);
         // after a ReLU nothing is negative: the M plane of this block stays 0
-        if (!(f & EF_RELU)) mbits |= (is_neg(y) ? 1u : 0u) << (j & 31);
+        if (!(f & EF_RELU)) mbits |= (is_neg(y) ? 1u : 0u) << (bit0 + j);
       }
     }
   }
-  if ((f & EF_PACK) && px.live) {
-    // output planes [n][group][y][x] uint64; this block of 32 channels is one half of a word
-    const int ob = o0 >> 5;
-    const size_t w = ((((size_t)px.n * (g.cw32_out >> 1) + (ob >> 1)) * hw + px.r) << 1) + (ob & 1);
-    e.outP[w] = pbits;
-    e.outM[w] = mbits;
-  }
+}
+
+// sign(y) of one 32-channel block: one half of a uint64 word of the [n][group][y][x] output planes.
+__device__ __forceinline__ void store_packed(const Geo& g, const Pix& px, int ob, uint32_t pbits,
+                                             uint32_t mbits, const EpiArgs& e) {
+  if (!(g.flags & EF_PACK) || (g.flags & EF_RAW) || !px.live) return;
+  const int hw = g.Ho * g.Wo;
+  const size_t w = ((((size_t)px.n * (g.cw32_out >> 1) + (ob >> 1)) * hw + px.r) << 1) + (ob & 1);
+  e.outP[w] = pbits;
+  e.outM[w] = mbits;
 }
 
 #define BNN_EPI_PARAMS                                                                          \
@@ -270,68 +274,91 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
 // Tiled kernel, weights streamed through SGPRs (scalar cache).  Best when all waves in
 // flight share one small weight block (large images, few output channels): BASELINE config 2.
 // ---------------------------------------------------------------------------------
-template <int KH, int KW, int CWC, int EP, int MINW>
+// Streams NACC x NW wave-uniform weight words (one contiguous run) through two 16-word SGPR
+// buffers and accumulates the disagreement counts of NACC output channels.  SMEM returns out of
+// order, so the only usable wait is lgkmcnt(0): `cur` is touched first so that this wait lands
+// BEFORE block b+1 is requested; b+1 then has the whole VALU block (32 instructions) to arrive.
+template <int NW, int NACC>
+__device__ __forceinline__ void stream_weights(const uint32_t* __restrict__ wrun,
+                                               const uint32_t (&pr)[NW], const uint32_t (&mr)[NW],
+                                               int (&acc)[NACC]) {
+  constexpr int WB = (NACC * NW) % 16 == 0 ? 16 : (NACC * NW) % 8 == 0 ? 8 : 4;
+  constexpr int NB = NACC * NW / WB;
+  static_assert((NACC * NW) % WB == 0, "weight run must be a whole number of blocks");
+  const WBlock<WB>* wq = reinterpret_cast<const WBlock<WB>*>(wrun);
+  WBlock<WB> cur = wq[0];
+  int t0 = 0, t1 = 0;  // two accumulation chains per channel (even / odd words)
+  static_for<NB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"s"(cur.v[0]), "s"(cur.v[WB - 1]));
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    WBlock<WB> nxt;
+    if constexpr (b + 1 < NB) nxt = wq[b + 1];
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<WB>([&](auto ec) {
+      constexpr int e = decltype(ec)::value;
+      constexpr int f = b * WB + e;
+      constexpr int j = f / NW, i = f % NW;
+      const uint32_t d = disagree(cur.v[e], mr[i], pr[i]);
+      // the first word of each chain uses the inline-constant form (v_bcnt d, 0): no v_mov
+      if constexpr (i == 0) t0 = __builtin_popcount(d);
+      else if constexpr (i == 1) t1 = __builtin_popcount(d);
+      else if constexpr (i & 1) t1 = popc_acc(d, t1);
+      else t0 = popc_acc(d, t0);
+      if constexpr (i == NW - 1) acc[j] += t0 + (NW > 1 ? t1 : 0);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (b + 1 < NB) cur = nxt;
+  });
+}
+
+// The 32 output channels of the block are produced in PASSES runs of 32/PASSES channels: fewer
+// live accumulators (more waves per SIMD) and 1/PASSES of the unrolled code, looped.
+//   MULTI == false: the layer has ONE chunk (C <= 64*CWC/2); its field is loaded once and stays
+//                   in registers across all passes.
+//   MULTI == true : any number of chunks; each pass walks the chunks and re-loads the field.
+template <int KH, int KW, int CWC, int EP, int MINW, int PASSES, bool MULTI>
 __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
     const uint32_t* __restrict__ P, const uint32_t* __restrict__ M, const uint32_t* __restrict__ W,
     BNN_EPI_PARAMS, const Geo g) {
   constexpr int T = KH * KW;
   constexpr int NW = T * CWC;  // words per (o, chunk)
+  constexpr int NACC = kOCB / PASSES;
   BNN_EPI_INIT;
   const Pix px = decode_pixel(g, blockIdx.x * kWave + threadIdx.x);
   const int ob = blockIdx.y;
-
-  int acc[kOCB];
-#pragma unroll
-  for (int j = 0; j < kOCB; ++j) acc[j] = 0;
-  int nz = 0;
+  uint32_t pbits = 0u, mbits = 0u;
 
   if (ob * kOCB < g.O) {
     const uint32_t* wblk = W + (size_t)ob * g.nchunk * (kOCB * NW);
-    for (int ch = 0; ch < g.nchunk; ++ch) {
-      uint32_t pr[NW], mr[NW];
-      load_field<KH, KW, CWC>(g, px, ch, P, M, pr, mr);
-      nz = count_nonzero<NW>(pr, mr, nz);
-      const uint32_t* wch = wblk + (size_t)ch * (kOCB * NW);
-      // The 32 x NW weight words of this (ob, chunk) are one contiguous, wave-uniform stream.
-      // Walk it in blocks of WB words through two SGPR buffers.  SMEM returns out of order, so
-      // the only usable wait is lgkmcnt(0): touch `cur` first so that this wait lands BEFORE
-      // block b+1 is requested; b+1 then has the whole VALU block below (2*WB instructions)
-      // to arrive.
-      constexpr int WB = 16;
-      constexpr int NB = kOCB * NW / WB;
-      static_assert((kOCB * NW) % WB == 0, "weight stream must be a whole number of blocks");
-      const WBlock<WB>* wq = reinterpret_cast<const WBlock<WB>*>(wch);
-      WBlock<WB> cur = wq[0];
-      int t0 = 0, t1 = 0;  // two accumulation chains per channel (even / odd words)
-      static_for<NB>([&](auto bc) {
-        constexpr int b = decltype(bc)::value;
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" ::"s"(cur.v[0]), "s"(cur.v[WB - 1]));
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        WBlock<WB> nxt;
-        if constexpr (b + 1 < NB) nxt = wq[b + 1];
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<WB>([&](auto ec) {
-          constexpr int e = decltype(ec)::value;
-          constexpr int f = b * WB + e;
-          constexpr int j = f / NW, i = f % NW;
-          const uint32_t d = disagree(cur.v[e], mr[i], pr[i]);
-          // the first word of each chain uses the inline-constant form (v_bcnt d, 0): no v_mov
-          if constexpr (i == 0) t0 = __builtin_popcount(d);
-          else if constexpr (i == 1) t1 = __builtin_popcount(d);
-          else if constexpr (i & 1) t1 = popc_acc(d, t1);
-          else t0 = popc_acc(d, t0);
-          if constexpr (i == NW - 1) acc[j] += t0 + (NW > 1 ? t1 : 0);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (b + 1 < NB) cur = nxt;
-      });
+    uint32_t pr[NW], mr[NW];
+    int nz = 0;
+    if constexpr (!MULTI) {
+      load_field<KH, KW, CWC>(g, px, 0, P, M, pr, mr);
+      nz = count_nonzero<NW>(pr, mr, 0);
+    }
+#pragma unroll 1
+    for (int ps = 0; ps < PASSES; ++ps) {
+      int acc[NACC];
+#pragma unroll
+      for (int j = 0; j < NACC; ++j) acc[j] = 0;
+      if constexpr (MULTI) {
+        for (int ch = 0; ch < g.nchunk; ++ch) {
+          load_field<KH, KW, CWC>(g, px, ch, P, M, pr, mr);
+          if (ps == 0) nz = count_nonzero<NW>(pr, mr, nz);
+          stream_weights<NW, NACC>(wblk + ((size_t)ch * kOCB + ps * NACC) * NW, pr, mr, acc);
+        }
+      } else {
+        stream_weights<NW, NACC>(wblk + (size_t)ps * (NACC * NW), pr, mr, acc);
+      }
+#pragma unroll
+      for (int j = 0; j < NACC; ++j) acc[j] = nz - 2 * acc[j];  // dot = non-zeros - 2*disagreements
+      epilogue<NACC, EP>(g, px, ob * kOCB + ps * NACC, acc, epi, pbits, mbits);
     }
   }
-#pragma unroll
-  for (int j = 0; j < kOCB; ++j) acc[j] = nz - 2 * acc[j];  // dot = non-zero count - 2 * disagreements
-  epilogue<kOCB, EP>(g, px, ob * kOCB, acc, epi);
+  store_packed(g, px, ob, pbits, mbits, epi);
 }
 
 // ---------------------------------------------------------------------------------
@@ -407,7 +434,9 @@ __global__ __launch_bounds__(kLdsWaves* kWave) void bconv_lds_kernel(
   }
 #pragma unroll
   for (int j = 0; j < kOCB; ++j) acc[j] = nz - 2 * acc[j];  // dot = non-zero count - 2 * disagreements
-  epilogue<kOCB, EP_RUNTIME>(g, px, ob * kOCB, acc, epi);
+  uint32_t pbits = 0u, mbits = 0u;
+  epilogue<kOCB, EP_RUNTIME>(g, px, ob * kOCB, acc, epi, pbits, mbits);
+  store_packed(g, px, ob, pbits, mbits, epi);
 }
 
 // ---------------------------------------------------------------------------------
@@ -473,7 +502,9 @@ __global__ __launch_bounds__(64) void bconv_generic_kernel(
       for (int k = 0; k < kOG; ++k) dotv[j0 + k] = (WZ ? nzw[k] : nz) - 2 * acc[k];
     }
   }
-  epilogue<kOCB, EP_RUNTIME>(g, px, ob * kOCB, dotv, epi);
+  uint32_t pbits = 0u, mbits = 0u;
+  epilogue<kOCB, EP_RUNTIME>(g, px, ob * kOCB, dotv, epi, pbits, mbits);
+  store_packed(g, px, ob, pbits, mbits, epi);
 }
 
 // ---------------------------------------------------------------------------------
@@ -509,11 +540,23 @@ static unsigned oblocks(const ConvP& p) {
   return (p.outP && p.outM) ? (unsigned)(2 * ((p.O + 63) / 64)) : nb;
 }
 
+#ifndef BNN_SGPR_PASSES  // passes per 32-channel block, single-chunk 3x3 layers
+#define BNN_SGPR_PASSES 4
+#endif
+#ifndef BNN_SGPR_PASSES_MULTI  // same, multi-chunk 3x3 layers (each pass re-loads the field)
+#define BNN_SGPR_PASSES_MULTI 1
+#endif
+
 template <int KH, int KW, int CWC, int EP, int MINW>
 static void launch_sgpr_t(const ConvP& p, const Geo& g, hipStream_t s) {
   const dim3 grid((p.npix + kWave - 1) / kWave, oblocks(p));
-  hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MINW>), grid, dim3(kWave), 0, s, p.P, p.M,
-                     p.W, BNN_EPI_ACTUALS, g);
+  constexpr bool k3 = KH * KW > 1;
+  if (k3 && p.nchunk == 1)
+    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MINW, k3 ? BNN_SGPR_PASSES : 1, false>),
+                       grid, dim3(kWave), 0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
+  else
+    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MINW, k3 ? BNN_SGPR_PASSES_MULTI : 1, true>),
+                       grid, dim3(kWave), 0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
 }
 
 // MINW: waves per SIMD the kernel is register-allocated for.  One-chunk layers (C <= 128) run

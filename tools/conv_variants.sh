@@ -5,8 +5,9 @@ set -u
 R="$(cd "$(dirname "$0")/.." && pwd)"
 V="$R/binary-networks-pytorch_amd/bnn_amd/_lib/variants"
 declare -A CFG=(
-  [w1]="-DBNN_TILED_MIN_WAVES=1"
-  [w4]="-DBNN_TILED_MIN_WAVES=4"
+  [p8]="-DBNN_SGPR_PASSES=8 -DBNN_SGPR_PASSES_MULTI=2"
+  [p4m2]="-DBNN_SGPR_PASSES=4 -DBNN_SGPR_PASSES_MULTI=2"
+  [p4m1]="-DBNN_SGPR_PASSES=4 -DBNN_SGPR_PASSES_MULTI=1"
 )
 if [ "${1:-build}" = "build" ]; then
   rm -rf "$V"; mkdir -p "$V"
