@@ -27,8 +27,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from . import hipops, native, ops
-from .bconfig import Identity
+from . import hipops, native
 
 _stats_lock = threading.Lock()
 _stats = {"conv2d": 0, "conv1d": 0, "linear": 0, "weight_packs": 0}
@@ -52,15 +51,25 @@ class Plan:
     scale: Optional[torch.Tensor]  # BasicScaleBinarizer.alpha or None
 
 
+_HOOK_MODULES = ("bnn_amd.ops", "bnn_amd.bconfig", "bnn.ops", "bnn.bconfig")
+
+
+def _is(obj, name: str) -> bool:
+    """Exact hook class, by name, from this package or from the reference package (so that a
+    model converted with the reference's own `bnn.ops` classes is accelerated as well)."""
+    t = type(obj)
+    return t.__name__ == name and t.__module__ in _HOOK_MODULES
+
+
 def _recognise(layer: nn.Module, out_channels: int) -> Optional[Plan]:
     pre = layer.activation_pre_process
     wpre = layer.weight_pre_process
     post = layer.activation_post_process
-    if type(pre) is not ops.BasicInputBinarizer or type(wpre) is not ops.XNORWeightBinarizer:
+    if not _is(pre, "BasicInputBinarizer") or not _is(wpre, "XNORWeightBinarizer"):
         return None
-    if type(post) is Identity:
+    if _is(post, "Identity"):
         scale = None
-    elif type(post) is ops.BasicScaleBinarizer and post.alpha.numel() == out_channels \
+    elif _is(post, "BasicScaleBinarizer") and post.alpha.numel() == out_channels \
             and post.alpha.dim() >= 2 and post.alpha.shape[1] == out_channels:
         scale = post.alpha
     else:

@@ -282,3 +282,20 @@ def test_cpu_never_uses_native_path():
     with torch.no_grad():
         conv(torch.randn(1, 8, 4, 4))
     assert fastpath.stats() == before
+
+
+def test_fast_path_recognises_exact_hook_classes_only():
+    from bnn_amd import fastpath
+
+    class Lookalike(BasicInputBinarizer):   # a subclass may change semantics: not accelerated
+        pass
+    good = bnn.prepare_binary_model(nn.Conv2d(8, 8, 3), xnor_cfg())
+    assert fastpath._recognise(good, 8) is not None
+    odd = bnn.prepare_binary_model(nn.Conv2d(8, 8, 3), bnn.BConfig(
+        activation_pre_process=Lookalike, weight_pre_process=XNORWeightBinarizer))
+    assert fastpath._recognise(odd, 8) is None
+    scaled = bnn.prepare_binary_model(nn.Conv2d(8, 8, 3), bnn.BConfig(**XNOR_SCALE))
+    assert fastpath._recognise(scaled, 8).scale is scaled.activation_post_process.alpha
+    adv = bnn.prepare_binary_model(nn.Conv2d(8, 8, 3), bnn.BConfig(
+        activation_pre_process=AdvancedInputBinarizer, weight_pre_process=XNORWeightBinarizer))
+    assert fastpath._recognise(adv, 8) is None
