@@ -106,6 +106,30 @@ def avgpool_pack(x: torch.Tensor, k: int) -> PackedAct:
     return a
 
 
+def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: torch.Tensor,
+            out_f32: bool = True, out_packed: bool = True):
+    """conv 7x7/2/3 (3->64, no bias) -> folded BN -> ReLU -> MaxPool 3/2/1 in one MFMA kernel
+    (bnn/models/resnet.py:93-96,150-153).  Returns (fp32 NCHW | None, PackedAct | None)."""
+    x = _require_cuda_f32(x, "stem input")
+    w = _require_cuda_f32(w.detach(), "stem weight")
+    if x.dim() != 4 or x.shape[1] != 3 or tuple(w.shape) != (64, 3, 7, 7):
+        raise native.NativeError("bnn_amd: stem7x7 expects x [N,3,H,W] and w [64,3,7,7]")
+    lib = native.require()
+    N, _, H, W = x.shape
+    hc, wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    hp, wp = (hc - 1) // 2 + 1, (wc - 1) // 2 + 1
+    bn_scale = _per_channel(bn_scale, 64, "bn_scale")
+    bn_shift = _per_channel(bn_shift, 64, "bn_shift")
+    with torch.cuda.device(x.device):
+        y = torch.empty((N, 64, hp, wp), dtype=torch.float32, device=x.device) if out_f32 else None
+        pk = empty_packed(N, 64, hp, wp, x.device) if out_packed else None
+        native.check(lib.bnn_hip_stem7x7_bn_relu_pool_pack_f32(
+            x.data_ptr(), w.data_ptr(), bn_scale.data_ptr(), bn_shift.data_ptr(), N, H, W, _ptr(y),
+            None if pk is None else pk.P.data_ptr(), None if pk is None else pk.M.data_ptr(),
+            _stream(x.device)), "bnn_hip_stem7x7_bn_relu_pool_pack_f32")
+    return y, pk
+
+
 def bn_relu_maxpool_pack(x: torch.Tensor, bn_scale=None, bn_shift=None, relu: bool = True, k: int = 3,
                          stride: int = 2, pad: int = 1, out_f32: bool = True, out_packed: bool = True):
     """Stem tail in one pass: folded BN -> MaxPool2d(k, stride, pad) -> ReLU, written as fp32

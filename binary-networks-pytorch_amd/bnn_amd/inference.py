@@ -74,6 +74,15 @@ def _plan_of(conv: nn.Module) -> fastpath.Plan:
     return plan
 
 
+def _is_float_layer(conv: nn.Module) -> bool:
+    """True for a stock conv or a binary-class conv whose recipe is all-Identity (kept real-valued
+    the way examples/cifar10.py:71 does it: custom_config_layers_name={'conv1': BConfig()})."""
+    if not isinstance(conv, BinaryConv2d):
+        return type(conv) is nn.Conv2d
+    return (type(conv.activation_pre_process) is nn.Identity and type(conv.weight_pre_process) is nn.Identity
+            and type(conv.activation_post_process).__name__ == "Identity")
+
+
 def _activation(act: nn.Module):
     if isinstance(act, nn.ReLU):
         return True, None
@@ -85,8 +94,9 @@ def _activation(act: nn.Module):
 class FusedResNet(nn.Module):
     """Inference executor for ``bnn_amd.models.ResNet`` built from ``BasicBlock`` (ResNet-18/34)."""
 
-    def __init__(self, model: ResNet) -> None:
+    def __init__(self, model: ResNet, use_mfma_stem: bool = True) -> None:
         super().__init__()
+        self.use_mfma_stem = use_mfma_stem
         if not isinstance(model, ResNet) or model.stem_type != "basic":
             raise FusionError("FusedResNet covers bnn_amd.models.ResNet with the 'basic' stem")
         self.model = model
@@ -118,6 +128,13 @@ class FusedResNet(nn.Module):
                 and not mp.ceil_mode and isinstance(mp.kernel_size, int) and isinstance(mp.stride, int) \
                 and isinstance(mp.padding, int):
             self._stem = (*fold_bn(m.bn1), (mp.kernel_size, mp.stride, mp.padding))
+        c1 = m.conv1
+        # the whole stem as one fp32-MFMA kernel when it is the canonical 7x7/2/3 conv + 3/2/1 pool
+        self._stem_mfma = (self.use_mfma_stem and self._stem is not None and self._stem[2] == (3, 2, 1)
+                           and isinstance(c1, nn.Conv2d) and c1.weight.shape == (64, 3, 7, 7)
+                           and c1.stride == (2, 2) and c1.padding == (3, 3) and c1.dilation == (1, 1)
+                           and c1.groups == 1 and c1.bias is None and c1.weight.dtype == torch.float32
+                           and _is_float_layer(c1))
         for stage in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in stage:
                 if not isinstance(blk, BasicBlock):
@@ -141,11 +158,13 @@ class FusedResNet(nn.Module):
         m = self.model
         # real-valued stem (first layer stays float: examples/cifar10.py:71): the conv runs in the
         # vendor library (MFMA), its BN -> ReLU -> MaxPool -> sign tail in one HBM pass
-        t = m.conv1(x)
-        if self._stem is not None:
+        if self._stem_mfma:
+            t, packed = hipops.stem7x7(x, m.conv1.weight, self._stem[0], self._stem[1])
+        elif self._stem is not None:
+            t = m.conv1(x)
             t, packed = hipops.bn_relu_maxpool_pack(t, self._stem[0], self._stem[1], True, *self._stem[2])
         else:
-            t = m.maxpool(m.relu(m.bn1(t)))
+            t = m.maxpool(m.relu(m.bn1(m.conv1(x))))
             packed = hipops.pack_act(t)
         last = len(self._blocks) - 1
         for i, b in enumerate(self._blocks):

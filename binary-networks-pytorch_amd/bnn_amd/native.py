@@ -26,7 +26,8 @@ ABI_VERSION = 2
 EXPORTED_SYMBOLS = (
     "bnn_hip_abi_version", "bnn_hip_status_string", "bnn_hip_launch_count", "bnn_hip_device_info",
     "bnn_hip_act_words", "bnn_hip_weight_layout", "bnn_hip_pack_act_f32",
-    "bnn_hip_avgpool_pack_f32", "bnn_hip_bn_relu_maxpool_pack_f32", "bnn_hip_pack_weight_f32", "bnn_hip_bconv2d",
+    "bnn_hip_avgpool_pack_f32", "bnn_hip_bn_relu_maxpool_pack_f32", "bnn_hip_stem7x7_bn_relu_pool_pack_f32",
+    "bnn_hip_pack_weight_f32", "bnn_hip_bconv2d",
     "bnn_hip_bconv2d_fused", "bnn_hip_bconv2d_dot", "bnn_hip_blinear",
     "bnn_hip_conv_workspace_bytes", "bnn_hip_bconv2d_f32", "bnn_hip_probe_int_alu",
 )
@@ -91,6 +92,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_weight_layout.argtypes = [_i, _i, _i, _i, ctypes.POINTER(WLayout)]
     lib.bnn_hip_pack_act_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _vp]
     lib.bnn_hip_avgpool_pack_f32.argtypes = [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]
+    lib.bnn_hip_stem7x7_bn_relu_pool_pack_f32.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]
     lib.bnn_hip_bn_relu_maxpool_pack_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i,
                                                      _vp, _vp, _vp, _vp]
     lib.bnn_hip_pack_weight_f32.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]

@@ -158,6 +158,20 @@ int bnn_hip_bn_relu_maxpool_pack_f32(const float* x, int N, int C, int H, int W,
                                           out_f32, P, M, static_cast<hipStream_t>(stream));
 }
 
+int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w, const float* bn_scale,
+                                          const float* bn_shift, int N, int H, int W, float* out_f32,
+                                          uint64_t* P, uint64_t* M, void* stream) {
+  if (!x || !w || !bn_scale || !bn_shift || N <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (!out_f32 && !P) return BNN_HIP_ERR_INVALID_ARG;
+  if ((P == nullptr) != (M == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
+  if (P && (!aligned(P, 8) || !aligned(M, 8))) return BNN_HIP_ERR_INVALID_ARG;
+  if ((long long)N * 3 * H * W > kMaxElems || (long long)N * 64 * H * W / 16 > kMaxElems)
+    return BNN_HIP_ERR_TOO_LARGE;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  return bnn::launch_stem(x, w, bn_scale, bn_shift, N, H, W, out_f32, P, M,
+                          static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_pack_weight_f32(const float* w, int O, int C, int KH, int KW, int center,
                             int compute_alpha, uint32_t* wbits, uint32_t* wnz, float* alpha,
                             int32_t* zero_flag, void* stream) {
