@@ -25,19 +25,24 @@ constexpr int ICH = ITH * ITW;                                   // 1365 floats 
 constexpr int NIN = CIN * ICH;                                   // 4095
 constexpr int SM = 257;                                          // stage row stride (bank-conflict pad)
 constexpr int NT = 256;
-// LDS carve (floats)
-constexpr int OFF_IN = 0;
-constexpr int OFF_W = 4096;                   // [K4 = 148][16][4]  -> one ds_read_b128 per B fragment set
-constexpr int OFF_STAGE = OFF_W + KSTEPS * 4 * COUT;
-constexpr int LDS_FLOATS = OFF_STAGE + COUT * SM;
+// LDS carve (floats).  The conv tile is staged 32 channels at a time into the space the input patch
+// occupied during the GEMM, which keeps a workgroup at 70.8 KB: TWO workgroups per CU, so one can
+// run its matrix phase while the other loads / pools.
+constexpr int HALF = 32;                                         // channels per staging round
+constexpr int OFF_IN = 0;                                        // input patch, later the stage
+constexpr int OFF_STAGE = 0;
+constexpr int OFF_W = HALF * SM;              // [K4 = 148][16][4]  -> one ds_read_b128 per B fragment set
+constexpr int LDS_FLOATS = OFF_W + KSTEPS * 4 * COUT;
+static_assert(HALF * SM >= NIN, "stage region must also hold the input patch");
 }  // namespace stem
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-__global__ __launch_bounds__(stem::NT) void stem_conv_bn_relu_pool_pack_kernel(
+__global__ __launch_bounds__(stem::NT, 2) void stem_conv_bn_relu_pool_pack_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bn_a,
     const float* __restrict__ bn_b, int N, int H, int W, int Hc, int Wc, int Hp, int Wp, int tiles_y,
-    int tiles_x, float* __restrict__ out, uint64_t* __restrict__ P, uint64_t* __restrict__ M) {
+    int tiles_x, int per_xcd, float* __restrict__ out, uint64_t* __restrict__ P,
+    uint64_t* __restrict__ M) {
   using namespace stem;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* in_t = lds + OFF_IN;
@@ -80,7 +85,12 @@ __global__ __launch_bounds__(stem::NT) void stem_conv_bn_relu_pool_pack_kernel(
   }
 
   const int ntiles = N * tiles_y * tiles_x;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // Tile order: workgroup b sits on XCD b % 8 (observed placement, used for speed only).  Each XCD
+  // walks ONE contiguous eighth of the tile list, so the tiles that share an output cache line
+  // (neighbours in x) and an input halo are handled by the same L2 within a short time window.
+  for (int seq = blockIdx.x; seq < per_xcd * 8; seq += gridDim.x) {
+    const int tile = (seq & 7) * per_xcd + (seq >> 3);
+    if (tile >= ntiles) continue;
     const int n = tile / (tiles_y * tiles_x);
     const int tr = tile - n * tiles_y * tiles_x;
     const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
@@ -88,7 +98,6 @@ __global__ __launch_bounds__(stem::NT) void stem_conv_bn_relu_pool_pack_kernel(
     const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;  // conv origin (pool pad 1)
     const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;  // input origin (conv pad 3)
 
-    __syncthreads();  // previous tile's pooling reads of `stage` / A reads of `in_t` are done
     for (int e = tid; e < NIN; e += NT) {
       const int c = e / ICH, rem = e - c * ICH, r = rem / ITW, col = rem - r * ITW;
       const int iy = iy0 + r, ix = ix0 + col;
@@ -120,59 +129,59 @@ __global__ __launch_bounds__(stem::NT) void stem_conv_bn_relu_pool_pack_kernel(
           acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[t], acc[s][t], 0, 0, 0);
     }
 
-    // ---- BN + ReLU, conv tile -> LDS.  D layout: col = lane&15 (channel in sub-tile), row = 4*(lane>>4)+r
+    __syncthreads();  // every wave is done reading the input patch: its space becomes the stage
+
+    // ---- two rounds of 32 channels: BN + ReLU -> LDS, then 3x3 / stride-2 max pool out of LDS
+    // D layout: col = lane&15 (channel in sub-tile), row = 4*(lane>>4)+r
+    const int p = tid >> 2, q = tid & 3;  // pooling role: pixel p (< 56), 8-channel group q
+    const int ly = p / PTW, lx = p - ly * PTW;
+    const int py = py0 + ly, px = px0 + lx;
+    const bool live = p < PTH * PTW && py < Hp && px < Wp;
+    const int mb = (2 * ly) * CTW + 2 * lx;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = (wave * 4 + s) * 16 + lg * 4 + r;
-        if (m < MPIX) {
-          const int cy = m / CTW, cx = m - cy * CTW;
-          const bool inside = (unsigned)(cy0 + cy) < (unsigned)Hc && (unsigned)(cx0 + cx) < (unsigned)Wc;
+      for (int s = 0; s < 4; ++s) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            float v = fmaxf(fmaf(acc[s][t][r], ba[t], bb[t]), 0.0f);
-            // positions outside the conv output are MaxPool padding: 0 never beats a ReLU output
-            stage[(16 * t + li) * SM + m] = inside ? v : 0.0f;
+        for (int r = 0; r < 4; ++r) {
+          const int m = (wave * 4 + s) * 16 + lg * 4 + r;
+          if (m < MPIX) {
+            const int cy = m / CTW, cx = m - cy * CTW;
+            const bool inside = (unsigned)(cy0 + cy) < (unsigned)Hc && (unsigned)(cx0 + cx) < (unsigned)Wc;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+              const int t = 2 * half + tt;
+              const float v = fmaxf(fmaf(acc[s][t][r], ba[t], bb[t]), 0.0f);
+              // positions outside the conv output are MaxPool padding: 0 never beats a ReLU output
+              stage[(16 * tt + li) * SM + m] = inside ? v : 0.0f;
+            }
           }
         }
       }
-    }
-    __syncthreads();
-
-    // ---- 3x3 / stride-2 max pool out of LDS, fp32 store + sign planes (M plane is 0 after ReLU)
-    // thread = (pooled pixel p < 56, channel quarter q): lanes 4p..4p+3 hold the 4 quarters of a pixel
-    {
-      const int p = tid >> 2, q = tid & 3;
+      __syncthreads();
       uint32_t bits = 0u;
-      int py = 0, px = 0;
-      bool live = false;
       if (p < PTH * PTW) {
-        const int ly = p / PTW, lx = p - ly * PTW;
-        py = py0 + ly;
-        px = px0 + lx;
-        live = py < Hp && px < Wp;
-        const int mb = (2 * ly) * CTW + 2 * lx;
-        for (int cc = 0; cc < 16; ++cc) {
-          const int ch = q * 16 + cc;
-          const float* sp = stage + ch * SM + mb;
-          float m0 = fmaxf(fmaxf(sp[0], sp[1]), sp[2]);
-          float m1 = fmaxf(fmaxf(sp[CTW], sp[CTW + 1]), sp[CTW + 2]);
-          float m2 = fmaxf(fmaxf(sp[2 * CTW], sp[2 * CTW + 1]), sp[2 * CTW + 2]);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+          const int cl = q * 8 + cc;
+          const float* sp = stage + cl * SM + mb;
+          const float m0 = fmaxf(fmaxf(sp[0], sp[1]), sp[2]);
+          const float m1 = fmaxf(fmaxf(sp[CTW], sp[CTW + 1]), sp[CTW + 2]);
+          const float m2 = fmaxf(fmaxf(sp[2 * CTW], sp[2 * CTW + 1]), sp[2 * CTW + 2]);
           const float v = fmaxf(fmaxf(m0, m1), m2);
-          if (live && out) out[(((size_t)n * COUT + ch) * Hp + py) * Wp + px] = v;
+          if (live && out) out[(((size_t)n * COUT + HALF * half + cl) * Hp + py) * Wp + px] = v;
           bits |= (is_pos(v) ? 1u : 0u) << cc;
         }
       }
-      // combine the four 16-bit quarters of a pixel (adjacent lanes) into one 64-bit word
+      // the four 8-bit groups of a pixel sit in adjacent lanes: one 32-bit half of the uint64 word
       const uint32_t b1 = __shfl_down(bits, 1, 64), b2 = __shfl_down(bits, 2, 64),
                      b3 = __shfl_down(bits, 3, 64);
       if (live && q == 0 && P) {
-        const uint64_t word = (uint64_t)(bits | (b1 << 16)) | ((uint64_t)(b2 | (b3 << 16)) << 32);
-        const size_t o = ((size_t)n * Hp + py) * Wp + px;  // cw64 == 1 for 64 channels
-        P[o] = word;
-        M[o] = 0ull;
+        const size_t o = (((size_t)n * Hp + py) * Wp + px) * 2 + half;  // cw64 == 1 for 64 channels
+        reinterpret_cast<uint32_t*>(P)[o] = bits | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        reinterpret_cast<uint32_t*>(M)[o] = 0u;  // nothing is negative after ReLU
       }
+      __syncthreads();  // stage is rewritten by the next round / the next tile's input patch
     }
   }
 }
@@ -189,7 +198,9 @@ int launch_stem(const float* x, const float* w, const float* bn_a, const float* 
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
   }
-  const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
+  const int per_xcd = (int)((ntiles + 7) / 8);
+  const long long want = 2LL * cus;  // two resident workgroups per CU
+  const unsigned grid = (unsigned)(ntiles < want ? ((ntiles + 7) / 8 * 8) : want);
   const size_t lds_bytes = (size_t)LDS_FLOATS * sizeof(float);
   static bool attr_set[64] = {false};  // >64 KB of dynamic LDS needs the opt-in, once per device
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
@@ -198,7 +209,7 @@ int launch_stem(const float* x, const float* w, const float* bn_a, const float* 
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   hipLaunchKernelGGL(stem_conv_bn_relu_pool_pack_kernel, dim3(grid), dim3(NT), lds_bytes, stream, x, w,
-                     bn_a, bn_b, N, H, W, Hc, Wc, Hp, Wp, tiles_y, tiles_x, out, P, M);
+                     bn_a, bn_b, N, H, W, Hc, Wc, Hp, Wp, tiles_y, tiles_x, per_xcd, out, P, M);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
