@@ -193,8 +193,8 @@ constexpr int kFlagsOut = EF_BN | EF_RES | EF_RELU | EF_OUTF | EF_PACK;
 
 template <int NACC, int EP>
 __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
-                                         const int (&dot)[NACC], const EpiArgs& e, uint32_t& pbits,
-                                         uint32_t& mbits) {
+                                         const int (&dot)[NACC], const float (&resv)[NACC],
+                                         const EpiArgs& e, uint32_t& pbits, uint32_t& mbits) {
   constexpr bool FUSED = EP != EP_PLAIN;
   const int hw = g.Ho * g.Wo;
   const unsigned lane_off = (unsigned)(px.n * g.O * hw + px.r);  // host keeps N*O*hw < 2^30
@@ -224,14 +224,6 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
     return;
   }
   const int bit0 = o0 & 31;  // position of channel o0 inside its 32-channel output word
-  // All residual loads of the wave are issued back to back BEFORE the per-channel arithmetic:
-  // one exposed memory latency per wave instead of one per channel.
-  float resv[NACC];
-  if (f & EF_RES) {
-#pragma unroll
-    for (int j = 0; j < NACC; ++j)
-      resv[j] = (px.live && (full || o0 + j < g.O)) ? (e.res + (size_t)(o0 + j) * hw)[lane_off] : 0.0f;
-  }
 #pragma unroll
   for (int j = 0; j < NACC; ++j) {
     const int o = o0 + j;
@@ -250,6 +242,25 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
       }
     }
   }
+}
+
+// Residual (shortcut) values of NACC channels for this lane's pixel.  Called at the START of a
+// pass, before the popcount loop, so the loads land while the vector ALU is busy: the epilogue
+// then finds them in registers instead of stalling on HBM once per pass.
+template <int NACC, int EP>
+__device__ __forceinline__ void prefetch_residual(const Geo& g, const Pix& px, int o0,
+                                                  const EpiArgs& e, float (&resv)[NACC]) {
+  const int f = EP == EP_MID ? kFlagsMid : EP == EP_OUT ? kFlagsOut : g.flags;
+  if (EP == EP_PLAIN || !(f & EF_RES) || (f & EF_RAW)) {
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) resv[j] = 0.0f;
+    return;
+  }
+  const int hw = g.Ho * g.Wo;
+  const unsigned lane_off = (unsigned)(px.n * g.O * hw + px.r);
+#pragma unroll
+  for (int j = 0; j < NACC; ++j)
+    resv[j] = (px.live && o0 + j < g.O) ? (e.res + (size_t)(o0 + j) * hw)[lane_off] : 0.0f;
 }
 
 // sign(y) of one 32-channel block: one half of a uint64 word of the [n][group][y][x] output planes.
@@ -342,6 +353,8 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
 #pragma unroll 1
     for (int ps = 0; ps < PASSES; ++ps) {
       int acc[NACC];
+      float resv[NACC];
+      prefetch_residual<NACC, EP>(g, px, ob * kOCB + ps * NACC, epi, resv);
 #pragma unroll
       for (int j = 0; j < NACC; ++j) acc[j] = 0;
       if constexpr (MULTI) {
@@ -355,7 +368,7 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       }
 #pragma unroll
       for (int j = 0; j < NACC; ++j) acc[j] = nz - 2 * acc[j];  // dot = non-zeros - 2*disagreements
-      epilogue<NACC, EP>(g, px, ob * kOCB + ps * NACC, acc, epi, pbits, mbits);
+      epilogue<NACC, EP>(g, px, ob * kOCB + ps * NACC, acc, resv, epi, pbits, mbits);
     }
   }
   store_packed(g, px, ob, pbits, mbits, epi);
@@ -435,7 +448,9 @@ __global__ __launch_bounds__(kLdsWaves* kWave) void bconv_lds_kernel(
 #pragma unroll
   for (int j = 0; j < kOCB; ++j) acc[j] = nz - 2 * acc[j];  // dot = non-zero count - 2 * disagreements
   uint32_t pbits = 0u, mbits = 0u;
-  epilogue<kOCB, EP_RUNTIME>(g, px, ob * kOCB, acc, epi, pbits, mbits);
+  float resv[kOCB];
+  prefetch_residual<kOCB, EP_RUNTIME>(g, px, ob * kOCB, epi, resv);
+  epilogue<kOCB, EP_RUNTIME>(g, px, ob * kOCB, acc, resv, epi, pbits, mbits);
   store_packed(g, px, ob, pbits, mbits, epi);
 }
 
@@ -503,7 +518,9 @@ __global__ __launch_bounds__(64) void bconv_generic_kernel(
     }
   }
   uint32_t pbits = 0u, mbits = 0u;
-  epilogue<kOCB, EP_RUNTIME>(g, px, ob * kOCB, dotv, epi, pbits, mbits);
+  float resv[kOCB];
+  prefetch_residual<kOCB, EP_RUNTIME>(g, px, ob * kOCB, epi, resv);
+  epilogue<kOCB, EP_RUNTIME>(g, px, ob * kOCB, dotv, resv, epi, pbits, mbits);
   store_packed(g, px, ob, pbits, mbits, epi);
 }
 
