@@ -323,3 +323,33 @@ def test_probe_reports_a_plausible_rate():
     rate = hipops.probe_int_alu(512)["lane_ops_per_s"]
     peak = info["compute_units"] * 4 * 32 * info["clock_khz"] * 1e3
     assert 0.05 * peak < rate < 1.2 * peak
+
+
+# ------------------------------------------------------- BASELINE config 5 building blocks at net level
+@pytest.mark.parametrize("name", ["resnet50_bottleneck", "resnet_hblock", "resnet18_preact_prelu"])
+def test_config5_style_networks_hip_equals_composition(name):
+    """Mixed 1x1 / 3x3 binary convs (Bottleneck), hierarchical blocks and the imagenet.py
+    pre-activation/PReLU dataflow: the per-layer HIP path against the torch composition (the
+    reference's own formulation, itself pinned to the reference by module-level fixtures)."""
+    from bnn_amd.models import ResNet, resnet50
+    torch.manual_seed(0)
+    if name == "resnet50_bottleneck":
+        net = resnet50(num_classes=100)
+    elif name == "resnet_hblock":
+        net = ResNet(HBlock, [1, 2, 1, 1], num_classes=100)
+    else:
+        net = resnet18(block_type=PreBasicBlock, activation=nn.PReLU, num_classes=100)
+    cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=BasicScaleBinarizer,
+                      weight_pre_process=XNORWeightBinarizer.with_args(center_weights=True))
+    net = bnn.prepare_binary_model(net, cfg, ignore_layers_name=["_first_", "_last_"])
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in gen.model_state(shapes, 5).items()})
+    net.eval()
+    x = torch.from_numpy(gen.normal(gen.seed_of("c5", name), (2, 3, 64, 64)))
+    with torch.no_grad():
+        ref = net(x).numpy()                       # CPU: torch composition
+        before = fastpath.stats()["conv2d"]
+        got = net.to(DEV)(x.to(DEV)).cpu().numpy()  # GPU: XNOR/popcount kernels per layer
+    n_bin = sum(isinstance(m, bnn.layers.Conv2d) for m in net.modules())
+    assert fastpath.stats()["conv2d"] == before + n_bin and n_bin >= 8
+    assert np.allclose(got, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
