@@ -106,15 +106,19 @@ class ResNet(nn.Module):
                              count_include_pad=False),
                 conv1x1(self.inplanes, out_ch, stride=1),
                 self._norm_layer(out_ch))
-        # HBlock cannot stride (hierarchical_block.py:23-24): pool in front of the stage instead
+        # HBlock cannot stride (hierarchical_block.py:23-24): pool in front of the stage instead.
+        # Its shortcut is pre-activation style like the block itself (BN -> conv): a binary conv
+        # must not binarise a raw residual sum, whose exactly-cancelling entries are 0 in exact
+        # arithmetic but +-1e-9 in any float convolution ("exact zeros").
         pre: List[nn.Module] = []
         block_stride = stride
         if block is HBlock and stride != 1:
             pre.append(nn.AvgPool2d(kernel_size=stride, stride=stride, ceil_mode=True,
                                     count_include_pad=False))
             block_stride = 1
-            shortcut = nn.Sequential(conv1x1(self.inplanes, out_ch, stride=1),
-                                     self._norm_layer(out_ch))
+        if block is HBlock and shortcut is not None:
+            shortcut = nn.Sequential(self._norm_layer(self.inplanes),
+                                     conv1x1(self.inplanes, out_ch, stride=1))
         stage = pre + [block(self.inplanes, planes, block_stride, shortcut, self.groups,
                              self.base_width, prev_dilation, self._norm_layer,
                              activation=self._activation)]
