@@ -203,8 +203,10 @@ def _flags(w: PackedWeight, force_generic: bool, weights: Optional[str]) -> int:
         f |= native.FLAG_WEIGHTS_SGPR
     elif weights == "lds":
         f |= native.FLAG_WEIGHTS_LDS
+    elif weights == "vgpr":
+        f |= native.FLAG_WEIGHTS_VGPR
     elif weights is not None:
-        raise ValueError("weights must be None, 'sgpr' or 'lds'")
+        raise ValueError("weights must be None, 'sgpr', 'vgpr' or 'lds'")
     return f
 
 

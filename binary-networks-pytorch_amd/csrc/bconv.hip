@@ -325,12 +325,63 @@ __device__ __forceinline__ void stream_weights(const uint32_t* __restrict__ wrun
   });
 }
 
+// Same traversal, weights through the VECTOR memory path: every lane loads the same address (the
+// texture unit broadcasts one cache line), the words land in VGPRs and feed v_bitop3_b32 as a vector
+// operand.  Vector loads return in order, so `vmcnt` can be counted and PD blocks are kept in flight:
+// that is what the scalar path cannot do (SMEM returns out of order -> only lgkmcnt(0) -> one block
+// of look-ahead).  Used where the scalar cache thrashes — wide layers on small images, where many
+// (output block, chunk) weight runs are live on a CU at once and every s_load is an L2 round trip.
+template <int NW, int NACC>
+__device__ __forceinline__ void stream_weights_vgpr(const uint32_t* __restrict__ wrun, int vzero,
+                                                    const uint32_t (&pr)[NW],
+                                                    const uint32_t (&mr)[NW], int (&acc)[NACC]) {
+  constexpr int WB = (NACC * NW) % 16 == 0 ? 16 : (NACC * NW) % 8 == 0 ? 8 : 4;
+  constexpr int NB = NACC * NW / WB;
+  constexpr int PD = NB < 3 ? NB : 3;  // blocks in flight
+  using V = typename WordVec<4>::type;
+  constexpr int VPB = WB / 4;
+  const V* wq = reinterpret_cast<const V*>(wrun) + vzero;  // lane-opaque 0: keeps the load vector
+  V ring[PD][VPB];
+#pragma unroll
+  for (int b = 0; b < PD; ++b)
+#pragma unroll
+    for (int v = 0; v < VPB; ++v) ring[b][v] = wq[b * VPB + v];
+  int t0 = 0, t1 = 0;
+  static_for<NB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    constexpr int slot = b % PD;
+    uint32_t cur[WB];
+#pragma unroll
+    for (int v = 0; v < VPB; ++v) {
+      const uint32_t* e4 = reinterpret_cast<const uint32_t*>(&ring[slot][v]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cur[v * 4 + e] = e4[e];
+    }
+    if constexpr (b + PD < NB) {
+#pragma unroll
+      for (int v = 0; v < VPB; ++v) ring[slot][v] = wq[(b + PD) * VPB + v];
+    }
+    static_for<WB>([&](auto ec) {
+      constexpr int e = decltype(ec)::value;
+      constexpr int f = b * WB + e;
+      constexpr int j = f / NW, i = f % NW;
+      const uint32_t d = disagree(cur[e], mr[i], pr[i]);
+      if constexpr (i == 0) t0 = __builtin_popcount(d);
+      else if constexpr (i == 1) t1 = __builtin_popcount(d);
+      else if constexpr (i & 1) t1 = popc_acc(d, t1);
+      else t0 = popc_acc(d, t0);
+      if constexpr (i == NW - 1) acc[j] += t0 + (NW > 1 ? t1 : 0);
+    });
+  });
+}
+
 // The 32 output channels of the block are produced in PASSES runs of 32/PASSES channels: fewer
 // live accumulators (more waves per SIMD) and 1/PASSES of the unrolled code, looped.
 //   MULTI == false: the layer has ONE chunk (C <= 64*CWC/2); its field is loaded once and stays
 //                   in registers across all passes.
 //   MULTI == true : any number of chunks; each pass walks the chunks and re-loads the field.
-template <int KH, int KW, int CWC, int EP, int MINW, int PASSES, bool MULTI>
+//   WV: weights through the vector path (stream_weights_vgpr) instead of SGPRs.
+template <int KH, int KW, int CWC, int EP, int MINW, int PASSES, bool MULTI, bool WV>
 __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
     const uint32_t* __restrict__ P, const uint32_t* __restrict__ M, const uint32_t* __restrict__ W,
     BNN_EPI_PARAMS, const Geo g) {
@@ -341,6 +392,10 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
   const Pix px = decode_pixel(g, blockIdx.x * kWave + threadIdx.x);
   const int ob = blockIdx.y;
   uint32_t pbits = 0u, mbits = 0u;
+  int vzero = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (WV) asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+#endif
 
   if (ob * kOCB < g.O) {
     const uint32_t* wblk = W + (size_t)ob * g.nchunk * (kOCB * NW);
@@ -361,10 +416,14 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
         for (int ch = 0; ch < g.nchunk; ++ch) {
           load_field<KH, KW, CWC>(g, px, ch, P, M, pr, mr);
           if (ps == 0) nz = count_nonzero<NW>(pr, mr, nz);
-          stream_weights<NW, NACC>(wblk + ((size_t)ch * kOCB + ps * NACC) * NW, pr, mr, acc);
+          const uint32_t* wrun = wblk + ((size_t)ch * kOCB + ps * NACC) * NW;
+          if constexpr (WV) stream_weights_vgpr<NW, NACC>(wrun, vzero, pr, mr, acc);
+          else stream_weights<NW, NACC>(wrun, pr, mr, acc);
         }
       } else {
-        stream_weights<NW, NACC>(wblk + (size_t)ps * (NACC * NW), pr, mr, acc);
+        const uint32_t* wrun = wblk + (size_t)ps * (NACC * NW);
+        if constexpr (WV) stream_weights_vgpr<NW, NACC>(wrun, vzero, pr, mr, acc);
+        else stream_weights<NW, NACC>(wrun, pr, mr, acc);
       }
 #pragma unroll
       for (int j = 0; j < NACC; ++j) acc[j] = nz - 2 * acc[j];  // dot = non-zeros - 2*disagreements
@@ -560,50 +619,53 @@ static unsigned oblocks(const ConvP& p) {
 #ifndef BNN_SGPR_PASSES  // passes per 32-channel block, single-chunk 3x3 layers
 #define BNN_SGPR_PASSES 4
 #endif
+#ifndef BNN_DEFAULT_MULTI_VGPR  // multi-chunk 3x3 layers: weights via the vector path by default
+#define BNN_DEFAULT_MULTI_VGPR 0
+#endif
 #ifndef BNN_SGPR_PASSES_MULTI  // same, multi-chunk 3x3 layers (each pass re-loads the field)
 #define BNN_SGPR_PASSES_MULTI 1
 #endif
 
-template <int KH, int KW, int CWC, int EP, int MINW>
-static void launch_sgpr_t(const ConvP& p, const Geo& g, hipStream_t s) {
+template <int KH, int KW, int CWC, int EP>
+static void launch_sgpr_t(const ConvP& p, const Geo& g, bool wv, hipStream_t s) {
   const dim3 grid((p.npix + kWave - 1) / kWave, oblocks(p));
   constexpr bool k3 = KH * KW > 1;
-  if (k3 && p.nchunk == 1)
-    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MINW, k3 ? BNN_SGPR_PASSES : 1, false>),
-                       grid, dim3(kWave), 0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
-  else
-    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MINW, k3 ? BNN_SGPR_PASSES_MULTI : 1, true>),
-                       grid, dim3(kWave), 0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
+  constexpr int P1 = k3 ? BNN_SGPR_PASSES : 1, PM = k3 ? BNN_SGPR_PASSES_MULTI : 1;
+  if (k3 && p.nchunk == 1) {
+    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, P1, false, false>), grid, dim3(kWave),
+                       0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
+    return;
+  }
+  if constexpr (k3 && CWC == 4) {  // the only shape class with several chunks of a large field
+    if (wv) {
+      hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, 2, true, true>), grid, dim3(kWave),
+                         0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
+      return;
+    }
+    // multi-chunk 3x3: measured best with all 32 accumulators live and the register file capped for
+    // 4 waves per SIMD (tools/bench_conv.py: 512->512 7x7 b256 100 us vs 131 us uncapped/2 passes)
+    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 4, PM, true, false>), grid, dim3(kWave), 0,
+                       s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
+    return;
+  }
+  hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, PM, true, false>), grid, dim3(kWave), 0,
+                     s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
 }
 
-// MINW: waves per SIMD the kernel is register-allocated for.  One-chunk layers (C <= 128) run
-// best unconstrained (166 VGPRs, 3 waves); multi-chunk layers re-load their field per chunk and
-// gain from the 4th wave (128 VGPRs) — measured on MI355X with tools/conv_variants.sh.
 // PROFILES: whether the compile-time epilogue profiles exist for this shape (3x3 only).
 template <int KH, int KW, int CWC, bool PROFILES>
-static void launch_sgpr(const ConvP& p, hipStream_t s) {
+static void launch_sgpr(const ConvP& p, int flags, hipStream_t s) {
   const Geo g = make_geo(p);
+  // multi-chunk 3x3 layers: weight path by build default unless the caller forces one
+  const bool wv = (flags & BNN_HIP_FLAG_WEIGHTS_VGPR) ||
+                  (BNN_DEFAULT_MULTI_VGPR && !(flags & BNN_HIP_FLAG_WEIGHTS_SGPR));
   const bool fused = (g.flags & (EF_BN | EF_RES | EF_RELU | EF_PRELU | EF_PACK)) != 0;
-  const bool multi = p.nchunk > 1 && KH * KW * CWC >= 36;
   if constexpr (PROFILES) {
-    if (g.flags == kFlagsMid) {
-      if (multi) launch_sgpr_t<KH, KW, CWC, EP_MID, 4>(p, g, s);
-      else launch_sgpr_t<KH, KW, CWC, EP_MID, 1>(p, g, s);
-      return;
-    }
-    if (g.flags == kFlagsOut) {
-      if (multi) launch_sgpr_t<KH, KW, CWC, EP_OUT, 4>(p, g, s);
-      else launch_sgpr_t<KH, KW, CWC, EP_OUT, 1>(p, g, s);
-      return;
-    }
-    if (multi) {
-      if (fused) launch_sgpr_t<KH, KW, CWC, EP_RUNTIME, 4>(p, g, s);
-      else launch_sgpr_t<KH, KW, CWC, EP_PLAIN, 4>(p, g, s);
-      return;
-    }
+    if (g.flags == kFlagsMid) return launch_sgpr_t<KH, KW, CWC, EP_MID>(p, g, wv, s);
+    if (g.flags == kFlagsOut) return launch_sgpr_t<KH, KW, CWC, EP_OUT>(p, g, wv, s);
   }
-  if (fused) launch_sgpr_t<KH, KW, CWC, EP_RUNTIME, 1>(p, g, s);
-  else launch_sgpr_t<KH, KW, CWC, EP_PLAIN, 1>(p, g, s);
+  if (fused) launch_sgpr_t<KH, KW, CWC, EP_RUNTIME>(p, g, wv, s);
+  else launch_sgpr_t<KH, KW, CWC, EP_PLAIN>(p, g, wv, s);
 }
 
 template <int KH, int KW, int CWC>
@@ -637,8 +699,9 @@ int choose_cwc(int cw32, int KH, int KW) {
 }
 
 // Weight source.  Measured on MI355X (tools/bench_conv.py, tools/exp_l4.py): the SGPR stream
-// beats the LDS-staged tile on every ResNet-18 shape (e.g. 512->512 7x7 b256: 140 vs 216 us),
-// so LDS is only taken on request.
+// beats both the LDS-staged tile and the vector-broadcast path on every ResNet-18 shape
+// (512->512 7x7 b256: 100 us SGPR, 162 us VGPR broadcast, 216 us LDS), so those are only taken
+// on request.
 static bool prefer_lds(const ConvP&, int flags) { return (flags & BNN_HIP_FLAG_WEIGHTS_LDS) != 0; }
 
 int launch_bconv(const ConvP& p, int flags, hipStream_t s) {
@@ -651,7 +714,7 @@ int launch_bconv(const ConvP& p, int flags, hipStream_t s) {
 #define BNN_PICK(KH_, KW_, C_, PROF_)                           \
   if (p.KH == KH_ && p.KW == KW_ && p.cwc == C_) {              \
     if (lds && PROF_) launch_lds<KH_, KW_, C_>(p, s);           \
-    else launch_sgpr<KH_, KW_, C_, PROF_>(p, s);                \
+    else launch_sgpr<KH_, KW_, C_, PROF_>(p, flags, s);         \
   } else
     BNN_PICK(3, 3, 4, true) BNN_PICK(3, 3, 2, true) BNN_PICK(1, 1, 16, false)
     BNN_PICK(1, 1, 8, false) BNN_PICK(1, 1, 4, false) BNN_PICK(1, 1, 2, false) { done = false; }

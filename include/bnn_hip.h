@@ -87,6 +87,7 @@ typedef struct bnn_hip_conv_desc {
 #define BNN_HIP_FLAG_WEIGHT_ZEROS 2  /* some sign(W) == 0: honour the wnz mask (slower kernel)  */
 #define BNN_HIP_FLAG_WEIGHTS_SGPR 4  /* tiled kernel: force the scalar-cache weight stream       */
 #define BNN_HIP_FLAG_WEIGHTS_LDS 8   /* tiled kernel: force the LDS-staged weight tile           */
+#define BNN_HIP_FLAG_WEIGHTS_VGPR 16 /* tiled kernel: force weights through the vector path    */
 
 /* Everything that happens to the integer dot after the popcount loop, fused into the conv
  * kernel so that activations can stay bit-packed between binary layers (callers:

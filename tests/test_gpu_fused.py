@@ -25,7 +25,7 @@ def u64(t):
 TILED = [c for c in LAYER_CASES if c.k in (1, 3) and c.dilation == 1 and c.winit != "withzeros"]
 
 
-@pytest.mark.parametrize("weights", ["sgpr", "lds"])
+@pytest.mark.parametrize("weights", ["sgpr", "vgpr", "lds"])
 @pytest.mark.parametrize("case", TILED, ids=lambda c: c.name)
 def test_weight_source_variants_bit_exact(case, weights):
     """Scalar-cache weight stream and LDS-staged weight tile compute the same integers."""

@@ -35,6 +35,7 @@ def main():
     N = int(os.environ.get("BATCH", "256"))
     iters = int(os.environ.get("ITERS", "20"))
     only = os.environ.get("ONLY")
+    wsel = os.environ.get("WEIGHTS") or None
     dev = torch.device("cuda:0")
     info = native.device_info(0)
     peak = info["compute_units"] * 64 * info["clock_khz"] * 1e3  # CUs x 64 x f_clk
@@ -46,12 +47,12 @@ def main():
         w = torch.from_numpy(gen.conv_weight("kaiming", 8, (O, C, k, k))).to(dev)
         pw, act = hipops.pack_weight(w), hipops.pack_act(x)
         for _ in range(3):
-            out = hipops.bconv2d(act, pw, stride=s, padding=p)
+            out = hipops.bconv2d(act, pw, stride=s, padding=p, weights=wsel)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(iters):
-            out = hipops.bconv2d(act, pw, stride=s, padding=p)
+            out = hipops.bconv2d(act, pw, stride=s, padding=p, weights=wsel)
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / iters
