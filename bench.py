@@ -102,13 +102,15 @@ def conv_c2_roofline(device, info, batch=256, iters=20, act_kind="relu"):
     K = C * 9
     lane_ops = 2.0 * ((K + 31) // 32) * N * O * H * W           # algorithmic: xor + popcount per 32 MACs
     peak = int_alu_peak(info)
-    in_bytes = N * H * W * (2 * 2 * 8 + 2)                       # packed planes + nzc
+    in_bytes = N * H * W * (2 * 2 * 8)                           # two planes x 2 uint64 words per pixel
     out_bytes = N * O * H * W * 4
     del out
+    traffic, traffic_note = pmc_traffic()
     return {
         "bound": "int_alu", "kernel": "bconv_sgpr_kernel<3,3,4>", "workload": "conv3x3 128->128 56x56 b256",
         "achieved": lane_ops / t_conv / 1e12, "peak": peak / 1e12, "unit": "Tlane-op/s",
-        "frac": lane_ops / t_conv / peak, "traffic": None,
+        "frac": lane_ops / t_conv / peak, "traffic": traffic, "traffic_note": traffic_note,
+        "algorithmic_bytes": in_bytes + out_bytes + O * K // 8,
         "avg_kernel_us": t_conv * 1e6, "images_per_s_kernel": N / t_conv,
         "images_per_s_fp32_in_out": N / (t_conv + t_pack),
         "hbm": {"conv_GBps": (in_bytes + out_bytes) / t_conv / 1e9,
@@ -119,6 +121,22 @@ def conv_c2_roofline(device, info, batch=256, iters=20, act_kind="relu"):
         "frac_of_simd32_peak": lane_ops / t_conv / simd32_peak(info),
         "act": act_kind,
     }
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the graded kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_c2_pmc_counters.json, collected by tools/gpu_profile.sh with separate --pmc runs).
+    FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
+    (checked on this box: pack_act's 411 MB float4 stream reads as 205 MB)."""
+    path = os.path.join(ROOT, "profiles", "r01_c2_pmc_counters.json")
+    try:
+        with open(path) as fh:
+            pmc = json.load(fh)
+        k = next(v for name, v in pmc.items() if "bconv_sgpr_kernel" in name)
+        return (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024, \
+            "2*FETCH_SIZE + WRITE_SIZE from profiles/r01_c2_pmc_counters.json (same kernel, same shape)"
+    except (OSError, StopIteration, KeyError, ValueError):
+        return None, "no PMC summary committed"
 
 
 def cpu_baseline(sample_batch=64, iters=6):

@@ -34,6 +34,8 @@ struct Geo {
   int npix;      // N*Ho*Wo
   int flags;     // EF_*
   int cw32_out;  // words per pixel per plane of the packed OUTPUT (EF_PACK)
+  int tiles;     // 64-pixel tiles of the output
+  int tiles_per_xcd;  // ceil(tiles / 8)
 };
 
 enum : int {
@@ -389,8 +391,16 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
   constexpr int NW = T * CWC;  // words per (o, chunk)
   constexpr int NACC = kOCB / PASSES;
   BNN_EPI_INIT;
-  const Pix px = decode_pixel(g, blockIdx.x * kWave + threadIdx.x);
-  const int ob = blockIdx.y;
+  // XCD-aware work order (1-D grid).  Workgroup b runs on XCD b % 8 (observed placement; only
+  // speed depends on it).  Each XCD owns ONE contiguous eighth of the pixel tiles and walks it
+  // once per output-channel block: its slice of the packed input (1/8 of a few tens of MB) stays
+  // in that XCD's 4 MB L2 across the blocks and across the 3-row halos of neighbouring tiles,
+  // instead of every XCD streaming the whole input once per block.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ob = slot / g.tiles_per_xcd;
+  const int tile = xcd * g.tiles_per_xcd + (slot - ob * g.tiles_per_xcd);
+  if (tile >= g.tiles) return;
+  const Pix px = decode_pixel(g, tile * kWave + threadIdx.x);
   uint32_t pbits = 0u, mbits = 0u;
   int vzero = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -593,6 +603,8 @@ static Geo make_geo(const ConvP& p) {
   g.dh = p.dh; g.dw = p.dw; g.cw32 = p.cw32; g.cwc = p.cwc; g.nchunk = p.nchunk;
   g.npix = p.npix;
   g.cw32_out = 2 * ((p.O + 63) / 64);
+  g.tiles = (p.npix + kWave - 1) / kWave;
+  g.tiles_per_xcd = (g.tiles + 7) / 8;
   int f = 0;
   if (p.raw) f |= EF_RAW;
   if (p.bias) f |= EF_BIAS;
@@ -628,7 +640,7 @@ static unsigned oblocks(const ConvP& p) {
 
 template <int KH, int KW, int CWC, int EP>
 static void launch_sgpr_t(const ConvP& p, const Geo& g, bool wv, hipStream_t s) {
-  const dim3 grid((p.npix + kWave - 1) / kWave, oblocks(p));
+  const dim3 grid((unsigned)(8 * g.tiles_per_xcd) * oblocks(p));  // see the XCD note in the kernel
   constexpr bool k3 = KH * KW > 1;
   constexpr int P1 = k3 ? BNN_SGPR_PASSES : 1, PM = k3 ? BNN_SGPR_PASSES_MULTI : 1;
   if (k3 && p.nchunk == 1) {
