@@ -83,6 +83,8 @@ def pack_act(x: torch.Tensor) -> PackedAct:
         raise native.NativeError(f"bnn_amd: pack_act expects NCHW, got shape {tuple(x.shape)}")
     lib = native.require()
     N, C, H, W = x.shape
+    if N == 0:  # empty batch: nothing to launch (the reference's conv2d returns an empty tensor too)
+        return empty_packed(0, C, H, W, x.device)
     with torch.cuda.device(x.device):
         a = empty_packed(N, C, H, W, x.device)
         native.check(lib.bnn_hip_pack_act_f32(x.data_ptr(), N, C, H, W, a.P.data_ptr(),
@@ -224,6 +226,8 @@ def bconv2d(a: PackedAct, w: PackedWeight, bias: Optional[torch.Tensor] = None,
     with torch.cuda.device(dev):
         out = torch.empty((d.N, d.O, ho, wo), dtype=torch.int32 if raw_dot else torch.float32,
                           device=dev)
+        if d.N == 0:
+            return out
         # one launch addresses < 2^31 elements: split the batch when a tensor is larger
         per_img = max(d.O * ho * wo, d.H * d.W)
         step = max(1, min(d.N, _MAX_ELEMS // max(per_img, 1)))

@@ -353,3 +353,50 @@ def test_config5_style_networks_hip_equals_composition(name):
     n_bin = sum(isinstance(m, bnn.layers.Conv2d) for m in net.modules())
     assert fastpath.stats()["conv2d"] == before + n_bin and n_bin >= 8
     assert np.allclose(got, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+
+
+# ------------------------------------------------------------------ edge cases of the host side
+def test_empty_batch_and_noncontiguous_inputs(golden_layers):
+    layer, x = make_layer(LAYER_CASES_BY_NAME["c2_relu"])
+    with torch.no_grad():
+        assert layer(torch.empty((0, 128, 12, 12), device=DEV)).shape == (0, 128, 12, 12)
+        xd = dev(x)
+        ref = layer(xd)
+        cl = xd.contiguous(memory_format=torch.channels_last)        # same values, NHWC strides
+        assert torch.equal(layer(cl), ref)
+        wide = torch.zeros((2, 128, 12, 20), device=DEV)
+        wide[..., 4:16] = xd
+        assert torch.equal(layer(wide[..., 4:16]), ref)              # strided view
+
+
+def test_batch_splitting_path_matches_single_launch(monkeypatch):
+    case = LAYER_CASES_BY_NAME["l2_ds_1x1"]
+    x, w, _, _ = case.tensors()
+    act, pw = hipops.pack_act(dev(np.concatenate([x] * 4))), hipops.pack_weight(dev(w))
+    whole = hipops.bconv2d(act, pw)
+    monkeypatch.setattr(hipops, "_MAX_ELEMS", 3 * 128 * 14 * 14)    # forces launches of <= 3 images
+    assert torch.equal(hipops.bconv2d(act, pw), whole)
+    assert torch.equal(hipops.bconv2d(act, pw, raw_dot=True), hipops.bconv2d(act, pw, raw_dot=True))
+
+
+def test_runs_on_the_current_side_stream():
+    case = LAYER_CASES_BY_NAME["c2_relu"]
+    x, w, _, _ = case.tensors()
+    xd, wd = dev(x), dev(w)
+    ref = hipops.bconv2d(hipops.pack_act(xd), hipops.pack_weight(wd), stride=1, padding=1)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out = hipops.bconv2d(hipops.pack_act(xd), hipops.pack_weight(wd), stride=1, padding=1)
+    side.synchronize()
+    assert torch.equal(out, ref)
+
+
+def test_half_precision_and_grad_mode_take_the_composition_path():
+    layer, x = make_layer(LAYER_CASES_BY_NAME["c2_relu"])
+    before = fastpath.stats()["conv2d"]
+    y = layer(dev(x).requires_grad_(True))          # autograd recording
+    y.sum().backward()
+    with torch.no_grad():
+        layer.half()(dev(x).half())                 # fp16 model: not the fp32 HIP path
+    assert fastpath.stats()["conv2d"] == before
