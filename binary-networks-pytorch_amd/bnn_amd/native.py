@@ -93,7 +93,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_weight_layout.argtypes = [_i, _i, _i, _i, ctypes.POINTER(WLayout)]
     lib.bnn_hip_pack_act_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _vp]
     lib.bnn_hip_avgpool_pack_f32.argtypes = [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]
-    lib.bnn_hip_stem7x7_bn_relu_pool_pack_f32.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]
+    lib.bnn_hip_stem7x7_bn_relu_pool_pack_f32.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]
     lib.bnn_hip_bn_relu_maxpool_pack_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i,
                                                      _vp, _vp, _vp, _vp]
     lib.bnn_hip_pack_weight_f32.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]

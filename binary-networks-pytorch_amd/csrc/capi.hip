@@ -159,8 +159,8 @@ int bnn_hip_bn_relu_maxpool_pack_f32(const float* x, int N, int C, int H, int W,
 }
 
 int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w, const float* bn_scale,
-                                          const float* bn_shift, int N, int H, int W, float* out_f32,
-                                          uint64_t* P, uint64_t* M, void* stream) {
+                                          const float* bn_shift, int N, int H, int W, int flags,
+                                          float* out_f32, uint64_t* P, uint64_t* M, void* stream) {
   if (!x || !w || !bn_scale || !bn_shift || N <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
   if (!out_f32 && !P) return BNN_HIP_ERR_INVALID_ARG;
   if ((P == nullptr) != (M == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
@@ -168,7 +168,7 @@ int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w, const 
   if ((long long)N * 3 * H * W > kMaxElems || (long long)N * 64 * H * W / 16 > kMaxElems)
     return BNN_HIP_ERR_TOO_LARGE;
   g_launches.fetch_add(1, std::memory_order_relaxed);
-  return bnn::launch_stem(x, w, bn_scale, bn_shift, N, H, W, out_f32, P, M,
+  return bnn::launch_stem(x, w, bn_scale, bn_shift, N, H, W, flags & BNN_HIP_STEM_EXACT_FP32, out_f32, P, M,
                           static_cast<hipStream_t>(stream));
 }
 

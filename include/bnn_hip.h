@@ -177,11 +177,15 @@ int bnn_hip_bn_relu_maxpool_pack_f32(const float* x, int N, int C, int H, int W,
  * (bnn/models/resnet.py:93-96,150-153): conv 7x7 / stride 2 / pad 3, 3 -> 64 channels, no bias
  * (w: float32 [64,3,7,7]) -> y*bn_scale[c] + bn_shift[c] -> ReLU -> MaxPool 3x3 / 2 / 1.
  * x: float32 [N,3,H,W].  Outputs (either may be NULL): out_f32 [N,64,Hp,Wp] and its sign planes
- * P, M ([N,1,Hp,Wp] uint64), Hp = ((H-1)/2 + 1 - 1)/2 + 1 (56 for H = 224).  fp32 matrix-core
- * arithmetic (v_mfma_f32_16x16x4_f32): same rounding class as an fp32 convolution.            */
+ * P, M ([N,1,Hp,Wp] uint64), Hp = ((H-1)/2 + 1 - 1)/2 + 1 (56 for H = 224).
+ * flags = 0: fp32 operands split into fp16 hi+lo halves (22 mantissa bits), products as
+ *            hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with fp32 accumulation — error
+ *            ~3e-7 relative, the rounding class of an fp32 convolution, at 3/16 of the matrix time;
+ * flags = BNN_HIP_STEM_EXACT_FP32: v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 fmaf chain.     */
+#define BNN_HIP_STEM_EXACT_FP32 1
 int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w,
                                           const float* bn_scale, const float* bn_shift,
-                                          int N, int H, int W,
+                                          int N, int H, int W, int flags,
                                           float* out_f32, uint64_t* P, uint64_t* M, void* stream);
 
 /* XNOR-Net weight binarisation.  w: float32 [O,C,KH,KW] contiguous.
