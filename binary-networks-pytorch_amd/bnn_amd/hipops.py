@@ -55,9 +55,12 @@ class PackedAct:
     P: torch.Tensor
     M: torch.Tensor
     shape: Tuple[int, int, int, int]  # logical (N, C, H, W)
+    # True when the producer guarantees M == 0 everywhere (values out of a ReLU are {0,+1}): the
+    # 3x3 kernels then keep only the P plane in registers (BNN_HIP_FLAG_ACT_NONNEG).
+    nonneg: bool = False
 
     def batch_slice(self, n0: int, n1: int) -> "PackedAct":
-        return PackedAct(self.P[n0:n1], self.M[n0:n1], (n1 - n0,) + tuple(self.shape[1:]))
+        return PackedAct(self.P[n0:n1], self.M[n0:n1], (n1 - n0,) + tuple(self.shape[1:]), self.nonneg)
 
 
 @dataclass
@@ -93,9 +96,10 @@ def pack_act(x: torch.Tensor) -> PackedAct:
     return a
 
 
-def avgpool_pack(x: torch.Tensor, k: int) -> PackedAct:
+def avgpool_pack(x: torch.Tensor, k: int, nonneg: bool = False) -> PackedAct:
     """``AvgPool2d(k, k, ceil_mode=True, count_include_pad=False)`` + sign, fused
-    (shortcut branch of bnn/models/resnet.py:128-133)."""
+    (shortcut branch of bnn/models/resnet.py:128-133).  ``nonneg``: the caller knows ``x >= 0``
+    (it is a ReLU output), so the averages are too."""
     x = _require_cuda_f32(x, "activation")
     lib = native.require()
     N, C, H, W = x.shape
@@ -105,6 +109,7 @@ def avgpool_pack(x: torch.Tensor, k: int) -> PackedAct:
         native.check(lib.bnn_hip_avgpool_pack_f32(x.data_ptr(), N, C, H, W, k, a.P.data_ptr(),
                                                   a.M.data_ptr(), _stream(x.device)),
                      "bnn_hip_avgpool_pack_f32")
+    a.nonneg = bool(nonneg)
     return a
 
 
@@ -130,6 +135,8 @@ def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: 
             1 if exact_fp32 else 0, _ptr(y),
             None if pk is None else pk.P.data_ptr(), None if pk is None else pk.M.data_ptr(),
             _stream(x.device)), "bnn_hip_stem7x7_bn_relu_pool_pack_f32")
+    if pk is not None:
+        pk.nonneg = True  # ReLU output
     return y, pk
 
 
@@ -150,6 +157,8 @@ def bn_relu_maxpool_pack(x: torch.Tensor, bn_scale=None, bn_shift=None, relu: bo
             x.data_ptr(), N, C, H, W, _ptr(bn_scale), _ptr(bn_shift), int(bool(relu)), k, stride, pad,
             _ptr(y), None if pk is None else pk.P.data_ptr(), None if pk is None else pk.M.data_ptr(),
             _stream(x.device)), "bnn_hip_bn_relu_maxpool_pack_f32")
+    if pk is not None:
+        pk.nonneg = bool(relu)
     return y, pk
 
 
@@ -199,9 +208,11 @@ def _desc(act_shape, w_shape, stride, padding, dilation, flags) -> native.ConvDe
     return native.ConvDesc(N, C, H, W, O, KH, KW, sh, sw, ph, pw, dh, dw, flags)
 
 
-def _flags(w: PackedWeight, force_generic: bool, weights: Optional[str]) -> int:
+def _flags(w: PackedWeight, force_generic: bool, weights: Optional[str], a: Optional[PackedAct] = None) -> int:
     f = (native.FLAG_FORCE_GENERIC if force_generic else 0) | \
         (native.FLAG_WEIGHT_ZEROS if w.has_zero else 0)
+    if a is not None and a.nonneg:
+        f |= native.FLAG_ACT_NONNEG
     if weights == "sgpr":
         f |= native.FLAG_WEIGHTS_SGPR
     elif weights == "lds":
@@ -219,7 +230,7 @@ def bconv2d(a: PackedAct, w: PackedWeight, bias: Optional[torch.Tensor] = None,
             weights: Optional[str] = None) -> torch.Tensor:
     """Binary convolution on packed operands -> fp32 NCHW (or int32 dot when ``raw_dot``)."""
     lib = native.require()
-    d = _desc(a.shape, w.shape, stride, padding, dilation, _flags(w, force_generic, weights))
+    d = _desc(a.shape, w.shape, stride, padding, dilation, _flags(w, force_generic, weights, a))
     ho, wo = conv_out_hw(d.H, d.W, d.KH, d.KW, stride, padding, dilation)
     dev = a.P.device
     bias = _per_channel(bias, d.O, "bias")
@@ -254,7 +265,7 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
     """Binary convolution + fused epilogue (see ``bnn_hip_epilogue``): returns
     ``(y_fp32 | None, PackedAct(sign(y)) | None)``."""
     lib = native.require()
-    d = _desc(a.shape, w.shape, stride, padding, dilation, _flags(w, force_generic, weights))
+    d = _desc(a.shape, w.shape, stride, padding, dilation, _flags(w, force_generic, weights, a))
     ho, wo = conv_out_hw(d.H, d.W, d.KH, d.KW, stride, padding, dilation)
     if d.N * max(d.O * ho * wo, d.H * d.W) > _MAX_ELEMS:
         raise native.NativeError("bnn_amd: bconv2d_fused: split the batch (tensor > 2^31-1 elements)")
@@ -279,6 +290,8 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
                                                w.wbits.data_ptr(), w.wnz.data_ptr(),
                                                ctypes.byref(e), _stream(dev)),
                      "bnn_hip_bconv2d_fused")
+    if pk is not None:
+        pk.nonneg = bool(relu) and prelu is None  # relu is applied before prelu: y >= 0
     return y, pk
 
 

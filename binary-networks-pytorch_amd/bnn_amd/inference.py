@@ -169,7 +169,7 @@ class FusedResNet(nn.Module):
         last = len(self._blocks) - 1
         for i, b in enumerate(self._blocks):
             if b["ds"] is not None:
-                sc_in = hipops.avgpool_pack(t, b["pool"]) if b["pool"] > 1 else packed
+                sc_in = hipops.avgpool_pack(t, b["pool"], nonneg=packed.nonneg) if b["pool"] > 1 else packed
                 idn, _ = b["ds"].run(sc_in, out_f32=True, out_packed=False)
             else:
                 idn = t

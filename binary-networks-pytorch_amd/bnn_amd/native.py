@@ -21,6 +21,7 @@ FLAG_WEIGHT_ZEROS = 2
 FLAG_WEIGHTS_SGPR = 4
 FLAG_WEIGHTS_LDS = 8
 FLAG_WEIGHTS_VGPR = 16
+FLAG_ACT_NONNEG = 32
 ABI_VERSION = 2
 
 # every symbol include/bnn_hip.h declares (tests assert the .so exports all of them)

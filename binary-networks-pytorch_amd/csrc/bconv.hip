@@ -128,7 +128,9 @@ __device__ __forceinline__ Pix decode_pixel(const Geo& g, int q) {
 
 // Receptive field of one chunk: T taps x CWC words x 2 planes into registers.  Taps that fall
 // into the zero padding yield P = M = 0 (padding is applied after sign(): conv.py:91-92).
-template <int KH, int KW, int CWC>
+// NN ("non-negative"): the caller guarantees the M plane is all zero (activations out of a ReLU are
+// {0,+1}); only P is loaded and `mr` stays dead, which halves the field's registers and loads.
+template <int KH, int KW, int CWC, bool NN = false>
 __device__ __forceinline__ void load_field(const Geo& g, const Pix& px, int ch,
                                            const uint32_t* __restrict__ P,
                                            const uint32_t* __restrict__ M,
@@ -151,24 +153,25 @@ __device__ __forceinline__ void load_field(const Geo& g, const Pix& px, int ch,
       uint32_t pv[2], mv[2];
       const size_t w = (img + (size_t)gi * plane + pix) * 2;
       load_words<2>(P, w, pv);
-      load_words<2>(M, w, mv);
+      if constexpr (!NN) load_words<2>(M, w, mv);
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         pr[t * CWC + gi * 2 + e] = ok ? pv[e] : 0u;
-        mr[t * CWC + gi * 2 + e] = ok ? mv[e] : 0u;
+        mr[t * CWC + gi * 2 + e] = (!NN && ok) ? mv[e] : 0u;
       }
     }
   }
 }
 
-template <int NW>
+template <int NW, bool NN = false>
 __device__ __forceinline__ int count_nonzero(const uint32_t (&pr)[NW], const uint32_t (&mr)[NW],
                                              int nz) {
   int a = nz, b = 0;
 #pragma unroll
   for (int i = 0; i < NW; ++i) {
-    if (i & 1) b = popc_acc(pr[i] | mr[i], b);
-    else a = popc_acc(pr[i] | mr[i], a);
+    const uint32_t v = NN ? pr[i] : (pr[i] | mr[i]);
+    if (i & 1) b = popc_acc(v, b);
+    else a = popc_acc(v, a);
   }
   return a + b;
 }
@@ -275,6 +278,25 @@ __device__ __forceinline__ void store_packed(const Geo& g, const Pix& px, int ob
   e.outM[w] = mbits;
 }
 
+// Same, for a wave that produced only part `part` of PARTS of the block's 32 channels (their bits
+// already sit at their final position inside the 32-bit word).
+template <int PARTS>
+__device__ __forceinline__ void store_packed_part(const Geo& g, const Pix& px, int ob, int part,
+                                                  uint32_t pbits, uint32_t mbits, const EpiArgs& e) {
+  static_assert(PARTS == 2 || PARTS == 4, "16- or 8-bit pieces");
+  if (!(g.flags & EF_PACK) || (g.flags & EF_RAW) || !px.live) return;
+  const int hw = g.Ho * g.Wo;
+  const size_t w = ((((size_t)px.n * (g.cw32_out >> 1) + (ob >> 1)) * hw + px.r) << 1) + (ob & 1);
+  constexpr int BITS = 32 / PARTS;
+  if constexpr (PARTS == 2) {
+    reinterpret_cast<uint16_t*>(e.outP)[w * 2 + part] = (uint16_t)(pbits >> (BITS * part));
+    reinterpret_cast<uint16_t*>(e.outM)[w * 2 + part] = (uint16_t)(mbits >> (BITS * part));
+  } else {
+    reinterpret_cast<uint8_t*>(e.outP)[w * 4 + part] = (uint8_t)(pbits >> (BITS * part));
+    reinterpret_cast<uint8_t*>(e.outM)[w * 4 + part] = (uint8_t)(mbits >> (BITS * part));
+  }
+}
+
 #define BNN_EPI_PARAMS                                                                          \
   const float *__restrict__ alpha, const float *__restrict__ bias, const float *__restrict__ scale, \
       const float *__restrict__ bn_a, const float *__restrict__ bn_b,                           \
@@ -291,30 +313,78 @@ __device__ __forceinline__ void store_packed(const Geo& g, const Pix& px, int ob
 // buffers and accumulates the disagreement counts of NACC output channels.  SMEM returns out of
 // order, so the only usable wait is lgkmcnt(0): `cur` is touched first so that this wait lands
 // BEFORE block b+1 is requested; b+1 then has the whole VALU block (32 instructions) to arrive.
-template <int NW, int NACC>
+#ifndef BNN_MULTI_RES_EARLY
+#define BNN_MULTI_RES_EARLY 0
+#endif
+
+// One block of the weight stream = WB wave-uniform words, fetched as s_load_dwordx16/x8/x4 pieces.
+template <int WB>
+struct WStream {
+  uint32_t v[WB];
+};
+template <int WB>
+__device__ __forceinline__ void load_wblock(const uint32_t* __restrict__ src, WStream<WB>& d) {
+  static_assert(WB % 4 == 0, "whole dwordx4 pieces");
+  constexpr int N16 = WB / 16, R = WB % 16;
+#pragma unroll
+  for (int i = 0; i < N16; ++i) {
+    const WBlock<16> t = *reinterpret_cast<const WBlock<16>*>(src + 16 * i);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) d.v[16 * i + e] = t.v[e];
+  }
+  if constexpr (R >= 8) {
+    const WBlock<8> t = *reinterpret_cast<const WBlock<8>*>(src + 16 * N16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d.v[16 * N16 + e] = t.v[e];
+  }
+  if constexpr (R % 8 == 4) {
+    const WBlock<4> t = *reinterpret_cast<const WBlock<4>*>(src + WB - 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d.v[WB - 4 + e] = t.v[e];
+  }
+}
+
+#ifndef BNN_WSTREAM_BLOCK  // preferred words per block of the scalar weight stream
+#define BNN_WSTREAM_BLOCK 32
+#endif
+constexpr int pick_wblock(int total) {
+  constexpr int pref = BNN_WSTREAM_BLOCK;
+  for (int wb = pref; wb >= 4; wb -= 4)
+    if (total % wb == 0) return wb;
+  return 4;
+}
+
+// The look-ahead is ONE block (see above), so the block must be long enough for the next one to
+// arrive while it is consumed: a scalar load that misses to L2 takes ~700 cycles, a block of WB
+// words keeps the SIMD busy for 8*WB cycles per resident wave.  With 16-word blocks that needs
+// >= 6 waves per SIMD; 32-word blocks (two s_load_dwordx16) need 3.
+// NN: `acc` counts AGREEMENTS, popcount(w & p) (one 4-byte VOP2 v_and + v_bcnt), instead of
+// disagreements; the caller turns them into the dot product with dot = 2*agree - nonzeros.
+template <int NW, int NACC, bool NN = false>
 __device__ __forceinline__ void stream_weights(const uint32_t* __restrict__ wrun,
                                                const uint32_t (&pr)[NW], const uint32_t (&mr)[NW],
                                                int (&acc)[NACC]) {
-  constexpr int WB = (NACC * NW) % 16 == 0 ? 16 : (NACC * NW) % 8 == 0 ? 8 : 4;
+  constexpr int WB = pick_wblock(NACC * NW);
   constexpr int NB = NACC * NW / WB;
   static_assert((NACC * NW) % WB == 0, "weight run must be a whole number of blocks");
-  const WBlock<WB>* wq = reinterpret_cast<const WBlock<WB>*>(wrun);
-  WBlock<WB> cur = wq[0];
+  WStream<WB> cur;
+  load_wblock<WB>(wrun, cur);
   int t0 = 0, t1 = 0;  // two accumulation chains per channel (even / odd words)
   static_for<NB>([&](auto bc) {
     constexpr int b = decltype(bc)::value;
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" ::"s"(cur.v[0]), "s"(cur.v[WB - 1]));
+    asm volatile("" ::"s"(cur.v[0]), "s"(cur.v[WB > 16 ? 16 : 0]), "s"(cur.v[WB > 32 ? 32 : 0]),
+                 "s"(cur.v[WB - 1]));  // one word of every piece: all of `cur` has landed
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    WBlock<WB> nxt;
-    if constexpr (b + 1 < NB) nxt = wq[b + 1];
+    WStream<WB> nxt;
+    if constexpr (b + 1 < NB) load_wblock<WB>(wrun + (b + 1) * WB, nxt);
     __builtin_amdgcn_sched_barrier(0);
     static_for<WB>([&](auto ec) {
       constexpr int e = decltype(ec)::value;
       constexpr int f = b * WB + e;
       constexpr int j = f / NW, i = f % NW;
-      const uint32_t d = disagree(cur.v[e], mr[i], pr[i]);
+      const uint32_t d = NN ? (cur.v[e] & pr[i]) : disagree(cur.v[e], mr[i], pr[i]);
       // the first word of each chain uses the inline-constant form (v_bcnt d, 0): no v_mov
       if constexpr (i == 0) t0 = __builtin_popcount(d);
       else if constexpr (i == 1) t1 = __builtin_popcount(d);
@@ -383,7 +453,12 @@ __device__ __forceinline__ void stream_weights_vgpr(const uint32_t* __restrict__
 //                   in registers across all passes.
 //   MULTI == true : any number of chunks; each pass walks the chunks and re-loads the field.
 //   WV: weights through the vector path (stream_weights_vgpr) instead of SGPRs.
-template <int KH, int KW, int CWC, int EP, int MINW, int PASSES, bool MULTI, bool WV>
+//   GSPLIT: the PASSES runs of a block are separate waves (grid is PASSES times larger) instead of a
+//           loop: finer work items for the small-image layers, whose few, long waves otherwise
+//           quantise badly over the 1024 SIMDs and all reach their HBM epilogue at the same moment.
+//   NN: non-negative activations (M plane all zero, BNN_HIP_FLAG_ACT_NONNEG): P-only field.
+template <int KH, int KW, int CWC, int EP, int MINW, int PASSES, bool MULTI, bool WV, bool GSPLIT = false,
+          bool NN = false>
 __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
     const uint32_t* __restrict__ P, const uint32_t* __restrict__ M, const uint32_t* __restrict__ W,
     BNN_EPI_PARAMS, const Geo g) {
@@ -397,8 +472,10 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
   // in that XCD's 4 MB L2 across the blocks and across the 3-row halos of neighbouring tiles,
   // instead of every XCD streaming the whole input once per block.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int ob = slot / g.tiles_per_xcd;
-  const int tile = xcd * g.tiles_per_xcd + (slot - ob * g.tiles_per_xcd);
+  const int obp = slot / g.tiles_per_xcd;  // (block, part) when GSPLIT
+  const int ob = GSPLIT ? obp / PASSES : obp;
+  const int part = GSPLIT ? obp - ob * PASSES : 0;
+  const int tile = xcd * g.tiles_per_xcd + (slot - obp * g.tiles_per_xcd);
   if (tile >= g.tiles) return;
   const Pix px = decode_pixel(g, tile * kWave + threadIdx.x);
   uint32_t pbits = 0u, mbits = 0u;
@@ -412,35 +489,42 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
     uint32_t pr[NW], mr[NW];
     int nz = 0;
     if constexpr (!MULTI) {
-      load_field<KH, KW, CWC>(g, px, 0, P, M, pr, mr);
-      nz = count_nonzero<NW>(pr, mr, 0);
+      load_field<KH, KW, CWC, NN>(g, px, 0, P, M, pr, mr);
+      nz = count_nonzero<NW, NN>(pr, mr, 0);
     }
 #pragma unroll 1
-    for (int ps = 0; ps < PASSES; ++ps) {
+    for (int ps = GSPLIT ? part : 0; ps < (GSPLIT ? part + 1 : PASSES); ++ps) {
       int acc[NACC];
       float resv[NACC];
-      prefetch_residual<NACC, EP>(g, px, ob * kOCB + ps * NACC, epi, resv);
+      // single-chunk: shortcut values are requested before the popcount loop and land under it.
+      // multi-chunk: the field + 32 accumulators already fill the 128-VGPR budget of 4 waves/SIMD;
+      // holding NACC more values across the loop spills (39 VGPRs measured), so they are fetched late.
+      constexpr bool RES_EARLY = !MULTI || BNN_MULTI_RES_EARLY;
+      if constexpr (RES_EARLY) prefetch_residual<NACC, EP>(g, px, ob * kOCB + ps * NACC, epi, resv);
 #pragma unroll
       for (int j = 0; j < NACC; ++j) acc[j] = 0;
       if constexpr (MULTI) {
         for (int ch = 0; ch < g.nchunk; ++ch) {
-          load_field<KH, KW, CWC>(g, px, ch, P, M, pr, mr);
-          if (ps == 0) nz = count_nonzero<NW>(pr, mr, nz);
+          load_field<KH, KW, CWC, NN>(g, px, ch, P, M, pr, mr);
+          if (GSPLIT || ps == 0) nz = count_nonzero<NW, NN>(pr, mr, nz);
           const uint32_t* wrun = wblk + ((size_t)ch * kOCB + ps * NACC) * NW;
           if constexpr (WV) stream_weights_vgpr<NW, NACC>(wrun, vzero, pr, mr, acc);
-          else stream_weights<NW, NACC>(wrun, pr, mr, acc);
+          else stream_weights<NW, NACC, NN>(wrun, pr, mr, acc);
         }
       } else {
         const uint32_t* wrun = wblk + (size_t)ps * (NACC * NW);
         if constexpr (WV) stream_weights_vgpr<NW, NACC>(wrun, vzero, pr, mr, acc);
-        else stream_weights<NW, NACC>(wrun, pr, mr, acc);
+        else stream_weights<NW, NACC, NN>(wrun, pr, mr, acc);
       }
+      if constexpr (!RES_EARLY) prefetch_residual<NACC, EP>(g, px, ob * kOCB + ps * NACC, epi, resv);
 #pragma unroll
-      for (int j = 0; j < NACC; ++j) acc[j] = nz - 2 * acc[j];  // dot = non-zeros - 2*disagreements
+      for (int j = 0; j < NACC; ++j)  // dot = non-zeros - 2*disagreements = 2*agreements - non-zeros
+        acc[j] = NN ? 2 * acc[j] - nz : nz - 2 * acc[j];
       epilogue<NACC, EP>(g, px, ob * kOCB + ps * NACC, acc, resv, epi, pbits, mbits);
     }
   }
-  store_packed(g, px, ob, pbits, mbits, epi);
+  if constexpr (GSPLIT) store_packed_part<PASSES>(g, px, ob, part, pbits, mbits, epi);
+  else store_packed(g, px, ob, pbits, mbits, epi);
 }
 
 // ---------------------------------------------------------------------------------
@@ -638,30 +722,62 @@ static unsigned oblocks(const ConvP& p) {
 #define BNN_SGPR_PASSES_MULTI 1
 #endif
 
-template <int KH, int KW, int CWC, int EP>
+#ifndef BNN_MULTI_GSPLIT  // pieces a 32-channel block of a multi-chunk 3x3 layer is split into (1 = off)
+#define BNN_MULTI_GSPLIT 2
+#endif
+#ifndef BNN_GSPLIT_MAX_WAVES  // ...when the unsplit launch has at most this many waves
+#define BNN_GSPLIT_MAX_WAVES 16384
+#endif
+
+#ifndef BNN_NN_MULTI_MINW  // waves per SIMD the non-negative multi-chunk kernels are allocated for
+#define BNN_NN_MULTI_MINW 1
+#endif
+
+// NN: the caller vouches for an all-zero M plane (BNN_HIP_FLAG_ACT_NONNEG); 3x3 kernels only.
+template <int KH, int KW, int CWC, int EP, bool NN>
 static void launch_sgpr_t(const ConvP& p, const Geo& g, bool wv, hipStream_t s) {
   const dim3 grid((unsigned)(8 * g.tiles_per_xcd) * oblocks(p));  // see the XCD note in the kernel
   constexpr bool k3 = KH * KW > 1;
   constexpr int P1 = k3 ? BNN_SGPR_PASSES : 1, PM = k3 ? BNN_SGPR_PASSES_MULTI : 1;
   if (k3 && p.nchunk == 1) {
-    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, P1, false, false>), grid, dim3(kWave),
-                       0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
+    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, P1, false, false, false, NN>), grid,
+                       dim3(kWave), 0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
     return;
   }
   if constexpr (k3 && CWC == 4) {  // the only shape class with several chunks of a large field
-    if (wv) {
+    if (wv && !NN) {
       hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, 2, true, true>), grid, dim3(kWave),
                          0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
       return;
     }
-    // multi-chunk 3x3: measured best with all 32 accumulators live and the register file capped for
-    // 4 waves per SIMD (tools/bench_conv.py: 512->512 7x7 b256 100 us vs 131 us uncapped/2 passes)
-    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 4, PM, true, false>), grid, dim3(kWave), 0,
-                       s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
+    // multi-chunk 3x3: all 32 accumulators live (one pass over the chunks); with both planes in
+    // registers the file is capped for 4 waves per SIMD (512->512 7x7 b256: 100 us vs 131 us
+    // uncapped / 2 passes), the P-only field fits without a cap.
+    constexpr int MW = NN ? BNN_NN_MULTI_MINW : 4;
+#if BNN_MULTI_GSPLIT > 1
+    // few pixel tiles per SIMD (ResNet layer3/4 at batch 256: 6 and 3 waves per SIMD): split the block
+    if ((long long)grid.x <= BNN_GSPLIT_MAX_WAVES) {
+      const dim3 grid2(grid.x * BNN_MULTI_GSPLIT);
+      hipLaunchKernelGGL(
+          (bconv_sgpr_kernel<KH, KW, CWC, EP, MW, BNN_MULTI_GSPLIT, true, false, true, NN>), grid2,
+          dim3(kWave), 0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
+      return;
+    }
+#endif
+    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MW, PM, true, false, false, NN>), grid,
+                       dim3(kWave), 0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
     return;
   }
-  hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, PM, true, false>), grid, dim3(kWave), 0,
-                     s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
+  hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, PM, true, false, false, NN>), grid,
+                     dim3(kWave), 0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
+}
+
+template <int KH, int KW, int CWC, int EP>
+static void launch_sgpr_e(const ConvP& p, const Geo& g, bool wv, bool nn, hipStream_t s) {
+  if constexpr (KH * KW > 1) {
+    if (nn) return launch_sgpr_t<KH, KW, CWC, EP, true>(p, g, wv, s);
+  }
+  launch_sgpr_t<KH, KW, CWC, EP, false>(p, g, wv, s);
 }
 
 // PROFILES: whether the compile-time epilogue profiles exist for this shape (3x3 only).
@@ -671,13 +787,14 @@ static void launch_sgpr(const ConvP& p, int flags, hipStream_t s) {
   // multi-chunk 3x3 layers: weight path by build default unless the caller forces one
   const bool wv = (flags & BNN_HIP_FLAG_WEIGHTS_VGPR) ||
                   (BNN_DEFAULT_MULTI_VGPR && !(flags & BNN_HIP_FLAG_WEIGHTS_SGPR));
+  const bool nn = (flags & BNN_HIP_FLAG_ACT_NONNEG) != 0;
   const bool fused = (g.flags & (EF_BN | EF_RES | EF_RELU | EF_PRELU | EF_PACK)) != 0;
   if constexpr (PROFILES) {
-    if (g.flags == kFlagsMid) return launch_sgpr_t<KH, KW, CWC, EP_MID>(p, g, wv, s);
-    if (g.flags == kFlagsOut) return launch_sgpr_t<KH, KW, CWC, EP_OUT>(p, g, wv, s);
+    if (g.flags == kFlagsMid) return launch_sgpr_e<KH, KW, CWC, EP_MID>(p, g, wv, nn, s);
+    if (g.flags == kFlagsOut) return launch_sgpr_e<KH, KW, CWC, EP_OUT>(p, g, wv, nn, s);
   }
-  if (fused) launch_sgpr_t<KH, KW, CWC, EP_RUNTIME>(p, g, wv, s);
-  else launch_sgpr_t<KH, KW, CWC, EP_PLAIN>(p, g, wv, s);
+  if (fused) launch_sgpr_e<KH, KW, CWC, EP_RUNTIME>(p, g, wv, nn, s);
+  else launch_sgpr_e<KH, KW, CWC, EP_PLAIN>(p, g, wv, nn, s);
 }
 
 template <int KH, int KW, int CWC>

@@ -88,6 +88,10 @@ typedef struct bnn_hip_conv_desc {
 #define BNN_HIP_FLAG_WEIGHTS_SGPR 4  /* tiled kernel: force the scalar-cache weight stream       */
 #define BNN_HIP_FLAG_WEIGHTS_LDS 8   /* tiled kernel: force the LDS-staged weight tile           */
 #define BNN_HIP_FLAG_WEIGHTS_VGPR 16 /* tiled kernel: force weights through the vector path    */
+#define BNN_HIP_FLAG_ACT_NONNEG 32   /* caller vouches that the M plane is ALL ZERO (activations
+                                        out of a ReLU / max-pool of a ReLU are {0,+1}): 3x3 kernels
+                                        then keep only the P plane in registers.  M must still be a
+                                        valid pointer.  A wrong promise gives wrong results.      */
 
 /* Everything that happens to the integer dot after the popcount loop, fused into the conv
  * kernel so that activations can stay bit-packed between binary layers (callers:

@@ -94,6 +94,27 @@ def test_conv_bit_exact_vs_oracle_and_close_to_reference(case, force_generic, go
         assert np.array_equal(dot, golden_layers[case.name + "/dot"].astype(np.int32))
 
 
+@pytest.mark.parametrize("case", [c for c in LAYER_CASES if c.k == 3], ids=lambda c: c.name)
+def test_nonneg_activation_kernels_bit_exact(case):
+    """BNN_HIP_FLAG_ACT_NONNEG (P-plane-only kernels for ReLU outputs, M == 0) on max(x, 0): same
+    integers and same float bits as the oracle, and as the general two-plane kernel."""
+    x, w, b, sc = case.tensors()
+    x = np.where(np.isnan(x), x, np.maximum(x, 0)).astype(np.float32)   # keep NaN probes: sign(NaN) = 0
+    act = hipops.pack_act(dev(x))
+    assert not act.nonneg and not u64(act.M).any()
+    pw = hipops.pack_weight(dev(w), case.center, case.compute_alpha)
+    kw = dict(stride=case.stride, padding=case.pad, dilation=case.dilation)
+    general = hipops.bconv2d(act, pw, raw_dot=True, **kw).cpu().numpy()
+    act.nonneg = True
+    dot = hipops.bconv2d(act, pw, raw_dot=True, **kw).cpu().numpy()
+    out = hipops.bconv2d(act, pw, None if b is None else dev(b), None if sc is None else dev(sc),
+                         **kw).cpu().numpy()
+    ref_out, ref_dot = oracle.binary_conv2d_int(x, w, b, sc, case.stride, case.pad, case.dilation,
+                                                case.center, case.compute_alpha)
+    assert np.array_equal(dot, ref_dot) and np.array_equal(dot, general)
+    assert np.array_equal(out, ref_out)
+
+
 @pytest.mark.parametrize("case", LINEAR_CASES, ids=lambda c: c.name)
 def test_linear_through_c_abi(case, golden_layers):
     import ctypes

@@ -46,6 +46,7 @@ def main():
         x = torch.from_numpy(gen.activation("relu", 7, (4, C, H, W))).to(dev).repeat(N // 4, 1, 1, 1)
         w = torch.from_numpy(gen.conv_weight("kaiming", 8, (O, C, k, k))).to(dev)
         pw, act = hipops.pack_weight(w), hipops.pack_act(x)
+        act.nonneg = os.environ.get("NONNEG") == "1"  # the synthetic input is a ReLU output: M == 0
         for _ in range(3):
             out = hipops.bconv2d(act, pw, stride=s, padding=p, weights=wsel)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -5,9 +5,10 @@ set -u
 R="$(cd "$(dirname "$0")/.." && pwd)"
 V="$R/binary-networks-pytorch_amd/bnn_amd/_lib/variants"
 declare -A CFG=(
-  [p8]="-DBNN_SGPR_PASSES=8 -DBNN_SGPR_PASSES_MULTI=2"
-  [p4m2]="-DBNN_SGPR_PASSES=4 -DBNN_SGPR_PASSES_MULTI=2"
-  [p4m1]="-DBNN_SGPR_PASSES=4 -DBNN_SGPR_PASSES_MULTI=1"
+  [nnw1]="-DBNN_NN_MULTI_MINW=1"
+  [nnw5]="-DBNN_NN_MULTI_MINW=5"
+  [nnw6]="-DBNN_NN_MULTI_MINW=6"
+  [nnw5gs1]="-DBNN_NN_MULTI_MINW=5 -DBNN_MULTI_GSPLIT=1"
 )
 if [ "${1:-build}" = "build" ]; then
   rm -rf "$V"; mkdir -p "$V"
@@ -20,5 +21,6 @@ else
   for k in "${!CFG[@]}"; do
     echo "=== $k (${CFG[$k]})"
     BNN_AMD_LIB="$V/$k/libbnn_hip.so" ONLY="${ONLY:-}" timeout 300 python "$R/tools/bench_conv.py" 2>&1 | grep -v amdgpu.ids
+    [ -n "${NET:-}" ] && BNN_AMD_LIB="$V/$k/libbnn_hip.so" timeout 300 python "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | cut -c1-200
   done
 fi
