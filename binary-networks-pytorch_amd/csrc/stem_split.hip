@@ -1,0 +1,339 @@
+// stem_split.hip — default arithmetic of the fused stem (see stem.hip for the layer and the exact mode):
+// fp32 operands split into fp16 hi + lo, product = hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with
+// fp32 accumulation (measured 3e-7 relative to an fp64 reference: the rounding class of an fp32 conv).
+// Operand range: |x| and |w| below 65504 (images and conv weights are O(1)); inf/NaN inputs give NaN.
+//
+// What differs from a textbook implicit GEMM, and why (all measured on MI355X, tools/bench_stem.py):
+//  * the split is done ONCE per input element when the patch is written to LDS (two fp16 planes), not
+//    per use: the matrix phase then has no conversion VALU work at all (it was the bottleneck);
+//  * K is laid out as 24 rows of 8: row = (c, ky), column = kx (kx = 7 and rows 21..23 carry zero
+//    weights).  A lane's 8 consecutive k of the MFMA A operand are then 8 ADJACENT halves of the patch:
+//    two ds_read2_b32 instead of 8 gathers + packing;
+//  * B (weights) never goes through LDS: a wave owns 32 of the 64 output channels and keeps their
+//    hi/lo fragments for all 6 k-steps in 96 VGPRs for the life of the persistent workgroup;
+//  * 8 waves = 4 pixel groups (4 sub-tiles of 16 conv pixels each) x 2 channel halves, one workgroup
+//    per CU.  (Measured alternative: two independent 4-wave workgroups per CU, one channel half each, so
+//    that one's matrix phase overlaps the other's pooling: 540 us vs 440 us — the phases are issue bound,
+//    not latency bound, and the patch is then fetched and split twice.)
+//  * the next tile's patch is fetched into registers during the matrix phase; tiles are walked in
+//    XCD-contiguous order;
+//  * max-pool reads each staged conv value ~3x instead of 9x: a thread owns one pooled COLUMN of one
+//    channel (17 row maxima -> 8 outputs); the sign bits of 8 channels are gathered with one ballot and
+//    leave as whole 64-bit words one tile later (byte stores from several waves into one word are slow).
+#include "bnn_dev.h"
+
+#ifndef BNN_STEM_ABL  // timing ablations only (wrong results): 1 matrix, 2 epilogue, 4 pooling, 8 fetch
+#define BNN_STEM_ABL 0
+#endif
+
+namespace bnn {
+
+namespace stem2 {
+constexpr int CIN = 3, KS = 7, COUT = 64;
+constexpr int KROWS = 24, KSTEPS = KROWS / 4;        // 6 k-steps of 32 (4 rows of 8)
+constexpr int PTH = 8, PTW = 7;                      // pooled tile
+constexpr int CTH = 2 * PTH + 1, CTW = 2 * PTW + 1;  // conv tile 17 x 15 (pool halo included)
+constexpr int MPIX = CTH * CTW;                      // 255
+constexpr int ITH = 2 * CTH + 5;                     // 39 input rows
+constexpr int ITWP = 36;                             // 35 input columns + 1 zero column (kx = 7)
+constexpr int ICHP = ITH * ITWP;                     // 1404 halves per channel
+constexpr int NINP = CIN * ICHP;                     // 4212 halves per plane
+constexpr int NROW = CIN * ITH;                      // 117 patch rows
+constexpr int NPC = ITWP / 2;                        // 18 column pairs per row
+constexpr int SM = 257;                              // stage row stride in floats (bank spread)
+constexpr int NT = 512;
+constexpr int RSTEP = NT / NPC;                      // 28 rows per sweep (504 fetching threads)
+constexpr int PER_T = (NROW + RSTEP - 1) / RSTEP;    // 5 column pairs per thread
+constexpr int SUBS = 4, TT = 2;                      // sub-tiles and channel tiles per wave
+// LDS carve (bytes)
+constexpr int OFF_HI = 0;
+constexpr int OFF_LO = OFF_HI + ((NINP * 2 + 15) / 16) * 16;
+constexpr int OFF_STAGE = OFF_LO + ((NINP * 2 + 15) / 16) * 16;
+constexpr int OFF_BITS = OFF_STAGE + COUT * SM * 4;  // sign bytes of the tile: [2][56 pixels][8]
+constexpr int LDS_BYTES = OFF_BITS + 2 * PTH * PTW * 8;
+}  // namespace stem2
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+__global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bn_a,
+    const float* __restrict__ bn_b, int N, int H, int W, int Hc, int Wc, int Hp, int Wp, int tiles_y,
+    int tiles_x, int per_xcd, float* __restrict__ out, uint64_t* __restrict__ P,
+    uint64_t* __restrict__ M) {
+  using namespace stem2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  _Float16* hiP = reinterpret_cast<_Float16*>(lds_raw + OFF_HI);
+  _Float16* loP = reinterpret_cast<_Float16*>(lds_raw + OFF_LO);
+  float* stage = reinterpret_cast<float*>(lds_raw + OFF_STAGE);
+  uint8_t* bits = lds_raw + OFF_BITS;  // double-buffered: tile t's words leave during tile t+1
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int mg = wave & 3, nh = wave >> 2;  // pixel group (4 sub-tiles), channel half
+
+  // ---- once: B fragments (hi, lo) of this wave's 2 channel tiles x 6 k-steps, in registers.
+  // MFMA 16x16x32 B operand: lane holds B[k = 8*lg + e][j = li], e = 0..7  ->  row 4*ks + lg, kx = e.
+  half8 bh[KSTEPS][TT], bl[KSTEPS][TT];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const int krow = 4 * ks + lg;
+    const int c = krow / KS, ky = krow - c * KS;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int o = 32 * nh + 16 * tt + li;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = (krow < CIN * KS && e < KS) ? w[((size_t)(o * CIN + c) * KS + ky) * KS + e] : 0.0f;
+        const _Float16 h = (_Float16)v;
+        bh[ks][tt][e] = h;
+        bl[ks][tt][e] = (_Float16)(v - (float)h);
+      }
+    }
+  }
+  // A operand: lane holds A[i = li][k = 8*lg + e] = patch[c][2*cy + ky][2*cx + e] of conv pixel
+  // m = 16*sub + li.  Offsets in halves; everything is even, so reads are 4-byte aligned.
+  int koff[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const int krow = 4 * ks + lg;
+    const int c = krow / KS, ky = krow - c * KS;
+    koff[ks] = krow < CIN * KS ? c * ICHP + ky * ITWP : 0;  // zero-weight rows: any valid address
+  }
+  int abase[SUBS];
+#pragma unroll
+  for (int i = 0; i < SUBS; ++i) {
+    int m = (SUBS * mg + i) * 16 + li;
+    if (m >= MPIX) m = MPIX - 1;
+    const int cy = m / CTW, cx = m - cy * CTW;
+    abase[i] = 2 * cy * ITWP + 2 * cx;
+  }
+  // BN constants of the accumulator layout (column = li -> channel 32*nh + 16*tt + li)
+  float ba[TT], bb[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    ba[tt] = bn_a[32 * nh + 16 * tt + li];
+    bb[tt] = bn_b[32 * nh + 16 * tt + li];
+  }
+  // fetch role: column pair `fpc` of patch rows frow0 + 28*u (row = c*39 + r)
+  const int fpc = tid % NPC, frow0 = tid / NPC;
+  const bool fetcher = tid < NPC * RSTEP;
+  int f_goff[PER_T];  // c*H*W + r*W + 2*fpc, or -1 past the patch
+#pragma unroll
+  for (int u = 0; u < PER_T; ++u) {
+    const int R = frow0 + RSTEP * u;
+    const int c = R / ITH, r = R - c * ITH;
+    f_goff[u] = (fetcher && R < NROW) ? (c * H + r) * W + 2 * fpc : -1;
+  }
+  // pooling role: one pooled column (8 outputs) of one channel; 8 channels x 8 column slots per wave
+  const int pchl = lane & 7, pplx = lane >> 3;  // channel within the wave's byte, pooled column (7 = idle)
+  const int pch = wave * 8 + pchl;
+
+  const int ntiles = N * tiles_y * tiles_x;
+  const int nseq = per_xcd * 8;
+  // Tile order: workgroup b sits on XCD b % 8 (observed placement, used for speed only).  Each XCD
+  // walks ONE contiguous eighth of the tile list: x-neighbours (shared halo, shared output lines) meet
+  // in the same L2 within a short time.
+  auto tile_of = [&](int seq) { return (seq & 7) * per_xcd + (seq >> 3); };
+
+  float nx0[PER_T], nx1[PER_T];
+  auto fetch = [&](int tile) {
+    const bool valid = tile < ntiles;
+    const int tl = valid ? tile : 0;
+    const int n = tl / (tiles_y * tiles_x);
+    const int tr = tl - n * tiles_y * tiles_x;
+    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+    const int iy0 = 2 * (2 * ty * PTH - 1) - 3, ix0 = 2 * (2 * tx * PTW - 1) - 3;
+    const float* xb = x + (size_t)n * CIN * H * W + (ptrdiff_t)iy0 * W + ix0;
+    const int ix = ix0 + 2 * fpc;
+    const bool okc0 = valid && (unsigned)ix < (unsigned)W;
+    const bool okc1 = valid && 2 * fpc + 1 < ITWP - 1 && (unsigned)(ix + 1) < (unsigned)W;  // col 35: zero
+#pragma unroll
+    for (int u = 0; u < PER_T; ++u) {
+      const int R = frow0 + RSTEP * u;
+      const int r = R - (R >= 2 * ITH ? 2 * ITH : R >= ITH ? ITH : 0);
+      const bool okr = f_goff[u] >= 0 && (unsigned)(iy0 + r) < (unsigned)H;
+      nx0[u] = (okr && okc0) ? xb[f_goff[u]] : 0.0f;
+      nx1[u] = (okr && okc1) ? xb[f_goff[u] + 1] : 0.0f;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < PER_T; ++u) {
+      const int R = frow0 + RSTEP * u;
+      if (fetcher && R < NROW) {
+        half2v h, l;
+        h[0] = (_Float16)nx0[u];
+        h[1] = (_Float16)nx1[u];
+        l[0] = (_Float16)(nx0[u] - (float)h[0]);
+        l[1] = (_Float16)(nx1[u] - (float)h[1]);
+        reinterpret_cast<half2v*>(hiP)[R * NPC + fpc] = h;
+        reinterpret_cast<half2v*>(loP)[R * NPC + fpc] = l;
+      }
+    }
+  };
+  auto load_a = [&](const _Float16* plane, int off) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(plane) + (off >> 1);
+    u32x4 v;
+    v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3];
+    return __builtin_bit_cast(half8, v);
+  };
+
+  // sign words of the PREVIOUS tile: its 8 waves left one byte each per pixel in LDS; 56 threads send
+  // them as whole 64-bit words (byte stores from 8 waves into one word cost ~80 us at batch 256)
+  int prev_n = -1, prev_py0 = 0, prev_px0 = 0, buf = 0;
+  auto flush_bits = [&](int b) {
+    if (P && prev_n >= 0 && tid < PTH * PTW) {
+      const int ply = tid / PTW, plx = tid - ply * PTW;
+      const int py = prev_py0 + ply, px = prev_px0 + plx;
+      if (py < Hp && px < Wp) {
+        const size_t o = ((size_t)prev_n * Hp + py) * Wp + px;
+        P[o] = *reinterpret_cast<const uint64_t*>(bits + (b * PTH * PTW + tid) * 8);
+        M[o] = 0;  // nothing is negative after ReLU
+      }
+    }
+  };
+
+  int seq = blockIdx.x;
+  if (seq < nseq) { fetch(tile_of(seq)); commit(); }
+  for (; seq < nseq; seq += gridDim.x) {
+    const int tile = tile_of(seq);
+    const bool valid = tile < ntiles;  // workgroup-uniform
+    __syncthreads();                   // this tile's patch is in LDS; `stage` is free again
+    flush_bits(buf ^ 1);
+    const int seq_next = seq + gridDim.x;
+#if !(BNN_STEM_ABL & 8)
+    if (seq_next < nseq) fetch(tile_of(seq_next));  // global loads fly during the matrix phase
+#endif
+    const int tl = valid ? tile : 0;
+    const int n = tl / (tiles_y * tiles_x);
+    const int tr = tl - n * tiles_y * tiles_x;
+    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+    const int py0 = ty * PTH, px0 = tx * PTW;        // pooled origin
+    const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;  // conv origin (pool pad 1)
+
+    // ---- implicit GEMM: 4 sub-tiles x 2 channel tiles x 6 k-steps x (lo*hi + hi*lo + hi*hi).
+    // Two sub-tiles at a time, product-type major: 4 independent accumulators between two MFMAs
+    // that touch the same one.
+    f32x4 acc[SUBS][TT];
+#pragma unroll
+    for (int i = 0; i < SUBS; ++i)
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[i][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if !(BNN_STEM_ABL & 1)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+      for (int ip = 0; ip < SUBS; ip += 2) {
+        half8 ah[2], al[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          ah[d] = load_a(hiP, abase[ip + d] + koff[ks]);
+          al[d] = load_a(loP, abase[ip + d] + koff[ks]);
+        }
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt)
+            acc[ip + d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[d], bh[ks][tt], acc[ip + d][tt], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt)
+            acc[ip + d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[d], bl[ks][tt], acc[ip + d][tt], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt)
+            acc[ip + d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[d], bh[ks][tt], acc[ip + d][tt], 0, 0, 0);
+      }
+    }
+#endif
+
+    // ---- BN + ReLU, conv tile -> LDS.  D layout: column = li (channel), row = 4*lg + r (pixel).
+#if !(BNN_STEM_ABL & 2)
+#pragma unroll
+    for (int i = 0; i < SUBS; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = (SUBS * mg + i) * 16 + lg * 4 + r;
+        if (m < MPIX) {
+          const int cy = m / CTW, cx = m - cy * CTW;
+          const bool inside = (unsigned)(cy0 + cy) < (unsigned)Hc && (unsigned)(cx0 + cx) < (unsigned)Wc;
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt) {
+            const float v = fmaxf(fmaf(acc[i][tt][r], ba[tt], bb[tt]), 0.0f);
+            // positions outside the conv output are MaxPool padding: 0 never beats a ReLU output
+            stage[(32 * nh + 16 * tt + li) * SM + m] = inside ? v : 0.0f;
+          }
+        }
+      }
+    }
+#endif
+    __syncthreads();  // conv tile staged; every wave is done reading the patch
+#if !(BNN_STEM_ABL & 8)
+    if (seq_next < nseq) commit();  // next patch: registers -> LDS (fp16 hi/lo), overlaps the pooling
+#endif
+
+#if !(BNN_STEM_ABL & 4)
+    // ---- 3x3 / stride-2 max pool: row maxima of the thread's 3 conv columns, then 8 column maxima
+    const int px = px0 + pplx;
+    const bool col_live = valid && pplx < PTW && px < Wp;
+    float hm[CTH];
+    {
+      const float* sp = stage + pch * SM + 2 * (pplx < PTW ? pplx : 0);
+#pragma unroll
+      for (int r = 0; r < CTH; ++r) hm[r] = fmaxf(fmaxf(sp[r * CTW], sp[r * CTW + 1]), sp[r * CTW + 2]);
+    }
+#pragma unroll
+    for (int ply = 0; ply < PTH; ++ply) {
+      const int py = py0 + ply;
+      const bool live = col_live && py < Hp;  // py < Hp is workgroup-uniform
+      const float v = fmaxf(fmaxf(hm[2 * ply], hm[2 * ply + 1]), hm[2 * ply + 2]);
+      if (live && out) out[(((size_t)n * COUT + pch) * Hp + py) * Wp + px] = v;
+      if (P) {  // lanes 8*plx .. 8*plx+7 hold the 8 channels of byte `wave` of pixel (ply, plx)
+        const unsigned long long mask = __ballot(live && is_pos(v));
+        if (pchl == 0 && pplx < PTW)
+          bits[((buf * PTH + ply) * PTW + pplx) * 8 + wave] = (uint8_t)(mask >> (8 * pplx));
+      }
+    }
+#endif
+    prev_n = valid ? n : -1;
+    prev_py0 = py0;
+    prev_px0 = px0;
+    buf ^= 1;
+  }
+  __syncthreads();
+  flush_bits(buf ^ 1);
+}
+
+int launch_stem_split(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
+                      int W, float* out, uint64_t* P, uint64_t* M, hipStream_t stream) {
+  using namespace stem2;
+  const int Hc = (H + 6 - KS) / 2 + 1, Wc = (W + 6 - KS) / 2 + 1;
+  const int Hp = (Hc + 2 - 3) / 2 + 1, Wp = (Wc + 2 - 3) / 2 + 1;
+  const int tiles_y = (Hp + PTH - 1) / PTH, tiles_x = (Wp + PTW - 1) / PTW;
+  const long long ntiles = (long long)N * tiles_y * tiles_x;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  }
+  const int per_xcd = (int)((ntiles + 7) / 8);
+  const long long want = cus;  // one resident workgroup (8 waves) per CU
+  const unsigned grid = (unsigned)(ntiles < want ? ((ntiles + 7) / 8 * 8) : want);
+  static bool attr_set[64] = {false};  // > 64 KB of dynamic LDS needs the opt-in, once per device
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_split_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(stem_split_kernel, dim3(grid), dim3(NT), LDS_BYTES, stream, x, w, bn_a, bn_b, N, H,
+                     W, Hc, Wc, Hp, Wp, tiles_y, tiles_x, per_xcd, out, P, M);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+}  // namespace bnn

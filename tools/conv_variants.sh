@@ -5,10 +5,13 @@ set -u
 R="$(cd "$(dirname "$0")/.." && pwd)"
 V="$R/binary-networks-pytorch_amd/bnn_amd/_lib/variants"
 declare -A CFG=(
-  [nnw1]="-DBNN_NN_MULTI_MINW=1"
-  [nnw5]="-DBNN_NN_MULTI_MINW=5"
-  [nnw6]="-DBNN_NN_MULTI_MINW=6"
-  [nnw5gs1]="-DBNN_NN_MULTI_MINW=5 -DBNN_MULTI_GSPLIT=1"
+  [abl0]="-DBNN_STEM_ABL=0"
+  [abl1]="-DBNN_STEM_ABL=1"
+  [abl2]="-DBNN_STEM_ABL=2"
+  [abl4]="-DBNN_STEM_ABL=4"
+  [abl8]="-DBNN_STEM_ABL=8"
+  [abl15]="-DBNN_STEM_ABL=15"
+  [abl7]="-DBNN_STEM_ABL=7"
 )
 if [ "${1:-build}" = "build" ]; then
   rm -rf "$V"; mkdir -p "$V"
@@ -20,7 +23,8 @@ if [ "${1:-build}" = "build" ]; then
 else
   for k in "${!CFG[@]}"; do
     echo "=== $k (${CFG[$k]})"
-    BNN_AMD_LIB="$V/$k/libbnn_hip.so" ONLY="${ONLY:-}" timeout 300 python "$R/tools/bench_conv.py" 2>&1 | grep -v amdgpu.ids
+    [ -z "${STEM:-}" ] && BNN_AMD_LIB="$V/$k/libbnn_hip.so" ONLY="${ONLY:-}" timeout 300 python "$R/tools/bench_conv.py" 2>&1 | grep -v amdgpu.ids
+    [ -n "${STEM:-}" ] && BNN_AMD_LIB="$V/$k/libbnn_hip.so" timeout 300 python "$R/tools/bench_stem.py" 2>&1 | grep "stem"
     [ -n "${NET:-}" ] && BNN_AMD_LIB="$V/$k/libbnn_hip.so" timeout 300 python "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | cut -c1-200
   done
 fi
