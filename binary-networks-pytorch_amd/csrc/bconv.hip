@@ -192,9 +192,11 @@ enum : int {
   EP_RUNTIME = 1,  // anything, decided at run time
   EP_MID = 2,      // BN + ReLU -> packed only            (conv1 of a BasicBlock)
   EP_OUT = 3,      // BN + residual + ReLU -> fp32 + packed (conv2 of a BasicBlock)
+  EP_DS = 4,       // BN -> fp32                            (1x1 conv of a shortcut branch)
 };
 constexpr int kFlagsMid = EF_BN | EF_RELU | EF_PACK;
 constexpr int kFlagsOut = EF_BN | EF_RES | EF_RELU | EF_OUTF | EF_PACK;
+constexpr int kFlagsDs = EF_BN | EF_OUTF;
 
 template <int NACC, int EP>
 __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
@@ -203,7 +205,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
   constexpr bool FUSED = EP != EP_PLAIN;
   const int hw = g.Ho * g.Wo;
   const unsigned lane_off = (unsigned)(px.n * g.O * hw + px.r);  // host keeps N*O*hw < 2^30
-  const int f = EP == EP_MID ? kFlagsMid : EP == EP_OUT ? kFlagsOut : g.flags;
+  const int f = EP == EP_MID ? kFlagsMid : EP == EP_OUT ? kFlagsOut : EP == EP_DS ? kFlagsDs : g.flags;
   const bool full = o0 + NACC <= g.O;
   if (f & EF_RAW) {
     if (px.live) {
@@ -255,7 +257,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
 template <int NACC, int EP>
 __device__ __forceinline__ void prefetch_residual(const Geo& g, const Pix& px, int o0,
                                                   const EpiArgs& e, float (&resv)[NACC]) {
-  const int f = EP == EP_MID ? kFlagsMid : EP == EP_OUT ? kFlagsOut : g.flags;
+  const int f = EP == EP_MID ? kFlagsMid : EP == EP_OUT ? kFlagsOut : EP == EP_DS ? kFlagsDs : g.flags;
   if (EP == EP_PLAIN || !(f & EF_RES) || (f & EF_RAW)) {
 #pragma unroll
     for (int j = 0; j < NACC; ++j) resv[j] = 0.0f;
@@ -792,6 +794,8 @@ static void launch_sgpr(const ConvP& p, int flags, hipStream_t s) {
   if constexpr (PROFILES) {
     if (g.flags == kFlagsMid) return launch_sgpr_e<KH, KW, CWC, EP_MID>(p, g, wv, nn, s);
     if (g.flags == kFlagsOut) return launch_sgpr_e<KH, KW, CWC, EP_OUT>(p, g, wv, nn, s);
+  } else {
+    if (g.flags == kFlagsDs) return launch_sgpr_e<KH, KW, CWC, EP_DS>(p, g, wv, nn, s);
   }
   if (fused) launch_sgpr_e<KH, KW, CWC, EP_RUNTIME>(p, g, wv, nn, s);
   else launch_sgpr_e<KH, KW, CWC, EP_PLAIN>(p, g, wv, nn, s);
