@@ -74,14 +74,17 @@ def simd32_peak(info) -> float:
     return info["compute_units"] * 4 * 32 * info["clock_khz"] * 1e3
 
 
-def conv_c2_roofline(device, info, batch=256, iters=20, act_kind="relu"):
+def conv_c2_roofline(device, info, batch=256, iters=20, act_kind="relu", nonneg=False):
     """BASELINE config 2: 3x3 Conv2d 128->128, 56x56, batch 256 — the graded kernel.
-    Times `iters` launches of bnn_hip_bconv2d with events on the launch stream."""
+    Times `iters` launches of bnn_hip_bconv2d with events on the launch stream.
+    ``nonneg``: promise the kernel that the input has no negative value (true for a ReLU output):
+    it then runs the P-plane-only variant the fused ResNet executor uses."""
     N, C, H, W, O = batch, 128, 56, 56, 128
     x = torch.from_numpy(gen.activation(act_kind, 7, (8, C, H, W))).to(device).repeat(N // 8, 1, 1, 1)
     w = torch.from_numpy(gen.conv_weight("kaiming", 8, (O, C, 3, 3))).to(device)
     pw = hipops.pack_weight(w)
     act = hipops.pack_act(x)
+    act.nonneg = bool(nonneg)
     for _ in range(3):
         out = hipops.bconv2d(act, pw, stride=1, padding=1)
     torch.cuda.synchronize(device)
@@ -95,7 +98,7 @@ def conv_c2_roofline(device, info, batch=256, iters=20, act_kind="relu"):
     # pack kernel (HBM-bound) timed the same way
     e0.record()
     for _ in range(iters):
-        act = hipops.pack_act(x)
+        hipops.pack_act(x)
     e1.record()
     torch.cuda.synchronize(device)
     t_pack = e0.elapsed_time(e1) * 1e-3 / iters
@@ -241,6 +244,9 @@ def main():
             rec["roofline"] = conv_c2_roofline(device, info, act_kind="relu")
             rec["roofline_normal_input"] = {k: v for k, v in conv_c2_roofline(device, info, act_kind="normal").items()
                                             if k in ("achieved", "frac", "avg_kernel_us")}
+            rec["roofline_relu_input_nonneg_kernel"] = {
+                k: v for k, v in conv_c2_roofline(device, info, act_kind="relu", nonneg=True).items()
+                if k in ("achieved", "frac", "avg_kernel_us")}
             rec["int_alu_probe_Tlane_ops"] = {
                 name: round(hipops.probe_int_alu(4096, device, mode)["lane_ops_per_s"] / 1e12, 2)
                 for mode, name in hipops.PROBE_MODES.items()}
