@@ -421,3 +421,38 @@ def test_half_precision_and_grad_mode_take_the_composition_path():
     with torch.no_grad():
         layer.half()(dev(x).half())                 # fp16 model: not the fp32 HIP path
     assert fastpath.stats()["conv2d"] == before
+
+
+def test_packed_checkpoint_round_trip_on_device(tmp_path):
+    """save_packed -> load_packed -> load_state_dict: the HIP forward is bit-identical (non-centred XNOR:
+    same sign bits, alpha recomputed exactly by the double-precision reduction of pack_weight)."""
+    from bnn_amd import checkpoint
+    from bnn_amd.inference import FusedResNet
+    net = _r18_for_ckpt()
+    x = dev(gen.normal(gen.seed_of("ckpt"), (4, 3, 64, 64)))
+    with torch.no_grad():
+        y0 = net(x).clone()
+        f0 = FusedResNet(net)(x).clone()
+    path = str(tmp_path / "r18.bnnpack")
+    stats = checkpoint.save_packed(net, path)
+    assert stats["binary_weights_packed"] * 30 < stats["binary_weights_fp32"]
+    net.load_state_dict(checkpoint.load_packed(path, map_location=DEV))
+    with torch.no_grad():
+        assert torch.equal(net(x), y0)
+        assert torch.equal(FusedResNet(net)(x), f0)
+
+
+def _r18_for_ckpt():
+    torch.manual_seed(0)
+    net = resnet18(num_classes=10)
+    cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
+                      weight_pre_process=XNORWeightBinarizer)
+    net = bnn.prepare_binary_model(net, cfg, ignore_layers_name=["conv1", "fc"])
+    g = torch.Generator().manual_seed(1)
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.weight.data = torch.rand(m.num_features, generator=g) + 0.5
+            m.bias.data = torch.randn(m.num_features, generator=g) * 0.3
+            m.running_mean = torch.randn(m.num_features, generator=g) * 0.5
+            m.running_var = torch.rand(m.num_features, generator=g) + 0.5
+    return net.to(DEV).eval()
