@@ -7,7 +7,9 @@ A layer takes the HIP path when ALL of the following hold (otherwise the torch c
   per-output-channel ``BasicScaleBinarizer``)      (reference: ``examples/cifar10.py:65-69``,
   ``test/test_layers.py:17-21``)
 * input and weight are float32 on the same HIP device
-* autograd is not recording (``torch.no_grad()`` / inference) — the kernels have no backward
+* autograd is not recording (``torch.no_grad()`` / inference); when it IS recording, ``Conv2d`` takes the
+  training variant (HIP forward, fp32 library backward with the straight-through estimator:
+  ``bnn_amd/training.py``), ``Conv1d``/``Linear`` fall back to the composition
 * ``groups == 1``, ``padding_mode == 'zeros'``, numeric padding
 
 When those hold and ``libbnn_hip.so`` cannot be loaded the call raises ``NativeError``: there is
@@ -30,7 +32,7 @@ import torch.nn as nn
 from . import hipops, native
 
 _stats_lock = threading.Lock()
-_stats = {"conv2d": 0, "conv1d": 0, "linear": 0, "weight_packs": 0}
+_stats = {"conv2d": 0, "conv1d": 0, "linear": 0, "weight_packs": 0, "conv2d_train": 0}
 
 
 def stats() -> dict:
@@ -92,6 +94,15 @@ def _eligible(layer: nn.Module, x: torch.Tensor, plan: Plan) -> bool:
     return True
 
 
+def _eligible_train(layer: nn.Module, x: torch.Tensor) -> bool:
+    """Autograd is recording and something on the path needs a gradient: HIP forward + library
+    backward (``bnn_amd/training.py``) instead of the pure torch composition."""
+    from . import training
+    w = layer.weight
+    return (training.ENABLED and torch.is_grad_enabled() and x.is_cuda and w.is_cuda and x.device == w.device
+            and x.dtype == torch.float32 and w.dtype == torch.float32)
+
+
 def _numeric_padding(layer) -> bool:
     return not isinstance(layer.padding, str) and layer.padding_mode == "zeros" and layer.groups == 1
 
@@ -101,6 +112,14 @@ def plan_conv2d(layer, x: torch.Tensor) -> Optional[Plan]:
         return None
     plan = _recognise(layer, layer.out_channels)
     return plan if plan is not None and _eligible(layer, x, plan) else None
+
+
+def plan_conv2d_train(layer, x: torch.Tensor) -> Optional[Plan]:
+    """Plan for a training-mode forward (only consulted when ``plan_conv2d`` declined)."""
+    if x.dim() != 4 or not _numeric_padding(layer):
+        return None
+    plan = _recognise(layer, layer.out_channels)
+    return plan if plan is not None and _eligible_train(layer, x) else None
 
 
 def plan_conv1d(layer, x: torch.Tensor) -> Optional[Plan]:
@@ -138,6 +157,15 @@ def conv2d(layer, x: torch.Tensor, plan: Plan) -> torch.Tensor:
     out = hipops.bconv2d(act, pw, layer.bias, plan.scale, layer.stride, layer.padding,
                          layer.dilation)
     _bump("conv2d")
+    return out
+
+
+def conv2d_train(layer, x: torch.Tensor, plan: Plan) -> torch.Tensor:
+    """Same forward under autograd: HIP kernels forward, fp32 library convolutions backward."""
+    from . import training
+    native.require()
+    out = training.conv2d_train(layer, x, plan, packed_weight(layer, plan))
+    _bump("conv2d_train")
     return out
 
 

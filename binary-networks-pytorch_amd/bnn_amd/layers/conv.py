@@ -48,6 +48,9 @@ class Conv2d(BinaryLayerMixin, nn.Conv2d):
         plan = fastpath.plan_conv2d(self, input)
         if plan is not None:
             return fastpath.conv2d(self, input, plan)
+        plan = fastpath.plan_conv2d_train(self, input)
+        if plan is not None:
+            return fastpath.conv2d_train(self, input, plan)
         x = self.activation_pre_process(input)
         out = self._conv_forward(x, self.weight_pre_process(self.weight), self.bias)
         return self.activation_post_process(out, input)

@@ -1,0 +1,125 @@
+"""Training path on the GPU: HIP XNOR/popcount forward under autograd, fp32 library
+backward with the straight-through estimator (bnn/ops.py:63-73), compared with the torch composition
+(the reference's formulation) on the same device."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import bnn_amd as bnn
+from bnn_amd import fastpath, training
+from bnn_amd.models import resnet18
+from bnn_amd.ops import BasicInputBinarizer, BasicScaleBinarizer, XNORWeightBinarizer
+from tests.golden import gen
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _layer(C, O, k, stride, pad, bias, scale, center, seed):
+    conv = nn.Conv2d(C, O, k, stride=stride, padding=pad, bias=bias)
+    conv.weight.data.copy_(torch.from_numpy(gen.conv_weight("kaiming", seed, (O, C, k, k))))
+    if bias:
+        conv.bias.data.copy_(torch.from_numpy(0.1 * gen.normal(seed + 1, (O,))))
+    cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer,
+                      activation_post_process=BasicScaleBinarizer if scale else bnn.Identity,
+                      weight_pre_process=XNORWeightBinarizer.with_args(center_weights=center))
+    layer = bnn.prepare_binary_model(conv, cfg)
+    if scale:
+        layer.activation_post_process.alpha.data.copy_(
+            torch.from_numpy((0.5 + gen.uniform(seed + 2, (O,))).astype(np.float32)).view(1, -1, 1, 1))
+    return layer.to(DEV).train()
+
+
+def _grads(layer, x_np, g_np, enabled):
+    training.ENABLED = enabled
+    try:
+        for p in layer.parameters():
+            p.grad = None
+        x = dev(x_np).requires_grad_(True)
+        y = layer(x)
+        y.backward(dev(g_np))
+        return y.detach(), x.grad.clone(), {n: p.grad.clone() for n, p in layer.named_parameters()}
+    finally:
+        training.ENABLED = True
+
+
+@pytest.mark.parametrize("C,O,k,stride,pad,bias,scale,center", [
+    (64, 64, 3, 1, 1, False, False, False),
+    (128, 96, 3, 2, 1, True, True, False),
+    (70, 40, 1, 1, 0, True, False, True),
+    (256, 64, 3, 1, 1, False, True, True),
+])
+def test_training_forward_and_gradients_match_composition(C, O, k, stride, pad, bias, scale, center):
+    layer = _layer(C, O, k, stride, pad, bias, scale, center, seed=C + O)
+    x = (gen.normal(5, (3, C, 12, 10)) * 0.8).astype(np.float32)      # |x| straddles the STE threshold 1
+    ho, wo = (12 + 2 * pad - k) // stride + 1, (10 + 2 * pad - k) // stride + 1
+    g = gen.normal(6, (3, O, ho, wo))
+    before = fastpath.stats()["conv2d_train"]
+    y1, gx1, gp1 = _grads(layer, x, g, enabled=True)
+    assert fastpath.stats()["conv2d_train"] == before + 1               # the HIP forward ran
+    y0, gx0, gp0 = _grads(layer, x, g, enabled=False)
+    assert fastpath.stats()["conv2d_train"] == before + 1               # ... and not in the control run
+    tol = dict(rtol=1e-4, atol=1e-5 * float(y0.abs().max()))
+    assert torch.allclose(y1, y0, **tol)
+    # input gradient: same library conv on the same operands, same STE mask
+    assert torch.allclose(gx1, gx0, rtol=1e-4, atol=1e-5 * float(gx0.abs().max()))
+    assert ((gx1 == 0) == (gx0 == 0)).all()
+    assert gp1.keys() == gp0.keys()
+    for n in gp0:
+        assert torch.allclose(gp1[n], gp0[n], rtol=1e-3, atol=1e-4 * float(gp0[n].abs().max()) + 1e-7), n
+
+
+def test_inference_and_training_forwards_agree_and_repack_after_optimizer_step():
+    layer = _layer(64, 64, 3, 1, 1, False, False, False, seed=9)
+    x = dev(gen.normal(3, (2, 64, 8, 8)))
+    with torch.no_grad():
+        y_inf = layer(x)
+    y_tr = layer(x.clone().requires_grad_(True))
+    assert torch.equal(y_inf, y_tr.detach())                             # same kernels, same packed weights
+    opt = torch.optim.SGD(layer.parameters(), lr=0.5)
+    packs = fastpath.stats()["weight_packs"]
+    y_tr.square().mean().backward()
+    opt.step()
+    y2 = layer(x.clone().requires_grad_(True))
+    assert fastpath.stats()["weight_packs"] == packs + 1                 # version counter changed -> re-pack
+    assert not torch.equal(y2.detach(), y_inf)
+
+
+def test_small_resnet_trains_on_the_hip_forward():
+    """A few SGD steps of a binary ResNet-18: the loss trajectory with the HIP forward follows the
+    composition's (identical math up to fp rounding in alpha and the conv sums)."""
+    def run(enabled):
+        training.ENABLED = enabled
+        try:
+            torch.manual_seed(0)
+            net = resnet18(num_classes=10)
+            cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
+                              weight_pre_process=XNORWeightBinarizer)
+            net = bnn.prepare_binary_model(net, cfg, ignore_layers_name=["conv1", "fc"]).to(DEV).train()
+            opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9)
+            x = dev(gen.normal(21, (16, 3, 64, 64)))
+            t = torch.arange(16, device=DEV) % 10
+            losses = []
+            for _ in range(4):
+                opt.zero_grad(set_to_none=True)
+                loss = nn.functional.cross_entropy(net(x), t)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.detach()))
+            return losses
+        finally:
+            training.ENABLED = True
+    before = fastpath.stats()["conv2d_train"]
+    fast = run(True)
+    assert fastpath.stats()["conv2d_train"] == before + 4 * 19
+    slow = run(False)
+    assert fast[-1] < fast[0]                                            # it learns
+    # same first forward up to sign flips of exact-zero sums (the float conv leaves +-1e-9 residues where
+    # the integer path gives 0.0: DESIGN.md "exact zero"), which batch-statistics BN amplifies slightly
+    assert abs(fast[0] - slow[0]) < 2e-3 * max(1.0, abs(slow[0]))
+    assert np.allclose(fast, slow, rtol=0.15)                            # same trajectory (sign flips allowed)
