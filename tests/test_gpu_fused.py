@@ -8,7 +8,7 @@ import torch.nn.functional as F
 import oracle
 from bnn_amd import hipops
 from tests.golden import gen
-from tests.golden.cases import LAYER_CASES, LAYER_CASES_BY_NAME
+from tests.golden.cases import LAYER_CASES, LAYER_CASES_BY_NAME, LayerCase
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -54,11 +54,28 @@ EPI_CASES = [
 ]
 
 
+# multi-chunk shapes with ragged channel blocks: exercise the split-block waves (16-bit packed stores)
+ADHOC = {c.name: c for c in [
+    LayerCase("adhoc_c256_o40", 2, 256, 9, 7, 40, 3, 1, 1, act="relu"),
+    LayerCase("adhoc_c512_o72_s2", 1, 512, 9, 9, 72, 3, 2, 1, act="relu"),
+    LayerCase("adhoc_c384_o100", 1, 384, 6, 5, 100, 3, 1, 1, act="normal"),
+]}
+EPI_CASES += [
+    ("adhoc_c256_o40", dict(bn=True, relu=True, res=True, prelu=False)),
+    ("adhoc_c512_o72_s2", dict(bn=True, relu=True, res=False, prelu=False)),
+    ("adhoc_c384_o100", dict(bn=True, relu=False, res=True, prelu=True)),
+]
+
+
+@pytest.mark.parametrize("nonneg", [False, True], ids=["two-plane", "nonneg"])
 @pytest.mark.parametrize("name,sw", EPI_CASES, ids=[f"{n}-{i}" for i, (n, _) in enumerate(EPI_CASES)])
-def test_fused_epilogue_bit_exact(name, sw):
-    case = LAYER_CASES_BY_NAME[name]
+def test_fused_epilogue_bit_exact(name, sw, nonneg):
+    case = LAYER_CASES_BY_NAME.get(name) or ADHOC[name]
+    if nonneg and not (case.act == "relu" and case.k == 3):
+        pytest.skip("P-plane-only kernels apply to 3x3 convs of non-negative inputs")
     x, w, b, sc = case.tensors()
     act = hipops.pack_act(dev(x))
+    act.nonneg = nonneg
     pw = hipops.pack_weight(dev(w), case.center, case.compute_alpha)
     _, dot = oracle.binary_conv2d_int(x, w, None, None, case.stride, case.pad, case.dilation,
                                       case.center, case.compute_alpha)
