@@ -197,6 +197,8 @@ def main():
         engine = FusedResNet(net)
         if args.engine == "graph":
             engine.capture(x)
+            x = engine.static_input   # the batch lives in the graph's input buffer (filled by capture):
+            #                           no per-step device-to-device copy of the 154 MB input
     model = ShardedInference(engine)
 
     def barrier():

@@ -180,10 +180,18 @@ class FusedResNet(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self._graph is not None and x.shape == self._gx.shape:
-            self._gx.copy_(x, non_blocking=True)
+            if x.data_ptr() != self._gx.data_ptr():   # callers that fill `static_input` in place skip the copy
+                self._gx.copy_(x, non_blocking=True)
             self._graph.replay()
             return self._gy
         return self._forward_impl(x)
+
+    @property
+    def static_input(self):
+        """The graph's input buffer (None before ``capture``).  Writing the batch into it in place
+        (e.g. as the destination of the host-to-device copy) and passing it to ``forward`` replays
+        the graph without the extra device-to-device copy of the input (154 MB at batch 256)."""
+        return getattr(self, "_gx", None) if self._graph is not None else None
 
     def capture(self, example: torch.Tensor) -> "FusedResNet":
         """Record the whole forward (for this input shape) into a HIP graph; later calls with the

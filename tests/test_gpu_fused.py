@@ -184,6 +184,14 @@ def test_fused_resnet18_graph_replay_is_bit_identical():
     y2 = fused(dev(gen.normal(6, (8, 3, 64, 64)))).clone()
     assert torch.equal(y0, y1) and not torch.equal(y1, y2)
     assert torch.equal(fused(x), y0)
+    # zero-copy replay: the caller fills the graph's own input buffer in place
+    buf = fused.static_input
+    assert buf is not None and buf.shape == x.shape and buf.data_ptr() != x.data_ptr()
+    x3 = dev(gen.normal(7, (8, 3, 64, 64)))
+    buf.copy_(x3)
+    y3 = fused(buf).clone()
+    fresh = FusedResNet(net)
+    assert torch.equal(y3, fresh(x3)) and not torch.equal(y3, y0)
 
 
 def test_fused_resnet18_prelu_variant():
