@@ -170,6 +170,37 @@ __global__ __launch_bounds__(256) void avgpool2_pack_kernel(const float* __restr
   P[o + 2] = pw1; M[o + 2] = mw1;
 }
 
+// k == 2 on even images whose width is not a multiple of 4 (14x14 -> 7x7): one aligned float2 per
+// input row and output.  Same tap order as the scalar kernel.
+__global__ __launch_bounds__(256) void avgpool2_pack_f2_kernel(const float* __restrict__ x, int C,
+                                                               int H, int W, int Ho, int Wo,
+                                                               long long npix_out, int cw32,
+                                                               uint32_t* __restrict__ P,
+                                                               uint32_t* __restrict__ M) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= npix_out) return;
+  const int word = blockIdx.y;
+  const int hw = Ho * Wo;
+  const int n = (int)(q / hw);
+  const int r = (int)(q - (long long)n * hw);
+  const int oy = r / Wo, ox = r - oy * Wo;
+  uint32_t pw = 0u, mw = 0u;
+  const float* base = x + (((size_t)n * C + (size_t)word * 32) * H + 2 * oy) * W + 2 * ox;
+  const size_t cstride = (size_t)H * W;
+#pragma unroll 8
+  for (int b = 0; b < 32; ++b) {
+    if (word * 32 + b >= C) break;
+    const float2 u = *reinterpret_cast<const float2*>(base + b * cstride);
+    const float2 v = *reinterpret_cast<const float2*>(base + b * cstride + W);
+    const float s = ((u.x + u.y) + v.x) + v.y;
+    pw |= (is_pos(s) ? 1u : 0u) << b;
+    mw |= (is_neg(s) ? 1u : 0u) << b;
+  }
+  const size_t o = ((((size_t)n * (cw32 >> 1) + (word >> 1)) * hw + r) << 1) + (word & 1);
+  P[o] = pw;
+  M[o] = mw;
+}
+
 int launch_avgpool_pack(const float* x, int N, int C, int H, int W, int k, uint64_t* P, uint64_t* M,
                         hipStream_t stream) {
   const int Ho = (H + k - 1) / k, Wo = (W + k - 1) / k;
@@ -179,6 +210,12 @@ int launch_avgpool_pack(const float* x, int N, int C, int H, int W, int k, uint6
     const long long npairs = npix / 2;
     hipLaunchKernelGGL(avgpool2_pack_kernel, dim3((unsigned)((npairs + 255) / 256), (unsigned)cw32),
                        dim3(256), 0, stream, x, C, H, W, Ho, Wo, npairs, cw32,
+                       reinterpret_cast<uint32_t*>(P), reinterpret_cast<uint32_t*>(M));
+    return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+  }
+  if (k == 2 && H % 2 == 0 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7u) == 0) {
+    hipLaunchKernelGGL(avgpool2_pack_f2_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)cw32),
+                       dim3(256), 0, stream, x, C, H, W, Ho, Wo, npix, cw32,
                        reinterpret_cast<uint32_t*>(P), reinterpret_cast<uint32_t*>(M));
     return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
   }
