@@ -16,6 +16,7 @@ from .bconfig import BConfig, Identity
 from .binarize import (DEFAULT_MODULE_MAPPING, get_modules_to_binarize, get_unique_devices_,
                        prepare_binary_model, swap_modules_by_name)
 from . import layers, ops  # noqa: F401
+from . import torch_ops  # noqa: F401  (registers torch.ops.bnn_amd.*)
 
 __all__ = [
     "__version__", "BConfig", "Identity", "DEFAULT_MODULE_MAPPING", "get_modules_to_binarize",

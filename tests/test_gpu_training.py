@@ -123,3 +123,37 @@ def test_small_resnet_trains_on_the_hip_forward():
     # the integer path gives 0.0: DESIGN.md "exact zero"), which batch-statistics BN amplifies slightly
     assert abs(fast[0] - slow[0]) < 2e-3 * max(1.0, abs(slow[0]))
     assert np.allclose(fast, slow, rtol=0.15)                            # same trajectory (sign flips allowed)
+
+
+def test_torch_custom_ops_forward_and_autograd():
+    """torch.ops.bnn_amd.binary_conv2d / binary_linear / pack_sign on the device: same numbers as the
+    layer, gradients equal the composition's."""
+    import oracle
+    layer = _layer(96, 40, 3, 2, 1, True, True, False, seed=77).eval()
+    x_np = (gen.normal(8, (2, 96, 9, 11)) * 0.9).astype(np.float32)
+    x = dev(x_np)
+    scale = layer.activation_post_process.alpha
+    with torch.no_grad():
+        ref = layer(x)
+        y = torch.ops.bnn_amd.binary_conv2d(x, layer.weight, layer.bias, scale, [2, 2], [1, 1], [1, 1], False, True)
+    assert torch.equal(y, ref)
+    P, M = torch.ops.bnn_amd.pack_sign(x)
+    Pr, Mr = oracle.pack_act(x_np)
+    assert np.array_equal(P.cpu().numpy().view(np.uint64), Pr) and np.array_equal(M.cpu().numpy().view(np.uint64), Mr)
+    # autograd through the op vs through the torch composition of the same layer
+    g = dev(gen.normal(9, tuple(ref.shape)))
+    xa = x.clone().requires_grad_(True)
+    w, b, s = (t.detach().clone().requires_grad_(True) for t in (layer.weight, layer.bias, scale))
+    torch.ops.bnn_amd.binary_conv2d(xa, w, b, s, [2, 2], [1, 1], [1, 1], False, True).backward(g)
+    _, gx0, gp0 = _grads(layer.train(), x_np, g.cpu().numpy(), enabled=False)
+    assert torch.allclose(xa.grad, gx0, rtol=1e-4, atol=1e-5 * float(gx0.abs().max()))
+    assert torch.allclose(w.grad, gp0["weight"], rtol=1e-3, atol=1e-4 * float(gp0["weight"].abs().max()))
+    assert torch.allclose(b.grad, gp0["bias"], rtol=1e-3, atol=1e-4 * float(gp0["bias"].abs().max()))
+    assert torch.allclose(s.grad, gp0["activation_post_process.alpha"], rtol=1e-3,
+                          atol=1e-4 * float(gp0["activation_post_process.alpha"].abs().max()))
+    # linear
+    lw = dev(gen.conv_weight("kaiming", 5, (11, 70, 1, 1)).reshape(11, 70))
+    lx = dev(gen.normal(6, (3, 5, 70)))
+    z = torch.ops.bnn_amd.binary_linear(lx, lw, None, None, False, True)
+    zr = torch.nn.functional.linear(torch.sign(lx), torch.sign(lw) * lw.abs().mean(dim=1, keepdim=True))
+    assert z.shape == (3, 5, 11) and torch.allclose(z, zr, rtol=1e-5, atol=1e-5)

@@ -76,3 +76,26 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     finally:
         monkeypatch.delenv("BNN_AMD_LIB")
         importlib.reload(native)
+
+
+def test_torch_custom_ops_are_registered_with_shape_inference_and_no_cpu_kernel():
+    """torch.ops.bnn_amd.* (SURVEY §8(b)): schema + meta kernels exist everywhere, compute only on HIP."""
+    import pytest
+    import torch
+
+    import bnn_amd  # noqa: F401
+    from bnn_amd import torch_ops
+    for name in torch_ops.OPS:
+        assert hasattr(torch.ops.bnn_amd, name)
+    x = torch.empty(2, 70, 9, 7, device="meta")
+    w = torch.empty(40, 70, 3, 3, device="meta")
+    y = torch.ops.bnn_amd.binary_conv2d(x, w, None, None, [2, 2], [1, 1], [1, 1], False, True)
+    assert y.shape == (2, 40, 5, 4) and y.dtype == torch.float32 and y.device.type == "meta"
+    P, M = torch.ops.bnn_amd.pack_sign(x)
+    assert P.shape == (2, 2, 9, 7) and P.dtype == torch.int64 and M.shape == P.shape
+    z = torch.ops.bnn_amd.binary_linear(torch.empty(3, 5, 70, device="meta"), torch.empty(11, 70, device="meta"),
+                                        None, None, False, True)
+    assert z.shape == (3, 5, 11)
+    with pytest.raises((NotImplementedError, RuntimeError)):   # product path: no CPU stand-in
+        torch.ops.bnn_amd.binary_conv2d(torch.zeros(1, 8, 4, 4), torch.zeros(4, 8, 3, 3), None, None,
+                                        [1, 1], [1, 1], [1, 1], False, True)
