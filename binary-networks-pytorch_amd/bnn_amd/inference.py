@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import fastpath, hipops, native
 from .layers import Conv2d as BinaryConv2d
-from .models.blocks import BasicBlock
+from .models.blocks import BasicBlock, Bottleneck
 from .models.resnet import ResNet
 
 
@@ -92,7 +92,8 @@ def _activation(act: nn.Module):
 
 
 class FusedResNet(nn.Module):
-    """Inference executor for ``bnn_amd.models.ResNet`` built from ``BasicBlock`` (ResNet-18/34)."""
+    """Inference executor for ``bnn_amd.models.ResNet`` built from ``BasicBlock`` (ResNet-18/34) or
+    ``Bottleneck`` (ResNet-50/101/152: mixed 1x1 / 3x3 binary convolutions)."""
 
     def __init__(self, model: ResNet, use_mfma_stem: bool = True) -> None:
         super().__init__()
@@ -137,10 +138,14 @@ class FusedResNet(nn.Module):
                            and _is_float_layer(c1))
         for stage in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in stage:
-                if not isinstance(blk, BasicBlock):
+                if type(blk) is BasicBlock:      # conv-BN-act, conv-BN-(+id)-act
+                    convs = [self._conv(blk.conv1, blk.bn1, blk.act1), self._conv(blk.conv2, blk.bn2, blk.act2)]
+                elif type(blk) is Bottleneck:    # 1x1-BN-act, 3x3-BN-act, 1x1-BN-(+id)-act  (res_block.py:98-118)
+                    convs = [self._conv(blk.conv1, blk.bn1, blk.act1), self._conv(blk.conv2, blk.bn2, blk.act2),
+                             self._conv(blk.conv3, blk.bn3, blk.act3)]
+                else:
                     raise FusionError(f"unsupported block {type(blk).__name__}")
-                entry = {"c1": self._conv(blk.conv1, blk.bn1, blk.act1),
-                         "c2": self._conv(blk.conv2, blk.bn2, blk.act2), "ds": None, "pool": 0}
+                entry = {"convs": convs, "ds": None, "pool": 0}
                 if blk.downsample is not None:
                     pool, conv, bn = blk.downsample[0], blk.downsample[1], blk.downsample[2]
                     k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
@@ -173,8 +178,9 @@ class FusedResNet(nn.Module):
                 idn, _ = b["ds"].run(sc_in, out_f32=True, out_packed=False)
             else:
                 idn = t
-            _, p1 = b["c1"].run(packed, out_f32=False, out_packed=True)
-            t, packed = b["c2"].run(p1, residual=idn, out_f32=True, out_packed=i != last)
+            for c in b["convs"][:-1]:           # activations travel between binary layers as bit planes
+                _, packed = c.run(packed, out_f32=False, out_packed=True)
+            t, packed = b["convs"][-1].run(packed, residual=idn, out_f32=True, out_packed=i != last)
         # real-valued head (last layer stays float)
         return m.fc(torch.flatten(m.avgpool(t), 1))
 

@@ -174,6 +174,33 @@ def test_fused_resnet18_matches_reference_logits(tag, shape):
     assert np.allclose(y, y_layerwise, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("activation", [None, nn.PReLU], ids=["relu", "prelu"])
+def test_fused_resnet50_bottleneck_matches_layerwise_and_cpu(activation):
+    """Bottleneck stages (1x1 -> 3x3(stride) -> 1x1): activations stay packed across the three
+    binary convs; only the block output is written in fp32."""
+    cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
+                      weight_pre_process=XNORWeightBinarizer)
+    kw = {} if activation is None else {"activation": activation}
+    net = bnn.prepare_binary_model(resnet50(num_classes=64, **kw), cfg,
+                                   custom_config_layers_name={"conv1": bnn.BConfig(), "fc": bnn.BConfig()})
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in gen.model_state(shapes, 2).items()})
+    net.eval()
+    x = torch.from_numpy(gen.normal(gen.seed_of("r50"), (2, 3, 96, 96)))
+    with torch.no_grad():
+        ref = net(x).numpy()                                   # CPU: torch composition
+    net = net.to(DEV)
+    fused = FusedResNet(net)
+    assert len(fused._blocks) == 16 and all(len(b["convs"]) == 3 for b in fused._blocks)
+    before = fastpath.stats()["conv2d"]
+    y = fused(x.to(DEV)).cpu().numpy()
+    assert fastpath.stats()["conv2d"] == before
+    with torch.no_grad():
+        lw = net(x.to(DEV)).cpu().numpy()                      # per-layer HIP path
+    assert np.allclose(y, lw, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+    assert np.allclose(y, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+
+
 def test_fused_resnet18_graph_replay_is_bit_identical():
     net = _r18()
     fused = FusedResNet(net)
@@ -206,8 +233,9 @@ def test_fused_resnet18_prelu_variant():
 def test_unsupported_models_are_left_alone():
     cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
                       weight_pre_process=XNORWeightBinarizer)
-    r50 = bnn.prepare_binary_model(resnet50(), cfg).to(DEV).eval()
-    assert optimize_for_inference(r50) is r50
+    from bnn_amd.models import PreBasicBlock
+    pre = bnn.prepare_binary_model(resnet18(block_type=PreBasicBlock), cfg).to(DEV).eval()
+    assert optimize_for_inference(pre) is pre          # pre-activation blocks: per-layer path only
     with pytest.raises(FusionError):
         FusedResNet(_r18().train())
     with pytest.raises(FusionError):
