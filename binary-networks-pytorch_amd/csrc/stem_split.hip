@@ -36,11 +36,20 @@ constexpr int CTH = 2 * PTH + 1, CTW = 2 * PTW + 1;  // conv tile 17 x 15 (pool 
 constexpr int MPIX = CTH * CTW;                      // 255
 constexpr int ITH = 2 * CTH + 5;                     // 39 input rows
 constexpr int ITWP = 36;                             // 35 input columns + 1 zero column (kx = 7)
-constexpr int ICHP = ITH * ITWP;                     // 1404 halves per channel
-constexpr int NINP = CIN * ICHP;                     // 4212 halves per plane
+// Patch rows are stored ROWH = 96 halves (48 dwords = 16 mod 32 banks) apart: the four k-rows a wave reads
+// at once (lane>>4 -> consecutive ky) then fall into alternating halves of the 32 LDS banks, so the two
+// 16-lane groups of each half-wave never collide.  (Dense rows of 18 dwords: +50 % LDS cycles on the
+// A-operand reads, measured with SQ_LDS_BANK_CONFLICT.)
+constexpr int ROWH = 96;
+constexpr int ICHP = ITH * ROWH;                     // halves per channel plane
+constexpr int NINP = CIN * ICHP;                     // halves per plane (22.5 KB)
 constexpr int NROW = CIN * ITH;                      // 117 patch rows
 constexpr int NPC = ITWP / 2;                        // 18 column pairs per row
-constexpr int SM = 257;                              // stage row stride in floats (bank spread)
+// Staged conv tile: [conv pixel m][channel], row stride SC floats.  SC = 68 (= 4 mod 64) makes both sides
+// conflict-free: the MFMA D layout writes (channel = lane&15, pixel = 4*(lane>>4)+r) -> bank lane&15 + 16*(lane>>4),
+// the pooling threads read (channel = lane&7 [+8*wave], column = lane>>3) -> bank lane&7 + 8*(lane>>3).
+// (The channel-major layout it replaces spent 55 % of the LDS-active cycles in bank conflicts: PMC.)
+constexpr int SC = COUT + 4;
 constexpr int NT = 512;
 constexpr int RSTEP = NT / NPC;                      // 28 rows per sweep (504 fetching threads)
 constexpr int PER_T = (NROW + RSTEP - 1) / RSTEP;    // 5 column pairs per thread
@@ -49,7 +58,7 @@ constexpr int SUBS = 4, TT = 2;                      // sub-tiles and channel ti
 constexpr int OFF_HI = 0;
 constexpr int OFF_LO = OFF_HI + ((NINP * 2 + 15) / 16) * 16;
 constexpr int OFF_STAGE = OFF_LO + ((NINP * 2 + 15) / 16) * 16;
-constexpr int OFF_BITS = OFF_STAGE + COUT * SM * 4;  // sign bytes of the tile: [2][56 pixels][8]
+constexpr int OFF_BITS = OFF_STAGE + (MPIX + 1) * SC * 4;  // sign bytes of the tile: [2][56 pixels][8]
 constexpr int LDS_BYTES = OFF_BITS + 2 * PTH * PTW * 8;
 }  // namespace stem2
 
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
   for (int ks = 0; ks < KSTEPS; ++ks) {
     const int krow = 4 * ks + lg;
     const int c = krow / KS, ky = krow - c * KS;
-    koff[ks] = krow < CIN * KS ? c * ICHP + ky * ITWP : 0;  // zero-weight rows: any valid address
+    koff[ks] = krow < CIN * KS ? c * ICHP + ky * ROWH : 0;  // zero-weight rows: any valid address
   }
   int abase[SUBS];
 #pragma unroll
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
     int m = (SUBS * mg + i) * 16 + li;
     if (m >= MPIX) m = MPIX - 1;
     const int cy = m / CTW, cx = m - cy * CTW;
-    abase[i] = 2 * cy * ITWP + 2 * cx;
+    abase[i] = 2 * cy * ROWH + 2 * cx;
   }
   // BN constants of the accumulator layout (column = li -> channel 32*nh + 16*tt + li)
   float ba[TT], bb[TT];
@@ -170,8 +179,8 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
         h[1] = (_Float16)nx1[u];
         l[0] = (_Float16)(nx0[u] - (float)h[0]);
         l[1] = (_Float16)(nx1[u] - (float)h[1]);
-        reinterpret_cast<half2v*>(hiP)[R * NPC + fpc] = h;
-        reinterpret_cast<half2v*>(loP)[R * NPC + fpc] = l;
+        reinterpret_cast<half2v*>(hiP)[R * (ROWH / 2) + fpc] = h;
+        reinterpret_cast<half2v*>(loP)[R * (ROWH / 2) + fpc] = l;
       }
     }
   };
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
   // them as whole 64-bit words (byte stores from 8 waves into one word cost ~80 us at batch 256)
   int prev_n = -1, prev_py0 = 0, prev_px0 = 0, buf = 0;
   auto flush_bits = [&](int b) {
-    if (P && prev_n >= 0 && tid < PTH * PTW) {
+    if (P && !(BNN_STEM_ABL & 32) && prev_n >= 0 && tid < PTH * PTW) {
       const int ply = tid / PTW, plx = tid - ply * PTW;
       const int py = prev_py0 + ply, px = prev_px0 + plx;
       if (py < Hp && px < Wp) {
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
           for (int tt = 0; tt < TT; ++tt) {
             const float v = fmaxf(fmaf(acc[i][tt][r], ba[tt], bb[tt]), 0.0f);
             // positions outside the conv output are MaxPool padding: 0 never beats a ReLU output
-            stage[(32 * nh + 16 * tt + li) * SM + m] = inside ? v : 0.0f;
+            stage[m * SC + 32 * nh + 16 * tt + li] = inside ? v : 0.0f;
           }
         }
       }
@@ -284,9 +293,10 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
     const bool col_live = valid && pplx < PTW && px < Wp;
     float hm[CTH];
     {
-      const float* sp = stage + pch * SM + 2 * (pplx < PTW ? pplx : 0);
+      const float* sp = stage + (2 * (pplx < PTW ? pplx : 0)) * SC + pch;
 #pragma unroll
-      for (int r = 0; r < CTH; ++r) hm[r] = fmaxf(fmaxf(sp[r * CTW], sp[r * CTW + 1]), sp[r * CTW + 2]);
+      for (int r = 0; r < CTH; ++r)
+        hm[r] = fmaxf(fmaxf(sp[(r * CTW) * SC], sp[(r * CTW + 1) * SC]), sp[(r * CTW + 2) * SC]);
     }
 #pragma unroll
     for (int ply = 0; ply < PTH; ++ply) {
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
       const bool live = col_live && py < Hp;  // py < Hp is workgroup-uniform
       const float v = fmaxf(fmaxf(hm[2 * ply], hm[2 * ply + 1]), hm[2 * ply + 2]);
       if (live && out) out[(((size_t)n * COUT + pch) * Hp + py) * Wp + px] = v;
-      if (P) {  // lanes 8*plx .. 8*plx+7 hold the 8 channels of byte `wave` of pixel (ply, plx)
+      if (P && !(BNN_STEM_ABL & 16)) {  // lanes 8*plx .. 8*plx+7 hold the 8 channels of byte `wave` of pixel (ply, plx)
         const unsigned long long mask = __ballot(live && is_pos(v));
         if (pchl == 0 && pplx < PTW)
           bits[((buf * PTH + ply) * PTW + pplx) * 8 + wave] = (uint8_t)(mask >> (8 * pplx));

@@ -6,12 +6,9 @@ R="$(cd "$(dirname "$0")/.." && pwd)"
 V="$R/binary-networks-pytorch_amd/bnn_amd/_lib/variants"
 declare -A CFG=(
   [abl0]="-DBNN_STEM_ABL=0"
-  [abl1]="-DBNN_STEM_ABL=1"
-  [abl2]="-DBNN_STEM_ABL=2"
-  [abl4]="-DBNN_STEM_ABL=4"
-  [abl8]="-DBNN_STEM_ABL=8"
-  [abl15]="-DBNN_STEM_ABL=15"
-  [abl7]="-DBNN_STEM_ABL=7"
+  [abl16]="-DBNN_STEM_ABL=16"
+  [abl32]="-DBNN_STEM_ABL=32"
+  [abl48]="-DBNN_STEM_ABL=48"
 )
 if [ "${1:-build}" = "build" ]; then
   rm -rf "$V"; mkdir -p "$V"
