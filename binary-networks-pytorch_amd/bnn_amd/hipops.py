@@ -96,6 +96,25 @@ def pack_act(x: torch.Tensor) -> PackedAct:
     return a
 
 
+def bn_act_pack(x: torch.Tensor, bn_scale=None, bn_shift=None, relu: bool = False) -> PackedAct:
+    """``sign(act(bn(x)))`` of an fp32 NCHW tensor in one pass: the input binarisation of a pre-activation
+    block (bnn/models/layers/res_block.py:148, hierarchical_block.py:39)."""
+    x = _require_cuda_f32(x, "activation")
+    if x.dim() != 4:
+        raise native.NativeError(f"bnn_amd: bn_act_pack expects NCHW, got shape {tuple(x.shape)}")
+    lib = native.require()
+    N, C, H, W = x.shape
+    bn_scale = _per_channel(bn_scale, C, "bn_scale")
+    bn_shift = _per_channel(bn_shift, C, "bn_shift")
+    with torch.cuda.device(x.device):
+        a = empty_packed(N, C, H, W, x.device)
+        native.check(lib.bnn_hip_bn_act_pack_f32(x.data_ptr(), N, C, H, W, _ptr(bn_scale), _ptr(bn_shift),
+                                                 int(bool(relu)), a.P.data_ptr(), a.M.data_ptr(),
+                                                 _stream(x.device)), "bnn_hip_bn_act_pack_f32")
+    a.nonneg = bool(relu)
+    return a
+
+
 def avgpool_pack(x: torch.Tensor, k: int, nonneg: bool = False) -> PackedAct:
     """``AvgPool2d(k, k, ceil_mode=True, count_include_pad=False)`` + sign, fused
     (shortcut branch of bnn/models/resnet.py:128-133).  ``nonneg``: the caller knows ``x >= 0``
@@ -261,9 +280,16 @@ def bconv2d(a: PackedAct, w: PackedWeight, bias: Optional[torch.Tensor] = None,
 def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, bn_scale=None,
                   bn_shift=None, residual=None, prelu=None, relu=False, out_f32=True,
                   out_packed=False, stride=1, padding=0, dilation=1, force_generic=False,
-                  weights: Optional[str] = None):
+                  weights: Optional[str] = None, residual_after_act: bool = False,
+                  pack_before_residual: bool = False, pack_scale=None, pack_shift=None,
+                  pack_relu: bool = False, out: Optional[torch.Tensor] = None, out_c_offset: int = 0):
     """Binary convolution + fused epilogue (see ``bnn_hip_epilogue``): returns
-    ``(y_fp32 | None, PackedAct(sign(y)) | None)``."""
+    ``(y_fp32 | None, PackedAct(sign(p)) | None)``.
+
+    ``out``: write the fp32 result into channels ``[out_c_offset, out_c_offset + O)`` of this
+    preallocated ``[N, C_total, Ho, Wo]`` tensor (``torch.cat`` in place); ``residual`` then has
+    ``C_total`` channels too.  The remaining keyword arguments are the pre-activation switches of
+    ``BNN_HIP_EPI_*`` (include/bnn_hip.h)."""
     lib = native.require()
     d = _desc(a.shape, w.shape, stride, padding, dilation, _flags(w, force_generic, weights, a))
     ho, wo = conv_out_hw(d.H, d.W, d.KH, d.KW, stride, padding, dilation)
@@ -275,23 +301,41 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
     bn_scale = _per_channel(bn_scale, d.O, "bn_scale")
     bn_shift = _per_channel(bn_shift, d.O, "bn_shift")
     prelu = _per_channel(prelu, d.O, "prelu")
+    pack_scale = _per_channel(pack_scale, d.O, "pack_scale")
+    pack_shift = _per_channel(pack_shift, d.O, "pack_shift")
+    c_total = d.O
+    if out is not None:
+        if not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.dim() == 4
+                and out.shape[0] == d.N and tuple(out.shape[2:]) == (ho, wo)
+                and 0 <= out_c_offset and out_c_offset + d.O <= out.shape[1]):
+            raise native.NativeError("bnn_amd: `out` must be a contiguous fp32 [N, C_total, Ho, Wo] tensor "
+                                     "with room for O channels at out_c_offset")
+        c_total = out.shape[1]
+        if d.N * c_total * ho * wo > _MAX_ELEMS:
+            raise native.NativeError("bnn_amd: bconv2d_fused: split the batch (tensor > 2^31-1 elements)")
     if residual is not None:
         residual = _require_cuda_f32(residual, "residual")
-        if tuple(residual.shape) != (d.N, d.O, ho, wo):
+        if tuple(residual.shape) != (d.N, c_total, ho, wo):
             raise native.NativeError(f"bnn_amd: residual shape {tuple(residual.shape)} != output")
+    eflags = (native.EPI_RES_AFTER_ACT if residual_after_act else 0) | \
+        (native.EPI_PACK_BEFORE_RES if pack_before_residual else 0) | (native.EPI_PACK_RELU if pack_relu else 0)
     with torch.cuda.device(dev):
-        y = torch.empty((d.N, d.O, ho, wo), dtype=torch.float32, device=dev) if out_f32 else None
+        y = out if out is not None else (
+            torch.empty((d.N, d.O, ho, wo), dtype=torch.float32, device=dev) if out_f32 else None)
         pk = empty_packed(d.N, d.O, ho, wo, dev) if out_packed else None
         e = native.Epilogue(w.alpha.data_ptr(), _ptr(bias), _ptr(post_scale), _ptr(bn_scale),
-                            _ptr(bn_shift), _ptr(residual), _ptr(prelu), int(bool(relu)), 0,
+                            _ptr(bn_shift), _ptr(residual), _ptr(prelu), int(bool(relu)), eflags,
                             _ptr(y), None if pk is None else pk.P.data_ptr(),
-                            None if pk is None else pk.M.data_ptr())
+                            None if pk is None else pk.M.data_ptr(), _ptr(pack_scale), _ptr(pack_shift),
+                            out_c_offset if out is not None else 0, c_total if out is not None else 0)
         native.check(lib.bnn_hip_bconv2d_fused(ctypes.byref(d), a.P.data_ptr(), a.M.data_ptr(),
                                                w.wbits.data_ptr(), w.wnz.data_ptr(),
                                                ctypes.byref(e), _stream(dev)),
                      "bnn_hip_bconv2d_fused")
-    if pk is not None:
-        pk.nonneg = bool(relu) and prelu is None  # relu is applied before prelu: y >= 0
+    if pk is not None:  # mirrors the kernel's rule for leaving the M plane at zero
+        late = residual is not None and residual_after_act
+        pk.nonneg = bool(pack_relu) or (bool(relu) and prelu is None and pack_scale is None
+                                        and (not late or pack_before_residual))
     return y, pk
 
 

@@ -22,12 +22,12 @@ FLAG_WEIGHTS_SGPR = 4
 FLAG_WEIGHTS_LDS = 8
 FLAG_WEIGHTS_VGPR = 16
 FLAG_ACT_NONNEG = 32
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/bnn_hip.h declares (tests assert the .so exports all of them)
 EXPORTED_SYMBOLS = (
     "bnn_hip_abi_version", "bnn_hip_status_string", "bnn_hip_launch_count", "bnn_hip_device_info",
-    "bnn_hip_act_words", "bnn_hip_weight_layout", "bnn_hip_pack_act_f32",
+    "bnn_hip_act_words", "bnn_hip_weight_layout", "bnn_hip_pack_act_f32", "bnn_hip_bn_act_pack_f32",
     "bnn_hip_avgpool_pack_f32", "bnn_hip_bn_relu_maxpool_pack_f32", "bnn_hip_stem7x7_bn_relu_pool_pack_f32",
     "bnn_hip_pack_weight_f32", "bnn_hip_bconv2d",
     "bnn_hip_bconv2d_fused", "bnn_hip_bconv2d_dot", "bnn_hip_blinear",
@@ -64,8 +64,15 @@ class Epilogue(ctypes.Structure):
     _fields_ = [("alpha", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("post_scale", ctypes.c_void_p),
                 ("bn_scale", ctypes.c_void_p), ("bn_shift", ctypes.c_void_p),
                 ("residual", ctypes.c_void_p), ("prelu", ctypes.c_void_p),
-                ("relu", ctypes.c_int32), ("reserved", ctypes.c_int32),
-                ("out_f32", ctypes.c_void_p), ("out_P", ctypes.c_void_p), ("out_M", ctypes.c_void_p)]
+                ("relu", ctypes.c_int32), ("flags", ctypes.c_int32),
+                ("out_f32", ctypes.c_void_p), ("out_P", ctypes.c_void_p), ("out_M", ctypes.c_void_p),
+                ("pack_scale", ctypes.c_void_p), ("pack_shift", ctypes.c_void_p),
+                ("out_c_offset", ctypes.c_int32), ("out_c_total", ctypes.c_int32)]
+
+
+EPI_RES_AFTER_ACT = 1
+EPI_PACK_BEFORE_RES = 2
+EPI_PACK_RELU = 4
 
 
 class NativeError(RuntimeError):
@@ -94,6 +101,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_weight_layout.argtypes = [_i, _i, _i, _i, ctypes.POINTER(WLayout)]
     lib.bnn_hip_pack_act_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _vp]
     lib.bnn_hip_avgpool_pack_f32.argtypes = [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]
+    lib.bnn_hip_bn_act_pack_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]
     lib.bnn_hip_stem7x7_bn_relu_pool_pack_f32.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]
     lib.bnn_hip_bn_relu_maxpool_pack_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i,
                                                      _vp, _vp, _vp, _vp]

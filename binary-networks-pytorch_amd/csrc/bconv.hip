@@ -34,6 +34,7 @@ struct Geo {
   int npix;      // N*Ho*Wo
   int flags;     // EF_*
   int cw32_out;  // words per pixel per plane of the packed OUTPUT (EF_PACK)
+  int c_off, c_tot;  // fp32 output / residual are [N,c_tot,Ho,Wo]; this conv owns channels c_off..c_off+O
   int tiles;     // 64-pixel tiles of the output
   int tiles_per_xcd;  // ceil(tiles / 8)
 };
@@ -48,6 +49,11 @@ enum : int {
   EF_PRELU = 64,
   EF_OUTF = 128,   // write y as fp32 NCHW
   EF_PACK = 256,   // write sign(y) as bit planes for the next binary layer
+  // pre-activation dataflows (BNN_HIP_EPI_*, include/bnn_hip.h)
+  EF_RES_LATE = 512,    // residual added after the activation
+  EF_PACK_PRE = 1024,   // binarise the value before a late residual
+  EF_PACK_AFF = 2048,   // next layer's BatchNorm applied to the value that is binarised
+  EF_PACK_RELU = 4096,  // planes of sign(relu(p)): M = 0
 };
 
 struct EpiArgs {
@@ -61,6 +67,8 @@ struct EpiArgs {
   void* out;
   uint32_t* outP;
   uint32_t* outM;
+  const float* pack_a;
+  const float* pack_b;
 };
 
 #ifndef BNN_TILED_MIN_WAVES  // waves per SIMD the tiled kernels are register-allocated for
@@ -204,7 +212,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
                                          const EpiArgs& e, uint32_t& pbits, uint32_t& mbits) {
   constexpr bool FUSED = EP != EP_PLAIN;
   const int hw = g.Ho * g.Wo;
-  const unsigned lane_off = (unsigned)(px.n * g.O * hw + px.r);  // host keeps N*O*hw < 2^30
+  const unsigned lane_off = (unsigned)(px.n * g.c_tot * hw + px.r);  // host keeps N*c_tot*hw < 2^31
   const int f = EP == EP_MID ? kFlagsMid : EP == EP_OUT ? kFlagsOut : EP == EP_DS ? kFlagsDs : g.flags;
   const bool full = o0 + NACC <= g.O;
   if (f & EF_RAW) {
@@ -212,7 +220,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
       int32_t* o32 = static_cast<int32_t*>(e.out);
 #pragma unroll
       for (int j = 0; j < NACC; ++j)
-        if (full || o0 + j < g.O) (o32 + (size_t)(o0 + j) * hw)[lane_off] = dot[j];
+        if (full || o0 + j < g.O) (o32 + (size_t)(o0 + j + g.c_off) * hw)[lane_off] = dot[j];
     }
     return;
   }
@@ -225,7 +233,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
       if (full || o < g.O) {
         float y = fmaf(e.alpha[o], (float)dot[j], hb ? e.bias[o] : 0.0f);
         if (hs) y *= e.scale[o];
-        if (px.live) (outf + (size_t)o * hw)[lane_off] = y;
+        if (px.live) (outf + (size_t)(o + g.c_off) * hw)[lane_off] = y;
       }
     }
     return;
@@ -238,14 +246,20 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
       float y = fmaf(e.alpha[o], (float)dot[j], (f & EF_BIAS) ? e.bias[o] : 0.0f);
       if (f & EF_SCALE) y *= e.scale[o];
       if (f & EF_BN) y = fmaf(y, e.bn_a[o], e.bn_b[o]);
-      if (f & EF_RES) y += resv[j];
+      if ((f & EF_RES) && !(f & EF_RES_LATE)) y += resv[j];
       if (f & EF_RELU) y = (y < 0.0f) ? 0.0f : y;  // keeps NaN, like torch.relu
       if (f & EF_PRELU) y = (y >= 0.0f) ? y : e.prelu[o] * y;
-      if ((f & EF_OUTF) && px.live) (outf + (size_t)o * hw)[lane_off] = y;
+      float pv = y;  // the value the next binary layer binarises
+      if ((f & EF_RES) && (f & EF_RES_LATE)) y += resv[j];
+      if (!(f & EF_PACK_PRE)) pv = y;
+      if ((f & EF_OUTF) && px.live) (outf + (size_t)(o + g.c_off) * hw)[lane_off] = y;
       if (f & EF_PACK) {
-        pbits |= (is_pos(y) ? 1u : 0u) << (bit0 + j);
-        // after a ReLU nothing is negative: the M plane of this block stays 0
-        if (!(f & EF_RELU)) mbits |= (is_neg(y) ? 1u : 0u) << (bit0 + j);
+        if (f & EF_PACK_AFF) pv = fmaf(pv, e.pack_a[o], e.pack_b[o]);
+        pbits |= (is_pos(pv) ? 1u : 0u) << (bit0 + j);
+        // straight out of a ReLU nothing is negative: the M plane of this block stays 0
+        const bool no_neg = (f & EF_PACK_RELU) ||
+                            ((f & EF_RELU) && !(f & EF_PACK_AFF) && (!(f & EF_RES_LATE) || (f & EF_PACK_PRE)));
+        if (!no_neg) mbits |= (is_neg(pv) ? 1u : 0u) << (bit0 + j);
       }
     }
   }
@@ -264,10 +278,10 @@ __device__ __forceinline__ void prefetch_residual(const Geo& g, const Pix& px, i
     return;
   }
   const int hw = g.Ho * g.Wo;
-  const unsigned lane_off = (unsigned)(px.n * g.O * hw + px.r);
+  const unsigned lane_off = (unsigned)(px.n * g.c_tot * hw + px.r);
 #pragma unroll
   for (int j = 0; j < NACC; ++j)
-    resv[j] = (px.live && o0 + j < g.O) ? (e.res + (size_t)(o0 + j) * hw)[lane_off] : 0.0f;
+    resv[j] = (px.live && o0 + j < g.O) ? (e.res + (size_t)(o0 + j + g.c_off) * hw)[lane_off] : 0.0f;
 }
 
 // sign(y) of one 32-channel block: one half of a uint64 word of the [n][group][y][x] output planes.
@@ -303,9 +317,10 @@ __device__ __forceinline__ void store_packed_part(const Geo& g, const Pix& px, i
   const float *__restrict__ alpha, const float *__restrict__ bias, const float *__restrict__ scale, \
       const float *__restrict__ bn_a, const float *__restrict__ bn_b,                           \
       const float *__restrict__ prelu, const float *__restrict__ res, void *__restrict__ out,   \
-      uint32_t *__restrict__ outP, uint32_t *__restrict__ outM
+      uint32_t *__restrict__ outP, uint32_t *__restrict__ outM,                                 \
+      const float *__restrict__ pack_a, const float *__restrict__ pack_b
 #define BNN_EPI_INIT \
-  EpiArgs epi{alpha, bias, scale, bn_a, bn_b, prelu, res, out, outP, outM}
+  EpiArgs epi{alpha, bias, scale, bn_a, bn_b, prelu, res, out, outP, outM, pack_a, pack_b}
 
 // ---------------------------------------------------------------------------------
 // Tiled kernel, weights streamed through SGPRs (scalar cache).  Best when all waves in
@@ -701,11 +716,18 @@ static Geo make_geo(const ConvP& p) {
   if (p.prelu) f |= EF_PRELU;
   if (p.out) f |= EF_OUTF;
   if (p.outP && p.outM) f |= EF_PACK;
+  if (p.res && (p.eflags & BNN_HIP_EPI_RES_AFTER_ACT)) f |= EF_RES_LATE;
+  if (p.res && (p.eflags & BNN_HIP_EPI_RES_AFTER_ACT) && (p.eflags & BNN_HIP_EPI_PACK_BEFORE_RES)) f |= EF_PACK_PRE;
+  if (p.pack_a && p.pack_b) f |= EF_PACK_AFF;
+  if (p.eflags & BNN_HIP_EPI_PACK_RELU) f |= EF_PACK_RELU;
+  g.c_off = p.c_off;
+  g.c_tot = p.c_tot > 0 ? p.c_tot : p.O;
   g.flags = f;
   return g;
 }
 
-#define BNN_EPI_ACTUALS p.alpha, p.bias, p.scale, p.bn_a, p.bn_b, p.prelu, p.res, p.out, p.outP, p.outM
+#define BNN_EPI_ACTUALS \
+  p.alpha, p.bias, p.scale, p.bn_a, p.bn_b, p.prelu, p.res, p.out, p.outP, p.outM, p.pack_a, p.pack_b
 
 // grid.y: one block per 32 output channels; in pack mode also the (all-zero) tail words of the
 // packed output row so that every word of the next layer's input is written.

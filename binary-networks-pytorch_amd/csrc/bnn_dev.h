@@ -59,6 +59,12 @@ struct ConvP {
   void* out;       // fp32 NCHW, or int32 NCHW when raw
   uint32_t* outP;  // packed sign planes of the output, or null
   uint32_t* outM;
+  // generalised epilogue (BNN_HIP_EPI_*): next layer's BN before packing, residual after the
+  // activation, packing the pre-residual value, channel slice of a wider output tensor
+  const float* pack_a;
+  const float* pack_b;
+  int eflags;
+  int c_off, c_tot;
   bool raw;
   bool relu;
   int N, H, Wd, Ho, Wo, O;
@@ -71,6 +77,8 @@ struct ConvP {
 int choose_cwc(int cw32, int KH, int KW);
 int launch_pack_act(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
                     hipStream_t stream);
+int launch_bn_act_pack(const float* x, int N, int C, int H, int W, const float* bn_a, const float* bn_b,
+                       int relu, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_avgpool_pack(const float* x, int N, int C, int H, int W, int k, uint64_t* P, uint64_t* M,
                         hipStream_t stream);
 int launch_bn_relu_maxpool_pack(const float* x, int N, int C, int H, int W, const float* bn_a,

@@ -45,6 +45,10 @@ int run_conv(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M, c
   if (!p.raw && !p.alpha) return BNN_HIP_ERR_INVALID_ARG;
   if ((p.bn_a == nullptr) != (p.bn_b == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
   if ((p.outP == nullptr) != (p.outM == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
+  if ((p.pack_a == nullptr) != (p.pack_b == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
+  if (p.c_tot == 0) { p.c_off = 0; p.c_tot = d->O; }
+  if (p.c_off < 0 || p.c_off + d->O > p.c_tot) return BNN_HIP_ERR_INVALID_ARG;
+  if ((long long)d->N * p.c_tot * Ho * Wo > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
   if ((d->flags & BNN_HIP_FLAG_WEIGHT_ZEROS) && !wnz) return BNN_HIP_ERR_INVALID_ARG;
   if (!aligned(P, 16) || !aligned(M, 16) || !aligned(wbits, 16)) return BNN_HIP_ERR_INVALID_ARG;
   if (p.outP && (!aligned(p.outP, 8) || !aligned(p.outM, 8))) return BNN_HIP_ERR_INVALID_ARG;
@@ -131,6 +135,18 @@ int bnn_hip_pack_act_f32(const float* x, int N, int C, int H, int W, uint64_t* P
   return bnn::launch_pack_act(x, N, C, H, W, P, M, static_cast<hipStream_t>(stream));
 }
 
+int bnn_hip_bn_act_pack_f32(const float* x, int N, int C, int H, int W, const float* bn_scale,
+                            const float* bn_shift, int relu, uint64_t* P, uint64_t* M, void* stream) {
+  if (!x || !P || !M || N <= 0 || C <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if ((bn_scale == nullptr) != (bn_shift == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
+  if ((long long)N * H * W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if ((C + 63) / 64 > 65535) return BNN_HIP_ERR_UNSUPPORTED;  // grid.y limit
+  if (!aligned(P, 8) || !aligned(M, 8) || !aligned(x, 4)) return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  return bnn::launch_bn_act_pack(x, N, C, H, W, bn_scale, bn_shift, relu, P, M,
+                                 static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_avgpool_pack_f32(const float* x, int N, int C, int H, int W, int k, uint64_t* P,
                              uint64_t* M, void* stream) {
   if (!x || !P || !M || N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0) return BNN_HIP_ERR_INVALID_ARG;
@@ -203,6 +219,9 @@ int bnn_hip_bconv2d_fused(const bnn_hip_conv_desc* d, const uint64_t* P, const u
   p.out = e->out_f32;
   p.outP = reinterpret_cast<uint32_t*>(e->out_P);
   p.outM = reinterpret_cast<uint32_t*>(e->out_M);
+  p.pack_a = e->pack_scale; p.pack_b = e->pack_shift;
+  p.eflags = e->flags;
+  p.c_off = e->out_c_offset; p.c_tot = e->out_c_total;
   return run_conv(d, P, M, wbits, wnz, p, stream);
 }
 

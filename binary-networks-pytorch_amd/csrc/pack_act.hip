@@ -24,11 +24,16 @@ struct PixVec<2> { using type = float2; };
 template <>
 struct PixVec<4> { using type = float4; };
 
-template <int VP>
+// AFF: v = fmaf(x, bn_a[c], bn_b[c]) first (eval-mode BatchNorm in front of a pre-activation block's
+// binary conv: res_block.py:148, hierarchical_block.py:39); relu != 0: planes of sign(max(v, 0)).
+template <int VP, bool AFF = false>
 __global__ __launch_bounds__(256) void pack_act_kernel(const float* __restrict__ x, int C, int HW,
                                                        long long npix, int cw64,
                                                        uint64_t* __restrict__ P,
-                                                       uint64_t* __restrict__ M) {
+                                                       uint64_t* __restrict__ M,
+                                                       const float* __restrict__ bn_a = nullptr,
+                                                       const float* __restrict__ bn_b = nullptr,
+                                                       int relu = 0) {
   using V = typename PixVec<VP>::type;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long pix0 = t * VP;
@@ -51,20 +56,24 @@ __global__ __launch_bounds__(256) void pack_act_kernel(const float* __restrict__
       for (int b = 31; b >= 0; --b) {
         const V xv = *reinterpret_cast<const V*>(xb + (size_t)(c0 + b) * HW);
         const float* xs = reinterpret_cast<const float*>(&xv);
+        const float ca = AFF && bn_a ? bn_a[c0 + b] : 1.0f, cb = AFF && bn_a ? bn_b[c0 + b] : 0.0f;
 #pragma unroll
         for (int v = 0; v < VP; ++v) {
-          pw[h][v] = (pw[h][v] << 1) | (is_pos(xs[v]) ? 1u : 0u);
-          mw[h][v] = (mw[h][v] << 1) | (is_neg(xs[v]) ? 1u : 0u);
+          const float u = (AFF && bn_a) ? fmaf(xs[v], ca, cb) : xs[v];
+          pw[h][v] = (pw[h][v] << 1) | (is_pos(u) ? 1u : 0u);
+          mw[h][v] = (mw[h][v] << 1) | ((!(AFF && relu) && is_neg(u)) ? 1u : 0u);
         }
       }
     } else {
       for (int b = 0; b < 32 && c0 + b < C; ++b) {
         const V xv = *reinterpret_cast<const V*>(xb + (size_t)(c0 + b) * HW);
         const float* xs = reinterpret_cast<const float*>(&xv);
+        const float ca = AFF && bn_a ? bn_a[c0 + b] : 1.0f, cb = AFF && bn_a ? bn_b[c0 + b] : 0.0f;
 #pragma unroll
         for (int v = 0; v < VP; ++v) {
-          pw[h][v] |= (is_pos(xs[v]) ? 1u : 0u) << b;
-          mw[h][v] |= (is_neg(xs[v]) ? 1u : 0u) << b;
+          const float u = (AFF && bn_a) ? fmaf(xs[v], ca, cb) : xs[v];
+          pw[h][v] |= (is_pos(u) ? 1u : 0u) << b;
+          mw[h][v] |= ((!(AFF && relu) && is_neg(u)) ? 1u : 0u) << b;
         }
       }
     }
@@ -87,11 +96,31 @@ int launch_pack_act(const float* x, int N, int C, int H, int W, uint64_t* P, uin
   const bool a8 = (reinterpret_cast<uintptr_t>(x) & 7u) == 0;
   auto grid = [&](long long nthr) { return dim3((unsigned)((nthr + 255) / 256), (unsigned)cw64); };
   if (HW % 4 == 0 && a16)
-    hipLaunchKernelGGL(pack_act_kernel<4>, grid(npix / 4), dim3(256), 0, stream, x, C, HW, npix, cw64, P, M);
+    hipLaunchKernelGGL((pack_act_kernel<4, false>), grid(npix / 4), dim3(256), 0, stream, x, C, HW, npix, cw64, P, M);
   else if (HW % 2 == 0 && a8)
-    hipLaunchKernelGGL(pack_act_kernel<2>, grid(npix / 2), dim3(256), 0, stream, x, C, HW, npix, cw64, P, M);
+    hipLaunchKernelGGL((pack_act_kernel<2, false>), grid(npix / 2), dim3(256), 0, stream, x, C, HW, npix, cw64, P, M);
   else
-    hipLaunchKernelGGL(pack_act_kernel<1>, grid(npix), dim3(256), 0, stream, x, C, HW, npix, cw64, P, M);
+    hipLaunchKernelGGL((pack_act_kernel<1, false>), grid(npix), dim3(256), 0, stream, x, C, HW, npix, cw64, P, M);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+int launch_bn_act_pack(const float* x, int N, int C, int H, int W, const float* bn_a, const float* bn_b,
+                       int relu, uint64_t* P, uint64_t* M, hipStream_t stream) {
+  const int HW = H * W;
+  const long long npix = (long long)N * HW;
+  const int cw64 = (C + 63) / 64;
+  const bool a16 = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+  const bool a8 = (reinterpret_cast<uintptr_t>(x) & 7u) == 0;
+  auto grid = [&](long long nthr) { return dim3((unsigned)((nthr + 255) / 256), (unsigned)cw64); };
+  if (HW % 4 == 0 && a16)
+    hipLaunchKernelGGL((pack_act_kernel<4, true>), grid(npix / 4), dim3(256), 0, stream, x, C, HW, npix, cw64,
+                       P, M, bn_a, bn_b, relu);
+  else if (HW % 2 == 0 && a8)
+    hipLaunchKernelGGL((pack_act_kernel<2, true>), grid(npix / 2), dim3(256), 0, stream, x, C, HW, npix, cw64,
+                       P, M, bn_a, bn_b, relu);
+  else
+    hipLaunchKernelGGL((pack_act_kernel<1, true>), grid(npix), dim3(256), 0, stream, x, C, HW, npix, cw64, P,
+                       M, bn_a, bn_b, relu);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 

@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 2
+#define BNN_HIP_ABI_VERSION 3
 #define BNN_HIP_OCB 32 /* output channels per weight block (padding granularity of O) */
 
 typedef enum bnn_hip_status {
@@ -102,7 +102,23 @@ typedef struct bnn_hip_conv_desc {
  *     y = y + residual[n,o,y,x]                        shortcut                 (optional)
  *     y = relu(y)  |  y = y >= 0 ? y : prelu[o]*y      activation               (optional)
  * Outputs: out_f32 (fp32 NCHW) and/or out_P/out_M (sign(y) as bit planes, format above, with
- * C := O; every word is written, pad bits 0).  At least one output is required. */
+ * C := O; every word is written, pad bits 0).  At least one output is required.
+ *
+ * Pre-activation dataflows (bnn/models/layers/res_block.py:121-167 PreBasicBlock,
+ * hierarchical_block.py:38-60 HBlock) order things differently; `flags` and the trailing fields
+ * cover them without leaving the kernel:
+ *     BNN_HIP_EPI_RES_AFTER_ACT    the residual is added AFTER the activation   (y = act(conv); y += id)
+ *     p = value that is binarised for the next binary layer:
+ *         default                      p = y (the stored value)
+ *         BNN_HIP_EPI_PACK_BEFORE_RES  p = the value before a RES_AFTER_ACT residual was added
+ *     pack_scale/pack_shift != NULL    p = fmaf(p, pack_scale[o], pack_shift[o])   (the NEXT layer's BatchNorm)
+ *     BNN_HIP_EPI_PACK_RELU            planes of sign(relu(p)):  P = (p > 0), M = 0
+ *     out_c_total != 0                 out_f32 and residual are [N,out_c_total,Ho,Wo] tensors and this
+ *                                      convolution owns channels [out_c_offset, out_c_offset + O)
+ *                                      (torch.cat of HBlock written in place).                     */
+#define BNN_HIP_EPI_RES_AFTER_ACT 1
+#define BNN_HIP_EPI_PACK_BEFORE_RES 2
+#define BNN_HIP_EPI_PACK_RELU 4
 typedef struct bnn_hip_epilogue {
   const float* alpha;      /* [o_pad]                                   */
   const float* bias;       /* [O] or NULL                               */
@@ -112,10 +128,14 @@ typedef struct bnn_hip_epilogue {
   const float* residual;   /* [N,O,Ho,Wo] or NULL                       */
   const float* prelu;      /* [O] or NULL                               */
   int32_t relu;            /* non-zero: clamp at 0 after the residual   */
-  int32_t reserved;
+  int32_t flags;           /* BNN_HIP_EPI_*                             */
   float* out_f32;          /* [N,O,Ho,Wo] or NULL                       */
   uint64_t* out_P;         /* [N,ceil(O/64),Ho,Wo] or NULL              */
   uint64_t* out_M;
+  const float* pack_scale; /* [O] or NULL (both or neither)             */
+  const float* pack_shift;
+  int32_t out_c_offset;    /* see above; 0/0 = plain [N,O,Ho,Wo]        */
+  int32_t out_c_total;
 } bnn_hip_epilogue;
 
 typedef struct bnn_hip_wlayout {
@@ -166,6 +186,12 @@ int bnn_hip_pack_act_f32(const float* x, int N, int C, int H, int W,
  * ceil(H/k) x ceil(W/k) pixels.                                                    */
 int bnn_hip_avgpool_pack_f32(const float* x, int N, int C, int H, int W, int k,
                              uint64_t* P, uint64_t* M, void* stream);
+
+/* BatchNorm(eval) -> [ReLU] -> sign() of an fp32 NCHW tensor in one pass: the input binarisation of a
+ * pre-activation block (res_block.py:148 `conv1(bn1(x))`, hierarchical_block.py:39 `conv1(act1(bn1(x)))`).
+ *   v = fmaf(x, bn_scale[c], bn_shift[c])  (both NULL: v = x);  relu != 0: planes of sign(max(v, 0)).  */
+int bnn_hip_bn_act_pack_f32(const float* x, int N, int C, int H, int W, const float* bn_scale,
+                            const float* bn_shift, int relu, uint64_t* P, uint64_t* M, void* stream);
 
 /* Tail of the real-valued stem, one pass over the stem conv's fp32 NCHW output
  * (bnn/models/resnet.py:150-153: bn1 -> relu -> maxpool, then the sign() of the first binary

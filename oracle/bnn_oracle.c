@@ -314,6 +314,39 @@ void orc_fused_epilogue(const int32_t* dot, int N, int O, int HoWo, const float*
       }
 }
 
+/* The generalised epilogue of bnn_hip_epilogue (ABI 3) for pre-activation blocks
+ * (bnn/models/layers/res_block.py:147-152 PreBasicBlock: act(conv(bn(x))) ... y += shortcut;
+ * hierarchical_block.py:39-47 HBlock: conv(act(bn(x))), torch.cat, y += shortcut), op for op:
+ *   y = fmaf(alpha, dot, bias); y *= post_scale; y = fmaf(y, bn_a, bn_b);
+ *   res_late == 0: y += res;   relu / prelu;   p = y;   res_late != 0: y += res;
+ *   pack_pre == 0: p = y;      out = y;        pack_a: p = fmaf(p, pack_a, pack_b);  pack_relu: p = max(p, 0)
+ * `out` / `res` are [N, c_tot, HoWo] with this conv's channels at c_off; `pv` is [N, O, HoWo].        */
+void orc_fused_epilogue2(const int32_t* dot, int N, int O, int HoWo, const float* alpha,
+                         const float* bias, const float* post_scale, const float* bn_a,
+                         const float* bn_b, const float* res, const float* prelu, int relu,
+                         int res_late, int pack_pre, const float* pack_a, const float* pack_b,
+                         int pack_relu, int c_off, int c_tot, float* out, float* pv) {
+  for (int n = 0; n < N; ++n)
+    for (int o = 0; o < O; ++o)
+      for (int i = 0; i < HoWo; ++i) {
+        const size_t idx = ((size_t)n * O + o) * HoWo + i;
+        const size_t odx = ((size_t)n * c_tot + c_off + o) * HoWo + i;
+        float y = fmaf(alpha[o], (float)dot[idx], bias ? bias[o] : 0.0f);
+        if (post_scale) y *= post_scale[o];
+        if (bn_a) y = fmaf(y, bn_a[o], bn_b[o]);
+        if (res && !res_late) y += res[odx];
+        if (relu) y = (y < 0.0f) ? 0.0f : y;
+        if (prelu) y = (y >= 0.0f) ? y : prelu[o] * y;
+        float p = y;
+        if (res && res_late) y += res[odx];
+        if (!(res && res_late && pack_pre)) p = y;
+        if (out) out[odx] = y;
+        if (pack_a) p = fmaf(p, pack_a[o], pack_b[o]);
+        if (pack_relu) p = (p < 0.0f) ? 0.0f : p;
+        pv[idx] = p;
+      }
+}
+
 /* AvgPool2d(k, stride k, ceil_mode=True, count_include_pad=False) as used by the shortcut of
  * bnn/models/resnet.py:128-133; sums taps in (dy, dx) order in float like the HIP kernel.   */
 void orc_avgpool_ceil(const float* x, int N, int C, int H, int W, int k, float* out) {

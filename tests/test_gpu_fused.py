@@ -103,6 +103,72 @@ def test_fused_epilogue_bit_exact(name, sw, nonneg):
     assert torch.equal(pk2.P, pk.P) and torch.equal(pk2.M, pk.M)
 
 
+PRE_CASES = [
+    # (layer case, switches) — the pre-activation orders of PreBasicBlock / HBlock (ABI 3 epilogue)
+    ("c2_relu", dict(act="relu", res=False, late=False, pre=False, aff=True, prelu_pack=False, slice_=None)),
+    ("c2_relu", dict(act="prelu", res=True, late=True, pre=False, aff=True, prelu_pack=False, slice_=None)),
+    ("l2_0_c1_s2", dict(act=None, res=True, late=True, pre=True, aff=True, prelu_pack=True, slice_=(32, 200))),
+    ("adhoc_c256_o40", dict(act=None, res=True, late=True, pre=True, aff=True, prelu_pack=True, slice_=(3, 50))),
+    ("adhoc_c512_o72_s2", dict(act="prelu", res=True, late=True, pre=False, aff=False, prelu_pack=False, slice_=(0, 72))),
+    ("l3_ds_1x1", dict(act="relu", res=True, late=True, pre=True, aff=False, prelu_pack=False, slice_=(64, 320))),
+    ("k5_generic", dict(act="relu", res=True, late=True, pre=False, aff=True, prelu_pack=True, slice_=(1, 20))),
+]
+
+
+@pytest.mark.parametrize("name,sw", PRE_CASES, ids=[f"{n}-{i}" for i, (n, _) in enumerate(PRE_CASES)])
+def test_preactivation_epilogue_bit_exact(name, sw):
+    case = LAYER_CASES_BY_NAME.get(name) or ADHOC[name]
+    x, w, b, sc = case.tensors()
+    act = hipops.pack_act(dev(x))
+    pw = hipops.pack_weight(dev(w), case.center, case.compute_alpha)
+    _, dot = oracle.binary_conv2d_int(x, w, None, None, case.stride, case.pad, case.dilation,
+                                      case.center, case.compute_alpha)
+    N, O = dot.shape[:2]
+    s = gen.seed_of("pre", name)
+    c_off, c_tot = sw["slice_"] if sw["slice_"] else (0, O)
+    full_shape = (N, c_tot) + dot.shape[2:]
+    res = gen.normal(s + 2, full_shape) if sw["res"] else None
+    pre = (0.25 * gen.uniform(s + 3, (O,))).astype(np.float32) if sw["act"] == "prelu" else None
+    pa = ((0.5 + gen.uniform(s + 4, (O,))) * np.where(np.arange(O) % 3 == 0, -1, 1)).astype(np.float32) if sw["aff"] else None
+    pb = (0.3 * gen.normal(s + 5, (O,))).astype(np.float32) if sw["aff"] else None
+    alpha = pw.alpha.cpu().numpy()[:O]
+    canvas = gen.normal(s + 6, full_shape)                 # pre-existing content of the wider tensor
+    ref_out, pv = oracle.fused_epilogue2(dot, alpha, b, sc, None, None, res, pre, sw["act"] == "relu",
+                                         res_late=sw["late"], pack_pre=sw["pre"], pack_a=pa, pack_b=pb,
+                                         pack_relu=sw["prelu_pack"], out=canvas.copy(), c_off=c_off)
+    opt = lambda a: None if a is None else dev(a)  # noqa: E731
+    out = dev(canvas) if sw["slice_"] else None
+    y, pk = hipops.bconv2d_fused(act, pw, bias=opt(b), post_scale=opt(sc), residual=opt(res), prelu=opt(pre),
+                                 relu=sw["act"] == "relu", residual_after_act=sw["late"],
+                                 pack_before_residual=sw["pre"], pack_scale=opt(pa), pack_shift=opt(pb),
+                                 pack_relu=sw["prelu_pack"], out=out, out_c_offset=c_off, out_f32=True,
+                                 out_packed=True, stride=case.stride, padding=case.pad, dilation=case.dilation)
+    assert np.array_equal(y.cpu().numpy(), ref_out)       # the slice is written, the rest of the canvas kept
+    P, M = oracle.pack_act(pv)
+    assert np.array_equal(u64(pk.P), P) and np.array_equal(u64(pk.M), M)
+    if pk.nonneg:
+        assert not M.any()
+
+
+@pytest.mark.parametrize("shape,relu,bn", [((2, 64, 14, 14), True, True), ((1, 70, 9, 7), False, True),
+                                            ((3, 200, 5, 5), True, False), ((2, 128, 8, 6), False, False)])
+def test_bn_act_pack_matches_sign_of_affine(shape, relu, bn):
+    """sign(act(bn(x))) in one pass == the torch sequence bn -> act -> sign the reference runs."""
+    C = shape[1]
+    x = gen.normal(gen.seed_of("bnpack", shape), shape)
+    a = ((0.5 + gen.uniform(1, (C,))) * np.where(np.arange(C) % 4 == 0, -1, 1)).astype(np.float32) if bn else None
+    b = (0.4 * gen.normal(2, (C,))).astype(np.float32) if bn else None
+    pk = hipops.bn_act_pack(dev(x), None if a is None else dev(a), None if b is None else dev(b), relu)
+    v = x.astype(np.float64)
+    if bn:
+        v = v * a.astype(np.float64).reshape(1, -1, 1, 1) + b.astype(np.float64).reshape(1, -1, 1, 1)
+    if relu:
+        v = np.maximum(v, 0)
+    P, M = oracle.pack_act(np.sign(v).astype(np.float32))
+    assert np.array_equal(u64(pk.P), P) and np.array_equal(u64(pk.M), M)
+    assert pk.nonneg == relu
+
+
 def test_two_fused_layers_equal_unfused_chain():
     """conv -> BN -> ReLU -> (packed) -> conv: packed hand-over == fp32 round trip."""
     c1, c2 = LAYER_CASES_BY_NAME["l2_128x28"], LAYER_CASES_BY_NAME["c2_relu"]

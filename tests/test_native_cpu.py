@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert os.path.exists(native.lib_path()), "build with __graft_entry__.build() first"
     lib = ctypes.CDLL(native.lib_path())
     syms = header_symbols()
-    assert len(syms) >= 18
+    assert len(syms) >= 19
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/bnn_hip.h but not exported"
     assert set(native.EXPORTED_SYMBOLS) == set(syms)
@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_require_loads_and_reports_abi():
     lib = native.require()
-    assert lib.bnn_hip_abi_version() == native.ABI_VERSION == 2
+    assert lib.bnn_hip_abi_version() == native.ABI_VERSION == 3
     assert lib.bnn_hip_status_string(0) == b"ok"
     assert b"invalid" in lib.bnn_hip_status_string(-1)
     assert isinstance(native.launch_count(), int)
