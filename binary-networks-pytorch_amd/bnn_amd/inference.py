@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import fastpath, hipops, native
 from .layers import Conv2d as BinaryConv2d
-from .models.blocks import BasicBlock, Bottleneck
+from .models.blocks import BasicBlock, Bottleneck, HBlock, PreBasicBlock
 from .models.resnet import ResNet
 
 
@@ -50,18 +50,19 @@ class _Conv:
     layer: BinaryConv2d
     plan: fastpath.Plan
     weight: hipops.PackedWeight
-    bn_scale: torch.Tensor
-    bn_shift: torch.Tensor
+    bn_scale: Optional[torch.Tensor]
+    bn_shift: Optional[torch.Tensor]
     relu: bool
     prelu: Optional[torch.Tensor]
 
-    def run(self, act: hipops.PackedAct, *, residual=None, out_f32: bool, out_packed: bool):
+    def run(self, act: hipops.PackedAct, *, residual=None, out_f32: bool, out_packed: bool, **epi):
+        """``epi``: the pre-activation switches of ``hipops.bconv2d_fused`` (late residual, pack affine, ...)."""
         lay = self.layer
         return hipops.bconv2d_fused(
             act, self.weight, bias=lay.bias, post_scale=self.plan.scale, bn_scale=self.bn_scale,
             bn_shift=self.bn_shift, residual=residual, prelu=self.prelu, relu=self.relu,
             out_f32=out_f32, out_packed=out_packed, stride=lay.stride, padding=lay.padding,
-            dilation=lay.dilation)
+            dilation=lay.dilation, **epi)
 
 
 def _plan_of(conv: nn.Module) -> fastpath.Plan:
@@ -92,8 +93,9 @@ def _activation(act: nn.Module):
 
 
 class FusedResNet(nn.Module):
-    """Inference executor for ``bnn_amd.models.ResNet`` built from ``BasicBlock`` (ResNet-18/34) or
-    ``Bottleneck`` (ResNet-50/101/152: mixed 1x1 / 3x3 binary convolutions)."""
+    """Inference executor for ``bnn_amd.models.ResNet`` built from ``BasicBlock`` (ResNet-18/34),
+    ``Bottleneck`` (ResNet-50/101/152: mixed 1x1 / 3x3 binary convolutions), ``PreBasicBlock`` (the
+    pre-activation dataflow of examples/imagenet.py) or ``HBlock`` (hierarchical blocks)."""
 
     def __init__(self, model: ResNet, use_mfma_stem: bool = True) -> None:
         super().__init__()
@@ -110,8 +112,18 @@ class FusedResNet(nn.Module):
         relu, prelu = (False, None) if act is None else _activation(act)
         if prelu is not None and prelu.numel() != conv.out_channels:
             prelu = prelu.expand(conv.out_channels).contiguous()
-        scale, shift = fold_bn(bn)
+        scale, shift = (None, None) if bn is None else fold_bn(bn)
         return _Conv(conv, plan, fastpath.packed_weight(conv, plan), scale, shift, relu, prelu)
+
+    @staticmethod
+    def _sign_through(act: nn.Module):
+        """How ``sign(act(v))`` is produced from ``v``: (relu_planes, ok).  ReLU: P = v > 0, M = 0.
+        PReLU with positive slopes: sign(prelu(v)) == sign(v).  Anything else is not fused."""
+        if isinstance(act, nn.ReLU):
+            return True
+        if isinstance(act, nn.PReLU) and bool((act.weight.detach() > 0).all()):
+            return False
+        raise FusionError(f"cannot binarise through {type(act).__name__} in a fused epilogue")
 
     def refresh(self) -> None:
         """(Re)derive packed weights and folded BN constants from the wrapped model."""
@@ -138,6 +150,27 @@ class FusedResNet(nn.Module):
                            and _is_float_layer(c1))
         for stage in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in stage:
+                if isinstance(blk, nn.AvgPool2d):   # HBlock stages pool in front (bnn_amd/models/resnet.py)
+                    self._blocks.append({"kind": "pool", "mod": blk})
+                    continue
+                if type(blk) is PreBasicBlock:      # BN-conv-act, BN-conv-act, (+id)   (res_block.py:147-152)
+                    entry = {"kind": "pre", "bn1": fold_bn(blk.bn1), "bn2": fold_bn(blk.bn2),
+                             "convs": [self._conv(blk.conv1, None, blk.act1), self._conv(blk.conv2, None, blk.act2)],
+                             "ds": None, "pool": 0}
+                    self._shortcut(blk, entry)
+                    self._blocks.append(entry)
+                    continue
+                if type(blk) is HBlock:             # three BN-act-conv stages, cat, (+id)  (hierarchical_block.py:38-60)
+                    entry = {"kind": "h", "planes": blk.conv1.out_channels * 2,
+                             "bn": [fold_bn(blk.bn1), fold_bn(blk.bn2), fold_bn(blk.bn3)],
+                             "relu": [self._sign_through(a) for a in (blk.act1, blk.act2, blk.act3)],
+                             "convs": [self._conv(c, None, None) for c in (blk.conv1, blk.conv2, blk.conv3)],
+                             "ds": None}
+                    if blk.downsample is not None:  # BN -> binary 1x1 (no BN behind it)
+                        bn, conv = blk.downsample[0], blk.downsample[1]
+                        entry["ds"] = (fold_bn(bn), self._conv(conv, None, None))
+                    self._blocks.append(entry)
+                    continue
                 if type(blk) is BasicBlock:      # conv-BN-act, conv-BN-(+id)-act
                     convs = [self._conv(blk.conv1, blk.bn1, blk.act1), self._conv(blk.conv2, blk.bn2, blk.act2)]
                 elif type(blk) is Bottleneck:    # 1x1-BN-act, 3x3-BN-act, 1x1-BN-(+id)-act  (res_block.py:98-118)
@@ -145,18 +178,23 @@ class FusedResNet(nn.Module):
                              self._conv(blk.conv3, blk.bn3, blk.act3)]
                 else:
                     raise FusionError(f"unsupported block {type(blk).__name__}")
-                entry = {"convs": convs, "ds": None, "pool": 0}
-                if blk.downsample is not None:
-                    pool, conv, bn = blk.downsample[0], blk.downsample[1], blk.downsample[2]
-                    k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
-                    if not (isinstance(pool, nn.AvgPool2d) and pool.ceil_mode and not pool.count_include_pad
-                            and pool.padding in (0, (0, 0))):
-                        raise FusionError("shortcut pooling must be AvgPool2d(k, k, ceil_mode=True, "
-                                          "count_include_pad=False)")
-                    entry["ds"] = self._conv(conv, bn, None)
-                    entry["pool"] = k
+                entry = {"kind": "post", "convs": convs, "ds": None, "pool": 0}
+                self._shortcut(blk, entry)
                 self._blocks.append(entry)
         self._graph = None
+
+    def _shortcut(self, blk, entry) -> None:
+        """AvgPool(ceil) -> binary 1x1 -> BN shortcut of bnn/models/resnet.py:128-133."""
+        if blk.downsample is None:
+            return
+        pool, conv, bn = blk.downsample[0], blk.downsample[1], blk.downsample[2]
+        k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
+        if not (isinstance(pool, nn.AvgPool2d) and pool.ceil_mode and not pool.count_include_pad
+                and pool.padding in (0, (0, 0))):
+            raise FusionError("shortcut pooling must be AvgPool2d(k, k, ceil_mode=True, "
+                              "count_include_pad=False)")
+        entry["ds"] = self._conv(conv, bn, None)
+        entry["pool"] = k
 
     @torch.no_grad()
     def _forward_impl(self, x: torch.Tensor) -> torch.Tensor:
@@ -173,6 +211,18 @@ class FusedResNet(nn.Module):
             packed = hipops.pack_act(t)
         last = len(self._blocks) - 1
         for i, b in enumerate(self._blocks):
+            nxt = self._blocks[i + 1] if i < last else None
+            if b["kind"] == "pool":
+                t, packed = b["mod"](t), None
+                continue
+            if b["kind"] == "pre":
+                t, packed = self._run_pre(b, nxt, t, packed)
+                continue
+            if b["kind"] == "h":
+                t, packed = self._run_h(b, t), None
+                continue
+            if packed is None:
+                packed = hipops.pack_act(t)
             if b["ds"] is not None:
                 sc_in = hipops.avgpool_pack(t, b["pool"], nonneg=packed.nonneg) if b["pool"] > 1 else packed
                 idn, _ = b["ds"].run(sc_in, out_f32=True, out_packed=False)
@@ -183,6 +233,47 @@ class FusedResNet(nn.Module):
             t, packed = b["convs"][-1].run(packed, residual=idn, out_f32=True, out_packed=i != last)
         # real-valued head (last layer stays float)
         return m.fc(torch.flatten(m.avgpool(t), 1))
+
+    def _run_pre(self, b, nxt, t, packed):
+        """PreBasicBlock: the block input travels as fp32 ``t`` (shortcut) and as ``sign(bn1(t))``; the
+        latter comes out of the previous block's last epilogue (its ``pack_scale`` = this ``bn1``)."""
+        if packed is None or not getattr(packed, "_pre_bn_of", None) is b:
+            packed = hipops.bn_act_pack(t, *b["bn1"], relu=False)
+        if b["ds"] is not None:
+            sc_in = hipops.avgpool_pack(t, b["pool"]) if b["pool"] > 1 else hipops.pack_act(t)
+            idn, _ = b["ds"].run(sc_in, out_f32=True, out_packed=False)
+        else:
+            idn = t
+        c1, c2 = b["convs"]
+        _, p1 = c1.run(packed, out_f32=False, out_packed=True, pack_scale=b["bn2"][0], pack_shift=b["bn2"][1])
+        if nxt is not None and nxt["kind"] == "pre":   # binarise for the next block's conv1 right here
+            t, pk = c2.run(p1, residual=idn, out_f32=True, out_packed=True, residual_after_act=True,
+                           pack_scale=nxt["bn1"][0], pack_shift=nxt["bn1"][1])
+            pk._pre_bn_of = nxt
+            return t, pk
+        t, _ = c2.run(p1, residual=idn, out_f32=True, out_packed=False, residual_after_act=True)
+        return t, None
+
+    def _run_h(self, b, t):
+        """HBlock: three BN-act-conv stages write their slice of the concatenated output in place, each
+        adds its slice of the shortcut and hands ``sign(act(bn_next(o_k)))`` to the next stage."""
+        if b["ds"] is not None:
+            (sa, sb), conv = b["ds"]
+            idn, _ = conv.run(hipops.bn_act_pack(t, sa, sb, relu=False), out_f32=True, out_packed=False)
+        else:
+            idn = t
+        c1, c2, c3 = b["convs"]
+        half = b["planes"] // 2
+        quarter = c2.layer.out_channels
+        p = hipops.bn_act_pack(t, *b["bn"][0], relu=b["relu"][0])
+        y = torch.empty((t.shape[0], b["planes"], t.shape[2], t.shape[3]), dtype=torch.float32, device=t.device)
+        late = dict(residual=idn, residual_after_act=True, pack_before_residual=True, out=y, out_f32=True)
+        _, p = c1.run(p, out_packed=True, out_c_offset=0, pack_scale=b["bn"][1][0], pack_shift=b["bn"][1][1],
+                      pack_relu=b["relu"][1], **late)
+        _, p = c2.run(p, out_packed=True, out_c_offset=half, pack_scale=b["bn"][2][0], pack_shift=b["bn"][2][1],
+                      pack_relu=b["relu"][2], **late)
+        c3.run(p, out_packed=False, out_c_offset=half + quarter, **late)
+        return y
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self._graph is not None and x.shape == self._gx.shape:
