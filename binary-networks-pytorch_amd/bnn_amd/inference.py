@@ -16,6 +16,7 @@ are derived once (call ``refresh()`` after changing parameters).  Eval mode only
 """
 from __future__ import annotations
 
+import contextlib
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -97,9 +98,11 @@ class FusedResNet(nn.Module):
     ``Bottleneck`` (ResNet-50/101/152: mixed 1x1 / 3x3 binary convolutions), ``PreBasicBlock`` (the
     pre-activation dataflow of examples/imagenet.py) or ``HBlock`` (hierarchical blocks)."""
 
-    def __init__(self, model: ResNet, use_mfma_stem: bool = True) -> None:
+    def __init__(self, model: ResNet, use_mfma_stem: bool = True, overlap_shortcut: bool = True) -> None:
         super().__init__()
         self.use_mfma_stem = use_mfma_stem
+        self.overlap_shortcut = overlap_shortcut
+        self._side = {}
         if not isinstance(model, ResNet) or model.stem_type != "basic":
             raise FusionError("FusedResNet covers bnn_amd.models.ResNet with the 'basic' stem")
         self.model = model
@@ -223,16 +226,37 @@ class FusedResNet(nn.Module):
                 continue
             if packed is None:
                 packed = hipops.pack_act(t)
+            side = None
             if b["ds"] is not None:
-                sc_in = hipops.avgpool_pack(t, b["pool"], nonneg=packed.nonneg) if b["pool"] > 1 else packed
-                idn, _ = b["ds"].run(sc_in, out_f32=True, out_packed=False)
+                # the shortcut branch (HBM-bound avg-pool + a small 1x1 conv) is independent of the block's
+                # first convs (ALU-bound): run it on a second stream and join before the residual is needed
+                cur = torch.cuda.current_stream(t.device)
+                side = self._side_stream(t.device) if self.overlap_shortcut else None
+                if side is not None:
+                    side.wait_stream(cur)
+                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                    sc_in = hipops.avgpool_pack(t, b["pool"], nonneg=packed.nonneg) if b["pool"] > 1 else packed
+                    idn, _ = b["ds"].run(sc_in, out_f32=True, out_packed=False)
+                if side is not None:
+                    t.record_stream(side)
+                    sc_in.P.record_stream(side)
+                    sc_in.M.record_stream(side)
             else:
                 idn = t
             for c in b["convs"][:-1]:           # activations travel between binary layers as bit planes
                 _, packed = c.run(packed, out_f32=False, out_packed=True)
+            if side is not None:
+                cur.wait_stream(side)
+                idn.record_stream(cur)
             t, packed = b["convs"][-1].run(packed, residual=idn, out_f32=True, out_packed=i != last)
         # real-valued head (last layer stays float)
         return m.fc(torch.flatten(m.avgpool(t), 1))
+
+    def _side_stream(self, device) -> torch.cuda.Stream:
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=device)
+        return self._side[key]
 
     def _run_pre(self, b, nxt, t, packed):
         """PreBasicBlock: the block input travels as fp32 ``t`` (shortcut) and as ``sign(bn1(t))``; the
