@@ -32,7 +32,7 @@ import torch.nn as nn  # noqa: E402
 
 import bnn_amd as bnn  # noqa: E402
 from bnn_amd import fastpath, hipops, native  # noqa: E402
-from bnn_amd.inference import FusedResNet  # noqa: E402
+from bnn_amd.inference import FusedResNet, PipelinedInference  # noqa: E402
 from bnn_amd.models import resnet18  # noqa: E402
 from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer  # noqa: E402
 from bnn_amd.parallel import ShardedInference  # noqa: E402
@@ -169,6 +169,9 @@ def main():
     ap.add_argument("--engine", choices=("graph", "fused", "layerwise"), default="graph",
                     help="graph: fused executor replayed as a HIP graph (default); fused: same, eager "
                          "launches; layerwise: the drop-in per-layer path (pack -> conv -> torch BN/ReLU)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="graph engine: batches in flight per GPU (graph-captured executors on their own HIP "
+                         "streams, replayed round-robin; 1 = strictly one batch at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -195,36 +198,51 @@ def main():
         engine = net
     else:
         engine = FusedResNet(net)
-        if args.engine == "graph":
-            engine.capture(x)
-            x = engine.static_input   # the batch lives in the graph's input buffer (filled by capture):
-            #                           no per-step device-to-device copy of the 154 MB input
-    model = ShardedInference(engine)
+    n_streams = max(1, args.streams) if args.engine == "graph" else 1
+    if args.engine == "graph":
+        # every stream owns a graph-captured executor whose static input buffer holds its batch (filled by
+        # capture): no per-step device-to-device copy of the 154 MB input, and `n_streams` batches in flight
+        pipe = PipelinedInference(net, x, n_streams=n_streams)
+        models = [ShardedInference(e) for e in pipe.engines]
+
+        def step(i, k_streams=n_streams):
+            k = i % k_streams
+            with torch.cuda.stream(pipe.streams[k]):
+                return models[k].forward_even(pipe.engines[k].static_input)
+    else:
+        model = ShardedInference(engine)
+
+        def step(i, k_streams=1):
+            return model.forward_even(x)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    launches0 = native.launch_count()
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            logits = model.forward_even(x)
+    def timed(steps, warmup, k_streams):
+        for i in range(warmup):
+            out = step(i, k_streams)
         torch.cuda.synchronize(device)
         barrier()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            logits = model.forward_even(x)
+        for i in range(steps):
+            out = step(warmup + i, k_streams)
         torch.cuda.synchronize(device)
         barrier()
         torch.cuda.synchronize(device)
-        dt = time.perf_counter() - t0
+        return time.perf_counter() - t0, out
+
+    launches0 = native.launch_count()
+    with torch.no_grad():
+        dt, logits = timed(args.steps, args.warmup, n_streams)
+        dt1 = timed(args.steps, 2, 1)[0] if n_streams > 1 else None   # same steps, one batch at a time
     assert logits.shape == (world * B, 1000) and torch.isfinite(logits).all()
     hip_launches = native.launch_count() - launches0
     if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt, dt1 or 0.0], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt, dt1 = float(tt[0].item()), (float(tt[1].item()) if dt1 is not None else None)
 
     if rank == 0:
         value = world * B * args.steps / dt
@@ -236,12 +254,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": "binary ResNet-18 (bnn.models resnet18, XNOR recipe of examples/cifar10.py, "
                                    "conv1+fc real-valued) 224x224 full forward, batch 256 per GPU",
-                       "engine": args.engine,
+                       "engine": args.engine, "batches_in_flight": n_streams,
                        "global_batch": world * B, "parallelism": f"dp{world} (batch shards, RCCL all-gather of logits)",
                        "hip_kernel_launches_per_step": hip_launches // max(args.steps + args.warmup, 1)},
             "device": {k: info[k] for k in ("name", "arch", "compute_units", "clock_khz")},
             "net_int_alu_frac": value / world * R18_LANE_OPS_PER_IMG / int_alu_peak(info),
         }
+        if dt1 is not None:
+            rec["one_batch_at_a_time"] = {"value": world * B * args.steps / dt1, "ms_per_step": dt1 / args.steps * 1e3}
         if not args.no_roofline:
             rec["roofline"] = conv_c2_roofline(device, info, act_kind="relu")
             rec["roofline_normal_input"] = {k: v for k, v in conv_c2_roofline(device, info, act_kind="normal").items()

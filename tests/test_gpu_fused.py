@@ -329,6 +329,26 @@ def test_fused_resnet18_graph_replay_is_bit_identical():
     assert torch.equal(y3, fresh(x3)) and not torch.equal(y3, y0)
 
 
+def test_pipelined_inference_two_streams_equals_single_stream():
+    from bnn_amd.inference import PipelinedInference
+    net = _r18()
+    xs = [dev(gen.normal(40 + i, (4, 3, 64, 64))) for i in range(5)]
+    single = FusedResNet(net)
+    want = [single(x).clone() for x in xs]
+    pipe = PipelinedInference(net, xs[0], n_streams=2)
+    assert len(pipe) == 2 and pipe.input(0).data_ptr() != pipe.input(1).data_ptr()
+    got = []
+    for i, x in enumerate(xs):
+        with torch.cuda.stream(pipe.stream(i)):
+            pipe.input(i).copy_(x)
+        y = pipe.launch(i)
+        with torch.cuda.stream(pipe.stream(i)):
+            got.append(y.clone())                      # the slot's buffer is reused two launches later
+    pipe.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+
+
 def test_fused_resnet18_prelu_variant():
     net = _r18(activation=nn.PReLU)
     fused = FusedResNet(net)

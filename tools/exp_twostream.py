@@ -1,0 +1,28 @@
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "binary-networks-pytorch_amd")]
+import torch
+import bench
+from bnn_amd.inference import FusedResNet
+from tests.golden import gen
+dev = torch.device("cuda:0")
+net = bench.build_model(dev)
+B = int(os.environ.get("BATCH", "256"))
+x = torch.from_numpy(gen.normal(100, (8, 3, 224, 224))).to(dev).repeat(B // 8, 1, 1, 1)
+NS = int(os.environ.get("STREAMS", "2"))
+streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+engines = []
+for s in streams:
+    with torch.cuda.stream(s):
+        engines.append(FusedResNet(net).capture(x))
+torch.cuda.synchronize()
+def run(n, k):
+    for i in range(n):
+        j = i % k
+        with torch.cuda.stream(streams[j]):
+            engines[j](engines[j].static_input)
+for k in (1, NS):
+    run(10, k); torch.cuda.synchronize(); t0 = time.perf_counter()
+    run(60, k); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 60
+    print("%d stream(s): %.4f ms per batch of %d -> %.0f img/s" % (k, dt * 1e3, B, B / dt))
