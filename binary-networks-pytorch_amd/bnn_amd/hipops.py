@@ -106,6 +106,10 @@ def bn_act_pack(x: torch.Tensor, bn_scale=None, bn_shift=None, relu: bool = Fals
     N, C, H, W = x.shape
     bn_scale = _per_channel(bn_scale, C, "bn_scale")
     bn_shift = _per_channel(bn_shift, C, "bn_shift")
+    if N == 0:
+        a = empty_packed(0, C, H, W, x.device)
+        a.nonneg = bool(relu)
+        return a
     with torch.cuda.device(x.device):
         a = empty_packed(N, C, H, W, x.device)
         native.check(lib.bnn_hip_bn_act_pack_f32(x.data_ptr(), N, C, H, W, _ptr(bn_scale), _ptr(bn_shift),

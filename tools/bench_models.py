@@ -20,6 +20,8 @@ cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_pr
                   weight_pre_process=XNORWeightBinarizer)
 x = torch.from_numpy(gen.normal(1, (8, 3, 224, 224))).to(dev).repeat(B // 8, 1, 1, 1)
 for name, ctor in NETS.items():
+    if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
+        continue
     net = bnn.prepare_binary_model(ctor(), cfg, custom_config_layers_name={"conv1": bnn.BConfig(), "fc": bnn.BConfig()})
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     net.load_state_dict({k: torch.from_numpy(v) for k, v in gen.model_state(shapes, 1).items()})
