@@ -344,7 +344,7 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
 
 
 PROBE_MODES = {0: "bitop3+bcnt", 1: "xor+bcnt", 2: "bcnt", 3: "bitop3", 4: "xor", 5: "fma_f32",
-               6: "add_u32"}
+               6: "add_u32", 7: "and_vgpr", 8: "and_vgpr+bcnt", 9: "xor_vgpr", 10: "and_sgpr+bcnt"}
 
 
 def probe_int_alu(iters: int = 4096, device: Optional[torch.device] = None, mode: int = 0) -> dict:

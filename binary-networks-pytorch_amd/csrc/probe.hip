@@ -11,6 +11,10 @@
 //   mode 4  v_xor_b32 only
 //   mode 5  v_fma_f32 only (reference point: the guide's 2-cycle wave64 FMA)
 //   mode 6  v_add_u32 only
+//   mode 7  v_and_b32 with VGPR-only operands
+//   mode 8  v_and_b32 (VGPR-only) + v_bcnt_u32_b32
+//   mode 9  v_xor_b32 with VGPR-only operands
+//   mode 10 v_and_b32 (scalar operand) + v_bcnt_u32_b32           <- the non-negative kernels' pair
 #include "bnn_dev.h"
 
 namespace bnn {
@@ -49,8 +53,18 @@ __global__ __launch_bounds__(256) void probe_kernel(int iters, uint32_t seed,
         asm volatile("v_xor_b32 %0, %2, %1" : "=v"(t[k]) : "v"(p[i]), "s"(w));
       } else if (MODE == 5) {
         asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[k]) : "v"(p[i]), "v"(m[i]));
-      } else {
+      } else if (MODE == 6) {
         asm volatile("v_add_u32 %0, %1, %0" : "+v"(a[k]) : "v"(p[i]));
+      } else if (MODE == 7) {
+        asm volatile("v_and_b32 %0, %1, %2" : "=v"(t[k]) : "v"(p[i]), "v"(m[(i + 3) & 15]));
+      } else if (MODE == 8) {
+        asm volatile("v_and_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1"
+                     : "=&v"(t[k]), "+v"(a[k]) : "v"(p[i]), "v"(m[(i + 3) & 15]));
+      } else if (MODE == 9) {
+        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(t[k]) : "v"(p[i]), "v"(m[(i + 3) & 15]));
+      } else {
+        asm volatile("v_and_b32 %0, %3, %2\n\tv_bcnt_u32_b32 %1, %0, %1"
+                     : "=&v"(t[k]), "+v"(a[k]) : "v"(p[i]), "s"(w));
       }
     }
     w = w * 1664525u + 1013904223u;
@@ -75,15 +89,19 @@ static void launch_any(int mode, int blocks, int iters, uint32_t seed, uint32_t*
     case 3: launch_mode<3>(blocks, iters, seed, sink, s); break;
     case 4: launch_mode<4>(blocks, iters, seed, sink, s); break;
     case 5: launch_mode<5>(blocks, iters, seed, sink, s); break;
-    default: launch_mode<6>(blocks, iters, seed, sink, s); break;
+    case 6: launch_mode<6>(blocks, iters, seed, sink, s); break;
+    case 7: launch_mode<7>(blocks, iters, seed, sink, s); break;
+    case 8: launch_mode<8>(blocks, iters, seed, sink, s); break;
+    case 9: launch_mode<9>(blocks, iters, seed, sink, s); break;
+    default: launch_mode<10>(blocks, iters, seed, sink, s); break;
   }
 }
 
 // ops per lane per loop step for each mode
-static int ops_per_step(int mode) { return (mode == 0 || mode == 1) ? 2 : 1; }
+static int ops_per_step(int mode) { return (mode == 0 || mode == 1 || mode == 8 || mode == 10) ? 2 : 1; }
 
 int launch_probe_int_alu(int mode, int iters, double* lane_ops_per_s, double* elapsed_ms, hipStream_t s) {
-  if (mode < 0 || mode > 6) return BNN_HIP_ERR_INVALID_ARG;
+  if (mode < 0 || mode > 10) return BNN_HIP_ERR_INVALID_ARG;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return BNN_HIP_ERR_NO_DEVICE;
   hipDeviceProp_t prop;

@@ -271,7 +271,8 @@ int bnn_hip_bconv2d_f32(const bnn_hip_conv_desc* d, const float* x,
 /* Roofline calibration: runs a register-only instruction stream on every CU at full
  * occupancy and reports the sustained 32-bit lane-ops/s.  mode: 0 = v_bitop3_b32 +
  * v_bcnt_u32_b32 (the hot loop's pair), 1 = v_xor_b32 + v_bcnt_u32_b32, 2 = bcnt only,
- * 3 = bitop3 only, 4 = xor only, 5 = v_fma_f32 only, 6 = v_add_u32 only.
+ * 3 = bitop3 only, 4 = xor only, 5 = v_fma_f32 only, 6 = v_add_u32 only, 7 = v_and_b32 with
+ * VGPR-only operands, 8 = that + bcnt, 9 = v_xor_b32 VGPR-only, 10 = v_and_b32 (scalar operand) + bcnt.
  * Synchronous (hipEvents on `stream`, temporary hipMalloc); not part of the inference path. */
 int bnn_hip_probe_int_alu(int mode, int iters, double* lane_ops_per_s, double* elapsed_ms,
                           void* stream);
