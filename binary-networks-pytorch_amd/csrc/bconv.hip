@@ -247,7 +247,9 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
       if (f & EF_SCALE) y *= e.scale[o];
       if (f & EF_BN) y = fmaf(y, e.bn_a[o], e.bn_b[o]);
       if ((f & EF_RES) && !(f & EF_RES_LATE)) y += resv[j];
-      if (f & EF_RELU) y = (y < 0.0f) ? 0.0f : y;  // keeps NaN, like torch.relu
+      // packed-only output of a ReLU: sign(relu(y)) has P = (y > 0), M = 0 — the clamp itself is dead work
+      const bool relu_dead = !(f & (EF_OUTF | EF_PRELU | EF_PACK_AFF | EF_RES_LATE));
+      if ((f & EF_RELU) && !relu_dead) y = (y < 0.0f) ? 0.0f : y;  // keeps NaN, like torch.relu
       if (f & EF_PRELU) y = (y >= 0.0f) ? y : e.prelu[o] * y;
       float pv = y;  // the value the next binary layer binarises
       if ((f & EF_RES) && (f & EF_RES_LATE)) y += resv[j];
