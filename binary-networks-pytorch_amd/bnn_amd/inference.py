@@ -98,9 +98,11 @@ class FusedResNet(nn.Module):
     ``Bottleneck`` (ResNet-50/101/152: mixed 1x1 / 3x3 binary convolutions), ``PreBasicBlock`` (the
     pre-activation dataflow of examples/imagenet.py) or ``HBlock`` (hierarchical blocks)."""
 
-    def __init__(self, model: ResNet, use_mfma_stem: bool = True, overlap_shortcut: bool = True) -> None:
+    def __init__(self, model: ResNet, use_mfma_stem: bool = True, overlap_shortcut: bool = True,
+                 stem_share_cu: bool = False) -> None:
         super().__init__()
         self.use_mfma_stem = use_mfma_stem
+        self.stem_share_cu = stem_share_cu   # one stem wave per SIMD: kernels of other streams stay co-resident
         self.overlap_shortcut = overlap_shortcut
         self._side = {}
         if not isinstance(model, ResNet) or model.stem_type != "basic":
@@ -205,7 +207,8 @@ class FusedResNet(nn.Module):
         # real-valued stem (first layer stays float: examples/cifar10.py:71): the conv runs in the
         # vendor library (MFMA), its BN -> ReLU -> MaxPool -> sign tail in one HBM pass
         if self._stem_mfma:
-            t, packed = hipops.stem7x7(x, m.conv1.weight, self._stem[0], self._stem[1])
+            t, packed = hipops.stem7x7(x, m.conv1.weight, self._stem[0], self._stem[1],
+                                       share_cu=self.stem_share_cu)
         elif self._stem is not None:
             t = m.conv1(x)
             t, packed = hipops.bn_relu_maxpool_pack(t, self._stem[0], self._stem[1], True, *self._stem[2])

@@ -85,7 +85,9 @@ int launch_bn_relu_maxpool_pack(const float* x, int N, int C, int H, int W, cons
                                 const float* bn_b, int relu, int k, int stride, int pad, float* out,
                                 uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_stem(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
-                int W, int exact_fp32, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
+                int W, int flags, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
+int launch_stem_lean(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
+                     int W, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_stem_split(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                       int W, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_pack_weight(const float* w, int O, int C, int KH, int KW, int center, int compute_alpha,

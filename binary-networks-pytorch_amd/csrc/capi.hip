@@ -184,7 +184,7 @@ int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w, const 
   if ((long long)N * 3 * H * W > kMaxElems || (long long)N * 64 * H * W / 16 > kMaxElems)
     return BNN_HIP_ERR_TOO_LARGE;
   g_launches.fetch_add(1, std::memory_order_relaxed);
-  return bnn::launch_stem(x, w, bn_scale, bn_shift, N, H, W, flags & BNN_HIP_STEM_EXACT_FP32, out_f32, P, M,
+  return bnn::launch_stem(x, w, bn_scale, bn_shift, N, H, W, flags, out_f32, P, M,
                           static_cast<hipStream_t>(stream));
 }
 

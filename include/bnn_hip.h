@@ -213,6 +213,10 @@ int bnn_hip_bn_relu_maxpool_pack_f32(const float* x, int N, int C, int H, int W,
  *            ~3e-7 relative, the rounding class of an fp32 convolution, at 3/16 of the matrix time;
  * flags = BNN_HIP_STEM_EXACT_FP32: v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 fmaf chain.     */
 #define BNN_HIP_STEM_EXACT_FP32 1
+/* Same arithmetic and results as flags = 0, but one wave per SIMD (4-wave workgroups): half of every register
+ * file stays free so that kernels of another stream (the binary convolutions of the other batch in flight)
+ * are co-resident with the stem instead of waiting for it.  Slower alone, faster in a pipeline.          */
+#define BNN_HIP_STEM_SHARE_CU 2
 int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w,
                                           const float* bn_scale, const float* bn_shift,
                                           int N, int H, int W, int flags,

@@ -10,11 +10,21 @@ net = bench.build_model(dev)
 B = int(os.environ.get("BATCH", "256"))
 x = torch.from_numpy(gen.normal(100, (8, 3, 224, 224))).to(dev).repeat(B // 8, 1, 1, 1)
 NS = int(os.environ.get("STREAMS", "2"))
+if os.environ.get("SKIP_STEM"):
+    from bnn_amd import hipops
+    _real = hipops.stem7x7
+    _cache = {}
+    def _fake(x, w, a, b, **kw):   # timing experiment: the stem's result is reused, its kernel never runs again
+        key = x.shape
+        if key not in _cache:
+            _cache[key] = _real(x, w, a, b, **kw)
+        return _cache[key]
+    hipops.stem7x7 = _fake
 streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
 engines = []
 for s in streams:
     with torch.cuda.stream(s):
-        engines.append(FusedResNet(net).capture(x))
+        engines.append(FusedResNet(net, stem_share_cu=bool(os.environ.get('LEAN'))).capture(x))
 torch.cuda.synchronize()
 def run(n, k):
     for i in range(n):
