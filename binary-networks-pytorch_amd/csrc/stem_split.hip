@@ -206,12 +206,20 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
     }
   };
 
+#ifdef BNN_STEM_TIMING  // per-phase cycle sums of every wave's lane 0, dumped over the M plane (debug builds)
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define STEM_T(k) { const unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; }
+#else
+#define STEM_T(k)
+#endif
   int seq = blockIdx.x;
   if (seq < nseq) { fetch(tile_of(seq)); commit(); }
   for (; seq < nseq; seq += gridDim.x) {
     const int tile = tile_of(seq);
     const bool valid = tile < ntiles;  // workgroup-uniform
+    STEM_T(5)
     __syncthreads();                   // this tile's patch is in LDS; `stage` is free again
+    STEM_T(0)
     flush_bits(buf ^ 1);
     const int seq_next = seq + gridDim.x;
 #if !(BNN_STEM_ABL & 8)
@@ -262,6 +270,7 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
     }
 #endif
 
+    STEM_T(1)
     // ---- BN + ReLU, conv tile -> LDS.  D layout: column = li (channel), row = 4*lg + r (pixel).
 #if !(BNN_STEM_ABL & 2)
 #pragma unroll
@@ -282,10 +291,13 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
       }
     }
 #endif
+    STEM_T(2)
     __syncthreads();  // conv tile staged; every wave is done reading the patch
+    STEM_T(3)
 #if !(BNN_STEM_ABL & 8)
     if (seq_next < nseq) commit();  // next patch: registers -> LDS (fp16 hi/lo), overlaps the pooling
 #endif
+    STEM_T(4)
 
 #if !(BNN_STEM_ABL & 4)
     // ---- 3x3 / stride-2 max pool: row maxima of the thread's 3 conv columns, then 8 column maxima
@@ -318,6 +330,12 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
   }
   __syncthreads();
   flush_bits(buf ^ 1);
+#ifdef BNN_STEM_TIMING
+  __syncthreads();
+  if (lane == 0 && M) {  // [workgroup][wave][6]: barrier0 wait, fetch-issue+matrix, epilogue, barrier1 wait, commit, pool
+    for (int k = 0; k < 6; ++k) M[((size_t)blockIdx.x * 8 + wave) * 6 + k] = tph[k];
+  }
+#endif
 }
 
 int launch_stem_split(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
