@@ -273,19 +273,34 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
     STEM_T(1)
     // ---- BN + ReLU, conv tile -> LDS.  D layout: column = li (channel), row = 4*lg + r (pixel).
 #if !(BNN_STEM_ABL & 2)
+    // three quarters of the tiles lie entirely inside the conv output: no per-pixel range tests there
+    const bool interior = cy0 >= 0 && cx0 >= 0 && cy0 + CTH <= Hc && cx0 + CTW <= Wc;  // workgroup-uniform
+    float* sdst = stage + ((SUBS * mg) * 16 + lg * 4) * SC + 32 * nh + li;
+    if (interior) {
 #pragma unroll
-    for (int i = 0; i < SUBS; ++i) {
+      for (int i = 0; i < SUBS; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = (SUBS * mg + i) * 16 + lg * 4 + r;
-        if (m < MPIX) {
-          const int cy = m / CTW, cx = m - cy * CTW;
-          const bool inside = (unsigned)(cy0 + cy) < (unsigned)Hc && (unsigned)(cx0 + cx) < (unsigned)Wc;
+        for (int r = 0; r < 4; ++r)
+          if ((SUBS * mg + i) * 16 + lg * 4 + r < MPIX) {
 #pragma unroll
-          for (int tt = 0; tt < TT; ++tt) {
-            const float v = fmaxf(fmaf(acc[i][tt][r], ba[tt], bb[tt]), 0.0f);
-            // positions outside the conv output are MaxPool padding: 0 never beats a ReLU output
-            stage[m * SC + 32 * nh + 16 * tt + li] = inside ? v : 0.0f;
+            for (int tt = 0; tt < TT; ++tt)
+              sdst[(i * 16 + r) * SC + 16 * tt] = fmaxf(fmaf(acc[i][tt][r], ba[tt], bb[tt]), 0.0f);
+          }
+    } else {
+#pragma unroll
+      for (int i = 0; i < SUBS; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = (SUBS * mg + i) * 16 + lg * 4 + r;
+          if (m < MPIX) {
+            const int cy = m / CTW, cx = m - cy * CTW;
+            const bool inside = (unsigned)(cy0 + cy) < (unsigned)Hc && (unsigned)(cx0 + cx) < (unsigned)Wc;
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+              const float v = fmaxf(fmaf(acc[i][tt][r], ba[tt], bb[tt]), 0.0f);
+              // positions outside the conv output are MaxPool padding: 0 never beats a ReLU output
+              sdst[(i * 16 + r) * SC + 16 * tt] = inside ? v : 0.0f;
+            }
           }
         }
       }
