@@ -254,7 +254,11 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
       float pv = y;  // the value the next binary layer binarises
       if ((f & EF_RES) && (f & EF_RES_LATE)) y += resv[j];
       if (!(f & EF_PACK_PRE)) pv = y;
+#if BNN_NT_STORE
+      if ((f & EF_OUTF) && px.live) __builtin_nontemporal_store(y, &(outf + (size_t)(o + g.c_off) * hw)[lane_off]);
+#else
       if ((f & EF_OUTF) && px.live) (outf + (size_t)(o + g.c_off) * hw)[lane_off] = y;
+#endif
       if (f & EF_PACK) {
         if (f & EF_PACK_AFF) pv = fmaf(pv, e.pack_a[o], e.pack_b[o]);
         pbits |= (is_pos(pv) ? 1u : 0u) << (bit0 + j);
@@ -332,6 +336,9 @@ __device__ __forceinline__ void store_packed_part(const Geo& g, const Pix& px, i
 // buffers and accumulates the disagreement counts of NACC output channels.  SMEM returns out of
 // order, so the only usable wait is lgkmcnt(0): `cur` is touched first so that this wait lands
 // BEFORE block b+1 is requested; b+1 then has the whole VALU block (32 instructions) to arrive.
+#ifndef BNN_NT_STORE  // fused epilogue: fp32 stores with the non-temporal hint
+#define BNN_NT_STORE 0
+#endif
 #ifndef BNN_MULTI_RES_EARLY
 #define BNN_MULTI_RES_EARLY 0
 #endif

@@ -5,10 +5,8 @@ set -u
 R="$(cd "$(dirname "$0")/.." && pwd)"
 V="$R/binary-networks-pytorch_amd/bnn_amd/_lib/variants"
 declare -A CFG=(
-  [abl0]="-DBNN_STEM_ABL=0"
-  [abl16]="-DBNN_STEM_ABL=16"
-  [abl32]="-DBNN_STEM_ABL=32"
-  [abl48]="-DBNN_STEM_ABL=48"
+  [base]="-DBNN_NT_STORE=0"
+  [nt]="-DBNN_NT_STORE=1"
 )
 if [ "${1:-build}" = "build" ]; then
   rm -rf "$V"; mkdir -p "$V"
