@@ -99,8 +99,9 @@ class FusedResNet(nn.Module):
     pre-activation dataflow of examples/imagenet.py) or ``HBlock`` (hierarchical blocks)."""
 
     def __init__(self, model: ResNet, use_mfma_stem: bool = True, overlap_shortcut: bool = True,
-                 stem_share_cu: bool = False) -> None:
+                 stem_share_cu: bool = False, stem_fp16: bool = False) -> None:
         super().__init__()
+        self.stem_fp16 = stem_fp16           # opt-in: plain fp16 stem operands (~5e-4 relative error)
         self.use_mfma_stem = use_mfma_stem
         self.stem_share_cu = stem_share_cu   # one stem wave per SIMD: kernels of other streams stay co-resident
         self.overlap_shortcut = overlap_shortcut
@@ -208,7 +209,7 @@ class FusedResNet(nn.Module):
         # vendor library (MFMA), its BN -> ReLU -> MaxPool -> sign tail in one HBM pass
         if self._stem_mfma:
             t, packed = hipops.stem7x7(x, m.conv1.weight, self._stem[0], self._stem[1],
-                                       share_cu=self.stem_share_cu)
+                                       share_cu=self.stem_share_cu, fp16=self.stem_fp16)
         elif self._stem is not None:
             t = m.conv1(x)
             t, packed = hipops.bn_relu_maxpool_pack(t, self._stem[0], self._stem[1], True, *self._stem[2])

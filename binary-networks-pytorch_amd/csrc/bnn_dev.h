@@ -89,7 +89,7 @@ int launch_stem(const float* x, const float* w, const float* bn_a, const float* 
 int launch_stem_lean(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                      int W, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_stem_split(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
-                      int W, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
+                      int W, int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_pack_weight(const float* w, int O, int C, int KH, int KW, int center, int compute_alpha,
                        const bnn_hip_wlayout& L, uint32_t* wbits, uint32_t* wnz, float* alpha,
                        int32_t* zero_flag, hipStream_t stream);

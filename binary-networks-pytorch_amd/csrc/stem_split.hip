@@ -67,6 +67,9 @@ using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using half2v = __attribute__((ext_vector_type(2))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
+// HALF: plain fp16 operands, one MFMA per product (BNN_HIP_STEM_FP16: the "fp16 MFMA stem" of BASELINE config
+// 5) — 1/3 of the matrix work, ~5e-4 relative error; the lo planes / fragments are then dead code.
+template <bool HALF>
 __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bn_a,
     const float* __restrict__ bn_b, int N, int H, int W, int Hc, int Wc, int Hp, int Wp, int tiles_y,
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
         l[0] = (_Float16)(nx0[u] - (float)h[0]);
         l[1] = (_Float16)(nx1[u] - (float)h[1]);
         reinterpret_cast<half2v*>(hiP)[R * (ROWH / 2) + fpc] = h;
-        reinterpret_cast<half2v*>(loP)[R * (ROWH / 2) + fpc] = l;
+        if constexpr (!HALF) reinterpret_cast<half2v*>(loP)[R * (ROWH / 2) + fpc] = l;
       }
     }
   };
@@ -249,18 +252,20 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           ah[d] = load_a(hiP, abase[ip + d] + koff[ks]);
-          al[d] = load_a(loP, abase[ip + d] + koff[ks]);
+          if constexpr (!HALF) al[d] = load_a(loP, abase[ip + d] + koff[ks]);
         }
+        if constexpr (!HALF) {
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+          for (int d = 0; d < 2; ++d)
 #pragma unroll
-          for (int tt = 0; tt < TT; ++tt)
-            acc[ip + d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[d], bh[ks][tt], acc[ip + d][tt], 0, 0, 0);
+            for (int tt = 0; tt < TT; ++tt)
+              acc[ip + d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[d], bh[ks][tt], acc[ip + d][tt], 0, 0, 0);
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+          for (int d = 0; d < 2; ++d)
 #pragma unroll
-          for (int tt = 0; tt < TT; ++tt)
-            acc[ip + d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[d], bl[ks][tt], acc[ip + d][tt], 0, 0, 0);
+            for (int tt = 0; tt < TT; ++tt)
+              acc[ip + d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[d], bl[ks][tt], acc[ip + d][tt], 0, 0, 0);
+        }
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -353,8 +358,9 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
 #endif
 }
 
-int launch_stem_split(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
-                      int W, float* out, uint64_t* P, uint64_t* M, hipStream_t stream) {
+template <bool HALF>
+static int launch_stem_split_t(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
+                               int W, float* out, uint64_t* P, uint64_t* M, hipStream_t stream) {
   using namespace stem2;
   const int Hc = (H + 6 - KS) / 2 + 1, Wc = (W + 6 - KS) / 2 + 1;
   const int Hp = (Hc + 2 - 3) / 2 + 1, Wp = (Wc + 2 - 3) / 2 + 1;
@@ -370,13 +376,19 @@ int launch_stem_split(const float* x, const float* w, const float* bn_a, const f
   const unsigned grid = (unsigned)(ntiles < want ? ((ntiles + 7) / 8 * 8) : want);
   static bool attr_set[64] = {false};  // > 64 KB of dynamic LDS needs the opt-in, once per device
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_split_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_split_kernel<HALF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(stem_split_kernel, dim3(grid), dim3(NT), LDS_BYTES, stream, x, w, bn_a, bn_b, N, H,
+  hipLaunchKernelGGL(stem_split_kernel<HALF>, dim3(grid), dim3(NT), LDS_BYTES, stream, x, w, bn_a, bn_b, N, H,
                      W, Hc, Wc, Hp, Wp, tiles_y, tiles_x, per_xcd, out, P, M);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+int launch_stem_split(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
+                      int W, int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream) {
+  return half ? launch_stem_split_t<true>(x, w, bn_a, bn_b, N, H, W, out, P, M, stream)
+              : launch_stem_split_t<false>(x, w, bn_a, bn_b, N, H, W, out, P, M, stream);
 }
 
 }  // namespace bnn

@@ -217,6 +217,9 @@ int bnn_hip_bn_relu_maxpool_pack_f32(const float* x, int N, int C, int H, int W,
  * file stays free so that kernels of another stream (the binary convolutions of the other batch in flight)
  * are co-resident with the stem instead of waiting for it.  Slower alone, faster in a pipeline.          */
 #define BNN_HIP_STEM_SHARE_CU 2
+/* Plain fp16 operands, one MFMA per product, fp32 accumulation (the "fp16 MFMA stem" of BASELINE config 5):
+ * ~5e-4 relative error instead of ~3e-7, one third of the matrix work.  Opt-in; not with the two flags above. */
+#define BNN_HIP_STEM_FP16 4
 int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w,
                                           const float* bn_scale, const float* bn_shift,
                                           int N, int H, int W, int flags,

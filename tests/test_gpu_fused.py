@@ -399,6 +399,19 @@ def test_stem_share_cu_variant_is_bit_identical(shape):
     assert torch.equal(p2.P, p0.P)
 
 
+def test_stem_fp16_option_is_half_precision_accurate():
+    """BNN_HIP_STEM_FP16 (BASELINE config 5's "fp16 MFMA stem"): opt-in, one MFMA per product."""
+    shape = (2, 3, 96, 96)
+    x = dev(gen.normal(gen.seed_of("stem16", shape), shape))
+    w = dev(gen.conv_weight("kaiming", 3, (64, 3, 7, 7)))
+    a = dev((0.5 + gen.uniform(1, (64,))).astype(np.float32))
+    b = dev((0.3 * gen.normal(2, (64,))).astype(np.float32))
+    y16, _ = hipops.stem7x7(x, w, a, b, fp16=True)
+    y, _ = hipops.stem7x7(x, w, a, b)
+    err = float((y16 - y).abs().max() / y.abs().max())
+    assert 1e-6 < err < 3e-3          # genuinely the cheaper arithmetic, and within fp16's class
+
+
 @pytest.mark.parametrize("exact", [False, True], ids=["f16x3", "fp32"])
 @pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 64, 64), (1, 3, 32, 32), (2, 3, 50, 38)])
 def test_mfma_stem_matches_torch_fp32_sequence(shape, exact):
