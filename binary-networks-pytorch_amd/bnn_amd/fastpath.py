@@ -23,6 +23,7 @@ of truth (reference: ``bnn/layers/conv.py:111-112`` shares it with the float mod
 from __future__ import annotations
 
 import threading
+import warnings
 from dataclasses import dataclass
 from typing import Optional
 
@@ -136,14 +137,24 @@ def plan_linear(layer, x: torch.Tensor) -> Optional[Plan]:
     return plan if plan is not None and _eligible(layer, x, plan) else None
 
 
-def packed_weight(layer, plan: Plan) -> hipops.PackedWeight:
-    """Cached ``XNORWeightBinarizer`` output for ``layer.weight`` (rebuilt when it changes)."""
+def packed_weight(layer, plan: Plan, sync: bool = True) -> hipops.PackedWeight:
+    """Cached ``XNORWeightBinarizer`` output for ``layer.weight`` (rebuilt when it changes).
+
+    ``sync=False`` (training step: the weight changed, and will change again) skips the host round trip that
+    reads the zero-weight flag: the pack is made under the assumption "no weight is exactly 0" and the flag of
+    the PREVIOUS pack — long since on the host — is what gets checked; a layer that ever showed a zero is
+    packed synchronously (mask kernel) from then on."""
     w = layer.weight
     key = (w.data_ptr(), w._version, str(w.device), tuple(w.shape), plan.center, plan.compute_alpha)
     cached = layer.__dict__.get("_bnn_packed")
     if cached is not None and cached[0] == key:
         return cached[1]
-    pw = hipops.pack_weight(w, plan.center, plan.compute_alpha)
+    if cached is not None and cached[1].zero_found_later():
+        layer.__dict__["_bnn_zero_seen"] = True
+        warnings.warn("bnn_amd: a binary weight became exactly 0 during training; the previous step's forward "
+                      "treated it as -1.  This layer now takes the zero-aware (slower) kernel.", RuntimeWarning)
+    sync = sync or layer.__dict__.get("_bnn_zero_seen", False)
+    pw = hipops.pack_weight(w, plan.center, plan.compute_alpha, sync=sync)
     layer.__dict__["_bnn_packed"] = (key, pw)
     _bump("weight_packs")
     return pw
@@ -164,7 +175,7 @@ def conv2d_train(layer, x: torch.Tensor, plan: Plan) -> torch.Tensor:
     """Same forward under autograd: HIP kernels forward, fp32 library convolutions backward."""
     from . import training
     native.require()
-    out = training.conv2d_train(layer, x, plan, packed_weight(layer, plan))
+    out = training.conv2d_train(layer, x, plan, packed_weight(layer, plan, sync=False))
     _bump("conv2d_train")
     return out
 

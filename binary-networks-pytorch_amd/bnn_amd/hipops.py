@@ -71,6 +71,16 @@ class PackedWeight:
     alpha: torch.Tensor   # float32 [o_pad]
     has_zero: bool
     shape: Tuple[int, int, int, int]  # logical (O, C, KH, KW)
+    # deferred zero check (pack_weight(..., sync=False)): pinned host copy of the flag + the event after it
+    zero_probe: Optional[tuple] = None
+
+    def zero_found_later(self) -> bool:
+        """True if a pack made with ``sync=False`` turned out to contain a zero weight (waits for the copy)."""
+        if self.zero_probe is None:
+            return False
+        host, ev = self.zero_probe
+        ev.synchronize()
+        return bool(host.item())
 
 
 def empty_packed(N: int, C: int, H: int, W: int, device) -> PackedAct:
@@ -186,9 +196,14 @@ def bn_relu_maxpool_pack(x: torch.Tensor, bn_scale=None, bn_shift=None, relu: bo
     return y, pk
 
 
-def pack_weight(w: torch.Tensor, center: bool = False, compute_alpha: bool = True) -> PackedWeight:
+def pack_weight(w: torch.Tensor, center: bool = False, compute_alpha: bool = True,
+                sync: bool = True) -> PackedWeight:
     """``XNORWeightBinarizer`` on device (bnn/ops.py:116-140).  Synchronises once to read the
-    zero-weight flag — call it when the weight changes, not per forward."""
+    zero-weight flag — call it when the weight changes, not per forward.
+
+    ``sync=False`` (training: the weight changes every step) assumes "no exact zero" and returns at once;
+    the flag travels to pinned host memory asynchronously and ``PackedWeight.zero_found_later()`` tells
+    afterwards whether the assumption held (the caller then re-packs with ``sync=True``)."""
     w = _require_cuda_f32(w.detach(), "weight")
     if w.dim() == 2:
         w = w[:, :, None, None]
@@ -210,6 +225,12 @@ def pack_weight(w: torch.Tensor, center: bool = False, compute_alpha: bool = Tru
                                                  wnz.data_ptr(), alpha.data_ptr(), flag.data_ptr(),
                                                  _stream(w.device)),
                      "bnn_hip_pack_weight_f32")
+        if not sync:
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(w.device))
+            return PackedWeight(wbits, wnz, alpha, False, (O, C, KH, KW), (host, ev))
         has_zero = bool(flag.item())
     return PackedWeight(wbits, wnz, alpha, has_zero, (O, C, KH, KW))
 

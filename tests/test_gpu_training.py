@@ -90,6 +90,29 @@ def test_inference_and_training_forwards_agree_and_repack_after_optimizer_step()
     assert not torch.equal(y2.detach(), y_inf)
 
 
+def test_training_pack_is_asynchronous_and_a_zero_weight_is_caught_one_step_later():
+    layer = _layer(64, 32, 3, 1, 1, False, False, False, seed=21)
+    x = dev(gen.normal(4, (2, 64, 6, 6)))
+    y = layer(x.clone().requires_grad_(True))
+    pw = layer.__dict__["_bnn_packed"][1]
+    assert pw.zero_probe is not None and not pw.has_zero and not pw.zero_found_later()
+    with torch.no_grad():
+        layer.weight[3, 5] = 0.0                       # exact zeros appear (e.g. a pruning step)
+    layer(x.clone().requires_grad_(True))              # packed optimistically: the zeros are only flagged
+    assert layer.__dict__["_bnn_packed"][1].zero_found_later()
+    with torch.no_grad():
+        layer.weight.mul_(1.0)                         # new version -> re-pack; the late flag is noticed now
+    with pytest.warns(RuntimeWarning, match="exactly 0"):
+        y2 = layer(x.clone().requires_grad_(True))
+    assert layer.__dict__["_bnn_packed"][1].has_zero   # synchronous, zero-aware pack from here on
+    training.ENABLED = False
+    try:
+        ref = layer(x.clone().requires_grad_(True))
+    finally:
+        training.ENABLED = True
+    assert torch.allclose(y2, ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
+
+
 def test_small_resnet_trains_on_the_hip_forward():
     """A few SGD steps of a binary ResNet-18: the loss trajectory with the HIP forward follows the
     composition's (identical math up to fp rounding in alpha and the conv sums)."""
