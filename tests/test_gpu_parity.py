@@ -456,3 +456,21 @@ def _r18_for_ckpt():
             m.running_mean = torch.randn(m.num_features, generator=g) * 0.5
             m.running_var = torch.rand(m.num_features, generator=g) + 0.5
     return net.to(DEV).eval()
+
+
+@pytest.mark.parametrize("C,O,k,stride,pad,L", [(64, 32, 3, 1, 1, 50), (70, 40, 5, 2, 2, 33), (128, 64, 1, 1, 0, 17)])
+def test_conv1d_hip_matches_composition(C, O, k, stride, pad, L):
+    """bnn.layers.Conv1d (bnn/layers/conv.py:10-62) on the device: an H == 1 convolution through the same
+    kernels (generic kernel for 1 x k windows), against the layer's own torch composition on CPU."""
+    torch.manual_seed(C + O + k)
+    conv = nn.Conv1d(C, O, k, stride=stride, padding=pad, bias=True)
+    cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
+                      weight_pre_process=XNORWeightBinarizer)
+    layer = bnn.prepare_binary_model(conv, cfg).eval()
+    x = torch.from_numpy(gen.normal(gen.seed_of("c1d", (C, O, k)), (3, C, L)))
+    with torch.no_grad():
+        ref = layer(x)
+        before = fastpath.stats()["conv1d"]
+        got = layer.to(DEV)(x.to(DEV)).cpu()
+    assert fastpath.stats()["conv1d"] == before + 1
+    assert got.shape == ref.shape and torch.allclose(got, ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
