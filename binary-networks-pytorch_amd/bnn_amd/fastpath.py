@@ -3,7 +3,8 @@
 A layer takes the HIP path when ALL of the following hold (otherwise the torch composition in
 ``layers/*.py`` — the reference's own formulation — runs):
 
-* hooks are exactly ``BasicInputBinarizer`` / ``XNORWeightBinarizer`` / (``Identity`` or a
+* hooks are exactly ``BasicInputBinarizer`` (or, for inference, ``AdvancedInputBinarizer`` with its default
+  ``tanh``, whose value is also ``sign(x)``) / ``XNORWeightBinarizer`` / (``Identity`` or a
   per-output-channel ``BasicScaleBinarizer``)      (reference: ``examples/cifar10.py:65-69``,
   ``test/test_layers.py:17-21``)
 * input and weight are float32 on the same HIP device
@@ -52,6 +53,7 @@ class Plan:
     center: bool
     compute_alpha: bool
     scale: Optional[torch.Tensor]  # BasicScaleBinarizer.alpha or None
+    ste: bool = True               # the input hook's backward is the hard-tanh STE (training fast path allowed)
 
 
 _HOOK_MODULES = ("bnn_amd.ops", "bnn_amd.bconfig", "bnn.ops", "bnn.bconfig")
@@ -68,7 +70,12 @@ def _recognise(layer: nn.Module, out_channels: int) -> Optional[Plan]:
     pre = layer.activation_pre_process
     wpre = layer.weight_pre_process
     post = layer.activation_post_process
-    if not _is(pre, "BasicInputBinarizer") or not _is(wpre, "XNORWeightBinarizer"):
+    basic = _is(pre, "BasicInputBinarizer")
+    # AdvancedInputBinarizer (bnn/ops.py:167-177) returns sign(f(t*x)); with the default f = tanh and t > 0
+    # that IS sign(x), only its gradient differs — so inference may take the same kernels, training may not
+    advanced = (_is(pre, "AdvancedInputBinarizer") and getattr(pre, "derivative_funct", None) is torch.tanh
+                and isinstance(getattr(pre, "t", None), (int, float)) and pre.t > 0)
+    if not (basic or advanced) or not _is(wpre, "XNORWeightBinarizer"):
         return None
     if _is(post, "Identity"):
         scale = None
@@ -77,7 +84,7 @@ def _recognise(layer: nn.Module, out_channels: int) -> Optional[Plan]:
         scale = post.alpha
     else:
         return None
-    return Plan(bool(wpre.center_weights), bool(wpre.compute_alpha), scale)
+    return Plan(bool(wpre.center_weights), bool(wpre.compute_alpha), scale, ste=basic)
 
 
 def _eligible(layer: nn.Module, x: torch.Tensor, plan: Plan) -> bool:
@@ -120,7 +127,7 @@ def plan_conv2d_train(layer, x: torch.Tensor) -> Optional[Plan]:
     if x.dim() != 4 or not _numeric_padding(layer):
         return None
     plan = _recognise(layer, layer.out_channels)
-    return plan if plan is not None and _eligible_train(layer, x) else None
+    return plan if plan is not None and plan.ste and _eligible_train(layer, x) else None
 
 
 def plan_conv1d(layer, x: torch.Tensor) -> Optional[Plan]:

@@ -298,4 +298,9 @@ def test_fast_path_recognises_exact_hook_classes_only():
     assert fastpath._recognise(scaled, 8).scale is scaled.activation_post_process.alpha
     adv = bnn.prepare_binary_model(nn.Conv2d(8, 8, 3), bnn.BConfig(
         activation_pre_process=AdvancedInputBinarizer, weight_pre_process=XNORWeightBinarizer))
-    assert fastpath._recognise(adv, 8) is None
+    plan = fastpath._recognise(adv, 8)          # value == sign(x) with the default tanh: inference only
+    assert plan is not None and plan.ste is False and fastpath._recognise(good, 8).ste is True
+    adv2 = bnn.prepare_binary_model(nn.Conv2d(8, 8, 3), bnn.BConfig(
+        activation_pre_process=AdvancedInputBinarizer.with_args(derivative_funct=torch.sigmoid),
+        weight_pre_process=XNORWeightBinarizer))
+    assert fastpath._recognise(adv2, 8) is None

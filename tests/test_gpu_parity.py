@@ -474,3 +474,28 @@ def test_conv1d_hip_matches_composition(C, O, k, stride, pad, L):
         got = layer.to(DEV)(x.to(DEV)).cpu()
     assert fastpath.stats()["conv1d"] == before + 1
     assert got.shape == ref.shape and torch.allclose(got, ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
+
+
+def test_advanced_input_binarizer_takes_the_hip_path_in_inference_only():
+    """AdvancedInputBinarizer (bnn/ops.py:167-177, SURVEY (f)2): value sign(tanh(t*x)) == sign(x) -> same kernels
+    for inference; its gradient is not the STE, so a training forward keeps the torch composition."""
+    from bnn_amd.ops import AdvancedInputBinarizer
+    case = LAYER_CASES_BY_NAME["c2_relu"]
+    x, w, _, _ = case.tensors()
+    conv = nn.Conv2d(case.C, case.O, case.k, stride=case.stride, padding=case.pad, bias=False)
+    conv.weight.data.copy_(torch.from_numpy(w))
+    mk = lambda pre: bnn.prepare_binary_model(  # noqa: E731
+        nn.Sequential(conv), bnn.BConfig(activation_pre_process=pre, activation_post_process=bnn.Identity,
+                                         weight_pre_process=XNORWeightBinarizer))[0].to(DEV).eval()
+    adv, basic = mk(AdvancedInputBinarizer), mk(BasicInputBinarizer)
+    s0 = fastpath.stats()
+    with torch.no_grad():
+        ya, yb = adv(dev(x)), basic(dev(x))
+    s1 = fastpath.stats()
+    assert s1["conv2d"] == s0["conv2d"] + 2 and torch.equal(ya, yb)
+    adv(dev(x).requires_grad_(True)).sum().backward()          # autograd: composition, not the STE fast path
+    assert fastpath.stats()["conv2d_train"] == s1["conv2d_train"]
+    odd = mk(AdvancedInputBinarizer.with_args(derivative_funct=torch.sigmoid))   # sign(sigmoid(.)) != sign(x)
+    with torch.no_grad():
+        odd(dev(x))
+    assert fastpath.stats()["conv2d"] == s1["conv2d"]
