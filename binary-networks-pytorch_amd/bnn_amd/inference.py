@@ -330,7 +330,9 @@ class FusedResNet(nn.Module):
                 self._forward_impl(self._gx)
         torch.cuda.current_stream(example.device).wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: HIP calls of OTHER threads (the RCCL watchdog of an initialised process group, data-loader
+        # pinning threads) must not invalidate the capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._gy = self._forward_impl(self._gx)
         self._graph = g
         return self
