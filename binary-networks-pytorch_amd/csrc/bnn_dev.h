@@ -86,6 +86,8 @@ int launch_bn_relu_maxpool_pack(const float* x, int N, int C, int H, int W, cons
                                 uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_stem(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                 int W, int flags, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
+int launch_stem_wide(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
+                     int W, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_stem_lean(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                      int W, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_stem_split(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,

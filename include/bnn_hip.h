@@ -220,6 +220,8 @@ int bnn_hip_bn_relu_maxpool_pack_f32(const float* x, int N, int C, int H, int W,
 /* Plain fp16 operands, one MFMA per product, fp32 accumulation (the "fp16 MFMA stem" of BASELINE config 5):
  * ~5e-4 relative error instead of ~3e-7, one third of the matrix work.  Opt-in; not with the two flags above. */
 #define BNN_HIP_STEM_FP16 4
+/* Same arithmetic and results as flags = 0 with 16 waves per workgroup (four per SIMD, weights read from LDS). */
+#define BNN_HIP_STEM_WIDE 8
 int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w,
                                           const float* bn_scale, const float* bn_shift,
                                           int N, int H, int W, int flags,

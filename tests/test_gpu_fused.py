@@ -397,6 +397,8 @@ def test_stem_share_cu_variant_is_bit_identical(shape):
     assert torch.equal(y0, y1) and torch.equal(p0.P, p1.P) and torch.equal(p0.M, p1.M)
     _, p2 = hipops.stem7x7(x, w, a, b, share_cu=True, out_f32=False)
     assert torch.equal(p2.P, p0.P)
+    y3, p3 = hipops.stem7x7(x, w, a, b, wide=True)          # 16 waves per workgroup: same bits again
+    assert torch.equal(y0, y3) and torch.equal(p0.P, p3.P) and torch.equal(p0.M, p3.M)
 
 
 def test_stem_fp16_option_is_half_precision_accurate():
