@@ -110,6 +110,7 @@ def test_training_pack_is_asynchronous_and_a_zero_weight_is_caught_one_step_late
         ref = layer(x.clone().requires_grad_(True))
     finally:
         training.ENABLED = True
+    y2, ref = y2.detach(), ref.detach()
     assert torch.allclose(y2, ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
 
 
