@@ -5,8 +5,9 @@ set -u
 R="$(cd "$(dirname "$0")/.." && pwd)"
 V="$R/binary-networks-pytorch_amd/bnn_amd/_lib/variants"
 declare -A CFG=(
-  [base]="-DBNN_NT_STORE=0"
-  [nt]="-DBNN_NT_STORE=1"
+  [p2]="-DBNN_SGPR_PASSES=2"
+  [p4]="-DBNN_SGPR_PASSES=4"
+  [p8]="-DBNN_SGPR_PASSES=8"
 )
 if [ "${1:-build}" = "build" ]; then
   rm -rf "$V"; mkdir -p "$V"
