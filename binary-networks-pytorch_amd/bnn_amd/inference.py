@@ -188,6 +188,8 @@ class FusedResNet(nn.Module):
                 self._shortcut(blk, entry)
                 self._blocks.append(entry)
         self._graph = None
+        self._tensors = list(m.parameters()) + list(m.buffers())
+        self._sig = self._signature()
 
     def _shortcut(self, blk, entry) -> None:
         """AvgPool(ceil) -> binary 1x1 -> BN shortcut of bnn/models/resnet.py:128-133."""
@@ -303,7 +305,17 @@ class FusedResNet(nn.Module):
         c3.run(p, out_packed=False, out_c_offset=half + quarter, **late)
         return y
 
+    def _signature(self):
+        """Changes whenever a parameter or buffer of the wrapped model is replaced or written in place
+        (optimizer step, ``load_state_dict``, ``.to()``): the derived data must then be rebuilt."""
+        return tuple((t.data_ptr(), t._version) for t in self._tensors)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._signature() != self._sig:        # weights changed since the packed forms were derived
+            recapture = self._graph is not None
+            self.refresh()
+            if recapture:
+                self.capture(self._gx)
         if self._graph is not None and x.shape == self._gx.shape:
             if x.data_ptr() != self._gx.data_ptr():   # callers that fill `static_input` in place skip the copy
                 self._gx.copy_(x, non_blocking=True)

@@ -349,6 +349,27 @@ def test_pipelined_inference_two_streams_equals_single_stream():
         assert torch.equal(a, b)
 
 
+def test_fused_executor_follows_weight_changes():
+    """Packed weights / folded BN are derived data: an in-place update or load_state_dict of the wrapped model is
+    noticed (parameter version counters) and the executor — and its captured graph — are rebuilt."""
+    net = _r18()
+    x = dev(gen.normal(12, (2, 3, 64, 64)))
+    fused = FusedResNet(net)
+    y0 = fused(x).clone()
+    with torch.no_grad():
+        net.layer2[0].conv1.weight.mul_(-1.0)          # flips every sign of one binary layer
+        net.layer1[0].bn1.running_mean.add_(0.25)
+    y1 = fused(x).clone()
+    assert not torch.equal(y0, y1) and torch.equal(y1, FusedResNet(net)(x))
+    fused.capture(x)
+    assert torch.equal(fused(x), y1)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    sd["layer3.1.conv2.weight"] = -sd["layer3.1.conv2.weight"]
+    net.load_state_dict(sd)
+    y2 = fused(x).clone()                              # graph re-captured behind the scenes
+    assert fused._graph is not None and not torch.equal(y2, y1) and torch.equal(y2, FusedResNet(net)(x))
+
+
 def test_fused_resnet18_prelu_variant():
     net = _r18(activation=nn.PReLU)
     fused = FusedResNet(net)
