@@ -12,7 +12,7 @@ and quirks, because this *is* the drop-in boundary (``prepare_binary_model`` is 
   special words ``_first_`` / ``_last_``.  NOTE the reference's lookup table is crossed
   (``binarize.py:47-50``): ``_last_`` selects the FIRST convertible layer and ``_first_`` the
   LAST one.  Recipes always pass both, so this is invisible there; it is reproduced here for
-  drop-in fidelity and pinned by ``tests/test_binarize_api.py``;
+  drop-in fidelity and pinned by ``tests/test_api_cpu.py``;
 * the converted layer keeps the device of the layer it replaces.
 """
 from __future__ import annotations

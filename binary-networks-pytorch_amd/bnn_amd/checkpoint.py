@@ -153,34 +153,56 @@ def _read(path: str):
     return header, data
 
 
-def _blob(data: bytes, ent: Dict[str, int], dtype) -> np.ndarray:
-    if ent["offset"] + ent["nbytes"] > len(data):
+def _blob(data: bytes, ent: Dict[str, int], dtype, expect_items: int = -1) -> np.ndarray:
+    """One blob of the data section.  Header fields are untrusted input: offsets must lie inside the file and the
+    byte count must be exactly what the tensor's shape and dtype imply."""
+    off, nb = ent.get("offset"), ent.get("nbytes")
+    if not isinstance(off, int) or not isinstance(nb, int) or off < 0 or nb < 0:
+        raise ValueError("BNNPACK1: corrupt header (offset / nbytes)")
+    if off + nb > len(data):
         raise ValueError("BNNPACK1: truncated file")
+    item = np.dtype(dtype).itemsize
+    if nb % item or (expect_items >= 0 and nb != expect_items * item):
+        raise ValueError(f"BNNPACK1: blob of {nb} bytes does not match its tensor ({expect_items} x {item} bytes)")
     return np.frombuffer(data, dtype=dtype, count=ent["nbytes"] // np.dtype(dtype).itemsize, offset=ent["offset"])
 
 
-def load_packed_signs(path: str) -> Dict[str, Tuple[np.ndarray, np.ndarray, dict]]:
-    """The packed content itself: key -> (sign int8 array of the weight's shape, alpha fp32 [O], meta)."""
-    header, data = _read(path)
+def _shape_of(ent) -> Tuple[int, ...]:
+    shape = ent.get("shape")
+    if not isinstance(shape, list) or any(not isinstance(d, int) or d < 0 for d in shape):
+        raise ValueError("BNNPACK1: corrupt header (shape)")
+    return tuple(shape)
+
+
+def _signs_from(header, data) -> Dict[str, Tuple[np.ndarray, np.ndarray, dict]]:
     out = {}
     for key, ent in header["tensors"].items():
         if ent["kind"] != "xnor":
             continue
-        n = int(np.prod(ent["shape"]))
-        pos = np.unpackbits(_blob(data, ent["bits"], np.uint8), count=n, bitorder="little").astype(np.int8)
+        shape = _shape_of(ent)
+        if len(shape) < 2:
+            raise ValueError(f"BNNPACK1: binary weight {key!r} must have rank >= 2")
+        n = int(np.prod(shape))
+        nbits = (n + 7) // 8
+        pos = np.unpackbits(_blob(data, ent["bits"], np.uint8, nbits), count=n, bitorder="little").astype(np.int8)
         s = 2 * pos - 1
         if "nz" in ent:
-            s = s * np.unpackbits(_blob(data, ent["nz"], np.uint8), count=n, bitorder="little").astype(np.int8)
-        out[key] = (s.reshape(ent["shape"]), _blob(data, ent["alpha"], "<f4").astype(np.float32),
+            s = s * np.unpackbits(_blob(data, ent["nz"], np.uint8, nbits), count=n, bitorder="little").astype(np.int8)
+        out[key] = (s.reshape(shape), _blob(data, ent["alpha"], "<f4", shape[0]).astype(np.float32),
                     {"center": ent["center"], "compute_alpha": ent["compute_alpha"]})
     return out
+
+
+def load_packed_signs(path: str) -> Dict[str, Tuple[np.ndarray, np.ndarray, dict]]:
+    """The packed content itself: key -> (sign int8 array of the weight's shape, alpha fp32 [O], meta)."""
+    return _signs_from(*_read(path))
 
 
 def load_packed(path: str, map_location=None) -> Dict[str, torch.Tensor]:
     """``state_dict`` (same keys / dtypes / shapes as the one saved) with binary weights
     re-materialised as described in the module docstring."""
     header, data = _read(path)
-    signs = load_packed_signs(path)
+    signs = _signs_from(header, data)
     sd = {}
     for key, ent in header["tensors"].items():
         if ent["kind"] == "xnor":
@@ -188,7 +210,8 @@ def load_packed(path: str, map_location=None) -> Dict[str, torch.Tensor]:
             arr = _reconstruct(s, alpha, meta["center"], meta["compute_alpha"])
         elif ent["kind"] == "raw":
             dt = np.dtype(ent["dtype"]).newbyteorder("<")
-            arr = _blob(data, ent["data"], dt).astype(np.dtype(ent["dtype"])).reshape(ent["shape"])
+            shape = _shape_of(ent)
+            arr = _blob(data, ent["data"], dt, int(np.prod(shape))).astype(np.dtype(ent["dtype"])).reshape(shape)
         else:
             raise ValueError(f"BNNPACK1: unknown tensor kind {ent['kind']!r}")
         t = torch.from_numpy(np.array(arr, copy=True))

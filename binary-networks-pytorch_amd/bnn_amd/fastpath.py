@@ -7,7 +7,8 @@ A layer takes the HIP path when ALL of the following hold (otherwise the torch c
   ``tanh``, whose value is also ``sign(x)``) / ``XNORWeightBinarizer`` / (``Identity`` or a
   per-output-channel ``BasicScaleBinarizer``)      (reference: ``examples/cifar10.py:65-69``,
   ``test/test_layers.py:17-21``)
-* input and weight are float32 on the same HIP device
+* input and weight are both float32 or both float16 (a ``.half()`` model: bit planes straight from the fp16
+  tensor, fp32 arithmetic inside, output rounded to fp16 once) on the same HIP device
 * autograd is not recording (``torch.no_grad()`` / inference); when it IS recording, ``Conv2d`` takes the
   training variant (HIP forward, fp32 library backward with the straight-through estimator:
   ``bnn_amd/training.py``), ``Conv1d``/``Linear`` fall back to the composition
@@ -91,7 +92,7 @@ def _eligible(layer: nn.Module, x: torch.Tensor, plan: Plan) -> bool:
     w = layer.weight
     if not (x.is_cuda and w.is_cuda and x.device == w.device):
         return False
-    if x.dtype != torch.float32 or w.dtype != torch.float32:
+    if x.dtype != w.dtype or x.dtype not in (torch.float32, torch.float16):
         return False
     if torch.is_grad_enabled():
         needs = x.requires_grad or w.requires_grad
@@ -144,22 +145,36 @@ def plan_linear(layer, x: torch.Tensor) -> Optional[Plan]:
     return plan if plan is not None and _eligible(layer, x, plan) else None
 
 
-def packed_weight(layer, plan: Plan, sync: bool = True) -> hipops.PackedWeight:
+def packed_weight(layer, plan: Plan, sync: bool = True, fresh: bool = False) -> hipops.PackedWeight:
     """Cached ``XNORWeightBinarizer`` output for ``layer.weight`` (rebuilt when it changes).
 
+    The cache key is the weight's storage pointer + version counter (+ recipe).  Autograd's version counter
+    does NOT see writes through ``weight.data`` (``p.data.clamp_()``, ``p.data.copy_(ema)``): after such a write
+    call ``invalidate(model)`` (inference) — the training forward never trusts the cache (``fresh=True``: it
+    re-derives sign bits and alpha from the current values on every call, like the reference does,
+    bnn/ops.py:129-140).
+
     ``sync=False`` (training step: the weight changed, and will change again) skips the host round trip that
-    reads the zero-weight flag: the pack is made under the assumption "no weight is exactly 0" and the flag of
-    the PREVIOUS pack — long since on the host — is what gets checked; a layer that ever showed a zero is
-    packed synchronously (mask kernel) from then on."""
+    reads the zero-weight flag: the pack is made under the assumption "no weight is exactly 0" and the flag
+    travels to pinned host memory asynchronously.  It is resolved by the NEXT call for this layer — a training
+    call checks the previous step's flag (long since on the host), an inference call (``sync=True``) waits for
+    it — and a layer that ever showed a zero is packed synchronously (mask-aware kernel) from then on."""
     w = layer.weight
     key = (w.data_ptr(), w._version, str(w.device), tuple(w.shape), plan.center, plan.compute_alpha)
     cached = layer.__dict__.get("_bnn_packed")
-    if cached is not None and cached[0] == key:
+    if cached is not None and cached[1].zero_probe is not None and (sync or fresh or cached[0] != key):
+        # a pack made without reading its zero flag: resolve it before it is trusted / replaced
+        pw = cached[1]
+        if pw.zero_found_later():
+            layer.__dict__["_bnn_zero_seen"] = True
+            warnings.warn("bnn_amd: a binary weight is exactly 0 (sign(0) == 0); a forward that ran before this "
+                          "was known treated it as -1.  This layer now takes the zero-aware kernels.",
+                          RuntimeWarning)
+            cached = None      # the unmasked pack is wrong for this weight: rebuild below
+        else:
+            pw.zero_probe = None
+    if cached is not None and cached[0] == key and not fresh:
         return cached[1]
-    if cached is not None and cached[1].zero_found_later():
-        layer.__dict__["_bnn_zero_seen"] = True
-        warnings.warn("bnn_amd: a binary weight became exactly 0 during training; the previous step's forward "
-                      "treated it as -1.  This layer now takes the zero-aware (slower) kernel.", RuntimeWarning)
     sync = sync or layer.__dict__.get("_bnn_zero_seen", False)
     pw = hipops.pack_weight(w, plan.center, plan.compute_alpha, sync=sync)
     layer.__dict__["_bnn_packed"] = (key, pw)
@@ -167,22 +182,39 @@ def packed_weight(layer, plan: Plan, sync: bool = True) -> hipops.PackedWeight:
     return pw
 
 
+def invalidate(module: nn.Module) -> int:
+    """Drop every cached packed weight under ``module`` (returns how many).  Needed after writing weights
+    through ``.data`` (weight clipping ``p.data.clamp_(-1, 1)``, EMA swaps ``p.data.copy_(ema)``, hand-written
+    SGD on ``.data``): those writes do not bump the Parameter's version counter, so nothing else can notice
+    them.  ``FusedResNet.refresh()`` calls this for the model it wraps."""
+    n = 0
+    for m in module.modules():
+        if m.__dict__.pop("_bnn_packed", None) is not None:
+            n += 1
+    return n
+
+
+def _f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """Per-channel constants of a ``.half()`` model, widened (exactly) for the fp32 epilogue."""
+    return t if t is None or t.dtype == torch.float32 else t.detach().float()
+
+
 def conv2d(layer, x: torch.Tensor, plan: Plan) -> torch.Tensor:
     """HIP evaluation of ``bnn.layers.Conv2d.forward`` (bnn/layers/conv.py:90-97)."""
     native.require()
     pw = packed_weight(layer, plan)
     act = hipops.pack_act(x)
-    out = hipops.bconv2d(act, pw, layer.bias, plan.scale, layer.stride, layer.padding,
+    out = hipops.bconv2d(act, pw, _f32(layer.bias), _f32(plan.scale), layer.stride, layer.padding,
                          layer.dilation)
     _bump("conv2d")
-    return out
+    return out.to(x.dtype)
 
 
 def conv2d_train(layer, x: torch.Tensor, plan: Plan) -> torch.Tensor:
     """Same forward under autograd: HIP kernels forward, fp32 library convolutions backward."""
     from . import training
     native.require()
-    out = training.conv2d_train(layer, x, plan, packed_weight(layer, plan, sync=False))
+    out = training.conv2d_train(layer, x, plan, packed_weight(layer, plan, sync=False, fresh=True))
     _bump("conv2d_train")
     return out
 
@@ -192,10 +224,10 @@ def conv1d(layer, x: torch.Tensor, plan: Plan) -> torch.Tensor:
     native.require()
     pw = packed_weight(layer, plan)
     act = hipops.pack_act(x.unsqueeze(2))
-    out = hipops.bconv2d(act, pw, layer.bias, plan.scale, (1, layer.stride[0]),
+    out = hipops.bconv2d(act, pw, _f32(layer.bias), _f32(plan.scale), (1, layer.stride[0]),
                          (0, layer.padding[0]), (1, layer.dilation[0]))
     _bump("conv1d")
-    return out.squeeze(2)
+    return out.squeeze(2).to(x.dtype)
 
 
 def linear(layer, x: torch.Tensor, plan: Plan) -> torch.Tensor:
@@ -205,6 +237,6 @@ def linear(layer, x: torch.Tensor, plan: Plan) -> torch.Tensor:
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
     act = hipops.pack_act(x2[:, :, None, None])
-    out = hipops.bconv2d(act, pw, layer.bias, plan.scale)
+    out = hipops.bconv2d(act, pw, _f32(layer.bias), _f32(plan.scale))
     _bump("linear")
-    return out.reshape(*lead, layer.out_features)
+    return out.reshape(*lead, layer.out_features).to(x.dtype)

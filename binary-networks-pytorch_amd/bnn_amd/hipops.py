@@ -90,8 +90,13 @@ def empty_packed(N: int, C: int, H: int, W: int, device) -> PackedAct:
 
 
 def pack_act(x: torch.Tensor) -> PackedAct:
-    """``BasicInputBinarizer`` on device: fp32 NCHW -> bit planes (bnn/ops.py:151-152)."""
-    x = _require_cuda_f32(x, "activation")
+    """``BasicInputBinarizer`` on device: fp32 (or fp16) NCHW -> bit planes (bnn/ops.py:151-152)."""
+    if x.dtype == torch.float16:
+        if not x.is_cuda:
+            raise native.NativeError(f"bnn_amd: activation must live on a HIP device, got {x.device}")
+        x = x.contiguous()
+    else:
+        x = _require_cuda_f32(x, "activation")
     if x.dim() != 4:
         raise native.NativeError(f"bnn_amd: pack_act expects NCHW, got shape {tuple(x.shape)}")
     lib = native.require()
@@ -100,9 +105,9 @@ def pack_act(x: torch.Tensor) -> PackedAct:
         return empty_packed(0, C, H, W, x.device)
     with torch.cuda.device(x.device):
         a = empty_packed(N, C, H, W, x.device)
-        native.check(lib.bnn_hip_pack_act_f32(x.data_ptr(), N, C, H, W, a.P.data_ptr(),
-                                              a.M.data_ptr(), _stream(x.device)),
-                     "bnn_hip_pack_act_f32")
+        fn = lib.bnn_hip_pack_act_f16 if x.dtype == torch.float16 else lib.bnn_hip_pack_act_f32
+        native.check(fn(x.data_ptr(), N, C, H, W, a.P.data_ptr(), a.M.data_ptr(), _stream(x.device)),
+                     "bnn_hip_pack_act")
     return a
 
 
@@ -147,8 +152,7 @@ def avgpool_pack(x: torch.Tensor, k: int, nonneg: bool = False) -> PackedAct:
 
 
 def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: torch.Tensor,
-            out_f32: bool = True, out_packed: bool = True, exact_fp32: bool = False, share_cu: bool = False,
-            fp16: bool = False, wide: bool = False):
+            out_f32: bool = True, out_packed: bool = True, exact_fp32: bool = False, fp16: bool = False):
     """conv 7x7/2/3 (3->64, no bias) -> folded BN -> ReLU -> MaxPool 3/2/1 in one MFMA kernel
     (bnn/models/resnet.py:93-96,150-153).  Returns (fp32 NCHW | None, PackedAct | None)."""
     x = _require_cuda_f32(x, "stem input")
@@ -166,12 +170,31 @@ def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: 
         pk = empty_packed(N, 64, hp, wp, x.device) if out_packed else None
         native.check(lib.bnn_hip_stem7x7_bn_relu_pool_pack_f32(
             x.data_ptr(), w.data_ptr(), bn_scale.data_ptr(), bn_shift.data_ptr(), N, H, W,
-            1 if exact_fp32 else (2 if share_cu else (4 if fp16 else (8 if wide else 0))), _ptr(y),
+            native.STEM_EXACT_FP32 if exact_fp32 else (native.STEM_FP16 if fp16 else 0), _ptr(y),
             None if pk is None else pk.P.data_ptr(), None if pk is None else pk.M.data_ptr(),
             _stream(x.device)), "bnn_hip_stem7x7_bn_relu_pool_pack_f32")
     if pk is not None:
         pk.nonneg = True  # ReLU output
     return y, pk
+
+
+def avgpool_fc(x: torch.Tensor, w_t: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """``fc(flatten(avgpool(x)))`` of bnn/models/resnet.py:160-164 in one kernel.  ``x``: fp32 ``[N,C,H,W]``,
+    ``w_t``: the Linear weight transposed to ``[C,O]`` (contiguous), ``bias``: ``[O]`` or None."""
+    x = _require_cuda_f32(x, "head input")
+    w_t = _require_cuda_f32(w_t.detach(), "head weight")
+    if x.dim() != 4 or w_t.dim() != 2 or w_t.shape[0] != x.shape[1]:
+        raise native.NativeError("bnn_amd: avgpool_fc expects x [N,C,H,W] and w_t [C,O]")
+    lib = native.require()
+    N, C, H, W = x.shape
+    O = w_t.shape[1]
+    bias = _per_channel(bias, O, "head bias")
+    with torch.cuda.device(x.device):
+        out = torch.empty((N, O), dtype=torch.float32, device=x.device)
+        if N:
+            native.check(lib.bnn_hip_avgpool_fc_f32(x.data_ptr(), N, C, H * W, w_t.data_ptr(), _ptr(bias), O,
+                                                    out.data_ptr(), _stream(x.device)), "bnn_hip_avgpool_fc_f32")
+    return out
 
 
 def bn_relu_maxpool_pack(x: torch.Tensor, bn_scale=None, bn_shift=None, relu: bool = True, k: int = 3,
@@ -204,6 +227,9 @@ def pack_weight(w: torch.Tensor, center: bool = False, compute_alpha: bool = Tru
     ``sync=False`` (training: the weight changes every step) assumes "no exact zero" and returns at once;
     the flag travels to pinned host memory asynchronously and ``PackedWeight.zero_found_later()`` tells
     afterwards whether the assumption held (the caller then re-packs with ``sync=True``)."""
+    half = w.dtype == torch.float16
+    if half:   # a `.half()` model: the sign bits are those of the exact fp32 widening; alpha is rounded to fp16 below
+        w = w.detach().float()
     w = _require_cuda_f32(w.detach(), "weight")
     if w.dim() == 2:
         w = w[:, :, None, None]
@@ -225,6 +251,8 @@ def pack_weight(w: torch.Tensor, center: bool = False, compute_alpha: bool = Tru
                                                  wnz.data_ptr(), alpha.data_ptr(), flag.data_ptr(),
                                                  _stream(w.device)),
                      "bnn_hip_pack_weight_f32")
+        if half:  # the reference computes alpha in the weight's own dtype (bnn/ops.py:116-127)
+            alpha = alpha.half().float()
         if not sync:
             host = torch.empty(1, dtype=torch.int32, pin_memory=True)
             host.copy_(flag, non_blocking=True)
@@ -262,10 +290,8 @@ def _flags(w: PackedWeight, force_generic: bool, weights: Optional[str], a: Opti
         f |= native.FLAG_WEIGHTS_SGPR
     elif weights == "lds":
         f |= native.FLAG_WEIGHTS_LDS
-    elif weights == "vgpr":
-        f |= native.FLAG_WEIGHTS_VGPR
     elif weights is not None:
-        raise ValueError("weights must be None, 'sgpr', 'vgpr' or 'lds'")
+        raise ValueError("weights must be None, 'sgpr' or 'lds'")
     return f
 
 

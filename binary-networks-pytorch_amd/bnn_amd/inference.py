@@ -34,16 +34,43 @@ class FusionError(RuntimeError):
 
 
 def fold_bn(bn: nn.BatchNorm2d):
-    """Eval-mode BatchNorm as one multiply-add per channel: y = x*scale + shift."""
+    """Eval-mode BatchNorm as one fused multiply-add per channel, ``y = fma(x, scale, shift)``, with the
+    constants rounded exactly as the reference's forward rounds them.
+
+    The reference evaluates ``bnN(...)`` with ATen's CPU kernel, which computes (all fp32)
+    ``scale = weight * (1 / sqrt(var + eps))``, ``shift = fma(-mean, scale, bias)`` and
+    ``out = fma(x, scale, shift)`` — measured: bit-identical on 1.6 M elements, whereas constants folded
+    in double precision differ in the last bit for 34 % of the elements.  A last-bit difference in front
+    of a ``sign()`` is a flipped activation, so the fold follows the reference's rounding, not the
+    "more accurate" one.  Done on the host in numpy (IEEE-correct fp32 sqrt / divide), 64..512 values."""
     if not isinstance(bn, nn.BatchNorm2d) or bn.running_mean is None:
         raise FusionError(f"cannot fold {type(bn).__name__} (needs BatchNorm2d with running stats)")
-    var = bn.running_var.detach().double()
-    mean = bn.running_mean.detach().double()
-    gamma = bn.weight.detach().double() if bn.weight is not None else torch.ones_like(var)
-    beta = bn.bias.detach().double() if bn.bias is not None else torch.zeros_like(var)
-    scale = gamma / torch.sqrt(var + bn.eps)
-    shift = beta - mean * scale
-    return scale.float().contiguous(), shift.float().contiguous()
+    import numpy as np
+    dev = bn.running_var.device
+    var = bn.running_var.detach().float().cpu().numpy()
+    mean = bn.running_mean.detach().float().cpu().numpy()
+    gamma = bn.weight.detach().float().cpu().numpy() if bn.weight is not None else np.ones_like(var)
+    beta = bn.bias.detach().float().cpu().numpy() if bn.bias is not None else np.zeros_like(var)
+    inv = np.float32(1.0) / np.sqrt(var + np.float32(bn.eps), dtype=np.float32)
+    scale = (gamma * inv).astype(np.float32)
+    # fma(-mean, scale, bias): the product of two fp32 values is exact in fp64, one rounding to fp32 after the add
+    shift = (beta.astype(np.float64) - mean.astype(np.float64) * scale.astype(np.float64)).astype(np.float32)
+    return torch.from_numpy(scale).to(dev), torch.from_numpy(shift).to(dev)
+
+
+_TAP = None
+
+
+@contextlib.contextmanager
+def tap_binary_inputs(fn):
+    """Debug/test hook: while active, ``fn(layer_name, PackedAct)`` is called with the bit planes every
+    binary convolution of a ``FusedResNet`` reads (eager launches only — not during graph replay)."""
+    global _TAP
+    prev, _TAP = _TAP, fn
+    try:
+        yield
+    finally:
+        _TAP = prev
 
 
 @dataclass
@@ -55,10 +82,13 @@ class _Conv:
     bn_shift: Optional[torch.Tensor]
     relu: bool
     prelu: Optional[torch.Tensor]
+    name: str = ""
 
     def run(self, act: hipops.PackedAct, *, residual=None, out_f32: bool, out_packed: bool, **epi):
         """``epi``: the pre-activation switches of ``hipops.bconv2d_fused`` (late residual, pack affine, ...)."""
         lay = self.layer
+        if _TAP is not None:
+            _TAP(self.name, act)
         return hipops.bconv2d_fused(
             act, self.weight, bias=lay.bias, post_scale=self.plan.scale, bn_scale=self.bn_scale,
             bn_shift=self.bn_shift, residual=residual, prelu=self.prelu, relu=self.relu,
@@ -99,11 +129,11 @@ class FusedResNet(nn.Module):
     pre-activation dataflow of examples/imagenet.py) or ``HBlock`` (hierarchical blocks)."""
 
     def __init__(self, model: ResNet, use_mfma_stem: bool = True, overlap_shortcut: bool = True,
-                 stem_share_cu: bool = False, stem_fp16: bool = False) -> None:
+                 stem_fp16: bool = False, stem_exact_fp32: bool = False) -> None:
         super().__init__()
         self.stem_fp16 = stem_fp16           # opt-in: plain fp16 stem operands (~5e-4 relative error)
         self.use_mfma_stem = use_mfma_stem
-        self.stem_share_cu = stem_share_cu   # one stem wave per SIMD: kernels of other streams stay co-resident
+        self.stem_exact_fp32 = stem_exact_fp32   # v_mfma_f32_16x16x4_f32: bit-for-bit an fp32 fmaf chain (slower)
         self.overlap_shortcut = overlap_shortcut
         self._side = {}
         if not isinstance(model, ResNet) or model.stem_type != "basic":
@@ -119,7 +149,8 @@ class FusedResNet(nn.Module):
         if prelu is not None and prelu.numel() != conv.out_channels:
             prelu = prelu.expand(conv.out_channels).contiguous()
         scale, shift = (None, None) if bn is None else fold_bn(bn)
-        return _Conv(conv, plan, fastpath.packed_weight(conv, plan), scale, shift, relu, prelu)
+        return _Conv(conv, plan, fastpath.packed_weight(conv, plan), scale, shift, relu, prelu,
+                     self._names.get(id(conv), ""))
 
     @staticmethod
     def _sign_through(act: nn.Module):
@@ -132,9 +163,12 @@ class FusedResNet(nn.Module):
         raise FusionError(f"cannot binarise through {type(act).__name__} in a fused epilogue")
 
     def refresh(self) -> None:
-        """(Re)derive packed weights and folded BN constants from the wrapped model."""
+        """(Re)derive packed weights and folded BN constants from the wrapped model.  Runs by itself when a
+        parameter/buffer was replaced or written in place (version counters); call it by hand after writes
+        through ``.data`` (they bypass the counters), then ``capture`` again if a graph was captured."""
         native.require()
         m = self.model
+        fastpath.invalidate(m)
         if m.training:
             raise FusionError("FusedResNet is inference-only: call model.eval() first")
         dev = m.fc.weight.device
@@ -142,6 +176,7 @@ class FusedResNet(nn.Module):
             raise FusionError("FusedResNet needs the model on a HIP device")
         self._blocks = []
         self._stem = None
+        self._names = {id(mod): name for name, mod in m.named_modules()}
         mp = m.maxpool
         if isinstance(mp, nn.MaxPool2d) and isinstance(m.bn1, nn.BatchNorm2d) and mp.dilation in (1, (1, 1)) \
                 and not mp.ceil_mode and isinstance(mp.kernel_size, int) and isinstance(mp.stride, int) \
@@ -154,6 +189,16 @@ class FusedResNet(nn.Module):
                            and c1.stride == (2, 2) and c1.padding == (3, 3) and c1.dilation == (1, 1)
                            and c1.groups == 1 and c1.bias is None and c1.weight.dtype == torch.float32
                            and _is_float_layer(c1))
+        # real-valued head (avgpool -> flatten -> fc, resnet.py:160-164) as one kernel when it is the canonical one
+        fc, ap = m.fc, m.avgpool
+        fc_float = type(fc) is nn.Linear or (
+            isinstance(fc, nn.Linear) and type(getattr(fc, "activation_pre_process", None)) is nn.Identity
+            and type(getattr(fc, "weight_pre_process", None)) is nn.Identity
+            and type(getattr(fc, "activation_post_process", None)).__name__ == "Identity")
+        self._head = None
+        if fc_float and isinstance(ap, nn.AdaptiveAvgPool2d) and ap.output_size in (1, (1, 1)) \
+                and fc.weight.dtype == torch.float32 and fc.in_features * 32 <= 160 * 1024:
+            self._head = (fc.weight.detach().t().contiguous(), None if fc.bias is None else fc.bias.detach())
         for stage in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in stage:
                 if isinstance(blk, nn.AvgPool2d):   # HBlock stages pool in front (bnn_amd/models/resnet.py)
@@ -211,7 +256,7 @@ class FusedResNet(nn.Module):
         # vendor library (MFMA), its BN -> ReLU -> MaxPool -> sign tail in one HBM pass
         if self._stem_mfma:
             t, packed = hipops.stem7x7(x, m.conv1.weight, self._stem[0], self._stem[1],
-                                       share_cu=self.stem_share_cu, fp16=self.stem_fp16)
+                                       exact_fp32=self.stem_exact_fp32, fp16=self.stem_fp16)
         elif self._stem is not None:
             t = m.conv1(x)
             t, packed = hipops.bn_relu_maxpool_pack(t, self._stem[0], self._stem[1], True, *self._stem[2])
@@ -256,6 +301,8 @@ class FusedResNet(nn.Module):
                 idn.record_stream(cur)
             t, packed = b["convs"][-1].run(packed, residual=idn, out_f32=True, out_packed=i != last)
         # real-valued head (last layer stays float)
+        if self._head is not None:
+            return hipops.avgpool_fc(t, *self._head)
         return m.fc(torch.flatten(m.avgpool(t), 1))
 
     def _side_stream(self, device) -> torch.cuda.Stream:

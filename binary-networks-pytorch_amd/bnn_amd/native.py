@@ -20,9 +20,10 @@ FLAG_FORCE_GENERIC = 1
 FLAG_WEIGHT_ZEROS = 2
 FLAG_WEIGHTS_SGPR = 4
 FLAG_WEIGHTS_LDS = 8
-FLAG_WEIGHTS_VGPR = 16
 FLAG_ACT_NONNEG = 32
-ABI_VERSION = 3
+STEM_EXACT_FP32 = 1
+STEM_FP16 = 4
+ABI_VERSION = 4
 
 # every symbol include/bnn_hip.h declares (tests assert the .so exports all of them)
 EXPORTED_SYMBOLS = (
@@ -31,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_avgpool_pack_f32", "bnn_hip_bn_relu_maxpool_pack_f32", "bnn_hip_stem7x7_bn_relu_pool_pack_f32",
     "bnn_hip_pack_weight_f32", "bnn_hip_bconv2d",
     "bnn_hip_bconv2d_fused", "bnn_hip_bconv2d_dot", "bnn_hip_blinear",
-    "bnn_hip_conv_workspace_bytes", "bnn_hip_bconv2d_f32", "bnn_hip_probe_int_alu",
+    "bnn_hip_conv_workspace_bytes", "bnn_hip_bconv2d_f32", "bnn_hip_probe_int_alu", "bnn_hip_avgpool_fc_f32", "bnn_hip_pack_act_f16",
 )
 
 
@@ -100,6 +101,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_act_words.argtypes = [_i]
     lib.bnn_hip_weight_layout.argtypes = [_i, _i, _i, _i, ctypes.POINTER(WLayout)]
     lib.bnn_hip_pack_act_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _vp]
+    lib.bnn_hip_pack_act_f16.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _vp]
     lib.bnn_hip_avgpool_pack_f32.argtypes = [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]
     lib.bnn_hip_bn_act_pack_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]
     lib.bnn_hip_stem7x7_bn_relu_pool_pack_f32.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]
@@ -114,6 +116,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_conv_workspace_bytes.restype = ctypes.c_size_t
     lib.bnn_hip_conv_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.bnn_hip_bconv2d_f32.argtypes = [ctypes.POINTER(ConvDesc)] + [_vp] * 9
+    lib.bnn_hip_avgpool_fc_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]
     lib.bnn_hip_probe_int_alu.argtypes = [_i, _i, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), _vp]
 

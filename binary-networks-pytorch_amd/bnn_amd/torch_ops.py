@@ -70,19 +70,23 @@ def _(x, weight, bias, post_scale, stride, padding, dilation, center_weights, co
 
 def _conv_setup(ctx, inputs, output):
     x, weight, bias, post_scale, stride, padding, dilation, center, compute_alpha = inputs
-    ctx.save_for_backward(x, weight, post_scale, output if post_scale is not None else None)
+    ctx.save_for_backward(x, weight, post_scale, bias)
     ctx.conf = (list(stride), list(padding), list(dilation), center, compute_alpha, bias is not None)
 
 
 def _conv_backward(ctx, g):
     from .ops import XNORWeightBinarizer
-    x, weight, post_scale, out = ctx.saved_tensors
+    x, weight, post_scale, bias = ctx.saved_tensors
     stride, padding, dilation, center, compute_alpha, has_bias = ctx.conf
     gs = None
     if post_scale is not None:
         s = post_scale.reshape(1, -1, 1, 1)
         if ctx.needs_input_grad[3]:
-            gs = (g * (out / s)).sum(dim=(0, 2, 3)).reshape(post_scale.shape)
+            # d out / d post_scale = the PRE-scale output, recomputed by the forward kernels (dividing the saved
+            # output by the scale would give NaN/inf for a zero entry of post_scale, where the gradient is finite)
+            pre = hipops.bconv2d(hipops.pack_act(x), hipops.pack_weight(weight, center, compute_alpha), bias, None,
+                                 tuple(stride), tuple(padding), tuple(dilation))
+            gs = (g * pre).sum(dim=(0, 2, 3)).reshape(post_scale.shape)
         g = g * s
     with torch.enable_grad():
         w = weight.detach().requires_grad_(True)

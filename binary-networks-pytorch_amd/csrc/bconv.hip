@@ -423,53 +423,50 @@ __device__ __forceinline__ void stream_weights(const uint32_t* __restrict__ wrun
   });
 }
 
-// Same traversal, weights through the VECTOR memory path: every lane loads the same address (the
-// texture unit broadcasts one cache line), the words land in VGPRs and feed v_bitop3_b32 as a vector
-// operand.  Vector loads return in order, so `vmcnt` can be counted and PD blocks are kept in flight:
-// that is what the scalar path cannot do (SMEM returns out of order -> only lgkmcnt(0) -> one block
-// of look-ahead).  Used where the scalar cache thrashes — wide layers on small images, where many
-// (output block, chunk) weight runs are live on a CU at once and every s_load is an L2 round trip.
+// Zero weights (sign(0) == 0: pruned nets, bnn/ops.py:66,136).  A second wave-uniform stream carries the
+// non-zero mask Z (same layout as the sign bits).  Per word and output channel:
+//     D_o  += popcount( ((W & M) | (~W & P)) & Z )     disagreements among positions whose weight is non-zero
+//     nz_o += popcount( (P | M) & Z )                  non-zero products: now a per-CHANNEL count
+// and dot = nz_o - 2*D_o.  Five VALU instructions per 32 MACs instead of two (bitop3, and, bcnt, bitop3, bcnt),
+// but still the register-resident field and the scalar weight stream — the shape-generic kernel that pruned nets
+// used to fall to is several times slower.  16-word blocks: two streams x (cur, nxt) = 64 SGPRs.
 template <int NW, int NACC>
-__device__ __forceinline__ void stream_weights_vgpr(const uint32_t* __restrict__ wrun, int vzero,
-                                                    const uint32_t (&pr)[NW],
-                                                    const uint32_t (&mr)[NW], int (&acc)[NACC]) {
-  constexpr int WB = (NACC * NW) % 16 == 0 ? 16 : (NACC * NW) % 8 == 0 ? 8 : 4;
-  constexpr int NB = NACC * NW / WB;
-  constexpr int PD = NB < 3 ? NB : 3;  // blocks in flight
-  using V = typename WordVec<4>::type;
-  constexpr int VPB = WB / 4;
-  const V* wq = reinterpret_cast<const V*>(wrun) + vzero;  // lane-opaque 0: keeps the load vector
-  V ring[PD][VPB];
-#pragma unroll
-  for (int b = 0; b < PD; ++b)
-#pragma unroll
-    for (int v = 0; v < VPB; ++v) ring[b][v] = wq[b * VPB + v];
+__device__ __forceinline__ void stream_weights_wz(const uint32_t* __restrict__ wrun,
+                                                  const uint32_t* __restrict__ zrun,
+                                                  const uint32_t (&pr)[NW], const uint32_t (&mr)[NW],
+                                                  int (&acc)[NACC], int (&nzacc)[NACC]) {
+  constexpr int total = NACC * NW;
+  constexpr int WB = total % 16 == 0 ? 16 : total % 8 == 0 ? 8 : 4;
+  constexpr int NB = total / WB;
+  static_assert(total % WB == 0, "weight run must be a whole number of blocks");
+  WStream<WB> cur, zcur;
+  load_wblock<WB>(wrun, cur);
+  load_wblock<WB>(zrun, zcur);
   int t0 = 0, t1 = 0;
   static_for<NB>([&](auto bc) {
     constexpr int b = decltype(bc)::value;
-    constexpr int slot = b % PD;
-    uint32_t cur[WB];
-#pragma unroll
-    for (int v = 0; v < VPB; ++v) {
-      const uint32_t* e4 = reinterpret_cast<const uint32_t*>(&ring[slot][v]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) cur[v * 4 + e] = e4[e];
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"s"(cur.v[0]), "s"(cur.v[WB - 1]), "s"(zcur.v[0]), "s"(zcur.v[WB - 1]));
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    WStream<WB> nxt, znxt;
+    if constexpr (b + 1 < NB) {
+      load_wblock<WB>(wrun + (b + 1) * WB, nxt);
+      load_wblock<WB>(zrun + (b + 1) * WB, znxt);
     }
-    if constexpr (b + PD < NB) {
-#pragma unroll
-      for (int v = 0; v < VPB; ++v) ring[slot][v] = wq[(b + PD) * VPB + v];
-    }
+    __builtin_amdgcn_sched_barrier(0);
     static_for<WB>([&](auto ec) {
       constexpr int e = decltype(ec)::value;
       constexpr int f = b * WB + e;
       constexpr int j = f / NW, i = f % NW;
-      const uint32_t d = disagree(cur[e], mr[i], pr[i]);
-      if constexpr (i == 0) t0 = __builtin_popcount(d);
-      else if constexpr (i == 1) t1 = __builtin_popcount(d);
-      else if constexpr (i & 1) t1 = popc_acc(d, t1);
-      else t0 = popc_acc(d, t0);
-      if constexpr (i == NW - 1) acc[j] += t0 + (NW > 1 ? t1 : 0);
+      const uint32_t d = disagree(cur.v[e], mr[i], pr[i]) & zcur.v[e];
+      const uint32_t n = (pr[i] | mr[i]) & zcur.v[e];
+      if constexpr (i == 0) { t0 = __builtin_popcount(d); t1 = __builtin_popcount(n); }
+      else { t0 = popc_acc(d, t0); t1 = popc_acc(n, t1); }
+      if constexpr (i == NW - 1) { acc[j] += t0; nzacc[j] += t1; }
     });
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (b + 1 < NB) { cur = nxt; zcur = znxt; }
   });
 }
 
@@ -478,16 +475,17 @@ __device__ __forceinline__ void stream_weights_vgpr(const uint32_t* __restrict__
 //   MULTI == false: the layer has ONE chunk (C <= 64*CWC/2); its field is loaded once and stays
 //                   in registers across all passes.
 //   MULTI == true : any number of chunks; each pass walks the chunks and re-loads the field.
-//   WV: weights through the vector path (stream_weights_vgpr) instead of SGPRs.
 //   GSPLIT: the PASSES runs of a block are separate waves (grid is PASSES times larger) instead of a
 //           loop: finer work items for the small-image layers, whose few, long waves otherwise
 //           quantise badly over the 1024 SIMDs and all reach their HBM epilogue at the same moment.
 //   NN: non-negative activations (M plane all zero, BNN_HIP_FLAG_ACT_NONNEG): P-only field.
-template <int KH, int KW, int CWC, int EP, int MINW, int PASSES, bool MULTI, bool WV, bool GSPLIT = false,
-          bool NN = false>
+//   WZ: some weights are exactly zero (BNN_HIP_FLAG_WEIGHT_ZEROS): second scalar stream with the mask `Z`.
+template <int KH, int KW, int CWC, int EP, int MINW, int PASSES, bool MULTI, bool GSPLIT = false, bool NN = false,
+          bool WZ = false>
 __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
     const uint32_t* __restrict__ P, const uint32_t* __restrict__ M, const uint32_t* __restrict__ W,
-    BNN_EPI_PARAMS, const Geo g) {
+    const uint32_t* __restrict__ Z, BNN_EPI_PARAMS, const Geo g) {
+  static_assert(!(WZ && (NN || GSPLIT)), "the zero-weight variant is two-plane, unsplit");
   constexpr int T = KH * KW;
   constexpr int NW = T * CWC;  // words per (o, chunk)
   constexpr int NACC = kOCB / PASSES;
@@ -505,13 +503,10 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
   if (tile >= g.tiles) return;
   const Pix px = decode_pixel(g, tile * kWave + threadIdx.x);
   uint32_t pbits = 0u, mbits = 0u;
-  int vzero = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-  if constexpr (WV) asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-#endif
 
   if (ob * kOCB < g.O) {
     const uint32_t* wblk = W + (size_t)ob * g.nchunk * (kOCB * NW);
+    const uint32_t* zblk = WZ ? Z + (size_t)ob * g.nchunk * (kOCB * NW) : nullptr;
     uint32_t pr[NW], mr[NW];
     int nz = 0;
     if constexpr (!MULTI) {
@@ -521,6 +516,7 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
 #pragma unroll 1
     for (int ps = GSPLIT ? part : 0; ps < (GSPLIT ? part + 1 : PASSES); ++ps) {
       int acc[NACC];
+      [[maybe_unused]] int nzacc[NACC];
       float resv[NACC];
       // single-chunk: shortcut values are requested before the popcount loop and land under it.
       // multi-chunk: the field + 32 accumulators already fill the 128-VGPR budget of 4 waves/SIMD;
@@ -528,24 +524,27 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       constexpr bool RES_EARLY = !MULTI || BNN_MULTI_RES_EARLY;
       if constexpr (RES_EARLY) prefetch_residual<NACC, EP>(g, px, ob * kOCB + ps * NACC, epi, resv);
 #pragma unroll
-      for (int j = 0; j < NACC; ++j) acc[j] = 0;
+      for (int j = 0; j < NACC; ++j) {
+        acc[j] = 0;
+        if constexpr (WZ) nzacc[j] = 0;
+      }
       if constexpr (MULTI) {
         for (int ch = 0; ch < g.nchunk; ++ch) {
           load_field<KH, KW, CWC, NN>(g, px, ch, P, M, pr, mr);
-          if (GSPLIT || ps == 0) nz = count_nonzero<NW, NN>(pr, mr, nz);
-          const uint32_t* wrun = wblk + ((size_t)ch * kOCB + ps * NACC) * NW;
-          if constexpr (WV) stream_weights_vgpr<NW, NACC>(wrun, vzero, pr, mr, acc);
-          else stream_weights<NW, NACC, NN>(wrun, pr, mr, acc);
+          if (!WZ && (GSPLIT || ps == 0)) nz = count_nonzero<NW, NN>(pr, mr, nz);
+          const size_t woff = ((size_t)ch * kOCB + ps * NACC) * NW;
+          if constexpr (WZ) stream_weights_wz<NW, NACC>(wblk + woff, zblk + woff, pr, mr, acc, nzacc);
+          else stream_weights<NW, NACC, NN>(wblk + woff, pr, mr, acc);
         }
       } else {
-        const uint32_t* wrun = wblk + (size_t)ps * (NACC * NW);
-        if constexpr (WV) stream_weights_vgpr<NW, NACC>(wrun, vzero, pr, mr, acc);
-        else stream_weights<NW, NACC, NN>(wrun, pr, mr, acc);
+        const size_t woff = (size_t)ps * (NACC * NW);
+        if constexpr (WZ) stream_weights_wz<NW, NACC>(wblk + woff, zblk + woff, pr, mr, acc, nzacc);
+        else stream_weights<NW, NACC, NN>(wblk + woff, pr, mr, acc);
       }
       if constexpr (!RES_EARLY) prefetch_residual<NACC, EP>(g, px, ob * kOCB + ps * NACC, epi, resv);
 #pragma unroll
       for (int j = 0; j < NACC; ++j)  // dot = non-zeros - 2*disagreements = 2*agreements - non-zeros
-        acc[j] = NN ? 2 * acc[j] - nz : nz - 2 * acc[j];
+        acc[j] = WZ ? nzacc[j] - 2 * acc[j] : NN ? 2 * acc[j] - nz : nz - 2 * acc[j];
       epilogue<NACC, EP>(g, px, ob * kOCB + ps * NACC, acc, resv, epi, pbits, mbits);
     }
   }
@@ -748,9 +747,6 @@ static unsigned oblocks(const ConvP& p) {
 #ifndef BNN_SGPR_PASSES  // passes per 32-channel block, single-chunk 3x3 layers
 #define BNN_SGPR_PASSES 4
 #endif
-#ifndef BNN_DEFAULT_MULTI_VGPR  // multi-chunk 3x3 layers: weights via the vector path by default
-#define BNN_DEFAULT_MULTI_VGPR 0
-#endif
 #ifndef BNN_SGPR_PASSES_MULTI  // same, multi-chunk 3x3 layers (each pass re-loads the field)
 #define BNN_SGPR_PASSES_MULTI 1
 #endif
@@ -768,21 +764,16 @@ static unsigned oblocks(const ConvP& p) {
 
 // NN: the caller vouches for an all-zero M plane (BNN_HIP_FLAG_ACT_NONNEG); 3x3 kernels only.
 template <int KH, int KW, int CWC, int EP, bool NN>
-static void launch_sgpr_t(const ConvP& p, const Geo& g, bool wv, hipStream_t s) {
+static void launch_sgpr_t(const ConvP& p, const Geo& g, hipStream_t s) {
   const dim3 grid((unsigned)(8 * g.tiles_per_xcd) * oblocks(p));  // see the XCD note in the kernel
   constexpr bool k3 = KH * KW > 1;
   constexpr int P1 = k3 ? BNN_SGPR_PASSES : 1, PM = k3 ? BNN_SGPR_PASSES_MULTI : 1;
   if (k3 && p.nchunk == 1) {
-    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, P1, false, false, false, NN>), grid,
-                       dim3(kWave), 0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
+    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, P1, false, false, NN>), grid,
+                       dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
     return;
   }
   if constexpr (k3 && CWC == 4) {  // the only shape class with several chunks of a large field
-    if (wv && !NN) {
-      hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, 2, true, true>), grid, dim3(kWave),
-                         0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
-      return;
-    }
     // multi-chunk 3x3: all 32 accumulators live (one pass over the chunks); with both planes in
     // registers the file is capped for 4 waves per SIMD (512->512 7x7 b256: 100 us vs 131 us
     // uncapped / 2 passes), the P-only field fits without a cap.
@@ -792,44 +783,58 @@ static void launch_sgpr_t(const ConvP& p, const Geo& g, bool wv, hipStream_t s) 
     if ((long long)grid.x <= BNN_GSPLIT_MAX_WAVES) {
       const dim3 grid2(grid.x * BNN_MULTI_GSPLIT);
       hipLaunchKernelGGL(
-          (bconv_sgpr_kernel<KH, KW, CWC, EP, MW, BNN_MULTI_GSPLIT, true, false, true, NN>), grid2,
-          dim3(kWave), 0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
+          (bconv_sgpr_kernel<KH, KW, CWC, EP, MW, BNN_MULTI_GSPLIT, true, true, NN>), grid2,
+          dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
       return;
     }
 #endif
-    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MW, PM, true, false, false, NN>), grid,
-                       dim3(kWave), 0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
+    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MW, PM, true, false, NN>), grid,
+                       dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
     return;
   }
-  hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, PM, true, false, false, NN>), grid,
-                     dim3(kWave), 0, s, p.P, p.M, p.W, BNN_EPI_ACTUALS, g);
+  hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, PM, true, false, NN>), grid,
+                     dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
 }
 
 template <int KH, int KW, int CWC, int EP>
-static void launch_sgpr_e(const ConvP& p, const Geo& g, bool wv, bool nn, hipStream_t s) {
+static void launch_sgpr_e(const ConvP& p, const Geo& g, bool nn, hipStream_t s) {
   if constexpr (KH * KW > 1) {
-    if (nn) return launch_sgpr_t<KH, KW, CWC, EP, true>(p, g, wv, s);
+    if (nn) return launch_sgpr_t<KH, KW, CWC, EP, true>(p, g, s);
   }
-  launch_sgpr_t<KH, KW, CWC, EP, false>(p, g, wv, s);
+  launch_sgpr_t<KH, KW, CWC, EP, false>(p, g, s);
+}
+
+// Zero-weight variant (BNN_HIP_FLAG_WEIGHT_ZEROS): two-plane field, 4 passes of 8 channels, run-time epilogue.
+template <int KH, int KW, int CWC, int EP>
+static void launch_sgpr_wz(const ConvP& p, const Geo& g, hipStream_t s) {
+  const dim3 grid((unsigned)(8 * g.tiles_per_xcd) * oblocks(p));
+  if (KH * KW > 1 && p.nchunk == 1)
+    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, 4, false, false, false, true>), grid,
+                       dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
+  else
+    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, 4, true, false, false, true>), grid,
+                       dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
 }
 
 // PROFILES: whether the compile-time epilogue profiles exist for this shape (3x3 only).
 template <int KH, int KW, int CWC, bool PROFILES>
 static void launch_sgpr(const ConvP& p, int flags, hipStream_t s) {
   const Geo g = make_geo(p);
-  // multi-chunk 3x3 layers: weight path by build default unless the caller forces one
-  const bool wv = (flags & BNN_HIP_FLAG_WEIGHTS_VGPR) ||
-                  (BNN_DEFAULT_MULTI_VGPR && !(flags & BNN_HIP_FLAG_WEIGHTS_SGPR));
   const bool nn = (flags & BNN_HIP_FLAG_ACT_NONNEG) != 0;
   const bool fused = (g.flags & (EF_BN | EF_RES | EF_RELU | EF_PRELU | EF_PACK)) != 0;
-  if constexpr (PROFILES) {
-    if (g.flags == kFlagsMid) return launch_sgpr_e<KH, KW, CWC, EP_MID>(p, g, wv, nn, s);
-    if (g.flags == kFlagsOut) return launch_sgpr_e<KH, KW, CWC, EP_OUT>(p, g, wv, nn, s);
-  } else {
-    if (g.flags == kFlagsDs) return launch_sgpr_e<KH, KW, CWC, EP_DS>(p, g, wv, nn, s);
+  if (flags & BNN_HIP_FLAG_WEIGHT_ZEROS) {
+    if (fused) launch_sgpr_wz<KH, KW, CWC, EP_RUNTIME>(p, g, s);
+    else launch_sgpr_wz<KH, KW, CWC, EP_PLAIN>(p, g, s);
+    return;
   }
-  if (fused) launch_sgpr_e<KH, KW, CWC, EP_RUNTIME>(p, g, wv, nn, s);
-  else launch_sgpr_e<KH, KW, CWC, EP_PLAIN>(p, g, wv, nn, s);
+  if constexpr (PROFILES) {
+    if (g.flags == kFlagsMid) return launch_sgpr_e<KH, KW, CWC, EP_MID>(p, g, nn, s);
+    if (g.flags == kFlagsOut) return launch_sgpr_e<KH, KW, CWC, EP_OUT>(p, g, nn, s);
+  } else {
+    if (g.flags == kFlagsDs) return launch_sgpr_e<KH, KW, CWC, EP_DS>(p, g, nn, s);
+  }
+  if (fused) launch_sgpr_e<KH, KW, CWC, EP_RUNTIME>(p, g, nn, s);
+  else launch_sgpr_e<KH, KW, CWC, EP_PLAIN>(p, g, nn, s);
 }
 
 template <int KH, int KW, int CWC>
@@ -863,21 +868,21 @@ int choose_cwc(int cw32, int KH, int KW) {
 }
 
 // Weight source.  Measured on MI355X (tools/bench_conv.py, tools/exp_l4.py): the SGPR stream
-// beats both the LDS-staged tile and the vector-broadcast path on every ResNet-18 shape
-// (512->512 7x7 b256: 100 us SGPR, 162 us VGPR broadcast, 216 us LDS), so those are only taken
+// beats the LDS-staged tile on every ResNet-18 shape (512->512 7x7 b256: 100 us SGPR, 216 us LDS;
+// a vector-broadcast weight path measured 162 us and was removed), so the LDS tile is only taken
 // on request.
 static bool prefer_lds(const ConvP&, int flags) { return (flags & BNN_HIP_FLAG_WEIGHTS_LDS) != 0; }
 
 int launch_bconv(const ConvP& p, int flags, hipStream_t s) {
   const bool wz = (flags & BNN_HIP_FLAG_WEIGHT_ZEROS) != 0;
-  const bool generic = (flags & BNN_HIP_FLAG_FORCE_GENERIC) || wz || p.dh != 1 || p.dw != 1;
+  const bool generic = (flags & BNN_HIP_FLAG_FORCE_GENERIC) || p.dh != 1 || p.dw != 1;
   bool done = false;
   if (!generic) {
     const bool lds = prefer_lds(p, flags);
     done = true;
 #define BNN_PICK(KH_, KW_, C_, PROF_)                           \
   if (p.KH == KH_ && p.KW == KW_ && p.cwc == C_) {              \
-    if (lds && PROF_) launch_lds<KH_, KW_, C_>(p, s);           \
+    if (lds && PROF_ && !wz) launch_lds<KH_, KW_, C_>(p, s);    \
     else launch_sgpr<KH_, KW_, C_, PROF_>(p, flags, s);         \
   } else
     BNN_PICK(3, 3, 4, true) BNN_PICK(3, 3, 2, true) BNN_PICK(1, 1, 16, false)

@@ -77,6 +77,8 @@ struct ConvP {
 int choose_cwc(int cw32, int KH, int KW);
 int launch_pack_act(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
                     hipStream_t stream);
+int launch_pack_act_f16(const void* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
+                        hipStream_t stream);
 int launch_bn_act_pack(const float* x, int N, int C, int H, int W, const float* bn_a, const float* bn_b,
                        int relu, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_avgpool_pack(const float* x, int N, int C, int H, int W, int k, uint64_t* P, uint64_t* M,
@@ -86,12 +88,10 @@ int launch_bn_relu_maxpool_pack(const float* x, int N, int C, int H, int W, cons
                                 uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_stem(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                 int W, int flags, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
-int launch_stem_wide(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
-                     int W, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
-int launch_stem_lean(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
-                     int W, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_stem_split(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                       int W, int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
+int launch_avgpool_fc(const float* x, const float* wt, const float* bias, float* out, int N, int C, int HW,
+                      int O, hipStream_t stream);
 int launch_pack_weight(const float* w, int O, int C, int KH, int KW, int center, int compute_alpha,
                        const bnn_hip_wlayout& L, uint32_t* wbits, uint32_t* wnz, float* alpha,
                        int32_t* zero_flag, hipStream_t stream);

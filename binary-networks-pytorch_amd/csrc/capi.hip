@@ -135,6 +135,16 @@ int bnn_hip_pack_act_f32(const float* x, int N, int C, int H, int W, uint64_t* P
   return bnn::launch_pack_act(x, N, C, H, W, P, M, static_cast<hipStream_t>(stream));
 }
 
+int bnn_hip_pack_act_f16(const void* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
+                         void* stream) {
+  if (!x || !P || !M || N <= 0 || C <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if ((long long)N * H * W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if ((C + 63) / 64 > 65535) return BNN_HIP_ERR_UNSUPPORTED;  // grid.y limit
+  if (!aligned(P, 8) || !aligned(M, 8) || !aligned(x, 2)) return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  return bnn::launch_pack_act_f16(x, N, C, H, W, P, M, static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_bn_act_pack_f32(const float* x, int N, int C, int H, int W, const float* bn_scale,
                             const float* bn_shift, int relu, uint64_t* P, uint64_t* M, void* stream) {
   if (!x || !P || !M || N <= 0 || C <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
@@ -186,6 +196,15 @@ int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w, const 
   g_launches.fetch_add(1, std::memory_order_relaxed);
   return bnn::launch_stem(x, w, bn_scale, bn_shift, N, H, W, flags, out_f32, P, M,
                           static_cast<hipStream_t>(stream));
+}
+
+int bnn_hip_avgpool_fc_f32(const float* x, int N, int C, int HW, const float* w_t, const float* bias, int O,
+                           float* out, void* stream) {
+  if (!x || !w_t || !out || N <= 0 || C <= 0 || HW <= 0 || O <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (!aligned(x, 4) || !aligned(w_t, 4) || !aligned(out, 4)) return BNN_HIP_ERR_INVALID_ARG;
+  if ((long long)N * C * HW > 4 * kMaxElems || (long long)N * O > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  return bnn::launch_avgpool_fc(x, w_t, bias, out, N, C, HW, O, static_cast<hipStream_t>(stream));
 }
 
 int bnn_hip_pack_weight_f32(const float* w, int O, int C, int KH, int KW, int center,

@@ -11,37 +11,39 @@
 // channel plane, every store is VP contiguous uint64 words of the [n][group][y][x] output
 // plane, and small images with many channels still fill the chip (parallelism = pixels/VP x
 // channel groups).
+#include <hip/hip_fp16.h>
+
 #include "bnn_dev.h"
 
 namespace bnn {
 
-template <int VP>
-struct PixVec;
-template <>
-struct PixVec<1> { using type = float; };
-template <>
-struct PixVec<2> { using type = float2; };
-template <>
-struct PixVec<4> { using type = float4; };
+// VP consecutive pixels of one channel, loaded with ONE instruction (4..16 bytes per lane).
+// T = float, or __half for `.half()` models (sign() of an fp16 value is the sign of its exact fp32 widening).
+template <typename T, int VP>
+struct alignas(sizeof(T) * VP) PixVec {
+  T v[VP];
+};
+__device__ __forceinline__ float widen(float v) { return v; }
+__device__ __forceinline__ float widen(__half v) { return __half2float(v); }
 
 // AFF: v = fmaf(x, bn_a[c], bn_b[c]) first (eval-mode BatchNorm in front of a pre-activation block's
 // binary conv: res_block.py:148, hierarchical_block.py:39); relu != 0: planes of sign(max(v, 0)).
-template <int VP, bool AFF = false>
-__global__ __launch_bounds__(256) void pack_act_kernel(const float* __restrict__ x, int C, int HW,
+template <int VP, bool AFF = false, typename T = float>
+__global__ __launch_bounds__(256) void pack_act_kernel(const T* __restrict__ x, int C, int HW,
                                                        long long npix, int cw64,
                                                        uint64_t* __restrict__ P,
                                                        uint64_t* __restrict__ M,
                                                        const float* __restrict__ bn_a = nullptr,
                                                        const float* __restrict__ bn_b = nullptr,
                                                        int relu = 0) {
-  using V = typename PixVec<VP>::type;
+  using V = PixVec<T, VP>;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long pix0 = t * VP;
   if (pix0 >= npix) return;
   const int g = blockIdx.y;
   const int n = (int)(pix0 / HW);
   const int r = (int)(pix0 - (long long)n * HW);
-  const float* xb = x + ((size_t)n * C) * HW + r;
+  const T* xb = x + ((size_t)n * C) * HW + r;
 
   uint32_t pw[2][VP], mw[2][VP];
 #pragma unroll
@@ -55,7 +57,9 @@ __global__ __launch_bounds__(256) void pack_act_kernel(const float* __restrict__
 #pragma unroll 16
       for (int b = 31; b >= 0; --b) {
         const V xv = *reinterpret_cast<const V*>(xb + (size_t)(c0 + b) * HW);
-        const float* xs = reinterpret_cast<const float*>(&xv);
+        float xs[VP];
+#pragma unroll
+        for (int v = 0; v < VP; ++v) xs[v] = widen(xv.v[v]);
         const float ca = AFF && bn_a ? bn_a[c0 + b] : 1.0f, cb = AFF && bn_a ? bn_b[c0 + b] : 0.0f;
 #pragma unroll
         for (int v = 0; v < VP; ++v) {
@@ -67,7 +71,9 @@ __global__ __launch_bounds__(256) void pack_act_kernel(const float* __restrict__
     } else {
       for (int b = 0; b < 32 && c0 + b < C; ++b) {
         const V xv = *reinterpret_cast<const V*>(xb + (size_t)(c0 + b) * HW);
-        const float* xs = reinterpret_cast<const float*>(&xv);
+        float xs[VP];
+#pragma unroll
+        for (int v = 0; v < VP; ++v) xs[v] = widen(xv.v[v]);
         const float ca = AFF && bn_a ? bn_a[c0 + b] : 1.0f, cb = AFF && bn_a ? bn_b[c0 + b] : 0.0f;
 #pragma unroll
         for (int v = 0; v < VP; ++v) {
@@ -87,21 +93,36 @@ __global__ __launch_bounds__(256) void pack_act_kernel(const float* __restrict__
   }
 }
 
-int launch_pack_act(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
-                    hipStream_t stream) {
+template <typename T>
+static int launch_pack_act_t(const T* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
+                             hipStream_t stream) {
   const int HW = H * W;
   const long long npix = (long long)N * HW;
   const int cw64 = (C + 63) / 64;
-  const bool a16 = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
-  const bool a8 = (reinterpret_cast<uintptr_t>(x) & 7u) == 0;
+  const bool a4 = (reinterpret_cast<uintptr_t>(x) & (4 * sizeof(T) - 1)) == 0;
+  const bool a2 = (reinterpret_cast<uintptr_t>(x) & (2 * sizeof(T) - 1)) == 0;
   auto grid = [&](long long nthr) { return dim3((unsigned)((nthr + 255) / 256), (unsigned)cw64); };
-  if (HW % 4 == 0 && a16)
-    hipLaunchKernelGGL((pack_act_kernel<4, false>), grid(npix / 4), dim3(256), 0, stream, x, C, HW, npix, cw64, P, M);
-  else if (HW % 2 == 0 && a8)
-    hipLaunchKernelGGL((pack_act_kernel<2, false>), grid(npix / 2), dim3(256), 0, stream, x, C, HW, npix, cw64, P, M);
+  const float* none = nullptr;
+  if (HW % 4 == 0 && a4)
+    hipLaunchKernelGGL((pack_act_kernel<4, false, T>), grid(npix / 4), dim3(256), 0, stream, x, C, HW, npix, cw64,
+                       P, M, none, none, 0);
+  else if (HW % 2 == 0 && a2)
+    hipLaunchKernelGGL((pack_act_kernel<2, false, T>), grid(npix / 2), dim3(256), 0, stream, x, C, HW, npix, cw64,
+                       P, M, none, none, 0);
   else
-    hipLaunchKernelGGL((pack_act_kernel<1, false>), grid(npix), dim3(256), 0, stream, x, C, HW, npix, cw64, P, M);
+    hipLaunchKernelGGL((pack_act_kernel<1, false, T>), grid(npix), dim3(256), 0, stream, x, C, HW, npix, cw64, P, M,
+                       none, none, 0);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+int launch_pack_act(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
+                    hipStream_t stream) {
+  return launch_pack_act_t<float>(x, N, C, H, W, P, M, stream);
+}
+
+int launch_pack_act_f16(const void* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
+                        hipStream_t stream) {
+  return launch_pack_act_t<__half>(static_cast<const __half*>(x), N, C, H, W, P, M, stream);
 }
 
 int launch_bn_act_pack(const float* x, int N, int C, int H, int W, const float* bn_a, const float* bn_b,

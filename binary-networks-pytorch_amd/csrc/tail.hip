@@ -1,0 +1,87 @@
+// tail.hip — the real-valued LAST layer of the reference's ResNets as one kernel:
+//     x = avgpool(x); x = torch.flatten(x, 1); x = fc(x)          (bnn/models/resnet.py:160-164)
+// i.e. AdaptiveAvgPool2d((1,1)) over the HW positions of every channel, then Linear(C -> O) with bias.
+// At ResNet-18 size (C = 512, HW = 49, O = 1000, batch 256) this is 25.7 MB of input and 0.13 G MAC:
+// launch- and latency-bound work that three library kernels (mean-reduce, GEMM, bias/copies) spent
+// ~100 us on; fused it is one pass with the means kept in LDS.
+//
+// Work decomposition: a workgroup owns IMG = 8 images x 256 output features.
+//   phase 1: thread (i, c) sums the HW contiguous values of channel c of image i (fp32, index order, then
+//            one division by HW — the order of ATen's CPU adaptive_avg_pool2d) -> m[c][i] in LDS;
+//   phase 2: thread o walks k = 0..C-1: one coalesced load of Wt[k][o] (the weight is passed transposed,
+//            [C][O], so that the 64 lanes of a wave read 256 contiguous bytes), two broadcast
+//            ds_read_b128 of m[k][0..7], eight fmaf.  The weight (2 MB at ResNet-18 size) is read once per
+//            8 images from L2.
+#include "bnn_dev.h"
+
+namespace bnn {
+
+namespace tail {
+constexpr int IMG = 8;
+constexpr int NT = 256;
+}  // namespace tail
+
+__global__ __launch_bounds__(tail::NT) void avgpool_fc_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ wt,
+                                                               const float* __restrict__ bias,
+                                                               float* __restrict__ out, int N, int C, int HW,
+                                                               int O) {
+  using namespace tail;
+  extern __shared__ __attribute__((aligned(16))) float m[];  // [C][IMG]
+  const int n0 = blockIdx.x * IMG;
+  const int tid = threadIdx.x;
+  const float hw = (float)HW;
+  for (int idx = tid; idx < C * IMG; idx += NT) {
+    const int i = idx / C, c = idx - i * C;
+    float s = 0.0f;
+    if (n0 + i < N) {
+      const float* p = x + ((size_t)(n0 + i) * C + c) * HW;
+#pragma unroll 7
+      for (int q = 0; q < HW; ++q) s += p[q];
+      s = s / hw;
+    }
+    m[c * IMG + i] = s;
+  }
+  __syncthreads();
+  const int o = blockIdx.y * NT + tid;
+  if (o >= O) return;
+  float acc[IMG];
+#pragma unroll
+  for (int i = 0; i < IMG; ++i) acc[i] = 0.0f;
+  const float* wp = wt + o;
+#pragma unroll 8
+  for (int k = 0; k < C; ++k) {
+    const float w = wp[(size_t)k * O];
+    const float4 a = *reinterpret_cast<const float4*>(&m[k * IMG]);
+    const float4 b = *reinterpret_cast<const float4*>(&m[k * IMG + 4]);
+    acc[0] = fmaf(a.x, w, acc[0]);
+    acc[1] = fmaf(a.y, w, acc[1]);
+    acc[2] = fmaf(a.z, w, acc[2]);
+    acc[3] = fmaf(a.w, w, acc[3]);
+    acc[4] = fmaf(b.x, w, acc[4]);
+    acc[5] = fmaf(b.y, w, acc[5]);
+    acc[6] = fmaf(b.z, w, acc[6]);
+    acc[7] = fmaf(b.w, w, acc[7]);
+  }
+  const float bv = bias ? bias[o] : 0.0f;
+#pragma unroll
+  for (int i = 0; i < IMG; ++i)
+    if (n0 + i < N) out[(size_t)(n0 + i) * O + o] = acc[i] + bv;
+}
+
+int launch_avgpool_fc(const float* x, const float* wt, const float* bias, float* out, int N, int C, int HW,
+                      int O, hipStream_t stream) {
+  using namespace tail;
+  const size_t lds = (size_t)C * IMG * sizeof(float);
+  if (lds > 160 * 1024) return BNN_HIP_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(avgpool_fc_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return BNN_HIP_ERR_UNSUPPORTED;
+  }
+  const dim3 grid((N + IMG - 1) / IMG, (O + NT - 1) / NT);
+  hipLaunchKernelGGL(avgpool_fc_kernel, grid, dim3(NT), lds, stream, x, wt, bias, out, N, C, HW, O);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+}  // namespace bnn

@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 3
+#define BNN_HIP_ABI_VERSION 4
 #define BNN_HIP_OCB 32 /* output channels per weight block (padding granularity of O) */
 
 typedef enum bnn_hip_status {
@@ -87,7 +87,6 @@ typedef struct bnn_hip_conv_desc {
 #define BNN_HIP_FLAG_WEIGHT_ZEROS 2  /* some sign(W) == 0: honour the wnz mask (slower kernel)  */
 #define BNN_HIP_FLAG_WEIGHTS_SGPR 4  /* tiled kernel: force the scalar-cache weight stream       */
 #define BNN_HIP_FLAG_WEIGHTS_LDS 8   /* tiled kernel: force the LDS-staged weight tile           */
-#define BNN_HIP_FLAG_WEIGHTS_VGPR 16 /* tiled kernel: force weights through the vector path    */
 #define BNN_HIP_FLAG_ACT_NONNEG 32   /* caller vouches that the M plane is ALL ZERO (activations
                                         out of a ReLU / max-pool of a ReLU are {0,+1}): 3x3 kernels
                                         then keep only the P plane in registers.  M must still be a
@@ -180,6 +179,12 @@ int bnn_hip_weight_layout(int O, int C, int KH, int KW, bnn_hip_wlayout* out);
 int bnn_hip_pack_act_f32(const float* x, int N, int C, int H, int W,
                          uint64_t* P, uint64_t* M, void* stream);
 
+/* Same planes from an IEEE half-precision tensor (a `.half()` model: Tensor.sign() of fp16 values,
+ * bnn/ops.py:66).  x: [N,C,H,W] of 16-bit floats, 2-byte aligned.  sign() is exact in any precision, so
+ * the planes equal those of the widened fp32 tensor bit for bit.                                  */
+int bnn_hip_pack_act_f16(const void* x, int N, int C, int H, int W,
+                         uint64_t* P, uint64_t* M, void* stream);
+
 /* AvgPool2d(kernel=k, stride=k, ceil_mode=True, count_include_pad=False) followed by
  * sign(): the shortcut branch of a down-sampling residual stage
  * (bnn/models/resnet.py:128-133: AvgPool2d -> binary conv1x1 -> BN).  Output planes have
@@ -213,19 +218,21 @@ int bnn_hip_bn_relu_maxpool_pack_f32(const float* x, int N, int C, int H, int W,
  *            ~3e-7 relative, the rounding class of an fp32 convolution, at 3/16 of the matrix time;
  * flags = BNN_HIP_STEM_EXACT_FP32: v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 fmaf chain.     */
 #define BNN_HIP_STEM_EXACT_FP32 1
-/* Same arithmetic and results as flags = 0, but one wave per SIMD (4-wave workgroups): half of every register
- * file stays free so that kernels of another stream (the binary convolutions of the other batch in flight)
- * are co-resident with the stem instead of waiting for it.  Slower alone, faster in a pipeline.          */
-#define BNN_HIP_STEM_SHARE_CU 2
 /* Plain fp16 operands, one MFMA per product, fp32 accumulation (the "fp16 MFMA stem" of BASELINE config 5):
- * ~5e-4 relative error instead of ~3e-7, one third of the matrix work.  Opt-in; not with the two flags above. */
+ * ~5e-4 relative error instead of ~3e-7, one third of the matrix work.  Opt-in; not with EXACT_FP32.        */
 #define BNN_HIP_STEM_FP16 4
-/* Same arithmetic and results as flags = 0 with 16 waves per workgroup (four per SIMD, weights read from LDS). */
-#define BNN_HIP_STEM_WIDE 8
 int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w,
                                           const float* bn_scale, const float* bn_shift,
                                           int N, int H, int W, int flags,
                                           float* out_f32, uint64_t* P, uint64_t* M, void* stream);
+
+/* The real-valued head of the reference's ResNets in one kernel (bnn/models/resnet.py:160-164:
+ * avgpool -> flatten -> fc):  out[n,o] = bias[o] + sum_c w_t[c,o] * mean_hw x[n,c,hw].
+ * x: float32 [N,C,HW] (an NCHW tensor with HW = H*W), w_t: the Linear weight TRANSPOSED to [C,O]
+ * (so that a wavefront reads contiguous bytes; nn.Linear stores [O,C]), bias: [O] or NULL,
+ * out: float32 [N,O].  fp32 fmaf accumulation in index order; C*32 bytes of LDS (C <= 5120).       */
+int bnn_hip_avgpool_fc_f32(const float* x, int N, int C, int HW, const float* w_t, const float* bias,
+                           int O, float* out, void* stream);
 
 /* XNOR-Net weight binarisation.  w: float32 [O,C,KH,KW] contiguous.
  *   center        != 0: subtract the mean over C per (o,ky,kx) first  (ops.py:130-132)

@@ -156,6 +156,68 @@ def make_resnet18():
     np.savez_compressed(os.path.join(HERE, "resnet18.npz"), **blob)
 
 
+def _binary_inputs(net, x, batch=32):
+    """Forward in mini-batches, returning (logits, {layer name: per-image sign checksum}) where the
+    checksums are tests/golden/sighash.py of every BINARY convolution's input, in execution order."""
+    from tests.golden import sighash
+    names, hashes = [], {}
+    hooks = []
+    for name, mod in net.named_modules():
+        if isinstance(mod, bnn.layers.Conv2d) and isinstance(mod.activation_pre_process, BasicInputBinarizer):
+            def pre(m, inp, name=name):
+                if name not in hashes:
+                    names.append(name)
+                    hashes[name] = []
+                hashes[name].append(sighash.sign_hash_torch(inp[0]).numpy())
+            hooks.append(mod.register_forward_pre_hook(pre))
+    outs = []
+    with torch.no_grad():
+        for i in range(0, x.shape[0], batch):
+            outs.append(net(t(x[i:i + batch])).numpy())
+    for h in hooks:
+        h.remove()
+    return np.concatenate(outs), names, np.stack([np.concatenate(hashes[n]) for n in names], 1)
+
+
+def make_resnet18_b256():
+    """G4 at the size the headline metric is quoted on (BASELINE config 3): reference logits of 256
+    distinct 224x224 images + the discrete state (sign checksums of all 19 binary-conv inputs) per image.
+    Also measures how far the reference moves from ITSELF when only its convolution backend changes
+    (oneDNN vs ATen's native im2col+GEMM): the noise floor any other implementation is judged against."""
+    net = ref_resnet18()
+    net = bnn.prepare_binary_model(net, xnor_cfg(), custom_config_layers_name={"conv1": bnn.BConfig(),
+                                                                               "fc": bnn.BConfig()})
+    load_state(net, seed=1)
+    net.eval()
+    x = gen.normal(gen.seed_of("r18", "b256"), (256, 3, 224, 224))
+    y, names, h = _binary_inputs(net, x)
+    with torch.backends.mkldnn.flags(enabled=False):
+        y2, _, h2 = _binary_inputs(net, x)
+    y64, _, h64 = _binary_inputs(net.double(), x.astype(np.float64), batch=16)   # the same model evaluated in fp64
+    net.float()
+    y64 = y64.astype(np.float32)
+
+    def compare(ya, ha, yb, hb):
+        ok = np.all(np.abs(ya - yb) <= 1e-3 * np.abs(yb).max() + 1e-3 * np.abs(yb), 1)
+        flipped = np.any(ha != hb, 1)
+        first = [int(np.argmax(ha[i] != hb[i])) for i in np.nonzero(flipped)[0]]
+        return {"images": int(ya.shape[0]), "within_tol": int(ok.sum()), "images_with_a_sign_flip": int(flipped.sum()),
+                "max_abs_logit_dev": float(np.abs(ya - yb).max()),
+                "max_dev_without_flip": float(np.abs(ya - yb)[~flipped].max()) if (~flipped).any() else 0.0,
+                "first_diverging_layer_histogram": {names[k]: first.count(k) for k in sorted(set(first))}}
+    self_check = {
+        "max_abs_logit": float(np.abs(y).max()), "torch": torch.__version__,
+        "tolerance": "per image: |a - b| <= 1e-3*max|b| + 1e-3*|b| on all 1000 logits",
+        "ref_onednn_vs_ref_native_conv": compare(y2, h2, y, h),
+        "ref_fp32_vs_ref_fp64": compare(y, h, y64, h64),
+        "ref_native_conv_vs_ref_fp64": compare(y2, h2, y64, h64),
+    }
+    print(json.dumps(self_check, indent=1))
+    np.savez_compressed(os.path.join(HERE, "resnet18_b256.npz"), logits=y, sign_hash=h, logits_f64=y64,
+                        sign_hash_f64=h64, layers=np.array(names), self_check=np.array(json.dumps(self_check)))
+    print("resnet18_b256", y.shape, h.shape, names)
+
+
 def make_blocks():
     """G5: module-level outputs of the blocks that call the hot path (config 5 building blocks)."""
     blob = {}
@@ -208,5 +270,6 @@ if __name__ == "__main__":
     make_ref_test_layers()
     make_layers()
     make_resnet18()
+    make_resnet18_b256()
     make_blocks()
     make_convert()

@@ -1,0 +1,151 @@
+"""BASELINE config 3 at the size the headline metric is quoted on: binary ResNet-18, 224x224, batch 256.
+
+Parity against the REFERENCE's own forward on 256 distinct images (fixture tests/golden/resnet18_b256.npz,
+written by tests/golden/make_golden.py from /root/reference: fp32 logits, the same model evaluated in fp64,
+and a position-weighted checksum of the sign() result in front of each of the 19 binary convolutions).
+
+A binarised network is discontinuous: an activation within rounding distance of 0 in front of a sign()
+lands on either side depending on summation order.  The reference itself does that — the fixture records
+that switching only its convolution backend (oneDNN -> ATen native) flips a sign somewhere in 42 of these
+256 images and moves logits by up to 0.15, while wherever no sign flips the logits agree to 3e-6.  So the
+contract ("within 1e-3 of the reference forward") is tested in two parts:
+
+  (1) STRICT: every image whose 19 sign checksums all equal the reference's is within 1e-3 (in fact 1e-4),
+  (2) COUNTED: the number of images with a flipped sign is bounded by the measured value (deterministic
+      kernels), reported per path together with the first layer that diverges, and compared with the
+      reference's distance to its own fp64 evaluation.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bnn_amd as bnn
+from bnn_amd import inference
+from bnn_amd.inference import FusedResNet, PipelinedInference
+from bnn_amd.models import resnet18
+from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer
+from tests.golden import gen, sighash
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+# images (of 256) allowed to differ from the reference in at least one sign(): measured on MI355X
+# (profiles/r02_c3_b256_parity.json) + 2 of slack for driver/compiler changes of the fp32 stem
+MAX_FLIPPED = {"layerwise": 10, "fused": 10, "fused_exact_stem": 10}
+
+
+def _r18():
+    cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
+                      weight_pre_process=XNORWeightBinarizer)
+    net = bnn.prepare_binary_model(resnet18(), cfg, custom_config_layers_name={
+        "conv1": bnn.BConfig(), "fc": bnn.BConfig()})
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in gen.model_state(shapes, 1).items()})
+    return net.to(DEV).eval()
+
+
+@pytest.fixture(scope="module")
+def fixture():
+    g = np.load(os.path.join(HERE, "golden", "resnet18_b256.npz"))
+    return {k: g[k] for k in g.files}
+
+
+@pytest.fixture(scope="module")
+def images():
+    return torch.from_numpy(gen.normal(gen.seed_of("r18", "b256"), (256, 3, 224, 224))).to(DEV)
+
+
+def _run_layerwise(net, x, names):
+    hashes = {n: None for n in names}
+    hooks = []
+    mods = dict(net.named_modules())
+    for n in names:
+        def pre(m, inp, n=n):
+            hashes[n] = sighash.sign_hash_torch(inp[0])
+        hooks.append(mods[n].register_forward_pre_hook(pre))
+    with torch.no_grad():
+        y = net(x)
+    for h in hooks:
+        h.remove()
+    return y, torch.stack([hashes[n] for n in names], 1)
+
+
+def _run_fused(net, x, names, **kw):
+    fused = FusedResNet(net, **kw)
+    hashes = {}
+
+    def tap(name, act):
+        hashes[name] = sighash.sign_hash_planes(act.P, act.M, act.shape[1])
+    with inference.tap_binary_inputs(tap):
+        y = fused(x)
+    assert set(hashes) == set(names), sorted(set(names) ^ set(hashes))
+    return y, torch.stack([hashes[n] for n in names], 1)
+
+
+def _compare(y, h, ref, href, names):
+    tol = 1e-3 * np.abs(ref).max() + 1e-3 * np.abs(ref)
+    dev_ = np.abs(y - ref)
+    ok = np.all(dev_ <= tol, 1)
+    flipped = np.any(h != href, 1)
+    first = [int(np.argmax(h[i] != href[i])) for i in np.nonzero(flipped)[0]]
+    return {"images": int(len(ok)), "within_tol": int(ok.sum()), "images_with_a_sign_flip": int(flipped.sum()),
+            "max_abs_logit_dev": float(dev_.max()),
+            "max_dev_without_flip": float(dev_[~flipped].max()) if (~flipped).any() else 0.0,
+            "argmax_agree": int((y.argmax(1) == ref.argmax(1)).sum()),
+            "first_diverging_layer_histogram": {names[k]: first.count(k) for k in sorted(set(first))}}, ok, flipped
+
+
+@pytest.mark.parametrize("path", ["layerwise", "fused", "fused_exact_stem"])
+def test_c3_batch256_against_reference_forward(path, fixture, images):
+    names = [str(n) for n in fixture["layers"]]
+    net = _r18()
+    if path == "layerwise":
+        y, h = _run_layerwise(net, images, names)
+    else:
+        y, h = _run_fused(net, images, names, stem_exact_fp32=(path == "fused_exact_stem"))
+    y, h = y.cpu().numpy(), h.cpu().numpy()
+    ref, href = fixture["logits"], fixture["sign_hash"]
+    rep, ok, flipped = _compare(y, h, ref, href, names)
+    rep64, ok64, flipped64 = _compare(y, h, fixture["logits_f64"], fixture["sign_hash_f64"], names)
+    report = {"path": path, "vs_reference_fp32": rep, "vs_reference_evaluated_in_fp64": rep64,
+              "reference_self_check": json.loads(str(fixture["self_check"]))}
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, f"c3_b256_parity_{path}.json"), "w") as fh:
+            json.dump(report, fh, indent=1)
+    print(json.dumps({k: report[k] for k in ("path", "vs_reference_fp32", "vs_reference_evaluated_in_fp64")}))
+    # (1) same integers everywhere  =>  same logits up to fp32 rounding of the real-valued layers
+    assert ok[~flipped].all() and ok64[~flipped64].all()
+    assert rep["max_dev_without_flip"] <= 1e-4 * np.abs(ref).max()
+    # (2) how many images saw a sign() decided differently (the reference vs its own fp64 evaluation: 3)
+    assert rep["images_with_a_sign_flip"] <= MAX_FLIPPED[path], rep
+    assert rep64["images_with_a_sign_flip"] <= MAX_FLIPPED[path], rep64
+    assert rep["within_tol"] >= 256 - MAX_FLIPPED[path]
+
+
+def test_c3_batch256_properties(images):
+    """Size-independent properties of the benched configuration (fused executor, batch 256, 224x224):
+    images are independent (any sub-batch gives the same bits), graph replay == eager launches,
+    two batches in flight == one at a time."""
+    net = _r18()
+    fused = FusedResNet(net)
+    y = fused(images).clone()
+    assert y.shape == (256, 1000) and torch.isfinite(y).all()
+    for lo, hi in ((0, 8), (100, 116), (251, 256)):
+        assert torch.equal(fused(images[lo:hi].contiguous()), y[lo:hi])
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(3)).to(DEV)
+    assert torch.equal(fused(images[perm].contiguous()), y[perm])
+    fused.capture(images)
+    assert torch.equal(fused(images), y)
+    pipe = PipelinedInference(net, images, n_streams=2)
+    other = torch.roll(images, 1, 0)
+    with torch.cuda.stream(pipe.stream(1)):
+        pipe.input(1).copy_(other)
+    outs = [pipe.launch(i) for i in range(2)]
+    pipe.synchronize()
+    assert torch.equal(outs[0], y) and torch.equal(outs[1], torch.roll(y, 1, 0))

@@ -413,14 +413,72 @@ def test_runs_on_the_current_side_stream():
     assert torch.equal(out, ref)
 
 
-def test_half_precision_and_grad_mode_take_the_composition_path():
+def test_grad_mode_takes_the_training_variant_not_the_inference_path():
     layer, x = make_layer(LAYER_CASES_BY_NAME["c2_relu"])
     before = fastpath.stats()["conv2d"]
     y = layer(dev(x).requires_grad_(True))          # autograd recording
     y.sum().backward()
-    with torch.no_grad():
-        layer.half()(dev(x).half())                 # fp16 model: not the fp32 HIP path
     assert fastpath.stats()["conv2d"] == before
+
+
+@pytest.mark.parametrize("name", ["c2_relu", "c2_normal", "special_vals", "tail_c96", "tail_c16_1x1"])
+def test_fp16_pack_is_bit_exact_and_half_models_stay_on_the_hip_path(name):
+    """`.half()` models (SURVEY §8b "dtype fp32/fp16"): planes straight from the fp16 tensor — sign() is exact in
+    any precision, so they equal the oracle's planes of the widened tensor bit for bit — fp32 arithmetic inside,
+    one rounding to fp16 at the end; compared with the reference formulation run by torch in fp16."""
+    case = LAYER_CASES_BY_NAME[name]
+    layer, x = make_layer(case)
+    xh = dev(x).half()
+    act = hipops.pack_act(xh)
+    P, M = oracle.pack_act(xh.float().cpu().numpy())
+    assert np.array_equal(u64(act.P), P) and np.array_equal(u64(act.M), M)
+    layer = layer.half()
+    before = fastpath.stats()["conv2d"]
+    with torch.no_grad():
+        y = layer(xh)
+        assert fastpath.stats()["conv2d"] == before + 1 and y.dtype == torch.float16
+        # the reference's own op sequence in fp16 (torch composition on the GPU)
+        xs = layer.activation_pre_process(xh)
+        ref = layer.activation_post_process(
+            F.conv2d(xs, layer.weight_pre_process(layer.weight), layer.bias, layer.stride, layer.padding,
+                     layer.dilation), xh)
+    ok = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(y), ok)
+    # fp16 has 11 significand bits: one rounding of the output (5e-4) + alpha rounded to fp16 (5e-4)
+    assert torch.allclose(y[ok].float(), ref[ok].float(), rtol=4e-3, atol=4e-3 * float(ref[ok].float().abs().max()))
+
+
+def test_writes_through_dot_data_need_invalidate_and_training_never_trusts_the_cache():
+    """`p.data.clamp_()` / `p.data.copy_(ema)` do not bump the version counter the packed-weight cache is keyed
+    on: the inference path needs `fastpath.invalidate`, the training forward re-derives the bits every call."""
+    layer, x = make_layer(LAYER_CASES_BY_NAME["c2_relu"])
+    xd = dev(x)
+    with torch.no_grad():
+        y0 = layer(xd)
+        v = layer.weight._version
+        layer.weight.data.mul_(-1.0)                  # invisible to autograd's version counter
+        assert layer.weight._version == v
+        assert torch.equal(layer(xd), y0)             # stale: documented behaviour
+        assert fastpath.invalidate(layer) == 1
+        assert torch.equal(layer(xd), -y0)
+        layer.weight.data.mul_(-1.0)
+    y_tr = layer(xd.clone().requires_grad_(True))     # training forward: always from the current values
+    assert torch.equal(y_tr.detach(), y0)
+
+
+def test_zero_weights_first_seen_by_a_grad_mode_forward_are_honoured_by_inference():
+    """A pack made by the training path skips reading the zero-weight flag; an inference forward that finds it in
+    the cache must resolve the flag first (sign(0) == 0, never -1)."""
+    case = LAYER_CASES_BY_NAME["zero_weights"]
+    layer, x = make_layer(case)
+    xd = dev(x)
+    with pytest.warns(RuntimeWarning, match="exactly 0"):
+        layer(xd.clone().requires_grad_(True))        # grad mode: optimistic pack, cached
+        with torch.no_grad():
+            y = layer(xd)                             # same key: must not reuse the unmasked pack
+    ref, _ = oracle.binary_conv2d_int(x, case.tensors()[1], None, None, case.stride, case.pad, case.dilation,
+                                      case.center, case.compute_alpha)
+    assert np.array_equal(y.cpu().numpy(), ref)
 
 
 def test_packed_checkpoint_round_trip_on_device(tmp_path):

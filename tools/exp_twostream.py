@@ -24,7 +24,7 @@ streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
 engines = []
 for s in streams:
     with torch.cuda.stream(s):
-        engines.append(FusedResNet(net, stem_share_cu=bool(os.environ.get('LEAN'))).capture(x))
+        engines.append(FusedResNet(net).capture(x))
 torch.cuda.synchronize()
 def run(n, k):
     for i in range(n):
