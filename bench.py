@@ -3,20 +3,25 @@
 with the int-ALU roofline of the dominant kernel (3x3 XNOR-popcount conv, BASELINE config 2) and a
 CPU baseline of the reference's op sequence beside it.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                                  # N = 1, config c3 (the headline)
+    python bench.py --gpus 8                         # spawns 8 ranks itself (torch.distributed.run, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-           --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 5
+           --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 5       # what the driver does
+    python bench.py --config c2                      # the single 3x3 layer, fp32 in -> fp32 out
+    python bench.py --config c5                      # ResNet(HBlock,[3,4,6,3]) + fp16 MFMA stem, 128 img/GPU
 
-One "step" = one forward pass of the whole network over one synthetic batch (256 images per GPU,
-resident in HBM before the timed region).  Weak scaling: every rank processes its own 256 images
-and the [256,1000] logits are all-gathered over RCCL at the end of every step.
-Prints ONE JSON line on rank 0.
+One "step" = one pass of the hot path over one synthetic batch per GPU, inputs resident in HBM before
+the timed region.  Weak scaling: every rank processes its own batch; for the networks the
+[B,1000] logits of all ranks are all-gathered over RCCL at the end of every step (the only exchange
+the path has).  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,22 +30,64 @@ for _p in (ROOT, os.path.join(ROOT, "binary-networks-pytorch_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+
+def self_launch(gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BNN_BENCH_LAUNCHER="self", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+        "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=("c3", "c2", "c5"), default="c3",
+                    help="BASELINE.json config: c3 binary ResNet-18 224x224 batch 256/GPU (headline; c4 is the same "
+                         "at --gpus 8), c2 the single 3x3 128->128 56x56 layer, c5 ResNet(HBlock,[3,4,6,3]) with the "
+                         "fp16 MFMA stem at 128 images/GPU")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: 256; c5: 128)")
+    ap.add_argument("--engine", choices=("graph", "fused", "layerwise"), default="graph",
+                    help="graph: fused executor replayed as a HIP graph (default); fused: same, eager "
+                         "launches; layerwise: the drop-in per-layer path (pack -> conv -> torch BN/ReLU)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="graph engine: batches in flight per GPU (graph-captured executors on their own HIP "
+                         "streams, replayed round-robin; 1 = strictly one batch at a time)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the exact-fp32-stem and one-batch-at-a-time lines")
+    return ap.parse_args()
+
+
+ARGS = parse_args()
+if "WORLD_SIZE" not in os.environ and ARGS.gpus > 1:
+    sys.exit(self_launch(ARGS.gpus))
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
-import torch.nn as nn  # noqa: E402
 
 import bnn_amd as bnn  # noqa: E402
-from bnn_amd import fastpath, hipops, native  # noqa: E402
+from bnn_amd import hipops, native  # noqa: E402
 from bnn_amd.inference import FusedResNet, PipelinedInference  # noqa: E402
-from bnn_amd.models import resnet18  # noqa: E402
+from bnn_amd.models import HBlock, ResNet, resnet18  # noqa: E402
 from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer  # noqa: E402
 from bnn_amd.parallel import ShardedInference  # noqa: E402
 from tests.golden import gen  # noqa: E402  (portable synthetic-data generator, no reference code)
 
 # ResNet-18 @224: algorithmic int lane-ops per image over all binary convs (SURVEY §A.2 / BASELINE.md §4)
 R18_LANE_OPS_PER_IMG = 105.97e6
-R18_BINARY_MAC_PER_IMG = 1.6955e9
+
+DTYPE = ("int1 xnor-popcount on the integer ALU (19 binary convs: two bit planes, v_bitop3_b32 + v_bcnt_u32_b32, "
+         "int32 accumulation) + fp32 epilogues (alpha, BN, residual) + stem conv with fp32 operands split into "
+         "fp16 hi+lo on v_mfma_f32_16x16x32_f16, fp32 accumulation (3e-7 relative; not IEEE fp32 — the "
+         "exact-fp32 stem is timed beside it) + fp32 avgpool/fc")
 
 
 def xnor_cfg():
@@ -49,10 +96,9 @@ def xnor_cfg():
                        weight_pre_process=XNORWeightBinarizer)
 
 
-def build_model(device):
+def build_model(device, ctor=resnet18):
     """examples/cifar10.py:61-71 model: resnet18, XNOR recipe, conv1 and fc real-valued."""
-    net = resnet18()
-    net = bnn.prepare_binary_model(net, xnor_cfg(), custom_config_layers_name={
+    net = bnn.prepare_binary_model(ctor(), xnor_cfg(), custom_config_layers_name={
         "conv1": bnn.BConfig(), "fc": bnn.BConfig()})
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     net.load_state_dict({k: torch.from_numpy(v) for k, v in gen.model_state(shapes, 1).items()})
@@ -74,6 +120,18 @@ def simd32_peak(info) -> float:
     return info["compute_units"] * 4 * 32 * info["clock_khz"] * 1e3
 
 
+def _event_time(fn, iters, device):
+    """Average seconds per call of ``fn`` over ``iters`` calls, HIP events on the launch stream."""
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(device)
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
 def conv_c2_roofline(device, info, batch=256, iters=20, act_kind="relu", nonneg=False):
     """BASELINE config 2: 3x3 Conv2d 128->128, 56x56, batch 256 — the graded kernel.
     Times `iters` launches of bnn_hip_bconv2d with events on the launch stream.
@@ -86,28 +144,18 @@ def conv_c2_roofline(device, info, batch=256, iters=20, act_kind="relu", nonneg=
     act = hipops.pack_act(x)
     act.nonneg = bool(nonneg)
     for _ in range(3):
-        out = hipops.bconv2d(act, pw, stride=1, padding=1)
-    torch.cuda.synchronize(device)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        out = hipops.bconv2d(act, pw, stride=1, padding=1)
-    e1.record()
-    torch.cuda.synchronize(device)
-    t_conv = e0.elapsed_time(e1) * 1e-3 / iters
-    # pack kernel (HBM-bound) timed the same way
-    e0.record()
-    for _ in range(iters):
-        hipops.pack_act(x)
-    e1.record()
-    torch.cuda.synchronize(device)
-    t_pack = e0.elapsed_time(e1) * 1e-3 / iters
+        hipops.bconv2d(act, pw, stride=1, padding=1)
+    t_conv = _event_time(lambda: hipops.bconv2d(act, pw, stride=1, padding=1), iters, device)
+    t_pack = _event_time(lambda: hipops.pack_act(x), iters, device)        # HBM-bound
+
+    def both():
+        hipops.bconv2d(hipops.pack_act(x), pw, stride=1, padding=1)
+    t_both = _event_time(both, iters, device)                              # the layer as config 2 states it
     K = C * 9
     lane_ops = 2.0 * ((K + 31) // 32) * N * O * H * W           # algorithmic: xor + popcount per 32 MACs
     peak = int_alu_peak(info)
     in_bytes = N * H * W * (2 * 2 * 8)                           # two planes x 2 uint64 words per pixel
     out_bytes = N * O * H * W * 4
-    del out
     traffic, traffic_note = pmc_traffic()
     return {
         "bound": "int_alu", "kernel": "bconv_sgpr_kernel<3,3,4>", "workload": "conv3x3 128->128 56x56 b256",
@@ -115,7 +163,9 @@ def conv_c2_roofline(device, info, batch=256, iters=20, act_kind="relu", nonneg=
         "frac": lane_ops / t_conv / peak, "traffic": traffic, "traffic_note": traffic_note,
         "algorithmic_bytes": in_bytes + out_bytes + O * K // 8,
         "avg_kernel_us": t_conv * 1e6, "images_per_s_kernel": N / t_conv,
-        "images_per_s_fp32_in_out": N / (t_conv + t_pack),
+        "fp32_in_fp32_out": {"us": t_both * 1e6, "images_per_s": N / t_both,
+                             "frac": lane_ops / t_both / peak,
+                             "note": "pack_act + conv back to back: config 2 as BASELINE.json words it"},
         "hbm": {"conv_GBps": (in_bytes + out_bytes) / t_conv / 1e9,
                 "pack_us": t_pack * 1e6, "pack_GBps": (N * C * H * W * 4 + in_bytes) / t_pack / 1e9,
                 "peak_GBps": 8000.0},
@@ -128,54 +178,69 @@ def conv_c2_roofline(device, info, batch=256, iters=20, act_kind="relu", nonneg=
 
 def pmc_traffic():
     """HBM bytes per launch of the graded kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_c2_pmc_counters.json, collected by tools/gpu_profile.sh with separate --pmc runs).
+    (profiles/rNN_c2_pmc_counters.json, collected by tools/gpu_profile.sh with separate --pmc runs).
     FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
     (checked on this box: pack_act's 411 MB float4 stream reads as 205 MB)."""
-    path = os.path.join(ROOT, "profiles", "r01_c2_pmc_counters.json")
-    try:
-        with open(path) as fh:
-            pmc = json.load(fh)
-        k = next(v for name, v in pmc.items() if "bconv_sgpr_kernel" in name)
-        return (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024, \
-            "2*FETCH_SIZE + WRITE_SIZE from profiles/r01_c2_pmc_counters.json (same kernel, same shape)"
-    except (OSError, StopIteration, KeyError, ValueError):
-        return None, "no PMC summary committed"
+    for name in ("r02_c2_pmc_counters.json", "r01_c2_pmc_counters.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                pmc = json.load(fh)
+            k = next(v for kn, v in pmc.items() if "bconv_sgpr_kernel" in kn)
+            return (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024, \
+                f"2*FETCH_SIZE + WRITE_SIZE from profiles/{name} (same kernel, same shape)"
+        except (OSError, StopIteration, KeyError, ValueError):
+            continue
+    return None, "no PMC summary committed"
 
 
-def cpu_baseline(sample_batch=64, iters=6):
-    """Reference op sequence (torch CPU: sign -> sign(W)*alpha -> conv2d) on the host cores."""
+def cpu_baseline():
+    """The reference's op sequence (torch CPU: sign -> sign(W)*alpha -> conv2d; oracle/torch_ref.py, pinned to
+    the reference's fixtures by tests/test_oracle_cpu.py) on the host cores: C3 (the metric's workload) as the
+    headline, C1 and C2 of SURVEY §8(d) beside it.  Bounded: ~15 s in total."""
     from oracle import torch_ref  # checker / baseline only
     shapes = torch_ref.resnet18_state_shapes()
     sd = {k: torch.from_numpy(v) for k, v in gen.model_state(shapes, 1).items()}
-    x = torch.from_numpy(gen.normal(3, (sample_batch, 3, 224, 224)))
     cores = torch.get_num_threads()
-    with torch.no_grad():
-        torch_ref.resnet18_forward(sd, x[:4])  # warm-up
-        t0 = time.perf_counter()
+
+    def timed(fn, iters):
+        fn()  # warm-up
+        ts = []
         for _ in range(iters):
-            torch_ref.resnet18_forward(sd, x)
-        dt = time.perf_counter() - t0
-    return {"value": sample_batch * iters / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} x batch {sample_batch} of the same ResNet-18 224x224 forward "
-                      f"(oracle/torch_ref.py, torch {torch.__version__} CPU, fp32, {dt:.1f} s)"}
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), float(sum(ts))
+    with torch.no_grad():
+        x3 = torch.from_numpy(gen.normal(3, (64, 3, 224, 224)))
+        t3, tot3 = timed(lambda: torch_ref.resnet18_forward(sd, x3), 3)
+        x1 = torch.from_numpy(gen.normal(0, (32, 3, 32, 32)))
+        t1, _ = timed(lambda: torch_ref.resnet18_forward(sd, x1), 5)
+        x2 = torch.from_numpy(gen.activation("relu", 7, (8, 128, 56, 56))).repeat(32, 1, 1, 1)
+        w2 = torch.from_numpy(gen.conv_weight("kaiming", 8, (128, 128, 3, 3)))
+        t2, _ = timed(lambda: torch_ref.binary_conv2d(x2, w2, None, 1, 1), 3)
+    return {"value": 64 / t3, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"median of 3 x batch 64 of the same ResNet-18 224x224 forward (oracle/torch_ref.py, "
+                      f"torch {torch.__version__} CPU, fp32, {tot3:.1f} s)",
+            "c1_resnet18_32x32_b32": {"value": 32 / t1, "unit": "images/s", "s_per_batch": t1},
+            "c2_conv3x3_128_56x56_b256": {"value": 256 / t2, "unit": "images/s", "s_per_batch": t2}}
+
+
+def dist_info(world):
+    rec = {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
+           "initialized": bool(dist.is_initialized()),
+           "launcher": os.environ.get("BNN_BENCH_LAUNCHER", "torchrun" if "WORLD_SIZE" in os.environ else "none")}
+    if dist.is_initialized():
+        rec["backend"] = dist.get_backend()
+        try:
+            rec["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001 - informational only
+            rec["rccl_version"] = None
+    assert rec["world_size"] == world
+    return rec
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
-    ap.add_argument("--engine", choices=("graph", "fused", "layerwise"), default="graph",
-                    help="graph: fused executor replayed as a HIP graph (default); fused: same, eager "
-                         "launches; layerwise: the drop-in per-layer path (pack -> conv -> torch BN/ReLU)")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="graph engine: batches in flight per GPU (graph-captured executors on their own HIP "
-                         "streams, replayed round-robin; 1 = strictly one batch at a time)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
-
+    args = ARGS
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -183,101 +248,154 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the GPU path has no CPU stand-in)")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:     # under a launcher — also at world size 1, so that N = 1 runs the same code
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     native.require()
     info = native.device_info(local_rank)
-    net = build_model(device)
-    B = args.batch
-    x = torch.from_numpy(gen.normal(100 + rank, (8, 3, 224, 224))).to(device).repeat(B // 8, 1, 1, 1)
-    x = x + 0.01 * torch.arange(B, device=device, dtype=torch.float32).view(B, 1, 1, 1)  # distinct images
-    if args.engine == "layerwise":
-        engine = net
-    else:
-        engine = FusedResNet(net)
-    n_streams = max(1, args.streams) if args.engine == "graph" else 1
-    if args.engine == "graph":
-        # every stream owns a graph-captured executor whose static input buffer holds its batch (filled by
-        # capture): no per-step device-to-device copy of the 154 MB input, and `n_streams` batches in flight
-        pipe = PipelinedInference(net, x, n_streams=n_streams)
-        models = [ShardedInference(e) for e in pipe.engines]
-
-        def step(i, k_streams=n_streams):
-            k = i % k_streams
-            with torch.cuda.stream(pipe.streams[k]):
-                return models[k].forward_even(pipe.engines[k].static_input)
-    else:
-        model = ShardedInference(engine)
-
-        def step(i, k_streams=1):
-            return model.forward_even(x)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    def timed(steps, warmup, k_streams):
+    def timed(step, steps, warmup):
         for i in range(warmup):
-            out = step(i, k_streams)
+            out = step(i)
         torch.cuda.synchronize(device)
         barrier()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         for i in range(steps):
-            out = step(warmup + i, k_streams)
+            out = step(warmup + i)
         torch.cuda.synchronize(device)
         barrier()
         torch.cuda.synchronize(device)
-        return time.perf_counter() - t0, out
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, out
 
-    launches0 = native.launch_count()
-    with torch.no_grad():
-        dt, logits = timed(args.steps, args.warmup, n_streams)
-        dt1 = timed(args.steps, 2, 1)[0] if n_streams > 1 else None   # same steps, one batch at a time
-    assert logits.shape == (world * B, 1000) and torch.isfinite(logits).all()
-    hip_launches = native.launch_count() - launches0
-    if world > 1:
-        tt = torch.tensor([dt, dt1 or 0.0], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, dt1 = float(tt[0].item()), (float(tt[1].item()) if dt1 is not None else None)
-
+    if args.config == "c2":
+        rec = bench_c2(args, world, rank, device, info, timed)
+    else:
+        rec = bench_net(args, world, rank, device, info, timed)
     if rank == 0:
-        value = world * B * args.steps / dt
-        rec = {
-            "metric": "images/sec binary ResNet-18 224x224 forward", "value": value, "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int1 xnor-popcount (binary convs) + fp32 (stem, BN, fc)",
-            "data": "synthetic",
-            "config": {"workload": "binary ResNet-18 (bnn.models resnet18, XNOR recipe of examples/cifar10.py, "
-                                   "conv1+fc real-valued) 224x224 full forward, batch 256 per GPU",
-                       "engine": args.engine, "batches_in_flight": n_streams,
-                       "global_batch": world * B, "parallelism": f"dp{world} (batch shards, RCCL all-gather of logits)",
-                       "hip_kernel_launches_per_step": hip_launches // max(args.steps + args.warmup, 1)},
-            "device": {k: info[k] for k in ("name", "arch", "compute_units", "clock_khz")},
-            "net_int_alu_frac": value / world * R18_LANE_OPS_PER_IMG / int_alu_peak(info),
-        }
-        if dt1 is not None:
-            rec["one_batch_at_a_time"] = {"value": world * B * args.steps / dt1, "ms_per_step": dt1 / args.steps * 1e3}
-        if not args.no_roofline:
-            rec["roofline"] = conv_c2_roofline(device, info, act_kind="relu")
-            rec["roofline_normal_input"] = {k: v for k, v in conv_c2_roofline(device, info, act_kind="normal").items()
-                                            if k in ("achieved", "frac", "avg_kernel_us")}
-            rec["roofline_relu_input_nonneg_kernel"] = {
-                k: v for k, v in conv_c2_roofline(device, info, act_kind="relu", nonneg=True).items()
-                if k in ("achieved", "frac", "avg_kernel_us")}
-            rec["int_alu_probe_Tlane_ops"] = {
-                name: round(hipops.probe_int_alu(4096, device, mode)["lane_ops_per_s"] / 1e12, 2)
-                for mode, name in hipops.PROBE_MODES.items()}
+        rec["dist"] = dist_info(world)
+        rec["device"] = {k: info[k] for k in ("name", "arch", "compute_units", "clock_khz")}
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec), flush=True)
     barrier()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def bench_c2(args, world, rank, device, info, timed):
+    """BASELINE config 2 as a bench line: value = the fp32-in -> fp32-out layer (pack_act + conv);
+    replicas only (a single layer has nothing to exchange)."""
+    N, C, H, W, O = args.batch or 256, 128, 56, 56, 128
+    x = torch.from_numpy(gen.activation("relu", 7, (8, C, H, W))).to(device).repeat(N // 8, 1, 1, 1)
+    pw = hipops.pack_weight(torch.from_numpy(gen.conv_weight("kaiming", 8, (O, C, 3, 3))).to(device))
+
+    def step(i):
+        return hipops.bconv2d(hipops.pack_act(x), pw, stride=1, padding=1)
+    dt, out = timed(step, args.steps, args.warmup)
+    assert out.shape == (N, O, H, W)
+    roof = None if args.no_roofline else conv_c2_roofline(device, info, batch=N, act_kind="relu")
+    lane_ops = 2.0 * ((C * 9 + 31) // 32) * N * O * H * W
+    rec = {"metric": "images/sec single 3x3 binary Conv2d 128->128 56x56 (fp32 NCHW in -> fp32 NCHW out)",
+           "value": world * N * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "int1 xnor-popcount (int32 accumulate) + fp32 alpha epilogue",
+           "data": "synthetic",
+           "config": {"workload": f"BASELINE config 2: Conv2d(128,128,3,padding=1) + XNOR recipe, x [{N},128,56,56] "
+                                  "relu(N(0,1)), pack_act + bconv2d per step", "parallelism": f"{world} replicas"},
+           "layer_int_alu_frac": lane_ops * args.steps / dt / int_alu_peak(info)}
+    if roof is not None:
+        rec["roofline"] = roof
+        rec["packed_input_only"] = {"images_per_s": roof["images_per_s_kernel"], "us": roof["avg_kernel_us"],
+                                    "frac": roof["frac"]}
+    return rec
+
+
+def bench_net(args, world, rank, device, info, timed):
+    c5 = args.config == "c5"
+    B = args.batch or (128 if c5 else 256)
+    net = build_model(device, (lambda: ResNet(HBlock, [3, 4, 6, 3])) if c5 else resnet18)
+    fused_kw = {"stem_fp16": True} if c5 else {}
+    x = torch.from_numpy(gen.normal(100 + rank, (8, 3, 224, 224))).to(device).repeat(B // 8, 1, 1, 1)
+    x = x + 0.01 * torch.arange(B, device=device, dtype=torch.float32).view(B, 1, 1, 1)  # distinct images
+    n_streams = max(1, args.streams) if args.engine == "graph" else 1
+
+    def make_step(**kw):
+        if args.engine == "graph":
+            # every stream owns a graph-captured executor whose static input buffer holds its batch (filled by
+            # capture): no per-step device-to-device copy of the 154 MB input, and `n_streams` batches in flight
+            pipe = PipelinedInference(net, x, n_streams=n_streams, **kw)
+            models = [ShardedInference(e) for e in pipe.engines]
+
+            def step(i, k_streams=n_streams):
+                k = i % k_streams
+                with torch.cuda.stream(pipe.streams[k]):
+                    return models[k].forward_even(pipe.engines[k].static_input)
+            return step
+        model = ShardedInference(net if args.engine == "layerwise" else FusedResNet(net, **kw))
+        return lambda i, k_streams=1: model.forward_even(x)
+
+    step = make_step(**fused_kw)
+    with torch.no_grad():
+        dt, logits = timed(step, args.steps, args.warmup)
+        assert logits.shape == (world * B, 1000) and bool(torch.isfinite(logits).all())
+        extras = {}
+        if not args.no_extras and args.engine == "graph":
+            if n_streams > 1:   # same steps, strictly one batch at a time
+                dt1, _ = timed(lambda i: step(i, 1), args.steps, 2)
+                extras["one_batch_at_a_time"] = {"value": world * B * args.steps / dt1,
+                                                 "ms_per_step": dt1 / args.steps * 1e3}
+            if not c5:          # the same network with the stem in exact fp32 arithmetic (v_mfma_f32_16x16x4_f32)
+                step_x = make_step(stem_exact_fp32=True)
+                dtx, lx = timed(step_x, args.steps, args.warmup)
+                extras["exact_fp32_stem"] = {
+                    "value": world * B * args.steps / dtx, "ms_per_step": dtx / args.steps * 1e3,
+                    "max_abs_logit_diff_vs_default": float((lx - logits).abs().max()),
+                    "note": "stem as a k-ordered fp32 fmaf chain on v_mfma_f32_16x16x4_f32 (bit-for-bit IEEE fp32)"}
+    if rank != 0:
+        return None
+    value = world * B * args.steps / dt
+    name = "ResNet(HBlock,[3,4,6,3]) (BASELINE config 5: build-defined, the reference cannot construct it)" if c5 \
+        else "binary ResNet-18 (bnn.models resnet18, XNOR recipe of examples/cifar10.py, conv1+fc real-valued)"
+    rec = {
+        "metric": "images/sec binary ResNet-18 224x224 forward" if not c5 else
+                  "images/sec binary hierarchical-block ResNet-[3,4,6,3] 224x224 forward",
+        "value": value, "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": DTYPE if not c5 else DTYPE.replace("fp32 operands split into fp16 hi+lo", "plain fp16 operands (BNN_HIP_STEM_FP16)"),
+        "data": "synthetic",
+        "config": {"workload": f"{name} 224x224 full forward, batch {B} per GPU",
+                   "engine": args.engine, "batches_in_flight": n_streams,
+                   "global_batch": world * B, "parallelism": f"dp{world} (batch shards, RCCL all-gather of logits)"},
+    }
+    rec.update(extras)
+    if not c5:
+        rec["net_int_alu_frac"] = value / world * R18_LANE_OPS_PER_IMG / int_alu_peak(info)
+    if not args.no_roofline:
+        rec["roofline"] = conv_c2_roofline(device, info, act_kind="relu")
+        rec["roofline_normal_input"] = {k: v for k, v in conv_c2_roofline(device, info, act_kind="normal").items()
+                                        if k in ("achieved", "frac", "avg_kernel_us")}
+        rec["roofline_relu_input_nonneg_kernel"] = {
+            k: v for k, v in conv_c2_roofline(device, info, act_kind="relu", nonneg=True).items()
+            if k in ("achieved", "frac", "avg_kernel_us")}
+        rec["int_alu_probe_Tlane_ops"] = {
+            name: round(hipops.probe_int_alu(4096, device, mode)["lane_ops_per_s"] / 1e12, 2)
+            for mode, name in hipops.PROBE_MODES.items()}
+    return rec
 
 
 if __name__ == "__main__":

@@ -345,8 +345,6 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
     lib = native.require()
     d = _desc(a.shape, w.shape, stride, padding, dilation, _flags(w, force_generic, weights, a))
     ho, wo = conv_out_hw(d.H, d.W, d.KH, d.KW, stride, padding, dilation)
-    if d.N * max(d.O * ho * wo, d.H * d.W) > _MAX_ELEMS:
-        raise native.NativeError("bnn_amd: bconv2d_fused: split the batch (tensor > 2^31-1 elements)")
     dev = a.P.device
     bias = _per_channel(bias, d.O, "bias")
     post_scale = _per_channel(post_scale, d.O, "post_scale")
@@ -363,8 +361,6 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
             raise native.NativeError("bnn_amd: `out` must be a contiguous fp32 [N, C_total, Ho, Wo] tensor "
                                      "with room for O channels at out_c_offset")
         c_total = out.shape[1]
-        if d.N * c_total * ho * wo > _MAX_ELEMS:
-            raise native.NativeError("bnn_amd: bconv2d_fused: split the batch (tensor > 2^31-1 elements)")
     if residual is not None:
         residual = _require_cuda_f32(residual, "residual")
         if tuple(residual.shape) != (d.N, c_total, ho, wo):
@@ -375,15 +371,24 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
         y = out if out is not None else (
             torch.empty((d.N, d.O, ho, wo), dtype=torch.float32, device=dev) if out_f32 else None)
         pk = empty_packed(d.N, d.O, ho, wo, dev) if out_packed else None
-        e = native.Epilogue(w.alpha.data_ptr(), _ptr(bias), _ptr(post_scale), _ptr(bn_scale),
-                            _ptr(bn_shift), _ptr(residual), _ptr(prelu), int(bool(relu)), eflags,
-                            _ptr(y), None if pk is None else pk.P.data_ptr(),
-                            None if pk is None else pk.M.data_ptr(), _ptr(pack_scale), _ptr(pack_shift),
-                            out_c_offset if out is not None else 0, c_total if out is not None else 0)
-        native.check(lib.bnn_hip_bconv2d_fused(ctypes.byref(d), a.P.data_ptr(), a.M.data_ptr(),
-                                               w.wbits.data_ptr(), w.wnz.data_ptr(),
-                                               ctypes.byref(e), _stream(dev)),
-                     "bnn_hip_bconv2d_fused")
+        # one launch addresses < 2^31 elements: split the batch when a tensor is larger (like bconv2d)
+        per_img = max(c_total * ho * wo, d.H * d.W, 1)
+        step = max(1, min(d.N, _MAX_ELEMS // per_img))
+        for n0 in range(0, d.N, step):
+            n1 = min(d.N, n0 + step)
+            dd = native.ConvDesc.from_buffer_copy(d)
+            dd.N = n1 - n0
+            e = native.Epilogue(w.alpha.data_ptr(), _ptr(bias), _ptr(post_scale), _ptr(bn_scale),
+                                _ptr(bn_shift), None if residual is None else residual[n0:n1].data_ptr(),
+                                _ptr(prelu), int(bool(relu)), eflags,
+                                None if y is None else y[n0:n1].data_ptr(),
+                                None if pk is None else pk.P[n0:n1].data_ptr(),
+                                None if pk is None else pk.M[n0:n1].data_ptr(), _ptr(pack_scale), _ptr(pack_shift),
+                                out_c_offset if out is not None else 0, c_total if out is not None else 0)
+            native.check(lib.bnn_hip_bconv2d_fused(ctypes.byref(dd), a.P[n0:n1].data_ptr(), a.M[n0:n1].data_ptr(),
+                                                   w.wbits.data_ptr(), w.wnz.data_ptr(),
+                                                   ctypes.byref(e), _stream(dev)),
+                         "bnn_hip_bconv2d_fused")
     if pk is not None:  # mirrors the kernel's rule for leaving the M plane at zero
         late = residual is not None and residual_after_act
         pk.nonneg = bool(pack_relu) or (bool(relu) and prelu is None and pack_scale is None

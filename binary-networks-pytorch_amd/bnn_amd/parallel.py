@@ -32,10 +32,14 @@ def shard_batch(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
 class ShardedInference(nn.Module):
     """Wraps a (replicated) model: ``forward(local_batch)`` returns the logits of ALL ranks."""
 
-    def __init__(self, model: nn.Module, group: Optional[dist.ProcessGroup] = None) -> None:
+    def __init__(self, model: nn.Module, group: Optional[dist.ProcessGroup] = None,
+                 force_collective: bool = False) -> None:
         super().__init__()
         self.model = model
         self.group = group
+        # issue the all-gather even in a one-rank group (tests: the RCCL call, its stream ordering and its
+        # behaviour next to graph replays are then exercised on a single GPU)
+        self.force_collective = force_collective
 
     @torch.no_grad()
     def forward(self, x_local: torch.Tensor) -> torch.Tensor:
@@ -64,7 +68,8 @@ class ShardedInference(nn.Module):
     def forward_even(self, x_local: torch.Tensor) -> torch.Tensor:
         """Fast path when every rank holds the same number of images: exactly one collective."""
         y = self.model(x_local).contiguous()
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or \
+                (dist.get_world_size(self.group) == 1 and not self.force_collective):
             return y
         out = y.new_empty((dist.get_world_size(self.group) * y.shape[0],) + y.shape[1:])
         dist.all_gather_into_tensor(out, y, group=self.group)

@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 
 import oracle
-from bnn_amd import hipops
+from bnn_amd import hipops, native
 from tests.golden import gen
 from tests.golden.cases import LAYER_CASES, LAYER_CASES_BY_NAME, LayerCase
 
@@ -448,3 +448,35 @@ def test_fused_resnet_with_and_without_mfma_stem_agree():
     assert a._stem_mfma and not b._stem_mfma
     ya, yb = a(x), b(x)
     assert torch.allclose(ya, yb, rtol=1e-3, atol=1e-3 * float(yb.abs().max()))
+
+
+@pytest.mark.parametrize("shape,O", [((256, 512, 7, 7), 1000), ((3, 512, 7, 7), 1000), ((9, 70, 3, 5), 13),
+                                     ((1, 2048, 7, 7), 1000), ((17, 64, 1, 1), 300)])
+def test_head_kernel_matches_fp64_avgpool_fc(shape, O):
+    """bnn_hip_avgpool_fc_f32 (avgpool -> flatten -> fc of bnn/models/resnet.py:160-164 in one kernel) against the
+    same computation in fp64: fp32 accumulation over C terms -> 2e-6 of the largest logit."""
+    N, C, H, W = shape
+    x = dev(np.maximum(gen.normal(gen.seed_of("head", shape), shape), 0))
+    w = dev(gen.conv_weight("default", 5, (O, C)))
+    b = dev((0.1 * gen.normal(6, (O,))).astype(np.float32))
+    y = hipops.avgpool_fc(x, w.t().contiguous(), b)
+    ref = (x.double().mean((2, 3)) @ w.double().t() + b.double())
+    assert y.shape == (N, O)
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    y2 = hipops.avgpool_fc(x, w.t().contiguous(), None)
+    assert torch.allclose(y2.double(), ref - b.double(), rtol=0, atol=2e-6 * float(ref.abs().max()))
+    lib_y = F.linear(torch.flatten(F.adaptive_avg_pool2d(x, 1), 1), w, b)          # what the reference runs
+    assert torch.allclose(y, lib_y, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+
+
+def test_fused_executor_uses_the_head_kernel_and_no_library_gemm():
+    net = _r18()
+    fused = FusedResNet(net)
+    assert fused._head is not None and fused._head[0].shape == (512, 1000)
+    x = dev(gen.normal(31, (4, 3, 64, 64)))
+    before = native.launch_count()
+    y = fused(x)
+    # stem + 16 convs + 3 shortcut convs + 3 avgpool-packs + head
+    assert native.launch_count() - before == 1 + 16 + 3 + 3 + 1
+    with torch.no_grad():
+        assert torch.allclose(y, net(x), rtol=1e-3, atol=1e-3 * float(y.abs().max()))

@@ -400,6 +400,61 @@ def test_batch_splitting_path_matches_single_launch(monkeypatch):
     assert torch.equal(hipops.bconv2d(act, pw, raw_dot=True), hipops.bconv2d(act, pw, raw_dot=True))
 
 
+def test_fused_batch_splitting_matches_single_launch(monkeypatch):
+    """bconv2d_fused splits the batch like bconv2d when a tensor exceeds one launch's 2^31-element addressing."""
+    case = LAYER_CASES_BY_NAME["l2_ds_1x1"]
+    x, w, _, _ = case.tensors()
+    act, pw = hipops.pack_act(dev(np.concatenate([x] * 4))), hipops.pack_weight(dev(w))
+    n, o, hw = 8, case.O, 14
+    res = dev(gen.normal(77, (n, o, hw, hw)))
+    a_, b_ = dev((0.5 + gen.uniform(1, (o,))).astype(np.float32)), dev((0.3 * gen.normal(2, (o,))).astype(np.float32))
+    kw = dict(bn_scale=a_, bn_shift=b_, residual=res, relu=True, out_f32=True, out_packed=True)
+    y0, p0 = hipops.bconv2d_fused(act, pw, **kw)
+    monkeypatch.setattr(hipops, "_MAX_ELEMS", 3 * o * hw * hw)       # forces launches of <= 3 images
+    y1, p1 = hipops.bconv2d_fused(act, pw, **kw)
+    assert torch.equal(y0, y1) and torch.equal(p0.P, p1.P) and torch.equal(p0.M, p1.M) and p0.nonneg == p1.nonneg
+    big = torch.zeros((n, 2 * o, hw, hw), device=DEV)
+    hipops.bconv2d_fused(act, pw, bn_scale=a_, bn_shift=b_, out=big, out_c_offset=o, out_f32=True)
+    monkeypatch.setattr(hipops, "_MAX_ELEMS", (1 << 31) - 1)
+    ref = torch.zeros_like(big)
+    hipops.bconv2d_fused(act, pw, bn_scale=a_, bn_shift=b_, out=ref, out_c_offset=o, out_f32=True)
+    assert torch.equal(big, ref)
+
+
+ZERO_W_SHAPES = [  # (N, C, H, W, O, k, stride, pad): single-chunk 3x3, both chunk widths, multi-chunk, 1x1 of every cwc
+    (2, 64, 9, 9, 40, 3, 1, 1), (2, 128, 8, 8, 32, 3, 2, 1), (1, 256, 7, 7, 64, 3, 1, 1), (1, 96, 6, 5, 33, 3, 1, 0),
+    (2, 64, 7, 7, 32, 1, 1, 0), (2, 128, 5, 5, 70, 1, 1, 0), (1, 256, 4, 4, 32, 1, 2, 0), (1, 512, 3, 3, 32, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("shape", ZERO_W_SHAPES, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("act_kind", ["relu", "sparse"])
+def test_tiled_zero_weight_kernels_bit_exact(shape, act_kind):
+    """Pruned weights (sign(0) == 0, bnn/ops.py:66,136) on the TILED kernels (BNN_HIP_FLAG_WEIGHT_ZEROS with a
+    second scalar stream for the mask): integer dot == oracle == the shape-generic kernel, fused epilogue too."""
+    N, C, H, W, O, k, st, pad = shape
+    x = gen.activation(act_kind, gen.seed_of("wz", shape), (N, C, H, W))
+    w = gen.conv_weight("withzeros", gen.seed_of("wzw", shape), (O, C, k, k))
+    act, pw = hipops.pack_act(dev(x)), hipops.pack_weight(dev(w))
+    assert pw.has_zero
+    dot = hipops.bconv2d(act, pw, stride=st, padding=pad, raw_dot=True)
+    gen_dot = hipops.bconv2d(act, pw, stride=st, padding=pad, raw_dot=True, force_generic=True)
+    _, ref_dot = oracle.binary_conv2d_int(x, w, None, None, st, pad)
+    assert np.array_equal(dot.cpu().numpy(), ref_dot) and torch.equal(dot, gen_dot)
+    out = hipops.bconv2d(act, pw, stride=st, padding=pad)
+    ref_out, _ = oracle.binary_conv2d_int(x, w, None, None, st, pad)
+    assert np.array_equal(out.cpu().numpy(), ref_out)
+    a_, b_ = dev((0.5 + gen.uniform(1, (O,))).astype(np.float32)), dev((0.3 * gen.normal(2, (O,))).astype(np.float32))
+    y0, p0 = hipops.bconv2d_fused(act, pw, bn_scale=a_, bn_shift=b_, relu=True, out_f32=True, out_packed=True,
+                                  stride=st, padding=pad)
+    y1, p1 = hipops.bconv2d_fused(act, pw, bn_scale=a_, bn_shift=b_, relu=True, out_f32=True, out_packed=True,
+                                  stride=st, padding=pad, force_generic=True)
+    assert torch.equal(y0, y1) and torch.equal(p0.P, p1.P) and torch.equal(p0.M, p1.M)
+    if act_kind == "relu":   # the non-negative promise is ignored by the zero-weight variant (two-plane maths)
+        act.nonneg = True
+        assert torch.equal(hipops.bconv2d(act, pw, stride=st, padding=pad, raw_dot=True), dot)
+
+
 def test_runs_on_the_current_side_stream():
     case = LAYER_CASES_BY_NAME["c2_relu"]
     x, w, _, _ = case.tensors()
