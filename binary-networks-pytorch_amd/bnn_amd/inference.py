@@ -197,7 +197,7 @@ class FusedResNet(nn.Module):
             and type(getattr(fc, "activation_post_process", None)).__name__ == "Identity")
         self._head = None
         if fc_float and isinstance(ap, nn.AdaptiveAvgPool2d) and ap.output_size in (1, (1, 1)) \
-                and fc.weight.dtype == torch.float32 and fc.in_features * 32 <= 160 * 1024:
+                and fc.weight.dtype == torch.float32 and fc.in_features * 16 <= 160 * 1024:
             self._head = (fc.weight.detach().t().contiguous(), None if fc.bias is None else fc.bias.detach())
         for stage in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in stage:

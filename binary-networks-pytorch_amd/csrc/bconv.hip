@@ -201,10 +201,16 @@ enum : int {
   EP_MID = 2,      // BN + ReLU -> packed only            (conv1 of a BasicBlock)
   EP_OUT = 3,      // BN + residual + ReLU -> fp32 + packed (conv2 of a BasicBlock)
   EP_DS = 4,       // BN -> fp32                            (1x1 conv of a shortcut branch)
+  EP_LAST = 5,     // BN + residual + ReLU -> fp32 only     (conv2 of the LAST BasicBlock: the head reads fp32)
 };
 constexpr int kFlagsMid = EF_BN | EF_RELU | EF_PACK;
 constexpr int kFlagsOut = EF_BN | EF_RES | EF_RELU | EF_OUTF | EF_PACK;
 constexpr int kFlagsDs = EF_BN | EF_OUTF;
+constexpr int kFlagsLast = EF_BN | EF_RES | EF_RELU | EF_OUTF;
+__device__ __forceinline__ constexpr int ep_flags(int ep, int runtime) {
+  return ep == EP_MID ? kFlagsMid : ep == EP_OUT ? kFlagsOut : ep == EP_DS ? kFlagsDs : ep == EP_LAST ? kFlagsLast
+                                                                                                        : runtime;
+}
 
 template <int NACC, int EP>
 __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
@@ -213,7 +219,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
   constexpr bool FUSED = EP != EP_PLAIN;
   const int hw = g.Ho * g.Wo;
   const unsigned lane_off = (unsigned)(px.n * g.c_tot * hw + px.r);  // host keeps N*c_tot*hw < 2^31
-  const int f = EP == EP_MID ? kFlagsMid : EP == EP_OUT ? kFlagsOut : EP == EP_DS ? kFlagsDs : g.flags;
+  const int f = ep_flags(EP, g.flags);
   const bool full = o0 + NACC <= g.O;
   if (f & EF_RAW) {
     if (px.live) {
@@ -277,7 +283,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
 template <int NACC, int EP>
 __device__ __forceinline__ void prefetch_residual(const Geo& g, const Pix& px, int o0,
                                                   const EpiArgs& e, float (&resv)[NACC]) {
-  const int f = EP == EP_MID ? kFlagsMid : EP == EP_OUT ? kFlagsOut : EP == EP_DS ? kFlagsDs : g.flags;
+  const int f = ep_flags(EP, g.flags);
   if (EP == EP_PLAIN || !(f & EF_RES) || (f & EF_RAW)) {
 #pragma unroll
     for (int j = 0; j < NACC; ++j) resv[j] = 0.0f;
@@ -830,6 +836,7 @@ static void launch_sgpr(const ConvP& p, int flags, hipStream_t s) {
   if constexpr (PROFILES) {
     if (g.flags == kFlagsMid) return launch_sgpr_e<KH, KW, CWC, EP_MID>(p, g, nn, s);
     if (g.flags == kFlagsOut) return launch_sgpr_e<KH, KW, CWC, EP_OUT>(p, g, nn, s);
+    if (g.flags == kFlagsLast) return launch_sgpr_e<KH, KW, CWC, EP_LAST>(p, g, nn, s);
   } else {
     if (g.flags == kFlagsDs) return launch_sgpr_e<KH, KW, CWC, EP_DS>(p, g, nn, s);
   }

@@ -5,28 +5,33 @@
 // launch- and latency-bound work that three library kernels (mean-reduce, GEMM, bias/copies) spent
 // ~100 us on; fused it is one pass with the means kept in LDS.
 //
-// Work decomposition: a workgroup owns IMG = 8 images x 256 output features.
-//   phase 1: thread (i, c) sums the HW contiguous values of channel c of image i (fp32, index order, then
-//            one division by HW — the order of ATen's CPU adaptive_avg_pool2d) -> m[c][i] in LDS;
-//   phase 2: thread o walks k = 0..C-1: one coalesced load of Wt[k][o] (the weight is passed transposed,
-//            [C][O], so that the 64 lanes of a wave read 256 contiguous bytes), two broadcast
-//            ds_read_b128 of m[k][0..7], eight fmaf.  The weight (2 MB at ResNet-18 size) is read once per
-//            8 images from L2.
+// Work decomposition: a workgroup owns IMG = 4 images x 256 output features (ResNet-18, batch 256: 64 x 4 = 256
+// workgroups, one per CU).  The kernel is latency-bound, so both phases are written for loads in flight:
+//   phase 1: thread (i, c) sums the HW contiguous values of channel c of image i — all HW loads of an item are
+//            issued before the first add when HW <= 64 (the 7x7 = 49 of every ResNet: one memory round trip per
+//            item instead of seven), fp32, index order, one division by HW (the order of ATen's CPU
+//            adaptive_avg_pool2d) -> m[c][i] in LDS;
+//   phase 2: thread o walks k = 0..C-1, 16 iterations in flight: one coalesced load of Wt[k][o] (the weight is
+//            passed transposed, [C][O], so that the 64 lanes of a wave read 256 contiguous bytes), one broadcast
+//            ds_read_b128 of m[k][0..3], four fmaf.  The weight (2 MB at ResNet-18 size) comes from L2.
 #include "bnn_dev.h"
 
 namespace bnn {
 
 namespace tail {
-constexpr int IMG = 8;
+constexpr int IMG = 4;
 constexpr int NT = 256;
 }  // namespace tail
 
+// HWC > 0: HW is this compile-time constant (49 for every 224x224 ResNet); 0: run-time HW, rolled loop.
+template <int HWC>
 __global__ __launch_bounds__(tail::NT) void avgpool_fc_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ wt,
                                                                const float* __restrict__ bias,
-                                                               float* __restrict__ out, int N, int C, int HW,
-                                                               int O) {
+                                                               float* __restrict__ out, int N, int C,
+                                                               int HW_rt, int O) {
   using namespace tail;
+  const int HW = HWC > 0 ? HWC : HW_rt;
   extern __shared__ __attribute__((aligned(16))) float m[];  // [C][IMG]
   const int n0 = blockIdx.x * IMG;
   const int tid = threadIdx.x;
@@ -36,8 +41,16 @@ __global__ __launch_bounds__(tail::NT) void avgpool_fc_kernel(const float* __res
     float s = 0.0f;
     if (n0 + i < N) {
       const float* p = x + ((size_t)(n0 + i) * C + c) * HW;
-#pragma unroll 7
-      for (int q = 0; q < HW; ++q) s += p[q];
+      if constexpr (HWC > 0) {
+        float v[HWC];
+#pragma unroll
+        for (int q = 0; q < HWC; ++q) v[q] = p[q];
+#pragma unroll
+        for (int q = 0; q < HWC; ++q) s += v[q];
+      } else {
+#pragma unroll 8
+        for (int q = 0; q < HW; ++q) s += p[q];
+      }
       s = s / hw;
     }
     m[c * IMG + i] = s;
@@ -49,19 +62,14 @@ __global__ __launch_bounds__(tail::NT) void avgpool_fc_kernel(const float* __res
 #pragma unroll
   for (int i = 0; i < IMG; ++i) acc[i] = 0.0f;
   const float* wp = wt + o;
-#pragma unroll 8
+#pragma unroll 16
   for (int k = 0; k < C; ++k) {
     const float w = wp[(size_t)k * O];
     const float4 a = *reinterpret_cast<const float4*>(&m[k * IMG]);
-    const float4 b = *reinterpret_cast<const float4*>(&m[k * IMG + 4]);
     acc[0] = fmaf(a.x, w, acc[0]);
     acc[1] = fmaf(a.y, w, acc[1]);
     acc[2] = fmaf(a.z, w, acc[2]);
     acc[3] = fmaf(a.w, w, acc[3]);
-    acc[4] = fmaf(b.x, w, acc[4]);
-    acc[5] = fmaf(b.y, w, acc[5]);
-    acc[6] = fmaf(b.z, w, acc[6]);
-    acc[7] = fmaf(b.w, w, acc[7]);
   }
   const float bv = bias ? bias[o] : 0.0f;
 #pragma unroll
@@ -75,12 +83,17 @@ int launch_avgpool_fc(const float* x, const float* wt, const float* bias, float*
   const size_t lds = (size_t)C * IMG * sizeof(float);
   if (lds > 160 * 1024) return BNN_HIP_ERR_UNSUPPORTED;
   if (lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(avgpool_fc_kernel),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(avgpool_fc_kernel<49>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(avgpool_fc_kernel<0>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return BNN_HIP_ERR_UNSUPPORTED;
   }
   const dim3 grid((N + IMG - 1) / IMG, (O + NT - 1) / NT);
-  hipLaunchKernelGGL(avgpool_fc_kernel, grid, dim3(NT), lds, stream, x, wt, bias, out, N, C, HW, O);
+  if (HW == 49)
+    hipLaunchKernelGGL(avgpool_fc_kernel<49>, grid, dim3(NT), lds, stream, x, wt, bias, out, N, C, HW, O);
+  else
+    hipLaunchKernelGGL(avgpool_fc_kernel<0>, grid, dim3(NT), lds, stream, x, wt, bias, out, N, C, HW, O);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 

@@ -230,7 +230,7 @@ int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w,
  * avgpool -> flatten -> fc):  out[n,o] = bias[o] + sum_c w_t[c,o] * mean_hw x[n,c,hw].
  * x: float32 [N,C,HW] (an NCHW tensor with HW = H*W), w_t: the Linear weight TRANSPOSED to [C,O]
  * (so that a wavefront reads contiguous bytes; nn.Linear stores [O,C]), bias: [O] or NULL,
- * out: float32 [N,O].  fp32 fmaf accumulation in index order; C*32 bytes of LDS (C <= 5120).       */
+ * out: float32 [N,O].  fp32 fmaf accumulation in index order; C*16 bytes of LDS (C <= 10240).       */
 int bnn_hip_avgpool_fc_f32(const float* x, int N, int C, int HW, const float* w_t, const float* bias,
                            int O, float* out, void* stream);
 

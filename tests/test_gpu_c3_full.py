@@ -171,7 +171,7 @@ def test_c5_hblock_3463_at_its_stated_size():
     fused16.capture(x)
     assert torch.equal(fused16(x), y)
     names = _binary_conv_names(net)
-    assert len(names) == 3 * 16 + 4                     # 16 HBlocks x 3 convs + 4 binary 1x1 shortcuts
+    assert len(names) == 3 * 16 + 3                     # 16 HBlocks x 3 convs + 3 binary 1x1 shortcuts
     xs = x[:8].contiguous()
     yl, hl = _run_layerwise(net, xs, names)
     yf, hf = _run_fused(net, xs, names)                 # default (fp32-class) stem

@@ -1,7 +1,8 @@
+"""Stem kernels at batch 256, 224x224: wave-specialised (default) vs lock-step, all output modes."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "binary-networks-pytorch_amd")]
-import torch, torch.nn.functional as F
+import torch
 from bnn_amd import hipops
 from tests.golden import gen
 dev = torch.device("cuda:0")
@@ -9,16 +10,15 @@ N = int(os.environ.get("BATCH", "256"))
 x = torch.from_numpy(gen.normal(1, (8, 3, 224, 224))).to(dev).repeat(N // 8, 1, 1, 1)
 w = torch.from_numpy(gen.conv_weight("kaiming", 3, (64, 3, 7, 7))).to(dev)
 a = torch.rand(64, device=dev) + 0.5; b = torch.randn(64, device=dev) * 0.3
-def t(fn, n=10):
-    for _ in range(2): fn()
+def t(fn, n=20):
+    for _ in range(3): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
-print("stem full       %.1f us" % t(lambda: hipops.stem7x7(x, w, a, b)))
-print("stem packed-only %.1f us" % t(lambda: hipops.stem7x7(x, w, a, b, out_f32=False)))
-print("stem f32-only   %.1f us" % t(lambda: hipops.stem7x7(x, w, a, b, out_packed=False)))
-print("miopen conv     %.1f us" % t(lambda: F.conv2d(x, w, None, 2, 3)))
-y = F.conv2d(x, w, None, 2, 3)
-print("tail kernel     %.1f us" % t(lambda: hipops.bn_relu_maxpool_pack(y, a, b, True, 3, 2, 1)))
+for name, kw in (("wave-specialised", {}), ("lock-step", {"_lockstep": True}), ("ws fp16", {"fp16": True}),
+                 ("lock-step fp16", {"fp16": True, "_lockstep": True}), ("exact fp32", {"exact_fp32": True})):
+    print("%-18s full %.1f us   packed-only %.1f us   f32-only %.1f us" % (
+        name, t(lambda: hipops.stem7x7(x, w, a, b, **kw)), t(lambda: hipops.stem7x7(x, w, a, b, out_f32=False, **kw)),
+        t(lambda: hipops.stem7x7(x, w, a, b, out_packed=False, **kw))))

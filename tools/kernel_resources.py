@@ -18,4 +18,4 @@ for b, n in zip(blocks, dem):
     if only and only not in n:
         continue
     scratch, occ = g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]")
-    print(f"{n:100s} v={g('VGPRs'):3d} s={g('SGPRs'):3d} scratch={scratch:4d} occ={occ}")
+    print(f"{n:100s} v={g('VGPRs'):3d} a={g('AGPRs'):3d} s={g('SGPRs'):3d} scratch={scratch:4d} occ={occ}")
