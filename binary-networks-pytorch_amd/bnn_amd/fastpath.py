@@ -177,6 +177,8 @@ def packed_weight(layer, plan: Plan, sync: bool = True, fresh: bool = False) -> 
         return cached[1]
     sync = sync or layer.__dict__.get("_bnn_zero_seen", False)
     pw = hipops.pack_weight(w, plan.center, plan.compute_alpha, sync=sync)
+    if pw.has_zero:  # once a layer has shown an exact zero it is always packed synchronously (mask-aware)
+        layer.__dict__["_bnn_zero_seen"] = True
     layer.__dict__["_bnn_packed"] = (key, pw)
     _bump("weight_packs")
     return pw

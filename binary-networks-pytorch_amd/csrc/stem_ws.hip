@@ -8,18 +8,20 @@
 // which 4.6 k are MFMA issue).  Here the 8 waves of the workgroup (one per CU, persistent) split into two roles,
 // one wave of each role on every SIMD:
 //
-//   waves 0..3  MATRIX : the implicit GEMM of tile t (M = 17x15 conv pixels, N = 64, K = 24 rows x 8), each wave
-//                        8 sub-tiles of 16 pixels x 32 channels with its B fragments (hi/lo, 6 k-steps) resident in
-//                        96 VGPRs and the A fragments software-pipelined one step ahead (nobody else hides its LDS
-//                        latency now); then BN + ReLU of its 64 accumulators into the LDS conv tile ("stage").
-//   waves 4..7  HELPER : while the matrix waves multiply tile t — (1) issue the global loads of tile t+1's input
-//                        patch, (2) max-pool tile t-1 out of `stage`, store fp32 + sign bytes, (3) split the loaded
-//                        patch into fp16 hi/lo and write it to the OTHER patch buffer.
+//   waves 0..3  MATRIX : issue the global loads of tile t+2's input patch; the implicit GEMM of tile t (M = 17x15
+//                        conv pixels, N = 64, K = 24 rows x 8), each wave 8 sub-tiles of 16 pixels x 32 channels
+//                        with its B fragments (hi/lo, 6 k-steps) resident in 96 VGPRs and the A fragments
+//                        software-pipelined one step ahead (nobody else hides its LDS latency now); then BN + ReLU
+//                        of its 64 accumulators into the LDS conv tile ("stage") and the loaded patch, split into
+//                        fp16 hi/lo, into the patch buffer the GEMM has just finished with.
+//   waves 4..7  POOL   : while the matrix waves multiply tile t, max-pool tile t-1 out of `stage` and store its
+//                        fp32 values and sign masks.
 //
-// Two barriers per tile:  [matrix t | pool t-1, patch t+1]  X  [BN/ReLU t -> stage | sign words t-1 -> HBM]  Y.
-// `stage` is single-buffered (pool t-1 is over before X), the patch is double-buffered; with the sign-byte
-// scratch that is 160.4 KB of the CU's 160 KiB LDS.  The tile time becomes max(matrix, helper work) + the
-// epilogue instead of their sum.
+// Two barriers per tile:  [loads t+2, matrix t | pool t-1]  X  [BN/ReLU t -> stage, patch t+2 -> LDS | sign words
+// t-1 -> HBM]  Y.  `stage` is single-buffered (pool t-1 is over before X), the patch is double-buffered; with the
+// sign-mask scratch that is 160.0 KB of the CU's 160 KiB LDS.  The waves that LOAD never STORE to global memory:
+// gfx950 has one vmcnt for both, a wave that needs a load result while it has stores in flight waits for the
+// stores' acknowledgements too (measured: 7-10 k cycles per tile when the pooling waves also fetched).
 #include "bnn_dev.h"
 
 namespace bnn {
@@ -46,8 +48,8 @@ constexpr int STEPS = KSTEPS * (SUBS / 2);           // 24 pipeline steps of 12 
 constexpr int PLANE_B = ((NINP * 2 + 15) / 16) * 16;
 constexpr int OFF_PATCH = 0;                         // [buf][hi, lo]
 constexpr int OFF_STAGE = OFF_PATCH + 4 * PLANE_B;
-constexpr int OFF_BITS = OFF_STAGE + (MPIX + 1) * SC * 4;  // sign bytes of one tile: [56 pixels][8]
-constexpr int LDS_BYTES = OFF_BITS + PTH * PTW * 8;
+constexpr int OFF_BITS = OFF_STAGE + (MPIX + 1) * SC * 4;  // sign masks of one tile: [8 channel groups][8 rows] x 64 bit
+constexpr int LDS_BYTES = OFF_BITS + 8 * PTH * 8;
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 }  // namespace stem5
 
@@ -55,6 +57,16 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using half2v = __attribute__((ext_vector_type(2))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: the helper waves would sit
+// at every barrier until their global STORES (pooled outputs, sign words) are acknowledged by the memory system —
+// a ~1 us round trip per tile on the critical path of the matrix waves (measured: +76 us per launch for the sign
+// words alone).  Nothing another wave reads goes through global memory here, so only lgkmcnt must reach zero.
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
 
 template <bool HALF>
 __global__ __launch_bounds__(stem5::NT, 2) void stem_ws_kernel(
@@ -121,12 +133,21 @@ __global__ __launch_bounds__(stem5::NT, 2) void stem_ws_kernel(
   }
 
   // ------------------------------------------------------------------ helper role: loop-invariant state
-  const int htid = tid - MWAVES * 64;          // 0..255 for helpers
+  const int htid = tid - MWAVES * 64;          // 0..255 for the pooling waves
   const int hwave = (wave - MWAVES) & 3;
-  const int fpc = htid % NPC, frow0 = htid / NPC;  // fetch: column pair `fpc` of patch rows frow0 + 14*u
-  const bool fetcher = !is_matrix && htid < NPC * RSTEP;
+  // fetch (matrix threads 0..251): column pair `fpc` of patch rows frow0 + 14*u
+  const int fpc = tid % NPC;
+  int frow0 = tid / NPC;
+  const bool fetcher = is_matrix && tid < NPC * RSTEP;
   const int pchl = lane & 7, pplx = lane >> 3;     // pooling: channel within a byte, pooled column (7 = idle)
   float nx0[PER_T], nx1[PER_T];
+  unsigned nxmask = 0;  // bit 2u / 2u+1: element u of nx0 / nx1 lies inside the image (else it is zero padding)
+  // The helper waves share their SIMD's issue slots with a matrix wave: what they cost is their INSTRUCTION COUNT
+  // (first version: 1240 per tile and wave — one exec-mask region per guarded load/store, 64-bit address
+  // arithmetic per access, 16 ballots + 16 byte stores — 10 k cycles per tile, more than the matrix phase).
+  // Everything below is written to be branch-free per element: clamped addresses + selects instead of guarded
+  // loads, one uniform base pointer + one 32-bit lane offset per access stream, one exec region per group.
+  const bool last_pair = fpc == NPC - 1;       // its second column is the zero column (kx = 7)
 
   auto fetch = [&](int tile) {
     const bool valid = tile < ntiles;
@@ -135,74 +156,116 @@ __global__ __launch_bounds__(stem5::NT, 2) void stem_ws_kernel(
     const int tr = tl - n * tiles_y * tiles_x;
     const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
     const int iy0 = 2 * (2 * ty * PTH - 1) - 3, ix0 = 2 * (2 * tx * PTW - 1) - 3;
-    const float* xb = x + (size_t)n * CIN * H * W + (ptrdiff_t)iy0 * W + ix0;
+    const float* xn = x + (size_t)n * CIN * H * W;          // uniform: SGPR base of every load
+    const int org = iy0 * W + ix0;                            // may be negative; only used when in range
     const int ix = ix0 + 2 * fpc;
     const bool okc0 = valid && (unsigned)ix < (unsigned)W;
-    const bool okc1 = valid && 2 * fpc + 1 < ITWP - 1 && (unsigned)(ix + 1) < (unsigned)W;  // col 35: zero
+    const bool okc1 = valid && !last_pair && (unsigned)(ix + 1) < (unsigned)W;
+    // (row, channel) of the 9 patch rows are loop-invariant; recomputed per tile (a few VALU ops) rather than held in
+    // 18 registers next to the GEMM's 226
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(frow0));
+#endif
+    unsigned mask = 0;
 #pragma unroll
     for (int u = 0; u < PER_T; ++u) {
       const int R = frow0 + RSTEP * u;
-      const int c = R / ITH, r = R - c * ITH;
-      const bool okr = fetcher && R < NROW && (unsigned)(iy0 + r) < (unsigned)H;
-      const int goff = (c * H + r) * W + 2 * fpc;
-      nx0[u] = (okr && okc0) ? xb[goff] : 0.0f;
-      nx1[u] = (okr && okc1) ? xb[goff + 1] : 0.0f;
+      const int c = (R >= ITH) + (R >= 2 * ITH);
+      const int r = R - c * ITH;
+      const bool okr = (unsigned)(iy0 + r) < (unsigned)H;
+      const bool k0 = okr && okc0, k1 = okr && okc1;
+      const int o = org + (c * H + r) * W + 2 * fpc;
+      // out-of-image elements read element 0 of the image (always valid); commit() zeroes them.  Nothing here
+      // may depend on the loaded VALUES: the loads must stay in flight across the GEMM that follows.
+      nx0[u] = xn[k0 ? o : 0];
+      nx1[u] = xn[k1 ? o + 1 : 0];
+      mask |= (k0 ? 1u : 0u) << (2 * u) | (k1 ? 2u : 0u) << (2 * u);
     }
+    nxmask = mask;
   };
   auto commit = [&](int buf) {
-    _Float16* hiP = hi_plane(buf);
-    _Float16* loP = lo_plane(buf);
+    half2v* hiP = reinterpret_cast<half2v*>(hi_plane(buf)) + frow0 * (ROWH / 2) + fpc;
+    half2v* loP = reinterpret_cast<half2v*>(lo_plane(buf)) + frow0 * (ROWH / 2) + fpc;
+    if (fetcher) {  // one exec region; rows frow0 + 14*u, u < 8, exist for every fetcher
 #pragma unroll
-    for (int u = 0; u < PER_T; ++u) {
-      const int R = frow0 + RSTEP * u;
-      if (fetcher && R < NROW) {
+      for (int u = 0; u < PER_T; ++u) {
+        const float x0 = (nxmask >> (2 * u)) & 1u ? nx0[u] : 0.0f;
+        const float x1 = (nxmask >> (2 * u)) & 2u ? nx1[u] : 0.0f;
         half2v h, l;
-        h[0] = (_Float16)nx0[u];
-        h[1] = (_Float16)nx1[u];
-        l[0] = (_Float16)(nx0[u] - (float)h[0]);
-        l[1] = (_Float16)(nx1[u] - (float)h[1]);
-        reinterpret_cast<half2v*>(hiP)[R * (ROWH / 2) + fpc] = h;
-        if constexpr (!HALF) reinterpret_cast<half2v*>(loP)[R * (ROWH / 2) + fpc] = l;
-      }
-    }
-  };
-  // 3x3 / stride-2 max pool of the staged tile (tn, tpy0, tpx0): a thread owns one pooled COLUMN of one channel
-  // (17 row maxima of 3 conv columns -> 8 outputs); 4 helper waves x 2 passes x 8 channels per wave.  The sign
-  // bits of 8 channels are gathered with one ballot into a byte of the tile's scratch.
-  auto pool = [&](bool tvalid, int tn, int tpy0, int tpx0) {
-    const int px = tpx0 + pplx;
-    const bool col_live = tvalid && pplx < PTW && px < Wp;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int byte = hwave + 4 * pass;
-      const int pch = 8 * byte + pchl;
-      float hm[CTH];
-      const float* sp = stage + (2 * (pplx < PTW ? pplx : 0)) * SC + pch;
-#pragma unroll
-      for (int r = 0; r < CTH; ++r)
-        hm[r] = fmaxf(fmaxf(sp[(r * CTW) * SC], sp[(r * CTW + 1) * SC]), sp[(r * CTW + 2) * SC]);
-#pragma unroll
-      for (int ply = 0; ply < PTH; ++ply) {
-        const int py = tpy0 + ply;
-        const bool live = col_live && py < Hp;
-        const float v = fmaxf(fmaxf(hm[2 * ply], hm[2 * ply + 1]), hm[2 * ply + 2]);
-        if (live && out) out[(((size_t)tn * COUT + pch) * Hp + py) * Wp + px] = v;
-        if (P) {  // lanes 8*plx .. 8*plx+7 hold the 8 channels of byte `byte` of pixel (ply, plx)
-          const unsigned long long mask = __ballot(live && is_pos(v));
-          if (pchl == 0 && pplx < PTW) bits[(ply * PTW + pplx) * 8 + byte] = (uint8_t)(mask >> (8 * pplx));
+        h[0] = (_Float16)x0;
+        h[1] = (_Float16)x1;
+        l[0] = (_Float16)(x0 - (float)h[0]);
+        l[1] = (_Float16)(x1 - (float)h[1]);
+        if (u < PER_T - 1 || frow0 + RSTEP * u < NROW) {
+          hiP[u * RSTEP * (ROWH / 2)] = h;
+          if constexpr (!HALF) loP[u * RSTEP * (ROWH / 2)] = l;
         }
       }
     }
   };
-  // the tile's 56 sign words leave as whole 64-bit stores (byte stores from several waves into one word are slow)
+  // 3x3 / stride-2 max pool of the staged tile (tn, tpy0, tpx0): a thread owns one pooled COLUMN of one channel
+  // (17 row maxima of 3 conv columns -> 8 outputs); 4 helper waves x 2 passes x 8 channels per wave.  Sign bits:
+  // lanes 8*plx .. 8*plx+7 hold the 8 channels of group g of pixel column plx, so the ballot of one pooled row IS
+  // the row's 7 sign bytes of that group; lane 0 parks the 8 row masks in LDS (`bits`: [group][row] 64-bit).
+  auto pool = [&](bool tvalid, int tn, int tpy0, int tpx0) {
+    const bool full = tvalid && tpy0 + PTH <= Hp && tpx0 + PTW <= Wp;  // uniform; every tile of a 224x224 input
+    const int px = tpx0 + pplx;
+    const bool col_live = tvalid && pplx < PTW && px < Wp;
+    const unsigned long long colmask = __ballot(col_live);
+    float* ob = out ? out + (((size_t)tn * COUT) * Hp + tpy0) * Wp + tpx0 : nullptr;  // uniform base
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int g = hwave + 4 * pass;
+      const int pch = 8 * g + pchl;
+      float hm[CTH], v[PTH];
+      const float* sp = stage + (2 * (pplx < PTW ? pplx : PTW - 1)) * SC + pch;
+#pragma unroll
+      for (int r = 0; r < CTH; ++r)
+        hm[r] = fmaxf(fmaxf(sp[(r * CTW) * SC], sp[(r * CTW + 1) * SC]), sp[(r * CTW + 2) * SC]);
+#pragma unroll
+      for (int ply = 0; ply < PTH; ++ply) v[ply] = fmaxf(fmaxf(hm[2 * ply], hm[2 * ply + 1]), hm[2 * ply + 2]);
+      if (ob) {
+        const unsigned voff = (unsigned)(pch * Hp * Wp + pplx);  // lane part of the address, 32 bits
+        if (full) {
+          if (pplx < PTW) {
+#pragma unroll
+            for (int ply = 0; ply < PTH; ++ply) ob[voff + (unsigned)(ply * Wp)] = v[ply];
+          }
+        } else {
+#pragma unroll
+          for (int ply = 0; ply < PTH; ++ply)
+            if (col_live && tpy0 + ply < Hp) ob[voff + (unsigned)(ply * Wp)] = v[ply];
+        }
+      }
+      if (P) {
+        unsigned long long rowmask[PTH];
+#pragma unroll
+        for (int ply = 0; ply < PTH; ++ply)
+          rowmask[ply] = (tpy0 + ply < Hp) ? (__ballot(is_pos(v[ply])) & colmask) : 0ull;
+        if (lane == 0) {
+          unsigned long long* bw = reinterpret_cast<unsigned long long*>(bits) + g * PTH;
+#pragma unroll
+          for (int ply = 0; ply < PTH; ++ply) bw[ply] = rowmask[ply];
+        }
+      }
+    }
+  };
+  // The tile's 56 sign words: thread (row, column) collects its byte from the 8 channel groups and sends one
+  // whole 64-bit word (byte stores from several waves into one word are slow).
   auto flush_bits = [&](bool tvalid, int tn, int tpy0, int tpx0) {
     if (P && tvalid && htid < PTH * PTW) {
       const int ply = htid / PTW, plx = htid - ply * PTW;
-      const int py = tpy0 + ply, px = tpx0 + plx;
-      if (py < Hp && px < Wp) {
-        const size_t o = ((size_t)tn * Hp + py) * Wp + px;
-        P[o] = *reinterpret_cast<const uint64_t*>(bits + htid * 8);
-        M[o] = 0;  // nothing is negative after ReLU
+      if (tpy0 + ply < Hp && tpx0 + plx < Wp) {
+        const uint8_t* bp = bits + ply * 8 + plx;
+        unsigned long long word = 0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) word |= (unsigned long long)bp[g * PTH * 8] << (8 * g);
+        uint64_t* pb = P + ((size_t)tn * Hp + tpy0) * Wp + tpx0;   // uniform base
+        const unsigned o = (unsigned)(ply * Wp + plx);
+        pb[o] = word;
+#ifndef BNN_STEM_TIMING
+        (M + ((size_t)tn * Hp + tpy0) * Wp + tpx0)[o] = 0;  // nothing is negative after ReLU
+#endif
       }
     }
   };
@@ -213,6 +276,14 @@ __global__ __launch_bounds__(stem5::NT, 2) void stem_ws_kernel(
     return __builtin_bit_cast(half8, v);
   };
 
+#ifdef BNN_STEM_TIMING  // per-segment cycle sums of every wave, dumped over the M plane (debug builds only)
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define STEM_T(k) { const unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; }
+#define STEM_T_DUMP() if (lane == 0 && M) for (int k = 0; k < 6; ++k) M[((size_t)blockIdx.x * 8 + wave) * 6 + k] = tph[k];
+#else
+#define STEM_T(k)
+#define STEM_T_DUMP()
+#endif
   // Decode a tile index (workgroup-uniform).
   struct TileAt { bool valid; int n, py0, px0, cy0, cx0; };
   auto tile_at = [&](int seq) {
@@ -236,9 +307,22 @@ __global__ __launch_bounds__(stem5::NT, 2) void stem_ws_kernel(
   // spills ~90 registers around the MFMA block.
   if (is_matrix) {
     int cur = 0;
-    __syncthreads();  // patch[0] holds the first tile
+    // patch pipeline: tiles t0, t1 are split into LDS up front; inside the loop the loads of tile t+2 are issued
+    // before the GEMM of tile t and land in LDS (the buffer that GEMM has just released) after barrier X
+    if (blockIdx.x < nseq) {
+      fetch(tile_of(blockIdx.x));
+      commit(0);
+    }
+    if (blockIdx.x + gridDim.x < nseq) {
+      fetch(tile_of(blockIdx.x + gridDim.x));
+      commit(1);
+    }
+    lds_barrier();  // patch[0], patch[1] hold the first two tiles
     for (int seq = blockIdx.x; seq < nseq; seq += gridDim.x) {
       const TileAt t = tile_at(seq);
+      const int seq2 = seq + 2 * gridDim.x;
+      STEM_T(5)
+      if (seq2 < nseq) fetch(tile_of(seq2));  // in flight during the GEMM
       // ---- implicit GEMM: 8 sub-tiles x 2 channel tiles x 6 k-steps x (lo*hi + hi*lo + hi*hi), two sub-tiles
       // per step (4 independent accumulators between two MFMAs on the same one), A fragments one step ahead.
       const _Float16* hiP = hi_plane(cur);
@@ -267,8 +351,12 @@ __global__ __launch_bounds__(stem5::NT, 2) void stem_ws_kernel(
 #pragma unroll
       for (int step = 0; step < STEPS; ++step) {
         const int b = step & 1, ks = step / (SUBS / 2), ip = 2 * (step % (SUBS / 2));
-        __builtin_amdgcn_sched_barrier(0);  // keep the pipeline one step deep: more prefetch only buys spills
+        // [loads of step+1] | [12 MFMAs of step]: the fences keep the scheduler from sinking the loads next to
+        // their uses (it does, to save registers) — they must be a whole step (~200 cycles) ahead, nobody else
+        // on this SIMD hides LDS latency for the matrix wave.
+        __builtin_amdgcn_sched_barrier(0);
         if (step + 1 < STEPS) lda(step + 1, b ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (!HALF) {
 #pragma unroll
           for (int d = 0; d < 2; ++d)
@@ -287,7 +375,9 @@ __global__ __launch_bounds__(stem5::NT, 2) void stem_ws_kernel(
           for (int tt = 0; tt < TT; ++tt)
             acc[ip + d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b][d], bh[ks][tt], acc[ip + d][tt], 0, 0, 0);
       }
-      __syncthreads();  // X: `stage` is free (the helpers pooled tile t-1), patch[cur^1] is written
+      STEM_T(0)
+      lds_barrier();  // X: `stage` is free (tile t-1 is pooled), every matrix wave is done with patch[cur]
+      STEM_T(1)
       // ---- BN + ReLU, conv tile -> LDS.  D layout: column = li (channel), row = 4*lg + r (pixel).
       // Three quarters of the tiles lie entirely inside the conv output: no per-pixel range tests there.
       const bool interior = t.cy0 >= 0 && t.cx0 >= 0 && t.cy0 + CTH <= Hc && t.cx0 + CTW <= Wc;  // uniform
@@ -301,11 +391,17 @@ __global__ __launch_bounds__(stem5::NT, 2) void stem_ws_kernel(
             for (int tt = 0; tt < TT; ++tt)  // row MPIX (the 256th pixel) exists in `stage` and is never read
               sdst[(i * 16 + r) * SC + 16 * tt] = fmaxf(fmaf(acc[i][tt][r], ba[tt], bb[tt]), 0.0f);
       } else {
+        // (cy, cx) of the 32 pixels are loop-invariant: laundering the base keeps the compiler from holding (and
+        // spilling) 64 quotients/remainders across the persistent loop — two VALU ops each to recompute.
+        int mbase = (SUBS * mg) * 16 + lg * 4;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(mbase));
+#endif
 #pragma unroll
         for (int i = 0; i < SUBS; ++i) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int m = (SUBS * mg + i) * 16 + lg * 4 + r;
+            const int m = mbase + i * 16 + r;
             const int cy = m / CTW, cx = m - cy * CTW;
             const bool inside = (unsigned)(t.cy0 + cy) < (unsigned)Hc && (unsigned)(t.cx0 + cx) < (unsigned)Wc;
 #pragma unroll
@@ -317,37 +413,38 @@ __global__ __launch_bounds__(stem5::NT, 2) void stem_ws_kernel(
           }
         }
       }
-      __syncthreads();  // Y: `stage` holds this tile
+      if (seq2 < nseq) commit(cur);  // tile t+2 takes the place of tile t
+      STEM_T(2)
+      lds_barrier();  // Y: `stage` holds this tile, patch[cur] the tile after next
+      STEM_T(3)
       cur ^= 1;
     }
-    __syncthreads();    // the helpers pool the last tile ...
+    lds_barrier();    // the pooling waves pool the last tile ...
+    STEM_T_DUMP()
     return;             // ... and send its sign words
   }
 
-  // ------------------------------------------------------------------ helper role
-  int cur = 0;
-  if (blockIdx.x < nseq) {
-    fetch(tile_of(blockIdx.x));
-    commit(0);
-  }
-  __syncthreads();  // patch[0] holds the first tile
+  // ------------------------------------------------------------------ pooling role
+  lds_barrier();
   TileAt prev;
   prev.valid = false;
   prev.n = prev.py0 = prev.px0 = prev.cy0 = prev.cx0 = 0;
   for (int seq = blockIdx.x; seq < nseq; seq += gridDim.x) {
-    const int seq_next = seq + gridDim.x;
-    if (seq_next < nseq) fetch(tile_of(seq_next));  // global loads fly while the previous tile is pooled
+    STEM_T(5)
     if (prev.valid) pool(true, prev.n, prev.py0, prev.px0);
-    if (seq_next < nseq) commit(cur ^ 1);
-    __syncthreads();  // X: pool done (`stage` free, sign bytes complete), patch[cur^1] written
+    STEM_T(1)
+    lds_barrier();  // X: pool done (`stage` free, sign masks complete)
+    STEM_T(2)
     if (prev.valid) flush_bits(true, prev.n, prev.py0, prev.px0);
-    __syncthreads();  // Y: `stage` holds tile `seq`
+    STEM_T(3)
+    lds_barrier();  // Y: `stage` holds tile `seq`
+    STEM_T(4)
     prev = tile_at(seq);
-    cur ^= 1;
   }
   if (prev.valid) pool(true, prev.n, prev.py0, prev.px0);
-  __syncthreads();
+  lds_barrier();
   if (prev.valid) flush_bits(true, prev.n, prev.py0, prev.px0);
+  STEM_T_DUMP()
 }
 
 template <bool HALF>
