@@ -152,8 +152,7 @@ def avgpool_pack(x: torch.Tensor, k: int, nonneg: bool = False) -> PackedAct:
 
 
 def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: torch.Tensor,
-            out_f32: bool = True, out_packed: bool = True, exact_fp32: bool = False, fp16: bool = False,
-            _lockstep: bool = False):
+            out_f32: bool = True, out_packed: bool = True, exact_fp32: bool = False, fp16: bool = False):
     """conv 7x7/2/3 (3->64, no bias) -> folded BN -> ReLU -> MaxPool 3/2/1 in one MFMA kernel
     (bnn/models/resnet.py:93-96,150-153).  Returns (fp32 NCHW | None, PackedAct | None)."""
     x = _require_cuda_f32(x, "stem input")
@@ -171,8 +170,7 @@ def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: 
         pk = empty_packed(N, 64, hp, wp, x.device) if out_packed else None
         native.check(lib.bnn_hip_stem7x7_bn_relu_pool_pack_f32(
             x.data_ptr(), w.data_ptr(), bn_scale.data_ptr(), bn_shift.data_ptr(), N, H, W,
-            (native.STEM_EXACT_FP32 if exact_fp32 else (native.STEM_FP16 if fp16 else 0)) | (16 if _lockstep else 0),
-            _ptr(y),
+            native.STEM_EXACT_FP32 if exact_fp32 else (native.STEM_FP16 if fp16 else 0), _ptr(y),
             None if pk is None else pk.P.data_ptr(), None if pk is None else pk.M.data_ptr(),
             _stream(x.device)), "bnn_hip_stem7x7_bn_relu_pool_pack_f32")
     if pk is not None:

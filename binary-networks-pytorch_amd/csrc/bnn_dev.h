@@ -92,8 +92,6 @@ int launch_stem_split(const float* x, const float* w, const float* bn_a, const f
                       int W, int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_avgpool_fc(const float* x, const float* wt, const float* bias, float* out, int N, int C, int HW,
                       int O, hipStream_t stream);
-int launch_stem_ws(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
-                   int W, int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_pack_weight(const float* w, int O, int C, int KH, int KW, int center, int compute_alpha,
                        const bnn_hip_wlayout& L, uint32_t* wbits, uint32_t* wnz, float* alpha,
                        int32_t* zero_flag, hipStream_t stream);

@@ -16,8 +16,6 @@
 // conv outputs never touch HBM (the library path writes and re-reads 822 MB at batch 256).  Persistent
 // workgroups (one per CU): weights are staged once; the NEXT tile's input patch is fetched into registers
 // while the matrix phase of the current tile runs; tiles are walked in XCD-contiguous order.
-#include <cstdlib>
-
 #include "bnn_dev.h"
 
 namespace bnn {
@@ -301,10 +299,7 @@ static int launch_stem_t(const float* x, const float* w, const float* bn_a, cons
 int launch_stem(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                 int W, int flags, float* out, uint64_t* P, uint64_t* M, hipStream_t stream) {
   if (flags & BNN_HIP_STEM_EXACT_FP32) return launch_stem_t<false>(x, w, bn_a, bn_b, N, H, W, out, P, M, stream);
-  // A/B switch while both kernels exist (internal flag 16, or the environment for whole-net runs)
-  static const bool env_lockstep = getenv("BNN_STEM_LOCKSTEP") != nullptr;
-  if (env_lockstep || (flags & 16)) return launch_stem_split(x, w, bn_a, bn_b, N, H, W, (flags & BNN_HIP_STEM_FP16) != 0, out, P, M, stream);
-  return launch_stem_ws(x, w, bn_a, bn_b, N, H, W, (flags & BNN_HIP_STEM_FP16) != 0, out, P, M, stream);
+  return launch_stem_split(x, w, bn_a, bn_b, N, H, W, (flags & BNN_HIP_STEM_FP16) != 0, out, P, M, stream);
 }
 
 }  // namespace bnn

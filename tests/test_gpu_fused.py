@@ -406,27 +406,6 @@ def test_stem_tail_matches_torch_sequence(shape):
     assert torch.equal(y2, F.max_pool2d(x, 2, 2, 0))
 
 
-@pytest.mark.parametrize("fp16", [False, True], ids=["split", "fp16"])
-@pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 64, 64), (1, 3, 32, 32), (2, 3, 50, 38), (5, 3, 96, 130),
-                                   (37, 3, 224, 224)])
-def test_wave_specialised_stem_is_bit_identical_to_the_lockstep_kernel(shape, fp16):
-    """stem_ws.hip (matrix waves + helper waves, pipelined over tiles) vs stem_split.hip (all waves in lock step):
-    every accumulator sees the same MFMA sequence, so outputs and sign planes are the same bits.  37 images at
-    224x224 = 2072 tiles: more than one per workgroup, so the cross-tile pipeline (double-buffered patch, single
-    staged tile, deferred sign words) is exercised including its drain."""
-    x = dev(gen.normal(gen.seed_of("stemws", shape), shape))
-    w = dev(gen.conv_weight("kaiming", 3, (64, 3, 7, 7)))
-    a = dev((0.5 + gen.uniform(1, (64,))).astype(np.float32) * np.where(np.arange(64) % 7 == 0, -1, 1).astype(np.float32))
-    b = dev((0.3 * gen.normal(2, (64,))).astype(np.float32))
-    y0, p0 = hipops.stem7x7(x, w, a, b, fp16=fp16, _lockstep=True)
-    y1, p1 = hipops.stem7x7(x, w, a, b, fp16=fp16)
-    assert torch.equal(y0, y1) and torch.equal(p0.P, p1.P) and torch.equal(p0.M, p1.M)
-    _, p2 = hipops.stem7x7(x, w, a, b, fp16=fp16, out_f32=False)
-    assert torch.equal(p2.P, p0.P)
-    y3, _ = hipops.stem7x7(x, w, a, b, fp16=fp16, out_packed=False)
-    assert torch.equal(y3, y0)
-
-
 def test_stem_fp16_option_is_half_precision_accurate():
     """BNN_HIP_STEM_FP16 (BASELINE config 5's "fp16 MFMA stem"): opt-in, one MFMA per product."""
     shape = (2, 3, 96, 96)
