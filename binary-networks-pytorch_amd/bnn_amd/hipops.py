@@ -396,6 +396,56 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
     return y, pk
 
 
+def grad_supported(x_shape, w_shape, stride, padding, dilation) -> bool:
+    """Shapes the binary-aware gradient kernels cover: 3x3 / stride 1 / padding 1 / dilation 1, width <= 64."""
+    return (tuple(w_shape[2:]) == (3, 3) and _pair(stride) == (1, 1) and _pair(padding) == (1, 1)
+            and _pair(dilation) == (1, 1) and x_shape[3] <= 64 and x_shape[0] > 0)
+
+
+def grad_pack_weight(w_hat: torch.Tensor):
+    """``What = sign(Wc) * alpha`` ([O,C,3,3] fp32) -> (sign fragments for the input-gradient kernel, alpha[O])."""
+    w_hat = _require_cuda_f32(w_hat.detach(), "w_hat")
+    lib = native.require()
+    O, C = w_hat.shape[0], w_hat.shape[1]
+    with torch.cuda.device(w_hat.device):
+        packed = torch.empty(int(lib.bnn_hip_grad_weight_pack_bytes(O, C)), dtype=torch.uint8, device=w_hat.device)
+        alpha = torch.empty(O, dtype=torch.float32, device=w_hat.device)
+        native.check(lib.bnn_hip_grad_pack_weight_f32(w_hat.data_ptr(), O, C, packed.data_ptr(), alpha.data_ptr(),
+                                                      _stream(w_hat.device)), "bnn_hip_grad_pack_weight_f32")
+    return packed, alpha
+
+
+def bconv3x3_grad_input(g: torch.Tensor, x: torch.Tensor, packed: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
+    """dL/dx of the binary 3x3/s1/p1 conv incl. the hard-tanh STE mask (bnn/ops.py:68-73)."""
+    g = _require_cuda_f32(g, "grad_output")
+    x = _require_cuda_f32(x, "input")
+    lib = native.require()
+    N, O, H, W = g.shape
+    C = x.shape[1]
+    with torch.cuda.device(g.device):
+        gx = torch.empty_like(x)
+        native.check(lib.bnn_hip_bconv3x3_grad_input_f32(g.data_ptr(), alpha.data_ptr(), packed.data_ptr(),
+                                                         x.data_ptr(), gx.data_ptr(), N, O, C, H, W,
+                                                         _stream(g.device)), "bnn_hip_bconv3x3_grad_input_f32")
+    return gx
+
+
+def bconv3x3_grad_weight(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dL/dWhat [O,C,3,3] of the binary 3x3/s1/p1 conv: correlation of g with sign(x)."""
+    g = _require_cuda_f32(g, "grad_output")
+    x = _require_cuda_f32(x, "input")
+    lib = native.require()
+    N, O, H, W = g.shape
+    C = x.shape[1]
+    splits = int(lib.bnn_hip_bconv3x3_grad_weight_splits(N, O, C))
+    with torch.cuda.device(g.device):
+        part = torch.empty((splits, O, C, 3, 3), dtype=torch.float32, device=g.device)
+        native.check(lib.bnn_hip_bconv3x3_grad_weight_f32(g.data_ptr(), x.data_ptr(), part.data_ptr(), splits,
+                                                          N, O, C, H, W, _stream(g.device)),
+                     "bnn_hip_bconv3x3_grad_weight_f32")
+        return part[0] if splits == 1 else part.sum(0)
+
+
 PROBE_MODES = {0: "bitop3+bcnt", 1: "xor+bcnt", 2: "bcnt", 3: "bitop3", 4: "xor", 5: "fma_f32",
                6: "add_u32", 7: "and_vgpr", 8: "and_vgpr+bcnt", 9: "xor_vgpr", 10: "and_sgpr+bcnt"}
 

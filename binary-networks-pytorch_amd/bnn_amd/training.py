@@ -2,17 +2,19 @@
 (reference: ``bnn/ops.py:63-73`` straight-through estimator,
 ``bnn/layers/conv.py:90-97`` forward, ``examples/imagenet.py:337-384`` training loop).
 
-    forward :  y = bconv2d( pack(sign(x)), pack(sign(Wc)), alpha ) [+ bias]        HIP kernels
-    backward:  g_xhat, g_what, g_bias = conv_backward(g_y, sign(x), W_hat)          library fp32 conv
-               g_x = g_xhat * 1[|x| < 1]                                            STE of ops.py:68-73
+    forward :  y = bconv2d( pack(sign(x)), pack(sign(Wc)), alpha ) [+ bias]        HIP XNOR/popcount kernels
+    backward:  g_xhat[n,c] = sum_o,k g_y * W_hat      g_x = g_xhat * 1[|x| < 1]       STE of ops.py:68-73
+               g_what[o,c] = sum_n,p g_y * sign(x)
                g_W through the weight hook's own autograd graph (sign STE + alpha = mean|W|)
 
-The gradient convolutions have a real-valued operand (``g_y``), so they are plain fp32 library
-convolutions (MIOpen via ``aten::convolution_backward``) — only the forward is XNOR/popcount work.
-``W_hat = weight_pre_process(W)`` is computed by the hook under autograd, which makes the weight
-gradient flow exactly as in the reference composition; the forward kernel consumes the cached packed
-form of the same weights (re-packed automatically after every optimiser step: the cache is keyed on
-the Parameter's version counter).
+Each gradient GEMM has ONE real operand (``g_y``) and one that is exactly ternary (``sign(Wc)``, ``sign(x)``).
+For the 3x3 / stride 1 / padding 1 layers (13 of the 19 binary convs of a ResNet-18, 89 % of its MACs) both run
+on hand-written MFMA kernels (``csrc/grad.hip``: g split into fp16 hi + lo, the ternary side exact in fp16, two
+``v_mfma_f32_16x16x32_f16`` per product, fp32 accumulation — the rounding class of an fp32 convolution at 1/8 of
+its matrix time), with the STE mask fused into the input-gradient store.  Strided and 1x1 layers use the library
+(``aten::convolution_backward``).  ``W_hat = weight_pre_process(W)`` is computed by the hook under autograd, which
+makes the weight gradient flow exactly as in the reference composition; the forward kernel re-derives the packed
+form of the same weights on every training forward (``fastpath.packed_weight(..., fresh=True)``).
 
 Data-parallel training is ordinary ``DistributedDataParallel`` over RCCL (backend ``"nccl"``), one
 process per GPU: the binary layers are ``nn.Module``s with ordinary fp32 Parameters, so gradient
@@ -26,6 +28,7 @@ import torch.nn as nn
 from . import hipops
 
 ENABLED = True  # set False to force the torch composition in training (tests compare the two)
+BINARY_GRADS = True  # False: library fp32 gradient convolutions for every layer (tests / A-B timing)
 
 
 class BinaryConv2dTrainFn(torch.autograd.Function):
@@ -43,6 +46,17 @@ class BinaryConv2dTrainFn(torch.autograd.Function):
         x, w_hat = ctx.saved_tensors
         stride, padding, dilation, has_bias, bias_shape = ctx.conf
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
+        if BINARY_GRADS and hipops.grad_supported(x.shape, w_hat.shape, stride, padding, dilation):
+            g = g.contiguous()
+            gx = gw = gb = None
+            if need_x:
+                packed, alpha = hipops.grad_pack_weight(w_hat)
+                gx = hipops.bconv3x3_grad_input(g, x, packed, alpha)      # STE mask fused
+            if need_w:
+                gw = hipops.bconv3x3_grad_weight(g, x)
+            if need_b:
+                gb = g.sum(dim=(0, 2, 3))
+            return gx, gw, gb, None, None, None
         xh = torch.sign(x)
         gx, gw, gb = torch.ops.aten.convolution_backward(
             g.contiguous(), xh, w_hat, list(bias_shape) if has_bias else None, list(stride), list(padding),

@@ -1,0 +1,378 @@
+// grad.hip — binary-aware gradient kernels of a fake-binarised 3x3 / stride 1 / pad 1 convolution
+// (reference: the autograd graph of bnn/layers/conv.py:90-97 with the straight-through
+// estimator of bnn/ops.py:68-73, as trained by examples/imagenet.py:337-384).
+//
+// For out = conv2d(sign(x), What), What = sign(Wc) * alpha, and an incoming gradient g = dL/d out:
+//
+//     dL/d xhat [n,c,y,x]   = sum_{o,ky,kx} g[n,o,y+1-ky,x+1-kx] * What[o,c,ky,kx]          ("dgrad")
+//     dL/d x                = dL/d xhat * 1[|x| < 1]                                       (hard-tanh STE, ops.py:68-73)
+//     dL/d What[o,c,ky,kx]  = sum_{n,y,x} g[n,o,y,x] * sign(x)[n,c,y+ky-1,x+kx-1]           ("wgrad")
+//
+// Both are GEMMs with ONE real-valued operand (g) and one operand that is exactly {-1,0,+1} (sign(Wc), sign(x)) —
+// the library evaluates them as full fp32 convolutions (157 TF peak).  Here the real operand is split into
+// fp16 hi + lo (22 mantissa bits, |g * alpha| < 65504), the ternary operand is EXACT in fp16, and every product is
+// two v_mfma_f32_16x16x32_f16 with fp32 accumulation: the rounding class of an fp32 convolution at 2/16 of the
+// fp32-MFMA matrix time.  alpha[o] is folded into the real operand (g' = alpha[o] * g, one fp32 multiply when the
+// tile enters LDS), so the weight operand stays ternary.
+//
+// K-slots.  A row of W <= 64 pixels is given a power-of-two slot (8, 16, 32 or 64 pixels, zero filled); a 64-pixel
+// chunk of the GEMM's pixel dimension is 64/slot consecutive image rows.  An 8-element MFMA fragment never
+// straddles an image row, and 7x7 .. 56x56 images all use >= 87.5 % of the chunk.
+//
+// Other strides / kernel sizes (3 of the 19 binary convs of a ResNet-18 each: 11 % of its MACs) stay on the
+// library path: bnn_amd/training.py.
+#include "bnn_dev.h"
+
+namespace bnn {
+
+namespace grad {
+constexpr int NT = 256;          // 4 waves
+constexpr int APIX = 40;         // dgrad patch: halves per pixel (32 channels + 8 pad: 80 B, conflict-free b128 reads)
+constexpr int AROW = 72;         // wgrad: halves per row of 64 k-slots (+8 pad: 144 B)
+constexpr int SROW = 68;         // dgrad output staging: floats per channel row of 64 pixels
+}  // namespace grad
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+
+struct GradGeo {
+  int N, O, C, H, W;
+  int slot, RR;  // pixels per row slot (pow2 >= W, >= 8); row slots per 64-pixel chunk = 64 / slot
+  int R;         // image rows a chunk advances by = min(RR, H)
+  int chunks;    // chunks per image = ceil(H / R)
+  int gshift;    // log2(slot / 8): 8-pixel groups per row slot
+};
+
+__device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const _Float16 h = (_Float16)v[e];
+    hi[e] = h;
+    lo[e] = (_Float16)(v[e] - (float)h);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- weight operand
+// alpha[o] = max |What[o,:,:,:]| (What = +-alpha or 0 exactly) and sign(What) in MFMA B-fragment order for dgrad:
+//   Bp[ob][tap][cs][lane][e] = sign(What[o = 32 ob + 8 (lane>>4) + e][c = 16 cs + (lane&15)][tap])   (fp16)
+__global__ __launch_bounds__(64) void grad_alpha_kernel(const float* __restrict__ what, int per_o,
+                                                        float* __restrict__ alpha) {
+  const float* p = what + (size_t)blockIdx.x * per_o;
+  float m = 0.0f;
+  for (int i = threadIdx.x; i < per_o; i += 64) m = fmaxf(m, fabsf(p[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if (threadIdx.x == 0) alpha[blockIdx.x] = m;
+}
+
+__global__ __launch_bounds__(64) void grad_pack_weight_kernel(const float* __restrict__ what, int O, int C,
+                                                              int CS, half8* __restrict__ Bp) {
+  const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+  const int cs = blockIdx.x % CS, tap = (blockIdx.x / CS) % 9, ob = blockIdx.x / (CS * 9);
+  const int c = 16 * cs + li;
+  half8 b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int o = 32 * ob + 8 * lg + e;
+    const float v = (o < O && c < C) ? what[((size_t)o * C + c) * 9 + tap] : 0.0f;
+    b[e] = (_Float16)(v > 0.0f ? 1.0f : v < 0.0f ? -1.0f : 0.0f);
+  }
+  Bp[(size_t)blockIdx.x * 64 + lane] = b;
+}
+
+// ------------------------------------------------------------------------------------------------- dgrad
+// GEMM: M = pixels (one 64-slot chunk of one image per workgroup), N = input channels c (16 * NSUB per wave,
+// 64 * NSUB per workgroup, grid.y blocks), K = (o, tap): loop over blocks of 32 output channels; per block the
+// chunk's rows +- 1 of g' = alpha[o] * g enter LDS as fp16 hi / lo, [pixel][32 o]; 9 taps = 9 k-steps of 32.
+// Epilogue: accumulators -> LDS [c][pixel] -> coalesced NCHW stores with the STE mask 1[|x| < 1].
+template <int NSUB>
+__global__ __launch_bounds__(grad::NT) void dgrad3x3_kernel(const float* __restrict__ g,
+                                                            const float* __restrict__ alpha,
+                                                            const half8* __restrict__ Bp,
+                                                            const float* __restrict__ xin,
+                                                            float* __restrict__ gx, const GradGeo q) {
+  using namespace grad;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int PW = q.W + 2, PP = (q.R + 2) * PW;  // patch width / pixels (halo included)
+  _Float16* pa_hi = reinterpret_cast<_Float16*>(lds_raw);
+  _Float16* pa_lo = pa_hi + (size_t)PP * APIX;
+  float* stage = reinterpret_cast<float*>(lds_raw);  // reused after the K loop
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int n = blockIdx.x / q.chunks, y0 = (blockIdx.x - n * q.chunks) * q.R;
+  const int HW = q.H * q.W;
+  const int CS = (q.C + 15) / 16, OB = (q.O + 31) / 32;
+  const int cs0 = (blockIdx.y * 4 + wave) * NSUB;  // first 16-channel group of this wave
+
+  // A-fragment base addresses of the 4 pixel sub-tiles: pixel m = 16 s + li -> (row ry, column x) of the chunk
+  int abase[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int m = 16 * s + li;
+    int ry = m / q.slot, x = m - ry * q.slot;
+    if (x >= q.W || ry >= q.R) { ry = 0; x = 0; }  // dead slot: any valid address, result is never stored
+    abase[s] = ((ry + 2) * PW + (x + 2)) * APIX + 8 * lg;  // tap (ky,kx) reads patch pixel (ry+2-ky, x+2-kx)
+  }
+
+  f32x4 acc[4][NSUB];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) acc[s][ns] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int ob = 0; ob < OB; ++ob) {
+    __syncthreads();  // previous block's patch is consumed
+    // ---- fill: item = (patch pixel, group of 8 output channels); 8 loads (coalesced along x across lanes)
+    for (int item = tid; item < PP * 4; item += NT) {
+      const int pix = item % PP, og = item / PP;
+      const int pr = pix / PW, pc = pix - pr * PW;
+      const int y = y0 - 1 + pr, x = pc - 1;
+      const bool in = (unsigned)y < (unsigned)q.H && (unsigned)x < (unsigned)q.W;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int o = 32 * ob + 8 * og + e;
+        const bool ok = in && o < q.O;
+        const float gv = g[ok ? ((size_t)n * q.O + o) * HW + y * q.W + x : 0];
+        const float av = alpha[ok ? o : 0];
+        v[e] = ok ? gv * av : 0.0f;
+      }
+      half8 hi, lo;
+      split8(v, hi, lo);
+      *reinterpret_cast<half8*>(pa_hi + pix * APIX + 8 * og) = hi;
+      *reinterpret_cast<half8*>(pa_lo + pix * APIX + 8 * og) = lo;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int toff = (ky * PW + kx) * APIX;
+      half8 b[NSUB];
+#pragma unroll
+      for (int ns = 0; ns < NSUB; ++ns) {
+        const int cs = cs0 + ns;
+        b[ns] = cs < CS ? Bp[((size_t)(ob * 9 + tap) * CS + cs) * 64 + lane] : half8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const half8 ah = *reinterpret_cast<const half8*>(pa_hi + abase[s] - toff);
+        const half8 al = *reinterpret_cast<const half8*>(pa_lo + abase[s] - toff);
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) {
+          acc[s][ns] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b[ns], acc[s][ns], 0, 0, 0);
+          acc[s][ns] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b[ns], acc[s][ns], 0, 0, 0);
+        }
+      }
+    }
+  }
+  __syncthreads();  // the patch is dead: its LDS becomes the [channel][pixel] staging tile
+  // D layout: column = li (channel within the 16-group), row = 4 lg + r (pixel within the sub-tile)
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        stage[((wave * NSUB + ns) * 16 + li) * SROW + 16 * s + 4 * lg + r] = acc[s][ns][r];
+  __syncthreads();
+  const int c_blk = blockIdx.y * 64 * NSUB;
+  for (int item = tid; item < 64 * NSUB * 64; item += NT) {
+    const int m = item & 63, cl = item >> 6;
+    const int ry = m / q.slot, x = m - ry * q.slot;
+    const int c = c_blk + cl, y = y0 + ry;
+    if (x < q.W && ry < q.R && y < q.H && c < q.C) {
+      const size_t o = ((size_t)n * q.C + c) * HW + y * q.W + x;
+      const float v = stage[cl * SROW + m];
+      gx[o] = fabsf(xin[o]) < 1.0f ? v : 0.0f;  // hard-tanh straight-through estimator (NaN x -> 0, like masked_fill)
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- wgrad
+// GEMM: M = 64 output channels o (one 16-row sub-tile per wave), N = 32 input channels x 9 taps (18 sub-tiles of
+// 16 columns, all of them in every wave: 72 accumulator registers), K = pixels: the workgroup walks the 64-slot
+// chunks of its share of the images (split-K over grid.x; partial sums are added by the caller).
+// Per chunk: g (fp16 hi / lo, [o][64 slots]) and sign(x) with one halo row above and below, stored THREE times,
+// shifted by kx - 1 pixels, so that every tap's 8-pixel fragment is a 16-byte aligned LDS read.
+__global__ __launch_bounds__(grad::NT) void wgrad3x3_kernel(const float* __restrict__ g,
+                                                            const float* __restrict__ xin,
+                                                            float* __restrict__ part, const GradGeo q,
+                                                            int imgs_per_split) {
+  using namespace grad;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int BR = q.RR + 2;                   // sign(x) rows per chunk (all row slots + halo, zero where no image row)
+  const int BROW = q.slot + 8;               // halves per row (16-byte aligned, bank spreading)
+  _Float16* a_hi = reinterpret_cast<_Float16*>(lds_raw);
+  _Float16* a_lo = a_hi + 64 * AROW;
+  _Float16* bsx = a_lo + 64 * AROW;          // [kx][c 0..31][row 0..BR-1][BROW]
+  const int bplane = 32 * BR * BROW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int o0 = blockIdx.z * 64, c0 = blockIdx.y * 32;
+  const int n_begin = blockIdx.x * imgs_per_split;
+  const int n_end = min(q.N, n_begin + imgs_per_split);
+  const int HW = q.H * q.W;
+  const int groups = 1 << q.gshift;          // 8-pixel groups per row slot
+
+  f32x4 acc[18];
+#pragma unroll
+  for (int j = 0; j < 18; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses of the two k-steps: k = 32 ks + 8 lg -> (row, column group) of the chunk
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int kk = 32 * ks + 8 * lg;
+    const int ry = kk / q.slot, xg = kk - ry * q.slot;
+    a_off[ks] = (16 * wave + li) * AROW + kk;
+    b_off[ks] = (li * BR + ry) * BROW + xg;    // + (half * 16 * BR + ky) * BROW + kx * bplane per sub-tile
+  }
+
+  for (int n = n_begin; n < n_end; ++n) {
+    for (int y0 = 0; y0 < q.H; y0 += q.R) {
+      __syncthreads();
+      // ---- g rows y0 .. y0+R-1 of 64 output channels
+      for (int item = tid; item < 64 * 8; item += NT) {   // 64 channels x 8 groups of 8 k-slots
+        const int g8 = item & 7, ol = item >> 3;
+        const int ry = g8 >> q.gshift, j = g8 & (groups - 1);
+        const int o = o0 + ol, y = y0 + ry;
+        const bool rowok = o < q.O && ry < q.R && y < q.H;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int x = 8 * j + e;
+          const bool ok = rowok && x < q.W;
+          const float gv = g[ok ? ((size_t)n * q.O + o) * HW + y * q.W + x : 0];
+          v[e] = ok ? gv : 0.0f;
+        }
+        half8 hi, lo;
+        split8(v, hi, lo);
+        *reinterpret_cast<half8*>(a_hi + ol * AROW + 8 * g8) = hi;
+        *reinterpret_cast<half8*>(a_lo + ol * AROW + 8 * g8) = lo;
+      }
+      // ---- sign(x) rows y0-1 .. y0+R of 32 input channels, three shifted copies: copy kx holds sx[p + kx - 1]
+      for (int item = tid; item < 32 * BR * groups; item += NT) {
+        const int j = item & (groups - 1), t = item >> q.gshift;
+        const int cl = t / BR, pr = t - cl * BR;
+        const int c = c0 + cl, y = y0 - 1 + pr;
+        // rows past the chunk's own R rows + halo belong to the next chunk: they stay zero here
+        const bool rowok = c < q.C && pr <= q.R + 1 && (unsigned)y < (unsigned)q.H;
+        _Float16 s[10];  // sx[8j-1 .. 8j+8]
+#pragma unroll
+        for (int e = 0; e < 10; ++e) {
+          const int x = 8 * j - 1 + e;
+          const bool ok = rowok && (unsigned)x < (unsigned)q.W;
+          const float xv = xin[ok ? ((size_t)n * q.C + c) * HW + y * q.W + x : 0];
+          s[e] = (_Float16)((ok && xv > 0.0f) ? 1.0f : (ok && xv < 0.0f) ? -1.0f : 0.0f);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          half8 hv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) hv[e] = s[e + kx];
+          *reinterpret_cast<half8*>(bsx + kx * bplane + (cl * BR + pr) * BROW + 8 * j) = hv;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const half8 ah = *reinterpret_cast<const half8*>(a_hi + a_off[ks]);
+        const half8 al = *reinterpret_cast<const half8*>(a_lo + a_off[ks]);
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+          const int half = j / 9, tap = j - half * 9, ky = tap / 3, kx = tap - ky * 3;
+          const half8 b = *reinterpret_cast<const half8*>(bsx + kx * bplane + b_off[ks] +
+                                                          (half * 16 * BR + ky) * BROW);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D layout: column = li (input channel within the half), row = 4 lg + r (output channel within the wave's 16)
+  float* dst = part + (size_t)blockIdx.x * q.O * q.C * 9;
+#pragma unroll
+  for (int j = 0; j < 18; ++j) {
+    const int half = j / 9, tap = j - half * 9;
+    const int c = c0 + 16 * half + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = o0 + 16 * wave + 4 * lg + r;
+      if (o < q.O && c < q.C) dst[((size_t)o * q.C + c) * 9 + tap] = acc[j][r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- host side
+static bool make_geo(int N, int O, int C, int H, int W, GradGeo* q) {
+  if (N <= 0 || O <= 0 || C <= 0 || H <= 0 || W <= 0 || W > 64) return false;
+  int slot = 8;
+  while (slot < W) slot *= 2;
+  q->N = N; q->O = O; q->C = C; q->H = H; q->W = W;
+  q->slot = slot;
+  q->RR = 64 / slot;
+  q->R = q->RR < H ? q->RR : H;
+  q->chunks = (H + q->R - 1) / q->R;
+  q->gshift = 0;
+  while ((8 << q->gshift) < slot) ++q->gshift;
+  return true;
+}
+
+size_t grad_weight_pack_bytes(int O, int C) {
+  return (size_t)((O + 31) / 32) * 9 * ((C + 15) / 16) * 64 * sizeof(half8);
+}
+
+int launch_grad_pack_weight(const float* what, int O, int C, void* packed, float* alpha, hipStream_t s) {
+  const int CS = (C + 15) / 16, OB = (O + 31) / 32;
+  hipLaunchKernelGGL(grad_alpha_kernel, dim3(O), dim3(64), 0, s, what, C * 9, alpha);
+  hipLaunchKernelGGL(grad_pack_weight_kernel, dim3(OB * 9 * CS), dim3(64), 0, s, what, O, C, CS,
+                     static_cast<half8*>(packed));
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+int launch_dgrad3x3(const float* g, const float* alpha, const void* packed, const float* xin, float* gx, int N,
+                    int O, int C, int H, int W, hipStream_t s) {
+  using namespace grad;
+  GradGeo q;
+  if (!make_geo(N, O, C, H, W, &q)) return BNN_HIP_ERR_UNSUPPORTED;
+  const int PP = (q.R + 2) * (W + 2);
+  const int nsub = C > 64 ? 2 : 1;
+  const size_t patch = (size_t)2 * PP * APIX * sizeof(_Float16);
+  const size_t stage = (size_t)64 * nsub * SROW * sizeof(float);
+  const size_t lds = patch > stage ? patch : stage;
+  const dim3 grid((unsigned)(N * q.chunks), (unsigned)((C + 64 * nsub - 1) / (64 * nsub)));
+  if (nsub == 2)
+    hipLaunchKernelGGL(dgrad3x3_kernel<2>, grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed), xin,
+                       gx, q);
+  else
+    hipLaunchKernelGGL(dgrad3x3_kernel<1>, grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed), xin,
+                       gx, q);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+int grad_wgrad_splits(int N, int O, int C) {
+  const int blocks = ((O + 63) / 64) * ((C + 31) / 32);
+  int s = (1024 + blocks - 1) / blocks;  // ~4 workgroups per CU in total
+  if (s > N) s = N;
+  if (s < 1) s = 1;
+  const int per = (N + s - 1) / s;
+  return (N + per - 1) / per;
+}
+
+int launch_wgrad3x3(const float* g, const float* xin, float* part, int splits, int N, int O, int C, int H, int W,
+                    hipStream_t s) {
+  using namespace grad;
+  GradGeo q;
+  if (!make_geo(N, O, C, H, W, &q)) return BNN_HIP_ERR_UNSUPPORTED;
+  if (splits < 1 || splits > N) return BNN_HIP_ERR_INVALID_ARG;
+  const int per = (N + splits - 1) / splits;
+  if ((N + per - 1) / per != splits) return BNN_HIP_ERR_INVALID_ARG;
+  const size_t lds = (size_t)(2 * 64 * AROW + 3 * 32 * (q.RR + 2) * (q.slot + 8)) * sizeof(_Float16);
+  const dim3 grid((unsigned)splits, (unsigned)((C + 31) / 32), (unsigned)((O + 63) / 64));
+  hipLaunchKernelGGL(wgrad3x3_kernel, grid, dim3(NT), lds, s, g, xin, part, q, per);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+}  // namespace bnn

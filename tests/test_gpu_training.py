@@ -183,3 +183,63 @@ def test_torch_custom_ops_forward_and_autograd():
     z = torch.ops.bnn_amd.binary_linear(lx, lw, None, None, False, True)
     zr = torch.nn.functional.linear(torch.sign(lx), torch.sign(lw) * lw.abs().mean(dim=1, keepdim=True))
     assert z.shape == (3, 5, 11) and torch.allclose(z, zr, rtol=1e-5, atol=1e-5)
+
+
+GRAD_SHAPES = [  # (N, O, C, H, W): every slot width (8/16/32/64), channel tails, multi-chunk images, both NSUB variants
+    (3, 64, 64, 12, 10), (2, 40, 70, 7, 7), (2, 128, 96, 14, 14), (2, 64, 64, 56, 56), (2, 512, 512, 7, 7),
+    (1, 32, 16, 5, 64), (5, 130, 200, 28, 28), (2, 16, 8, 1, 1), (3, 96, 33, 9, 17), (1, 256, 256, 14, 14),
+]
+
+
+@pytest.mark.parametrize("shape", GRAD_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_binary_gradient_kernels_match_library_backward(shape):
+    """csrc/grad.hip (MFMA: g split into fp16 hi+lo, ternary operand exact) against aten::convolution_backward on
+    the same operands: dL/dx (with the STE mask) and dL/dWhat, fp32-convolution rounding class."""
+    from bnn_amd import hipops
+    N, O, C, H, W = shape
+    x = dev((gen.normal(gen.seed_of("gx", shape), (N, C, H, W)) * 0.9).astype(np.float32))
+    x.view(-1)[::7] = 0.0                                            # exact zeros: sign(0) == 0
+    g = dev(gen.normal(gen.seed_of("gg", shape), (N, O, H, W)))
+    w = dev(gen.conv_weight("kaiming", gen.seed_of("gw", shape), (O, C, 3, 3)))
+    w.view(-1)[::11] = 0.0                                           # and zero weights
+    w_hat = torch.sign(w) * w.abs().flatten(1).mean(1).view(-1, 1, 1, 1)
+    assert hipops.grad_supported(x.shape, w_hat.shape, 1, 1, 1)
+    packed, alpha = hipops.grad_pack_weight(w_hat)
+    assert torch.equal(alpha, w_hat.abs().flatten(1).amax(1))
+    gx = hipops.bconv3x3_grad_input(g, x, packed, alpha)
+    gw = hipops.bconv3x3_grad_weight(g, x)
+    rx, rw, _ = torch.ops.aten.convolution_backward(g, torch.sign(x), w_hat, None, [1, 1], [1, 1], [1, 1], False,
+                                                    [0, 0], 1, [True, True, False])
+    rx = rx.masked_fill(x.abs() >= 1, 0)
+    assert gx.shape == rx.shape and gw.shape == rw.shape
+    assert ((gx == 0) | (x.abs() < 1)).all() and ((x.abs() >= 1) <= (gx == 0)).all()
+    assert torch.allclose(gx, rx, rtol=1e-4, atol=2e-5 * float(rx.abs().max()))
+    assert torch.allclose(gw, rw, rtol=1e-4, atol=2e-5 * float(rw.abs().max()))
+    # fp64 reference: the error is that of an fp32 convolution, not of fp16 operands
+    rx64, rw64, _ = torch.ops.aten.convolution_backward(g.double(), torch.sign(x).double(), w_hat.double(), None,
+                                                        [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, True, False])
+    rx64 = rx64.masked_fill(x.abs() >= 1, 0)
+    assert float((gx.double() - rx64).abs().max()) <= 4e-6 * float(rx64.abs().max())
+    assert float((gw.double() - rw64).abs().max()) <= 4e-6 * float(rw64.abs().max())
+
+
+def test_binary_gradient_kernels_are_used_and_can_be_switched_off():
+    layer = _layer(64, 64, 3, 1, 1, False, False, False, seed=33)
+    x = (gen.normal(8, (2, 64, 14, 14)) * 0.8).astype(np.float32)
+    g = gen.normal(9, (2, 64, 14, 14))
+    from bnn_amd import native
+    n0 = native.launch_count()
+    y1, gx1, gp1 = _grads(layer, x, g, enabled=True)
+    launches_binary = native.launch_count() - n0
+    training.BINARY_GRADS = False
+    try:
+        n0 = native.launch_count()
+        y0, gx0, gp0 = _grads(layer, x, g, enabled=True)
+        launches_library = native.launch_count() - n0
+    finally:
+        training.BINARY_GRADS = True
+    assert launches_binary == launches_library + 4      # alpha + sign fragments + dgrad + wgrad
+    assert torch.equal(y1, y0)
+    assert torch.allclose(gx1, gx0, rtol=1e-4, atol=2e-5 * float(gx0.abs().max()))
+    for n in gp0:
+        assert torch.allclose(gp1[n], gp0[n], rtol=1e-3, atol=1e-4 * float(gp0[n].abs().max()) + 1e-7), n

@@ -9,8 +9,9 @@ from bnn_amd.models import resnet18
 from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer
 dev = torch.device("cuda:0")
 B = int(os.environ.get("BATCH", "64"))
-def run(enabled, steps=6):
+def run(enabled, steps=6, binary_grads=True):
     training.ENABLED = enabled
+    training.BINARY_GRADS = binary_grads
     torch.manual_seed(0)
     net = resnet18(num_classes=1000)
     cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
@@ -26,5 +27,6 @@ def run(enabled, steps=6):
         loss.backward(); opt.step()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
-a = run(True); b = run(False)
-print("batch %d: HIP-forward training step %.1f ms (%.0f img/s); composition %.1f ms (%.0f img/s)" % (B, a, B / a * 1e3, b, B / b * 1e3))
+a = run(True); a2 = run(True, binary_grads=False); b = run(False)
+print("batch %d: training step  HIP forward + MFMA gradient kernels %.1f ms (%.0f img/s) | HIP forward + library backward "
+      "%.1f ms (%.0f img/s) | composition %.1f ms (%.0f img/s)" % (B, a, B / a * 1e3, a2, B / a2 * 1e3, b, B / b * 1e3))
