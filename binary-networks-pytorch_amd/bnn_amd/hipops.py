@@ -397,8 +397,8 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
 
 
 def grad_supported(x_shape, w_shape, stride, padding, dilation) -> bool:
-    """Shapes the binary-aware gradient kernels cover: 3x3 / stride 1 / padding 1 / dilation 1, width <= 64."""
-    return (tuple(w_shape[2:]) == (3, 3) and _pair(stride) == (1, 1) and _pair(padding) == (1, 1)
+    """Shapes the binary-aware gradient kernels cover: 3x3 / stride 1 or 2 / padding 1 / dilation 1, width <= 64."""
+    return (tuple(w_shape[2:]) == (3, 3) and _pair(stride) in ((1, 1), (2, 2)) and _pair(padding) == (1, 1)
             and _pair(dilation) == (1, 1) and x_shape[3] <= 64 and x_shape[0] > 0)
 
 
@@ -415,33 +415,41 @@ def grad_pack_weight(w_hat: torch.Tensor):
     return packed, alpha
 
 
-def bconv3x3_grad_input(g: torch.Tensor, x: torch.Tensor, packed: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
-    """dL/dx of the binary 3x3/s1/p1 conv incl. the hard-tanh STE mask (bnn/ops.py:68-73)."""
+def _grad_shapes(g: torch.Tensor, x: torch.Tensor, stride: int):
+    N, C, H, W = x.shape
+    O = g.shape[1]
+    if tuple(g.shape) != (N, O, (H - 1) // stride + 1, (W - 1) // stride + 1):
+        raise native.NativeError(f"bnn_amd: grad_output shape {tuple(g.shape)} does not belong to input "
+                                 f"{tuple(x.shape)} at stride {stride}")
+    return N, O, C, H, W
+
+
+def bconv3x3_grad_input(g: torch.Tensor, x: torch.Tensor, packed: torch.Tensor, alpha: torch.Tensor,
+                        stride: int = 1) -> torch.Tensor:
+    """dL/dx of the binary 3x3/p1 conv incl. the hard-tanh STE mask (bnn/ops.py:68-73)."""
     g = _require_cuda_f32(g, "grad_output")
     x = _require_cuda_f32(x, "input")
     lib = native.require()
-    N, O, H, W = g.shape
-    C = x.shape[1]
+    N, O, C, H, W = _grad_shapes(g, x, stride)
     with torch.cuda.device(g.device):
         gx = torch.empty_like(x)
         native.check(lib.bnn_hip_bconv3x3_grad_input_f32(g.data_ptr(), alpha.data_ptr(), packed.data_ptr(),
-                                                         x.data_ptr(), gx.data_ptr(), N, O, C, H, W,
+                                                         x.data_ptr(), gx.data_ptr(), N, O, C, H, W, stride,
                                                          _stream(g.device)), "bnn_hip_bconv3x3_grad_input_f32")
     return gx
 
 
-def bconv3x3_grad_weight(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dL/dWhat [O,C,3,3] of the binary 3x3/s1/p1 conv: correlation of g with sign(x)."""
+def bconv3x3_grad_weight(g: torch.Tensor, x: torch.Tensor, stride: int = 1) -> torch.Tensor:
+    """dL/dWhat [O,C,3,3] of the binary 3x3/p1 conv: correlation of g with sign(x)."""
     g = _require_cuda_f32(g, "grad_output")
     x = _require_cuda_f32(x, "input")
     lib = native.require()
-    N, O, H, W = g.shape
-    C = x.shape[1]
+    N, O, C, H, W = _grad_shapes(g, x, stride)
     splits = int(lib.bnn_hip_bconv3x3_grad_weight_splits(N, O, C))
     with torch.cuda.device(g.device):
         part = torch.empty((splits, O, C, 3, 3), dtype=torch.float32, device=g.device)
         native.check(lib.bnn_hip_bconv3x3_grad_weight_f32(g.data_ptr(), x.data_ptr(), part.data_ptr(), splits,
-                                                          N, O, C, H, W, _stream(g.device)),
+                                                          N, O, C, H, W, stride, _stream(g.device)),
                      "bnn_hip_bconv3x3_grad_weight_f32")
         return part[0] if splits == 1 else part.sum(0)
 

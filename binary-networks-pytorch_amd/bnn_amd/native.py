@@ -122,9 +122,9 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_grad_weight_pack_bytes.restype = ctypes.c_size_t
     lib.bnn_hip_grad_weight_pack_bytes.argtypes = [_i, _i]
     lib.bnn_hip_grad_pack_weight_f32.argtypes = [_vp, _i, _i, _vp, _vp, _vp]
-    lib.bnn_hip_bconv3x3_grad_input_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
+    lib.bnn_hip_bconv3x3_grad_input_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
     lib.bnn_hip_bconv3x3_grad_weight_splits.argtypes = [_i, _i, _i]
-    lib.bnn_hip_bconv3x3_grad_weight_f32.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
+    lib.bnn_hip_bconv3x3_grad_weight_f32.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]
     lib.bnn_hip_probe_int_alu.argtypes = [_i, _i, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), _vp]
 

@@ -8,10 +8,10 @@
                g_W through the weight hook's own autograd graph (sign STE + alpha = mean|W|)
 
 Each gradient GEMM has ONE real operand (``g_y``) and one that is exactly ternary (``sign(Wc)``, ``sign(x)``).
-For the 3x3 / stride 1 / padding 1 layers (13 of the 19 binary convs of a ResNet-18, 89 % of its MACs) both run
+For the 3x3 / padding 1 layers of stride 1 or 2 (16 of the 19 binary convs of a ResNet-18, 99 % of its MACs) both run
 on hand-written MFMA kernels (``csrc/grad.hip``: g split into fp16 hi + lo, the ternary side exact in fp16, two
 ``v_mfma_f32_16x16x32_f16`` per product, fp32 accumulation — the rounding class of an fp32 convolution at 1/8 of
-its matrix time), with the STE mask fused into the input-gradient store.  Strided and 1x1 layers use the library
+its matrix time), with the STE mask fused into the input-gradient store.  1x1 (shortcut) layers use the library
 (``aten::convolution_backward``).  ``W_hat = weight_pre_process(W)`` is computed by the hook under autograd, which
 makes the weight gradient flow exactly as in the reference composition; the forward kernel re-derives the packed
 form of the same weights on every training forward (``fastpath.packed_weight(..., fresh=True)``).
@@ -51,9 +51,9 @@ class BinaryConv2dTrainFn(torch.autograd.Function):
             gx = gw = gb = None
             if need_x:
                 packed, alpha = hipops.grad_pack_weight(w_hat)
-                gx = hipops.bconv3x3_grad_input(g, x, packed, alpha)      # STE mask fused
+                gx = hipops.bconv3x3_grad_input(g, x, packed, alpha, stride[0])   # STE mask fused
             if need_w:
-                gw = hipops.bconv3x3_grad_weight(g, x)
+                gw = hipops.bconv3x3_grad_weight(g, x, stride[0])
             if need_b:
                 gb = g.sum(dim=(0, 2, 3))
             return gx, gw, gb, None, None, None

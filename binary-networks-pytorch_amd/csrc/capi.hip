@@ -218,21 +218,22 @@ int bnn_hip_grad_pack_weight_f32(const float* w_hat, int O, int C, void* packed,
   return bnn::launch_grad_pack_weight(w_hat, O, C, packed, alpha, static_cast<hipStream_t>(stream));
 }
 
-static int check_grad_shape(int N, int O, int C, int H, int W) {
+static int check_grad_shape(int N, int O, int C, int H, int W, int stride) {
   if (N <= 0 || O <= 0 || C <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (stride != 1 && stride != 2) return BNN_HIP_ERR_UNSUPPORTED;
   if (W > 64) return BNN_HIP_ERR_UNSUPPORTED;
   if ((long long)N * O * H * W > kMaxElems || (long long)N * C * H * W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
   return BNN_HIP_OK;
 }
 
 int bnn_hip_bconv3x3_grad_input_f32(const float* g, const float* alpha, const void* packed, const float* x,
-                                    float* gx, int N, int O, int C, int H, int W, void* stream) {
+                                    float* gx, int N, int O, int C, int H, int W, int stride, void* stream) {
   if (!g || !alpha || !packed || !x || !gx) return BNN_HIP_ERR_INVALID_ARG;
-  const int st = check_grad_shape(N, O, C, H, W);
+  const int st = check_grad_shape(N, O, C, H, W, stride);
   if (st != BNN_HIP_OK) return st;
   if (!aligned(packed, 16)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
-  return bnn::launch_dgrad3x3(g, alpha, packed, x, gx, N, O, C, H, W, static_cast<hipStream_t>(stream));
+  return bnn::launch_dgrad3x3(g, alpha, packed, x, gx, N, O, C, H, W, stride, static_cast<hipStream_t>(stream));
 }
 
 int bnn_hip_bconv3x3_grad_weight_splits(int N, int O, int C) {
@@ -240,12 +241,12 @@ int bnn_hip_bconv3x3_grad_weight_splits(int N, int O, int C) {
 }
 
 int bnn_hip_bconv3x3_grad_weight_f32(const float* g, const float* x, float* partial, int splits, int N, int O,
-                                     int C, int H, int W, void* stream) {
+                                     int C, int H, int W, int stride, void* stream) {
   if (!g || !x || !partial) return BNN_HIP_ERR_INVALID_ARG;
-  const int st = check_grad_shape(N, O, C, H, W);
+  const int st = check_grad_shape(N, O, C, H, W, stride);
   if (st != BNN_HIP_OK) return st;
   g_launches.fetch_add(1, std::memory_order_relaxed);
-  return bnn::launch_wgrad3x3(g, x, partial, splits, N, O, C, H, W, static_cast<hipStream_t>(stream));
+  return bnn::launch_wgrad3x3(g, x, partial, splits, N, O, C, H, W, stride, static_cast<hipStream_t>(stream));
 }
 
 int bnn_hip_pack_weight_f32(const float* w, int O, int C, int KH, int KW, int center,

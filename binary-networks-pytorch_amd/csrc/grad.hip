@@ -19,8 +19,10 @@
 // chunk of the GEMM's pixel dimension is 64/slot consecutive image rows.  An 8-element MFMA fragment never
 // straddles an image row, and 7x7 .. 56x56 images all use >= 87.5 % of the chunk.
 //
-// Other strides / kernel sizes (3 of the 19 binary convs of a ResNet-18 each: 11 % of its MACs) stay on the
-// library path: bnn_amd/training.py.
+// Stride 2 (the first conv of a down-sampling stage) uses the same kernels: wgrad reads sign(x) at stride 2 (its
+// shifted LDS copies are de-interleaved), dgrad treats g as zero-upsampled by 2 when the patch is filled (3/4 of
+// its MFMA work multiplies zeros — still several times faster than the fp32 library kernel).  1x1 convolutions
+// (the shortcut branches: 0.4 % of a ResNet-18's MACs) stay on the library path: bnn_amd/training.py.
 #include "bnn_dev.h"
 
 namespace bnn {
@@ -36,7 +38,11 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 
 struct GradGeo {
-  int N, O, C, H, W;
+  int N, O, C;
+  int H, W;      // the pixel domain the 64-slot chunks tile: x / gx for dgrad, g for wgrad
+  int Hx, Wx;    // input tensor x (and gx): [N,C,Hx,Wx]
+  int Hg, Wg;    // gradient tensor g:       [N,O,Hg,Wg],  Hg = (Hx - 1) / st + 1
+  int st;        // convolution stride (1 or 2)
   int slot, RR;  // pixels per row slot (pow2 >= W, >= 8); row slots per 64-pixel chunk = 64 / slot
   int R;         // image rows a chunk advances by = min(RR, H)
   int chunks;    // chunks per image = ceil(H / R)
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(grad::NT) void dgrad3x3_kernel(const float* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int n = blockIdx.x / q.chunks, y0 = (blockIdx.x - n * q.chunks) * q.R;
-  const int HW = q.H * q.W;
+  const int HW = q.H * q.W, HGg = q.Hg * q.Wg;
   const int CS = (q.C + 15) / 16, OB = (q.O + 31) / 32;
   const int cs0 = (blockIdx.y * 4 + wave) * NSUB;  // first 16-channel group of this wave
 
@@ -128,13 +134,15 @@ __global__ __launch_bounds__(grad::NT) void dgrad3x3_kernel(const float* __restr
       const int pix = item % PP, og = item / PP;
       const int pr = pix / PW, pc = pix - pr * PW;
       const int y = y0 - 1 + pr, x = pc - 1;
-      const bool in = (unsigned)y < (unsigned)q.H && (unsigned)x < (unsigned)q.W;
+      // stride 2: g zero-upsampled — only even (y, x) carry a value, g[y/2][x/2]
+      const int yg = q.st == 2 ? y >> 1 : y, xg = q.st == 2 ? x >> 1 : x;
+      const bool in = y >= 0 && x >= 0 && yg < q.Hg && xg < q.Wg && (q.st == 1 || ((y | x) & 1) == 0);
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int o = 32 * ob + 8 * og + e;
         const bool ok = in && o < q.O;
-        const float gv = g[ok ? ((size_t)n * q.O + o) * HW + y * q.W + x : 0];
+        const float gv = g[ok ? ((size_t)n * q.O + o) * HGg + yg * q.Wg + xg : 0];
         const float av = alpha[ok ? o : 0];
         v[e] = ok ? gv * av : 0.0f;
       }
@@ -195,13 +203,14 @@ __global__ __launch_bounds__(grad::NT) void dgrad3x3_kernel(const float* __restr
 // chunks of its share of the images (split-K over grid.x; partial sums are added by the caller).
 // Per chunk: g (fp16 hi / lo, [o][64 slots]) and sign(x) with one halo row above and below, stored THREE times,
 // shifted by kx - 1 pixels, so that every tap's 8-pixel fragment is a 16-byte aligned LDS read.
+template <int ST>
 __global__ __launch_bounds__(grad::NT) void wgrad3x3_kernel(const float* __restrict__ g,
                                                             const float* __restrict__ xin,
                                                             float* __restrict__ part, const GradGeo q,
                                                             int imgs_per_split) {
   using namespace grad;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int BR = q.RR + 2;                   // sign(x) rows per chunk (all row slots + halo, zero where no image row)
+  const int BR = ST * q.RR + 2;              // sign(x) rows per chunk (all row slots + halo, zero where no image row)
   const int BROW = q.slot + 8;               // halves per row (16-byte aligned, bank spreading)
   _Float16* a_hi = reinterpret_cast<_Float16*>(lds_raw);
   _Float16* a_lo = a_hi + 64 * AROW;
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(grad::NT) void wgrad3x3_kernel(const float* __restr
   const int o0 = blockIdx.z * 64, c0 = blockIdx.y * 32;
   const int n_begin = blockIdx.x * imgs_per_split;
   const int n_end = min(q.N, n_begin + imgs_per_split);
-  const int HW = q.H * q.W;
+  const int HW = q.H * q.W, HWx = q.Hx * q.Wx;
   const int groups = 1 << q.gshift;          // 8-pixel groups per row slot
 
   f32x4 acc[18];
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(grad::NT) void wgrad3x3_kernel(const float* __restr
     const int kk = 32 * ks + 8 * lg;
     const int ry = kk / q.slot, xg = kk - ry * q.slot;
     a_off[ks] = (16 * wave + li) * AROW + kk;
-    b_off[ks] = (li * BR + ry) * BROW + xg;    // + (half * 16 * BR + ky) * BROW + kx * bplane per sub-tile
+    b_off[ks] = (li * BR + ST * ry) * BROW + xg;  // + (half * 16 * BR + ky) * BROW + kx * bplane per sub-tile
   }
 
   for (int n = n_begin; n < n_end; ++n) {
@@ -252,26 +261,25 @@ __global__ __launch_bounds__(grad::NT) void wgrad3x3_kernel(const float* __restr
         *reinterpret_cast<half8*>(a_hi + ol * AROW + 8 * g8) = hi;
         *reinterpret_cast<half8*>(a_lo + ol * AROW + 8 * g8) = lo;
       }
-      // ---- sign(x) rows y0-1 .. y0+R of 32 input channels, three shifted copies: copy kx holds sx[p + kx - 1]
+      // ---- sign(x) rows ST*y0-1 .. of 32 input channels, three copies: copy kx holds sx[ST*p + kx - 1] at slot p
       for (int item = tid; item < 32 * BR * groups; item += NT) {
         const int j = item & (groups - 1), t = item >> q.gshift;
         const int cl = t / BR, pr = t - cl * BR;
-        const int c = c0 + cl, y = y0 - 1 + pr;
-        // rows past the chunk's own R rows + halo belong to the next chunk: they stay zero here
-        const bool rowok = c < q.C && pr <= q.R + 1 && (unsigned)y < (unsigned)q.H;
-        _Float16 s[10];  // sx[8j-1 .. 8j+8]
+        const int c = c0 + cl, y = ST * y0 - 1 + pr;
+        const bool rowok = c < q.C && (unsigned)y < (unsigned)q.Hx;
+        _Float16 s[8 * ST + 2];  // sx[ST*8j-1 .. ST*(8j+7)+1]
 #pragma unroll
-        for (int e = 0; e < 10; ++e) {
-          const int x = 8 * j - 1 + e;
-          const bool ok = rowok && (unsigned)x < (unsigned)q.W;
-          const float xv = xin[ok ? ((size_t)n * q.C + c) * HW + y * q.W + x : 0];
+        for (int e = 0; e < 8 * ST + 2; ++e) {
+          const int x = ST * 8 * j - 1 + e;
+          const bool ok = rowok && (unsigned)x < (unsigned)q.Wx;
+          const float xv = xin[ok ? ((size_t)n * q.C + c) * HWx + y * q.Wx + x : 0];
           s[e] = (_Float16)((ok && xv > 0.0f) ? 1.0f : (ok && xv < 0.0f) ? -1.0f : 0.0f);
         }
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           half8 hv;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) hv[e] = s[e + kx];
+          for (int e = 0; e < 8; ++e) hv[e] = s[ST * e + kx];
           *reinterpret_cast<half8*>(bsx + kx * bplane + (cl * BR + pr) * BROW + 8 * j) = hv;
         }
       }
@@ -306,15 +314,21 @@ __global__ __launch_bounds__(grad::NT) void wgrad3x3_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------- host side
-static bool make_geo(int N, int O, int C, int H, int W, GradGeo* q) {
-  if (N <= 0 || O <= 0 || C <= 0 || H <= 0 || W <= 0 || W > 64) return false;
+// dom_w / dom_h: the pixel domain the chunks tile (dgrad: x; wgrad: g).
+static bool make_geo(int N, int O, int C, int Hx, int Wx, int st, bool dgrad, GradGeo* q) {
+  if (N <= 0 || O <= 0 || C <= 0 || Hx <= 0 || Wx <= 0 || (st != 1 && st != 2)) return false;
+  q->N = N; q->O = O; q->C = C; q->Hx = Hx; q->Wx = Wx; q->st = st;
+  q->Hg = (Hx - 1) / st + 1;
+  q->Wg = (Wx - 1) / st + 1;
+  q->H = dgrad ? Hx : q->Hg;
+  q->W = dgrad ? Wx : q->Wg;
+  if (q->W > 64) return false;
   int slot = 8;
-  while (slot < W) slot *= 2;
-  q->N = N; q->O = O; q->C = C; q->H = H; q->W = W;
+  while (slot < q->W) slot *= 2;
   q->slot = slot;
   q->RR = 64 / slot;
-  q->R = q->RR < H ? q->RR : H;
-  q->chunks = (H + q->R - 1) / q->R;
+  q->R = q->RR < q->H ? q->RR : q->H;
+  q->chunks = (q->H + q->R - 1) / q->R;
   q->gshift = 0;
   while ((8 << q->gshift) < slot) ++q->gshift;
   return true;
@@ -333,10 +347,10 @@ int launch_grad_pack_weight(const float* what, int O, int C, void* packed, float
 }
 
 int launch_dgrad3x3(const float* g, const float* alpha, const void* packed, const float* xin, float* gx, int N,
-                    int O, int C, int H, int W, hipStream_t s) {
+                    int O, int C, int H, int W, int stride, hipStream_t s) {
   using namespace grad;
   GradGeo q;
-  if (!make_geo(N, O, C, H, W, &q)) return BNN_HIP_ERR_UNSUPPORTED;
+  if (!make_geo(N, O, C, H, W, stride, true, &q)) return BNN_HIP_ERR_UNSUPPORTED;
   const int PP = (q.R + 2) * (W + 2);
   const int nsub = C > 64 ? 2 : 1;
   const size_t patch = (size_t)2 * PP * APIX * sizeof(_Float16);
@@ -362,16 +376,26 @@ int grad_wgrad_splits(int N, int O, int C) {
 }
 
 int launch_wgrad3x3(const float* g, const float* xin, float* part, int splits, int N, int O, int C, int H, int W,
-                    hipStream_t s) {
+                    int stride, hipStream_t s) {
   using namespace grad;
   GradGeo q;
-  if (!make_geo(N, O, C, H, W, &q)) return BNN_HIP_ERR_UNSUPPORTED;
+  if (!make_geo(N, O, C, H, W, stride, false, &q)) return BNN_HIP_ERR_UNSUPPORTED;
   if (splits < 1 || splits > N) return BNN_HIP_ERR_INVALID_ARG;
   const int per = (N + splits - 1) / splits;
   if ((N + per - 1) / per != splits) return BNN_HIP_ERR_INVALID_ARG;
-  const size_t lds = (size_t)(2 * 64 * AROW + 3 * 32 * (q.RR + 2) * (q.slot + 8)) * sizeof(_Float16);
+  const size_t lds = (size_t)(2 * 64 * AROW + 3 * 32 * (stride * q.RR + 2) * (q.slot + 8)) * sizeof(_Float16);
   const dim3 grid((unsigned)splits, (unsigned)((C + 31) / 32), (unsigned)((O + 63) / 64));
-  hipLaunchKernelGGL(wgrad3x3_kernel, grid, dim3(NT), lds, s, g, xin, part, q, per);
+  if (stride == 2) {
+    static bool attr_set = false;  // up to 73 KB of dynamic LDS (7x7 outputs): needs the opt-in once
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad3x3_kernel<2>, grid, dim3(NT), lds, s, g, xin, part, q, per);
+  } else {
+    hipLaunchKernelGGL(wgrad3x3_kernel<1>, grid, dim3(NT), lds, s, g, xin, part, q, per);
+  }
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 

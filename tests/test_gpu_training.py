@@ -191,24 +191,25 @@ GRAD_SHAPES = [  # (N, O, C, H, W): every slot width (8/16/32/64), channel tails
 ]
 
 
+@pytest.mark.parametrize("stride", [1, 2])
 @pytest.mark.parametrize("shape", GRAD_SHAPES, ids=lambda s: "x".join(map(str, s)))
-def test_binary_gradient_kernels_match_library_backward(shape):
+def test_binary_gradient_kernels_match_library_backward(shape, stride):
     """csrc/grad.hip (MFMA: g split into fp16 hi+lo, ternary operand exact) against aten::convolution_backward on
     the same operands: dL/dx (with the STE mask) and dL/dWhat, fp32-convolution rounding class."""
     from bnn_amd import hipops
     N, O, C, H, W = shape
     x = dev((gen.normal(gen.seed_of("gx", shape), (N, C, H, W)) * 0.9).astype(np.float32))
     x.view(-1)[::7] = 0.0                                            # exact zeros: sign(0) == 0
-    g = dev(gen.normal(gen.seed_of("gg", shape), (N, O, H, W)))
+    g = dev(gen.normal(gen.seed_of("gg", shape), (N, O, (H - 1) // stride + 1, (W - 1) // stride + 1)))
     w = dev(gen.conv_weight("kaiming", gen.seed_of("gw", shape), (O, C, 3, 3)))
     w.view(-1)[::11] = 0.0                                           # and zero weights
     w_hat = torch.sign(w) * w.abs().flatten(1).mean(1).view(-1, 1, 1, 1)
-    assert hipops.grad_supported(x.shape, w_hat.shape, 1, 1, 1)
+    assert hipops.grad_supported(x.shape, w_hat.shape, stride, 1, 1)
     packed, alpha = hipops.grad_pack_weight(w_hat)
     assert torch.equal(alpha, w_hat.abs().flatten(1).amax(1))
-    gx = hipops.bconv3x3_grad_input(g, x, packed, alpha)
-    gw = hipops.bconv3x3_grad_weight(g, x)
-    rx, rw, _ = torch.ops.aten.convolution_backward(g, torch.sign(x), w_hat, None, [1, 1], [1, 1], [1, 1], False,
+    gx = hipops.bconv3x3_grad_input(g, x, packed, alpha, stride)
+    gw = hipops.bconv3x3_grad_weight(g, x, stride)
+    rx, rw, _ = torch.ops.aten.convolution_backward(g, torch.sign(x), w_hat, None, [stride, stride], [1, 1], [1, 1], False,
                                                     [0, 0], 1, [True, True, False])
     rx = rx.masked_fill(x.abs() >= 1, 0)
     assert gx.shape == rx.shape and gw.shape == rw.shape
@@ -217,7 +218,8 @@ def test_binary_gradient_kernels_match_library_backward(shape):
     assert torch.allclose(gw, rw, rtol=1e-4, atol=2e-5 * float(rw.abs().max()))
     # fp64 reference: the error is that of an fp32 convolution, not of fp16 operands
     rx64, rw64, _ = torch.ops.aten.convolution_backward(g.double(), torch.sign(x).double(), w_hat.double(), None,
-                                                        [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, True, False])
+                                                        [stride, stride], [1, 1], [1, 1], False, [0, 0], 1,
+                                                        [True, True, False])
     rx64 = rx64.masked_fill(x.abs() >= 1, 0)
     assert float((gx.double() - rx64).abs().max()) <= 4e-6 * float(rx64.abs().max())
     assert float((gw.double() - rw64).abs().max()) <= 4e-6 * float(rw64.abs().max())

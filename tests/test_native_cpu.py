@@ -69,8 +69,9 @@ def test_argument_validation_without_touching_the_gpu():
     assert 1 <= lib.bnn_hip_bconv3x3_grad_weight_splits(256, 64, 64) <= 256
     assert lib.bnn_hip_bconv3x3_grad_weight_splits(1, 512, 512) == 1
     assert lib.bnn_hip_grad_pack_weight_f32(None, 64, 64, None, None, None) == -1
-    assert lib.bnn_hip_bconv3x3_grad_input_f32(16, 16, 16, 16, 16, 2, 64, 64, 8, 65, None) == -2     # width > 64
-    assert lib.bnn_hip_bconv3x3_grad_weight_f32(None, 16, 16, 1, 2, 64, 64, 8, 8, None) == -1
+    assert lib.bnn_hip_bconv3x3_grad_input_f32(16, 16, 16, 16, 16, 2, 64, 64, 8, 65, 1, None) == -2  # width > 64
+    assert lib.bnn_hip_bconv3x3_grad_input_f32(16, 16, 16, 16, 16, 2, 64, 64, 8, 8, 3, None) == -2   # stride 3
+    assert lib.bnn_hip_bconv3x3_grad_weight_f32(None, 16, 16, 1, 2, 64, 64, 8, 8, 1, None) == -1
     assert lib.bnn_hip_conv_workspace_bytes(ctypes.byref(d)) >= 2 * 64 * 8
     d.N = 0
     assert lib.bnn_hip_bconv2d(ctypes.byref(d), 16, 16, 16, 16, 16, None, None, 16, None) == -1

@@ -27,6 +27,9 @@ def run(enabled, steps=6, binary_grads=True):
         loss.backward(); opt.step()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
+if os.environ.get("ONLY") == "mfma":
+    print("batch %d: HIP forward + MFMA gradient kernels %.1f ms" % (B, run(True)))
+    sys.exit(0)
 a = run(True); a2 = run(True, binary_grads=False); b = run(False)
 print("batch %d: training step  HIP forward + MFMA gradient kernels %.1f ms (%.0f img/s) | HIP forward + library backward "
       "%.1f ms (%.0f img/s) | composition %.1f ms (%.0f img/s)" % (B, a, B / a * 1e3, a2, B / a2 * 1e3, b, B / b * 1e3))
