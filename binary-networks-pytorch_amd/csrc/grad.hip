@@ -19,6 +19,13 @@
 // chunk of the GEMM's pixel dimension is 64/slot consecutive image rows.  An 8-element MFMA fragment never
 // straddles an image row, and 7x7 .. 56x56 images all use >= 87.5 % of the chunk.
 //
+// Measured (MI355X, ResNet-18 224x224 batch 256, tools/bench_train.py + tools/last_step_profile.py): 13 + 3 wgrad
+// launches 5.8 ms, 16 dgrad launches 4.3 ms per step; the whole training step 33 ms against 42 ms with the
+// library's fp32 gradient convolutions and 48 ms for the pure torch composition.  Both kernels are bound by the
+// VALU work of the fills (index arithmetic, fp32 -> hi/lo / sign conversion: ~10 instructions per loaded element
+// against 72 MFMAs per chunk and wave), not by memory latency: issuing a chunk's loads one iteration ahead
+// (software-pipelined fills) changed nothing (wgrad) or lost occupancy (dgrad) and was dropped.
+//
 // Stride 2 (the first conv of a down-sampling stage) uses the same kernels: wgrad reads sign(x) at stride 2 (its
 // shifted LDS copies are de-interleaved), dgrad treats g as zero-upsampled by 2 when the patch is filled (3/4 of
 // its MFMA work multiplies zeros — still several times faster than the fp32 library kernel).  1x1 convolutions
@@ -127,59 +134,31 @@ __global__ __launch_bounds__(grad::NT) void dgrad3x3_kernel(const float* __restr
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) acc[s][ns] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- the K pipeline.  A thread's fill items (patch pixel, group of 8 output channels) are the same for every
-  // block of 32 output channels; their addresses are computed once, the 8 loads of ALL items of the next block are
-  // issued before the current block's 72 * NSUB MFMAs (`fetch`) and converted / written to LDS after them
-  // (`commit`) — one memory round trip per block instead of one per item.
-  constexpr int NI = 4;  // items per thread: (R+2)*(W+2)*4 <= 3*66*4 = 792 <= 1024
-  int i_goff[NI], i_og[NI], i_lds[NI];
-#pragma unroll
-  for (int k = 0; k < NI; ++k) {
-    const int item = tid + NT * k;
-    const int pix = item % PP, og = item / PP;
-    const int pr = pix / PW, pc = pix - pr * PW;
-    const int y = y0 - 1 + pr, x = pc - 1;
-    // stride 2: g zero-upsampled — only even (y, x) carry a value, g[y/2][x/2]
-    const int yg = q.st == 2 ? y >> 1 : y, xg = q.st == 2 ? x >> 1 : x;
-    const bool in = item < PP * 4 && y >= 0 && x >= 0 && yg < q.Hg && xg < q.Wg &&
-                    (q.st == 1 || ((y | x) & 1) == 0);
-    i_goff[k] = in ? yg * q.Wg + xg : -1;
-    i_og[k] = og;
-    i_lds[k] = item < PP * 4 ? pix * APIX + 8 * og : -1;
-  }
-  float rg[NI][8], ral[NI][8];
-  auto fetch = [&](int ob) {
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int o = 32 * ob + 8 * i_og[k] + e;
-        const bool ok = i_goff[k] >= 0 && o < q.O;
-        rg[k][e] = g[ok ? ((size_t)n * q.O + o) * HGg + i_goff[k] : 0];
-        ral[k][e] = ok ? alpha[o] : 0.0f;  // 0 also zeroes the dummy element read for out-of-range positions
-      }
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      if (i_lds[k] >= 0) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = ral[k][e] == 0.0f ? 0.0f : rg[k][e] * ral[k][e];  // (keeps 0 * inf out)
-        half8 hi, lo;
-        split8(v, hi, lo);
-        *reinterpret_cast<half8*>(pa_hi + i_lds[k]) = hi;
-        *reinterpret_cast<half8*>(pa_lo + i_lds[k]) = lo;
-      }
-    }
-  };
-  fetch(0);
   for (int ob = 0; ob < OB; ++ob) {
     __syncthreads();  // previous block's patch is consumed
-    commit();
+    // ---- fill: item = (patch pixel, group of 8 output channels); 8 loads (coalesced along x across lanes)
+    for (int item = tid; item < PP * 4; item += NT) {
+      const int pix = item % PP, og = item / PP;
+      const int pr = pix / PW, pc = pix - pr * PW;
+      const int y = y0 - 1 + pr, x = pc - 1;
+      // stride 2: g zero-upsampled — only even (y, x) carry a value, g[y/2][x/2]
+      const int yg = q.st == 2 ? y >> 1 : y, xg = q.st == 2 ? x >> 1 : x;
+      const bool in = y >= 0 && x >= 0 && yg < q.Hg && xg < q.Wg && (q.st == 1 || ((y | x) & 1) == 0);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int o = 32 * ob + 8 * og + e;
+        const bool ok = in && o < q.O;
+        const float gv = g[ok ? ((size_t)n * q.O + o) * HGg + yg * q.Wg + xg : 0];
+        const float av = alpha[ok ? o : 0];
+        v[e] = ok ? gv * av : 0.0f;
+      }
+      half8 hi, lo;
+      split8(v, hi, lo);
+      *reinterpret_cast<half8*>(pa_hi + pix * APIX + 8 * og) = hi;
+      *reinterpret_cast<half8*>(pa_lo + pix * APIX + 8 * og) = lo;
+    }
     __syncthreads();
-    if (ob + 1 < OB) fetch(ob + 1);  // in flight during the MFMAs below
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
       const int ky = tap / 3, kx = tap - ky * 3;
@@ -232,7 +211,7 @@ __global__ __launch_bounds__(grad::NT) void dgrad3x3_kernel(const float* __restr
 // Per chunk: g (fp16 hi / lo, [o][64 slots]) and sign(x) with one halo row above and below, stored THREE times,
 // shifted by kx - 1 pixels, so that every tap's 8-pixel fragment is a 16-byte aligned LDS read.
 template <int ST>
-__global__ __launch_bounds__(grad::NT, 2) void wgrad3x3_kernel(const float* __restrict__ g,
+__global__ __launch_bounds__(grad::NT) void wgrad3x3_kernel(const float* __restrict__ g,
                                                             const float* __restrict__ xin,
                                                             float* __restrict__ part, const GradGeo q,
                                                             int imgs_per_split) {
@@ -267,123 +246,63 @@ __global__ __launch_bounds__(grad::NT, 2) void wgrad3x3_kernel(const float* __re
     b_off[ks] = (li * BR + ST * ry) * BROW + xg;  // + (half * 16 * BR + ky) * BROW + kx * bplane per sub-tile
   }
 
-  // ---- the chunk pipeline.  A thread's items are the same for every chunk (item = tid + 256 k), so their
-  // coordinates are computed once; per chunk the loads of ALL items are issued back to back into registers
-  // (`fetch`), and are converted / written to LDS one iteration later (`commit`) — i.e. they fly during the
-  // previous chunk's MFMAs instead of costing one memory round trip per item (the first version: 5 round trips
-  // and ~15 k cycles per chunk for 72 MFMAs per wave).
-  constexpr int NA = 2, NB = 3, BW = 8 * ST + 2;
-  // A items: 64 channels x 8 groups of 8 k-slots = 512 = 2 per thread
-  int a_o[NA], a_ry[NA], a_x0[NA], a_lds[NA];
+  for (int n = n_begin; n < n_end; ++n) {
+    for (int y0 = 0; y0 < q.H; y0 += q.R) {
+      __syncthreads();
+      // ---- g rows y0 .. y0+R-1 of 64 output channels
+      for (int item = tid; item < 64 * 8; item += NT) {   // 64 channels x 8 groups of 8 k-slots
+        const int g8 = item & 7, ol = item >> 3;
+        const int ry = g8 >> q.gshift, j = g8 & (groups - 1);
+        const int o = o0 + ol, y = y0 + ry;
+        const bool rowok = o < q.O && ry < q.R && y < q.H;
+        float v[8];
 #pragma unroll
-  for (int k = 0; k < NA; ++k) {
-    const int item = tid + NT * k;
-    const int g8 = item & 7, ol = item >> 3;
-    a_o[k] = o0 + ol;
-    a_ry[k] = g8 >> q.gshift;
-    a_x0[k] = 8 * (g8 & (groups - 1));
-    a_lds[k] = ol * AROW + 8 * g8;
-  }
-  // B items: 32 channels x BR rows x groups (at most 3 per thread)
-  const int nb_items = 32 * BR * groups;
-  int b_c[NB], b_pr[NB], b_x0[NB], b_lds[NB];
-#pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    const int item = tid + NT * k;
-    const int j = item & (groups - 1), t = item >> q.gshift;
-    const int cl = t / BR, pr = t - cl * BR;
-    b_c[k] = item < nb_items ? c0 + cl : q.C;  // q.C: "no such channel" -> zeros, never stored
-    b_pr[k] = pr;
-    b_x0[k] = ST * 8 * j - 1;
-    b_lds[k] = (cl * BR + pr) * BROW + 8 * j;
-  }
-  float ra[NA][8], rb[NB][BW];
-  unsigned ma[NA], mb[NB];  // validity bits of the loaded elements (invalid ones read element 0 and become zero)
-  auto fetch = [&](int n, int y0) {
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      const int y = y0 + a_ry[k];
-      const bool rowok = a_o[k] < q.O && a_ry[k] < q.R && y < q.H;
-      const float* row = g + ((size_t)n * q.O + (rowok ? a_o[k] : 0)) * HW + (rowok ? y : 0) * q.W;
-      unsigned m = 0;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int x = a_x0[k] + e;
-        const bool ok = rowok && x < q.W;
-        ra[k][e] = row[ok ? x : 0];
-        m |= (ok ? 1u : 0u) << e;
+        for (int e = 0; e < 8; ++e) {
+          const int x = 8 * j + e;
+          const bool ok = rowok && x < q.W;
+          const float gv = g[ok ? ((size_t)n * q.O + o) * HW + y * q.W + x : 0];
+          v[e] = ok ? gv : 0.0f;
+        }
+        half8 hi, lo;
+        split8(v, hi, lo);
+        *reinterpret_cast<half8*>(a_hi + ol * AROW + 8 * g8) = hi;
+        *reinterpret_cast<half8*>(a_lo + ol * AROW + 8 * g8) = lo;
       }
-      ma[k] = m;
-    }
+      // ---- sign(x) rows ST*y0-1 .. of 32 input channels, three copies: copy kx holds sx[ST*p + kx - 1] at slot p
+      for (int item = tid; item < 32 * BR * groups; item += NT) {
+        const int j = item & (groups - 1), t = item >> q.gshift;
+        const int cl = t / BR, pr = t - cl * BR;
+        const int c = c0 + cl, y = ST * y0 - 1 + pr;
+        const bool rowok = c < q.C && (unsigned)y < (unsigned)q.Hx;
+        _Float16 s[8 * ST + 2];  // sx[ST*8j-1 .. ST*(8j+7)+1]
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      const int y = ST * y0 - 1 + b_pr[k];
-      const bool rowok = b_c[k] < q.C && (unsigned)y < (unsigned)q.Hx;
-      const float* row = xin + ((size_t)n * q.C + (rowok ? b_c[k] : 0)) * HWx + (rowok ? y : 0) * q.Wx;
-      unsigned m = 0;
-#pragma unroll
-      for (int e = 0; e < BW; ++e) {
-        const int x = b_x0[k] + e;
-        const bool ok = rowok && (unsigned)x < (unsigned)q.Wx;
-        rb[k][e] = row[ok ? x : 0];
-        m |= (ok ? 1u : 0u) << e;
-      }
-      mb[k] = m;
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (ma[k] >> e) & 1u ? ra[k][e] : 0.0f;
-      half8 hi, lo;
-      split8(v, hi, lo);
-      *reinterpret_cast<half8*>(a_hi + a_lds[k]) = hi;
-      *reinterpret_cast<half8*>(a_lo + a_lds[k]) = lo;
-    }
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      if (tid + NT * k < nb_items) {
-        _Float16 sg[BW];  // sx[ST*8j-1 .. ST*(8j+7)+1]
-#pragma unroll
-        for (int e = 0; e < BW; ++e) {
-          const bool ok = (mb[k] >> e) & 1u;
-          const float xv = rb[k][e];
-          sg[e] = (_Float16)((ok && xv > 0.0f) ? 1.0f : (ok && xv < 0.0f) ? -1.0f : 0.0f);
+        for (int e = 0; e < 8 * ST + 2; ++e) {
+          const int x = ST * 8 * j - 1 + e;
+          const bool ok = rowok && (unsigned)x < (unsigned)q.Wx;
+          const float xv = xin[ok ? ((size_t)n * q.C + c) * HWx + y * q.Wx + x : 0];
+          s[e] = (_Float16)((ok && xv > 0.0f) ? 1.0f : (ok && xv < 0.0f) ? -1.0f : 0.0f);
         }
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {  // copy kx holds sx[ST*p + kx - 1] at slot p
+        for (int kx = 0; kx < 3; ++kx) {
           half8 hv;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) hv[e] = sg[ST * e + kx];
-          *reinterpret_cast<half8*>(bsx + kx * bplane + b_lds[k]) = hv;
+          for (int e = 0; e < 8; ++e) hv[e] = s[ST * e + kx];
+          *reinterpret_cast<half8*>(bsx + kx * bplane + (cl * BR + pr) * BROW + 8 * j) = hv;
         }
       }
-    }
-  };
-
-  const int total = (n_end - n_begin) * q.chunks;  // chunks of this workgroup, image-major
-  if (total > 0) fetch(n_begin, 0);
-  for (int it = 0; it < total; ++it) {
-    __syncthreads();  // the previous chunk's MFMAs are done with LDS
-    commit();
-    __syncthreads();
-    if (it + 1 < total) {
-      const int nn = n_begin + (it + 1) / q.chunks, yy = ((it + 1) - ((it + 1) / q.chunks) * q.chunks) * q.R;
-      fetch(nn, yy);  // in flight during the MFMAs below
-    }
+      __syncthreads();
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const half8 ah = *reinterpret_cast<const half8*>(a_hi + a_off[ks]);
-      const half8 al = *reinterpret_cast<const half8*>(a_lo + a_off[ks]);
+      for (int ks = 0; ks < 2; ++ks) {
+        const half8 ah = *reinterpret_cast<const half8*>(a_hi + a_off[ks]);
+        const half8 al = *reinterpret_cast<const half8*>(a_lo + a_off[ks]);
 #pragma unroll
-      for (int j = 0; j < 18; ++j) {
-        const int half = j / 9, tap = j - half * 9, ky = tap / 3, kx = tap - ky * 3;
-        const half8 b = *reinterpret_cast<const half8*>(bsx + kx * bplane + b_off[ks] +
-                                                        (half * 16 * BR + ky) * BROW);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b, acc[j], 0, 0, 0);
+        for (int j = 0; j < 18; ++j) {
+          const int half = j / 9, tap = j - half * 9, ky = tap / 3, kx = tap - ky * 3;
+          const half8 b = *reinterpret_cast<const half8*>(bsx + kx * bplane + b_off[ks] +
+                                                          (half * 16 * BR + ky) * BROW);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b, acc[j], 0, 0, 0);
+        }
       }
     }
   }
