@@ -13,7 +13,7 @@ import torch
 
 from . import native
 
-_MAX_ELEMS = (1 << 31) - 1
+_MAX_ELEMS = (1 << 30) - 1  # fp32 elements one conv launch addresses (32-bit byte offsets inside the kernels)
 
 
 def _pair(v) -> Tuple[int, int]:

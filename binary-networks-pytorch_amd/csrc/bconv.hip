@@ -116,6 +116,21 @@ __device__ __forceinline__ void load_words(const uint32_t* __restrict__ src, siz
   for (int i = 0; i < LV; ++i) dst[i] = e[i];
 }
 
+// Global access as UNIFORM base + 32-bit per-lane BYTE offset: the form gfx950 encodes as
+// `global_load/store v_data, v_off, s[base:base+1]` — no 64-bit vector address per access (two VALU ops and two
+// VGPRs each when the offset is an element index the compiler cannot prove small).  The C-ABI keeps every tensor a
+// launch touches below 2^32 bytes (capi.hip), so the byte offsets cannot wrap.  (hipcc takes this form for the
+// field loads; for per-channel bases it re-associates to (base + lane) + channel, a 64-bit vector address again —
+// pinning the base with an "s"-constrained asm turns the access into a FLAT one, which is worse.)
+template <class T>
+__device__ __forceinline__ T ld_off(const T* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ void st_off(T* __restrict__ base, unsigned byte_off, T v) {
+  *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
 // Output pixel of this lane.
 struct Pix {
   int q, n, r, oy, ox;
@@ -149,7 +164,7 @@ __device__ __forceinline__ void load_field(const Geo& g, const Pix& px, int ch,
   constexpr int GC = CWC / 2;  // 64-channel groups per chunk
   const int cw64 = g.cw32 >> 1;
   const int plane = g.H * g.Wd;
-  const size_t img = ((size_t)px.n * cw64 + (size_t)ch * GC) * plane;
+  const unsigned img = (unsigned)((px.n * cw64 + ch * GC) * plane);  // uint64 words; host keeps planes < 2^29 words
 #pragma unroll
   for (int t = 0; t < KH * KW; ++t) {
     const int iy = px.oy * g.sh - g.ph + t / KW;
@@ -158,15 +173,14 @@ __device__ __forceinline__ void load_field(const Geo& g, const Pix& px, int ch,
     const int pix = ok ? iy * g.Wd + ix : 0;
 #pragma unroll
     for (int gi = 0; gi < GC; ++gi) {
-      uint32_t pv[2], mv[2];
-      const size_t w = (img + (size_t)gi * plane + pix) * 2;
-      load_words<2>(P, w, pv);
-      if constexpr (!NN) load_words<2>(M, w, mv);
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        pr[t * CWC + gi * 2 + e] = ok ? pv[e] : 0u;
-        mr[t * CWC + gi * 2 + e] = (!NN && ok) ? mv[e] : 0u;
-      }
+      const unsigned boff = (img + (unsigned)(gi * plane + pix)) * 8u;
+      const uint2 pv = ld_off(reinterpret_cast<const uint2*>(P), boff);
+      uint2 mv = {0u, 0u};
+      if constexpr (!NN) mv = ld_off(reinterpret_cast<const uint2*>(M), boff);
+      pr[t * CWC + gi * 2] = ok ? pv.x : 0u;
+      pr[t * CWC + gi * 2 + 1] = ok ? pv.y : 0u;
+      mr[t * CWC + gi * 2] = (!NN && ok) ? mv.x : 0u;
+      mr[t * CWC + gi * 2 + 1] = (!NN && ok) ? mv.y : 0u;
     }
   }
 }
@@ -212,21 +226,29 @@ __device__ __forceinline__ constexpr int ep_flags(int ep, int runtime) {
                                                                                                         : runtime;
 }
 
-template <int NACC, int EP>
+// FULL: all NACC channels exist (o0 + NACC <= O; wave-uniform, chosen by the caller) AND no per-lane guard: lanes past
+// the last pixel were clamped to it by decode_pixel(), compute the same values and store them to the same addresses.
+// The point is the instruction stream, not the handful of skipped compares: with a guard per access the compiler puts
+// every residual load and every store into its own exec-mask region and, being conservative at the joins, an
+// `s_waitcnt vmcnt(0)` in front of EVERY store — a wave then pays a full memory round trip per channel (measured on
+// the conv2-type kernels: the two fp32 streams were purely additive to the ALU time, 74 + 29 + 29 = 132 us).
+// Straight-line code lets the loads and stores of a pass queue up behind each other.
+template <int NACC, int EP, bool FULL = false>
 __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
                                          const int (&dot)[NACC], const float (&resv)[NACC],
                                          const EpiArgs& e, uint32_t& pbits, uint32_t& mbits) {
   constexpr bool FUSED = EP != EP_PLAIN;
   const int hw = g.Ho * g.Wo;
-  const unsigned lane_off = (unsigned)(px.n * g.c_tot * hw + px.r);  // host keeps N*c_tot*hw < 2^31
+  const unsigned lane_off = (unsigned)(px.n * g.c_tot * hw + px.r) * 4u;  // BYTES; host keeps N*c_tot*hw < 2^30
   const int f = ep_flags(EP, g.flags);
-  const bool full = o0 + NACC <= g.O;
+  const bool full = FULL || o0 + NACC <= g.O;
+  const bool live = FULL || px.live;
   if (f & EF_RAW) {
-    if (px.live) {
+    if (live) {
       int32_t* o32 = static_cast<int32_t*>(e.out);
 #pragma unroll
       for (int j = 0; j < NACC; ++j)
-        if (full || o0 + j < g.O) (o32 + (size_t)(o0 + j + g.c_off) * hw)[lane_off] = dot[j];
+        if (full || o0 + j < g.O) st_off(o32 + (size_t)(o0 + j + g.c_off) * hw, lane_off, dot[j]);
     }
     return;
   }
@@ -239,7 +261,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
       if (full || o < g.O) {
         float y = fmaf(e.alpha[o], (float)dot[j], hb ? e.bias[o] : 0.0f);
         if (hs) y *= e.scale[o];
-        if (px.live) (outf + (size_t)(o + g.c_off) * hw)[lane_off] = y;
+        if (live) st_off(outf + (size_t)(o + g.c_off) * hw, lane_off, y);
       }
     }
     return;
@@ -261,9 +283,9 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
       if ((f & EF_RES) && (f & EF_RES_LATE)) y += resv[j];
       if (!(f & EF_PACK_PRE)) pv = y;
 #if BNN_NT_STORE
-      if ((f & EF_OUTF) && px.live) __builtin_nontemporal_store(y, &(outf + (size_t)(o + g.c_off) * hw)[lane_off]);
+      if ((f & EF_OUTF) && live) __builtin_nontemporal_store(y, &(outf + (size_t)(o + g.c_off) * hw)[lane_off]);
 #else
-      if ((f & EF_OUTF) && px.live) (outf + (size_t)(o + g.c_off) * hw)[lane_off] = y;
+      if ((f & EF_OUTF) && live) st_off(outf + (size_t)(o + g.c_off) * hw, lane_off, y);
 #endif
       if (f & EF_PACK) {
         if (f & EF_PACK_AFF) pv = fmaf(pv, e.pack_a[o], e.pack_b[o]);
@@ -280,7 +302,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
 // Residual (shortcut) values of NACC channels for this lane's pixel.  Called at the START of a
 // pass, before the popcount loop, so the loads land while the vector ALU is busy: the epilogue
 // then finds them in registers instead of stalling on HBM once per pass.
-template <int NACC, int EP>
+template <int NACC, int EP, bool FULL = false>
 __device__ __forceinline__ void prefetch_residual(const Geo& g, const Pix& px, int o0,
                                                   const EpiArgs& e, float (&resv)[NACC]) {
   const int f = ep_flags(EP, g.flags);
@@ -290,20 +312,21 @@ __device__ __forceinline__ void prefetch_residual(const Geo& g, const Pix& px, i
     return;
   }
   const int hw = g.Ho * g.Wo;
-  const unsigned lane_off = (unsigned)(px.n * g.c_tot * hw + px.r);
+  const unsigned lane_off = (unsigned)(px.n * g.c_tot * hw + px.r) * 4u;  // bytes
 #pragma unroll
   for (int j = 0; j < NACC; ++j)
-    resv[j] = (px.live && o0 + j < g.O) ? (e.res + (size_t)(o0 + j + g.c_off) * hw)[lane_off] : 0.0f;
+    resv[j] = (FULL || (px.live && o0 + j < g.O)) ? ld_off(e.res + (size_t)(o0 + j + g.c_off) * hw, lane_off) : 0.0f;
 }
 
 // sign(y) of one 32-channel block: one half of a uint64 word of the [n][group][y][x] output planes.
 __device__ __forceinline__ void store_packed(const Geo& g, const Pix& px, int ob, uint32_t pbits,
                                              uint32_t mbits, const EpiArgs& e) {
-  if (!(g.flags & EF_PACK) || (g.flags & EF_RAW) || !px.live) return;
+  // lanes past the last pixel hold a copy of it (decode_pixel): they store the same word to the same place
+  if (!(g.flags & EF_PACK) || (g.flags & EF_RAW)) return;
   const int hw = g.Ho * g.Wo;
-  const size_t w = ((((size_t)px.n * (g.cw32_out >> 1) + (ob >> 1)) * hw + px.r) << 1) + (ob & 1);
-  e.outP[w] = pbits;
-  e.outM[w] = mbits;
+  const unsigned w = (unsigned)((((px.n * (g.cw32_out >> 1) + (ob >> 1)) * hw + px.r) << 1) + (ob & 1)) * 4u;  // bytes
+  st_off(e.outP, w, pbits);
+  st_off(e.outM, w, mbits);
 }
 
 // Same, for a wave that produced only part `part` of PARTS of the block's 32 channels (their bits
@@ -312,7 +335,7 @@ template <int PARTS>
 __device__ __forceinline__ void store_packed_part(const Geo& g, const Pix& px, int ob, int part,
                                                   uint32_t pbits, uint32_t mbits, const EpiArgs& e) {
   static_assert(PARTS == 2 || PARTS == 4, "16- or 8-bit pieces");
-  if (!(g.flags & EF_PACK) || (g.flags & EF_RAW) || !px.live) return;
+  if (!(g.flags & EF_PACK) || (g.flags & EF_RAW)) return;
   const int hw = g.Ho * g.Wo;
   const size_t w = ((((size_t)px.n * (g.cw32_out >> 1) + (ob >> 1)) * hw + px.r) << 1) + (ob & 1);
   constexpr int BITS = 32 / PARTS;
@@ -519,6 +542,17 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       load_field<KH, KW, CWC, NN>(g, px, 0, P, M, pr, mr);
       nz = count_nonzero<NW, NN>(pr, mr, 0);
     }
+    // conv2-type single-chunk kernels (BN + residual + ReLU -> fp32 [+ packed]): ALL shortcut values of the block
+    // are requested up front.  gfx950 counts loads and stores in one vmcnt, and once both kinds are pending the
+    // compiler has to wait for vmcnt(0): a residual load issued after the previous pass's stores would make the
+    // wave wait for those stores' acknowledgements in every pass.  Loads first, stores only after the last load
+    // has been consumed: the stores of a pass are never waited for.  Costs 24 VGPRs (8 -> 6 waves per SIMD).
+    constexpr bool RES_ALL = !MULTI && !GSPLIT && PASSES > 1 && (EP == EP_OUT || EP == EP_LAST);
+    [[maybe_unused]] float resq[RES_ALL ? kOCB : 1];
+    if constexpr (RES_ALL) {
+      if ((ob + 1) * kOCB <= g.O) prefetch_residual<kOCB, EP, true>(g, px, ob * kOCB, epi, resq);
+      else prefetch_residual<kOCB, EP>(g, px, ob * kOCB, epi, resq);
+    }
 #pragma unroll 1
     for (int ps = GSPLIT ? part : 0; ps < (GSPLIT ? part + 1 : PASSES); ++ps) {
       int acc[NACC];
@@ -527,8 +561,18 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       // single-chunk: shortcut values are requested before the popcount loop and land under it.
       // multi-chunk: the field + 32 accumulators already fill the 128-VGPR budget of 4 waves/SIMD;
       // holding NACC more values across the loop spills (39 VGPRs measured), so they are fetched late.
-      constexpr bool RES_EARLY = !MULTI || BNN_MULTI_RES_EARLY;
-      if constexpr (RES_EARLY) prefetch_residual<NACC, EP>(g, px, ob * kOCB + ps * NACC, epi, resv);
+      constexpr bool RES_EARLY = !RES_ALL && (!MULTI || BNN_MULTI_RES_EARLY);
+      const bool fullb = ob * kOCB + (ps + 1) * NACC <= g.O;  // wave-uniform
+      if constexpr (RES_ALL) {  // this pass's values are the head of the queue; the rest moves up (rolled loop)
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) resv[j] = resq[j];
+#pragma unroll
+        for (int j = 0; j + NACC < kOCB; ++j) resq[j] = resq[j + NACC];
+      }
+      if constexpr (RES_EARLY) {
+        if (fullb) prefetch_residual<NACC, EP, true>(g, px, ob * kOCB + ps * NACC, epi, resv);
+        else prefetch_residual<NACC, EP>(g, px, ob * kOCB + ps * NACC, epi, resv);
+      }
 #pragma unroll
       for (int j = 0; j < NACC; ++j) {
         acc[j] = 0;
@@ -547,11 +591,15 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
         if constexpr (WZ) stream_weights_wz<NW, NACC>(wblk + woff, zblk + woff, pr, mr, acc, nzacc);
         else stream_weights<NW, NACC, NN>(wblk + woff, pr, mr, acc);
       }
-      if constexpr (!RES_EARLY) prefetch_residual<NACC, EP>(g, px, ob * kOCB + ps * NACC, epi, resv);
+      if constexpr (!RES_EARLY && !RES_ALL) {
+        if (fullb) prefetch_residual<NACC, EP, true>(g, px, ob * kOCB + ps * NACC, epi, resv);
+        else prefetch_residual<NACC, EP>(g, px, ob * kOCB + ps * NACC, epi, resv);
+      }
 #pragma unroll
       for (int j = 0; j < NACC; ++j)  // dot = non-zeros - 2*disagreements = 2*agreements - non-zeros
         acc[j] = WZ ? nzacc[j] - 2 * acc[j] : NN ? 2 * acc[j] - nz : nz - 2 * acc[j];
-      epilogue<NACC, EP>(g, px, ob * kOCB + ps * NACC, acc, resv, epi, pbits, mbits);
+      if (fullb) epilogue<NACC, EP, true>(g, px, ob * kOCB + ps * NACC, acc, resv, epi, pbits, mbits);
+      else epilogue<NACC, EP>(g, px, ob * kOCB + ps * NACC, acc, resv, epi, pbits, mbits);
     }
   }
   if constexpr (GSPLIT) store_packed_part<PASSES>(g, px, ob, part, pbits, mbits, epi);

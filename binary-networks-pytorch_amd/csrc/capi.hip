@@ -14,6 +14,10 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 constexpr long long kMaxElems = (1LL << 31) - 1;
+// the convolution kernels address every tensor as uniform base + 32-bit BYTE offset per lane: fp32 / int32 tensors
+// of one launch stay below 2^30 elements, packed planes (uint64 per 64 channels per pixel) below 2^29 words
+constexpr long long kMaxConvElems = (1LL << 30) - 1;
+constexpr long long kMaxPlaneWords = (1LL << 29) - 1;
 
 int out_dim(int in, int k, int s, int p, int d) { return (in + 2 * p - d * (k - 1) - 1) / s + 1; }
 
@@ -27,8 +31,9 @@ int check_desc(const bnn_hip_conv_desc* d, int* Ho, int* Wo) {
   const int ho = out_dim(d->H, d->KH, d->stride_h, d->pad_h, d->dil_h);
   const int wo = out_dim(d->W, d->KW, d->stride_w, d->pad_w, d->dil_w);
   if (ho <= 0 || wo <= 0) return BNN_HIP_ERR_INVALID_ARG;
-  if ((long long)d->N * d->H * d->W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
-  if ((long long)d->N * d->O * ho * wo > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if ((long long)d->N * d->H * d->W * ((d->C + 63) / 64) > kMaxPlaneWords) return BNN_HIP_ERR_TOO_LARGE;
+  if ((long long)d->N * ho * wo * ((d->O + 63) / 64) > kMaxPlaneWords) return BNN_HIP_ERR_TOO_LARGE;
+  if ((long long)d->N * d->O * ho * wo > kMaxConvElems) return BNN_HIP_ERR_TOO_LARGE;
   *Ho = ho;
   *Wo = wo;
   return BNN_HIP_OK;
@@ -48,7 +53,7 @@ int run_conv(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M, c
   if ((p.pack_a == nullptr) != (p.pack_b == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
   if (p.c_tot == 0) { p.c_off = 0; p.c_tot = d->O; }
   if (p.c_off < 0 || p.c_off + d->O > p.c_tot) return BNN_HIP_ERR_INVALID_ARG;
-  if ((long long)d->N * p.c_tot * Ho * Wo > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if ((long long)d->N * p.c_tot * Ho * Wo > kMaxConvElems) return BNN_HIP_ERR_TOO_LARGE;
   if ((d->flags & BNN_HIP_FLAG_WEIGHT_ZEROS) && !wnz) return BNN_HIP_ERR_INVALID_ARG;
   if (!aligned(P, 16) || !aligned(M, 16) || !aligned(wbits, 16)) return BNN_HIP_ERR_INVALID_ARG;
   if (p.outP && (!aligned(p.outP, 8) || !aligned(p.outM, 8))) return BNN_HIP_ERR_INVALID_ARG;

@@ -68,7 +68,8 @@ typedef enum bnn_hip_status {
   BNN_HIP_ERR_INVALID_ARG = -1,  /* null pointer, non-positive size, misaligned buffer        */
   BNN_HIP_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels implement                   */
   BNN_HIP_ERR_LAUNCH = -3,       /* hipGetLastError() != hipSuccess after a launch             */
-  BNN_HIP_ERR_TOO_LARGE = -4,    /* a tensor exceeds the 2^31-element addressing of one launch */
+  BNN_HIP_ERR_TOO_LARGE = -4,    /* a tensor exceeds one launch's addressing: 2^30 fp32 elements (4 GiB) for the
+                                    convolution entry points, 2^31 elements elsewhere — split the batch */
   BNN_HIP_ERR_NO_DEVICE = -5     /* no HIP device / wrong architecture                         */
 } bnn_hip_status;
 
