@@ -315,7 +315,9 @@ __device__ __forceinline__ void prefetch_residual(const Geo& g, const Pix& px, i
   const unsigned lane_off = (unsigned)(px.n * g.c_tot * hw + px.r) * 4u;  // bytes
 #pragma unroll
   for (int j = 0; j < NACC; ++j)
-    resv[j] = (FULL || (px.live && o0 + j < g.O)) ? ld_off(e.res + (size_t)(o0 + j + g.c_off) * hw, lane_off) : 0.0f;
+    // lanes past the last pixel load too (they were clamped to it): they must compute the same sign bits as the
+    // live copy, because store_packed() lets them store
+    resv[j] = (FULL || o0 + j < g.O) ? ld_off(e.res + (size_t)(o0 + j + g.c_off) * hw, lane_off) : 0.0f;
 }
 
 // sign(y) of one 32-channel block: one half of a uint64 word of the [n][group][y][x] output planes.
