@@ -1,10 +1,13 @@
 #!/bin/bash
-# Collect the artefacts quoted in DESIGN.md / bench.py: kernel-trace stats of the default bench command
-# and PMC counters (separate passes) of the graded conv kernel.  Run on the GPU box:
-#   gpurun --timeout 1500 -- 'bash tools/gpu_profile.sh'
+# Collect the artefacts quoted in DESIGN.md / bench.py: bench lines, kernel-trace stats of the bench command (default:
+# two batches in flight; and one batch in flight), PMC counters (separate passes, kernel-trace only) of the graded
+# conv kernel and of the stem kernel.  Run on the GPU box:   gpurun --timeout 1500 -- 'bash tools/gpu_profile.sh'
 R="${GRAFT_REPO_ROOT:-$(pwd)}"; OUT="$R/gpurun_out/final"; rm -rf "$OUT"; mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
 timeout 900 python "$R/bench.py" --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/bench.json"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/stats.log" 2>&1
+timeout 300 python "$R/bench.py" --config c2 --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/bench_c2.json"
+timeout 600 python "$R/bench.py" --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > "$OUT/bench_c5.json"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python "$R/bench.py" --steps 20 --warmup 5 --no-extras --no-cpu-baseline > "$OUT/stats.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -o bench1 -- python "$R/bench.py" --steps 20 --warmup 5 --streams 1 --no-extras --no-cpu-baseline --no-roofline > "$OUT/stats1.log" 2>&1
 pmc() { n=$1; shift
   ONLY=c2 ITERS=3 timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$n" -o $n -- python "$R/tools/bench_conv.py" > "$OUT/$n.log" 2>&1; }
 pmc sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
@@ -12,4 +15,13 @@ pmc sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTI
 pmc grbm GRBM_GUI_ACTIVE GRBM_COUNT
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
-cut -c1-400 "$OUT/bench.json"; echo; head -8 "$OUT"/stats/*kernel_stats.csv | cut -c1-140
+spmc() { n=$1; shift
+  ONLY=default timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/stem_$n" -o stem_$n -- python "$R/tools/bench_stem.py" > "$OUT/stem_$n.log" 2>&1; }
+spmc a SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
+spmc b SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+spmc c SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL
+spmc d GRBM_GUI_ACTIVE
+spmc e FETCH_SIZE
+spmc f WRITE_SIZE
+find "$OUT" -name "*kernel_trace.csv" -size +8M -delete
+cut -c1-400 "$OUT/bench.json"; echo; head -8 "$OUT"/stats1/*kernel_stats.csv 2>/dev/null | cut -c1-140
