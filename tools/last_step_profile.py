@@ -1,13 +1,15 @@
-"""Kernel time of the LAST training step in a rocprofv3 kernel trace: python tools/last_step_profile.py trace.csv <step_ms>"""
+"""Kernel time of the LAST step in a rocprofv3 kernel trace:
+   python tools/last_step_profile.py trace.csv <step_ms> [anchor]     (window ends with the last kernel whose name has `anchor`)"""
 import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 win = float(sys.argv[2]) * 1e6
-end = max(int(r["End_Timestamp"]) for r in rows)
-sel = [r for r in rows if int(r["Start_Timestamp"]) >= end - win]
+anchor = sys.argv[3] if len(sys.argv) > 3 else ""
+end = max(int(r["End_Timestamp"]) for r in rows if anchor in r["Kernel_Name"])
+sel = [r for r in rows if end - win <= int(r["Start_Timestamp"]) and int(r["End_Timestamp"]) <= end]
 agg = collections.defaultdict(lambda: [0, 0])
 for r in sel:
     n = r["Kernel_Name"]
-    n = n.replace("void ", "").split("(")[0][:90]
+    n = n.replace("void ", "").replace("bnn::", "").split("(")[0][:90]
     agg[n][0] += 1
     agg[n][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 tot = sum(v[1] for v in agg.values())
