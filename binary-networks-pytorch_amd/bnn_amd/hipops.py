@@ -151,6 +151,24 @@ def avgpool_pack(x: torch.Tensor, k: int, nonneg: bool = False) -> PackedAct:
     return a
 
 
+def orpool_packed(a: PackedAct, k: int) -> PackedAct:
+    """``sign(AvgPool2d(k, k, ceil_mode=True, count_include_pad=False)(x))`` from the sign planes of a
+    NON-NEGATIVE ``x`` (``a.nonneg``): the OR of the P plane over each window (include/bnn_hip.h)."""
+    if not a.nonneg:
+        raise native.NativeError("bnn_amd: orpool_packed needs planes of a non-negative tensor (nonneg=True)")
+    lib = native.require()
+    N, C, H, W = a.shape
+    ho, wo = (H + k - 1) // k, (W + k - 1) // k
+    dev = a.P.device
+    with torch.cuda.device(dev):
+        out = empty_packed(N, C, ho, wo, dev)
+        if N:
+            native.check(lib.bnn_hip_orpool_packed(a.P.data_ptr(), N, C, H, W, k, out.P.data_ptr(), out.M.data_ptr(),
+                                                   _stream(dev)), "bnn_hip_orpool_packed")
+    out.nonneg = True
+    return out
+
+
 def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: torch.Tensor,
             out_f32: bool = True, out_packed: bool = True, exact_fp32: bool = False, fp16: bool = False):
     """conv 7x7/2/3 (3->64, no bias) -> folded BN -> ReLU -> MaxPool 3/2/1 in one MFMA kernel

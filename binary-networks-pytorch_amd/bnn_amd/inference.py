@@ -286,10 +286,16 @@ class FusedResNet(nn.Module):
                 if side is not None:
                     side.wait_stream(cur)
                 with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                    sc_in = hipops.avgpool_pack(t, b["pool"], nonneg=packed.nonneg) if b["pool"] > 1 else packed
+                    if b["pool"] > 1 and packed.nonneg:   # sign(avg of non-negative values) = OR of the sign bits
+                        sc_in = hipops.orpool_packed(packed, b["pool"])
+                    elif b["pool"] > 1:
+                        sc_in = hipops.avgpool_pack(t, b["pool"])
+                    else:
+                        sc_in = packed
                     idn, _ = b["ds"].run(sc_in, out_f32=True, out_packed=False)
                 if side is not None:
                     t.record_stream(side)
+                    packed.P.record_stream(side)
                     sc_in.P.record_stream(side)
                     sc_in.M.record_stream(side)
             else:

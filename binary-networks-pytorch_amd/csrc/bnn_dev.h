@@ -83,6 +83,8 @@ int launch_bn_act_pack(const float* x, int N, int C, int H, int W, const float* 
                        int relu, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_avgpool_pack(const float* x, int N, int C, int H, int W, int k, uint64_t* P, uint64_t* M,
                         hipStream_t stream);
+int launch_orpool_packed(const uint64_t* P, int N, int C, int H, int W, int k, uint64_t* outP, uint64_t* outM,
+                         hipStream_t stream);
 int launch_bn_relu_maxpool_pack(const float* x, int N, int C, int H, int W, const float* bn_a,
                                 const float* bn_b, int relu, int k, int stride, int pad, float* out,
                                 uint64_t* P, uint64_t* M, hipStream_t stream);

@@ -172,6 +172,15 @@ int bnn_hip_avgpool_pack_f32(const float* x, int N, int C, int H, int W, int k, 
   return bnn::launch_avgpool_pack(x, N, C, H, W, k, P, M, static_cast<hipStream_t>(stream));
 }
 
+int bnn_hip_orpool_packed(const uint64_t* P, int N, int C, int H, int W, int k, uint64_t* out_P,
+                          uint64_t* out_M, void* stream) {
+  if (!P || !out_P || !out_M || N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if ((long long)N * ((C + 63) / 64) * H * W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (!aligned(P, 8) || !aligned(out_P, 8) || !aligned(out_M, 8)) return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  return bnn::launch_orpool_packed(P, N, C, H, W, k, out_P, out_M, static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_bn_relu_maxpool_pack_f32(const float* x, int N, int C, int H, int W,
                                      const float* bn_scale, const float* bn_shift, int relu, int k,
                                      int stride, int pad, float* out_f32, uint64_t* P, uint64_t* M,

@@ -185,6 +185,46 @@ __global__ __launch_bounds__(256) void avgpool_pack_kernel(const float* __restri
   M[o] = mw;
 }
 
+// The same shortcut input when the tensor is NON-NEGATIVE (a ReLU output — every ResNet stage transition) and its
+// sign planes already exist: an average of non-negative values is positive iff one of them is, so
+//     sign(AvgPool_k(x)) = OR over the k x k window of the P plane,   M = 0,
+// computed from 2 bits per element instead of re-reading the fp32 tensor (206 MB -> 6.4 MB for the 64-channel
+// 56x56 stage at batch 256: 38 us -> launch-bound).  Exact for finite inputs (a sum of non-negative floats is
+// positive iff a term is); a NaN element makes the reference's average NaN (sign 0) while the OR ignores it.
+__global__ __launch_bounds__(256) void orpool_packed_kernel(const uint64_t* __restrict__ P, int H, int W, int k,
+                                                            int Ho, int Wo, long long nwords,
+                                                            uint64_t* __restrict__ outP,
+                                                            uint64_t* __restrict__ outM) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;  // (n * cw64 + g, oy, ox)
+  if (q >= nwords) return;
+  const int hw = Ho * Wo;
+  const long long plane = q / hw;
+  const int r = (int)(q - plane * hw);
+  const int oy = r / Wo, ox = r - oy * Wo;
+  const uint64_t* src = P + plane * H * W;
+  uint64_t acc = 0;
+  for (int dy = 0; dy < k; ++dy) {
+    const int iy = oy * k + dy;
+    if (iy >= H) break;
+    for (int dx = 0; dx < k; ++dx) {
+      const int ix = ox * k + dx;
+      if (ix >= W) break;
+      acc |= src[(size_t)iy * W + ix];
+    }
+  }
+  outP[q] = acc;
+  outM[q] = 0;
+}
+
+int launch_orpool_packed(const uint64_t* P, int N, int C, int H, int W, int k, uint64_t* outP, uint64_t* outM,
+                         hipStream_t stream) {
+  const int Ho = (H + k - 1) / k, Wo = (W + k - 1) / k;
+  const long long nwords = (long long)N * ((C + 63) / 64) * Ho * Wo;
+  hipLaunchKernelGGL(orpool_packed_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, P, H, W, k,
+                     Ho, Wo, nwords, outP, outM);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
 // k == 2 on even images with W % 4 == 0 (every ResNet stage transition): one thread produces two
 // adjacent outputs from one aligned float4 per input row.  Same tap order as the scalar kernel.
 __global__ __launch_bounds__(256) void avgpool2_pack_kernel(const float* __restrict__ x, int C,

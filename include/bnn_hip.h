@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 5
+#define BNN_HIP_ABI_VERSION 6
 #define BNN_HIP_OCB 32 /* output channels per weight block (padding granularity of O) */
 
 typedef enum bnn_hip_status {
@@ -192,6 +192,14 @@ int bnn_hip_pack_act_f16(const void* x, int N, int C, int H, int W,
  * ceil(H/k) x ceil(W/k) pixels.                                                    */
 int bnn_hip_avgpool_pack_f32(const float* x, int N, int C, int H, int W, int k,
                              uint64_t* P, uint64_t* M, void* stream);
+
+/* The same shortcut input from the SIGN PLANES of a NON-NEGATIVE tensor (a ReLU output: M == 0): the average of
+ * non-negative values is positive iff one of them is, so sign(AvgPool_k(x)) is the OR of the P plane over each
+ * k x k window (ceil mode: windows are clipped at the border) — 2 bits per element read instead of 32.
+ * P: [N,ceil(C/64),H,W]; out_P / out_M: [N,ceil(C/64),ceil(H/k),ceil(W/k)], out_M is written as 0.
+ * Exact for finite inputs; the caller vouches for x >= 0 (as with BNN_HIP_FLAG_ACT_NONNEG).            */
+int bnn_hip_orpool_packed(const uint64_t* P, int N, int C, int H, int W, int k,
+                          uint64_t* out_P, uint64_t* out_M, void* stream);
 
 /* BatchNorm(eval) -> [ReLU] -> sign() of an fp32 NCHW tensor in one pass: the input binarisation of a
  * pre-activation block (res_block.py:148 `conv1(bn1(x))`, hierarchical_block.py:39 `conv1(act1(bn1(x)))`).

@@ -212,6 +212,26 @@ from bnn_amd.models import resnet18, resnet50  # noqa: E402
 from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer  # noqa: E402
 
 
+@pytest.mark.parametrize("shape,k", [((2, 64, 56, 56), 2), ((3, 128, 7, 7), 2), ((2, 70, 9, 5), 2), ((1, 200, 13, 10), 3),
+                                     ((4, 512, 14, 14), 2), ((1, 64, 1, 1), 2)])
+def test_orpool_of_sign_planes_equals_avgpool_then_sign_for_nonnegative_inputs(shape, k):
+    """bnn_hip_orpool_packed: for x >= 0, sign(AvgPool_k(x)) (ceil mode, clipped windows) == OR of the P plane — from
+    the planes alone, bit-exact against torch's pool + sign AND against the fp32-reading avgpool_pack kernel."""
+    x = dev(gen.activation("relu", gen.seed_of("orpool", shape), shape))
+    x.view(-1)[::5] = 0.0
+    act = hipops.pack_act(x)
+    act.nonneg = True
+    got = hipops.orpool_packed(act, k)
+    ref = torch.sign(F.avg_pool2d(x, k, k, 0, ceil_mode=True, count_include_pad=False))
+    P, M = oracle.pack_act(ref.cpu().numpy())
+    assert np.array_equal(u64(got.P), P) and np.array_equal(u64(got.M), M) and got.nonneg
+    via_f32 = hipops.avgpool_pack(x, k, nonneg=True)
+    assert torch.equal(via_f32.P, got.P) and torch.equal(via_f32.M, got.M)
+    act.nonneg = False
+    with pytest.raises(native.NativeError):
+        hipops.orpool_packed(act, k)
+
+
 def _r18(activation=None):
     cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
                       weight_pre_process=XNORWeightBinarizer)
@@ -476,7 +496,7 @@ def test_fused_executor_uses_the_head_kernel_and_no_library_gemm():
     x = dev(gen.normal(31, (4, 3, 64, 64)))
     before = native.launch_count()
     y = fused(x)
-    # stem + 16 convs + 3 shortcut convs + 3 avgpool-packs + head
+    # stem + 16 convs + 3 shortcut convs + 3 OR-pools of sign planes + head
     assert native.launch_count() - before == 1 + 16 + 3 + 3 + 1
     with torch.no_grad():
         assert torch.allclose(y, net(x), rtol=1e-3, atol=1e-3 * float(y.abs().max()))

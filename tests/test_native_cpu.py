@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_require_loads_and_reports_abi():
     lib = native.require()
-    assert lib.bnn_hip_abi_version() == native.ABI_VERSION == 5
+    assert lib.bnn_hip_abi_version() == native.ABI_VERSION == 6
     assert lib.bnn_hip_status_string(0) == b"ok"
     assert b"invalid" in lib.bnn_hip_status_string(-1)
     assert isinstance(native.launch_count(), int)
@@ -61,6 +61,8 @@ def test_argument_validation_without_touching_the_gpu():
     assert lib.bnn_hip_avgpool_pack_f32(None, 1, 1, 1, 1, 2, None, None, None) == -1
     assert lib.bnn_hip_pack_weight_f32(None, 1, 1, 1, 1, 0, 1, None, None, None, None, None) == -1
     assert lib.bnn_hip_pack_act_f16(None, 1, 1, 1, 1, None, None, None) == -1
+    assert lib.bnn_hip_orpool_packed(None, 1, 64, 8, 8, 2, None, None, None) == -1
+    assert lib.bnn_hip_orpool_packed(16, 1, 64, 8, 8, 0, 16, 16, None) == -1
     assert lib.bnn_hip_avgpool_fc_f32(None, 1, 1, 1, None, None, 1, None, None) == -1
     assert lib.bnn_hip_avgpool_fc_f32(16, 0, 512, 49, 16, None, 1000, 16, None) == -1
     # gradient kernels: host-side geometry helpers and argument checks
