@@ -19,6 +19,7 @@ stand in a training graph.
 """
 from __future__ import annotations
 
+import collections
 from typing import List, Optional, Tuple
 
 import torch
@@ -26,6 +27,31 @@ import torch
 from . import hipops, native
 
 _NS = "bnn_amd"
+
+
+_PACK_CACHE: "collections.OrderedDict" = collections.OrderedDict()
+_PACK_CACHE_MAX = 256
+
+
+def _packed(weight: torch.Tensor, center: bool, compute_alpha: bool) -> hipops.PackedWeight:
+    """Packed form of ``weight``, cached on (storage pointer, version counter, shape, recipe): the pack reads its
+    zero-weight flag with a blocking ``.item()``, which would make the ops unusable under HIP-graph capture and slow
+    in a training graph if it ran on every call.  (Writes through ``weight.data`` bypass the version counter: call
+    ``torch_ops.clear_cache()`` after them.)"""
+    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), center, compute_alpha)
+    pw = _PACK_CACHE.get(key)
+    if pw is None:
+        pw = hipops.pack_weight(weight, center, compute_alpha)
+        _PACK_CACHE[key] = pw
+        while len(_PACK_CACHE) > _PACK_CACHE_MAX:
+            _PACK_CACHE.popitem(last=False)
+    else:
+        _PACK_CACHE.move_to_end(key)
+    return pw
+
+
+def clear_cache() -> None:
+    _PACK_CACHE.clear()
 
 
 def _need_gpu(*ts: Optional[torch.Tensor]) -> None:
@@ -57,7 +83,7 @@ def binary_conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
     """``post_scale * (conv2d(sign(x), sign(Wc) * alpha) + bias)`` — ``bnn.layers.Conv2d.forward`` with
     ``BasicInputBinarizer`` / ``XNORWeightBinarizer`` / optional ``BasicScaleBinarizer`` hooks."""
     _need_gpu(x, weight, bias, post_scale)
-    pw = hipops.pack_weight(weight, center_weights, compute_alpha)
+    pw = _packed(weight, center_weights, compute_alpha)
     return hipops.bconv2d(hipops.pack_act(x), pw, bias, post_scale, tuple(stride), tuple(padding), tuple(dilation))
 
 
@@ -84,7 +110,7 @@ def _conv_backward(ctx, g):
         if ctx.needs_input_grad[3]:
             # d out / d post_scale = the PRE-scale output, recomputed by the forward kernels (dividing the saved
             # output by the scale would give NaN/inf for a zero entry of post_scale, where the gradient is finite)
-            pre = hipops.bconv2d(hipops.pack_act(x), hipops.pack_weight(weight, center, compute_alpha), bias, None,
+            pre = hipops.bconv2d(hipops.pack_act(x), _packed(weight, center, compute_alpha), bias, None,
                                  tuple(stride), tuple(padding), tuple(dilation))
             gs = (g * pre).sum(dim=(0, 2, 3)).reshape(post_scale.shape)
         g = g * s
@@ -108,7 +134,7 @@ def binary_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
                   post_scale: Optional[torch.Tensor], center_weights: bool, compute_alpha: bool) -> torch.Tensor:
     """``bnn.layers.Linear.forward`` (bnn/layers/linear.py:22-27) as a 1x1 convolution over 1x1 images."""
     _need_gpu(x, weight, bias, post_scale)
-    pw = hipops.pack_weight(weight, center_weights, compute_alpha)
+    pw = _packed(weight, center_weights, compute_alpha)
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
     out = hipops.bconv2d(hipops.pack_act(x2[:, :, None, None]), pw, bias, post_scale)
