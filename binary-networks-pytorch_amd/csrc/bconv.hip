@@ -131,6 +131,29 @@ __device__ __forceinline__ void st_off(T* __restrict__ base, unsigned byte_off, 
   *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
+// Buffer addressing for the fp32 streams of the straight-line epilogue: base = a 128-bit descriptor in SGPRs,
+// per-channel byte offset = the instruction's SGPR `soffset`, per-lane byte offset = one VGPR (`offen`) —
+// `buffer_load_dword v, v_off, s[desc:desc+3], s_chan offen`.  With plain pointers hipcc re-associates
+// (base + lane) + channel into a 64-bit VECTOR address per access (two VALU ops and a VGPR pair each).
+// The descriptor is built from kernel arguments only (wave-uniform); 0x00020000 = raw 32-bit data format.
+#if defined(__HIP_DEVICE_COMPILE__)
+using BufRsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ BufRsrc make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld(BufRsrc r, unsigned lane_boff, unsigned chan_boff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_boff, (int)chan_boff, 0));
+}
+__device__ __forceinline__ void buf_st(BufRsrc r, unsigned lane_boff, unsigned chan_boff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)lane_boff, (int)chan_boff, 0);
+}
+#else  // host pass of hipcc only parses these
+struct BufRsrc {};
+__device__ __forceinline__ BufRsrc make_rsrc(const void*) { return {}; }
+__device__ __forceinline__ float buf_ld(BufRsrc, unsigned, unsigned) { return 0.0f; }
+__device__ __forceinline__ void buf_st(BufRsrc, unsigned, unsigned, float) {}
+#endif
+
 // Output pixel of this lane.
 struct Pix {
   int q, n, r, oy, ox;
@@ -285,7 +308,11 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
 #if BNN_NT_STORE
       if ((f & EF_OUTF) && live) __builtin_nontemporal_store(y, &(outf + (size_t)(o + g.c_off) * hw)[lane_off]);
 #else
-      if ((f & EF_OUTF) && live) st_off(outf + (size_t)(o + g.c_off) * hw, lane_off, y);
+      if constexpr (FULL) {
+        if (f & EF_OUTF) buf_st(make_rsrc(e.out), lane_off, (unsigned)(o + g.c_off) * (unsigned)hw * 4u, y);
+      } else {
+        if ((f & EF_OUTF) && live) st_off(outf + (size_t)(o + g.c_off) * hw, lane_off, y);
+      }
 #endif
       if (f & EF_PACK) {
         if (f & EF_PACK_AFF) pv = fmaf(pv, e.pack_a[o], e.pack_b[o]);
@@ -317,7 +344,8 @@ __device__ __forceinline__ void prefetch_residual(const Geo& g, const Pix& px, i
   for (int j = 0; j < NACC; ++j)
     // lanes past the last pixel load too (they were clamped to it): they must compute the same sign bits as the
     // live copy, because store_packed() lets them store
-    resv[j] = (FULL || o0 + j < g.O) ? ld_off(e.res + (size_t)(o0 + j + g.c_off) * hw, lane_off) : 0.0f;
+    if constexpr (FULL) resv[j] = buf_ld(make_rsrc(e.res), lane_off, (unsigned)(o0 + j + g.c_off) * (unsigned)hw * 4u);
+    else resv[j] = (o0 + j < g.O) ? ld_off(e.res + (size_t)(o0 + j + g.c_off) * hw, lane_off) : 0.0f;
 }
 
 // sign(y) of one 32-channel block: one half of a uint64 word of the [n][group][y][x] output planes.
