@@ -11,14 +11,16 @@
 //    two ds_read2_b32 instead of 8 gathers + packing;
 //  * B (weights) never goes through LDS: a wave owns 32 of the 64 output channels and keeps their
 //    hi/lo fragments for all 6 k-steps in 96 VGPRs for the life of the persistent workgroup;
-//  * 8 waves = 4 pixel groups (4 sub-tiles of 16 conv pixels each) x 2 channel halves, one workgroup
-//    per CU.  (Measured alternative: two independent 4-wave workgroups per CU, one channel half each, so
-//    that one's matrix phase overlaps the other's pooling: 540 us vs 440 us — the phases are issue bound,
-//    not latency bound, and the patch is then fetched and split twice.)
+//  * 4 waves = 2 pixel groups (5 sub-tiles of 16 conv pixels each) x 2 channel halves; TWO such
+//    workgroups per CU, each on its own 4 x 8 pooled tile, so that one's matrix phase can run beside the
+//    other's fetch / pooling / stores (one 8-wave workgroup on an 8 x 7 tile: 329 us vs 306 us, round 2).
+//    The accumulators go through in two passes (4 + 1 sub-tiles) to stay inside 256 VGPRs.
+//    (Round-1 alternative that lost, 540 vs 440 us: two workgroups that SHARE a tile, one channel half
+//    each — the patch is then fetched and split twice.)
 //  * the next tile's patch is fetched into registers during the matrix phase; tiles are walked in
 //    XCD-contiguous order;
 //  * max-pool reads each staged conv value ~3x instead of 9x: a thread owns one pooled COLUMN of one
-//    channel (17 row maxima -> 8 outputs); the sign bits of 8 channels are gathered with one ballot and
+//    channel (9 row maxima -> 4 outputs); the sign bits of 8 channels are gathered with one ballot and
 //    leave as whole 64-bit words one tile later (byte stores from several waves into one word are slow).
 #include "bnn_dev.h"
 
@@ -31,34 +33,39 @@ namespace bnn {
 namespace stem2 {
 constexpr int CIN = 3, KS = 7, COUT = 64;
 constexpr int KROWS = 24, KSTEPS = KROWS / 4;        // 6 k-steps of 32 (4 rows of 8)
-constexpr int PTH = 8, PTW = 7;                      // pooled tile
-constexpr int CTH = 2 * PTH + 1, CTW = 2 * PTW + 1;  // conv tile 17 x 15 (pool halo included)
-constexpr int MPIX = CTH * CTW;                      // 255
-constexpr int ITH = 2 * CTH + 5;                     // 39 input rows
-constexpr int ITWP = 36;                             // 35 input columns + 1 zero column (kx = 7)
+// Two INDEPENDENT 4-wave workgroups per CU, each on a 4 x 8 pooled tile: the phases of one (fetch, matrix,
+// BN, pooling + stores) are serialised by its barriers, but the CU interleaves them with the other
+// workgroup's.  One 8-wave workgroup on an 8 x 7 tile: 329 us; this: 306 us (same GPU, batch 256).
+constexpr int PTH = 4, PTW = 8;                      // pooled tile
+constexpr int NT = 256, SUBS = 5;                    // threads; 16-pixel sub-tiles per wave
+constexpr int CTH = 2 * PTH + 1, CTW = 2 * PTW + 1;  // conv tile 9 x 17 (pool halo included)
+constexpr int MPIX = CTH * CTW;                      // 153
+constexpr int ITH = 2 * CTH + 5;                     // 23 input rows
+constexpr int ITWP = 2 * CTW + 6;                    // 39 input columns + 1 zero column (kx = 7)
 // Patch rows are stored ROWH = 96 halves (48 dwords = 16 mod 32 banks) apart: the four k-rows a wave reads
 // at once (lane>>4 -> consecutive ky) then fall into alternating halves of the 32 LDS banks, so the two
 // 16-lane groups of each half-wave never collide.  (Dense rows of 18 dwords: +50 % LDS cycles on the
 // A-operand reads, measured with SQ_LDS_BANK_CONFLICT.)
 constexpr int ROWH = 96;
 constexpr int ICHP = ITH * ROWH;                     // halves per channel plane
-constexpr int NINP = CIN * ICHP;                     // halves per plane (22.5 KB)
-constexpr int NROW = CIN * ITH;                      // 117 patch rows
-constexpr int NPC = ITWP / 2;                        // 18 column pairs per row
+constexpr int NINP = CIN * ICHP;                     // halves per plane (13 KB)
+constexpr int NROW = CIN * ITH;                      // 69 patch rows
+constexpr int NPC = ITWP / 2;                        // 20 column pairs per row
 // Staged conv tile: [conv pixel m][channel], row stride SC floats.  SC = 68 (= 4 mod 64) makes both sides
 // conflict-free: the MFMA D layout writes (channel = lane&15, pixel = 4*(lane>>4)+r) -> bank lane&15 + 16*(lane>>4),
 // the pooling threads read (channel = lane&7 [+8*wave], column = lane>>3) -> bank lane&7 + 8*(lane>>3).
 // (The channel-major layout it replaces spent 55 % of the LDS-active cycles in bank conflicts: PMC.)
 constexpr int SC = COUT + 4;
-constexpr int NT = 512;
-constexpr int RSTEP = NT / NPC;                      // 28 rows per sweep (504 fetching threads)
-constexpr int PER_T = (NROW + RSTEP - 1) / RSTEP;    // 5 column pairs per thread
-constexpr int SUBS = 4, TT = 2;                      // sub-tiles and channel tiles per wave
+constexpr int NW = NT / 64, MG = NW / 2;             // waves; pixel groups
+constexpr int PJ = COUT / (NW * 8);                  // pooling passes (8 channels per wave and pass)
+constexpr int RSTEP = NT / NPC;                      // 12 rows per sweep (240 fetching threads)
+constexpr int PER_T = (NROW + RSTEP - 1) / RSTEP;    // 6 column pairs per thread
+constexpr int TT = 2, SPASS = 4;                     // channel tiles per wave; sub-tiles per accumulator pass
 // LDS carve (bytes)
 constexpr int OFF_HI = 0;
 constexpr int OFF_LO = OFF_HI + ((NINP * 2 + 15) / 16) * 16;
 constexpr int OFF_STAGE = OFF_LO + ((NINP * 2 + 15) / 16) * 16;
-constexpr int OFF_BITS = OFF_STAGE + (MPIX + 1) * SC * 4;  // sign bytes of the tile: [2][56 pixels][8]
+constexpr int OFF_BITS = OFF_STAGE + (MPIX + 1) * SC * 4;  // sign bytes of the tile: [2][32 pixels][8]
 constexpr int LDS_BYTES = OFF_BITS + 2 * PTH * PTW * 8;
 }  // namespace stem2
 
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int mg = wave & 3, nh = wave >> 2;  // pixel group (4 sub-tiles), channel half
+  const int mg = wave % MG, nh = wave / MG;  // pixel group (SUBS sub-tiles), channel half
 
   // ---- once: B fragments (hi, lo) of this wave's 2 channel tiles x 6 k-steps, in registers.
   // MFMA 16x16x32 B operand: lane holds B[k = 8*lg + e][j = li], e = 0..7  ->  row 4*ks + lg, kx = e.
@@ -133,16 +140,9 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
   // fetch role: column pair `fpc` of patch rows frow0 + 28*u (row = c*39 + r)
   const int fpc = tid % NPC, frow0 = tid / NPC;
   const bool fetcher = tid < NPC * RSTEP;
-  int f_goff[PER_T];  // c*H*W + r*W + 2*fpc, or -1 past the patch
-#pragma unroll
-  for (int u = 0; u < PER_T; ++u) {
-    const int R = frow0 + RSTEP * u;
-    const int c = R / ITH, r = R - c * ITH;
-    f_goff[u] = (fetcher && R < NROW) ? (c * H + r) * W + 2 * fpc : -1;
-  }
-  // pooling role: one pooled column (8 outputs) of one channel; 8 channels x 8 column slots per wave
+  // pooling role: one pooled column (PTH outputs) of one channel, PJ times; 8 channels x 8 columns per wave and pass
   const int pchl = lane & 7, pplx = lane >> 3;  // channel within the wave's byte, pooled column (7 = idle)
-  const int pch = wave * 8 + pchl;
+  const int pch0 = wave * 8 + pchl;
 
   const int ntiles = N * tiles_y * tiles_x;
   const int nseq = per_xcd * 8;
@@ -163,13 +163,17 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
     const int ix = ix0 + 2 * fpc;
     const bool okc0 = valid && (unsigned)ix < (unsigned)W;
     const bool okc1 = valid && 2 * fpc + 1 < ITWP - 1 && (unsigned)(ix + 1) < (unsigned)W;  // col 35: zero
+    const float* xl = xb + 2 * fpc;
+    int fr = frow0;
+    asm volatile("" : "+v"(fr));  // per-row offsets are recomputed per tile: hoisted, they only get spilled
 #pragma unroll
     for (int u = 0; u < PER_T; ++u) {
-      const int R = frow0 + RSTEP * u;
-      const int r = R - (R >= 2 * ITH ? 2 * ITH : R >= ITH ? ITH : 0);
-      const bool okr = f_goff[u] >= 0 && (unsigned)(iy0 + r) < (unsigned)H;
-      nx0[u] = (okr && okc0) ? xb[f_goff[u]] : 0.0f;
-      nx1[u] = (okr && okc1) ? xb[f_goff[u] + 1] : 0.0f;
+      const int R = fr + RSTEP * u;
+      const int c = (R >= 2 * ITH) + (R >= ITH), r = R - c * ITH;
+      const int goff = (c * H + r) * W;  // c*H*W + r*W
+      const bool okr = fetcher && R < NROW && (unsigned)(iy0 + r) < (unsigned)H;
+      nx0[u] = (okr && okc0) ? xl[goff] : 0.0f;
+      nx1[u] = (okr && okc1) ? xl[goff + 1] : 0.0f;
     }
   };
   auto commit = [&]() {
@@ -194,8 +198,8 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
     return __builtin_bit_cast(half8, v);
   };
 
-  // sign words of the PREVIOUS tile: its 8 waves left one byte each per pixel in LDS; 56 threads send
-  // them as whole 64-bit words (byte stores from 8 waves into one word cost ~80 us at batch 256)
+  // sign words of the PREVIOUS tile: its waves left 8 bytes per pixel in LDS; PTH*PTW threads send them
+  // as whole 64-bit words (byte stores from several waves into one word cost ~80 us at batch 256)
   int prev_n = -1, prev_py0 = 0, prev_px0 = 0, buf = 0;
   auto flush_bits = [&](int b) {
     if (P && !(BNN_STEM_ABL & 32) && prev_n >= 0 && tid < PTH * PTW) {
@@ -235,82 +239,87 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
     const int py0 = ty * PTH, px0 = tx * PTW;        // pooled origin
     const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;  // conv origin (pool pad 1)
 
-    // ---- implicit GEMM: 4 sub-tiles x 2 channel tiles x 6 k-steps x (lo*hi + hi*lo + hi*hi).
+    // ---- implicit GEMM: SUBS sub-tiles x 2 channel tiles x 6 k-steps x (lo*hi + hi*lo + hi*hi).
     // Two sub-tiles at a time, product-type major: 4 independent accumulators between two MFMAs
     // that touch the same one.
-    f32x4 acc[SUBS][TT];
+    // The sub-tiles go through in passes of at most SPASS (accumulators of one pass live at a time).
+    // ---- BN + ReLU, conv tile -> LDS.  D layout: column = li (channel), row = 4*lg + r (pixel).
 #pragma unroll
-    for (int i = 0; i < SUBS; ++i)
+    for (int s0 = 0; s0 < SUBS; s0 += SPASS) {
+      if (s0) __builtin_amdgcn_sched_barrier(0);  // one pass's accumulators at a time
+      f32x4 acc[SPASS][TT];
 #pragma unroll
-      for (int tt = 0; tt < TT; ++tt) acc[i][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < SPASS; ++i)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc[i][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #if !(BNN_STEM_ABL & 1)
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
+      for (int ks = 0; ks < KSTEPS; ++ks) {
 #pragma unroll
-      for (int ip = 0; ip < SUBS; ip += 2) {
-        half8 ah[2], al[2];
+        for (int ip = 0; ip < SPASS; ip += 2) {
+          if (s0 + ip >= SUBS) continue;
+          half8 ah[2], al[2];
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          ah[d] = load_a(hiP, abase[ip + d] + koff[ks]);
-          if constexpr (!HALF) al[d] = load_a(loP, abase[ip + d] + koff[ks]);
-        }
-        if constexpr (!HALF) {
-#pragma unroll
-          for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt)
-              acc[ip + d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[d], bh[ks][tt], acc[ip + d][tt], 0, 0, 0);
-#pragma unroll
-          for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt)
-              acc[ip + d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[d], bl[ks][tt], acc[ip + d][tt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-          for (int tt = 0; tt < TT; ++tt)
-            acc[ip + d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[d], bh[ks][tt], acc[ip + d][tt], 0, 0, 0);
-      }
-    }
-#endif
-
-    STEM_T(1)
-    // ---- BN + ReLU, conv tile -> LDS.  D layout: column = li (channel), row = 4*lg + r (pixel).
-#if !(BNN_STEM_ABL & 2)
-    // three quarters of the tiles lie entirely inside the conv output: no per-pixel range tests there
-    const bool interior = cy0 >= 0 && cx0 >= 0 && cy0 + CTH <= Hc && cx0 + CTW <= Wc;  // workgroup-uniform
-    float* sdst = stage + ((SUBS * mg) * 16 + lg * 4) * SC + 32 * nh + li;
-    if (interior) {
-#pragma unroll
-      for (int i = 0; i < SUBS; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if ((SUBS * mg + i) * 16 + lg * 4 + r < MPIX) {
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt)
-              sdst[(i * 16 + r) * SC + 16 * tt] = fmaxf(fmaf(acc[i][tt][r], ba[tt], bb[tt]), 0.0f);
+          for (int d = 0; d < 2; ++d) {
+            if (s0 + ip + d >= SUBS) continue;
+            ah[d] = load_a(hiP, abase[s0 + ip + d] + koff[ks]);
+            if constexpr (!HALF) al[d] = load_a(loP, abase[s0 + ip + d] + koff[ks]);
           }
-    } else {
+          if constexpr (!HALF) {
 #pragma unroll
-      for (int i = 0; i < SUBS; ++i) {
+            for (int d = 0; d < 2 && s0 + ip + d < SUBS; ++d)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = (SUBS * mg + i) * 16 + lg * 4 + r;
-          if (m < MPIX) {
-            const int cy = m / CTW, cx = m - cy * CTW;
-            const bool inside = (unsigned)(cy0 + cy) < (unsigned)Hc && (unsigned)(cx0 + cx) < (unsigned)Wc;
+              for (int tt = 0; tt < TT; ++tt)
+                acc[ip + d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[d], bh[ks][tt], acc[ip + d][tt], 0, 0, 0);
 #pragma unroll
-            for (int tt = 0; tt < TT; ++tt) {
-              const float v = fmaxf(fmaf(acc[i][tt][r], ba[tt], bb[tt]), 0.0f);
-              // positions outside the conv output are MaxPool padding: 0 never beats a ReLU output
-              sdst[(i * 16 + r) * SC + 16 * tt] = inside ? v : 0.0f;
+            for (int d = 0; d < 2 && s0 + ip + d < SUBS; ++d)
+#pragma unroll
+              for (int tt = 0; tt < TT; ++tt)
+                acc[ip + d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[d], bl[ks][tt], acc[ip + d][tt], 0, 0, 0);
+          }
+#pragma unroll
+          for (int d = 0; d < 2 && s0 + ip + d < SUBS; ++d)
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+              acc[ip + d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[d], bh[ks][tt], acc[ip + d][tt], 0, 0, 0);
+        }
+      }
+#endif
+#if !(BNN_STEM_ABL & 2)
+      // three quarters of the tiles lie entirely inside the conv output: no per-pixel range tests there
+      const bool interior = cy0 >= 0 && cx0 >= 0 && cy0 + CTH <= Hc && cx0 + CTW <= Wc;  // workgroup-uniform
+      float* sdst = stage + ((SUBS * mg) * 16 + lg * 4) * SC + 32 * nh + li;
+      if (interior) {
+#pragma unroll
+        for (int i = 0; i < SPASS; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (s0 + i < SUBS && (SUBS * mg + s0 + i) * 16 + lg * 4 + r < MPIX) {
+#pragma unroll
+              for (int tt = 0; tt < TT; ++tt)
+                sdst[((s0 + i) * 16 + r) * SC + 16 * tt] = fmaxf(fmaf(acc[i][tt][r], ba[tt], bb[tt]), 0.0f);
+            }
+      } else {
+#pragma unroll
+        for (int i = 0; i < SPASS; ++i) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = (SUBS * mg + s0 + i) * 16 + lg * 4 + r;
+            if (s0 + i < SUBS && m < MPIX) {
+              const int cy = m / CTW, cx = m - cy * CTW;
+              const bool inside = (unsigned)(cy0 + cy) < (unsigned)Hc && (unsigned)(cx0 + cx) < (unsigned)Wc;
+#pragma unroll
+              for (int tt = 0; tt < TT; ++tt) {
+                const float v = fmaxf(fmaf(acc[i][tt][r], ba[tt], bb[tt]), 0.0f);
+                // positions outside the conv output are MaxPool padding: 0 never beats a ReLU output
+                sdst[((s0 + i) * 16 + r) * SC + 16 * tt] = inside ? v : 0.0f;
+              }
             }
           }
         }
       }
-    }
 #endif
+    }
     STEM_T(2)
     __syncthreads();  // conv tile staged; every wave is done reading the patch
     STEM_T(3)
@@ -320,26 +329,30 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
     STEM_T(4)
 
 #if !(BNN_STEM_ABL & 4)
-    // ---- 3x3 / stride-2 max pool: row maxima of the thread's 3 conv columns, then 8 column maxima
+    // ---- 3x3 / stride-2 max pool: row maxima of the thread's 3 conv columns, then PTH column maxima
     const int px = px0 + pplx;
     const bool col_live = valid && pplx < PTW && px < Wp;
-    float hm[CTH];
-    {
-      const float* sp = stage + (2 * (pplx < PTW ? pplx : 0)) * SC + pch;
 #pragma unroll
-      for (int r = 0; r < CTH; ++r)
-        hm[r] = fmaxf(fmaxf(sp[(r * CTW) * SC], sp[(r * CTW + 1) * SC]), sp[(r * CTW + 2) * SC]);
-    }
+    for (int pj = 0; pj < PJ; ++pj) {
+      const int pch = pch0 + NW * 8 * pj;
+      float hm[CTH];
+      {
+        const float* sp = stage + (2 * (pplx < PTW ? pplx : 0)) * SC + pch;
 #pragma unroll
-    for (int ply = 0; ply < PTH; ++ply) {
-      const int py = py0 + ply;
-      const bool live = col_live && py < Hp;  // py < Hp is workgroup-uniform
-      const float v = fmaxf(fmaxf(hm[2 * ply], hm[2 * ply + 1]), hm[2 * ply + 2]);
-      if (live && out) out[(((size_t)n * COUT + pch) * Hp + py) * Wp + px] = v;
-      if (P && !(BNN_STEM_ABL & 16)) {  // lanes 8*plx .. 8*plx+7 hold the 8 channels of byte `wave` of pixel (ply, plx)
-        const unsigned long long mask = __ballot(live && is_pos(v));
-        if (pchl == 0 && pplx < PTW)
-          bits[((buf * PTH + ply) * PTW + pplx) * 8 + wave] = (uint8_t)(mask >> (8 * pplx));
+        for (int r = 0; r < CTH; ++r)
+          hm[r] = fmaxf(fmaxf(sp[(r * CTW) * SC], sp[(r * CTW + 1) * SC]), sp[(r * CTW + 2) * SC]);
+      }
+#pragma unroll
+      for (int ply = 0; ply < PTH; ++ply) {
+        const int py = py0 + ply;
+        const bool live = col_live && py < Hp;  // py < Hp is workgroup-uniform
+        const float v = fmaxf(fmaxf(hm[2 * ply], hm[2 * ply + 1]), hm[2 * ply + 2]);
+        if (live && out) out[(((size_t)n * COUT + pch) * Hp + py) * Wp + px] = v;
+        if (P && !(BNN_STEM_ABL & 16)) {  // lanes 8*plx .. 8*plx+7 hold the 8 channels of one byte of pixel (ply, plx)
+          const unsigned long long mask = __ballot(live && is_pos(v));
+          if (pchl == 0 && pplx < PTW)
+            bits[((buf * PTH + ply) * PTW + pplx) * 8 + wave + NW * pj] = (uint8_t)(mask >> (8 * pplx));
+        }
       }
     }
 #endif
@@ -372,7 +385,7 @@ static int launch_stem_split_t(const float* x, const float* w, const float* bn_a
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
   }
   const int per_xcd = (int)((ntiles + 7) / 8);
-  const long long want = cus;  // one resident workgroup (8 waves) per CU
+  const long long want = (long long)cus * (8 / NW);  // 8 waves (two workgroups) per CU
   const unsigned grid = (unsigned)(ntiles < want ? ((ntiles + 7) / 8 * 8) : want);
   static bool attr_set[64] = {false};  // > 64 KB of dynamic LDS needs the opt-in, once per device
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
