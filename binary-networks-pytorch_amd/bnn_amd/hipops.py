@@ -415,20 +415,26 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
 
 
 def grad_supported(x_shape, w_shape, stride, padding, dilation) -> bool:
-    """Shapes the binary-aware gradient kernels cover: 3x3 / stride 1 or 2 / padding 1 / dilation 1, width <= 64."""
-    return (tuple(w_shape[2:]) == (3, 3) and _pair(stride) in ((1, 1), (2, 2)) and _pair(padding) == (1, 1)
-            and _pair(dilation) == (1, 1) and x_shape[3] <= 64 and x_shape[0] > 0)
+    """Shapes the binary-aware gradient kernels cover: 3x3 / stride 1 or 2 / padding 1 and 1x1 / stride 1 / padding 0,
+    dilation 1, width <= 64."""
+    k = tuple(w_shape[2:])
+    if _pair(dilation) != (1, 1) or x_shape[3] > 64 or x_shape[0] <= 0:
+        return False
+    if k == (3, 3):
+        return _pair(stride) in ((1, 1), (2, 2)) and _pair(padding) == (1, 1)
+    return k == (1, 1) and _pair(stride) == (1, 1) and _pair(padding) == (0, 0)
 
 
 def grad_pack_weight(w_hat: torch.Tensor):
-    """``What = sign(Wc) * alpha`` ([O,C,3,3] fp32) -> (sign fragments for the input-gradient kernel, alpha[O])."""
+    """``What = sign(Wc) * alpha`` ([O,C,k,k] fp32, k = 3 or 1) -> (sign fragments for the input-gradient kernel,
+    alpha[O])."""
     w_hat = _require_cuda_f32(w_hat.detach(), "w_hat")
     lib = native.require()
-    O, C = w_hat.shape[0], w_hat.shape[1]
+    O, C, k = w_hat.shape[0], w_hat.shape[1], w_hat.shape[2]
     with torch.cuda.device(w_hat.device):
-        packed = torch.empty(int(lib.bnn_hip_grad_weight_pack_bytes(O, C)), dtype=torch.uint8, device=w_hat.device)
+        packed = torch.empty(int(lib.bnn_hip_grad_weight_pack_bytes(O, C, k)), dtype=torch.uint8, device=w_hat.device)
         alpha = torch.empty(O, dtype=torch.float32, device=w_hat.device)
-        native.check(lib.bnn_hip_grad_pack_weight_f32(w_hat.data_ptr(), O, C, packed.data_ptr(), alpha.data_ptr(),
+        native.check(lib.bnn_hip_grad_pack_weight_f32(w_hat.data_ptr(), O, C, k, packed.data_ptr(), alpha.data_ptr(),
                                                       _stream(w_hat.device)), "bnn_hip_grad_pack_weight_f32")
     return packed, alpha
 
@@ -437,38 +443,38 @@ def _grad_shapes(g: torch.Tensor, x: torch.Tensor, stride: int):
     N, C, H, W = x.shape
     O = g.shape[1]
     if tuple(g.shape) != (N, O, (H - 1) // stride + 1, (W - 1) // stride + 1):
-        raise native.NativeError(f"bnn_amd: grad_output shape {tuple(g.shape)} does not belong to input "
-                                 f"{tuple(x.shape)} at stride {stride}")
+        raise native.NativeError(f"bnn_amd: grad_output {tuple(g.shape)} does not belong to input {tuple(x.shape)} "
+                                 f"at stride {stride}")
     return N, O, C, H, W
 
 
-def bconv3x3_grad_input(g: torch.Tensor, x: torch.Tensor, packed: torch.Tensor, alpha: torch.Tensor,
-                        stride: int = 1) -> torch.Tensor:
-    """dL/dx of the binary 3x3/p1 conv incl. the hard-tanh STE mask (bnn/ops.py:68-73)."""
+def bconv_grad_input(g: torch.Tensor, x: torch.Tensor, packed: torch.Tensor, alpha: torch.Tensor,
+                     ksize: int = 3, stride: int = 1) -> torch.Tensor:
+    """dL/dx of the binary 3x3/p1 or 1x1/p0 conv incl. the hard-tanh STE mask (bnn/ops.py:68-73)."""
     g = _require_cuda_f32(g, "grad_output")
     x = _require_cuda_f32(x, "input")
     lib = native.require()
     N, O, C, H, W = _grad_shapes(g, x, stride)
     with torch.cuda.device(g.device):
         gx = torch.empty_like(x)
-        native.check(lib.bnn_hip_bconv3x3_grad_input_f32(g.data_ptr(), alpha.data_ptr(), packed.data_ptr(),
-                                                         x.data_ptr(), gx.data_ptr(), N, O, C, H, W, stride,
-                                                         _stream(g.device)), "bnn_hip_bconv3x3_grad_input_f32")
+        native.check(lib.bnn_hip_bconv_grad_input_f32(g.data_ptr(), alpha.data_ptr(), packed.data_ptr(),
+                                                      x.data_ptr(), gx.data_ptr(), N, O, C, H, W, ksize, stride,
+                                                      _stream(g.device)), "bnn_hip_bconv_grad_input_f32")
     return gx
 
 
-def bconv3x3_grad_weight(g: torch.Tensor, x: torch.Tensor, stride: int = 1) -> torch.Tensor:
-    """dL/dWhat [O,C,3,3] of the binary 3x3/p1 conv: correlation of g with sign(x)."""
+def bconv_grad_weight(g: torch.Tensor, x: torch.Tensor, ksize: int = 3, stride: int = 1) -> torch.Tensor:
+    """dL/dWhat [O,C,k,k] of the binary 3x3/p1 or 1x1/p0 conv: correlation of g with sign(x)."""
     g = _require_cuda_f32(g, "grad_output")
     x = _require_cuda_f32(x, "input")
     lib = native.require()
     N, O, C, H, W = _grad_shapes(g, x, stride)
-    splits = int(lib.bnn_hip_bconv3x3_grad_weight_splits(N, O, C))
+    splits = int(lib.bnn_hip_bconv_grad_weight_splits(N, O, C, ksize))
     with torch.cuda.device(g.device):
-        part = torch.empty((splits, O, C, 3, 3), dtype=torch.float32, device=g.device)
-        native.check(lib.bnn_hip_bconv3x3_grad_weight_f32(g.data_ptr(), x.data_ptr(), part.data_ptr(), splits,
-                                                          N, O, C, H, W, stride, _stream(g.device)),
-                     "bnn_hip_bconv3x3_grad_weight_f32")
+        part = torch.empty((splits, O, C, ksize, ksize), dtype=torch.float32, device=g.device)
+        native.check(lib.bnn_hip_bconv_grad_weight_f32(g.data_ptr(), x.data_ptr(), part.data_ptr(), splits,
+                                                       N, O, C, H, W, ksize, stride, _stream(g.device)),
+                     "bnn_hip_bconv_grad_weight_f32")
         return part[0] if splits == 1 else part.sum(0)
 
 

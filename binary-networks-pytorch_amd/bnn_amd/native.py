@@ -23,7 +23,7 @@ FLAG_WEIGHTS_LDS = 8
 FLAG_ACT_NONNEG = 32
 STEM_EXACT_FP32 = 1
 STEM_FP16 = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol include/bnn_hip.h declares (tests assert the .so exports all of them)
 EXPORTED_SYMBOLS = (
@@ -33,8 +33,8 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_pack_weight_f32", "bnn_hip_bconv2d",
     "bnn_hip_bconv2d_fused", "bnn_hip_bconv2d_dot", "bnn_hip_blinear",
     "bnn_hip_conv_workspace_bytes", "bnn_hip_bconv2d_f32", "bnn_hip_probe_int_alu", "bnn_hip_avgpool_fc_f32", "bnn_hip_pack_act_f16", "bnn_hip_orpool_packed",
-    "bnn_hip_grad_weight_pack_bytes", "bnn_hip_grad_pack_weight_f32", "bnn_hip_bconv3x3_grad_input_f32",
-    "bnn_hip_bconv3x3_grad_weight_splits", "bnn_hip_bconv3x3_grad_weight_f32",
+    "bnn_hip_grad_weight_pack_bytes", "bnn_hip_grad_pack_weight_f32", "bnn_hip_bconv_grad_input_f32",
+    "bnn_hip_bconv_grad_weight_splits", "bnn_hip_bconv_grad_weight_f32",
 )
 
 
@@ -121,11 +121,11 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_bconv2d_f32.argtypes = [ctypes.POINTER(ConvDesc)] + [_vp] * 9
     lib.bnn_hip_avgpool_fc_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]
     lib.bnn_hip_grad_weight_pack_bytes.restype = ctypes.c_size_t
-    lib.bnn_hip_grad_weight_pack_bytes.argtypes = [_i, _i]
-    lib.bnn_hip_grad_pack_weight_f32.argtypes = [_vp, _i, _i, _vp, _vp, _vp]
-    lib.bnn_hip_bconv3x3_grad_input_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]
-    lib.bnn_hip_bconv3x3_grad_weight_splits.argtypes = [_i, _i, _i]
-    lib.bnn_hip_bconv3x3_grad_weight_f32.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]
+    lib.bnn_hip_grad_weight_pack_bytes.argtypes = [_i, _i, _i]
+    lib.bnn_hip_grad_pack_weight_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp]
+    lib.bnn_hip_bconv_grad_input_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]
+    lib.bnn_hip_bconv_grad_weight_splits.argtypes = [_i, _i, _i, _i]
+    lib.bnn_hip_bconv_grad_weight_f32.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
     lib.bnn_hip_probe_int_alu.argtypes = [_i, _i, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), _vp]
 

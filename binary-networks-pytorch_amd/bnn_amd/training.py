@@ -51,9 +51,9 @@ class BinaryConv2dTrainFn(torch.autograd.Function):
             gx = gw = gb = None
             if need_x:
                 packed, alpha = hipops.grad_pack_weight(w_hat)
-                gx = hipops.bconv3x3_grad_input(g, x, packed, alpha, stride[0])   # STE mask fused
+                gx = hipops.bconv_grad_input(g, x, packed, alpha, w_hat.shape[2], stride[0])   # STE mask fused
             if need_w:
-                gw = hipops.bconv3x3_grad_weight(g, x, stride[0])
+                gw = hipops.bconv_grad_weight(g, x, w_hat.shape[2], stride[0])
             if need_b:
                 gb = g.sum(dim=(0, 2, 3))
             return gx, gw, gb, None, None, None

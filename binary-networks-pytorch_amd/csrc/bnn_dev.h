@@ -94,13 +94,13 @@ int launch_stem_split(const float* x, const float* w, const float* bn_a, const f
                       int W, int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_avgpool_fc(const float* x, const float* wt, const float* bias, float* out, int N, int C, int HW,
                       int O, hipStream_t stream);
-size_t grad_weight_pack_bytes(int O, int C);
-int launch_grad_pack_weight(const float* what, int O, int C, void* packed, float* alpha, hipStream_t s);
-int launch_dgrad3x3(const float* g, const float* alpha, const void* packed, const float* xin, float* gx, int N,
-                    int O, int C, int H, int W, int stride, hipStream_t s);
-int grad_wgrad_splits(int N, int O, int C);
-int launch_wgrad3x3(const float* g, const float* xin, float* part, int splits, int N, int O, int C, int H, int W,
-                    int stride, hipStream_t s);
+size_t grad_weight_pack_bytes(int O, int C, int ks);
+int launch_grad_pack_weight(const float* what, int O, int C, int ks, void* packed, float* alpha, hipStream_t s);
+int launch_dgrad(const float* g, const float* alpha, const void* packed, const float* xin, float* gx, int N, int O,
+                 int C, int H, int W, int ks, int stride, hipStream_t s);
+int grad_wgrad_splits(int N, int O, int C, int ks);
+int launch_wgrad(const float* g, const float* xin, float* part, int splits, int N, int O, int C, int H, int W, int ks,
+                 int stride, hipStream_t s);
 int launch_pack_weight(const float* w, int O, int C, int KH, int KW, int center, int compute_alpha,
                        const bnn_hip_wlayout& L, uint32_t* wbits, uint32_t* wnz, float* alpha,
                        int32_t* zero_flag, hipStream_t stream);

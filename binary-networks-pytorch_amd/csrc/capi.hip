@@ -221,46 +221,51 @@ int bnn_hip_avgpool_fc_f32(const float* x, int N, int C, int HW, const float* w_
   return bnn::launch_avgpool_fc(x, w_t, bias, out, N, C, HW, O, static_cast<hipStream_t>(stream));
 }
 
-size_t bnn_hip_grad_weight_pack_bytes(int O, int C) {
-  return (O > 0 && C > 0) ? bnn::grad_weight_pack_bytes(O, C) : 0;
+static bool grad_ks_ok(int ksize) { return ksize == 1 || ksize == 3; }
+
+size_t bnn_hip_grad_weight_pack_bytes(int O, int C, int ksize) {
+  return (O > 0 && C > 0 && grad_ks_ok(ksize)) ? bnn::grad_weight_pack_bytes(O, C, ksize) : 0;
 }
 
-int bnn_hip_grad_pack_weight_f32(const float* w_hat, int O, int C, void* packed, float* alpha, void* stream) {
+int bnn_hip_grad_pack_weight_f32(const float* w_hat, int O, int C, int ksize, void* packed, float* alpha,
+                                 void* stream) {
   if (!w_hat || !packed || !alpha || O <= 0 || C <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (!grad_ks_ok(ksize)) return BNN_HIP_ERR_UNSUPPORTED;
   if (!aligned(packed, 16)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(2, std::memory_order_relaxed);
-  return bnn::launch_grad_pack_weight(w_hat, O, C, packed, alpha, static_cast<hipStream_t>(stream));
+  return bnn::launch_grad_pack_weight(w_hat, O, C, ksize, packed, alpha, static_cast<hipStream_t>(stream));
 }
 
-static int check_grad_shape(int N, int O, int C, int H, int W, int stride) {
+static int check_grad_shape(int N, int O, int C, int H, int W, int ksize, int stride) {
   if (N <= 0 || O <= 0 || C <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
-  if (stride != 1 && stride != 2) return BNN_HIP_ERR_UNSUPPORTED;
+  if (!grad_ks_ok(ksize) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1)) return BNN_HIP_ERR_UNSUPPORTED;
   if (W > 64) return BNN_HIP_ERR_UNSUPPORTED;
   if ((long long)N * O * H * W > kMaxElems || (long long)N * C * H * W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
   return BNN_HIP_OK;
 }
 
-int bnn_hip_bconv3x3_grad_input_f32(const float* g, const float* alpha, const void* packed, const float* x,
-                                    float* gx, int N, int O, int C, int H, int W, int stride, void* stream) {
+int bnn_hip_bconv_grad_input_f32(const float* g, const float* alpha, const void* packed, const float* x, float* gx,
+                                 int N, int O, int C, int H, int W, int ksize, int stride, void* stream) {
   if (!g || !alpha || !packed || !x || !gx) return BNN_HIP_ERR_INVALID_ARG;
-  const int st = check_grad_shape(N, O, C, H, W, stride);
+  const int st = check_grad_shape(N, O, C, H, W, ksize, stride);
   if (st != BNN_HIP_OK) return st;
   if (!aligned(packed, 16)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
-  return bnn::launch_dgrad3x3(g, alpha, packed, x, gx, N, O, C, H, W, stride, static_cast<hipStream_t>(stream));
+  return bnn::launch_dgrad(g, alpha, packed, x, gx, N, O, C, H, W, ksize, stride, static_cast<hipStream_t>(stream));
 }
 
-int bnn_hip_bconv3x3_grad_weight_splits(int N, int O, int C) {
-  return (N > 0 && O > 0 && C > 0) ? bnn::grad_wgrad_splits(N, O, C) : BNN_HIP_ERR_INVALID_ARG;
+int bnn_hip_bconv_grad_weight_splits(int N, int O, int C, int ksize) {
+  return (N > 0 && O > 0 && C > 0 && grad_ks_ok(ksize)) ? bnn::grad_wgrad_splits(N, O, C, ksize)
+                                                         : BNN_HIP_ERR_INVALID_ARG;
 }
 
-int bnn_hip_bconv3x3_grad_weight_f32(const float* g, const float* x, float* partial, int splits, int N, int O,
-                                     int C, int H, int W, int stride, void* stream) {
+int bnn_hip_bconv_grad_weight_f32(const float* g, const float* x, float* partial, int splits, int N, int O, int C,
+                                  int H, int W, int ksize, int stride, void* stream) {
   if (!g || !x || !partial) return BNN_HIP_ERR_INVALID_ARG;
-  const int st = check_grad_shape(N, O, C, H, W, stride);
+  const int st = check_grad_shape(N, O, C, H, W, ksize, stride);
   if (st != BNN_HIP_OK) return st;
   g_launches.fetch_add(1, std::memory_order_relaxed);
-  return bnn::launch_wgrad3x3(g, x, partial, splits, N, O, C, H, W, stride, static_cast<hipStream_t>(stream));
+  return bnn::launch_wgrad(g, x, partial, splits, N, O, C, H, W, ksize, stride, static_cast<hipStream_t>(stream));
 }
 
 int bnn_hip_pack_weight_f32(const float* w, int O, int C, int KH, int KW, int center,

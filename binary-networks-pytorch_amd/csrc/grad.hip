@@ -1,4 +1,4 @@
-// grad.hip — binary-aware gradient kernels of a fake-binarised 3x3 / stride 1 / pad 1 convolution
+// grad.hip — binary-aware gradient kernels of a fake-binarised 3x3 / pad 1 (stride 1 or 2) or 1x1 / pad 0 convolution
 // (reference: the autograd graph of bnn/layers/conv.py:90-97 with the straight-through
 // estimator of bnn/ops.py:68-73, as trained by examples/imagenet.py:337-384).
 //
@@ -28,8 +28,9 @@
 //
 // Stride 2 (the first conv of a down-sampling stage) uses the same kernels: wgrad reads sign(x) at stride 2 (its
 // shifted LDS copies are de-interleaved), dgrad treats g as zero-upsampled by 2 when the patch is filled (3/4 of
-// its MFMA work multiplies zeros — still several times faster than the fp32 library kernel).  1x1 convolutions
-// (the shortcut branches: 0.4 % of a ResNet-18's MACs) stay on the library path: bnn_amd/training.py.
+// its MFMA work multiplies zeros).  1x1 / stride 1 convolutions (the shortcut branches behind an AvgPool:
+// 0.4 % of a ResNet-18's MACs) are the same kernels with one tap and no halo; the weight-gradient kernel then
+// takes 128 input channels per workgroup instead of 32 so that a wave still has 8 accumulator tiles per g fragment.
 #include "bnn_dev.h"
 
 namespace bnn {
@@ -79,15 +80,15 @@ __global__ __launch_bounds__(64) void grad_alpha_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(64) void grad_pack_weight_kernel(const float* __restrict__ what, int O, int C,
-                                                              int CS, half8* __restrict__ Bp) {
+                                                              int CS, int T, half8* __restrict__ Bp) {
   const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
-  const int cs = blockIdx.x % CS, tap = (blockIdx.x / CS) % 9, ob = blockIdx.x / (CS * 9);
+  const int cs = blockIdx.x % CS, tap = (blockIdx.x / CS) % T, ob = blockIdx.x / (CS * T);
   const int c = 16 * cs + li;
   half8 b;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int o = 32 * ob + 8 * lg + e;
-    const float v = (o < O && c < C) ? what[((size_t)o * C + c) * 9 + tap] : 0.0f;
+    const float v = (o < O && c < C) ? what[((size_t)o * C + c) * T + tap] : 0.0f;
     b[e] = (_Float16)(v > 0.0f ? 1.0f : v < 0.0f ? -1.0f : 0.0f);
   }
   Bp[(size_t)blockIdx.x * 64 + lane] = b;
@@ -98,15 +99,16 @@ __global__ __launch_bounds__(64) void grad_pack_weight_kernel(const float* __res
 // 64 * NSUB per workgroup, grid.y blocks), K = (o, tap): loop over blocks of 32 output channels; per block the
 // chunk's rows +- 1 of g' = alpha[o] * g enter LDS as fp16 hi / lo, [pixel][32 o]; 9 taps = 9 k-steps of 32.
 // Epilogue: accumulators -> LDS [c][pixel] -> coalesced NCHW stores with the STE mask 1[|x| < 1].
-template <int NSUB>
-__global__ __launch_bounds__(grad::NT) void dgrad3x3_kernel(const float* __restrict__ g,
+template <int NSUB, int KS>
+__global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict__ g,
                                                             const float* __restrict__ alpha,
                                                             const half8* __restrict__ Bp,
                                                             const float* __restrict__ xin,
                                                             float* __restrict__ gx, const GradGeo q) {
   using namespace grad;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int PW = q.W + 2, PP = (q.R + 2) * PW;  // patch width / pixels (halo included)
+  constexpr int PD = KS / 2, T = KS * KS;
+  const int PW = q.W + 2 * PD, PP = (q.R + 2 * PD) * PW;  // patch width / pixels (halo included)
   _Float16* pa_hi = reinterpret_cast<_Float16*>(lds_raw);
   _Float16* pa_lo = pa_hi + (size_t)PP * APIX;
   float* stage = reinterpret_cast<float*>(lds_raw);  // reused after the K loop
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(grad::NT) void dgrad3x3_kernel(const float* __restr
     const int m = 16 * s + li;
     int ry = m / q.slot, x = m - ry * q.slot;
     if (x >= q.W || ry >= q.R) { ry = 0; x = 0; }  // dead slot: any valid address, result is never stored
-    abase[s] = ((ry + 2) * PW + (x + 2)) * APIX + 8 * lg;  // tap (ky,kx) reads patch pixel (ry+2-ky, x+2-kx)
+    abase[s] = ((ry + 2 * PD) * PW + (x + 2 * PD)) * APIX + 8 * lg;  // tap (ky,kx) reads patch pixel (ry+2PD-ky, x+2PD-kx)
   }
 
   f32x4 acc[4][NSUB];
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(grad::NT) void dgrad3x3_kernel(const float* __restr
     for (int item = tid; item < PP * 4; item += NT) {
       const int pix = item % PP, og = item / PP;
       const int pr = pix / PW, pc = pix - pr * PW;
-      const int y = y0 - 1 + pr, x = pc - 1;
+      const int y = y0 - PD + pr, x = pc - PD;
       // stride 2: g zero-upsampled — only even (y, x) carry a value, g[y/2][x/2]
       const int yg = q.st == 2 ? y >> 1 : y, xg = q.st == 2 ? x >> 1 : x;
       const bool in = y >= 0 && x >= 0 && yg < q.Hg && xg < q.Wg && (q.st == 1 || ((y | x) & 1) == 0);
@@ -160,14 +162,14 @@ __global__ __launch_bounds__(grad::NT) void dgrad3x3_kernel(const float* __restr
     }
     __syncthreads();
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap - ky * 3;
+    for (int tap = 0; tap < T; ++tap) {
+      const int ky = tap / KS, kx = tap - ky * KS;
       const int toff = (ky * PW + kx) * APIX;
       half8 b[NSUB];
 #pragma unroll
       for (int ns = 0; ns < NSUB; ++ns) {
         const int cs = cs0 + ns;
-        b[ns] = cs < CS ? Bp[((size_t)(ob * 9 + tap) * CS + cs) * 64 + lane] : half8{0, 0, 0, 0, 0, 0, 0, 0};
+        b[ns] = cs < CS ? Bp[((size_t)(ob * T + tap) * CS + cs) * 64 + lane] : half8{0, 0, 0, 0, 0, 0, 0, 0};
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -210,31 +212,32 @@ __global__ __launch_bounds__(grad::NT) void dgrad3x3_kernel(const float* __restr
 // chunks of its share of the images (split-K over grid.x; partial sums are added by the caller).
 // Per chunk: g (fp16 hi / lo, [o][64 slots]) and sign(x) with one halo row above and below, stored THREE times,
 // shifted by kx - 1 pixels, so that every tap's 8-pixel fragment is a 16-byte aligned LDS read.
-template <int ST>
-__global__ __launch_bounds__(grad::NT) void wgrad3x3_kernel(const float* __restrict__ g,
+template <int ST, int KS, int NC>
+__global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict__ g,
                                                             const float* __restrict__ xin,
                                                             float* __restrict__ part, const GradGeo q,
                                                             int imgs_per_split) {
   using namespace grad;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int BR = ST * q.RR + 2;              // sign(x) rows per chunk (all row slots + halo, zero where no image row)
+  constexpr int PD = KS / 2, T = KS * KS, NJ = NC * T;  // NC 16-channel sub-tiles of input channels per workgroup
+  const int BR = ST * q.RR + 2 * PD;         // sign(x) rows per chunk (all row slots + halo, zero where no image row)
   const int BROW = q.slot + 8;               // halves per row (16-byte aligned, bank spreading)
   _Float16* a_hi = reinterpret_cast<_Float16*>(lds_raw);
   _Float16* a_lo = a_hi + 64 * AROW;
-  _Float16* bsx = a_lo + 64 * AROW;          // [kx][c 0..31][row 0..BR-1][BROW]
-  const int bplane = 32 * BR * BROW;
+  _Float16* bsx = a_lo + 64 * AROW;          // [kx][c 0..16 NC-1][row 0..BR-1][BROW]
+  const int bplane = 16 * NC * BR * BROW;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int o0 = blockIdx.z * 64, c0 = blockIdx.y * 32;
+  const int o0 = blockIdx.z * 64, c0 = blockIdx.y * 16 * NC;
   const int n_begin = blockIdx.x * imgs_per_split;
   const int n_end = min(q.N, n_begin + imgs_per_split);
   const int HW = q.H * q.W, HWx = q.Hx * q.Wx;
   const int groups = 1 << q.gshift;          // 8-pixel groups per row slot
 
-  f32x4 acc[18];
+  f32x4 acc[NJ];
 #pragma unroll
-  for (int j = 0; j < 18; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment addresses of the two k-steps: k = 32 ks + 8 lg -> (row, column group) of the chunk
   int a_off[2], b_off[2];
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(grad::NT) void wgrad3x3_kernel(const float* __restr
     const int kk = 32 * ks + 8 * lg;
     const int ry = kk / q.slot, xg = kk - ry * q.slot;
     a_off[ks] = (16 * wave + li) * AROW + kk;
-    b_off[ks] = (li * BR + ST * ry) * BROW + xg;  // + (half * 16 * BR + ky) * BROW + kx * bplane per sub-tile
+    b_off[ks] = (li * BR + ST * ry) * BROW + xg;  // + (sub * 16 * BR + ky) * BROW + kx * bplane per sub-tile
   }
 
   for (int n = n_begin; n < n_end; ++n) {
@@ -268,22 +271,22 @@ __global__ __launch_bounds__(grad::NT) void wgrad3x3_kernel(const float* __restr
         *reinterpret_cast<half8*>(a_hi + ol * AROW + 8 * g8) = hi;
         *reinterpret_cast<half8*>(a_lo + ol * AROW + 8 * g8) = lo;
       }
-      // ---- sign(x) rows ST*y0-1 .. of 32 input channels, three copies: copy kx holds sx[ST*p + kx - 1] at slot p
-      for (int item = tid; item < 32 * BR * groups; item += NT) {
+      // ---- sign(x) rows ST*y0-PD .. of 16 NC input channels, KS copies: copy kx holds sx[ST*p + kx - PD] at slot p
+      for (int item = tid; item < 16 * NC * BR * groups; item += NT) {
         const int j = item & (groups - 1), t = item >> q.gshift;
         const int cl = t / BR, pr = t - cl * BR;
-        const int c = c0 + cl, y = ST * y0 - 1 + pr;
+        const int c = c0 + cl, y = ST * y0 - PD + pr;
         const bool rowok = c < q.C && (unsigned)y < (unsigned)q.Hx;
-        _Float16 s[8 * ST + 2];  // sx[ST*8j-1 .. ST*(8j+7)+1]
+        _Float16 s[8 * ST + 2 * PD];  // sx[ST*8j-PD .. ST*(8j+7)+PD]
 #pragma unroll
-        for (int e = 0; e < 8 * ST + 2; ++e) {
-          const int x = ST * 8 * j - 1 + e;
+        for (int e = 0; e < 8 * ST + 2 * PD; ++e) {
+          const int x = ST * 8 * j - PD + e;
           const bool ok = rowok && (unsigned)x < (unsigned)q.Wx;
           const float xv = xin[ok ? ((size_t)n * q.C + c) * HWx + y * q.Wx + x : 0];
           s[e] = (_Float16)((ok && xv > 0.0f) ? 1.0f : (ok && xv < 0.0f) ? -1.0f : 0.0f);
         }
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
+        for (int kx = 0; kx < KS; ++kx) {
           half8 hv;
 #pragma unroll
           for (int e = 0; e < 8; ++e) hv[e] = s[ST * e + kx];
@@ -296,10 +299,10 @@ __global__ __launch_bounds__(grad::NT) void wgrad3x3_kernel(const float* __restr
         const half8 ah = *reinterpret_cast<const half8*>(a_hi + a_off[ks]);
         const half8 al = *reinterpret_cast<const half8*>(a_lo + a_off[ks]);
 #pragma unroll
-        for (int j = 0; j < 18; ++j) {
-          const int half = j / 9, tap = j - half * 9, ky = tap / 3, kx = tap - ky * 3;
+        for (int j = 0; j < NJ; ++j) {
+          const int sub = j / T, tap = j - sub * T, ky = tap / KS, kx = tap - ky * KS;
           const half8 b = *reinterpret_cast<const half8*>(bsx + kx * bplane + b_off[ks] +
-                                                          (half * 16 * BR + ky) * BROW);
+                                                          (sub * 16 * BR + ky) * BROW);
           acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b, acc[j], 0, 0, 0);
           acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b, acc[j], 0, 0, 0);
         }
@@ -307,15 +310,15 @@ __global__ __launch_bounds__(grad::NT) void wgrad3x3_kernel(const float* __restr
     }
   }
   // D layout: column = li (input channel within the half), row = 4 lg + r (output channel within the wave's 16)
-  float* dst = part + (size_t)blockIdx.x * q.O * q.C * 9;
+  float* dst = part + (size_t)blockIdx.x * q.O * q.C * T;
 #pragma unroll
-  for (int j = 0; j < 18; ++j) {
-    const int half = j / 9, tap = j - half * 9;
-    const int c = c0 + 16 * half + li;
+  for (int j = 0; j < NJ; ++j) {
+    const int sub = j / T, tap = j - sub * T;
+    const int c = c0 + 16 * sub + li;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int o = o0 + 16 * wave + 4 * lg + r;
-      if (o < q.O && c < q.C) dst[((size_t)o * q.C + c) * 9 + tap] = acc[j][r];
+      if (o < q.O && c < q.C) dst[((size_t)o * q.C + c) * T + tap] = acc[j][r];
     }
   }
 }
@@ -341,40 +344,51 @@ static bool make_geo(int N, int O, int C, int Hx, int Wx, int st, bool dgrad, Gr
   return true;
 }
 
-size_t grad_weight_pack_bytes(int O, int C) {
-  return (size_t)((O + 31) / 32) * 9 * ((C + 15) / 16) * 64 * sizeof(half8);
+static bool ks_ok(int ks, int stride) { return ks == 3 || (ks == 1 && stride == 1); }
+static constexpr int kWgradNC1 = 8;  // 1x1 weight gradient: 128 input channels per workgroup
+
+size_t grad_weight_pack_bytes(int O, int C, int ks) {
+  return (size_t)((O + 31) / 32) * ks * ks * ((C + 15) / 16) * 64 * sizeof(half8);
 }
 
-int launch_grad_pack_weight(const float* what, int O, int C, void* packed, float* alpha, hipStream_t s) {
-  const int CS = (C + 15) / 16, OB = (O + 31) / 32;
-  hipLaunchKernelGGL(grad_alpha_kernel, dim3(O), dim3(64), 0, s, what, C * 9, alpha);
-  hipLaunchKernelGGL(grad_pack_weight_kernel, dim3(OB * 9 * CS), dim3(64), 0, s, what, O, C, CS,
+int launch_grad_pack_weight(const float* what, int O, int C, int ks, void* packed, float* alpha, hipStream_t s) {
+  if (!ks_ok(ks, 1)) return BNN_HIP_ERR_UNSUPPORTED;
+  const int CS = (C + 15) / 16, OB = (O + 31) / 32, T = ks * ks;
+  hipLaunchKernelGGL(grad_alpha_kernel, dim3(O), dim3(64), 0, s, what, C * T, alpha);
+  hipLaunchKernelGGL(grad_pack_weight_kernel, dim3(OB * T * CS), dim3(64), 0, s, what, O, C, CS, T,
                      static_cast<half8*>(packed));
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
-int launch_dgrad3x3(const float* g, const float* alpha, const void* packed, const float* xin, float* gx, int N,
-                    int O, int C, int H, int W, int stride, hipStream_t s) {
+template <int KS>
+static int launch_dgrad_t(const float* g, const float* alpha, const void* packed, const float* xin, float* gx,
+                          const GradGeo& q, hipStream_t s) {
   using namespace grad;
-  GradGeo q;
-  if (!make_geo(N, O, C, H, W, stride, true, &q)) return BNN_HIP_ERR_UNSUPPORTED;
-  const int PP = (q.R + 2) * (W + 2);
-  const int nsub = C > 64 ? 2 : 1;
+  const int PP = (q.R + 2 * (KS / 2)) * (q.W + 2 * (KS / 2));
+  const int nsub = q.C > 64 ? 2 : 1;
   const size_t patch = (size_t)2 * PP * APIX * sizeof(_Float16);
   const size_t stage = (size_t)64 * nsub * SROW * sizeof(float);
   const size_t lds = patch > stage ? patch : stage;
-  const dim3 grid((unsigned)(N * q.chunks), (unsigned)((C + 64 * nsub - 1) / (64 * nsub)));
+  const dim3 grid((unsigned)(q.N * q.chunks), (unsigned)((q.C + 64 * nsub - 1) / (64 * nsub)));
   if (nsub == 2)
-    hipLaunchKernelGGL(dgrad3x3_kernel<2>, grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed), xin,
+    hipLaunchKernelGGL((dgrad_kernel<2, KS>), grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed), xin,
                        gx, q);
   else
-    hipLaunchKernelGGL(dgrad3x3_kernel<1>, grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed), xin,
+    hipLaunchKernelGGL((dgrad_kernel<1, KS>), grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed), xin,
                        gx, q);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
-int grad_wgrad_splits(int N, int O, int C) {
-  const int blocks = ((O + 63) / 64) * ((C + 31) / 32);
+int launch_dgrad(const float* g, const float* alpha, const void* packed, const float* xin, float* gx, int N, int O,
+                 int C, int H, int W, int ks, int stride, hipStream_t s) {
+  GradGeo q;
+  if (!ks_ok(ks, stride) || !make_geo(N, O, C, H, W, stride, true, &q)) return BNN_HIP_ERR_UNSUPPORTED;
+  return ks == 3 ? launch_dgrad_t<3>(g, alpha, packed, xin, gx, q, s) : launch_dgrad_t<1>(g, alpha, packed, xin, gx, q, s);
+}
+
+int grad_wgrad_splits(int N, int O, int C, int ks) {
+  const int cb = ks == 3 ? 32 : 16 * kWgradNC1;
+  const int blocks = ((O + 63) / 64) * ((C + cb - 1) / cb);
   int s = (1024 + blocks - 1) / blocks;  // ~4 workgroups per CU in total
   if (s > N) s = N;
   if (s < 1) s = 1;
@@ -382,26 +396,30 @@ int grad_wgrad_splits(int N, int O, int C) {
   return (N + per - 1) / per;
 }
 
-int launch_wgrad3x3(const float* g, const float* xin, float* part, int splits, int N, int O, int C, int H, int W,
-                    int stride, hipStream_t s) {
+int launch_wgrad(const float* g, const float* xin, float* part, int splits, int N, int O, int C, int H, int W, int ks,
+                 int stride, hipStream_t s) {
   using namespace grad;
   GradGeo q;
-  if (!make_geo(N, O, C, H, W, stride, false, &q)) return BNN_HIP_ERR_UNSUPPORTED;
+  if (!ks_ok(ks, stride) || !make_geo(N, O, C, H, W, stride, false, &q)) return BNN_HIP_ERR_UNSUPPORTED;
   if (splits < 1 || splits > N) return BNN_HIP_ERR_INVALID_ARG;
   const int per = (N + splits - 1) / splits;
   if ((N + per - 1) / per != splits) return BNN_HIP_ERR_INVALID_ARG;
-  const size_t lds = (size_t)(2 * 64 * AROW + 3 * 32 * (stride * q.RR + 2) * (q.slot + 8)) * sizeof(_Float16);
-  const dim3 grid((unsigned)splits, (unsigned)((C + 31) / 32), (unsigned)((O + 63) / 64));
-  if (stride == 2) {
+  const int nc = ks == 3 ? 2 : kWgradNC1;
+  const size_t lds =
+      (size_t)(2 * 64 * AROW + ks * 16 * nc * (stride * q.RR + 2 * (ks / 2)) * (q.slot + 8)) * sizeof(_Float16);
+  const dim3 grid((unsigned)splits, (unsigned)((C + 16 * nc - 1) / (16 * nc)), (unsigned)((O + 63) / 64));
+  if (ks == 1) {
+    hipLaunchKernelGGL((wgrad_kernel<1, 1, kWgradNC1>), grid, dim3(NT), lds, s, g, xin, part, q, per);
+  } else if (stride == 2) {
     static bool attr_set = false;  // up to 73 KB of dynamic LDS (7x7 outputs): needs the opt-in once
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_kernel<2>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<2, 3, 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad3x3_kernel<2>, grid, dim3(NT), lds, s, g, xin, part, q, per);
+    hipLaunchKernelGGL((wgrad_kernel<2, 3, 2>), grid, dim3(NT), lds, s, g, xin, part, q, per);
   } else {
-    hipLaunchKernelGGL(wgrad3x3_kernel<1>, grid, dim3(NT), lds, s, g, xin, part, q, per);
+    hipLaunchKernelGGL((wgrad_kernel<1, 3, 2>), grid, dim3(NT), lds, s, g, xin, part, q, per);
   }
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }

@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 6
+#define BNN_HIP_ABI_VERSION 7
 #define BNN_HIP_OCB 32 /* output channels per weight block (padding granularity of O) */
 
 typedef enum bnn_hip_status {
@@ -256,28 +256,31 @@ int bnn_hip_pack_weight_f32(const float* w, int O, int C, int KH, int KW,
                             int32_t* zero_flag, void* stream);
 
 /* ---- training: gradients of  out = conv2d(sign(x), What), What = sign(Wc) * alpha, for the
- * 3x3 / stride 1 or 2 / padding 1 / dilation 1 layer (bnn/layers/conv.py:90-97 under autograd; input STE
- * bnn/ops.py:68-73).
+ * 3x3 / stride 1 or 2 / padding 1 layer and the 1x1 / stride 1 / padding 0 layer, dilation 1
+ * (bnn/layers/conv.py:90-97 under autograd; input STE bnn/ops.py:68-73).  `ksize` is 3 or 1, p = ksize / 2.
  * Each is a GEMM with one real operand (the incoming gradient g, split into fp16 hi + lo) and one operand that is
  * exactly {-1,0,+1}: two v_mfma_f32_16x16x32_f16 per product, fp32 accumulation (fp32-convolution rounding class).
  * x: the layer's fp32 input [N,C,H,W], W <= 64; g: float32 [N,O,Hg,Wg] with Hg = (H-1)/stride + 1 (same for W).
+ * Anything else (other kernel sizes, a strided 1x1, W > 64): BNN_HIP_ERR_UNSUPPORTED — the caller keeps its
+ * fp32 path for those.
  *
- *   bnn_hip_grad_pack_weight_f32   What [O,C,3,3] (= +-alpha[o] or 0) -> alpha[o] = max|What[o]| and sign(What) as
- *                                  fp16 MFMA fragments in `packed` (bnn_hip_grad_weight_pack_bytes(O, C) bytes,
+ *   bnn_hip_grad_pack_weight_f32   What [O,C,k,k] (= +-alpha[o] or 0) -> alpha[o] = max|What[o]| and sign(What) as
+ *                                  fp16 MFMA fragments in `packed` (bnn_hip_grad_weight_pack_bytes(O, C, k) bytes,
  *                                  16-byte aligned); once per optimiser step.
- *   bnn_hip_bconv3x3_grad_input_f32   gx[n,c,y,x] = 1[|x| < 1] * sum_{o,ky,kx} g[n,o,(y+1-ky)/s,(x+1-kx)/s] * What[o,c,ky,kx]
- *                                  (terms whose (y+1-ky, x+1-kx) is not a multiple of the stride s do not exist)
- *   bnn_hip_bconv3x3_grad_weight_f32  partial[s,o,c,ky,kx] = sum over the images of split s and all pixels of
- *                                  g[n,o,y,x] * sign(x)[n,c,s*y+ky-1,s*x+kx-1];  dL/dWhat = sum_s partial[s]
- *                                  (s < splits = bnn_hip_bconv3x3_grad_weight_splits(N, O, C); the caller adds
+ *   bnn_hip_bconv_grad_input_f32   gx[n,c,y,x] = 1[|x| < 1] * sum_{o,ky,kx} g[n,o,(y+p-ky)/s,(x+p-kx)/s] * What[o,c,ky,kx]
+ *                                  (terms whose (y+p-ky, x+p-kx) is not a multiple of the stride s do not exist)
+ *   bnn_hip_bconv_grad_weight_f32  partial[s,o,c,ky,kx] = sum over the images of split s and all pixels of
+ *                                  g[n,o,y,x] * sign(x)[n,c,s*y+ky-p,s*x+kx-p];  dL/dWhat = sum_s partial[s]
+ *                                  (s < splits = bnn_hip_bconv_grad_weight_splits(N, O, C, k); the caller adds
  *                                  the `splits` slabs — a deterministic reduction instead of float atomics).       */
-size_t bnn_hip_grad_weight_pack_bytes(int O, int C);
-int bnn_hip_grad_pack_weight_f32(const float* w_hat, int O, int C, void* packed, float* alpha, void* stream);
-int bnn_hip_bconv3x3_grad_input_f32(const float* g, const float* alpha, const void* packed, const float* x,
-                                    float* gx, int N, int O, int C, int H, int W, int stride, void* stream);
-int bnn_hip_bconv3x3_grad_weight_splits(int N, int O, int C);
-int bnn_hip_bconv3x3_grad_weight_f32(const float* g, const float* x, float* partial, int splits,
-                                     int N, int O, int C, int H, int W, int stride, void* stream);
+size_t bnn_hip_grad_weight_pack_bytes(int O, int C, int ksize);
+int bnn_hip_grad_pack_weight_f32(const float* w_hat, int O, int C, int ksize, void* packed, float* alpha,
+                                 void* stream);
+int bnn_hip_bconv_grad_input_f32(const float* g, const float* alpha, const void* packed, const float* x, float* gx,
+                                 int N, int O, int C, int H, int W, int ksize, int stride, void* stream);
+int bnn_hip_bconv_grad_weight_splits(int N, int O, int C, int ksize);
+int bnn_hip_bconv_grad_weight_f32(const float* g, const float* x, float* partial, int splits,
+                                  int N, int O, int C, int H, int W, int ksize, int stride, void* stream);
 
 /* Binary convolution on packed operands.  out: float32 [N,O,Ho,Wo] contiguous.
  *   out[n,o,y,x] = fmaf(alpha[o], dot, bias ? bias[o] : 0) * (post_scale ? post_scale[o] : 1)

@@ -440,7 +440,8 @@ def test_stem_fp16_option_is_half_precision_accurate():
 
 
 @pytest.mark.parametrize("exact", [False, True], ids=["f16x3", "fp32"])
-@pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 64, 64), (1, 3, 32, 32), (2, 3, 50, 38)])
+@pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 64, 64), (1, 3, 32, 32), (2, 3, 50, 38), (1, 3, 97, 131),
+                                   (5, 3, 33, 65), (1, 3, 7, 9)])
 def test_mfma_stem_matches_torch_fp32_sequence(shape, exact):
     """conv7x7/2 -> BN -> ReLU -> MaxPool(3,2,1) on the matrix cores vs the torch ops.
     Default arithmetic: fp16 hi/lo split (3 MFMAs, fp32 accumulate); exact: the fp32 MFMA."""

@@ -191,38 +191,52 @@ GRAD_SHAPES = [  # (N, O, C, H, W): every slot width (8/16/32/64), channel tails
 ]
 
 
-@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("ks,stride", [(3, 1), (3, 2), (1, 1)], ids=["3x3s1", "3x3s2", "1x1"])
 @pytest.mark.parametrize("shape", GRAD_SHAPES, ids=lambda s: "x".join(map(str, s)))
-def test_binary_gradient_kernels_match_library_backward(shape, stride):
+def test_binary_gradient_kernels_match_library_backward(shape, ks, stride):
     """csrc/grad.hip (MFMA: g split into fp16 hi+lo, ternary operand exact) against aten::convolution_backward on
-    the same operands: dL/dx (with the STE mask) and dL/dWhat, fp32-convolution rounding class."""
+    the same operands: dL/dx (with the STE mask) and dL/dWhat, fp32-convolution rounding class.  3x3 / pad 1 at
+    stride 1 and 2, and the 1x1 / pad 0 layer of the shortcut branches."""
     from bnn_amd import hipops
     N, O, C, H, W = shape
+    pad = ks // 2
     x = dev((gen.normal(gen.seed_of("gx", shape), (N, C, H, W)) * 0.9).astype(np.float32))
     x.view(-1)[::7] = 0.0                                            # exact zeros: sign(0) == 0
     g = dev(gen.normal(gen.seed_of("gg", shape), (N, O, (H - 1) // stride + 1, (W - 1) // stride + 1)))
-    w = dev(gen.conv_weight("kaiming", gen.seed_of("gw", shape), (O, C, 3, 3)))
+    w = dev(gen.conv_weight("kaiming", gen.seed_of("gw", shape), (O, C, ks, ks)))
     w.view(-1)[::11] = 0.0                                           # and zero weights
     w_hat = torch.sign(w) * w.abs().flatten(1).mean(1).view(-1, 1, 1, 1)
-    assert hipops.grad_supported(x.shape, w_hat.shape, stride, 1, 1)
+    assert hipops.grad_supported(x.shape, w_hat.shape, stride, pad, 1)
     packed, alpha = hipops.grad_pack_weight(w_hat)
     assert torch.equal(alpha, w_hat.abs().flatten(1).amax(1))
-    gx = hipops.bconv3x3_grad_input(g, x, packed, alpha, stride)
-    gw = hipops.bconv3x3_grad_weight(g, x, stride)
-    rx, rw, _ = torch.ops.aten.convolution_backward(g, torch.sign(x), w_hat, None, [stride, stride], [1, 1], [1, 1], False,
-                                                    [0, 0], 1, [True, True, False])
+    gx = hipops.bconv_grad_input(g, x, packed, alpha, ks, stride)
+    gw = hipops.bconv_grad_weight(g, x, ks, stride)
+    conf = ([stride, stride], [pad, pad], [1, 1], False, [0, 0], 1, [True, True, False])
+    rx, rw, _ = torch.ops.aten.convolution_backward(g, torch.sign(x), w_hat, None, *conf)
     rx = rx.masked_fill(x.abs() >= 1, 0)
     assert gx.shape == rx.shape and gw.shape == rw.shape
     assert ((gx == 0) | (x.abs() < 1)).all() and ((x.abs() >= 1) <= (gx == 0)).all()
     assert torch.allclose(gx, rx, rtol=1e-4, atol=2e-5 * float(rx.abs().max()))
     assert torch.allclose(gw, rw, rtol=1e-4, atol=2e-5 * float(rw.abs().max()))
     # fp64 reference: the error is that of an fp32 convolution, not of fp16 operands
-    rx64, rw64, _ = torch.ops.aten.convolution_backward(g.double(), torch.sign(x).double(), w_hat.double(), None,
-                                                        [stride, stride], [1, 1], [1, 1], False, [0, 0], 1,
-                                                        [True, True, False])
+    rx64, rw64, _ = torch.ops.aten.convolution_backward(g.double(), torch.sign(x).double(), w_hat.double(), None, *conf)
     rx64 = rx64.masked_fill(x.abs() >= 1, 0)
     assert float((gx.double() - rx64).abs().max()) <= 4e-6 * float(rx64.abs().max())
     assert float((gw.double() - rw64).abs().max()) <= 4e-6 * float(rw64.abs().max())
+
+
+def test_unsupported_gradient_shapes_fall_back_to_the_library():
+    from bnn_amd import hipops
+    assert not hipops.grad_supported((2, 8, 8, 8), (8, 8, 1, 1), 2, 0, 1)     # strided 1x1
+    assert not hipops.grad_supported((2, 8, 8, 8), (8, 8, 3, 3), 1, 0, 1)     # 3x3 without padding
+    assert not hipops.grad_supported((2, 8, 8, 8), (8, 8, 5, 5), 1, 2, 1)
+    assert not hipops.grad_supported((2, 8, 8, 65), (8, 8, 3, 3), 1, 1, 1)    # rows wider than a 64-slot chunk
+    layer = _layer(8, 8, 1, 2, 0, False, False, False, seed=5)
+    x = (gen.normal(3, (2, 8, 9, 9)) * 0.8).astype(np.float32)
+    g = gen.normal(4, (2, 8, 5, 5))
+    y, gx, gp = _grads(layer, x, g, enabled=True)
+    y0, gx0, gp0 = _grads(layer, x, g, enabled=False)
+    assert torch.allclose(y, y0, rtol=1e-5, atol=1e-5) and torch.allclose(gx, gx0, rtol=1e-4, atol=1e-5)
 
 
 def test_binary_gradient_kernels_are_used_and_can_be_switched_off():

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_require_loads_and_reports_abi():
     lib = native.require()
-    assert lib.bnn_hip_abi_version() == native.ABI_VERSION == 6
+    assert lib.bnn_hip_abi_version() == native.ABI_VERSION == 7
     assert lib.bnn_hip_status_string(0) == b"ok"
     assert b"invalid" in lib.bnn_hip_status_string(-1)
     assert isinstance(native.launch_count(), int)
@@ -66,14 +66,18 @@ def test_argument_validation_without_touching_the_gpu():
     assert lib.bnn_hip_avgpool_fc_f32(None, 1, 1, 1, None, None, 1, None, None) == -1
     assert lib.bnn_hip_avgpool_fc_f32(16, 0, 512, 49, 16, None, 1000, 16, None) == -1
     # gradient kernels: host-side geometry helpers and argument checks
-    assert lib.bnn_hip_grad_weight_pack_bytes(64, 64) == 2 * 9 * 4 * 64 * 16
-    assert lib.bnn_hip_grad_weight_pack_bytes(0, 64) == 0
-    assert 1 <= lib.bnn_hip_bconv3x3_grad_weight_splits(256, 64, 64) <= 256
-    assert lib.bnn_hip_bconv3x3_grad_weight_splits(1, 512, 512) == 1
-    assert lib.bnn_hip_grad_pack_weight_f32(None, 64, 64, None, None, None) == -1
-    assert lib.bnn_hip_bconv3x3_grad_input_f32(16, 16, 16, 16, 16, 2, 64, 64, 8, 65, 1, None) == -2  # width > 64
-    assert lib.bnn_hip_bconv3x3_grad_input_f32(16, 16, 16, 16, 16, 2, 64, 64, 8, 8, 3, None) == -2   # stride 3
-    assert lib.bnn_hip_bconv3x3_grad_weight_f32(None, 16, 16, 1, 2, 64, 64, 8, 8, 1, None) == -1
+    assert lib.bnn_hip_grad_weight_pack_bytes(64, 64, 3) == 2 * 9 * 4 * 64 * 16
+    assert lib.bnn_hip_grad_weight_pack_bytes(64, 64, 1) == 2 * 4 * 64 * 16
+    assert lib.bnn_hip_grad_weight_pack_bytes(0, 64, 3) == 0 and lib.bnn_hip_grad_weight_pack_bytes(64, 64, 5) == 0
+    assert 1 <= lib.bnn_hip_bconv_grad_weight_splits(256, 64, 64, 3) <= 256
+    assert lib.bnn_hip_bconv_grad_weight_splits(1, 512, 512, 3) == 1
+    assert 1 <= lib.bnn_hip_bconv_grad_weight_splits(256, 128, 64, 1) <= 256
+    assert lib.bnn_hip_grad_pack_weight_f32(None, 64, 64, 3, None, None, None) == -1
+    assert lib.bnn_hip_grad_pack_weight_f32(16, 64, 64, 5, 16, 16, None) == -2          # 5x5: unsupported
+    assert lib.bnn_hip_bconv_grad_input_f32(16, 16, 16, 16, 16, 2, 64, 64, 8, 65, 3, 1, None) == -2  # width > 64
+    assert lib.bnn_hip_bconv_grad_input_f32(16, 16, 16, 16, 16, 2, 64, 64, 8, 8, 3, 3, None) == -2   # stride 3
+    assert lib.bnn_hip_bconv_grad_input_f32(16, 16, 16, 16, 16, 2, 64, 64, 8, 8, 1, 2, None) == -2   # strided 1x1
+    assert lib.bnn_hip_bconv_grad_weight_f32(None, 16, 16, 1, 2, 64, 64, 8, 8, 3, 1, None) == -1
     assert lib.bnn_hip_conv_workspace_bytes(ctypes.byref(d)) >= 2 * 64 * 8
     d.N = 0
     assert lib.bnn_hip_bconv2d(ctypes.byref(d), 16, 16, 16, 16, 16, None, None, 16, None) == -1

@@ -40,8 +40,8 @@ for C, O, H, st in SHAPES:
     alpha = w.abs().mean(dim=(1, 2, 3), keepdim=True)
     what = torch.sign(w) * alpha
     packed, al = hipops.grad_pack_weight(what)
-    td = t(lambda: hipops.bconv3x3_grad_input(g, x, packed, al, st))
-    tw = t(lambda: hipops.bconv3x3_grad_weight(g, x, st))
+    td = t(lambda: hipops.bconv_grad_input(g, x, packed, al, 3, st))
+    tw = t(lambda: hipops.bconv_grad_weight(g, x, 3, st))
     flop = 2.0 * N * C * O * 9 * Ho * Ho * 2  # hi + lo product per MAC
     fd = flop * (st * st) / (td * 1e-6) / 2.5e15  # dgrad multiplies the zero-upsampled g: st^2 times the MFMA work
     fw = flop / (tw * 1e-6) / 2.5e15
