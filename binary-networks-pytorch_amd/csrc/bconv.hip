@@ -539,12 +539,15 @@ __device__ __forceinline__ void stream_weights_wz(const uint32_t* __restrict__ w
 //           quantise badly over the 1024 SIMDs and all reach their HBM epilogue at the same moment.
 //   NN: non-negative activations (M plane all zero, BNN_HIP_FLAG_ACT_NONNEG): P-only field.
 //   WZ: some weights are exactly zero (BNN_HIP_FLAG_WEIGHT_ZEROS): second scalar stream with the mask `Z`.
+//   OBW: consecutive 32-channel blocks one wave produces from ONE load of its field (single-chunk layers: the
+//        field load, its padding selects and the non-zero count are ~10 % of a block's instructions).
 template <int KH, int KW, int CWC, int EP, int MINW, int PASSES, bool MULTI, bool GSPLIT = false, bool NN = false,
-          bool WZ = false>
+          bool WZ = false, int OBW = 1>
 __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
     const uint32_t* __restrict__ P, const uint32_t* __restrict__ M, const uint32_t* __restrict__ W,
     const uint32_t* __restrict__ Z, BNN_EPI_PARAMS, const Geo g) {
   static_assert(!(WZ && (NN || GSPLIT)), "the zero-weight variant is two-plane, unsplit");
+  static_assert(OBW == 1 || (!MULTI && !GSPLIT), "several blocks per wave: single-chunk, unsplit kernels only");
   constexpr int T = KH * KW;
   constexpr int NW = T * CWC;  // words per (o, chunk)
   constexpr int NACC = kOCB / PASSES;
@@ -556,22 +559,26 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
   // instead of every XCD streaming the whole input once per block.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int obp = slot / g.tiles_per_xcd;  // (block, part) when GSPLIT
-  const int ob = GSPLIT ? obp / PASSES : obp;
-  const int part = GSPLIT ? obp - ob * PASSES : 0;
+  const int ob0 = GSPLIT ? obp / PASSES : obp * OBW;
+  const int part = GSPLIT ? obp - ob0 * PASSES : 0;
   const int tile = xcd * g.tiles_per_xcd + (slot - obp * g.tiles_per_xcd);
   if (tile >= g.tiles) return;
   const Pix px = decode_pixel(g, tile * kWave + threadIdx.x);
-  uint32_t pbits = 0u, mbits = 0u;
-
-  if (ob * kOCB < g.O) {
-    const uint32_t* wblk = W + (size_t)ob * g.nchunk * (kOCB * NW);
-    const uint32_t* zblk = WZ ? Z + (size_t)ob * g.nchunk * (kOCB * NW) : nullptr;
-    uint32_t pr[NW], mr[NW];
-    int nz = 0;
-    if constexpr (!MULTI) {
+  uint32_t pr[NW], mr[NW];
+  int nz = 0;
+  if constexpr (!MULTI) {
+    if (ob0 * kOCB < g.O) {
       load_field<KH, KW, CWC, NN>(g, px, 0, P, M, pr, mr);
       nz = count_nonzero<NW, NN>(pr, mr, 0);
     }
+  }
+#pragma unroll 1
+  for (int obi = 0; obi < OBW; ++obi) {
+  const int ob = ob0 + obi;
+  uint32_t pbits = 0u, mbits = 0u;
+  if (ob * kOCB < g.O) {
+    const uint32_t* wblk = W + (size_t)ob * g.nchunk * (kOCB * NW);
+    const uint32_t* zblk = WZ ? Z + (size_t)ob * g.nchunk * (kOCB * NW) : nullptr;
     // conv2-type single-chunk kernels (BN + residual + ReLU -> fp32 [+ packed]): ALL shortcut values of the block
     // are requested up front.  gfx950 counts loads and stores in one vmcnt, and once both kinds are pending the
     // compiler has to wait for vmcnt(0): a residual load issued after the previous pass's stores would make the
@@ -634,6 +641,7 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
   }
   if constexpr (GSPLIT) store_packed_part<PASSES>(g, px, ob, part, pbits, mbits, epi);
   else store_packed(g, px, ob, pbits, mbits, epi);
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -842,6 +850,10 @@ static unsigned oblocks(const ConvP& p) {
 #define BNN_GSPLIT_MAX_WAVES 16384
 #endif
 
+#ifndef BNN_SGPR_OBW  // 32-channel blocks per wave of the single-chunk 3x3 EP_PLAIN kernels (1 = one block per wave)
+#define BNN_SGPR_OBW 2
+#endif
+
 #ifndef BNN_NN_MULTI_MINW  // waves per SIMD the non-negative multi-chunk kernels are allocated for
 #define BNN_NN_MULTI_MINW 1
 #endif
@@ -853,6 +865,19 @@ static void launch_sgpr_t(const ConvP& p, const Geo& g, hipStream_t s) {
   constexpr bool k3 = KH * KW > 1;
   constexpr int P1 = k3 ? BNN_SGPR_PASSES : 1, PM = k3 ? BNN_SGPR_PASSES_MULTI : 1;
   if (k3 && p.nchunk == 1) {
+#if BNN_SGPR_OBW > 1
+    // several blocks per wave, one field load: the drop-in (alpha [, bias] -> fp32) layer only.  128->128 56x56 b256:
+    // 0.715 -> 0.73 of the int-ALU peak; with the fused residual-block epilogues the whole net LOSES 2 % with one
+    // batch in flight (fewer, longer waves) and is unchanged with two.
+    if constexpr (EP == EP_PLAIN) {
+      if (oblocks(p) >= BNN_SGPR_OBW) {
+        const dim3 grid2((unsigned)(8 * g.tiles_per_xcd) * ((oblocks(p) + BNN_SGPR_OBW - 1) / BNN_SGPR_OBW));
+        hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, P1, false, false, NN, false, BNN_SGPR_OBW>), grid2,
+                           dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
+        return;
+      }
+    }
+#endif
     hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, P1, false, false, NN>), grid,
                        dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
     return;
