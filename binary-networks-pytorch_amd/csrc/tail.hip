@@ -11,7 +11,8 @@
 //            issued before the first add when HW <= 64 (the 7x7 = 49 of every ResNet: one memory round trip per
 //            item instead of seven), fp32, index order, one division by HW (the order of ATen's CPU
 //            adaptive_avg_pool2d) -> m[c][i] in LDS;
-//   phase 2: thread o walks k = 0..C-1, 16 iterations in flight: one coalesced load of Wt[k][o] (the weight is
+//   phase 2: thread o walks k = 0..C-1, 32 iterations in flight (16: 29 us at batch 256, 32: 23 us; computing the means
+//            once in a separate wide launch and starting from them: 23.5 us — not adopted): one coalesced load of Wt[k][o] (the weight is
 //            passed transposed, [C][O], so that the 64 lanes of a wave read 256 contiguous bytes), one broadcast
 //            ds_read_b128 of m[k][0..3], four fmaf.  The weight (2 MB at ResNet-18 size) comes from L2.
 #include "bnn_dev.h"
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(tail::NT) void avgpool_fc_kernel(const float* __res
 #pragma unroll
   for (int i = 0; i < IMG; ++i) acc[i] = 0.0f;
   const float* wp = wt + o;
-#pragma unroll 16
+#pragma unroll 32
   for (int k = 0; k < C; ++k) {
     const float w = wp[(size_t)k * O];
     const float4 a = *reinterpret_cast<const float4*>(&m[k * IMG]);
