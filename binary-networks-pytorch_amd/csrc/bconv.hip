@@ -154,6 +154,19 @@ __device__ __forceinline__ float buf_ld(BufRsrc, unsigned, unsigned) { return 0.
 __device__ __forceinline__ void buf_st(BufRsrc, unsigned, unsigned, float) {}
 #endif
 
+// word = 2 * word + bit: ONE v_addc_co_u32 whose carry-in is the lane mask of `bit` (hipcc builds the same value from
+// v_cndmask + v_or3 + a shift: two instructions per bit).
+__device__ __forceinline__ uint32_t shift_in(uint32_t word, bool bit) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long mask = __builtin_amdgcn_ballot_w64(bit);
+  unsigned long long carry_out;
+  asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(word), "=s"(carry_out) : "s"(mask));
+  return word;
+#else
+  return word + word + (bit ? 1u : 0u);
+#endif
+}
+
 // Output pixel of this lane.
 struct Pix {
   int q, n, r, oy, ox;
@@ -290,6 +303,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
     return;
   }
   const int bit0 = o0 & 31;  // position of channel o0 inside its 32-channel output word
+  [[maybe_unused]] float pvs[NACC];  // FULL: the values to binarise; their bits are shifted in after the arithmetic
 #pragma unroll
   for (int j = 0; j < NACC; ++j) {
     const int o = o0 + j;
@@ -316,11 +330,30 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
 #endif
       if (f & EF_PACK) {
         if (f & EF_PACK_AFF) pv = fmaf(pv, e.pack_a[o], e.pack_b[o]);
-        pbits |= (is_pos(pv) ? 1u : 0u) << (bit0 + j);
         // straight out of a ReLU nothing is negative: the M plane of this block stays 0
         const bool no_neg = (f & EF_PACK_RELU) ||
                             ((f & EF_RELU) && !(f & EF_PACK_AFF) && (!(f & EF_RES_LATE) || (f & EF_PACK_PRE)));
-        if (!no_neg) mbits |= (is_neg(pv) ? 1u : 0u) << (bit0 + j);
+        if constexpr (FULL) {
+          pvs[j] = pv;
+        } else {
+          pbits |= (is_pos(pv) ? 1u : 0u) << (bit0 + j);
+          if (!no_neg) mbits |= (is_neg(pv) ? 1u : 0u) << (bit0 + j);
+        }
+      }
+    }
+  }
+  if constexpr (FULL) {
+    if (f & EF_PACK) {
+      // shift-in: word = 2*word + bit is ONE v_addc_co_u32 with the compare result as carry-in (instead of
+      // v_cndmask + v_or3 + shift); the channels arrive in ascending order, so the finished word is bit-reversed
+      // (store_packed* undo that with one v_bfrev_b32 per block).  Kept apart from the arithmetic above so that hipcc
+      // still pairs the BatchNorm fmas of two channels into v_pk_fma_f32.
+      const bool no_neg = (f & EF_PACK_RELU) ||
+                          ((f & EF_RELU) && !(f & EF_PACK_AFF) && (!(f & EF_RES_LATE) || (f & EF_PACK_PRE)));
+#pragma unroll
+      for (int j = 0; j < NACC; ++j) {
+        pbits = shift_in(pbits, is_pos(pvs[j]));
+        if (!no_neg) mbits = shift_in(mbits, is_neg(pvs[j]));
       }
     }
   }
@@ -349,10 +382,15 @@ __device__ __forceinline__ void prefetch_residual(const Geo& g, const Pix& px, i
 }
 
 // sign(y) of one 32-channel block: one half of a uint64 word of the [n][group][y][x] output planes.
+// `rev`: the words were built by shift-in (straight-line epilogue, all 32 channels of the block): bit-reversed.
 __device__ __forceinline__ void store_packed(const Geo& g, const Pix& px, int ob, uint32_t pbits,
-                                             uint32_t mbits, const EpiArgs& e) {
+                                             uint32_t mbits, const EpiArgs& e, bool rev = false) {
   // lanes past the last pixel hold a copy of it (decode_pixel): they store the same word to the same place
   if (!(g.flags & EF_PACK) || (g.flags & EF_RAW)) return;
+  if (rev) {
+    pbits = __builtin_bitreverse32(pbits);
+    mbits = __builtin_bitreverse32(mbits);
+  }
   const int hw = g.Ho * g.Wo;
   const unsigned w = (unsigned)((((px.n * (g.cw32_out >> 1) + (ob >> 1)) * hw + px.r) << 1) + (ob & 1)) * 4u;  // bytes
   st_off(e.outP, w, pbits);
@@ -361,11 +399,16 @@ __device__ __forceinline__ void store_packed(const Geo& g, const Pix& px, int ob
 
 // Same, for a wave that produced only part `part` of PARTS of the block's 32 channels (their bits
 // already sit at their final position inside the 32-bit word).
+// `rev`: the part's 32 / PARTS bits were built by shift-in from bit 0 (bit-reversed, not yet at their position).
 template <int PARTS>
 __device__ __forceinline__ void store_packed_part(const Geo& g, const Pix& px, int ob, int part,
-                                                  uint32_t pbits, uint32_t mbits, const EpiArgs& e) {
+                                                  uint32_t pbits, uint32_t mbits, const EpiArgs& e, bool rev = false) {
   static_assert(PARTS == 2 || PARTS == 4, "16- or 8-bit pieces");
   if (!(g.flags & EF_PACK) || (g.flags & EF_RAW)) return;
+  if (rev) {  // bits 0 .. 32/PARTS-1 reversed -> the top of bitreverse32; move them to the part's position
+    pbits = (__builtin_bitreverse32(pbits) >> (32 - 32 / PARTS)) << ((32 / PARTS) * part);
+    mbits = (__builtin_bitreverse32(mbits) >> (32 - 32 / PARTS)) << ((32 / PARTS) * part);
+  }
   const int hw = g.Ho * g.Wo;
   const size_t w = ((((size_t)px.n * (g.cw32_out >> 1) + (ob >> 1)) * hw + px.r) << 1) + (ob & 1);
   constexpr int BITS = 32 / PARTS;
@@ -599,7 +642,9 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       // multi-chunk: the field + 32 accumulators already fill the 128-VGPR budget of 4 waves/SIMD;
       // holding NACC more values across the loop spills (39 VGPRs measured), so they are fetched late.
       constexpr bool RES_EARLY = !RES_ALL && (!MULTI || BNN_MULTI_RES_EARLY);
-      const bool fullb = ob * kOCB + (ps + 1) * NACC <= g.O;  // wave-uniform
+      // wave-uniform; the same for every pass of a block: a block either builds its sign words by shift-in (straight-
+      // line epilogue) or by OR-ing bits into place (guarded epilogue), never both
+      const bool fullb = (ob + 1) * kOCB <= g.O;
       if constexpr (RES_ALL) {  // this pass's values are the head of the queue; the rest moves up (rolled loop)
 #pragma unroll
         for (int j = 0; j < NACC; ++j) resv[j] = resq[j];
@@ -639,8 +684,9 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       else epilogue<NACC, EP>(g, px, ob * kOCB + ps * NACC, acc, resv, epi, pbits, mbits);
     }
   }
-  if constexpr (GSPLIT) store_packed_part<PASSES>(g, px, ob, part, pbits, mbits, epi);
-  else store_packed(g, px, ob, pbits, mbits, epi);
+  const bool rev = (ob + 1) * kOCB <= g.O;  // == fullb of every pass of this block
+  if constexpr (GSPLIT) store_packed_part<PASSES>(g, px, ob, part, pbits, mbits, epi, rev);
+  else store_packed(g, px, ob, pbits, mbits, epi, rev);
   }
 }
 
