@@ -252,14 +252,24 @@ enum : int {
   EP_OUT = 3,      // BN + residual + ReLU -> fp32 + packed (conv2 of a BasicBlock)
   EP_DS = 4,       // BN -> fp32                            (1x1 conv of a shortcut branch)
   EP_LAST = 5,     // BN + residual + ReLU -> fp32 only     (conv2 of the LAST BasicBlock: the head reads fp32)
+  EP_HB = 6,       // HBlock stages 1, 2 (hierarchical_block.py:38-60): raw conv + late residual -> fp32 slice of the
+                   // concatenation; planes of sign(relu(bn_next(conv))) for the next stage
+  EP_HB3 = 7,      // HBlock stage 3: raw conv + late residual -> fp32 slice
 };
 constexpr int kFlagsMid = EF_BN | EF_RELU | EF_PACK;
 constexpr int kFlagsOut = EF_BN | EF_RES | EF_RELU | EF_OUTF | EF_PACK;
 constexpr int kFlagsDs = EF_BN | EF_OUTF;
 constexpr int kFlagsLast = EF_BN | EF_RES | EF_RELU | EF_OUTF;
+constexpr int kFlagsHb = EF_RES | EF_RES_LATE | EF_PACK_PRE | EF_OUTF | EF_PACK | EF_PACK_AFF | EF_PACK_RELU;
+constexpr int kFlagsHb3 = EF_RES | EF_RES_LATE | EF_PACK_PRE | EF_OUTF;
 __device__ __forceinline__ constexpr int ep_flags(int ep, int runtime) {
-  return ep == EP_MID ? kFlagsMid : ep == EP_OUT ? kFlagsOut : ep == EP_DS ? kFlagsDs : ep == EP_LAST ? kFlagsLast
-                                                                                                        : runtime;
+  return ep == EP_MID ? kFlagsMid
+         : ep == EP_OUT ? kFlagsOut
+         : ep == EP_DS ? kFlagsDs
+         : ep == EP_LAST ? kFlagsLast
+         : ep == EP_HB ? kFlagsHb
+         : ep == EP_HB3 ? kFlagsHb3
+                        : runtime;
 }
 
 // FULL: all NACC channels exist (o0 + NACC <= O; wave-uniform, chosen by the caller) AND no per-lane guard: lanes past
@@ -986,6 +996,8 @@ static void launch_sgpr(const ConvP& p, int flags, hipStream_t s) {
     if (g.flags == kFlagsMid) return launch_sgpr_e<KH, KW, CWC, EP_MID>(p, g, nn, s);
     if (g.flags == kFlagsOut) return launch_sgpr_e<KH, KW, CWC, EP_OUT>(p, g, nn, s);
     if (g.flags == kFlagsLast) return launch_sgpr_e<KH, KW, CWC, EP_LAST>(p, g, nn, s);
+    if (g.flags == kFlagsHb) return launch_sgpr_e<KH, KW, CWC, EP_HB>(p, g, nn, s);
+    if (g.flags == kFlagsHb3) return launch_sgpr_e<KH, KW, CWC, EP_HB3>(p, g, nn, s);
   } else {
     if (g.flags == kFlagsDs) return launch_sgpr_e<KH, KW, CWC, EP_DS>(p, g, nn, s);
   }
