@@ -332,10 +332,11 @@ def bench_net(args, world, rank, device, info, timed):
     x = x + 0.01 * torch.arange(B, device=device, dtype=torch.float32).view(B, 1, 1, 1)  # distinct images
     n_streams = max(1, args.streams) if args.engine == "graph" else 1
 
-    def make_step(**kw):
+    def make_step(n_streams=n_streams, **kw):
         if args.engine == "graph":
             # every stream owns a graph-captured executor whose static input buffer holds its batch (filled by
             # capture): no per-step device-to-device copy of the 154 MB input, and `n_streams` batches in flight
+            # (with more than one the executors run in throughput mode: BNN_HIP_FLAG_THROUGHPUT)
             pipe = PipelinedInference(net, x, n_streams=n_streams, **kw)
             models = [ShardedInference(e) for e in pipe.engines]
 
@@ -353,8 +354,9 @@ def bench_net(args, world, rank, device, info, timed):
         assert logits.shape == (world * B, 1000) and bool(torch.isfinite(logits).all())
         extras = {}
         if not args.no_extras and args.engine == "graph":
-            if n_streams > 1:   # same steps, strictly one batch at a time
-                dt1, _ = timed(lambda i: step(i, 1), args.steps, 2)
+            if n_streams > 1:   # same steps, strictly one batch at a time (an executor built for that: latency mode)
+                step1 = make_step(n_streams=1, **fused_kw)
+                dt1, _ = timed(step1, args.steps, args.warmup)
                 extras["one_batch_at_a_time"] = {"value": world * B * args.steps / dt1,
                                                  "ms_per_step": dt1 / args.steps * 1e3}
             if not c5:          # the same network with the stem in exact fp32 arithmetic (v_mfma_f32_16x16x4_f32)

@@ -299,9 +299,10 @@ def _desc(act_shape, w_shape, stride, padding, dilation, flags) -> native.ConvDe
     return native.ConvDesc(N, C, H, W, O, KH, KW, sh, sw, ph, pw, dh, dw, flags)
 
 
-def _flags(w: PackedWeight, force_generic: bool, weights: Optional[str], a: Optional[PackedAct] = None) -> int:
+def _flags(w: PackedWeight, force_generic: bool, weights: Optional[str], a: Optional[PackedAct] = None,
+           throughput: bool = False) -> int:
     f = (native.FLAG_FORCE_GENERIC if force_generic else 0) | \
-        (native.FLAG_WEIGHT_ZEROS if w.has_zero else 0)
+        (native.FLAG_WEIGHT_ZEROS if w.has_zero else 0) | (native.FLAG_THROUGHPUT if throughput else 0)
     if a is not None and a.nonneg:
         f |= native.FLAG_ACT_NONNEG
     if weights == "sgpr":
@@ -352,16 +353,17 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
                   out_packed=False, stride=1, padding=0, dilation=1, force_generic=False,
                   weights: Optional[str] = None, residual_after_act: bool = False,
                   pack_before_residual: bool = False, pack_scale=None, pack_shift=None,
-                  pack_relu: bool = False, out: Optional[torch.Tensor] = None, out_c_offset: int = 0):
+                  pack_relu: bool = False, out: Optional[torch.Tensor] = None, out_c_offset: int = 0,
+                  throughput: bool = False):
     """Binary convolution + fused epilogue (see ``bnn_hip_epilogue``): returns
     ``(y_fp32 | None, PackedAct(sign(p)) | None)``.
 
     ``out``: write the fp32 result into channels ``[out_c_offset, out_c_offset + O)`` of this
     preallocated ``[N, C_total, Ho, Wo]`` tensor (``torch.cat`` in place); ``residual`` then has
     ``C_total`` channels too.  The remaining keyword arguments are the pre-activation switches of
-    ``BNN_HIP_EPI_*`` (include/bnn_hip.h)."""
+    ``BNN_HIP_EPI_*`` (include/bnn_hip.h); ``throughput``: ``BNN_HIP_FLAG_THROUGHPUT`` (several batches in flight)."""
     lib = native.require()
-    d = _desc(a.shape, w.shape, stride, padding, dilation, _flags(w, force_generic, weights, a))
+    d = _desc(a.shape, w.shape, stride, padding, dilation, _flags(w, force_generic, weights, a, throughput))
     ho, wo = conv_out_hw(d.H, d.W, d.KH, d.KW, stride, padding, dilation)
     dev = a.P.device
     bias = _per_channel(bias, d.O, "bias")

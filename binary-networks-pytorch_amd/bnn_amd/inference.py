@@ -83,6 +83,7 @@ class _Conv:
     relu: bool
     prelu: Optional[torch.Tensor]
     name: str = ""
+    throughput: bool = False   # BNN_HIP_FLAG_THROUGHPUT: several batches in flight (PipelinedInference)
 
     def run(self, act: hipops.PackedAct, *, residual=None, out_f32: bool, out_packed: bool, **epi):
         """``epi``: the pre-activation switches of ``hipops.bconv2d_fused`` (late residual, pack affine, ...)."""
@@ -93,7 +94,7 @@ class _Conv:
             act, self.weight, bias=lay.bias, post_scale=self.plan.scale, bn_scale=self.bn_scale,
             bn_shift=self.bn_shift, residual=residual, prelu=self.prelu, relu=self.relu,
             out_f32=out_f32, out_packed=out_packed, stride=lay.stride, padding=lay.padding,
-            dilation=lay.dilation, **epi)
+            dilation=lay.dilation, throughput=self.throughput, **epi)
 
 
 def _plan_of(conv: nn.Module) -> fastpath.Plan:
@@ -129,8 +130,10 @@ class FusedResNet(nn.Module):
     pre-activation dataflow of examples/imagenet.py) or ``HBlock`` (hierarchical blocks)."""
 
     def __init__(self, model: ResNet, use_mfma_stem: bool = True, overlap_shortcut: bool = True,
-                 stem_fp16: bool = False, stem_exact_fp32: bool = False) -> None:
+                 stem_fp16: bool = False, stem_exact_fp32: bool = False, throughput_mode: bool = False) -> None:
         super().__init__()
+        # several batches in flight on other streams: kernels prefer fewer, longer waves (BNN_HIP_FLAG_THROUGHPUT)
+        self.throughput_mode = throughput_mode
         self.stem_fp16 = stem_fp16           # opt-in: plain fp16 stem operands (~5e-4 relative error)
         self.use_mfma_stem = use_mfma_stem
         self.stem_exact_fp32 = stem_exact_fp32   # v_mfma_f32_16x16x4_f32: bit-for-bit an fp32 fmaf chain (slower)
@@ -150,7 +153,7 @@ class FusedResNet(nn.Module):
             prelu = prelu.expand(conv.out_channels).contiguous()
         scale, shift = (None, None) if bn is None else fold_bn(bn)
         return _Conv(conv, plan, fastpath.packed_weight(conv, plan), scale, shift, relu, prelu,
-                     self._names.get(id(conv), ""))
+                     self._names.get(id(conv), ""), self.throughput_mode)
 
     @staticmethod
     def _sign_through(act: nn.Module):
@@ -420,6 +423,7 @@ class PipelinedInference:
         if n_streams < 1:
             raise ValueError("n_streams must be >= 1")
         dev = example.device
+        fused_kwargs.setdefault("throughput_mode", n_streams > 1)
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
         self.engines: List[FusedResNet] = []
         cur = torch.cuda.current_stream(dev)

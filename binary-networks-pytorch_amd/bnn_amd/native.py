@@ -21,6 +21,7 @@ FLAG_WEIGHT_ZEROS = 2
 FLAG_WEIGHTS_SGPR = 4
 FLAG_WEIGHTS_LDS = 8
 FLAG_ACT_NONNEG = 32
+FLAG_THROUGHPUT = 64
 STEM_EXACT_FP32 = 1
 STEM_FP16 = 4
 ABI_VERSION = 7

@@ -915,8 +915,10 @@ static unsigned oblocks(const ConvP& p) {
 #endif
 
 // NN: the caller vouches for an all-zero M plane (BNN_HIP_FLAG_ACT_NONNEG); 3x3 kernels only.
+// split_ok: the multi-chunk kernels may split a 32-channel block over two waves (lower latency of ONE batch; with
+// several batches in flight — BNN_HIP_FLAG_THROUGHPUT — the unsplit kernel's single field load per block wins).
 template <int KH, int KW, int CWC, int EP, bool NN>
-static void launch_sgpr_t(const ConvP& p, const Geo& g, hipStream_t s) {
+static void launch_sgpr_t(const ConvP& p, const Geo& g, bool split_ok, hipStream_t s) {
   const dim3 grid((unsigned)(8 * g.tiles_per_xcd) * oblocks(p));  // see the XCD note in the kernel
   constexpr bool k3 = KH * KW > 1;
   constexpr int P1 = k3 ? BNN_SGPR_PASSES : 1, PM = k3 ? BNN_SGPR_PASSES_MULTI : 1;
@@ -945,7 +947,7 @@ static void launch_sgpr_t(const ConvP& p, const Geo& g, hipStream_t s) {
     constexpr int MW = NN ? BNN_NN_MULTI_MINW : 4;
 #if BNN_MULTI_GSPLIT > 1
     // few pixel tiles per SIMD (ResNet layer3/4 at batch 256: 6 and 3 waves per SIMD): split the block
-    if ((long long)grid.x <= BNN_GSPLIT_MAX_WAVES) {
+    if (split_ok && (long long)grid.x <= BNN_GSPLIT_MAX_WAVES) {
       const dim3 grid2(grid.x * BNN_MULTI_GSPLIT);
       hipLaunchKernelGGL(
           (bconv_sgpr_kernel<KH, KW, CWC, EP, MW, BNN_MULTI_GSPLIT, true, true, NN>), grid2,
@@ -962,11 +964,11 @@ static void launch_sgpr_t(const ConvP& p, const Geo& g, hipStream_t s) {
 }
 
 template <int KH, int KW, int CWC, int EP>
-static void launch_sgpr_e(const ConvP& p, const Geo& g, bool nn, hipStream_t s) {
+static void launch_sgpr_e(const ConvP& p, const Geo& g, bool nn, bool split_ok, hipStream_t s) {
   if constexpr (KH * KW > 1) {
-    if (nn) return launch_sgpr_t<KH, KW, CWC, EP, true>(p, g, s);
+    if (nn) return launch_sgpr_t<KH, KW, CWC, EP, true>(p, g, split_ok, s);
   }
-  launch_sgpr_t<KH, KW, CWC, EP, false>(p, g, s);
+  launch_sgpr_t<KH, KW, CWC, EP, false>(p, g, split_ok, s);
 }
 
 // Zero-weight variant (BNN_HIP_FLAG_WEIGHT_ZEROS): two-plane field, 4 passes of 8 channels, run-time epilogue.
@@ -986,6 +988,7 @@ template <int KH, int KW, int CWC, bool PROFILES>
 static void launch_sgpr(const ConvP& p, int flags, hipStream_t s) {
   const Geo g = make_geo(p);
   const bool nn = (flags & BNN_HIP_FLAG_ACT_NONNEG) != 0;
+  const bool so = (flags & BNN_HIP_FLAG_THROUGHPUT) == 0;
   const bool fused = (g.flags & (EF_BN | EF_RES | EF_RELU | EF_PRELU | EF_PACK)) != 0;
   if (flags & BNN_HIP_FLAG_WEIGHT_ZEROS) {
     if (fused) launch_sgpr_wz<KH, KW, CWC, EP_RUNTIME>(p, g, s);
@@ -993,16 +996,16 @@ static void launch_sgpr(const ConvP& p, int flags, hipStream_t s) {
     return;
   }
   if constexpr (PROFILES) {
-    if (g.flags == kFlagsMid) return launch_sgpr_e<KH, KW, CWC, EP_MID>(p, g, nn, s);
-    if (g.flags == kFlagsOut) return launch_sgpr_e<KH, KW, CWC, EP_OUT>(p, g, nn, s);
-    if (g.flags == kFlagsLast) return launch_sgpr_e<KH, KW, CWC, EP_LAST>(p, g, nn, s);
-    if (g.flags == kFlagsHb) return launch_sgpr_e<KH, KW, CWC, EP_HB>(p, g, nn, s);
-    if (g.flags == kFlagsHb3) return launch_sgpr_e<KH, KW, CWC, EP_HB3>(p, g, nn, s);
+    if (g.flags == kFlagsMid) return launch_sgpr_e<KH, KW, CWC, EP_MID>(p, g, nn, so, s);
+    if (g.flags == kFlagsOut) return launch_sgpr_e<KH, KW, CWC, EP_OUT>(p, g, nn, so, s);
+    if (g.flags == kFlagsLast) return launch_sgpr_e<KH, KW, CWC, EP_LAST>(p, g, nn, so, s);
+    if (g.flags == kFlagsHb) return launch_sgpr_e<KH, KW, CWC, EP_HB>(p, g, nn, so, s);
+    if (g.flags == kFlagsHb3) return launch_sgpr_e<KH, KW, CWC, EP_HB3>(p, g, nn, so, s);
   } else {
-    if (g.flags == kFlagsDs) return launch_sgpr_e<KH, KW, CWC, EP_DS>(p, g, nn, s);
+    if (g.flags == kFlagsDs) return launch_sgpr_e<KH, KW, CWC, EP_DS>(p, g, nn, so, s);
   }
-  if (fused) launch_sgpr_e<KH, KW, CWC, EP_RUNTIME>(p, g, nn, s);
-  else launch_sgpr_e<KH, KW, CWC, EP_PLAIN>(p, g, nn, s);
+  if (fused) launch_sgpr_e<KH, KW, CWC, EP_RUNTIME>(p, g, nn, so, s);
+  else launch_sgpr_e<KH, KW, CWC, EP_PLAIN>(p, g, nn, so, s);
 }
 
 template <int KH, int KW, int CWC>

@@ -92,6 +92,10 @@ typedef struct bnn_hip_conv_desc {
                                         out of a ReLU / max-pool of a ReLU are {0,+1}): 3x3 kernels
                                         then keep only the P plane in registers.  M must still be a
                                         valid pointer.  A wrong promise gives wrong results.      */
+#define BNN_HIP_FLAG_THROUGHPUT 64   /* other work shares the GPU (several batches in flight): prefer fewer,
+                                        longer waves — the multi-chunk 3x3 kernels then do not split a
+                                        32-channel block over two waves (same results; ResNet-18 b256:
+                                        -3 % with one batch in flight, +2 % with two)              */
 
 /* Everything that happens to the integer dot after the popcount loop, fused into the conv
  * kernel so that activations can stay bit-packed between binary layers (callers:

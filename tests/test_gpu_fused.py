@@ -490,6 +490,16 @@ def test_head_kernel_matches_fp64_avgpool_fc(shape, O):
     assert torch.allclose(y, lib_y, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
 
 
+def test_throughput_mode_changes_the_kernel_choice_not_the_result():
+    """BNN_HIP_FLAG_THROUGHPUT (PipelinedInference with several batches in flight): the multi-chunk 3x3 kernels keep a
+    32-channel block in one wave instead of splitting it — bit-identical logits."""
+    net = _r18()
+    x = dev(gen.normal(41, (8, 3, 96, 96)))
+    a, b = FusedResNet(net), FusedResNet(net, throughput_mode=True)
+    assert b._blocks[0]["convs"][0].throughput and not a._blocks[0]["convs"][0].throughput
+    assert torch.equal(a(x), b(x))
+
+
 def test_fused_executor_uses_the_head_kernel_and_no_library_gemm():
     net = _r18()
     fused = FusedResNet(net)
