@@ -17,6 +17,7 @@ are derived once (call ``refresh()`` after changing parameters).  Eval mode only
 from __future__ import annotations
 
 import contextlib
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -423,7 +424,8 @@ class PipelinedInference:
         if n_streams < 1:
             raise ValueError("n_streams must be >= 1")
         dev = example.device
-        fused_kwargs.setdefault("throughput_mode", n_streams > 1)
+        env = os.environ.get("BNN_AMD_THROUGHPUT")   # "0" / "1": override for experiments
+        fused_kwargs.setdefault("throughput_mode", n_streams > 1 if env is None else env == "1")
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
         self.engines: List[FusedResNet] = []
         cur = torch.cuda.current_stream(dev)

@@ -947,7 +947,9 @@ static void launch_sgpr_t(const ConvP& p, const Geo& g, bool split_ok, hipStream
     constexpr int MW = NN ? BNN_NN_MULTI_MINW : 4;
 #if BNN_MULTI_GSPLIT > 1
     // few pixel tiles per SIMD (ResNet layer3/4 at batch 256: 6 and 3 waves per SIMD): split the block
-    if (split_ok && (long long)grid.x <= BNN_GSPLIT_MAX_WAVES) {
+    // throughput mode keeps the split for launches of fewer than 2048 waves (two per SIMD): those need it even
+    // beside another batch (config-5 net at batch 128: 127 k images/s with the split, 119 k without)
+    if ((split_ok || grid.x < 2048u) && (long long)grid.x <= BNN_GSPLIT_MAX_WAVES) {
       const dim3 grid2(grid.x * BNN_MULTI_GSPLIT);
       hipLaunchKernelGGL(
           (bconv_sgpr_kernel<KH, KW, CWC, EP, MW, BNN_MULTI_GSPLIT, true, true, NN>), grid2,
