@@ -196,6 +196,25 @@ def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: 
     return y, pk
 
 
+def sign_thresholds(w: PackedWeight, bn_scale: torch.Tensor, bn_shift: torch.Tensor, bias=None, post_scale=None):
+    """Integer form of ``sign(relu(bn(alpha * dot + bias)))`` for ``bconv2d_fused(..., sign_thresholds=...)``:
+    int32 ``[O, 2]`` = (lo, span) per channel, derived on the device with the epilogue's own float operations
+    (include/bnn_hip.h: bnn_hip_sign_thresholds_f32).  Valid for THIS weight pack and THESE BatchNorm constants."""
+    lib = native.require()
+    O, C, KH, KW = w.shape
+    dev = w.alpha.device
+    bn_scale = _per_channel(bn_scale, O, "bn_scale")
+    bn_shift = _per_channel(bn_shift, O, "bn_shift")
+    bias = _per_channel(bias, O, "bias")
+    post_scale = _per_channel(post_scale, O, "post_scale")
+    with torch.cuda.device(dev):
+        thr = torch.empty((O, 2), dtype=torch.int32, device=dev)
+        native.check(lib.bnn_hip_sign_thresholds_f32(w.alpha.data_ptr(), _ptr(bias), _ptr(post_scale), bn_scale.data_ptr(),
+                                                     bn_shift.data_ptr(), O, C * KH * KW, thr.data_ptr(), _stream(dev)),
+                     "bnn_hip_sign_thresholds_f32")
+    return thr
+
+
 def avgpool_fc(x: torch.Tensor, w_t: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """``fc(flatten(avgpool(x)))`` of bnn/models/resnet.py:160-164 in one kernel.  ``x``: fp32 ``[N,C,H,W]``,
     ``w_t``: the Linear weight transposed to ``[C,O]`` (contiguous), ``bias``: ``[O]`` or None."""
@@ -354,7 +373,7 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
                   weights: Optional[str] = None, residual_after_act: bool = False,
                   pack_before_residual: bool = False, pack_scale=None, pack_shift=None,
                   pack_relu: bool = False, out: Optional[torch.Tensor] = None, out_c_offset: int = 0,
-                  throughput: bool = False):
+                  throughput: bool = False, sign_thresholds: Optional[torch.Tensor] = None):
     """Binary convolution + fused epilogue (see ``bnn_hip_epilogue``): returns
     ``(y_fp32 | None, PackedAct(sign(p)) | None)``.
 
@@ -404,7 +423,8 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
                                 None if y is None else y[n0:n1].data_ptr(),
                                 None if pk is None else pk.P[n0:n1].data_ptr(),
                                 None if pk is None else pk.M[n0:n1].data_ptr(), _ptr(pack_scale), _ptr(pack_shift),
-                                out_c_offset if out is not None else 0, c_total if out is not None else 0)
+                                out_c_offset if out is not None else 0, c_total if out is not None else 0,
+                                _ptr(sign_thresholds))
             native.check(lib.bnn_hip_bconv2d_fused(ctypes.byref(dd), a.P[n0:n1].data_ptr(), a.M[n0:n1].data_ptr(),
                                                    w.wbits.data_ptr(), w.wnz.data_ptr(),
                                                    ctypes.byref(e), _stream(dev)),

@@ -85,17 +85,20 @@ class _Conv:
     prelu: Optional[torch.Tensor]
     name: str = ""
     throughput: bool = False   # BNN_HIP_FLAG_THROUGHPUT: several batches in flight (PipelinedInference)
+    thr: Optional[torch.Tensor] = None   # integer sign thresholds of a BN + ReLU -> planes-only epilogue
 
     def run(self, act: hipops.PackedAct, *, residual=None, out_f32: bool, out_packed: bool, **epi):
         """``epi``: the pre-activation switches of ``hipops.bconv2d_fused`` (late residual, pack affine, ...)."""
         lay = self.layer
         if _TAP is not None:
             _TAP(self.name, act)
+        # BN + ReLU -> planes only (conv1 of a BasicBlock): the sign bit is an integer interval test on the dot
+        thr = self.thr if (out_packed and not out_f32 and residual is None and not epi) else None
         return hipops.bconv2d_fused(
             act, self.weight, bias=lay.bias, post_scale=self.plan.scale, bn_scale=self.bn_scale,
             bn_shift=self.bn_shift, residual=residual, prelu=self.prelu, relu=self.relu,
             out_f32=out_f32, out_packed=out_packed, stride=lay.stride, padding=lay.padding,
-            dilation=lay.dilation, throughput=self.throughput, **epi)
+            dilation=lay.dilation, throughput=self.throughput, sign_thresholds=thr, **epi)
 
 
 def _plan_of(conv: nn.Module) -> fastpath.Plan:
@@ -131,8 +134,11 @@ class FusedResNet(nn.Module):
     pre-activation dataflow of examples/imagenet.py) or ``HBlock`` (hierarchical blocks)."""
 
     def __init__(self, model: ResNet, use_mfma_stem: bool = True, overlap_shortcut: bool = True,
-                 stem_fp16: bool = False, stem_exact_fp32: bool = False, throughput_mode: bool = False) -> None:
+                 stem_fp16: bool = False, stem_exact_fp32: bool = False, throughput_mode: bool = False,
+                 int_thresholds: bool = True) -> None:
         super().__init__()
+        # BN + ReLU + sign of the conv1-type layers as an integer interval test on the dot (same bits, fewer instructions)
+        self.int_thresholds = int_thresholds
         # several batches in flight on other streams: kernels prefer fewer, longer waves (BNN_HIP_FLAG_THROUGHPUT)
         self.throughput_mode = throughput_mode
         self.stem_fp16 = stem_fp16           # opt-in: plain fp16 stem operands (~5e-4 relative error)
@@ -153,8 +159,12 @@ class FusedResNet(nn.Module):
         if prelu is not None and prelu.numel() != conv.out_channels:
             prelu = prelu.expand(conv.out_channels).contiguous()
         scale, shift = (None, None) if bn is None else fold_bn(bn)
-        return _Conv(conv, plan, fastpath.packed_weight(conv, plan), scale, shift, relu, prelu,
-                     self._names.get(id(conv), ""), self.throughput_mode)
+        pw = fastpath.packed_weight(conv, plan)
+        thr = None
+        if (self.int_thresholds and scale is not None and relu and prelu is None and conv.bias is None
+                and plan.scale is None and not pw.has_zero):
+            thr = hipops.sign_thresholds(pw, scale, shift)
+        return _Conv(conv, plan, pw, scale, shift, relu, prelu, self._names.get(id(conv), ""), self.throughput_mode, thr)
 
     @staticmethod
     def _sign_through(act: nn.Module):

@@ -24,7 +24,7 @@ FLAG_ACT_NONNEG = 32
 FLAG_THROUGHPUT = 64
 STEM_EXACT_FP32 = 1
 STEM_FP16 = 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # every symbol include/bnn_hip.h declares (tests assert the .so exports all of them)
 EXPORTED_SYMBOLS = (
@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_avgpool_pack_f32", "bnn_hip_bn_relu_maxpool_pack_f32", "bnn_hip_stem7x7_bn_relu_pool_pack_f32",
     "bnn_hip_pack_weight_f32", "bnn_hip_bconv2d",
     "bnn_hip_bconv2d_fused", "bnn_hip_bconv2d_dot", "bnn_hip_blinear",
-    "bnn_hip_conv_workspace_bytes", "bnn_hip_bconv2d_f32", "bnn_hip_probe_int_alu", "bnn_hip_avgpool_fc_f32", "bnn_hip_pack_act_f16", "bnn_hip_orpool_packed",
+    "bnn_hip_conv_workspace_bytes", "bnn_hip_bconv2d_f32", "bnn_hip_probe_int_alu", "bnn_hip_avgpool_fc_f32", "bnn_hip_sign_thresholds_f32", "bnn_hip_pack_act_f16", "bnn_hip_orpool_packed",
     "bnn_hip_grad_weight_pack_bytes", "bnn_hip_grad_pack_weight_f32", "bnn_hip_bconv_grad_input_f32",
     "bnn_hip_bconv_grad_weight_splits", "bnn_hip_bconv_grad_weight_f32",
 )
@@ -71,7 +71,8 @@ class Epilogue(ctypes.Structure):
                 ("relu", ctypes.c_int32), ("flags", ctypes.c_int32),
                 ("out_f32", ctypes.c_void_p), ("out_P", ctypes.c_void_p), ("out_M", ctypes.c_void_p),
                 ("pack_scale", ctypes.c_void_p), ("pack_shift", ctypes.c_void_p),
-                ("out_c_offset", ctypes.c_int32), ("out_c_total", ctypes.c_int32)]
+                ("out_c_offset", ctypes.c_int32), ("out_c_total", ctypes.c_int32),
+                ("sign_thresholds", ctypes.c_void_p)]
 
 
 EPI_RES_AFTER_ACT = 1
@@ -121,6 +122,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_conv_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.bnn_hip_bconv2d_f32.argtypes = [ctypes.POINTER(ConvDesc)] + [_vp] * 9
     lib.bnn_hip_avgpool_fc_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]
+    lib.bnn_hip_sign_thresholds_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]
     lib.bnn_hip_grad_weight_pack_bytes.restype = ctypes.c_size_t
     lib.bnn_hip_grad_weight_pack_bytes.argtypes = [_i, _i, _i]
     lib.bnn_hip_grad_pack_weight_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp]

@@ -69,6 +69,7 @@ struct EpiArgs {
   uint32_t* outM;
   const float* pack_a;
   const float* pack_b;
+  const int32_t* thr;  // EP_MIDT: per channel {lo, count-1} of the dot interval whose sign bit is 1
 };
 
 #ifndef BNN_TILED_MIN_WAVES  // waves per SIMD the tiled kernels are register-allocated for
@@ -255,6 +256,8 @@ enum : int {
   EP_HB = 6,       // HBlock stages 1, 2 (hierarchical_block.py:38-60): raw conv + late residual -> fp32 slice of the
                    // concatenation; planes of sign(relu(bn_next(conv))) for the next stage
   EP_HB3 = 7,      // HBlock stage 3: raw conv + late residual -> fp32 slice
+  EP_MIDT = 8,     // EP_MID with the BN + ReLU + sign folded into an integer interval test on the dot (thresholds
+                   // derived on the device from the same float operations: bnn_hip_sign_thresholds_f32)
 };
 constexpr int kFlagsMid = EF_BN | EF_RELU | EF_PACK;
 constexpr int kFlagsOut = EF_BN | EF_RES | EF_RELU | EF_OUTF | EF_PACK;
@@ -263,7 +266,7 @@ constexpr int kFlagsLast = EF_BN | EF_RES | EF_RELU | EF_OUTF;
 constexpr int kFlagsHb = EF_RES | EF_RES_LATE | EF_PACK_PRE | EF_OUTF | EF_PACK | EF_PACK_AFF | EF_PACK_RELU;
 constexpr int kFlagsHb3 = EF_RES | EF_RES_LATE | EF_PACK_PRE | EF_OUTF;
 __device__ __forceinline__ constexpr int ep_flags(int ep, int runtime) {
-  return ep == EP_MID ? kFlagsMid
+  return (ep == EP_MID || ep == EP_MIDT) ? kFlagsMid
          : ep == EP_OUT ? kFlagsOut
          : ep == EP_DS ? kFlagsDs
          : ep == EP_LAST ? kFlagsLast
@@ -313,6 +316,19 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
     return;
   }
   const int bit0 = o0 & 31;  // position of channel o0 inside its 32-channel output word
+  if constexpr (EP == EP_MIDT) {
+    // sign(relu(bn(alpha * dot))) == 1  <=>  lo[o] <= dot <= lo[o] + span[o]  (one unsigned compare); M stays 0
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) {
+      const int o = o0 + j;
+      if (full || o < g.O) {
+        const bool bit = (unsigned)(dot[j] - e.thr[2 * o]) <= (unsigned)e.thr[2 * o + 1];
+        if constexpr (FULL) pbits = shift_in(pbits, bit);
+        else pbits |= (bit ? 1u : 0u) << (bit0 + j);
+      }
+    }
+    return;
+  }
   [[maybe_unused]] float pvs[NACC];  // FULL: the values to binarise; their bits are shifted in after the arithmetic
 #pragma unroll
   for (int j = 0; j < NACC; ++j) {
@@ -436,9 +452,9 @@ __device__ __forceinline__ void store_packed_part(const Geo& g, const Pix& px, i
       const float *__restrict__ bn_a, const float *__restrict__ bn_b,                           \
       const float *__restrict__ prelu, const float *__restrict__ res, void *__restrict__ out,   \
       uint32_t *__restrict__ outP, uint32_t *__restrict__ outM,                                 \
-      const float *__restrict__ pack_a, const float *__restrict__ pack_b
+      const float *__restrict__ pack_a, const float *__restrict__ pack_b, const int32_t *__restrict__ thr
 #define BNN_EPI_INIT \
-  EpiArgs epi{alpha, bias, scale, bn_a, bn_b, prelu, res, out, outP, outM, pack_a, pack_b}
+  EpiArgs epi{alpha, bias, scale, bn_a, bn_b, prelu, res, out, outP, outM, pack_a, pack_b, thr}
 
 // ---------------------------------------------------------------------------------
 // Tiled kernel, weights streamed through SGPRs (scalar cache).  Best when all waves in
@@ -883,7 +899,7 @@ static Geo make_geo(const ConvP& p) {
 }
 
 #define BNN_EPI_ACTUALS \
-  p.alpha, p.bias, p.scale, p.bn_a, p.bn_b, p.prelu, p.res, p.out, p.outP, p.outM, p.pack_a, p.pack_b
+  p.alpha, p.bias, p.scale, p.bn_a, p.bn_b, p.prelu, p.res, p.out, p.outP, p.outM, p.pack_a, p.pack_b, p.thr
 
 // grid.y: one block per 32 output channels; in pack mode also the (all-zero) tail words of the
 // packed output row so that every word of the next layer's input is written.
@@ -998,6 +1014,7 @@ static void launch_sgpr(const ConvP& p, int flags, hipStream_t s) {
     return;
   }
   if constexpr (PROFILES) {
+    if (g.flags == kFlagsMid && p.thr) return launch_sgpr_e<KH, KW, CWC, EP_MIDT>(p, g, nn, so, s);
     if (g.flags == kFlagsMid) return launch_sgpr_e<KH, KW, CWC, EP_MID>(p, g, nn, so, s);
     if (g.flags == kFlagsOut) return launch_sgpr_e<KH, KW, CWC, EP_OUT>(p, g, nn, so, s);
     if (g.flags == kFlagsLast) return launch_sgpr_e<KH, KW, CWC, EP_LAST>(p, g, nn, so, s);

@@ -63,6 +63,7 @@ struct ConvP {
   // activation, packing the pre-residual value, channel slice of a wider output tensor
   const float* pack_a;
   const float* pack_b;
+  const int32_t* thr;  // sign thresholds {lo, span} per channel (BN + ReLU -> packed-only epilogue), or null
   int eflags;
   int c_off, c_tot;
   bool raw;
@@ -75,6 +76,8 @@ struct ConvP {
 
 // host-side launchers (one per .hip file); return a bnn_hip_status
 int choose_cwc(int cw32, int KH, int KW);
+int launch_sign_thresholds(const float* alpha, const float* bias, const float* scale, const float* bn_a,
+                           const float* bn_b, int O, int kmax, int32_t* thr, hipStream_t stream);
 int launch_pack_act(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
                     hipStream_t stream);
 int launch_pack_act_f16(const void* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,

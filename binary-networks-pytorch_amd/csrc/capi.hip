@@ -300,9 +300,21 @@ int bnn_hip_bconv2d_fused(const bnn_hip_conv_desc* d, const uint64_t* P, const u
   p.outP = reinterpret_cast<uint32_t*>(e->out_P);
   p.outM = reinterpret_cast<uint32_t*>(e->out_M);
   p.pack_a = e->pack_scale; p.pack_b = e->pack_shift;
+  p.thr = e->sign_thresholds;
+  if (p.thr && !aligned(p.thr, 4)) return BNN_HIP_ERR_INVALID_ARG;
   p.eflags = e->flags;
   p.c_off = e->out_c_offset; p.c_tot = e->out_c_total;
   return run_conv(d, P, M, wbits, wnz, p, stream);
+}
+
+int bnn_hip_sign_thresholds_f32(const float* alpha, const float* bias, const float* post_scale, const float* bn_scale,
+                                const float* bn_shift, int O, int kmax, int32_t* thresholds, void* stream) {
+  if (!alpha || !thresholds || O <= 0 || kmax <= 0 || kmax >= (1 << 24)) return BNN_HIP_ERR_INVALID_ARG;
+  if ((bn_scale == nullptr) != (bn_shift == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
+  if (!aligned(thresholds, 4)) return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  return bnn::launch_sign_thresholds(alpha, bias, post_scale, bn_scale, bn_shift, O, kmax, thresholds,
+                                     static_cast<hipStream_t>(stream));
 }
 
 int bnn_hip_bconv2d_dot(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M,

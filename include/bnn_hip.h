@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 7
+#define BNN_HIP_ABI_VERSION 8
 #define BNN_HIP_OCB 32 /* output channels per weight block (padding granularity of O) */
 
 typedef enum bnn_hip_status {
@@ -140,7 +140,20 @@ typedef struct bnn_hip_epilogue {
   const float* pack_shift;
   int32_t out_c_offset;    /* see above; 0/0 = plain [N,O,Ho,Wo]        */
   int32_t out_c_total;
+  const int32_t* sign_thresholds; /* NULL, or [O][2] from bnn_hip_sign_thresholds_f32 for THIS alpha / bn_scale /
+                                     bn_shift: used when the epilogue is exactly BN + ReLU -> planes only (no bias,
+                                     scale, residual, fp32 output): the sign bit then comes from an integer interval
+                                     test on the dot — same bits as the float path, fewer instructions.  Ignored
+                                     otherwise.                                                          */
 } bnn_hip_epilogue;
+
+/* Per channel the interval of integer dots (|dot| <= kmax = C*KH*KW) whose epilogue value
+ *   fmaf(fmaf(alpha, dot, bias) [* post_scale], bn_scale, bn_shift)   is > 0:
+ * thresholds[2o] = lo, thresholds[2o+1] = span, bit = (unsigned)(dot - lo) <= (unsigned)span.  Found by bisection with
+ * the conv epilogue's own float operations (every step is monotone in dot).  Re-derive when any input changes.   */
+int bnn_hip_sign_thresholds_f32(const float* alpha, const float* bias, const float* post_scale,
+                                const float* bn_scale, const float* bn_shift, int O, int kmax,
+                                int32_t* thresholds, void* stream);
 
 typedef struct bnn_hip_wlayout {
   int32_t cw32;     /* 32-bit words per pixel per plane (= 2*ceil(C/64))          */

@@ -490,6 +490,51 @@ def test_head_kernel_matches_fp64_avgpool_fc(shape, O):
     assert torch.allclose(y, lib_y, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 14, 14, 64, 1), (2, 64, 12, 10, 128, 2), (2, 128, 9, 9, 96, 1),
+                                   (2, 256, 7, 7, 256, 1), (1, 512, 7, 7, 64, 1), (2, 70, 6, 5, 40, 1)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_integer_sign_thresholds_give_the_float_epilogue_bits(shape):
+    """bnn_hip_sign_thresholds_f32: BN + ReLU + sign of a conv1-type layer as an integer interval test on the dot.
+    The planes must equal the float epilogue's bit for bit — including channels with a negative, zero, huge, tiny
+    or NaN BatchNorm constant and all-zero weights (alpha = 0) — and the table must reproduce the float predicate on
+    every dot the layer produced."""
+    N, C, H, W, O, stride = shape
+    x = dev(np.maximum(gen.normal(gen.seed_of("thrx", shape), (N, C, H, W)), 0))
+    w = gen.conv_weight("kaiming", gen.seed_of("thrw", shape), (O, C, 3, 3))
+    w[3] = 0.0                                                    # a channel whose alpha is 0
+    bn_a = (0.5 + gen.uniform(1, (O,))).astype(np.float32) * np.where(np.arange(O) % 3 == 0, -1, 1).astype(np.float32)
+    bn_b = (2.0 * gen.normal(2, (O,))).astype(np.float32)
+    bn_a[1], bn_b[1] = 0.0, 0.25                                  # constant positive
+    bn_a[2], bn_b[2] = 0.0, -0.25                                 # constant negative
+    bn_a[5], bn_b[5] = 1e30, 1.0                                  # overflow to +-inf
+    bn_a[6], bn_b[6] = 1e-30, -1e-38                              # denormal products
+    bn_b[7] = np.nan                                              # never positive
+    bn_a[8], bn_b[8] = 1.0, 0.0                                   # the threshold sits exactly at dot = 0
+    pw = hipops.pack_weight(dev(w))
+    act = hipops.pack_act(x)
+    act.nonneg = True
+    a_t, b_t = dev(bn_a), dev(bn_b)
+    thr = hipops.sign_thresholds(pw, a_t, b_t)
+    kw = dict(bn_scale=a_t, bn_shift=b_t, relu=True, out_f32=False, out_packed=True, stride=stride, padding=1)
+    _, ref = hipops.bconv2d_fused(act, pw, **kw)
+    _, got = hipops.bconv2d_fused(act, pw, sign_thresholds=thr, **kw)
+    assert torch.equal(got.P, ref.P) and torch.equal(got.M, ref.M) and not bool(got.M.any())
+    # the table against the float predicate on the dots themselves
+    dot = hipops.bconv2d(act, pw, stride=stride, padding=1, raw_dot=True)                      # int32 [N,O,Ho,Wo]
+    lo, span = thr[:, 0].view(1, -1, 1, 1).long(), thr[:, 1].view(1, -1, 1, 1).long()
+    bit = ((dot.long() - lo) & 0xFFFFFFFF) <= (span & 0xFFFFFFFF)
+    P, _ = oracle.pack_act(np.where(bit.cpu().numpy(), 1.0, 0.0).astype(np.float32))
+    assert np.array_equal(u64(ref.P), P)
+
+
+def test_fused_resnet_with_integer_thresholds_is_bit_identical():
+    net = _r18()
+    x = dev(gen.normal(43, (4, 3, 96, 96)))
+    a, b = FusedResNet(net), FusedResNet(net, int_thresholds=False)
+    assert a._blocks[0]["convs"][0].thr is not None and b._blocks[0]["convs"][0].thr is None
+    assert torch.equal(a(x), b(x))
+
+
 def test_throughput_mode_changes_the_kernel_choice_not_the_result():
     """BNN_HIP_FLAG_THROUGHPUT (PipelinedInference with several batches in flight): the multi-chunk 3x3 kernels keep a
     32-channel block in one wave instead of splitting it — bit-identical logits."""
