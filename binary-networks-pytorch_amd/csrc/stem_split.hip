@@ -290,14 +290,21 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
       const bool interior = cy0 >= 0 && cx0 >= 0 && cy0 + CTH <= Hc && cx0 + CTW <= Wc;  // workgroup-uniform
       float* sdst = stage + ((SUBS * mg) * 16 + lg * 4) * SC + 32 * nh + li;
       if (interior) {
+        // BN of two accumulator rows at a time: one v_pk_fma_f32 instead of two v_fma_f32 (the ReLU has no packed form)
+        typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int i = 0; i < SPASS; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (s0 + i < SUBS && (SUBS * mg + s0 + i) * 16 + lg * 4 + r < MPIX) {
+          for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-              for (int tt = 0; tt < TT; ++tt)
-                sdst[((s0 + i) * 16 + r) * SC + 16 * tt] = fmaxf(fmaf(acc[i][tt][r], ba[tt], bb[tt]), 0.0f);
+            for (int rp = 0; rp < 4; rp += 2) {
+              if (s0 + i >= SUBS) continue;
+              const f2 y = __builtin_elementwise_fma(f2{acc[i][tt][rp], acc[i][tt][rp + 1]}, f2{ba[tt], ba[tt]},
+                                                     f2{bb[tt], bb[tt]});
+#pragma unroll
+              for (int q = 0; q < 2; ++q)
+                if ((SUBS * mg + s0 + i) * 16 + lg * 4 + rp + q < MPIX)
+                  sdst[((s0 + i) * 16 + rp + q) * SC + 16 * tt] = fmaxf(y[q], 0.0f);
             }
       } else {
 #pragma unroll
