@@ -73,6 +73,30 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using half2v = __attribute__((ext_vector_type(2))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+
+// Buffer addressing for the output streams: 128-bit descriptor in SGPRs + ONE per-lane byte offset (tile-invariant,
+// computed once) + a wave-uniform byte offset per store in an SGPR (`soffset`).  With plain pointers every store cost
+// a 64-bit multiply-add chain in the vector ALU (~7 instructions; the kernel's time outside the MFMAs is VALU issue).
+// Dead lanes carry an out-of-range offset (the store is dropped); a null tensor is a descriptor with zero records.
+#if defined(__HIP_DEVICE_COMPILE__)
+using StemRsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ StemRsrc stem_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? (int)bytes : 0, 0x00020000);
+}
+__device__ __forceinline__ void stem_st(StemRsrc r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void stem_st2(StemRsrc r, unsigned voff, unsigned soff, u32x2 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, 0);
+}
+#else  // the host pass of hipcc only parses these
+struct StemRsrc {};
+__device__ __forceinline__ StemRsrc stem_rsrc(const void*, unsigned) { return {}; }
+__device__ __forceinline__ void stem_st(StemRsrc, unsigned, unsigned, float) {}
+__device__ __forceinline__ void stem_st2(StemRsrc, unsigned, unsigned, u32x2) {}
+#endif
+constexpr unsigned kStemOOB = 0xFFFFFFF0u;  // beyond every descriptor's num_records
 
 // HALF: plain fp16 operands, one MFMA per product (BNN_HIP_STEM_FP16: the "fp16 MFMA stem" of BASELINE config
 // 5) — 1/3 of the matrix work, ~5e-4 relative error; the lo planes / fragments are then dead code.
@@ -81,7 +105,7 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bn_a,
     const float* __restrict__ bn_b, int N, int H, int W, int Hc, int Wc, int Hp, int Wp, int tiles_y,
     int tiles_x, int per_xcd, float* __restrict__ out, uint64_t* __restrict__ P,
-    uint64_t* __restrict__ M) {
+    uint64_t* __restrict__ M, unsigned out_bytes, unsigned plane_bytes) {
   using namespace stem2;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   _Float16* hiP = reinterpret_cast<_Float16*>(lds_raw + OFF_HI);
@@ -143,6 +167,10 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
   // pooling role: one pooled column (PTH outputs) of one channel, PJ times; 8 channels x 8 columns per wave and pass
   const int pchl = lane & 7, pplx = lane >> 3;  // channel within the wave's byte, pooled column (7 = idle)
   const int pch0 = wave * 8 + pchl;
+  const StemRsrc r_out = stem_rsrc(out, out_bytes), r_P = stem_rsrc(P, plane_bytes), r_M = stem_rsrc(M, plane_bytes);
+  // per-lane byte offsets of the output streams relative to the tile's (wave-uniform) origin
+  const unsigned out_lane = (unsigned)((pch0 * Hp) * Wp + pplx) * 4u;          // channel pch0, pooled column pplx
+  const unsigned flush_lane = (unsigned)((tid / PTW) * Wp + tid % PTW) * 8u;    // pixel (tid / PTW, tid % PTW) of a tile
 
   const int ntiles = N * tiles_y * tiles_x;
   const int nseq = per_xcd * 8;
@@ -202,14 +230,13 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
   // as whole 64-bit words (byte stores from several waves into one word cost ~80 us at batch 256)
   int prev_n = -1, prev_py0 = 0, prev_px0 = 0, buf = 0;
   auto flush_bits = [&](int b) {
-    if (P && !(BNN_STEM_ABL & 32) && prev_n >= 0 && tid < PTH * PTW) {
+    if (!(BNN_STEM_ABL & 32) && prev_n >= 0 && tid < PTH * PTW) {  // wave 0 only
       const int ply = tid / PTW, plx = tid - ply * PTW;
-      const int py = prev_py0 + ply, px = prev_px0 + plx;
-      if (py < Hp && px < Wp) {
-        const size_t o = ((size_t)prev_n * Hp + py) * Wp + px;
-        P[o] = *reinterpret_cast<const uint64_t*>(bits + (b * PTH * PTW + tid) * 8);
-        M[o] = 0;  // nothing is negative after ReLU
-      }
+      const bool ok = prev_py0 + ply < Hp && prev_px0 + plx < Wp;
+      const unsigned soff = (unsigned)((prev_n * Hp + prev_py0) * Wp + prev_px0) * 8u;
+      const u32x2 word = *reinterpret_cast<const u32x2*>(bits + (b * PTH * PTW + tid) * 8);
+      stem_st2(r_P, ok ? flush_lane : kStemOOB, soff, word);
+      stem_st2(r_M, ok ? flush_lane : kStemOOB, soff, u32x2{0u, 0u});  // nothing is negative after ReLU
     }
   };
 
@@ -339,6 +366,8 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
     // ---- 3x3 / stride-2 max pool: row maxima of the thread's 3 conv columns, then PTH column maxima
     const int px = px0 + pplx;
     const bool col_live = valid && pplx < PTW && px < Wp;
+    const unsigned out_voff = col_live ? out_lane : kStemOOB;
+    const unsigned out_tile = (unsigned)((n * COUT * Hp + py0) * Wp + px0) * 4u;  // wave-uniform
 #pragma unroll
     for (int pj = 0; pj < PJ; ++pj) {
       const int pch = pch0 + NW * 8 * pj;
@@ -354,8 +383,9 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
         const int py = py0 + ply;
         const bool live = col_live && py < Hp;  // py < Hp is workgroup-uniform
         const float v = fmaxf(fmaxf(hm[2 * ply], hm[2 * ply + 1]), hm[2 * ply + 2]);
-        if (live && out) out[(((size_t)n * COUT + pch) * Hp + py) * Wp + px] = v;
-        if (P && !(BNN_STEM_ABL & 16)) {  // lanes 8*plx .. 8*plx+7 hold the 8 channels of one byte of pixel (ply, plx)
+        if (py < Hp)  // workgroup-uniform
+          stem_st(r_out, out_voff, out_tile + (unsigned)((NW * 8 * pj * Hp + ply) * Wp) * 4u, v);
+        if (P != nullptr && !(BNN_STEM_ABL & 16)) {  // lanes 8*plx .. 8*plx+7 hold the 8 channels of one byte of pixel (ply, plx)
           const unsigned long long mask = __ballot(live && is_pos(v));
           if (pchl == 0 && pplx < PTW)
             bits[((buf * PTH + ply) * PTW + pplx) * 8 + wave + NW * pj] = (uint8_t)(mask >> (8 * pplx));
@@ -400,8 +430,11 @@ static int launch_stem_split_t(const float* x, const float* w, const float* bn_a
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
+  // byte sizes of the output streams (the C-ABI caps every tensor below 2^32 bytes)
+  const unsigned out_bytes = (unsigned)((long long)N * COUT * Hp * Wp * 4);
+  const unsigned plane_bytes = (unsigned)((long long)N * Hp * Wp * 8);
   hipLaunchKernelGGL(stem_split_kernel<HALF>, dim3(grid), dim3(NT), LDS_BYTES, stream, x, w, bn_a, bn_b, N, H,
-                     W, Hc, Wc, Hp, Wp, tiles_y, tiles_x, per_xcd, out, P, M);
+                     W, Hc, Wc, Hp, Wp, tiles_y, tiles_x, per_xcd, out, P, M, out_bytes, plane_bytes);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
