@@ -317,7 +317,9 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
       const bool interior = cy0 >= 0 && cx0 >= 0 && cy0 + CTH <= Hc && cx0 + CTW <= Wc;  // workgroup-uniform
       float* sdst = stage + ((SUBS * mg) * 16 + lg * 4) * SC + 32 * nh + li;
       if (interior) {
-        // BN of two accumulator rows at a time: one v_pk_fma_f32 instead of two v_fma_f32 (the ReLU has no packed form)
+        // BN of two accumulator rows at a time: one v_pk_fma_f32 instead of two v_fma_f32.  The ReLU is applied AFTER
+        // the max-pool (max and relu commute exactly; padding positions are staged as 0): 8 clamps per thread there
+        // instead of 40 here
         typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int i = 0; i < SPASS; ++i)
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
 #pragma unroll
               for (int q = 0; q < 2; ++q)
                 if ((SUBS * mg + s0 + i) * 16 + lg * 4 + rp + q < MPIX)
-                  sdst[((s0 + i) * 16 + rp + q) * SC + 16 * tt] = fmaxf(y[q], 0.0f);
+                  sdst[((s0 + i) * 16 + rp + q) * SC + 16 * tt] = y[q];
             }
       } else {
 #pragma unroll
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
               const bool inside = (unsigned)(cy0 + cy) < (unsigned)Hc && (unsigned)(cx0 + cx) < (unsigned)Wc;
 #pragma unroll
               for (int tt = 0; tt < TT; ++tt) {
-                const float v = fmaxf(fmaf(acc[i][tt][r], ba[tt], bb[tt]), 0.0f);
+                const float v = fmaf(acc[i][tt][r], ba[tt], bb[tt]);
                 // positions outside the conv output are MaxPool padding: 0 never beats a ReLU output
                 sdst[((s0 + i) * 16 + r) * SC + 16 * tt] = inside ? v : 0.0f;
               }
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(stem2::NT, 2) void stem_split_kernel(
       for (int ply = 0; ply < PTH; ++ply) {
         const int py = py0 + ply;
         const bool live = col_live && py < Hp;  // py < Hp is workgroup-uniform
-        const float v = fmaxf(fmaxf(hm[2 * ply], hm[2 * ply + 1]), hm[2 * ply + 2]);
+        const float v = fmaxf(fmaxf(fmaxf(hm[2 * ply], hm[2 * ply + 1]), hm[2 * ply + 2]), 0.0f);  // max-pool, then ReLU
         if (py < Hp)  // workgroup-uniform
           stem_st(r_out, out_voff, out_tile + (unsigned)((NW * 8 * pj * Hp + ply) * Wp) * 4u, v);
         if (P != nullptr && !(BNN_STEM_ABL & 16)) {  // lanes 8*plx .. 8*plx+7 hold the 8 channels of one byte of pixel (ply, plx)
