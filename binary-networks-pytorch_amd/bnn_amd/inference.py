@@ -135,8 +135,10 @@ class FusedResNet(nn.Module):
 
     def __init__(self, model: ResNet, use_mfma_stem: bool = True, overlap_shortcut: bool = True,
                  stem_fp16: bool = False, stem_exact_fp32: bool = False, throughput_mode: bool = False,
-                 int_thresholds: bool = True) -> None:
+                 int_thresholds: bool = True, skip_dead_f32: bool = True) -> None:
         super().__init__()
+        # the last conv of a block writes no fp32 tensor when the next block consumes sign planes only
+        self.skip_dead_f32 = skip_dead_f32
         # BN + ReLU + sign of the conv1-type layers as an integer interval test on the dot (same bits, fewer instructions)
         self.int_thresholds = int_thresholds
         # several batches in flight on other streams: kernels prefer fewer, longer waves (BNN_HIP_FLAG_THROUGHPUT)
@@ -295,8 +297,9 @@ class FusedResNet(nn.Module):
             if b["ds"] is not None:
                 # the shortcut branch (HBM-bound avg-pool + a small 1x1 conv) is independent of the block's
                 # first convs (ALU-bound): run it on a second stream and join before the residual is needed
-                cur = torch.cuda.current_stream(t.device)
-                side = self._side_stream(t.device) if self.overlap_shortcut else None
+                dev_ = packed.P.device      # (t is None when the previous block skipped its dead fp32 output)
+                cur = torch.cuda.current_stream(dev_)
+                side = self._side_stream(dev_) if self.overlap_shortcut else None
                 if side is not None:
                     side.wait_stream(cur)
                 with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
@@ -308,7 +311,8 @@ class FusedResNet(nn.Module):
                         sc_in = packed
                     idn, _ = b["ds"].run(sc_in, out_f32=True, out_packed=False)
                 if side is not None:
-                    t.record_stream(side)
+                    if t is not None:
+                        t.record_stream(side)
                     packed.P.record_stream(side)
                     sc_in.P.record_stream(side)
                     sc_in.M.record_stream(side)
@@ -319,7 +323,12 @@ class FusedResNet(nn.Module):
             if side is not None:
                 cur.wait_stream(side)
                 idn.record_stream(cur)
-            t, packed = b["convs"][-1].run(packed, residual=idn, out_f32=True, out_packed=i != last)
+            # the fp32 output is dead when the next block reads sign planes only: its convs always do, its shortcut
+            # does when it is AvgPool -> binary 1x1 (-> OR-pool of the planes of a non-negative tensor, or no pooling)
+            c2 = b["convs"][-1]
+            dead_f32 = (self.skip_dead_f32 and nxt is not None and nxt["kind"] == "post" and nxt["ds"] is not None
+                        and (nxt["pool"] <= 1 or (c2.relu and c2.prelu is None)))
+            t, packed = c2.run(packed, residual=idn, out_f32=not dead_f32, out_packed=i != last)
         # real-valued head (last layer stays float)
         if self._head is not None:
             return hipops.avgpool_fc(t, *self._head)

@@ -99,6 +99,16 @@ __device__ __forceinline__ int popc_acc(uint32_t x, int acc) {
   return acc + __builtin_popcount(x);
 #endif
 }
+// Same with a wave-uniform addend (an SGPR or an inline constant: the start value of a chain costs no VGPR).
+__device__ __forceinline__ int popc_acc_s(uint32_t x, int acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "s"(acc));
+  return r;
+#else
+  return acc + __builtin_popcount(x);
+#endif
+}
 
 // WB consecutive weight words, loaded with one s_load_dwordx16.
 template <int WB>
@@ -256,11 +266,14 @@ enum : int {
   EP_HB = 6,       // HBlock stages 1, 2 (hierarchical_block.py:38-60): raw conv + late residual -> fp32 slice of the
                    // concatenation; planes of sign(relu(bn_next(conv))) for the next stage
   EP_HB3 = 7,      // HBlock stage 3: raw conv + late residual -> fp32 slice
+  EP_OUTP = 9,     // BN + residual + ReLU -> packed only  (conv2 of a BasicBlock whose fp32 output nobody reads: the
+                   // next block takes its shortcut from the sign planes — AvgPool -> binary 1x1 — like its convs)
   EP_MIDT = 8,     // EP_MID with the BN + ReLU + sign folded into an integer interval test on the dot (thresholds
                    // derived on the device from the same float operations: bnn_hip_sign_thresholds_f32)
 };
 constexpr int kFlagsMid = EF_BN | EF_RELU | EF_PACK;
 constexpr int kFlagsOut = EF_BN | EF_RES | EF_RELU | EF_OUTF | EF_PACK;
+constexpr int kFlagsOutP = EF_BN | EF_RES | EF_RELU | EF_PACK;
 constexpr int kFlagsDs = EF_BN | EF_OUTF;
 constexpr int kFlagsLast = EF_BN | EF_RES | EF_RELU | EF_OUTF;
 constexpr int kFlagsHb = EF_RES | EF_RES_LATE | EF_PACK_PRE | EF_OUTF | EF_PACK | EF_PACK_AFF | EF_PACK_RELU;
@@ -268,6 +281,7 @@ constexpr int kFlagsHb3 = EF_RES | EF_RES_LATE | EF_PACK_PRE | EF_OUTF;
 __device__ __forceinline__ constexpr int ep_flags(int ep, int runtime) {
   return (ep == EP_MID || ep == EP_MIDT) ? kFlagsMid
          : ep == EP_OUT ? kFlagsOut
+         : ep == EP_OUTP ? kFlagsOutP
          : ep == EP_DS ? kFlagsDs
          : ep == EP_LAST ? kFlagsLast
          : ep == EP_HB ? kFlagsHb
@@ -282,17 +296,36 @@ __device__ __forceinline__ constexpr int ep_flags(int ep, int runtime) {
 // `s_waitcnt vmcnt(0)` in front of EVERY store — a wave then pays a full memory round trip per channel (measured on
 // the conv2-type kernels: the two fp32 streams were purely additive to the ALU time, 74 + 29 + 29 = 132 us).
 // Straight-line code lets the loads and stores of a pass queue up behind each other.
-template <int NACC, int EP, bool FULL = false>
+// RAWF (straight-line epilogue of the compile-time profiles): `dot` is not the dot product but the BIT PATTERN of the float
+// 2^23 + count — the popcount chains of stream_weights() start from 0x4B000000, and an integer added to that pattern is
+// added to the float's value.  The dot product then is fma(value - 2^23, dscale, doff) with dscale = +-2 and doff =
+// -+(non-zero inputs of the lane): two packed instructions per channel PAIR, all operands small integers, so exact —
+// instead of add-shift, subtract and v_cvt_f32_i32 per channel.
+constexpr uint32_t kCountSeed = 0x4B000000u;  // 2^23 as fp32
+template <int NACC, int EP, bool FULL = false, bool RAWF = false>
 __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
                                          const int (&dot)[NACC], const float (&resv)[NACC],
-                                         const EpiArgs& e, uint32_t& pbits, uint32_t& mbits) {
+                                         const EpiArgs& e, uint32_t& pbits, uint32_t& mbits,
+                                         [[maybe_unused]] int negnz = 0, [[maybe_unused]] float dscale = 0.0f,
+                                         [[maybe_unused]] float doff = 0.0f) {
+  static_assert(!RAWF || (FULL && NACC % 2 == 0 && EP != EP_RUNTIME && EP != EP_MIDT), "see above");
+  // EP_MIDT: `dot` holds 2*agreements and `negnz` the lane's -(non-zero inputs); every other profile: the dot product
   constexpr bool FUSED = EP != EP_PLAIN;
+  using f2 = __attribute__((ext_vector_type(2))) float;
+  [[maybe_unused]] auto dot_pair = [&](int j) -> f2 {
+    if constexpr (RAWF) {
+      const f2 c = f2{__int_as_float(dot[j]), __int_as_float(dot[j + 1])} - f2{8388608.0f, 8388608.0f};
+      return __builtin_elementwise_fma(c, f2{dscale, dscale}, f2{doff, doff});
+    } else {
+      return f2{(float)dot[j], (float)dot[j + 1]};
+    }
+  };
   const int hw = g.Ho * g.Wo;
   const unsigned lane_off = (unsigned)(px.n * g.c_tot * hw + px.r) * 4u;  // BYTES; host keeps N*c_tot*hw < 2^30
   const int f = ep_flags(EP, g.flags);
   const bool full = FULL || o0 + NACC <= g.O;
   const bool live = FULL || px.live;
-  if (f & EF_RAW) {
+  if (!RAWF && (f & EF_RAW)) {  // (launch_sgpr() sends raw output to the run-time profile)
     if (live) {
       int32_t* o32 = static_cast<int32_t*>(e.out);
 #pragma unroll
@@ -304,6 +337,18 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
   float* outf = static_cast<float*>(e.out);
   if (!FUSED) {  // alpha, optional bias / post-scale, fp32 store: the drop-in Conv2d.forward
     const bool hb = (f & EF_BIAS) != 0, hs = (f & EF_SCALE) != 0;
+    if constexpr (FULL && NACC % 2 == 0) {  // two channels per v_pk_fma_f32 (see the fused profiles below)
+#pragma unroll
+      for (int j = 0; j < NACC; j += 2) {
+        const int o = o0 + j;
+        f2 y = __builtin_elementwise_fma(f2{e.alpha[o], e.alpha[o + 1]}, dot_pair(j),
+                                         hb ? f2{e.bias[o], e.bias[o + 1]} : f2{0.0f, 0.0f});
+        if (hs) y *= f2{e.scale[o], e.scale[o + 1]};
+        buf_st(make_rsrc(e.out), lane_off, (unsigned)(o + g.c_off) * (unsigned)hw * 4u, y.x);
+        buf_st(make_rsrc(e.out), lane_off, (unsigned)(o + 1 + g.c_off) * (unsigned)hw * 4u, y.y);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NACC; ++j) {
       const int o = o0 + j;
@@ -322,7 +367,13 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
     for (int j = 0; j < NACC; ++j) {
       const int o = o0 + j;
       if (full || o < g.O) {
-        const bool bit = (unsigned)(dot[j] - e.thr[2 * o]) <= (unsigned)e.thr[2 * o + 1];
+        // dot - lo as 2*agree + (-nonzeros) + (-lo): ONE v_add3_u32 behind the kernel's v_add_lshl_u32 (the negations
+        // are hidden from the optimiser, which would otherwise turn the sum back into two subtractions)
+        int neglo = -e.thr[2 * o];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+s"(neglo));
+#endif
+        const bool bit = (unsigned)(dot[j] + negnz + neglo) <= (unsigned)e.thr[2 * o + 1];
         if constexpr (FULL) pbits = shift_in(pbits, bit);
         else pbits |= (bit ? 1u : 0u) << (bit0 + j);
       }
@@ -330,6 +381,45 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
     return;
   }
   [[maybe_unused]] float pvs[NACC];  // FULL: the values to binarise; their bits are shifted in after the arithmetic
+  if constexpr (FULL && NACC % 2 == 0) {
+    // Straight-line epilogue, two channels per instruction: v_pk_fma_f32 / v_pk_add_f32 take the wave-uniform
+    // constants of channels (o, o+1) as ONE aligned SGPR pair (gfx950 VALU instructions read one scalar operand, so
+    // the scalar form needs a v_mov per second constant), and the ReLU is one v_max_i32 on the bit pattern
+    // (negative floats are negative integers; +NaN stays NaN like torch.relu, -0.0 becomes +0.0 which compares equal).
+    // Same fp32 operations in the same order per channel as the scalar loop below: bit-identical results.
+    const f2 zero2 = {0.0f, 0.0f};
+    const bool no_clamp = !(f & (EF_OUTF | EF_PRELU | EF_PACK_AFF | EF_RES_LATE));
+#pragma unroll
+    for (int j = 0; j < NACC; j += 2) {
+      const int o = o0 + j;
+      f2 y = __builtin_elementwise_fma(f2{e.alpha[o], e.alpha[o + 1]}, dot_pair(j),
+                                       (f & EF_BIAS) ? f2{e.bias[o], e.bias[o + 1]} : zero2);
+      if (f & EF_SCALE) y *= f2{e.scale[o], e.scale[o + 1]};
+      if (f & EF_BN) y = __builtin_elementwise_fma(y, f2{e.bn_a[o], e.bn_a[o + 1]}, f2{e.bn_b[o], e.bn_b[o + 1]});
+      if ((f & EF_RES) && !(f & EF_RES_LATE)) y += f2{resv[j], resv[j + 1]};
+      if ((f & EF_RELU) && !no_clamp) {
+        const float yx = y.x, yy = y.y;  // (bit_cast straight on a vector element reads element 0 with hipcc 7.2)
+        y = f2{__int_as_float(max(__float_as_int(yx), 0)), __int_as_float(max(__float_as_int(yy), 0))};
+      }
+      if (f & EF_PRELU) {
+        y.x = (y.x >= 0.0f) ? y.x : e.prelu[o] * y.x;
+        y.y = (y.y >= 0.0f) ? y.y : e.prelu[o + 1] * y.y;
+      }
+      f2 pv = y;
+      if ((f & EF_RES) && (f & EF_RES_LATE)) y += f2{resv[j], resv[j + 1]};
+      if (!(f & EF_PACK_PRE)) pv = y;
+      if (f & EF_OUTF) {
+        buf_st(make_rsrc(e.out), lane_off, (unsigned)(o + g.c_off) * (unsigned)hw * 4u, y.x);
+        buf_st(make_rsrc(e.out), lane_off, (unsigned)(o + 1 + g.c_off) * (unsigned)hw * 4u, y.y);
+      }
+      if (f & EF_PACK) {
+        if (f & EF_PACK_AFF)
+          pv = __builtin_elementwise_fma(pv, f2{e.pack_a[o], e.pack_a[o + 1]}, f2{e.pack_b[o], e.pack_b[o + 1]});
+        pvs[j] = pv.x;
+        pvs[j + 1] = pv.y;
+      }
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < NACC; ++j) {
     const int o = o0 + j;
@@ -367,6 +457,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
         }
       }
     }
+  }
   }
   if constexpr (FULL) {
     if (f & EF_PACK) {
@@ -498,6 +589,15 @@ __device__ __forceinline__ void load_wblock(const uint32_t* __restrict__ src, WS
   }
 }
 
+#ifndef BNN_OUT4_MINW  // waves per SIMD the conv2-type kernel on a 128-channel P-only field is allocated for
+#define BNN_OUT4_MINW 5
+#endif
+#ifndef BNN_RES_UNROLL  // conv2-type single-chunk kernels: passes per iteration of the (otherwise rolled) pass loop
+#define BNN_RES_UNROLL 1
+#endif
+#ifndef BNN_CHAINS  // v_bcnt accumulation chains per output channel in stream_weights (1 or 2)
+#define BNN_CHAINS 2
+#endif
 #ifndef BNN_WSTREAM_BLOCK  // preferred words per block of the scalar weight stream
 #define BNN_WSTREAM_BLOCK 32
 #endif
@@ -514,10 +614,11 @@ constexpr int pick_wblock(int total) {
 // >= 6 waves per SIMD; 32-word blocks (two s_load_dwordx16) need 3.
 // NN: `acc` counts AGREEMENTS, popcount(w & p) (one 4-byte VOP2 v_and + v_bcnt), instead of
 // disagreements; the caller turns them into the dot product with dot = 2*agree - nonzeros.
-template <int NW, int NACC, bool NN = false>
+// USEED: the counts start from the wave-uniform `useed` (single-chunk kernels) instead of from acc[].
+template <int NW, int NACC, bool NN = false, bool USEED = false>
 __device__ __forceinline__ void stream_weights(const uint32_t* __restrict__ wrun,
                                                const uint32_t (&pr)[NW], const uint32_t (&mr)[NW],
-                                               int (&acc)[NACC]) {
+                                               int (&acc)[NACC], [[maybe_unused]] int useed = 0) {
   constexpr int WB = pick_wblock(NACC * NW);
   constexpr int NB = NACC * NW / WB;
   static_assert((NACC * NW) % WB == 0, "weight run must be a whole number of blocks");
@@ -539,12 +640,20 @@ __device__ __forceinline__ void stream_weights(const uint32_t* __restrict__ wrun
       constexpr int f = b * WB + e;
       constexpr int j = f / NW, i = f % NW;
       const uint32_t d = NN ? (cur.v[e] & pr[i]) : disagree(cur.v[e], mr[i], pr[i]);
-      // the first word of each chain uses the inline-constant form (v_bcnt d, 0): no v_mov
-      if constexpr (i == 0) t0 = __builtin_popcount(d);
+#if BNN_CHAINS == 1
+      // one chain per channel, continued from the running count: no t0 + t1 add per channel and chunk
+      if constexpr (USEED && i == 0) acc[j] = popc_acc_s(d, useed);
+      else acc[j] = popc_acc(d, acc[j]);
+      (void)t0; (void)t1;
+#else
+      // the even chain continues from the running count (acc[j]: 0, the count seed, or the previous chunks' sum); the
+      // first word of the odd chain uses the inline-constant form (v_bcnt d, 0)
+      if constexpr (i == 0) t0 = USEED ? popc_acc_s(d, useed) : popc_acc(d, acc[j]);
       else if constexpr (i == 1) t1 = __builtin_popcount(d);
       else if constexpr (i & 1) t1 = popc_acc(d, t1);
       else t0 = popc_acc(d, t0);
-      if constexpr (i == NW - 1) acc[j] += t0 + (NW > 1 ? t1 : 0);
+      if constexpr (i == NW - 1) acc[j] = t0 + (NW > 1 ? t1 : 0);
+#endif
     });
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (b + 1 < NB) cur = nxt;
@@ -617,6 +726,7 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
     const uint32_t* __restrict__ Z, BNN_EPI_PARAMS, const Geo g) {
   static_assert(!(WZ && (NN || GSPLIT)), "the zero-weight variant is two-plane, unsplit");
   static_assert(OBW == 1 || (!MULTI && !GSPLIT), "several blocks per wave: single-chunk, unsplit kernels only");
+  static_assert(!(WZ && EP == EP_MIDT), "the threshold epilogue takes the non-zero count per lane, not per channel");
   constexpr int T = KH * KW;
   constexpr int NW = T * CWC;  // words per (o, chunk)
   constexpr int NACC = kOCB / PASSES;
@@ -659,8 +769,9 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       if ((ob + 1) * kOCB <= g.O) prefetch_residual<kOCB, EP, true>(g, px, ob * kOCB, epi, resq);
       else prefetch_residual<kOCB, EP>(g, px, ob * kOCB, epi, resq);
     }
-#pragma unroll 1
-    for (int ps = GSPLIT ? part : 0; ps < (GSPLIT ? part + 1 : PASSES); ++ps) {
+    // One pass = NACC channels of the block.  `qc` (RES_ALL kernels): which NACC-slice of the shortcut queue is this
+    // pass's (the queue moves up after every BNN_RES_UNROLL passes: registers cannot be indexed by the pass number).
+    auto one_pass = [&](int ps, auto qc) __attribute__((always_inline)) {
       int acc[NACC];
       [[maybe_unused]] int nzacc[NACC];
       float resv[NACC];
@@ -671,19 +782,19 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       // wave-uniform; the same for every pass of a block: a block either builds its sign words by shift-in (straight-
       // line epilogue) or by OR-ing bits into place (guarded epilogue), never both
       const bool fullb = (ob + 1) * kOCB <= g.O;
-      if constexpr (RES_ALL) {  // this pass's values are the head of the queue; the rest moves up (rolled loop)
+      if constexpr (RES_ALL) {
 #pragma unroll
-        for (int j = 0; j < NACC; ++j) resv[j] = resq[j];
-#pragma unroll
-        for (int j = 0; j + NACC < kOCB; ++j) resq[j] = resq[j + NACC];
+        for (int j = 0; j < NACC; ++j) resv[j] = resq[decltype(qc)::value * NACC + j];
       }
       if constexpr (RES_EARLY) {
         if (fullb) prefetch_residual<NACC, EP, true>(g, px, ob * kOCB + ps * NACC, epi, resv);
         else prefetch_residual<NACC, EP>(g, px, ob * kOCB + ps * NACC, epi, resv);
       }
+      // compile-time profiles with a float epilogue: the counts are kept as the bit pattern of 2^23 + count (epilogue())
+      constexpr bool SEEDED = !WZ && NACC % 2 == 0 && EP != EP_RUNTIME && EP != EP_MIDT;
 #pragma unroll
       for (int j = 0; j < NACC; ++j) {
-        acc[j] = 0;
+        acc[j] = SEEDED ? (int)kCountSeed : 0;
         if constexpr (WZ) nzacc[j] = 0;
       }
       if constexpr (MULTI) {
@@ -697,17 +808,49 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       } else {
         const size_t woff = (size_t)ps * (NACC * NW);
         if constexpr (WZ) stream_weights_wz<NW, NACC>(wblk + woff, zblk + woff, pr, mr, acc, nzacc);
-        else stream_weights<NW, NACC, NN>(wblk + woff, pr, mr, acc);
+        else stream_weights<NW, NACC, NN, true>(wblk + woff, pr, mr, acc, SEEDED ? (int)kCountSeed : 0);
       }
       if constexpr (!RES_EARLY && !RES_ALL) {
         if (fullb) prefetch_residual<NACC, EP, true>(g, px, ob * kOCB + ps * NACC, epi, resv);
         else prefetch_residual<NACC, EP>(g, px, ob * kOCB + ps * NACC, epi, resv);
       }
+      [[maybe_unused]] int negnz = NN ? -nz : nz;  // EP_MIDT (see its epilogue): dot = -+2*acc + negnz
+#if defined(__HIP_DEVICE_COMPILE__)
+      if constexpr (EP == EP_MIDT) asm("" : "+v"(negnz));
+#endif
+      if constexpr (SEEDED) {
+        if (fullb) {
+          epilogue<NACC, EP, true, true>(g, px, ob * kOCB + ps * NACC, acc, resv, epi, pbits, mbits, 0,
+                                         NN ? 2.0f : -2.0f, NN ? -(float)nz : (float)nz);
+          return;
+        }
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) acc[j] -= (int)kCountSeed;
+      }
 #pragma unroll
       for (int j = 0; j < NACC; ++j)  // dot = non-zeros - 2*disagreements = 2*agreements - non-zeros
-        acc[j] = WZ ? nzacc[j] - 2 * acc[j] : NN ? 2 * acc[j] - nz : nz - 2 * acc[j];
-      if (fullb) epilogue<NACC, EP, true>(g, px, ob * kOCB + ps * NACC, acc, resv, epi, pbits, mbits);
-      else epilogue<NACC, EP>(g, px, ob * kOCB + ps * NACC, acc, resv, epi, pbits, mbits);
+        acc[j] = WZ                 ? nzacc[j] - 2 * acc[j]
+                 : EP == EP_MIDT    ? (NN ? 2 * acc[j] : -2 * acc[j])
+                 : NN               ? 2 * acc[j] - nz
+                                    : nz - 2 * acc[j];
+      if (fullb) epilogue<NACC, EP, true>(g, px, ob * kOCB + ps * NACC, acc, resv, epi, pbits, mbits, negnz);
+      else epilogue<NACC, EP>(g, px, ob * kOCB + ps * NACC, acc, resv, epi, pbits, mbits, negnz);
+    };
+    if constexpr (RES_ALL) {
+      constexpr int UNR = BNN_RES_UNROLL;  // passes per iteration of the rolled loop
+      static_assert(PASSES % UNR == 0, "whole iterations");
+#pragma unroll 1
+      for (int pg = 0; pg < PASSES / UNR; ++pg) {
+        static_for<UNR>([&](auto uc) __attribute__((always_inline)) { one_pass(pg * UNR + decltype(uc)::value, uc); });
+        if constexpr (UNR < PASSES) {  // the rest of the queue moves up
+#pragma unroll
+          for (int j = 0; j + UNR * NACC < kOCB; ++j) resq[j] = resq[j + UNR * NACC];
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int ps = GSPLIT ? part : 0; ps < (GSPLIT ? part + 1 : PASSES); ++ps)
+        one_pass(ps, std::integral_constant<int, 0>{});
     }
   }
   const bool rev = (ob + 1) * kOCB <= g.O;  // == fullb of every pass of this block
@@ -952,7 +1095,9 @@ static void launch_sgpr_t(const ConvP& p, const Geo& g, bool split_ok, hipStream
       }
     }
 #endif
-    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, P1, false, false, NN>), grid,
+    // conv2-type epilogue on a 128-channel P-only field: 97 VGPRs uncapped, one over the budget of 5 waves per SIMD
+    constexpr int MW1 = (NN && CWC == 4 && EP == EP_OUT) ? BNN_OUT4_MINW : 1;
+    hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MW1, P1, false, false, NN>), grid,
                        dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
     return;
   }
@@ -1007,7 +1152,8 @@ static void launch_sgpr(const ConvP& p, int flags, hipStream_t s) {
   const Geo g = make_geo(p);
   const bool nn = (flags & BNN_HIP_FLAG_ACT_NONNEG) != 0;
   const bool so = (flags & BNN_HIP_FLAG_THROUGHPUT) == 0;
-  const bool fused = (g.flags & (EF_BN | EF_RES | EF_RELU | EF_PRELU | EF_PACK)) != 0;
+  // (the int32 "raw" output is a run-time switch: EP_PLAIN keeps its counts in float form and cannot serve it)
+  const bool fused = (g.flags & (EF_BN | EF_RES | EF_RELU | EF_PRELU | EF_PACK | EF_RAW)) != 0;
   if (flags & BNN_HIP_FLAG_WEIGHT_ZEROS) {
     if (fused) launch_sgpr_wz<KH, KW, CWC, EP_RUNTIME>(p, g, s);
     else launch_sgpr_wz<KH, KW, CWC, EP_PLAIN>(p, g, s);
@@ -1017,6 +1163,7 @@ static void launch_sgpr(const ConvP& p, int flags, hipStream_t s) {
     if (g.flags == kFlagsMid && p.thr) return launch_sgpr_e<KH, KW, CWC, EP_MIDT>(p, g, nn, so, s);
     if (g.flags == kFlagsMid) return launch_sgpr_e<KH, KW, CWC, EP_MID>(p, g, nn, so, s);
     if (g.flags == kFlagsOut) return launch_sgpr_e<KH, KW, CWC, EP_OUT>(p, g, nn, so, s);
+    if (g.flags == kFlagsOutP) return launch_sgpr_e<KH, KW, CWC, EP_OUTP>(p, g, nn, so, s);
     if (g.flags == kFlagsLast) return launch_sgpr_e<KH, KW, CWC, EP_LAST>(p, g, nn, so, s);
     if (g.flags == kFlagsHb) return launch_sgpr_e<KH, KW, CWC, EP_HB>(p, g, nn, so, s);
     if (g.flags == kFlagsHb3) return launch_sgpr_e<KH, KW, CWC, EP_HB3>(p, g, nn, so, s);

@@ -556,3 +556,23 @@ def test_fused_executor_uses_the_head_kernel_and_no_library_gemm():
     assert native.launch_count() - before == 1 + 16 + 3 + 3 + 1
     with torch.no_grad():
         assert torch.allclose(y, net(x), rtol=1e-3, atol=1e-3 * float(y.abs().max()))
+
+
+def test_dead_fp32_outputs_are_not_written_and_nothing_changes():
+    """The last conv of layer1/2/3 feeds a block that reads sign planes only (convs AND the AvgPool -> binary 1x1
+    shortcut): its fp32 tensor is skipped (compiled profile BN + residual + ReLU -> planes).  Same logits, bit for bit,
+    for the ResNet-18 / 34 block pattern, odd spatial sizes (ceil-mode pooling) and a ragged batch."""
+    for net, shape in ((_r18(), (4, 3, 96, 96)), (_r18(), (3, 3, 75, 61))):
+        x = dev(gen.normal(47, shape))
+        a, b = FusedResNet(net), FusedResNet(net, skip_dead_f32=False)
+        assert torch.equal(a(x), b(x))
+    # the epilogue itself, against the same call with the fp32 tensor switched on
+    act = hipops.pack_act(dev(gen.activation("relu", 5, (2, 64, 20, 20)))); act.nonneg = True
+    pw = hipops.pack_weight(dev(gen.conv_weight("kaiming", 6, (64, 64, 3, 3))))
+    res = dev(gen.normal(7, (2, 64, 20, 20)))
+    kw = dict(bn_scale=dev(gen.normal(8, (64,))) * 0.2 + 1.0, bn_shift=dev(gen.normal(9, (64,))) * 0.3, relu=True,
+              residual=res, stride=1, padding=1, out_packed=True)
+    y, full = hipops.bconv2d_fused(act, pw, out_f32=True, **kw)
+    none, only = hipops.bconv2d_fused(act, pw, out_f32=False, **kw)
+    assert none is None and torch.equal(only.P, full.P) and torch.equal(only.M, full.M) and only.nonneg
+    assert torch.equal(only.P, hipops.pack_act(y).P)

@@ -8,8 +8,8 @@ import numpy as np, torch
 from bnn_amd import hipops
 from tests.golden import gen
 dev = torch.device("cuda:0")
-def t(fn, n=20):
-    for _ in range(3): fn()
+def t(fn, n=100):
+    for _ in range(30): fn()  # also keeps the clocks up (the first timed region after idle runs ~15 % slow)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
     for _ in range(n): fn()
