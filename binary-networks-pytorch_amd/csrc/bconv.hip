@@ -37,6 +37,9 @@ struct Geo {
   int c_off, c_tot;  // fp32 output / residual are [N,c_tot,Ho,Wo]; this conv owns channels c_off..c_off+O
   int tiles;     // 64-pixel tiles of the output
   int tiles_per_xcd;  // ceil(tiles / 8)
+  // index arithmetic of the tiled kernels: q / (Ho*Wo) and r / Wo as multiply-high + shift (s < 0: divisor 1)
+  uint32_t m_hw, m_wo;
+  int s_hw, s_wo;
 };
 
 enum : int {
@@ -182,17 +185,56 @@ __device__ __forceinline__ uint32_t shift_in(uint32_t word, bool bit) {
 struct Pix {
   int q, n, r, oy, ox;
   bool live;
+  // per-lane parts of the tensor offsets (elements / uint64 words), computed once:
+  unsigned out_base;  // n*c_tot*Ho*Wo + r              fp32 output and residual, channel 0
+  unsigned pk_base;   // n*(cw32_out/2)*Ho*Wo + r       packed output, group 0
+  unsigned in_base;   // n*(cw32/2)*H*W                 packed input, group 0, pixel 0
 };
 
+// FAST (the tiled kernels; launch_bconv() checks the ranges): 32-bit integer multiplies and divides are the slow
+// instructions of the vector ALU (v_mul_lo/hi_u32 issue at quarter rate; a division by a run-time value is ~20
+// instructions, four of them such multiplies).  With every factor below 2^24 the products are v_mul_u32_u24 (full
+// rate) and the two divisions one v_mul_hi_u32 + shift each (Geo::m_*, s_*): ~60 issue slots per wave less.
+// (unsigned: a v_mul_u32_u24 ignores its operands' high bits, so nested products need no re-extension; the signed
+// form would put a shift pair between two multiplies)
+template <bool FAST>
+__device__ __forceinline__ int imul(int a, int b) {
+  if constexpr (FAST) {
+    int r = (int)__umul24((unsigned)a, (unsigned)b);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // opaque: a consumer that only needs the low 24 bits (another u24 multiply) would otherwise strip this one's
+    // operand masks, and what is left is selected as the quarter-rate v_mul_lo_u32 again
+    asm("" : "+v"(r));
+#endif
+    return r;
+  } else {
+    return a * b;
+  }
+}
+__device__ __forceinline__ uint32_t fast_div(uint32_t x, uint32_t m, int sh) {
+  return sh < 0 ? x : (__umulhi(x, m) >> sh);
+}
+
+template <bool FAST = false>
 __device__ __forceinline__ Pix decode_pixel(const Geo& g, int q) {
   Pix p;
   p.live = q < g.npix;
   p.q = p.live ? q : g.npix - 1;
   const int hw = g.Ho * g.Wo;
-  p.n = p.q / hw;
-  p.r = p.q - p.n * hw;
-  p.oy = p.r / g.Wo;
-  p.ox = p.r - p.oy * g.Wo;
+  if constexpr (FAST) {
+    p.n = (int)fast_div((uint32_t)p.q, g.m_hw, g.s_hw);
+    p.r = p.q - imul<true>(p.n, hw);
+    p.oy = (int)fast_div((uint32_t)p.r, g.m_wo, g.s_wo);
+    p.ox = p.r - imul<true>(p.oy, g.Wo);
+  } else {
+    p.n = p.q / hw;
+    p.r = p.q - p.n * hw;
+    p.oy = p.r / g.Wo;
+    p.ox = p.r - p.oy * g.Wo;
+  }
+  p.out_base = (unsigned)(imul<FAST>(imul<FAST>(p.n, g.c_tot), hw) + p.r);
+  p.pk_base = (unsigned)(imul<FAST>(imul<FAST>(p.n, g.cw32_out >> 1), hw) + p.r);
+  p.in_base = (unsigned)imul<FAST>(imul<FAST>(p.n, g.cw32 >> 1), g.H * g.Wd);
   return p;
 }
 
@@ -200,7 +242,7 @@ __device__ __forceinline__ Pix decode_pixel(const Geo& g, int q) {
 // into the zero padding yield P = M = 0 (padding is applied after sign(): conv.py:91-92).
 // NN ("non-negative"): the caller guarantees the M plane is all zero (activations out of a ReLU are
 // {0,+1}); only P is loaded and `mr` stays dead, which halves the field's registers and loads.
-template <int KH, int KW, int CWC, bool NN = false>
+template <int KH, int KW, int CWC, bool NN = false, bool FAST = false>
 __device__ __forceinline__ void load_field(const Geo& g, const Pix& px, int ch,
                                            const uint32_t* __restrict__ P,
                                            const uint32_t* __restrict__ M,
@@ -209,15 +251,16 @@ __device__ __forceinline__ void load_field(const Geo& g, const Pix& px, int ch,
   // Planes are stored channel-group planar, [n][group of 64 channels][y][x] uint64: the 64
   // lanes of a wave (consecutive pixels) read 512 contiguous bytes per load whatever C is.
   constexpr int GC = CWC / 2;  // 64-channel groups per chunk
-  const int cw64 = g.cw32 >> 1;
   const int plane = g.H * g.Wd;
-  const unsigned img = (unsigned)((px.n * cw64 + ch * GC) * plane);  // uint64 words; host keeps planes < 2^29 words
+  const unsigned img = px.in_base + (unsigned)(ch * GC * plane);  // uint64 words; host keeps planes < 2^29 words
+  const int iy0 = imul<FAST>(px.oy, g.sh) - g.ph, ix0 = imul<FAST>(px.ox, g.sw) - g.pw;
+  const int row0 = imul<FAST>(px.oy, g.sh * g.Wd) - g.ph * g.Wd;  // iy0 * W with non-negative factors only
 #pragma unroll
   for (int t = 0; t < KH * KW; ++t) {
-    const int iy = px.oy * g.sh - g.ph + t / KW;
-    const int ix = px.ox * g.sw - g.pw + t % KW;
+    const int iy = iy0 + t / KW;
+    const int ix = ix0 + t % KW;
     const bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.Wd;
-    const int pix = ok ? iy * g.Wd + ix : 0;
+    const int pix = ok ? row0 + (t / KW) * g.Wd + ix : 0;
 #pragma unroll
     for (int gi = 0; gi < GC; ++gi) {
       const unsigned boff = (img + (unsigned)(gi * plane + pix)) * 8u;
@@ -321,7 +364,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
     }
   };
   const int hw = g.Ho * g.Wo;
-  const unsigned lane_off = (unsigned)(px.n * g.c_tot * hw + px.r) * 4u;  // BYTES; host keeps N*c_tot*hw < 2^30
+  const unsigned lane_off = px.out_base * 4u;  // BYTES; host keeps N*c_tot*hw < 2^30
   const int f = ep_flags(EP, g.flags);
   const bool full = FULL || o0 + NACC <= g.O;
   const bool live = FULL || px.live;
@@ -489,7 +532,7 @@ __device__ __forceinline__ void prefetch_residual(const Geo& g, const Pix& px, i
     return;
   }
   const int hw = g.Ho * g.Wo;
-  const unsigned lane_off = (unsigned)(px.n * g.c_tot * hw + px.r) * 4u;  // bytes
+  const unsigned lane_off = px.out_base * 4u;  // bytes
 #pragma unroll
   for (int j = 0; j < NACC; ++j)
     // lanes past the last pixel load too (they were clamped to it): they must compute the same sign bits as the
@@ -509,7 +552,7 @@ __device__ __forceinline__ void store_packed(const Geo& g, const Pix& px, int ob
     mbits = __builtin_bitreverse32(mbits);
   }
   const int hw = g.Ho * g.Wo;
-  const unsigned w = (unsigned)((((px.n * (g.cw32_out >> 1) + (ob >> 1)) * hw + px.r) << 1) + (ob & 1)) * 4u;  // bytes
+  const unsigned w = (((px.pk_base + (unsigned)((ob >> 1) * hw)) << 1) + (unsigned)(ob & 1)) * 4u;  // bytes
   st_off(e.outP, w, pbits);
   st_off(e.outM, w, mbits);
 }
@@ -527,7 +570,7 @@ __device__ __forceinline__ void store_packed_part(const Geo& g, const Pix& px, i
     mbits = (__builtin_bitreverse32(mbits) >> (32 - 32 / PARTS)) << ((32 / PARTS) * part);
   }
   const int hw = g.Ho * g.Wo;
-  const size_t w = ((((size_t)px.n * (g.cw32_out >> 1) + (ob >> 1)) * hw + px.r) << 1) + (ob & 1);
+  const size_t w = (((size_t)px.pk_base + (size_t)(ob >> 1) * hw) << 1) + (ob & 1);
   constexpr int BITS = 32 / PARTS;
   if constexpr (PARTS == 2) {
     reinterpret_cast<uint16_t*>(e.outP)[w * 2 + part] = (uint16_t)(pbits >> (BITS * part));
@@ -742,12 +785,12 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
   const int part = GSPLIT ? obp - ob0 * PASSES : 0;
   const int tile = xcd * g.tiles_per_xcd + (slot - obp * g.tiles_per_xcd);
   if (tile >= g.tiles) return;
-  const Pix px = decode_pixel(g, tile * kWave + threadIdx.x);
+  const Pix px = decode_pixel<true>(g, tile * kWave + threadIdx.x);
   uint32_t pr[NW], mr[NW];
   int nz = 0;
   if constexpr (!MULTI) {
     if (ob0 * kOCB < g.O) {
-      load_field<KH, KW, CWC, NN>(g, px, 0, P, M, pr, mr);
+      load_field<KH, KW, CWC, NN, true>(g, px, 0, P, M, pr, mr);
       nz = count_nonzero<NW, NN>(pr, mr, 0);
     }
   }
@@ -771,7 +814,7 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
     }
     // One pass = NACC channels of the block.  `qc` (RES_ALL kernels): which NACC-slice of the shortcut queue is this
     // pass's (the queue moves up after every BNN_RES_UNROLL passes: registers cannot be indexed by the pass number).
-    auto one_pass = [&](int ps, auto qc) __attribute__((always_inline)) {
+    auto one_pass = [&, px](int ps, auto qc) __attribute__((always_inline)) {
       int acc[NACC];
       [[maybe_unused]] int nzacc[NACC];
       float resv[NACC];
@@ -799,7 +842,7 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       }
       if constexpr (MULTI) {
         for (int ch = 0; ch < g.nchunk; ++ch) {
-          load_field<KH, KW, CWC, NN>(g, px, ch, P, M, pr, mr);
+          load_field<KH, KW, CWC, NN, true>(g, px, ch, P, M, pr, mr);
           if (!WZ && (GSPLIT || ps == 0)) nz = count_nonzero<NW, NN>(pr, mr, nz);
           const size_t woff = ((size_t)ch * kOCB + ps * NACC) * NW;
           if constexpr (WZ) stream_weights_wz<NW, NACC>(wblk + woff, zblk + woff, pr, mr, acc, nzacc);
@@ -1012,8 +1055,30 @@ __global__ __launch_bounds__(64) void bconv_generic_kernel(
 // ---------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------
+// q / d for 0 <= q < 2^31 as (q * m) >> (32 + s)  (Granlund & Montgomery: m = ceil(2^(31+l) / d), l = ceil(log2 d),
+// s = l - 1; m < 2^32 for d >= 2); d == 1 is flagged with s = -1.
+static void div_magic(uint32_t d, uint32_t& m, int& s) {
+  if (d <= 1) { m = 0; s = -1; return; }
+  int l = 0;
+  while ((1ull << l) < d) ++l;
+  m = (uint32_t)(((1ull << (31 + l)) + d - 1) / d);
+  s = l - 1;
+}
+
+// The tiled kernels multiply indices with v_mul_u32_u24 / v_mul_i32_i24 (decode_pixel<true>): every factor must stay
+// below 2^23.  Anything larger (4096 x 2048 images, batches of millions) takes the shape-generic kernel.
+static bool small_indices(const ConvP& p) {
+  const long long lim = 1ll << 23;
+  const long long c_tot = p.c_tot > 0 ? p.c_tot : p.O;
+  return (long long)p.N * c_tot < lim && (long long)p.N * ((p.O + 63) / 64) < lim &&
+         (long long)p.N * (p.cw32 >> 1) < lim && (long long)p.Ho * p.Wo < lim &&
+         (long long)(p.H + p.ph + 2) * (p.Wd + p.pw + 2) < lim && (long long)p.sh * p.Wd < lim && p.sw < 4096;
+}
+
 static Geo make_geo(const ConvP& p) {
   Geo g;
+  div_magic((uint32_t)(p.Ho * p.Wo), g.m_hw, g.s_hw);
+  div_magic((uint32_t)p.Wo, g.m_wo, g.s_wo);
   g.N = p.N; g.H = p.H; g.Wd = p.Wd; g.Ho = p.Ho; g.Wo = p.Wo; g.O = p.O;
   g.KH = p.KH; g.KW = p.KW; g.sh = p.sh; g.sw = p.sw; g.ph = p.ph; g.pw = p.pw;
   g.dh = p.dh; g.dw = p.dw; g.cw32 = p.cw32; g.cwc = p.cwc; g.nchunk = p.nchunk;
@@ -1212,7 +1277,7 @@ static bool prefer_lds(const ConvP&, int flags) { return (flags & BNN_HIP_FLAG_W
 
 int launch_bconv(const ConvP& p, int flags, hipStream_t s) {
   const bool wz = (flags & BNN_HIP_FLAG_WEIGHT_ZEROS) != 0;
-  const bool generic = (flags & BNN_HIP_FLAG_FORCE_GENERIC) || p.dh != 1 || p.dw != 1;
+  const bool generic = (flags & BNN_HIP_FLAG_FORCE_GENERIC) || p.dh != 1 || p.dw != 1 || !small_indices(p);
   bool done = false;
   if (!generic) {
     const bool lds = prefer_lds(p, flags);
