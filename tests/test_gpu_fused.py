@@ -576,3 +576,25 @@ def test_dead_fp32_outputs_are_not_written_and_nothing_changes():
     none, only = hipops.bconv2d_fused(act, pw, out_f32=False, **kw)
     assert none is None and torch.equal(only.P, full.P) and torch.equal(only.M, full.M) and only.nonneg
     assert torch.equal(only.P, hipops.pack_act(y).P)
+
+
+def test_images_beyond_the_24_bit_index_range_take_the_generic_kernel():
+    """The tiled kernels multiply indices with 24-bit multiplies; launch_bconv() sends anything with an index factor
+    of 2^23 or more (here Ho*Wo = 4100^2 > 2^24, second image: n*Ho*Wo needs the full multiply) to the shape-generic
+    kernel.  Size-independent check: a 3x3 convolution is local, so strips of the big result must equal the result
+    of the same layer on the strips alone (which the tiled kernels compute)."""
+    H = W = 4100
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(2, 64, H, W, device="cuda", generator=g)
+    pw = hipops.pack_weight(dev(gen.conv_weight("kaiming", 3, (16, 64, 3, 3))))   # N*O*Ho*Wo stays below 2^30
+    kw = dict(bn_scale=dev(gen.normal(4, (16,))) * 0.2 + 1.0, bn_shift=dev(gen.normal(5, (16,))) * 2.0, relu=True,
+              stride=1, padding=1, out_f32=False, out_packed=True)
+    _, big = hipops.bconv2d_fused(hipops.pack_act(x), pw, **kw)
+    for n, rows in ((0, slice(0, 40)), (1, slice(H - 40, H)), (1, slice(2000, 2040))):
+        strip = x[n:n + 1, :, rows].contiguous()
+        _, small = hipops.bconv2d_fused(hipops.pack_act(strip), pw, **kw)
+        r0 = rows.start
+        lo, hi = (0 if r0 == 0 else 1), (40 if rows.stop == H else 39)       # rows whose 3x3 window lies inside the strip
+        assert torch.equal(big.P[n:n + 1, :, r0 + lo:r0 + hi], small.P[:, :, lo:hi])
+        assert torch.equal(big.M[n:n + 1, :, r0 + lo:r0 + hi], small.M[:, :, lo:hi])
+    assert bool(big.P.any()) and not bool(big.M.any())
