@@ -461,6 +461,12 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
         pvs[j] = pv.x;
         pvs[j + 1] = pv.y;
       }
+#if BNN_EPI_GROUP > 0
+      // 32 channels in one pass (multi-chunk kernels): without a fence the scheduler requests the constants of all
+      // of them up front — ~100 SGPRs next to the weight stream's 64 — and spills them to VGPR lanes
+      if constexpr (NACC > BNN_EPI_GROUP)
+        if ((j + 2) % BNN_EPI_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
     }
   } else {
 #pragma unroll
@@ -632,6 +638,9 @@ __device__ __forceinline__ void load_wblock(const uint32_t* __restrict__ src, WS
   }
 }
 
+#ifndef BNN_EPI_GROUP  // channels of the straight-line epilogue between two scheduling fences (0 = none)
+#define BNN_EPI_GROUP 8
+#endif
 #ifndef BNN_OUT4_MINW  // waves per SIMD the conv2-type kernel on a 128-channel P-only field is allocated for
 #define BNN_OUT4_MINW 5
 #endif
@@ -853,31 +862,49 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
         if constexpr (WZ) stream_weights_wz<NW, NACC>(wblk + woff, zblk + woff, pr, mr, acc, nzacc);
         else stream_weights<NW, NACC, NN, true>(wblk + woff, pr, mr, acc, SEEDED ? (int)kCountSeed : 0);
       }
-      if constexpr (!RES_EARLY && !RES_ALL) {
-        if (fullb) prefetch_residual<NACC, EP, true>(g, px, ob * kOCB + ps * NACC, epi, resv);
-        else prefetch_residual<NACC, EP>(g, px, ob * kOCB + ps * NACC, epi, resv);
-      }
+      // ONE branch on `fullb` around everything that differs: with the late shortcut fetch and the epilogue under two
+      // separate ifs, the guarded side's 32 per-channel predicates are computed at the common dominator — in front of
+      // the first if, on every wave — and spilled to VGPR lanes (215 v_readlane + 123 v_writelane in the 512->512 kernel).
+      constexpr bool RES_LATE_FETCH = !RES_EARLY && !RES_ALL;
+      const int o0 = ob * kOCB + ps * NACC;
       [[maybe_unused]] int negnz = NN ? -nz : nz;  // EP_MIDT (see its epilogue): dot = -+2*acc + negnz
 #if defined(__HIP_DEVICE_COMPILE__)
       if constexpr (EP == EP_MIDT) asm("" : "+v"(negnz));
 #endif
-      if constexpr (SEEDED) {
-        if (fullb) {
-          epilogue<NACC, EP, true, true>(g, px, ob * kOCB + ps * NACC, acc, resv, epi, pbits, mbits, 0,
-                                         NN ? 2.0f : -2.0f, NN ? -(float)nz : (float)nz);
-          return;
+      auto to_dot = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NACC; ++j)  // dot = non-zeros - 2*disagreements = 2*agreements - non-zeros
+          acc[j] = WZ                 ? nzacc[j] - 2 * acc[j]
+                   : EP == EP_MIDT    ? (NN ? 2 * acc[j] : -2 * acc[j])
+                   : NN               ? 2 * acc[j] - nz
+                                      : nz - 2 * acc[j];
+      };
+      if constexpr (EP == EP_RUNTIME) {  // (the run-time profile under its 128-register cap spills more that way: as before)
+        if constexpr (RES_LATE_FETCH) {
+          if (fullb) prefetch_residual<NACC, EP, true>(g, px, o0, epi, resv);
+          else prefetch_residual<NACC, EP>(g, px, o0, epi, resv);
         }
+        to_dot();
+        if (fullb) epilogue<NACC, EP, true>(g, px, o0, acc, resv, epi, pbits, mbits, negnz);
+        else epilogue<NACC, EP>(g, px, o0, acc, resv, epi, pbits, mbits, negnz);
+      } else if (fullb) {
+        if constexpr (RES_LATE_FETCH) prefetch_residual<NACC, EP, true>(g, px, o0, epi, resv);
+        if constexpr (SEEDED) {
+          epilogue<NACC, EP, true, true>(g, px, o0, acc, resv, epi, pbits, mbits, 0, NN ? 2.0f : -2.0f,
+                                         NN ? -(float)nz : (float)nz);
+        } else {
+          to_dot();
+          epilogue<NACC, EP, true>(g, px, o0, acc, resv, epi, pbits, mbits, negnz);
+        }
+      } else {
+        if constexpr (RES_LATE_FETCH) prefetch_residual<NACC, EP>(g, px, o0, epi, resv);
+        if constexpr (SEEDED) {
 #pragma unroll
-        for (int j = 0; j < NACC; ++j) acc[j] -= (int)kCountSeed;
+          for (int j = 0; j < NACC; ++j) acc[j] -= (int)kCountSeed;
+        }
+        to_dot();
+        epilogue<NACC, EP>(g, px, o0, acc, resv, epi, pbits, mbits, negnz);
       }
-#pragma unroll
-      for (int j = 0; j < NACC; ++j)  // dot = non-zeros - 2*disagreements = 2*agreements - non-zeros
-        acc[j] = WZ                 ? nzacc[j] - 2 * acc[j]
-                 : EP == EP_MIDT    ? (NN ? 2 * acc[j] : -2 * acc[j])
-                 : NN               ? 2 * acc[j] - nz
-                                    : nz - 2 * acc[j];
-      if (fullb) epilogue<NACC, EP, true>(g, px, ob * kOCB + ps * NACC, acc, resv, epi, pbits, mbits, negnz);
-      else epilogue<NACC, EP>(g, px, ob * kOCB + ps * NACC, acc, resv, epi, pbits, mbits, negnz);
     };
     if constexpr (RES_ALL) {
       constexpr int UNR = BNN_RES_UNROLL;  // passes per iteration of the rolled loop
