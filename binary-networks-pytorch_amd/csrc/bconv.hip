@@ -461,12 +461,6 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
         pvs[j] = pv.x;
         pvs[j + 1] = pv.y;
       }
-#if BNN_EPI_GROUP > 0
-      // 32 channels in one pass (multi-chunk kernels): without a fence the scheduler requests the constants of all
-      // of them up front — ~100 SGPRs next to the weight stream's 64 — and spills them to VGPR lanes
-      if constexpr (NACC > BNN_EPI_GROUP)
-        if ((j + 2) % BNN_EPI_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
-#endif
     }
   } else {
 #pragma unroll
@@ -638,17 +632,11 @@ __device__ __forceinline__ void load_wblock(const uint32_t* __restrict__ src, WS
   }
 }
 
-#ifndef BNN_EPI_GROUP  // channels of the straight-line epilogue between two scheduling fences (0 = none)
-#define BNN_EPI_GROUP 8
-#endif
 #ifndef BNN_OUT4_MINW  // waves per SIMD the conv2-type kernel on a 128-channel P-only field is allocated for
 #define BNN_OUT4_MINW 5
 #endif
 #ifndef BNN_RES_UNROLL  // conv2-type single-chunk kernels: passes per iteration of the (otherwise rolled) pass loop
 #define BNN_RES_UNROLL 1
-#endif
-#ifndef BNN_CHAINS  // v_bcnt accumulation chains per output channel in stream_weights (1 or 2)
-#define BNN_CHAINS 2
 #endif
 #ifndef BNN_WSTREAM_BLOCK  // preferred words per block of the scalar weight stream
 #define BNN_WSTREAM_BLOCK 32
@@ -692,12 +680,6 @@ __device__ __forceinline__ void stream_weights(const uint32_t* __restrict__ wrun
       constexpr int f = b * WB + e;
       constexpr int j = f / NW, i = f % NW;
       const uint32_t d = NN ? (cur.v[e] & pr[i]) : disagree(cur.v[e], mr[i], pr[i]);
-#if BNN_CHAINS == 1
-      // one chain per channel, continued from the running count: no t0 + t1 add per channel and chunk
-      if constexpr (USEED && i == 0) acc[j] = popc_acc_s(d, useed);
-      else acc[j] = popc_acc(d, acc[j]);
-      (void)t0; (void)t1;
-#else
       // the even chain continues from the running count (acc[j]: 0, the count seed, or the previous chunks' sum); the
       // first word of the odd chain uses the inline-constant form (v_bcnt d, 0)
       if constexpr (i == 0) t0 = USEED ? popc_acc_s(d, useed) : popc_acc(d, acc[j]);
@@ -705,7 +687,6 @@ __device__ __forceinline__ void stream_weights(const uint32_t* __restrict__ wrun
       else if constexpr (i & 1) t1 = popc_acc(d, t1);
       else t0 = popc_acc(d, t0);
       if constexpr (i == NW - 1) acc[j] = t0 + (NW > 1 ? t1 : 0);
-#endif
     });
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (b + 1 < NB) cur = nxt;
