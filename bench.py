@@ -14,6 +14,10 @@ One "step" = one pass of the hot path over one synthetic batch per GPU, inputs r
 the timed region.  Weak scaling: every rank processes its own batch; for the networks the
 [B,1000] logits of all ranks are all-gathered over RCCL at the end of every step (the only exchange
 the path has).  Prints ONE JSON line on rank 0.
+
+Timing: --spinup untimed steps (default ~0.25 s of work; the clocks of an idle GPU need that long to come up),
+then W warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides, max over ranks.
+The roofline block times 50 launches of the graded kernel with events after --roofline-spinup launches of it.
 """
 from __future__ import annotations
 
@@ -59,10 +63,18 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=2,
                     help="graph engine: batches in flight per GPU (graph-captured executors on their own HIP "
                          "streams, replayed round-robin; 1 = strictly one batch at a time)")
+    ap.add_argument("--spinup", type=int, default=-1,
+                    help="untimed steps in front of the warm-up steps that bring the GPU clocks up from idle "
+                         "(default: about 0.25 s of work: 200 for the nets, 750 for c2; 0 = none)")
+    ap.add_argument("--roofline-spinup", type=int, default=1000,
+                    help="untimed launches of the graded kernel in front of its event-timed launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-fp32-stem and one-batch-at-a-time lines")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.spinup < 0:
+        a.spinup = 750 if a.config == "c2" else 200
+    return a
 
 
 ARGS = parse_args()
@@ -132,7 +144,7 @@ def _event_time(fn, iters, device):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def conv_c2_roofline(device, info, batch=256, iters=20, act_kind="relu", nonneg=False):
+def conv_c2_roofline(device, info, batch=256, iters=50, act_kind="relu", nonneg=False):
     """BASELINE config 2: 3x3 Conv2d 128->128, 56x56, batch 256 — the graded kernel.
     Times `iters` launches of bnn_hip_bconv2d with events on the launch stream.
     ``nonneg``: promise the kernel that the input has no negative value (true for a ReLU output):
@@ -143,7 +155,9 @@ def conv_c2_roofline(device, info, batch=256, iters=20, act_kind="relu", nonneg=
     pw = hipops.pack_weight(w)
     act = hipops.pack_act(x)
     act.nonneg = bool(nonneg)
-    for _ in range(3):
+    # ~0.25 s of the same launches first: the host-side preparation above left the GPU idle, and the first region after
+    # a pause runs at ramping clocks (~15 % slow); the events then bracket `iters` launches at the sustained clock
+    for _ in range(ARGS.roofline_spinup):
         hipops.bconv2d(act, pw, stride=1, padding=1)
     t_conv = _event_time(lambda: hipops.bconv2d(act, pw, stride=1, padding=1), iters, device)
     t_pack = _event_time(lambda: hipops.pack_act(x), iters, device)        # HBM-bound
@@ -162,7 +176,8 @@ def conv_c2_roofline(device, info, batch=256, iters=20, act_kind="relu", nonneg=
         "achieved": lane_ops / t_conv / 1e12, "peak": peak / 1e12, "unit": "Tlane-op/s",
         "frac": lane_ops / t_conv / peak, "traffic": traffic, "traffic_note": traffic_note,
         "algorithmic_bytes": in_bytes + out_bytes + O * K // 8,
-        "avg_kernel_us": t_conv * 1e6, "images_per_s_kernel": N / t_conv,
+        "avg_kernel_us": t_conv * 1e6, "images_per_s_kernel": N / t_conv, "timed_launches": iters,
+        "spinup_launches": ARGS.roofline_spinup,
         "fp32_in_fp32_out": {"us": t_both * 1e6, "images_per_s": N / t_both,
                              "frac": lane_ops / t_both / peak,
                              "note": "pack_act + conv back to back: config 2 as BASELINE.json words it"},
@@ -262,6 +277,12 @@ def main():
             dist.barrier()
 
     def timed(step, steps, warmup):
+        # The engine clock of an idle GPU takes a few hundred ms of work to come up (the first timed region after a
+        # pause measured ~15 % slow), and W = 5 warm-up steps are 6 ms.  A fixed number of the SAME
+        # steps (same count on every rank: the step may contain a collective) runs first; it is reported as
+        # "spinup_steps" in the JSON line and is outside both the W warm-up steps and the K timed steps.
+        for i in range(args.spinup):
+            step(i)
         for i in range(warmup):
             out = step(i)
         torch.cuda.synchronize(device)
@@ -321,7 +342,7 @@ def bench_c2(args, world, rank, device, info, timed):
     lane_ops = 2.0 * ((C * 9 + 31) // 32) * N * O * H * W
     rec = {"metric": "images/sec single 3x3 binary Conv2d 128->128 56x56 (fp32 NCHW in -> fp32 NCHW out)",
            "value": world * N * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "warmup": args.warmup, "spinup_steps": args.spinup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "int1 xnor-popcount (int32 accumulate) + fp32 alpha epilogue",
            "data": "synthetic",
            "config": {"workload": f"BASELINE config 2: Conv2d(128,128,3,padding=1) + XNOR recipe, x [{N},128,56,56] "
@@ -388,7 +409,7 @@ def bench_net(args, world, rank, device, info, timed):
         "metric": "images/sec binary ResNet-18 224x224 forward" if not c5 else
                   "images/sec binary hierarchical-block ResNet-[3,4,6,3] 224x224 forward",
         "value": value, "unit": "images/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps": args.spinup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
         "dtype": DTYPE if not c5 else DTYPE.replace("fp32 operands split into fp16 hi+lo", "plain fp16 operands (BNN_HIP_STEM_FP16)"),
