@@ -38,8 +38,9 @@ struct Geo {
   int tiles;     // 64-pixel tiles of the output
   int tiles_per_xcd;  // ceil(tiles / 8)
   // index arithmetic of the tiled kernels: q / (Ho*Wo) and r / Wo as multiply-high + shift (s < 0: divisor 1)
-  uint32_t m_hw, m_wo;
-  int s_hw, s_wo;
+  uint32_t m_hw, m_wo, m_tpx;
+  int s_hw, s_wo, s_tpx;
+  unsigned in_bytes;  // bytes of one packed input plane tensor (P or M): the range of the field loads' descriptor
 };
 
 enum : int {
@@ -155,6 +156,12 @@ using BufRsrc = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ BufRsrc make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
 }
+__device__ __forceinline__ BufRsrc make_rsrc_sized(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint32_t buf_ld_u32(BufRsrc r, unsigned boff) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, (int)boff, 0, 0);
+}
 __device__ __forceinline__ float buf_ld(BufRsrc r, unsigned lane_boff, unsigned chan_boff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_boff, (int)chan_boff, 0));
 }
@@ -164,6 +171,8 @@ __device__ __forceinline__ void buf_st(BufRsrc r, unsigned lane_boff, unsigned c
 #else  // host pass of hipcc only parses these
 struct BufRsrc {};
 __device__ __forceinline__ BufRsrc make_rsrc(const void*) { return {}; }
+__device__ __forceinline__ BufRsrc make_rsrc_sized(const void*, unsigned) { return {}; }
+__device__ __forceinline__ uint32_t buf_ld_u32(BufRsrc, unsigned) { return 0u; }
 __device__ __forceinline__ float buf_ld(BufRsrc, unsigned, unsigned) { return 0.0f; }
 __device__ __forceinline__ void buf_st(BufRsrc, unsigned, unsigned, float) {}
 #endif
@@ -242,7 +251,9 @@ __device__ __forceinline__ Pix decode_pixel(const Geo& g, int q) {
 // into the zero padding yield P = M = 0 (padding is applied after sign(): conv.py:91-92).
 // NN ("non-negative"): the caller guarantees the M plane is all zero (activations out of a ReLU are
 // {0,+1}); only P is loaded and `mr` stays dead, which halves the field's registers and loads.
-template <int KH, int KW, int CWC, bool NN = false, bool FAST = false>
+// BUFLD: field loads through a sized buffer descriptor (single-chunk kernels; the multi-chunk ones have no SGPRs to spare
+// beside the 64 of the weight stream: the descriptor pushed 100+ v_readlane/v_writelane into their chunk loop).
+template <int KH, int KW, int CWC, bool NN = false, bool FAST = false, bool BUFLD = false>
 __device__ __forceinline__ void load_field(const Geo& g, const Pix& px, int ch,
                                            const uint32_t* __restrict__ P,
                                            const uint32_t* __restrict__ M,
@@ -260,6 +271,21 @@ __device__ __forceinline__ void load_field(const Geo& g, const Pix& px, int ch,
     const int iy = iy0 + t / KW;
     const int ix = ix0 + t % KW;
     const bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.Wd;
+    if constexpr (BUFLD) {
+      // buffer loads: a tap in the zero padding gets an offset beyond the descriptor's range and the hardware returns
+      // 0 for it — no select per loaded word behind the load (2 x CWC v_cndmask per tap).  (Two 4-byte loads per
+      // uint64: hipcc 7.2 mis-lowers the 8-byte buffer-load builtin; the backend merges the pair where it can.)
+      const BufRsrc rP = make_rsrc_sized(P, g.in_bytes), rM = make_rsrc_sized(M, g.in_bytes);
+#pragma unroll
+      for (int gi = 0; gi < GC; ++gi) {
+        const unsigned boff = ok ? (img + (unsigned)(gi * plane + row0 + (t / KW) * g.Wd + ix)) * 8u : 0xFFFFFFF8u;
+        pr[t * CWC + gi * 2] = buf_ld_u32(rP, boff);
+        pr[t * CWC + gi * 2 + 1] = buf_ld_u32(rP, boff + 4u);
+        mr[t * CWC + gi * 2] = NN ? 0u : buf_ld_u32(rM, boff);
+        mr[t * CWC + gi * 2 + 1] = NN ? 0u : buf_ld_u32(rM, boff + 4u);
+      }
+      continue;
+    }
     const int pix = ok ? row0 + (t / KW) * g.Wd + ix : 0;
 #pragma unroll
     for (int gi = 0; gi < GC; ++gi) {
@@ -770,7 +796,7 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
   // in that XCD's 4 MB L2 across the blocks and across the 3-row halos of neighbouring tiles,
   // instead of every XCD streaming the whole input once per block.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int obp = slot / g.tiles_per_xcd;  // (block, part) when GSPLIT
+  const int obp = (int)fast_div((uint32_t)slot, g.m_tpx, g.s_tpx);  // slot / tiles_per_xcd: (block, part) when GSPLIT
   const int ob0 = GSPLIT ? obp / PASSES : obp * OBW;
   const int part = GSPLIT ? obp - ob0 * PASSES : 0;
   const int tile = xcd * g.tiles_per_xcd + (slot - obp * g.tiles_per_xcd);
@@ -780,7 +806,7 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
   int nz = 0;
   if constexpr (!MULTI) {
     if (ob0 * kOCB < g.O) {
-      load_field<KH, KW, CWC, NN, true>(g, px, 0, P, M, pr, mr);
+      load_field<KH, KW, CWC, NN, true, true>(g, px, 0, P, M, pr, mr);
       nz = count_nonzero<NW, NN>(pr, mr, 0);
     }
   }
@@ -1087,6 +1113,8 @@ static Geo make_geo(const ConvP& p) {
   Geo g;
   div_magic((uint32_t)(p.Ho * p.Wo), g.m_hw, g.s_hw);
   div_magic((uint32_t)p.Wo, g.m_wo, g.s_wo);
+  div_magic((uint32_t)(((p.npix + kWave - 1) / kWave + 7) / 8), g.m_tpx, g.s_tpx);
+  g.in_bytes = (unsigned)((long long)p.N * (p.cw32 >> 1) * p.H * p.Wd * 8);  // capi.hip: below 2^32 - 8
   g.N = p.N; g.H = p.H; g.Wd = p.Wd; g.Ho = p.Ho; g.Wo = p.Wo; g.O = p.O;
   g.KH = p.KH; g.KW = p.KW; g.sh = p.sh; g.sw = p.sw; g.ph = p.ph; g.pw = p.pw;
   g.dh = p.dh; g.dw = p.dw; g.cw32 = p.cw32; g.cwc = p.cwc; g.nchunk = p.nchunk;
