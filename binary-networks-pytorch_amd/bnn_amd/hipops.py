@@ -198,7 +198,8 @@ def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: 
 
 def sign_thresholds(w: PackedWeight, bn_scale: torch.Tensor, bn_shift: torch.Tensor, bias=None, post_scale=None):
     """Integer form of ``sign(relu(bn(alpha * dot + bias)))`` for ``bconv2d_fused(..., sign_thresholds=...)``:
-    int32 ``[O, 2]`` = (lo, span) per channel, derived on the device with the epilogue's own float operations
+    int32 ``[O, 2]`` = (bound T, flip word of the channel's 32-channel block), ``bit = (dot >= T) ^ flip``, derived on
+    the device with the epilogue's own float operations
     (include/bnn_hip.h: bnn_hip_sign_thresholds_f32).  Valid for THIS weight pack and THESE BatchNorm constants."""
     lib = native.require()
     O, C, KH, KW = w.shape

@@ -92,7 +92,7 @@ class _Conv:
         lay = self.layer
         if _TAP is not None:
             _TAP(self.name, act)
-        # BN + ReLU -> planes only (conv1 of a BasicBlock): the sign bit is an integer interval test on the dot
+        # BN + ReLU -> planes only (conv1 of a BasicBlock): the sign bit is an integer compare of the dot
         thr = self.thr if (out_packed and not out_f32 and residual is None and not epi) else None
         return hipops.bconv2d_fused(
             act, self.weight, bias=lay.bias, post_scale=self.plan.scale, bn_scale=self.bn_scale,
@@ -139,7 +139,7 @@ class FusedResNet(nn.Module):
         super().__init__()
         # the last conv of a block writes no fp32 tensor when the next block consumes sign planes only
         self.skip_dead_f32 = skip_dead_f32
-        # BN + ReLU + sign of the conv1-type layers as an integer interval test on the dot (same bits, fewer instructions)
+        # BN + ReLU + sign of the conv1-type layers as an integer compare of the dot (same bits, fewer instructions)
         self.int_thresholds = int_thresholds
         # several batches in flight on other streams: kernels prefer fewer, longer waves (BNN_HIP_FLAG_THROUGHPUT)
         self.throughput_mode = throughput_mode

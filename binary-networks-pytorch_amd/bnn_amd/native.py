@@ -24,7 +24,7 @@ FLAG_ACT_NONNEG = 32
 FLAG_THROUGHPUT = 64
 STEM_EXACT_FP32 = 1
 STEM_FP16 = 4
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # every symbol include/bnn_hip.h declares (tests assert the .so exports all of them)
 EXPORTED_SYMBOLS = (

@@ -73,7 +73,7 @@ struct EpiArgs {
   uint32_t* outM;
   const float* pack_a;
   const float* pack_b;
-  const int32_t* thr;  // EP_MIDT: per channel {lo, count-1} of the dot interval whose sign bit is 1
+  const int32_t* thr;  // EP_MIDT: per channel {T, flip word of its 32-channel block}: bit = (dot >= T) ^ flip (bnn_hip.h)
 };
 
 #ifndef BNN_TILED_MIN_WAVES  // waves per SIMD the tiled kernels are register-allocated for
@@ -337,7 +337,7 @@ enum : int {
   EP_HB3 = 7,      // HBlock stage 3: raw conv + late residual -> fp32 slice
   EP_OUTP = 9,     // BN + residual + ReLU -> packed only  (conv2 of a BasicBlock whose fp32 output nobody reads: the
                    // next block takes its shortcut from the sign planes — AvgPool -> binary 1x1 — like its convs)
-  EP_MIDT = 8,     // EP_MID with the BN + ReLU + sign folded into an integer interval test on the dot (thresholds
+  EP_MIDT = 8,     // EP_MID with the BN + ReLU + sign folded into an integer compare of the dot (thresholds
                    // derived on the device from the same float operations: bnn_hip_sign_thresholds_f32)
 };
 constexpr int kFlagsMid = EF_BN | EF_RELU | EF_PACK;
@@ -378,7 +378,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
                                          [[maybe_unused]] int negnz = 0, [[maybe_unused]] float dscale = 0.0f,
                                          [[maybe_unused]] float doff = 0.0f) {
   static_assert(!RAWF || (FULL && NACC % 2 == 0 && EP != EP_RUNTIME && EP != EP_MIDT), "see above");
-  // EP_MIDT: `dot` holds 2*agreements and `negnz` the lane's -(non-zero inputs); every other profile: the dot product
+  // EP_MIDT: `dot` holds the raw popcount, `dscale` +-2 and `negnz` the lane's -+(non-zero inputs); other profiles: the dot product
   constexpr bool FUSED = EP != EP_PLAIN;
   using f2 = __attribute__((ext_vector_type(2))) float;
   [[maybe_unused]] auto dot_pair = [&](int j) -> f2 {
@@ -431,18 +431,15 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
   }
   const int bit0 = o0 & 31;  // position of channel o0 inside its 32-channel output word
   if constexpr (EP == EP_MIDT) {
-    // sign(relu(bn(alpha * dot))) == 1  <=>  lo[o] <= dot <= lo[o] + span[o]  (one unsigned compare); M stays 0
+    // sign(relu(bn(alpha * dot))) == 1  <=>  (dot >= T[o]) ^ flip[o]  (csrc/thresholds.hip); M stays 0.  `dot` holds the
+    // agreement (NN) / disagreement count of ONE popcount chain: dot = +-2*count + negnz is a single v_lshl_add_u32, the
+    // compare takes T as its scalar operand, the flips of the block are one XOR at store time (store_packed*).
+    const int km = (int)dscale;  // +2 / -2
 #pragma unroll
     for (int j = 0; j < NACC; ++j) {
       const int o = o0 + j;
       if (full || o < g.O) {
-        // dot - lo as 2*agree + (-nonzeros) + (-lo): ONE v_add3_u32 behind the kernel's v_add_lshl_u32 (the negations
-        // are hidden from the optimiser, which would otherwise turn the sum back into two subtractions)
-        int neglo = -e.thr[2 * o];
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm("" : "+s"(neglo));
-#endif
-        const bool bit = (unsigned)(dot[j] + negnz + neglo) <= (unsigned)e.thr[2 * o + 1];
+        const bool bit = dot[j] * km + negnz >= e.thr[2 * o];
         if constexpr (FULL) pbits = shift_in(pbits, bit);
         else pbits |= (bit ? 1u : 0u) << (bit0 + j);
       }
@@ -569,14 +566,16 @@ __device__ __forceinline__ void prefetch_residual(const Geo& g, const Pix& px, i
 
 // sign(y) of one 32-channel block: one half of a uint64 word of the [n][group][y][x] output planes.
 // `rev`: the words were built by shift-in (straight-line epilogue, all 32 channels of the block): bit-reversed.
+// `xorw` (EP_MIDT): the flip bits of the block's channels, applied to the finished P word.
 __device__ __forceinline__ void store_packed(const Geo& g, const Pix& px, int ob, uint32_t pbits,
-                                             uint32_t mbits, const EpiArgs& e, bool rev = false) {
+                                             uint32_t mbits, const EpiArgs& e, bool rev = false, uint32_t xorw = 0u) {
   // lanes past the last pixel hold a copy of it (decode_pixel): they store the same word to the same place
   if (!(g.flags & EF_PACK) || (g.flags & EF_RAW)) return;
   if (rev) {
     pbits = __builtin_bitreverse32(pbits);
     mbits = __builtin_bitreverse32(mbits);
   }
+  pbits ^= xorw;
   const int hw = g.Ho * g.Wo;
   const unsigned w = (((px.pk_base + (unsigned)((ob >> 1) * hw)) << 1) + (unsigned)(ob & 1)) * 4u;  // bytes
   st_off(e.outP, w, pbits);
@@ -588,13 +587,15 @@ __device__ __forceinline__ void store_packed(const Geo& g, const Pix& px, int ob
 // `rev`: the part's 32 / PARTS bits were built by shift-in from bit 0 (bit-reversed, not yet at their position).
 template <int PARTS>
 __device__ __forceinline__ void store_packed_part(const Geo& g, const Pix& px, int ob, int part,
-                                                  uint32_t pbits, uint32_t mbits, const EpiArgs& e, bool rev = false) {
+                                                  uint32_t pbits, uint32_t mbits, const EpiArgs& e, bool rev = false,
+                                                  uint32_t xorw = 0u) {
   static_assert(PARTS == 2 || PARTS == 4, "16- or 8-bit pieces");
   if (!(g.flags & EF_PACK) || (g.flags & EF_RAW)) return;
   if (rev) {  // bits 0 .. 32/PARTS-1 reversed -> the top of bitreverse32; move them to the part's position
     pbits = (__builtin_bitreverse32(pbits) >> (32 - 32 / PARTS)) << ((32 / PARTS) * part);
     mbits = (__builtin_bitreverse32(mbits) >> (32 - 32 / PARTS)) << ((32 / PARTS) * part);
   }
+  pbits ^= xorw & (((1u << (32 / PARTS)) - 1u) << ((32 / PARTS) * part));
   const int hw = g.Ho * g.Wo;
   const size_t w = (((size_t)px.pk_base + (size_t)(ob >> 1) * hw) << 1) + (ob & 1);
   constexpr int BITS = 32 / PARTS;
@@ -681,7 +682,9 @@ constexpr int pick_wblock(int total) {
 // NN: `acc` counts AGREEMENTS, popcount(w & p) (one 4-byte VOP2 v_and + v_bcnt), instead of
 // disagreements; the caller turns them into the dot product with dot = 2*agree - nonzeros.
 // USEED: the counts start from the wave-uniform `useed` (single-chunk kernels) instead of from acc[].
-template <int NW, int NACC, bool NN = false, bool USEED = false>
+// ONECHAIN: one popcount chain per channel instead of an even and an odd one (no t0 + t1 add at the end; the
+// threshold epilogue then needs three instructions per channel).
+template <int NW, int NACC, bool NN = false, bool USEED = false, bool ONECHAIN = false>
 __device__ __forceinline__ void stream_weights(const uint32_t* __restrict__ wrun,
                                                const uint32_t (&pr)[NW], const uint32_t (&mr)[NW],
                                                int (&acc)[NACC], [[maybe_unused]] int useed = 0) {
@@ -706,6 +709,11 @@ __device__ __forceinline__ void stream_weights(const uint32_t* __restrict__ wrun
       constexpr int f = b * WB + e;
       constexpr int j = f / NW, i = f % NW;
       const uint32_t d = NN ? (cur.v[e] & pr[i]) : disagree(cur.v[e], mr[i], pr[i]);
+      if constexpr (ONECHAIN) {
+        acc[j] = (USEED && i == 0) ? popc_acc_s(d, useed) : popc_acc(d, acc[j]);
+        (void)t0; (void)t1;
+        return;
+      }
       // the even chain continues from the running count (acc[j]: 0, the count seed, or the previous chunks' sum); the
       // first word of the odd chain uses the inline-constant form (v_bcnt d, 0)
       if constexpr (i == 0) t0 = USEED ? popc_acc_s(d, useed) : popc_acc(d, acc[j]);
@@ -862,19 +870,19 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
           if (!WZ && (GSPLIT || ps == 0)) nz = count_nonzero<NW, NN>(pr, mr, nz);
           const size_t woff = ((size_t)ch * kOCB + ps * NACC) * NW;
           if constexpr (WZ) stream_weights_wz<NW, NACC>(wblk + woff, zblk + woff, pr, mr, acc, nzacc);
-          else stream_weights<NW, NACC, NN>(wblk + woff, pr, mr, acc);
+          else stream_weights<NW, NACC, NN, false, EP == EP_MIDT>(wblk + woff, pr, mr, acc);
         }
       } else {
         const size_t woff = (size_t)ps * (NACC * NW);
         if constexpr (WZ) stream_weights_wz<NW, NACC>(wblk + woff, zblk + woff, pr, mr, acc, nzacc);
-        else stream_weights<NW, NACC, NN, true>(wblk + woff, pr, mr, acc, SEEDED ? (int)kCountSeed : 0);
+        else stream_weights<NW, NACC, NN, true, EP == EP_MIDT>(wblk + woff, pr, mr, acc, SEEDED ? (int)kCountSeed : 0);
       }
       // ONE branch on `fullb` around everything that differs: with the late shortcut fetch and the epilogue under two
       // separate ifs, the guarded side's 32 per-channel predicates are computed at the common dominator — in front of
       // the first if, on every wave — and spilled to VGPR lanes (215 v_readlane + 123 v_writelane in the 512->512 kernel).
       constexpr bool RES_LATE_FETCH = !RES_EARLY && !RES_ALL;
       const int o0 = ob * kOCB + ps * NACC;
-      [[maybe_unused]] int negnz = NN ? -nz : nz;  // EP_MIDT (see its epilogue): dot = -+2*acc + negnz
+      [[maybe_unused]] int negnz = NN ? -nz : nz;  // EP_MIDT (see its epilogue): dot = +-2*count + negnz
 #if defined(__HIP_DEVICE_COMPILE__)
       if constexpr (EP == EP_MIDT) asm("" : "+v"(negnz));
 #endif
@@ -882,7 +890,7 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
 #pragma unroll
         for (int j = 0; j < NACC; ++j)  // dot = non-zeros - 2*disagreements = 2*agreements - non-zeros
           acc[j] = WZ                 ? nzacc[j] - 2 * acc[j]
-                   : EP == EP_MIDT    ? (NN ? 2 * acc[j] : -2 * acc[j])
+                   : EP == EP_MIDT    ? acc[j]          // the raw count: its epilogue scales and offsets it itself
                    : NN               ? 2 * acc[j] - nz
                                       : nz - 2 * acc[j];
       };
@@ -901,7 +909,7 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
                                          NN ? -(float)nz : (float)nz);
         } else {
           to_dot();
-          epilogue<NACC, EP, true>(g, px, o0, acc, resv, epi, pbits, mbits, negnz);
+          epilogue<NACC, EP, true>(g, px, o0, acc, resv, epi, pbits, mbits, negnz, NN ? 2.0f : -2.0f);
         }
       } else {
         if constexpr (RES_LATE_FETCH) prefetch_residual<NACC, EP>(g, px, o0, epi, resv);
@@ -910,7 +918,7 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
           for (int j = 0; j < NACC; ++j) acc[j] -= (int)kCountSeed;
         }
         to_dot();
-        epilogue<NACC, EP>(g, px, o0, acc, resv, epi, pbits, mbits, negnz);
+        epilogue<NACC, EP>(g, px, o0, acc, resv, epi, pbits, mbits, negnz, NN ? 2.0f : -2.0f);
       }
     };
     if constexpr (RES_ALL) {
@@ -931,8 +939,12 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
     }
   }
   const bool rev = (ob + 1) * kOCB <= g.O;  // == fullb of every pass of this block
-  if constexpr (GSPLIT) store_packed_part<PASSES>(g, px, ob, part, pbits, mbits, epi, rev);
-  else store_packed(g, px, ob, pbits, mbits, epi, rev);
+  uint32_t xorw = 0u;  // EP_MIDT: flip bits of this block's channels (blocks past O — zero tail words — have none)
+  if constexpr (EP == EP_MIDT) {
+    if (ob * kOCB < g.O) xorw = (uint32_t)epi.thr[2 * (ob * kOCB) + 1];
+  }
+  if constexpr (GSPLIT) store_packed_part<PASSES>(g, px, ob, part, pbits, mbits, epi, rev, xorw);
+  else store_packed(g, px, ob, pbits, mbits, epi, rev, xorw);
   }
 }
 

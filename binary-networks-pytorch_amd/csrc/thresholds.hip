@@ -5,9 +5,13 @@
 //     P[o] = ( fmaf( fmaf(alpha[o], dot, bias[o]) [* scale[o]], bn_a[o], bn_b[o] ) > 0 ),      dot in [-K, K] integer.
 // Every step is a monotone function of `dot` (rounding is monotone), so the set of dots whose bit is 1 is an INTERVAL.
 // One thread per channel finds its ends by bisection, evaluating exactly the float operations of the conv epilogue
-// (csrc/bconv.hip: epilogue()); the conv kernel then needs one subtract and one unsigned compare per channel and pixel
-// instead of int->float, two fmas and a float compare — same bits by construction (tests/test_gpu_fused.py).
-//     thr[2o] = lo, thr[2o+1] = span:   P  <=>  (unsigned)(dot - lo) <= (unsigned)span
+// (csrc/bconv.hip: epilogue()); the conv kernel then needs one integer compare per channel and pixel instead of
+// int->float, two fmas and a float compare — same bits by construction (tests/test_gpu_fused.py).
+// A monotone function crosses zero once, so the interval always touches an end of [-K, K] and ONE one-sided compare
+// is enough:   thr[2o] = T,   P  <=>  (dot >= T) XOR flip_o ,
+// with the flip bits of a 32-channel block gathered into one word that every thr[2o+1] of the block repeats
+// (bit k = flip of channel 32*(o/32) + k): increasing channels have flip 0 and T = first dot whose bit is 1,
+// decreasing ones flip 1 and T = last such dot + 1; "always" is T = -K, "never" (a NaN constant too) T = 2^30.
 #include "bnn_dev.h"
 
 namespace bnn {
@@ -19,9 +23,10 @@ __global__ __launch_bounds__(256) void sign_threshold_kernel(const float* __rest
                                                              const float* __restrict__ bn_b, int O, int kmax,
                                                              int32_t* __restrict__ thr) {
   const int o = blockIdx.x * 256 + threadIdx.x;
-  if (o >= O) return;
-  const float al = alpha[o], bi = bias ? bias[o] : 0.0f, sc = scale ? scale[o] : 1.0f;
-  const float a = bn_a ? bn_a[o] : 1.0f, b = bn_b ? bn_b[o] : 0.0f;
+  const bool in = o < O;
+  const int oc = in ? o : O - 1;  // lanes past the last channel recompute it (they take part in the ballot below)
+  const float al = alpha[oc], bi = bias ? bias[oc] : 0.0f, sc = scale ? scale[oc] : 1.0f;
+  const float a = bn_a ? bn_a[oc] : 1.0f, b = bn_b ? bn_b[oc] : 0.0f;
   auto pos = [&](int d) {
     float y = fmaf(al, (float)d, bi);
     if (scale) y *= sc;
@@ -29,28 +34,35 @@ __global__ __launch_bounds__(256) void sign_threshold_kernel(const float* __rest
     return is_pos(y);
   };
   const bool p0 = pos(-kmax), p1 = pos(kmax);
-  int lo, span;
-  if (p0 && p1) {          // always 1
-    lo = -kmax; span = 2 * kmax;
-  } else if (!p0 && !p1) {  // never 1 (a NaN constant lands here too): an interval no dot can reach
-    lo = 0x40000000; span = 0;
-  } else if (p1) {          // increasing: [first d with pos(d), kmax]
+  int T;
+  bool flip = false;
+  if (p0 && p1) {           // always 1
+    T = -kmax;
+  } else if (!p0 && !p1) {  // never 1 (a NaN constant lands here too): a bound no dot can reach
+    T = 0x40000000;
+  } else if (p1) {          // increasing: 1 on [first d with pos(d), kmax]
     int l = -kmax, h = kmax;  // pos(l) == false, pos(h) == true
     while (h - l > 1) {
       const int m = l + (h - l) / 2;
       if (pos(m)) h = m; else l = m;
     }
-    lo = h; span = kmax - h;
-  } else {                  // decreasing: [-kmax, last d with pos(d)]
+    T = h;
+  } else {                  // decreasing: 1 on [-kmax, last d with pos(d)] = NOT (d >= that + 1)
     int l = -kmax, h = kmax;  // pos(l) == true, pos(h) == false
     while (h - l > 1) {
       const int m = l + (h - l) / 2;
       if (pos(m)) l = m; else h = m;
     }
-    lo = -kmax; span = l + kmax;
+    T = h;
+    flip = true;
   }
-  thr[2 * o] = lo;
-  thr[2 * o + 1] = span;
+  // flip word of the 32-channel block: a wave holds two consecutive blocks (256 threads = consecutive channels)
+  const unsigned long long fm = __ballot(in && flip);
+  const uint32_t word = (threadIdx.x & 32) ? (uint32_t)(fm >> 32) : (uint32_t)fm;
+  if (in) {
+    thr[2 * o] = T;
+    thr[2 * o + 1] = (int32_t)word;
+  }
 }
 
 int launch_sign_thresholds(const float* alpha, const float* bias, const float* scale, const float* bn_a,

@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 8
+#define BNN_HIP_ABI_VERSION 9
 #define BNN_HIP_OCB 32 /* output channels per weight block (padding granularity of O) */
 
 typedef enum bnn_hip_status {
@@ -142,15 +142,17 @@ typedef struct bnn_hip_epilogue {
   int32_t out_c_total;
   const int32_t* sign_thresholds; /* NULL, or [O][2] from bnn_hip_sign_thresholds_f32 for THIS alpha / bn_scale /
                                      bn_shift: used when the epilogue is exactly BN + ReLU -> planes only (no bias,
-                                     scale, residual, fp32 output): the sign bit then comes from an integer interval
-                                     test on the dot — same bits as the float path, fewer instructions.  Ignored
+                                     scale, residual, fp32 output): the sign bit then comes from an integer compare
+                                     of the dot — same bits as the float path, fewer instructions.  Ignored
                                      otherwise.                                                          */
 } bnn_hip_epilogue;
 
-/* Per channel the interval of integer dots (|dot| <= kmax = C*KH*KW) whose epilogue value
- *   fmaf(fmaf(alpha, dot, bias) [* post_scale], bn_scale, bn_shift)   is > 0:
- * thresholds[2o] = lo, thresholds[2o+1] = span, bit = (unsigned)(dot - lo) <= (unsigned)span.  Found by bisection with
- * the conv epilogue's own float operations (every step is monotone in dot).  Re-derive when any input changes.   */
+/* Per channel the integer dots (|dot| <= kmax = C*KH*KW) whose epilogue value
+ *   fmaf(fmaf(alpha, dot, bias) [* post_scale], bn_scale, bn_shift)   is > 0.
+ * Every step is monotone in dot, so that set is one-sided:  bit = (dot >= T) XOR flip.
+ * thresholds[2o] = T; thresholds[2o+1] = the flip bits of o's 32-channel block as one word (bit k = channel
+ * 32*(o/32)+k; every entry of a block repeats it).  Found by bisection with the conv epilogue's own float
+ * operations.  Re-derive when any input changes.  (ABI 9; up to ABI 8 the table held {lo, span} of an interval.)   */
 int bnn_hip_sign_thresholds_f32(const float* alpha, const float* bias, const float* post_scale,
                                 const float* bn_scale, const float* bn_shift, int O, int kmax,
                                 int32_t* thresholds, void* stream);

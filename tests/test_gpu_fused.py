@@ -521,8 +521,11 @@ def test_integer_sign_thresholds_give_the_float_epilogue_bits(shape):
     assert torch.equal(got.P, ref.P) and torch.equal(got.M, ref.M) and not bool(got.M.any())
     # the table against the float predicate on the dots themselves
     dot = hipops.bconv2d(act, pw, stride=stride, padding=1, raw_dot=True)                      # int32 [N,O,Ho,Wo]
-    lo, span = thr[:, 0].view(1, -1, 1, 1).long(), thr[:, 1].view(1, -1, 1, 1).long()
-    bit = ((dot.long() - lo) & 0xFFFFFFFF) <= (span & 0xFFFFFFFF)
+    T = thr[:, 0].view(1, -1, 1, 1).long()                      # bit = (dot >= T) XOR flip (include/bnn_hip.h)
+    ch = torch.arange(O, device=thr.device)
+    flip = ((thr[:, 1].long() & 0xFFFFFFFF) >> (ch % 32)) & 1
+    assert all(int(thr[o, 1]) == int(thr[o - o % 32, 1]) for o in range(O))   # one word per 32-channel block
+    bit = (dot.long() >= T) ^ flip.view(1, -1, 1, 1).bool()
     P, _ = oracle.pack_act(np.where(bit.cpu().numpy(), 1.0, 0.0).astype(np.float32))
     assert np.array_equal(u64(ref.P), P)
 
