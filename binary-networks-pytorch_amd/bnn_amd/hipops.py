@@ -14,6 +14,17 @@ import torch
 from . import native
 
 _MAX_ELEMS = (1 << 30) - 1  # fp32 elements one conv launch addresses (32-bit byte offsets inside the kernels)
+# the tiled conv kernels multiply indices with 24-bit multiplies (csrc/bconv.hip: small_indices()); a launch whose
+# images x channels factor reaches 2^23 would silently take the slow shape-generic kernel — split the batch first
+_MAX_INDEX_FACTOR = (1 << 23) - 1
+
+
+def _batch_step(n: int, per_img_elems: int, chan_factor: int) -> int:
+    """Images per launch: as many as keep every tensor of the launch below ``_MAX_ELEMS`` elements and
+    ``images * chan_factor`` (channels of the widest fp32 tensor, 64-channel groups of the planes) below the
+    tiled kernels' index range."""
+    step = min(n, _MAX_ELEMS // max(per_img_elems, 1), _MAX_INDEX_FACTOR // max(chan_factor, 1))
+    return max(1, step)
 
 
 def _pair(v) -> Tuple[int, int]:
@@ -352,7 +363,7 @@ def bconv2d(a: PackedAct, w: PackedWeight, bias: Optional[torch.Tensor] = None,
             return out
         # one launch addresses < 2^31 elements: split the batch when a tensor is larger
         per_img = max(d.O * ho * wo, d.H * d.W)
-        step = max(1, min(d.N, _MAX_ELEMS // max(per_img, 1)))
+        step = _batch_step(d.N, per_img, max(d.O, (d.C + 63) // 64))
         for n0 in range(0, d.N, step):
             n1 = min(d.N, n0 + step)
             dd = native.ConvDesc.from_buffer_copy(d)
@@ -413,7 +424,7 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
         pk = empty_packed(d.N, d.O, ho, wo, dev) if out_packed else None
         # one launch addresses < 2^31 elements: split the batch when a tensor is larger (like bconv2d)
         per_img = max(c_total * ho * wo, d.H * d.W, 1)
-        step = max(1, min(d.N, _MAX_ELEMS // per_img))
+        step = _batch_step(d.N, per_img, max(c_total, d.O, (d.C + 63) // 64))
         for n0 in range(0, d.N, step):
             n1 = min(d.N, n0 + step)
             dd = native.ConvDesc.from_buffer_copy(d)

@@ -117,3 +117,15 @@ def test_torch_custom_ops_are_registered_with_shape_inference_and_no_cpu_kernel(
     with pytest.raises((NotImplementedError, RuntimeError)):   # product path: no CPU stand-in
         torch.ops.bnn_amd.binary_conv2d(torch.zeros(1, 8, 4, 4), torch.zeros(4, 8, 3, 3), None, None,
                                         [1, 1], [1, 1], [1, 1], False, True)
+
+
+def test_batch_step_respects_both_launch_limits():
+    """hipops splits a batch so that one launch stays inside the kernels' addressing (2^30 elements per tensor) AND
+    inside the tiled kernels' 24-bit index factors (images x channels < 2^23: beyond that the C side would fall back
+    to the slow shape-generic kernel)."""
+    from bnn_amd import hipops
+    assert hipops._batch_step(256, 512 * 7 * 7, 512) == 256                      # ResNet-18 layer4: one launch
+    assert hipops._batch_step(8192, 2048 * 7 * 7, 2048) == 4095                  # 8192 x 2048 channels: index factor
+    assert 4095 * 2048 < (1 << 23) <= 4096 * 2048
+    assert hipops._batch_step(4096, 64 * 112 * 112, 64) == ((1 << 30) - 1) // (64 * 112 * 112)   # addressing
+    assert hipops._batch_step(5, 1 << 40, 1) == 1 and hipops._batch_step(3, 0, 0) == 3           # degenerate inputs
