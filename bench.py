@@ -162,9 +162,14 @@ def conv_c2_roofline(device, info, batch=256, iters=50, act_kind="relu", nonneg=
     t_conv = _event_time(lambda: hipops.bconv2d(act, pw, stride=1, padding=1), iters, device)
     t_pack = _event_time(lambda: hipops.pack_act(x), iters, device)        # HBM-bound
 
-    def both():
+    for _ in range(min(200, ARGS.roofline_spinup)):
+        hipops.bconv2d_direct(x, pw, stride=1, padding=1)
+    # the layer as config 2 states it (fp32 NCHW in -> fp32 NCHW out): ONE launch, sign(x) on the fly in LDS
+    t_both = _event_time(lambda: hipops.bconv2d_direct(x, pw, stride=1, padding=1), iters, device)
+
+    def two_launches():
         hipops.bconv2d(hipops.pack_act(x), pw, stride=1, padding=1)
-    t_both = _event_time(both, iters, device)                              # the layer as config 2 states it
+    t_two = _event_time(two_launches, iters, device)
     K = C * 9
     lane_ops = 2.0 * ((K + 31) // 32) * N * O * H * W           # algorithmic: xor + popcount per 32 MACs
     peak = int_alu_peak(info)
@@ -179,8 +184,13 @@ def conv_c2_roofline(device, info, batch=256, iters=50, act_kind="relu", nonneg=
         "avg_kernel_us": t_conv * 1e6, "images_per_s_kernel": N / t_conv, "timed_launches": iters,
         "spinup_launches": ARGS.roofline_spinup,
         "fp32_in_fp32_out": {"us": t_both * 1e6, "images_per_s": N / t_both,
-                             "frac": lane_ops / t_both / peak,
-                             "note": "pack_act + conv back to back: config 2 as BASELINE.json words it"},
+                             "frac": lane_ops / t_both / peak, "kernel": "bconv_fly_kernel<3,3,4>",
+                             "algorithmic_bytes": N * C * H * W * 4 + out_bytes + O * K // 8,
+                             "GBps": (N * C * H * W * 4 + out_bytes) / t_both / 1e9,
+                             "note": "config 2 as BASELINE.json words it, ONE launch (bnn_hip_bconv2d_direct): "
+                                     "activations binarised on the fly into LDS, no packed copy in HBM",
+                             "two_launch_form": {"us": t_two * 1e6, "frac": lane_ops / t_two / peak,
+                                                 "note": "pack_act + bconv2d through a 26 MB workspace (round 2)"}},
         "hbm": {"conv_GBps": (in_bytes + out_bytes) / t_conv / 1e9,
                 "pack_us": t_pack * 1e6, "pack_GBps": (N * C * H * W * 4 + in_bytes) / t_pack / 1e9,
                 "peak_GBps": 8000.0},
@@ -317,24 +327,23 @@ def main():
 
 
 def bench_c2(args, world, rank, device, info, timed):
-    """BASELINE config 2 as a bench line: value = the fp32-in -> fp32-out layer (pack_act + conv);
+    """BASELINE config 2 as a bench line: value = the fp32-in -> fp32-out layer, one launch per step;
     replicas only (a single layer has nothing to exchange)."""
     N, C, H, W, O = args.batch or 256, 128, 56, 56, 128
     x = torch.from_numpy(gen.activation("relu", 7, (8, C, H, W))).to(device).repeat(N // 8, 1, 1, 1)
     pw = hipops.pack_weight(torch.from_numpy(gen.conv_weight("kaiming", 8, (O, C, 3, 3))).to(device))
 
     def step(i):
-        return hipops.bconv2d(hipops.pack_act(x), pw, stride=1, padding=1)
+        return hipops.bconv2d_direct(x, pw, stride=1, padding=1)
     dt, out = timed(step, args.steps, args.warmup)
     assert out.shape == (N, O, H, W)
-    # two batches in flight (the way the whole-net headline is run): the HBM-bound packing of one batch beside
-    # the ALU-bound convolution of the other
+    # two batches in flight (the way the whole-net headline is run)
     streams = [torch.cuda.Stream(device=device) for _ in range(2)]
     xs = [x, x.clone()]
 
     def step2(i):
         with torch.cuda.stream(streams[i & 1]):
-            return hipops.bconv2d(hipops.pack_act(xs[i & 1]), pw, stride=1, padding=1)
+            return hipops.bconv2d_direct(xs[i & 1], pw, stride=1, padding=1)
     for st in streams:
         st.wait_stream(torch.cuda.current_stream(device))
     dt2, _ = timed(step2, args.steps, args.warmup)
@@ -346,7 +355,8 @@ def bench_c2(args, world, rank, device, info, timed):
            "scaling": "weak", "vs_baseline": None, "dtype": "int1 xnor-popcount (int32 accumulate) + fp32 alpha epilogue",
            "data": "synthetic",
            "config": {"workload": f"BASELINE config 2: Conv2d(128,128,3,padding=1) + XNOR recipe, x [{N},128,56,56] "
-                                  "relu(N(0,1)), pack_act + bconv2d per step", "parallelism": f"{world} replicas"},
+                                  "relu(N(0,1)), one bnn_hip_bconv2d_direct launch per step (sign(x) on the fly)",
+                      "parallelism": f"{world} replicas"},
            "layer_int_alu_frac": lane_ops * args.steps / dt / int_alu_peak(info),
            "two_batches_in_flight": {"value": world * N * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3,
                                      "layer_int_alu_frac": lane_ops * args.steps / dt2 / int_alu_peak(info)}}

@@ -205,9 +205,9 @@ def conv2d(layer, x: torch.Tensor, plan: Plan) -> torch.Tensor:
     """HIP evaluation of ``bnn.layers.Conv2d.forward`` (bnn/layers/conv.py:90-97)."""
     native.require()
     pw = packed_weight(layer, plan)
-    act = hipops.pack_act(x)
-    out = hipops.bconv2d(act, pw, _f32(layer.bias), _f32(plan.scale), layer.stride, layer.padding,
-                         layer.dilation)
+    # one launch: sign(x) is computed inside the convolution kernel (csrc/bconv_fly.hip)
+    out = hipops.bconv2d_direct(x, pw, _f32(layer.bias), _f32(plan.scale), layer.stride, layer.padding,
+                                layer.dilation)
     _bump("conv2d")
     return out.to(x.dtype)
 
@@ -225,9 +225,8 @@ def conv1d(layer, x: torch.Tensor, plan: Plan) -> torch.Tensor:
     """``Conv1d`` as an ``H == 1`` 2-D convolution (bnn/layers/conv.py:36-43)."""
     native.require()
     pw = packed_weight(layer, plan)
-    act = hipops.pack_act(x.unsqueeze(2))
-    out = hipops.bconv2d(act, pw, _f32(layer.bias), _f32(plan.scale), (1, layer.stride[0]),
-                         (0, layer.padding[0]), (1, layer.dilation[0]))
+    out = hipops.bconv2d_direct(x.unsqueeze(2), pw, _f32(layer.bias), _f32(plan.scale), (1, layer.stride[0]),
+                                (0, layer.padding[0]), (1, layer.dilation[0]))
     _bump("conv1d")
     return out.squeeze(2).to(x.dtype)
 
@@ -238,7 +237,6 @@ def linear(layer, x: torch.Tensor, plan: Plan) -> torch.Tensor:
     pw = packed_weight(layer, plan)
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
-    act = hipops.pack_act(x2[:, :, None, None])
-    out = hipops.bconv2d(act, pw, _f32(layer.bias), _f32(plan.scale))
+    out = hipops.bconv2d_direct(x2[:, :, None, None], pw, _f32(layer.bias), _f32(plan.scale))
     _bump("linear")
     return out.reshape(*lead, layer.out_features).to(x.dtype)

@@ -379,6 +379,63 @@ def bconv2d(a: PackedAct, w: PackedWeight, bias: Optional[torch.Tensor] = None,
     return out
 
 
+def direct_plan(x_shape, w: PackedWeight, stride=1, padding=0, dilation=1) -> Optional[native.FlyPlan]:
+    """The band plan ``bconv2d_direct`` would use for this geometry, or None where the one-launch layer does not
+    apply (include/bnn_hip.h: bnn_hip_bconv2d_direct_plan)."""
+    lib = native.require()
+    d = _desc(tuple(x_shape), w.shape, stride, padding, dilation, native.FLAG_WEIGHT_ZEROS if w.has_zero else 0)
+    plan = native.FlyPlan()
+    st = lib.bnn_hip_bconv2d_direct_plan(ctypes.byref(d), ctypes.byref(plan))
+    if st == -2:      # BNN_HIP_ERR_UNSUPPORTED
+        return None
+    native.check(st, "bnn_hip_bconv2d_direct_plan")
+    return plan
+
+
+def bconv2d_direct(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None,
+                   post_scale: Optional[torch.Tensor] = None, stride=1, padding=0, dilation=1,
+                   plan: Optional[native.FlyPlan] = None, force_generic: bool = False) -> torch.Tensor:
+    """``Conv2d.forward`` of the reference (bnn/layers/conv.py:90-97) in ONE launch: fp32 or fp16 NCHW activations in,
+    fp32 NCHW out, ``sign(x)`` computed on the fly inside the convolution kernel (csrc/bconv_fly.hip) — no packed
+    copy of the activations in HBM.  Geometries the one-launch kernel does not cover (an output row with its halo
+    larger than a CU's LDS) take ``pack_act`` + ``bconv2d``; the results are bit-identical either way."""
+    if x.dtype == torch.float16:
+        if not x.is_cuda:
+            raise native.NativeError(f"bnn_amd: activation must live on a HIP device, got {x.device}")
+        x = x.contiguous()
+    else:
+        x = _require_cuda_f32(x, "activation")
+    if x.dim() != 4:
+        raise native.NativeError(f"bnn_amd: bconv2d_direct expects NCHW, got shape {tuple(x.shape)}")
+    lib = native.require()
+    d = _desc(tuple(x.shape), w.shape, stride, padding, dilation, _flags(w, force_generic, None))
+    ho, wo = conv_out_hw(d.H, d.W, d.KH, d.KW, stride, padding, dilation)
+    dev = x.device
+    bias = _per_channel(bias, d.O, "bias")
+    post_scale = _per_channel(post_scale, d.O, "post_scale")
+    with torch.cuda.device(dev):
+        out = torch.empty((d.N, d.O, ho, wo), dtype=torch.float32, device=dev)
+        if d.N == 0:
+            return out
+        per_img = max(d.O * ho * wo, d.C * d.H * d.W)
+        step = _batch_step(d.N, per_img, max(d.O, (d.C + 63) // 64))
+        dtype = native.DTYPE_F16 if x.dtype == torch.float16 else native.DTYPE_F32
+        for n0 in range(0, d.N, step):
+            n1 = min(d.N, n0 + step)
+            dd = native.ConvDesc.from_buffer_copy(d)
+            dd.N = n1 - n0
+            st = lib.bnn_hip_bconv2d_direct(ctypes.byref(dd), x[n0:n1].data_ptr(), dtype, w.wbits.data_ptr(),
+                                            w.wnz.data_ptr(), w.alpha.data_ptr(), _ptr(bias), _ptr(post_scale),
+                                            out[n0:n1].data_ptr(), None if plan is None else ctypes.byref(plan),
+                                            _stream(dev))
+            if st == -2 and plan is None:   # BNN_HIP_ERR_UNSUPPORTED: the two-launch form of the same layer
+                out[n0:n1] = bconv2d(pack_act(x[n0:n1]), w, bias, post_scale, stride, padding, dilation,
+                                     force_generic=force_generic)
+                continue
+            native.check(st, "bnn_hip_bconv2d_direct")
+    return out
+
+
 def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, bn_scale=None,
                   bn_shift=None, residual=None, prelu=None, relu=False, out_f32=True,
                   out_packed=False, stride=1, padding=0, dilation=1, force_generic=False,

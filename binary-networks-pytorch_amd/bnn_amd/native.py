@@ -24,7 +24,9 @@ FLAG_ACT_NONNEG = 32
 FLAG_THROUGHPUT = 64
 STEM_EXACT_FP32 = 1
 STEM_FP16 = 4
-ABI_VERSION = 9
+ABI_VERSION = 10
+DTYPE_F32 = 0
+DTYPE_F16 = 1
 
 # every symbol include/bnn_hip.h declares (tests assert the .so exports all of them)
 EXPORTED_SYMBOLS = (
@@ -36,6 +38,7 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_conv_workspace_bytes", "bnn_hip_bconv2d_f32", "bnn_hip_probe_int_alu", "bnn_hip_avgpool_fc_f32", "bnn_hip_sign_thresholds_f32", "bnn_hip_pack_act_f16", "bnn_hip_orpool_packed",
     "bnn_hip_grad_weight_pack_bytes", "bnn_hip_grad_pack_weight_f32", "bnn_hip_bconv_grad_input_f32",
     "bnn_hip_bconv_grad_weight_splits", "bnn_hip_bconv_grad_weight_f32",
+    "bnn_hip_bconv2d_direct", "bnn_hip_bconv2d_direct_plan",
 )
 
 
@@ -51,6 +54,12 @@ class WLayout(ctypes.Structure):
     _fields_ = [("cw32", ctypes.c_int32), ("cwc", ctypes.c_int32), ("nchunk", ctypes.c_int32),
                 ("taps", ctypes.c_int32), ("o_pad", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("n_words", ctypes.c_int64)]
+
+
+class FlyPlan(ctypes.Structure):
+    """``bnn_hip_fly_plan``"""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "images_per_band", "rows_per_band", "waves", "blocks_per_unit", "lds_bytes", "n_bands")]
 
 
 class DevInfo(ctypes.Structure):
@@ -121,6 +130,9 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_conv_workspace_bytes.restype = ctypes.c_size_t
     lib.bnn_hip_conv_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
     lib.bnn_hip_bconv2d_f32.argtypes = [ctypes.POINTER(ConvDesc)] + [_vp] * 9
+    lib.bnn_hip_bconv2d_direct_plan.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(FlyPlan)]
+    lib.bnn_hip_bconv2d_direct.argtypes = [ctypes.POINTER(ConvDesc), _vp, _i] + [_vp] * 6 + \
+        [ctypes.POINTER(FlyPlan), _vp]
     lib.bnn_hip_avgpool_fc_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]
     lib.bnn_hip_sign_thresholds_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]
     lib.bnn_hip_grad_weight_pack_bytes.restype = ctypes.c_size_t

@@ -20,6 +20,7 @@ stand in a training graph.
 from __future__ import annotations
 
 import collections
+import weakref
 from typing import List, Optional, Tuple
 
 import torch
@@ -37,16 +38,25 @@ def _packed(weight: torch.Tensor, center: bool, compute_alpha: bool) -> hipops.P
     """Packed form of ``weight``, cached on (storage pointer, version counter, shape, recipe): the pack reads its
     zero-weight flag with a blocking ``.item()``, which would make the ops unusable under HIP-graph capture and slow
     in a training graph if it ran on every call.  (Writes through ``weight.data`` bypass the version counter: call
-    ``torch_ops.clear_cache()`` after them.)"""
+    ``torch_ops.clear_cache()`` after them.)
+
+    An entry keeps a weak reference to the tensor it was made from and is only trusted while that very tensor is
+    alive: the caching allocator hands the address of a freed weight to the next tensor of the same shape, whose
+    version counter is 0 again — pointer + version alone would return the previous tensor's signs and alpha."""
     key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), center, compute_alpha)
-    pw = _PACK_CACHE.get(key)
-    if pw is None:
-        pw = hipops.pack_weight(weight, center, compute_alpha)
-        _PACK_CACHE[key] = pw
-        while len(_PACK_CACHE) > _PACK_CACHE_MAX:
-            _PACK_CACHE.popitem(last=False)
-    else:
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0]() is weight:
         _PACK_CACHE.move_to_end(key)
+        return hit[1]
+    pw = hipops.pack_weight(weight, center, compute_alpha)
+    try:
+        ref = weakref.ref(weight, lambda _r, k=key: _PACK_CACHE.pop(k, None))   # dropped with its tensor
+    except TypeError:       # (fake / functional tensor wrappers): not cacheable
+        return pw
+    _PACK_CACHE[key] = (ref, pw)
+    _PACK_CACHE.move_to_end(key)
+    while len(_PACK_CACHE) > _PACK_CACHE_MAX:
+        _PACK_CACHE.popitem(last=False)
     return pw
 
 
@@ -84,7 +94,7 @@ def binary_conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
     ``BasicInputBinarizer`` / ``XNORWeightBinarizer`` / optional ``BasicScaleBinarizer`` hooks."""
     _need_gpu(x, weight, bias, post_scale)
     pw = _packed(weight, center_weights, compute_alpha)
-    return hipops.bconv2d(hipops.pack_act(x), pw, bias, post_scale, tuple(stride), tuple(padding), tuple(dilation))
+    return hipops.bconv2d_direct(x, pw, bias, post_scale, tuple(stride), tuple(padding), tuple(dilation))
 
 
 @binary_conv2d.register_fake
@@ -110,8 +120,8 @@ def _conv_backward(ctx, g):
         if ctx.needs_input_grad[3]:
             # d out / d post_scale = the PRE-scale output, recomputed by the forward kernels (dividing the saved
             # output by the scale would give NaN/inf for a zero entry of post_scale, where the gradient is finite)
-            pre = hipops.bconv2d(hipops.pack_act(x), _packed(weight, center, compute_alpha), bias, None,
-                                 tuple(stride), tuple(padding), tuple(dilation))
+            pre = hipops.bconv2d_direct(x, _packed(weight, center, compute_alpha), bias, None,
+                                        tuple(stride), tuple(padding), tuple(dilation))
             gs = (g * pre).sum(dim=(0, 2, 3)).reshape(post_scale.shape)
         g = g * s
     with torch.enable_grad():
@@ -137,7 +147,7 @@ def binary_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
     pw = _packed(weight, center_weights, compute_alpha)
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
-    out = hipops.bconv2d(hipops.pack_act(x2[:, :, None, None]), pw, bias, post_scale)
+    out = hipops.bconv2d_direct(x2[:, :, None, None], pw, bias, post_scale)
     return out.reshape(*lead, weight.shape[0])
 
 

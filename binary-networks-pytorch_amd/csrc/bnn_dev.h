@@ -63,7 +63,7 @@ struct ConvP {
   // activation, packing the pre-residual value, channel slice of a wider output tensor
   const float* pack_a;
   const float* pack_b;
-  const int32_t* thr;  // sign thresholds {lo, span} per channel (BN + ReLU -> packed-only epilogue), or null
+  const int32_t* thr;  // sign thresholds {T, flip word of the block} per channel (BN + ReLU -> packed-only epilogue), or null
   int eflags;
   int c_off, c_tot;
   bool raw;
@@ -72,6 +72,7 @@ struct ConvP {
   int KH, KW, sh, sw, ph, pw, dh, dw;
   int cw32, cwc, nchunk;
   int npix;  // N*Ho*Wo
+  int C;     // input channels
 };
 
 // host-side launchers (one per .hip file); return a bnn_hip_status
@@ -108,6 +109,11 @@ int launch_pack_weight(const float* w, int O, int C, int KH, int KW, int center,
                        const bnn_hip_wlayout& L, uint32_t* wbits, uint32_t* wnz, float* alpha,
                        int32_t* zero_flag, hipStream_t stream);
 int launch_bconv(const ConvP& p, int flags, hipStream_t s);
+// bconv_fly.hip: the whole layer in one launch, activations (fp32, or fp16 when x_half) binarised on the fly into LDS.
+// p.P / p.M are unused; p.alpha / bias / scale / out as for launch_bconv.  `plan` may be null (default plan).
+bool fly_supported(const ConvP& p);
+int fly_default_plan(const ConvP& p, int flags, bnn_hip_fly_plan* plan);
+int launch_bconv_fly(const ConvP& p, const void* x, int x_half, int flags, const bnn_hip_fly_plan* plan, hipStream_t s);
 int launch_probe_int_alu(int mode, int iters, double* lane_ops_per_s, double* elapsed_ms, hipStream_t s);
 
 }  // namespace bnn

@@ -68,6 +68,7 @@ int run_conv(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M, c
   p.ph = d->pad_h; p.pw = d->pad_w; p.dh = d->dil_h; p.dw = d->dil_w;
   p.cw32 = L.cw32; p.cwc = L.cwc; p.nchunk = L.nchunk;
   p.npix = d->N * Ho * Wo;
+  p.C = d->C;
   g_launches.fetch_add(1, std::memory_order_relaxed);
   return bnn::launch_bconv(p, d->flags, static_cast<hipStream_t>(stream));
 }
@@ -335,8 +336,57 @@ int bnn_hip_blinear(int B, int F, int O, const uint64_t* P, const uint64_t* M, c
   return bnn_hip_bconv2d(&d, P, M, wbits, wnz, alpha, bias, post_scale, out, stream);
 }
 
+// Geometry part of a ConvP for the one-launch layer (no packed operands).
+static int fly_convp(const bnn_hip_conv_desc* d, bnn::ConvP* out) {
+  int Ho = 0, Wo = 0;
+  const int st = check_desc(d, &Ho, &Wo);
+  if (st != BNN_HIP_OK) return st;
+  if ((long long)d->N * d->C * d->H * d->W > kMaxConvElems) return BNN_HIP_ERR_TOO_LARGE;
+  bnn::ConvP p = empty_convp();
+  bnn_hip_wlayout L;
+  bnn_hip_weight_layout(d->O, d->C, d->KH, d->KW, &L);
+  p.N = d->N; p.H = d->H; p.Wd = d->W; p.Ho = Ho; p.Wo = Wo; p.O = d->O; p.C = d->C;
+  p.KH = d->KH; p.KW = d->KW; p.sh = d->stride_h; p.sw = d->stride_w;
+  p.ph = d->pad_h; p.pw = d->pad_w; p.dh = d->dil_h; p.dw = d->dil_w;
+  p.cw32 = L.cw32; p.cwc = L.cwc; p.nchunk = L.nchunk;
+  p.npix = d->N * Ho * Wo;
+  p.c_off = 0; p.c_tot = d->O;
+  *out = p;
+  return BNN_HIP_OK;
+}
+
+int bnn_hip_bconv2d_direct_plan(const bnn_hip_conv_desc* d, bnn_hip_fly_plan* plan) {
+  if (!plan) return BNN_HIP_ERR_INVALID_ARG;
+  bnn::ConvP p;
+  const int st = fly_convp(d, &p);
+  if (st != BNN_HIP_OK) return st;
+  return bnn::fly_default_plan(p, d->flags, plan);
+}
+
+int bnn_hip_bconv2d_direct(const bnn_hip_conv_desc* d, const void* x, int x_dtype, const uint32_t* wbits,
+                           const uint32_t* wnz, const float* alpha, const float* bias, const float* post_scale,
+                           float* out, const bnn_hip_fly_plan* plan, void* stream) {
+  if (!d || !x || !wbits || !alpha || !out) return BNN_HIP_ERR_INVALID_ARG;
+  if (x_dtype != BNN_HIP_DTYPE_F32 && x_dtype != BNN_HIP_DTYPE_F16) return BNN_HIP_ERR_INVALID_ARG;
+  if (!aligned(x, x_dtype == BNN_HIP_DTYPE_F16 ? 2 : 4) || !aligned(wbits, 16) || !aligned(out, 4))
+    return BNN_HIP_ERR_INVALID_ARG;
+  if ((d->flags & BNN_HIP_FLAG_WEIGHT_ZEROS) && !wnz) return BNN_HIP_ERR_INVALID_ARG;
+  bnn::ConvP p;
+  const int st = fly_convp(d, &p);
+  if (st != BNN_HIP_OK) return st;
+  p.W = wbits; p.Z = wnz; p.alpha = alpha; p.bias = bias; p.scale = post_scale; p.out = out;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  return bnn::launch_bconv_fly(p, x, x_dtype == BNN_HIP_DTYPE_F16, d->flags, plan, static_cast<hipStream_t>(stream));
+}
+
+static bool direct_applies(const bnn_hip_conv_desc* d) {
+  bnn::ConvP p;
+  return fly_convp(d, &p) == BNN_HIP_OK && bnn::fly_supported(p);
+}
+
 size_t bnn_hip_conv_workspace_bytes(const bnn_hip_conv_desc* d) {
   if (!d || d->N <= 0 || d->C <= 0 || d->H <= 0 || d->W <= 0) return 0;
+  if (direct_applies(d)) return 0;
   const size_t npix = (size_t)d->N * d->H * d->W;
   return 2 * align_up(npix * ((d->C + 63) / 64) * sizeof(uint64_t), 256);
 }
@@ -344,7 +394,10 @@ size_t bnn_hip_conv_workspace_bytes(const bnn_hip_conv_desc* d) {
 int bnn_hip_bconv2d_f32(const bnn_hip_conv_desc* d, const float* x, const uint32_t* wbits,
                         const uint32_t* wnz, const float* alpha, const float* bias,
                         const float* post_scale, float* out, void* workspace, void* stream) {
-  if (!d || !x || !workspace || !aligned(workspace, 16)) return BNN_HIP_ERR_INVALID_ARG;
+  if (!d || !x) return BNN_HIP_ERR_INVALID_ARG;
+  if (direct_applies(d))
+    return bnn_hip_bconv2d_direct(d, x, BNN_HIP_DTYPE_F32, wbits, wnz, alpha, bias, post_scale, out, nullptr, stream);
+  if (!workspace || !aligned(workspace, 16)) return BNN_HIP_ERR_INVALID_ARG;
   int Ho, Wo;
   int st = check_desc(d, &Ho, &Wo);
   if (st != BNN_HIP_OK) return st;

@@ -12,6 +12,7 @@
  *   bnn_hip_pack_act_f32      <- bnn/ops.py:63-66,151-152   SignActivation.forward / BasicInputBinarizer.forward
  *   bnn_hip_pack_weight_f32   <- bnn/ops.py:116-140         XNORWeightBinarizer._compute_alpha / .forward
  *   bnn_hip_bconv2d           <- bnn/layers/conv.py:90-97   Conv2d.forward  (nn.Conv2d._conv_forward + post-process)
+ *   bnn_hip_bconv2d_direct    <- bnn/layers/conv.py:90-97   the same forward from the FLOAT input, sign() on the fly
  *   bnn_hip_blinear           <- bnn/layers/linear.py:22-27 Linear.forward  (F.linear + post-process)
  *   post_scale argument       <- bnn/ops.py:200-202         BasicScaleBinarizer.forward (out.mul_(alpha))
  *   (Identity post-process    <- bnn/bconfig.py:6-8 : pass post_scale = NULL)
@@ -60,7 +61,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 9
+#define BNN_HIP_ABI_VERSION 10
 #define BNN_HIP_OCB 32 /* output channels per weight block (padding granularity of O) */
 
 typedef enum bnn_hip_status {
@@ -331,8 +332,41 @@ int bnn_hip_blinear(int B, int F, int O,
                     const float* alpha, const float* bias, const float* post_scale,
                     float* out, void* stream);
 
-/* Convenience: fp32 NCHW in -> fp32 NCHW out in one call (pack + conv).  `workspace`
- * must hold bnn_hip_conv_workspace_bytes(d) bytes, 16-byte aligned.                */
+/* ---- The LAYER in one launch (ABI 10): bnn.layers.Conv2d.forward (bnn/layers/conv.py:90-97) from the float
+ * activation tensor to the float output, sign(x) (bnn/ops.py:63-66,151-152) computed ON THE FLY inside the
+ * convolution kernel: a workgroup binarises its band of the input (whole images, or a run of output rows of one
+ * image with its halo) straight into LDS as two bit planes and convolves it from there — no packed copy of the
+ * activations in HBM, no workspace, the input is read once.  Same integers, same float epilogue, same bits as
+ * bnn_hip_pack_act_f32 + bnn_hip_bconv2d.
+ *   x: [N,C,H,W] contiguous, x_dtype = BNN_HIP_DTYPE_F32 (4-byte aligned) or BNN_HIP_DTYPE_F16 (a `.half()` model:
+ *      the planes are those of the exactly widened values; the output stays fp32, the caller rounds it once);
+ *      N*C*H*W < 2^30 elements per launch.
+ *   plan: NULL = bnn_hip_bconv2d_direct_plan()'s choice.  A caller's plan (tests, tuning) supplies
+ *      images_per_band / rows_per_band / waves / blocks_per_unit; lds_bytes and n_bands are outputs of the planner.
+ * Returns BNN_HIP_ERR_UNSUPPORTED when not even one output row of one image with its halo fits into the 160 KiB
+ * of LDS of a CU (or an index factor leaves the 24-bit multiplies of the tiled kernels): use
+ * bnn_hip_pack_act_f32 + bnn_hip_bconv2d (what bnn_hip_bconv2d_f32 does by itself) for those.                   */
+#define BNN_HIP_DTYPE_F32 0
+#define BNN_HIP_DTYPE_F16 1
+typedef struct bnn_hip_fly_plan {
+  int32_t images_per_band;  /* whole images per workgroup (>= 1); > 1 only with rows_per_band == Ho            */
+  int32_t rows_per_band;    /* output rows per workgroup: Ho = whole images                                     */
+  int32_t waves;            /* wavefronts per workgroup, 1..16                                                  */
+  int32_t blocks_per_unit;  /* 32-channel output blocks per work unit (one load of the field): 1, 2 or 4;
+                               > 1 is honoured by the single-chunk 3x3 kernels only                            */
+  int32_t lds_bytes;        /* out: dynamic LDS per workgroup                                                   */
+  int32_t n_bands;          /* out: workgroups of the launch                                                    */
+} bnn_hip_fly_plan;
+/* HOST: the plan bnn_hip_bconv2d_direct(plan = NULL) uses for this geometry. */
+int bnn_hip_bconv2d_direct_plan(const bnn_hip_conv_desc* d, bnn_hip_fly_plan* plan);
+int bnn_hip_bconv2d_direct(const bnn_hip_conv_desc* d, const void* x, int x_dtype,
+                           const uint32_t* wbits, const uint32_t* wnz,
+                           const float* alpha, const float* bias, const float* post_scale,
+                           float* out, const bnn_hip_fly_plan* plan, void* stream);
+
+/* fp32 NCHW in -> fp32 NCHW out.  ONE launch (bnn_hip_bconv2d_direct) wherever that path applies:
+ * bnn_hip_conv_workspace_bytes(d) is then 0 and `workspace` may be NULL.  For the remaining geometries (see above)
+ * it is pack_act + conv through `workspace` (bnn_hip_conv_workspace_bytes(d) bytes, 16-byte aligned).          */
 size_t bnn_hip_conv_workspace_bytes(const bnn_hip_conv_desc* d);
 int bnn_hip_bconv2d_f32(const bnn_hip_conv_desc* d, const float* x,
                         const uint32_t* wbits, const uint32_t* wnz,

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_require_loads_and_reports_abi():
     lib = native.require()
-    assert lib.bnn_hip_abi_version() == native.ABI_VERSION == 9
+    assert lib.bnn_hip_abi_version() == native.ABI_VERSION == 10
     assert lib.bnn_hip_status_string(0) == b"ok"
     assert b"invalid" in lib.bnn_hip_status_string(-1)
     assert isinstance(native.launch_count(), int)
@@ -78,9 +78,46 @@ def test_argument_validation_without_touching_the_gpu():
     assert lib.bnn_hip_bconv_grad_input_f32(16, 16, 16, 16, 16, 2, 64, 64, 8, 8, 3, 3, None) == -2   # stride 3
     assert lib.bnn_hip_bconv_grad_input_f32(16, 16, 16, 16, 16, 2, 64, 64, 8, 8, 1, 2, None) == -2   # strided 1x1
     assert lib.bnn_hip_bconv_grad_weight_f32(None, 16, 16, 1, 2, 64, 64, 8, 8, 3, 1, None) == -1
-    assert lib.bnn_hip_conv_workspace_bytes(ctypes.byref(d)) >= 2 * 64 * 8
+    assert lib.bnn_hip_conv_workspace_bytes(ctypes.byref(d)) == 0       # the layer is one launch: no workspace
+    assert lib.bnn_hip_bconv2d_direct(ctypes.byref(d), None, 0, None, None, None, None, None, None, None, None) == -1
+    assert lib.bnn_hip_bconv2d_direct(ctypes.byref(d), 16, 7, 16, 16, 16, None, None, 16, None, None) == -1   # dtype
+    assert lib.bnn_hip_bconv2d_direct_plan(ctypes.byref(d), None) == -1
     d.N = 0
     assert lib.bnn_hip_bconv2d(ctypes.byref(d), 16, 16, 16, 16, 16, None, None, 16, None) == -1
+
+
+def test_direct_layer_plans_fit_the_lds_and_cover_the_output():
+    """Host-side planner of the one-launch layer (bnn_hip_bconv2d_direct_plan): the band of a workgroup fits a CU's
+    160 KiB of LDS, the bands tile the output, and only geometries whose single output row cannot fit are refused."""
+    lib = native.require()
+
+    def plan(N, C, H, W, O, k, s=1, p=0, dil=1):
+        d = native.ConvDesc(N, C, H, W, O, k, k, s, s, p, p, dil, dil, 0)
+        pl = native.FlyPlan()
+        st = lib.bnn_hip_bconv2d_direct_plan(ctypes.byref(d), ctypes.byref(pl))
+        return st, pl, d
+
+    # BASELINE config 2: one whole image per workgroup (58 x 58 cells x 32 B = 107.6 KB), 16 waves, 256 bands
+    st, pl, _ = plan(256, 128, 56, 56, 128, 3, 1, 1)
+    assert st == 0 and (pl.images_per_band, pl.rows_per_band, pl.waves, pl.n_bands) == (1, 56, 16, 256)
+    assert 58 * 58 * 32 <= pl.lds_bytes <= 58 * 58 * 32 + 1024 and pl.blocks_per_unit == 2
+    shapes = [(256, 64, 56, 56, 64, 3, 1, 1), (256, 64, 56, 56, 128, 3, 2, 1), (256, 128, 28, 28, 128, 3, 1, 1),
+              (256, 256, 14, 14, 256, 3, 1, 1), (256, 512, 7, 7, 512, 3, 1, 1), (256, 256, 7, 7, 512, 1, 1, 0),
+              (1, 3, 11, 13, 16, 3, 1, 1), (2, 128, 40, 300, 64, 3, 1, 1), (1, 64, 12, 12, 16, 3, 1, 2, 2),
+              (4, 512, 224, 224, 64, 3, 1, 1), (7, 1024, 4, 4, 64, 1, 1, 0), (3, 32, 9, 9, 8, 5, 1, 2)]
+    for sh in shapes:
+        st, pl, d = plan(*sh)
+        assert st == 0, sh
+        assert 0 < pl.lds_bytes <= 160 * 1024 and 1 <= pl.waves <= 16 and pl.blocks_per_unit in (1, 2, 4)
+        ho = (d.H + 2 * d.pad_h - d.dil_h * (d.KH - 1) - 1) // d.stride_h + 1
+        assert 1 <= pl.rows_per_band <= ho and (pl.images_per_band == 1 or pl.rows_per_band == ho)
+        assert pl.n_bands == -(-d.N // pl.images_per_band) * -(-ho // pl.rows_per_band)
+        assert lib.bnn_hip_conv_workspace_bytes(ctypes.byref(d)) == 0
+    # several small images share a band; a 2000-pixel-wide 512-channel row does not fit at all
+    st, pl, _ = plan(4096, 512, 7, 7, 512, 3, 1, 1)
+    assert st == 0 and pl.images_per_band > 1
+    st, pl, d = plan(1, 512, 3, 2000, 32, 3, 1, 1)
+    assert st == -2 and lib.bnn_hip_conv_workspace_bytes(ctypes.byref(d)) > 0
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
