@@ -59,7 +59,8 @@ class WLayout(ctypes.Structure):
 class FlyPlan(ctypes.Structure):
     """``bnn_hip_fly_plan``"""
     _fields_ = [(n, ctypes.c_int32) for n in (
-        "images_per_band", "rows_per_band", "waves", "blocks_per_unit", "lds_bytes", "n_bands")]
+        "images_per_band", "rows_per_band", "waves", "blocks_per_unit", "pack_ahead", "fine_head", "fine_tail", "producers",
+        "lds_bytes", "n_bands")]
 
 
 class DevInfo(ctypes.Structure):

@@ -398,8 +398,13 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
         f2 y = __builtin_elementwise_fma(f2{e.alpha[o], e.alpha[o + 1]}, dot_pair(j),
                                          hb ? f2{e.bias[o], e.bias[o + 1]} : f2{0.0f, 0.0f});
         if (hs) y *= f2{e.scale[o], e.scale[o + 1]};
+#ifdef BNN_EXP_NOSTORE  // experiment (tools/fly_variants.sh): compute everything, store (almost) nothing
+        if (y.x == 12345.678f)
+#endif
+        {
         buf_st(make_rsrc(e.out), lane_off, (unsigned)(o + g.c_off) * (unsigned)hw * 4u, y.x);
         buf_st(make_rsrc(e.out), lane_off, (unsigned)(o + 1 + g.c_off) * (unsigned)hw * 4u, y.y);
+        }
       }
       return;
     }
@@ -669,13 +674,21 @@ constexpr int pick_wblock(int total) {
 // USEED: the counts start from the wave-uniform `useed` (single-chunk kernels) instead of from acc[].
 // ONECHAIN: one popcount chain per channel instead of an even and an odd one (no t0 + t1 add at the end; the
 // threshold epilogue then needs three instructions per channel).
-template <int NW, int NACC, bool NN = false, bool USEED = false, bool ONECHAIN = false>
+// ILP: words whose v_bitop3 are issued back to back BEFORE their v_bcnt (1 = each v_bcnt right behind the v_bitop3 it
+// depends on: fine when several waves interleave on the SIMD, but a wave that runs alone — the others blocked on
+// memory, or gone at the tail of a workgroup — then waits out the VALU latency on every pair).
+#ifndef BNN_STREAM_ILP
+#define BNN_STREAM_ILP 1
+#endif
+template <int NW, int NACC, bool NN = false, bool USEED = false, bool ONECHAIN = false, int ILP = BNN_STREAM_ILP>
 __device__ __forceinline__ void stream_weights(const uint32_t* __restrict__ wrun,
                                                const uint32_t (&pr)[NW], const uint32_t (&mr)[NW],
                                                int (&acc)[NACC], [[maybe_unused]] int useed = 0) {
   constexpr int WB = pick_wblock(NACC * NW);
   constexpr int NB = NACC * NW / WB;
   static_assert((NACC * NW) % WB == 0, "weight run must be a whole number of blocks");
+  static_assert(ILP == 1 || ILP == 2 || ILP == 4, "words per group");
+  static_assert(WB % ILP == 0, "whole groups per block");
   WStream<WB> cur;
   load_wblock<WB>(wrun, cur);
   int t0 = 0, t1 = 0;  // two accumulation chains per channel (even / odd words)
@@ -689,23 +702,35 @@ __device__ __forceinline__ void stream_weights(const uint32_t* __restrict__ wrun
     WStream<WB> nxt;
     if constexpr (b + 1 < NB) load_wblock<WB>(wrun + (b + 1) * WB, nxt);
     __builtin_amdgcn_sched_barrier(0);
-    static_for<WB>([&](auto ec) {
-      constexpr int e = decltype(ec)::value;
-      constexpr int f = b * WB + e;
-      constexpr int j = f / NW, i = f % NW;
-      const uint32_t d = NN ? (cur.v[e] & pr[i]) : disagree(cur.v[e], mr[i], pr[i]);
-      if constexpr (ONECHAIN) {
-        acc[j] = (USEED && i == 0) ? popc_acc_s(d, useed) : popc_acc(d, acc[j]);
-        (void)t0; (void)t1;
-        return;
-      }
-      // the even chain continues from the running count (acc[j]: 0, the count seed, or the previous chunks' sum); the
-      // first word of the odd chain uses the inline-constant form (v_bcnt d, 0)
-      if constexpr (i == 0) t0 = USEED ? popc_acc_s(d, useed) : popc_acc(d, acc[j]);
-      else if constexpr (i == 1) t1 = __builtin_popcount(d);
-      else if constexpr (i & 1) t1 = popc_acc(d, t1);
-      else t0 = popc_acc(d, t0);
-      if constexpr (i == NW - 1) acc[j] = t0 + (NW > 1 ? t1 : 0);
+    static_for<WB / ILP>([&](auto gc) {
+      constexpr int e0 = decltype(gc)::value * ILP;
+      uint32_t d[ILP];
+      static_for<ILP>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int i = (b * WB + e0 + k) % NW;
+        d[k] = NN ? (cur.v[e0 + k] & pr[i]) : disagree(cur.v[e0 + k], mr[i], pr[i]);
+      });
+#if defined(__HIP_DEVICE_COMPILE__)
+      if constexpr (ILP == 2) asm volatile("" : "+v"(d[0]), "+v"(d[1]));
+      if constexpr (ILP == 4) asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+#endif
+      static_for<ILP>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int f = b * WB + e0 + k;
+        constexpr int j = f / NW, i = f % NW;
+        if constexpr (ONECHAIN) {
+          acc[j] = (USEED && i == 0) ? popc_acc_s(d[k], useed) : popc_acc(d[k], acc[j]);
+          (void)t0; (void)t1;
+        } else {
+          // the even chain continues from the running count (acc[j]: 0, the count seed, or the previous chunks' sum);
+          // the first word of the odd chain uses the inline-constant form (v_bcnt d, 0)
+          if constexpr (i == 0) t0 = USEED ? popc_acc_s(d[k], useed) : popc_acc(d[k], acc[j]);
+          else if constexpr (i == 1) t1 = __builtin_popcount(d[k]);
+          else if constexpr (i & 1) t1 = popc_acc(d[k], t1);
+          else t0 = popc_acc(d[k], t0);
+          if constexpr (i == NW - 1) acc[j] = t0 + (NW > 1 ? t1 : 0);
+        }
+      });
     });
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (b + 1 < NB) cur = nxt;

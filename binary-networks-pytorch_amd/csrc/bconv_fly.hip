@@ -11,25 +11,32 @@
 //   * workgroup = ONE BAND of the output: `kimg` whole images, or `BR` output rows of one image.  Its input window
 //     (band rows + halo, zero padding materialised as zero cells) lives in LDS as sign planes:
 //         cell(slab, row, col) = 2 x cw32 words;  layout [plane][chunk][cell][cwc words]  (a lane's receptive field
-//         is `taps` ds_read_b128, consecutive lanes = consecutive cells: conflict-free)
-//   * the waves of the workgroup are identical workers driven by two ticket counters in LDS — no barrier after the
-//     initial zero fill:
+//         is `taps` ds_read_b128, consecutive lanes = consecutive cells: conflict-free), plus one counter per cell:
+//         its non-zero channels (the window's count is `taps` loads and adds instead of 2 VALU per field word)
+//   * two ticket counters in LDS drive the waves — no barrier after the initial zero fill:
 //       - PACK items   (64 consecutive input pixels x one 32-channel word): lane = pixel, 32 coalesced dword loads
-//         (buffer loads: per-channel offset in an SGPR), sign bits by v_alignbit_b32, non-zero bits by
+//         (buffer loads: per-channel offset in an SGPR, non-temporal), sign bits by v_alignbit_b32, non-zero bits by
 //         v_cmp_class_f32 + v_addc_co_u32 (NaN / +-0 -> neither plane, denormals keep their sign), two ds_write_b32,
 //         then ready[pixel group] += 1 (release)
-//       - CONV units   (64 consecutive output pixels x OBW 32-channel blocks): wait until the ready counters of the
-//         input pixel groups under the unit's receptive fields are complete (acquire), load the field from LDS into
-//         registers, then exactly the main loop of bconv_sgpr_kernel: weights through the scalar cache into SGPRs,
-//         v_bitop3_b32 + v_bcnt_u32_b32, fmaf epilogue, coalesced NCHW stores
-//     A wave takes a unit ticket, first packs until the pack tickets are `ahead` pixel groups in front of its unit,
-//     and — should its inputs still be missing — keeps packing while it waits: whoever waits works, so the scheme
-//     cannot deadlock, and the HBM latency of one wave's packing hides under the popcount loops of the other waves
-//     of its SIMD (4 per SIMD).  The input is read from HBM exactly once per band (halo rows of a row-split band
-//     twice).
+//       - CONV units   (64 consecutive output pixels x a run of 8-channel passes): wait until the ready counters of
+//         the input pixel groups under the unit's receptive fields are complete (acquire), load the field from LDS
+//         into registers, then exactly the main loop of bconv_sgpr_kernel: weights through the scalar cache into
+//         SGPRs, v_bitop3_b32 + v_bcnt_u32_b32, fmaf epilogue, coalesced NCHW stores
+//   * PRODUCER waves (the first `nprod` of the workgroup) take pack tickets front to back as fast as HBM delivers, then
+//     join the others; the other waves take unit tickets and only pack while they have to WAIT for their inputs
+//     (start-up): whoever waits works, so the scheme cannot deadlock.  Producers never store and consumers (almost)
+//     never load: gfx950 counts loads and stores in ONE counter (vmcnt), so a wave that mixes them waits for its
+//     stores' acknowledgements whenever it needs a loaded value (measured: packing between the popcount passes of a
+//     wave — "asynchronous", loads landing under the next pass — was 15 % SLOWER than dedicated producers).
+//   * wave-uniform state is NOT kept across a unit: the popcount loop owns 64 of the ~100 SGPRs for the weight
+//     stream, and everything else alive across it was spilled to VGPR lanes and read back with v_readlane — ~200
+//     VALU instructions per unit.  Each iteration re-reads what it needs from the kernel-argument segment instead
+//     (s_load, no VALU): fresh_geo().
+//   The input is read from HBM exactly once per band (halo rows of a row-split band twice).
 #include <hip/hip_fp16.h>
 
 #include <algorithm>
+#include <cstddef>
 
 #include "bconv_core.h"
 
@@ -44,12 +51,70 @@ struct FlyGeo {
   int kimg, BR, nbi;     // band: whole images per band | output rows per band, bands per image
   int HPS, WP, ncell;    // LDS slab: rows per image, row pitch (cells), cells per band
   int prr;               // kimg > 1: real input pixels per image slab
-  int nobu;              // work units per pixel group: ceil(ceil(O / 32) / OBW)
-  int ahead;             // pixel groups the packing is kept in front of a unit
-  unsigned off_ready, off_P, off_M, lds16;  // byte offsets into the dynamic LDS; total size in 16-byte pieces
-  uint32_t m_nwords, m_W, m_prr, m_nobu;
-  int s_nwords, s_W, s_prr, s_nobu;
+  // work units, in PASSES of the kernel (a pass = 32 / ppb output channels of one 32-channel block):
+  int ppb;               // passes per 32-channel block (the kernel's PASSES)
+  int npp;               // passes per pixel group: ceil(O / 32) * ppb
+  int cpu;               // passes per COARSE unit (blocks_per_unit * ppb): one load of the field
+  int nobu;              // coarse units per pixel group: ceil(npp / cpu)
+  int fine_head, fine_tail;  // pixel groups at the start / end of a band whose units are single passes: the first
+                             // rows get all waves at once (they are all that is packed yet), the last ones even out
+                             // the waves' finishing times
+  int ahead;             // no producer waves: pixel groups the packing is kept in front of a unit
+  int nprod;             // producer waves per workgroup
+  unsigned off_ready, off_P, off_M, off_cnt, lds16;  // byte offsets into the dynamic LDS; total size / 16
+  uint32_t m_nwords, m_W, m_prr, m_nobu, m_cwc, m_npp;
+  int s_nwords, s_W, s_prr, s_nobu, s_cwc, s_npp;
 };
+
+// The kernels' arguments: seven pointers (kept as __restrict__ kernel parameters: the compiler must know that the
+// weights are not written by the launch to stream them through the scalar cache), then the two geometry blocks —
+// which the kernels never touch through their formal parameters: fresh_geo() re-reads them.
+struct FlyPtrs {
+  const void* x;        // activations: fp32 / fp16 NCHW
+  const uint32_t* W;    // packed weights (bnn_hip_pack_weight_f32)
+  const uint32_t* Z;    // their non-zero mask (BNN_HIP_FLAG_WEIGHT_ZEROS)
+  const float* alpha;
+  const float* bias;
+  const float* scale;
+  void* out;
+};
+struct FlyArgs {   // = the layout of the kernel-argument segment
+  FlyPtrs ptr;
+  Geo g;
+  FlyGeo f;
+};
+struct FlyGeos {
+  Geo g;
+  FlyGeo f;
+};
+#define BNN_FLY_PARAMS                                                                                   \
+  const void *__restrict__ x, const uint32_t *__restrict__ W, const uint32_t *__restrict__ Z,            \
+      const float *__restrict__ alpha, const float *__restrict__ bias, const float *__restrict__ scale,  \
+      void *__restrict__ out, const Geo, const FlyGeo
+#define BNN_FLY_PTRS FlyPtrs{x, W, Z, alpha, bias, scale, out}
+
+// The geometry, re-read from the kernel-argument segment (constant address space: uniform loads from it are s_load
+// instructions; only the fields a caller uses survive).  The empty asm makes the pointer a NEW value for the
+// optimiser at every call, so that the loads are neither hoisted out of the unit loop nor kept alive across the
+// popcount loop.
+__device__ __forceinline__ FlyGeos fresh_geo() {
+  FlyGeos a;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const uint32_t __attribute__((address_space(4))) * KWords;
+  KWords p = (KWords)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  static_assert(sizeof(FlyGeos) % 4 == 0 && offsetof(FlyArgs, g) % 4 == 0, "whole dwords");
+  static_assert(offsetof(FlyArgs, g) == sizeof(FlyPtrs) && offsetof(FlyArgs, f) == sizeof(FlyPtrs) + sizeof(Geo) &&
+                    alignof(Geo) == 4 && alignof(FlyGeo) == 4 && offsetof(FlyGeos, f) == sizeof(Geo),
+                "the geometry blocks follow the seven pointers without padding, as the kernel parameters do");
+  uint32_t* d = reinterpret_cast<uint32_t*>(&a);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(FlyGeos) / 4; ++i) d[i] = p[offsetof(FlyArgs, g) / 4 + i];
+#else
+  a = FlyGeos{};
+#endif
+  return a;
+}
 
 // One band (wave-uniform).
 struct Band {
@@ -121,12 +186,16 @@ __device__ __forceinline__ uint32_t take_ticket(uint32_t* ctr, int lane) {
 
 constexpr int kClassNonzero = kClassPos | kClassNeg;  // finite non-zero or infinite: sign(x) != 0
 
+#ifndef BNN_FLY_LOAD_AUX  // cache policy of the activation loads: 2 = nt on gfx950 (the tensor is read exactly once;
+#define BNN_FLY_LOAD_AUX 2  // measured on config 2: 254 us with nt, 269 us with the default policy)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint32_t buf_ld_u32s(BufRsrc r, unsigned lane_boff, unsigned chan_boff) {
-  return __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_boff, (int)chan_boff, 0);
+  return __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_boff, (int)chan_boff, BNN_FLY_LOAD_AUX);
 }
 __device__ __forceinline__ uint32_t buf_ld_u16s(BufRsrc r, unsigned lane_boff, unsigned chan_boff) {
-  return (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, (int)lane_boff, (int)chan_boff, 0);
+  return (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, (int)lane_boff, (int)chan_boff,
+                                                                        BNN_FLY_LOAD_AUX);
 }
 // One fp32 element into the two running words of its pixel:
 //     s = 2 * s + (x >> 31)          sign bit                     v_alignbit_b32 on the pair {s, x}
@@ -151,58 +220,66 @@ __device__ __forceinline__ void shift_in_f32(uint32_t& s, uint32_t& z, uint32_t 
 }
 #endif
 
-// sign() of one 32-channel word of 64 consecutive input pixels (lane = pixel): P / M bits of channels c0 .. c0+31
-// (channel c0 + b in bit b; channels >= C: 0).  All loads of the word are in flight at once.
-//   fp32: S = sign bits, Z = "sign(x) != 0" bits (shift_in_f32: three VALU instructions per element);
-//         P = Z & ~S, M = Z & S.  -0.0 and NaN have Z = 0, denormals Z = 1: the planes of
-//         pack_act_kernel bit for bit.
+// What a wave needs to take part in the band's dataflow (LDS pointers; rebuilt per unit).
+struct FlyCtx {
+  uint32_t* ctl;        // [0] unit tickets, [1] pack tickets
+  uint32_t* ready;      // per input pixel group: words packed so far
+  uint32_t* ldsP;
+  uint32_t* ldsM;
+  uint32_t* cnt;        // per cell: channels with sign(x) != 0
+  int lane;
+  int nitems;
+};
+
+__device__ __forceinline__ FlyCtx make_ctx(const FlyGeo& f, const Band& B, unsigned char* smem, int lane) {
+  FlyCtx c;
+  c.ctl = reinterpret_cast<uint32_t*>(smem);
+  c.ready = reinterpret_cast<uint32_t*>(smem + f.off_ready);
+  c.ldsP = reinterpret_cast<uint32_t*>(smem + f.off_P);
+  c.ldsM = reinterpret_cast<uint32_t*>(smem + f.off_M);
+  c.cnt = reinterpret_cast<uint32_t*>(smem + f.off_cnt);
+  c.lane = lane;
+  c.nitems = B.nipg * f.nwords;
+#ifdef BNN_FLY_EXP_SKIP_PACK
+  c.nitems = 0;
+#endif
+  return c;
+}
+
+// sign() of the 32 channels c0 .. c0+31 of 64 consecutive input pixels (lane = pixel), all 32 loads in flight at once:
+// P / M bits with channel c0 + b in bit b.
+//   fp32: s = sign bits, z = "sign(x) != 0" bits (shift_in_f32: three VALU instructions per element), P = z & ~s,
+//         M = z & s.  -0.0 and NaN have z = 0, denormals z = 1: the planes of pack_act_kernel bit for bit.
 //   fp16: the class test of the exactly widened value (what pack_act_kernel<__half> does).
+// A word at the channel tail re-reads channel C-1 for its missing channels (valid memory, no branches); the caller
+// clears their bits.
 template <bool HALF>
 __device__ __forceinline__ void pack_word(BufRsrc rx, unsigned voff, int c0, int C, unsigned chan_bytes,
                                           uint32_t& P, uint32_t& M) {
-  // a word at the channel tail re-reads channel C-1 for its missing channels (valid memory, no branches) and
-  // clears their bits afterwards
   uint32_t v[32];
 #pragma unroll
   for (int b = 0; b < 32; ++b) {
     const unsigned so = (unsigned)min(c0 + b, C - 1) * chan_bytes;
     v[b] = HALF ? buf_ld_u16s(rx, voff, so) : buf_ld_u32s(rx, voff, so);
   }
-  const int nch = C - c0;
-  const uint32_t keep = nch >= 32 ? 0xFFFFFFFFu : ((1u << nch) - 1u);
-  if constexpr (HALF) {
-    uint32_t p = 0u, m = 0u;
+  uint32_t s = 0u, z = 0u;
 #pragma unroll
-    for (int b = 31; b >= 0; --b) {
+  for (int b = 31; b >= 0; --b) {
+    if constexpr (HALF) {
       const float u = __half2float(__ushort_as_half((unsigned short)v[b]));
-      p = shift_in(p, is_pos(u));
-      m = shift_in(m, is_neg(u));
+      s = shift_in(s, is_pos(u));
+      z = shift_in(z, is_neg(u));
+    } else {
+      shift_in_f32(s, z, v[b], (uint32_t)kClassNonzero);
     }
-    P = p & keep;
-    M = m & keep;
-  } else {
-    uint32_t s = 0u, z = 0u;
-#pragma unroll
-    for (int b = 31; b >= 0; --b) shift_in_f32(s, z, v[b], (uint32_t)kClassNonzero);
-    z &= keep;
-    P = z & ~s;
-    M = z & s;
   }
+  P = HALF ? s : (z & ~s);
+  M = HALF ? z : (z & s);
 }
 
-// Everything a wave needs to take part in the band's dataflow.
-struct FlyCtx {
-  uint32_t* ctl;        // [0] unit tickets, [1] pack tickets
-  uint32_t* ready;      // per input pixel group: words packed so far
-  uint32_t* ldsP;
-  uint32_t* ldsM;
-  int lane;
-  int nitems;
-};
-
-// Pack one item if any is left; false when all items have been handed out.
-__device__ __forceinline__ bool pack_one(const Geo& g, const FlyGeo& f, const Band& B, const FlyCtx& c,
-                                         const void* __restrict__ x) {
+// Pack the next item if one is left (synchronously); false when all items have been handed out.
+__device__ __forceinline__ bool pack_item(const void* __restrict__ x, const Geo& g, const FlyGeo& f, const Band& B,
+                                          const FlyCtx& c) {
   if (__hip_atomic_load(&c.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)c.nitems) return false;
   const uint32_t t = take_ticket(&c.ctl[1], c.lane);
   if (t >= (uint32_t)c.nitems) return false;
@@ -219,19 +296,28 @@ __device__ __forceinline__ bool pack_one(const Geo& g, const FlyGeo& f, const Ba
   const int rowl = (int)fast_div((uint32_t)r, f.m_W, f.s_W);
   const int ix = r - rowl * g.Wd;
   const unsigned esz = f.in_half ? 2u : 4u;
+#ifdef BNN_FLY_EXP_SAMEIMG  // experiment: every band reads image 0 (the activations come out of L2 / MALL)
+  const unsigned elem = (unsigned)(B.iy_lo * g.Wd + r);
+#else
   const unsigned elem = (unsigned)(B.n0 + slab) * (unsigned)f.C * (unsigned)f.HW + (unsigned)(B.iy_lo * g.Wd + r);
+#endif
   const unsigned voff = valid ? elem * esz : 0xFFFFFFF0u;  // beyond the descriptor: the hardware returns 0
-  const int cell = (slab * f.HPS + (B.iy_lo - B.iy_base) + rowl) * f.WP + ix + g.pw;
+  const unsigned cell = (unsigned)((slab * f.HPS + (B.iy_lo - B.iy_base) + rowl) * f.WP + ix + g.pw);
   const BufRsrc rx = make_rsrc_sized(x, f.x_bytes);
-  const unsigned chan_bytes = (unsigned)f.HW * esz;
   uint32_t Pw, Mw;
-  if (f.in_half) pack_word<true>(rx, voff, w * 32, f.C, chan_bytes, Pw, Mw);
-  else pack_word<false>(rx, voff, w * 32, f.C, chan_bytes, Pw, Mw);
-  const int wch = w / f.cwc, wi = w - wch * f.cwc;
-  const unsigned a = (unsigned)(wch * f.ncell + cell) * (unsigned)f.cwc + (unsigned)wi;
+  if (f.in_half) pack_word<true>(rx, voff, w * 32, f.C, (unsigned)f.HW * 2u, Pw, Mw);
+  else pack_word<false>(rx, voff, w * 32, f.C, (unsigned)f.HW * 4u, Pw, Mw);
+  const int nch = f.C - w * 32;
+  const uint32_t keep = nch >= 32 ? 0xFFFFFFFFu : ((1u << nch) - 1u);
+  Pw &= keep;
+  Mw &= keep;
   if (valid) {
+    const int wch = (int)fast_div((uint32_t)w, f.m_cwc, f.s_cwc), wi = w - wch * f.cwc;
+    const unsigned a = ((unsigned)(wch * f.ncell) + cell) * (unsigned)f.cwc + (unsigned)wi;
     c.ldsP[a] = Pw;
     c.ldsM[a] = Mw;
+    __hip_atomic_fetch_add(&c.cnt[cell], (uint32_t)__builtin_popcount(Pw | Mw), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   // the cell writes of every lane precede the counter update in this wave's LDS instruction stream
   if (c.lane == 0) __hip_atomic_fetch_add(&c.ready[ipg], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -252,64 +338,136 @@ __device__ __forceinline__ bool range_ready(const FlyGeo& f, const FlyCtx& c, in
 #endif
 }
 
-// The dataflow skeleton: zero fill, then units until the tickets run out.  `conv(pg, obu)` computes one unit.
+#ifdef BNN_FLY_TIMING  // variant builds only (tools/exp_fly_timing.py): per-wave cycle stamps of the dataflow
+__device__ unsigned long long bnn_fly_dbg[8 * 16 * 4096];
+#define FLY_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define FLY_NOW() 0ull
+#endif
+
+// The dataflow skeleton: zero fill, producers, then units until the tickets run out.
+// `conv(g, f, B, c, pg, p0, np, lane)` computes one unit: passes p0 .. p0+np-1 of pixel group pg.
 template <class ConvUnit>
-__device__ __forceinline__ void fly_run(const Geo& g, const FlyGeo& f, const void* __restrict__ x,
-                                        unsigned char* smem, ConvUnit&& conv) {
+__device__ __forceinline__ void fly_run(const void* __restrict__ x, unsigned char* smem, ConvUnit&& conv) {
   const int tid = threadIdx.x, lane = tid & 63;
+  [[maybe_unused]] const unsigned long long t_entry = FLY_NOW();
+  [[maybe_unused]] unsigned long long t_first = 0, t_wait = 0, t_conv = 0, t_pack = 0, n_units = 0, n_items = 0;
   {  // zero padding cells, counters, tickets: the whole allocation
+    const unsigned n16 = fresh_geo().f.lds16;
     uint4* z = reinterpret_cast<uint4*>(smem);
     const uint4 zero = {0u, 0u, 0u, 0u};
-    for (unsigned i = tid; i < f.lds16; i += blockDim.x) z[i] = zero;
+    for (unsigned i = tid; i < n16; i += blockDim.x) z[i] = zero;
   }
   __syncthreads();
-  const Band B = make_band(g, f, blockIdx.x);
-  FlyCtx c;
-  c.ctl = reinterpret_cast<uint32_t*>(smem);
-  c.ready = reinterpret_cast<uint32_t*>(smem + f.off_ready);
-  c.ldsP = reinterpret_cast<uint32_t*>(smem + f.off_P);
-  c.ldsM = reinterpret_cast<uint32_t*>(smem + f.off_M);
-  c.lane = lane;
-  c.nitems = B.nipg * f.nwords;
-  const int nunits = B.npg * f.nobu;
+#ifdef BNN_FLY_EXP_SKIP_PACK  // experiment: the convolution alone (on an all-zero tile)
+  {
+    const FlyGeos A = fresh_geo();
+    const Band B = make_band(A.g, A.f, blockIdx.x);
+    uint32_t* ready = reinterpret_cast<uint32_t*>(smem + A.f.off_ready);
+    for (int i = tid; i < B.nipg; i += blockDim.x) ready[i] = (uint32_t)A.f.nwords;
+    __syncthreads();
+  }
+#endif
+  [[maybe_unused]] const unsigned long long t_zero = FLY_NOW();
+  {  // PRODUCER waves: the band front to back, as fast as HBM delivers; then they join the others
+    const FlyGeos A = fresh_geo();
+    if ((tid >> 6) < A.f.nprod) {
+      const Band B = make_band(A.g, A.f, blockIdx.x);
+      const FlyCtx c = make_ctx(A.f, B, smem, lane);
+      while (pack_item(x, A.g, A.f, B, c)) {
+#ifdef BNN_FLY_TIMING
+        ++n_items;
+#endif
+      }
+#ifdef BNN_FLY_TIMING
+      t_pack = FLY_NOW() - t_zero;
+#endif
+    }
+  }
   for (;;) {
+    const FlyGeos A = fresh_geo();
+    const Geo& g = A.g;
+    const FlyGeo& f = A.f;
+    const Band B = make_band(g, f, blockIdx.x);
+    const FlyCtx c = make_ctx(f, B, smem, lane);
+    // units: single passes over the first `fine_head` and the last `fine_tail` pixel groups, coarse units between
+    const int pg_head = min(f.fine_head, B.npg), pg_tail = min(f.fine_tail, B.npg - pg_head);
+    const int u_head = pg_head * f.npp, u_mid = (B.npg - pg_head - pg_tail) * f.nobu;
+    const int nunits = u_head + u_mid + pg_tail * f.npp;
     const uint32_t u = take_ticket(&c.ctl[0], lane);
     if (u >= (uint32_t)nunits) break;
-    const int pg = (int)fast_div(u, f.m_nobu, f.s_nobu);
-    const int obu = (int)u - pg * f.nobu;
-    // keep the packing `ahead` pixel groups in front of this unit, and wait for the unit's own inputs; a wave that
-    // has to wait packs meanwhile (one call site: the packing code exists once per kernel)
+    int pg, p0, np;  // pixel group, first pass, passes
+    if (u < (uint32_t)u_head || u >= (uint32_t)(u_head + u_mid)) {
+      const uint32_t v = u < (uint32_t)u_head ? u : u - (uint32_t)(u_head + u_mid);
+      const int q = (int)fast_div(v, f.m_npp, f.s_npp);
+      pg = (u < (uint32_t)u_head ? 0 : B.npg - pg_tail) + q;
+      p0 = (int)v - q * f.npp;
+      np = 1;
+    } else {
+      const uint32_t v = u - (uint32_t)u_head;
+      const int q = (int)fast_div(v, f.m_nobu, f.s_nobu);
+      pg = pg_head + q;
+      p0 = ((int)v - q * f.nobu) * f.cpu;
+      np = min(f.cpu, f.npp - p0);
+    }
     int lo, hi;
-    need_range(g, f, B, min(pg + f.ahead, B.npg - 1), lo, hi);
-    const uint32_t want = (uint32_t)min((hi + 1) * f.nwords, c.nitems);
-    need_range(g, f, B, pg, lo, hi);
+    uint32_t want = 0u;  // without producer waves: pack tickets that should have been handed out by now
+    if (f.nprod == 0) {
+      need_range(g, f, B, min(pg + f.ahead, B.npg - 1), lo, hi);
+      want = (uint32_t)min((hi + 1) * f.nwords, c.nitems);
+    }
+    need_range(g, f, B, pg, lo, hi);  // this unit's own inputs
+    [[maybe_unused]] const unsigned long long t_u0 = FLY_NOW();
     for (unsigned idle = 0;;) {
       if (__hip_atomic_load(&c.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want &&
           range_ready(f, c, lo, hi))
         break;
-      if (!pack_one(g, f, B, c, x)) {
+      if (pack_item(x, g, f, B, c)) {  // whoever waits works
+#ifdef BNN_FLY_TIMING
+        ++n_items;
+#endif
+      } else {
         // every item has been handed out: the missing ones are in flight in other waves (a few microseconds).
         // Watchdog: seconds of idling can only mean a lost update — abort the launch loudly rather than hang.
         __builtin_amdgcn_s_sleep(8);
         if (++idle > (1u << 24)) __builtin_trap();
       }
     }
-    conv(B, c, pg, obu, lane);
+#ifdef BNN_FLY_TIMING
+    const unsigned long long t_c0 = FLY_NOW();
+    if (!t_first) t_first = t_c0;
+    t_wait += t_c0 - t_u0;
+#endif
+    conv(g, f, B, c, pg, p0, np, lane);
+#ifdef BNN_FLY_TIMING
+    t_conv += FLY_NOW() - t_c0;
+    ++n_units;
+#endif
   }
+#ifdef BNN_FLY_TIMING
+  if (lane == 0 && blockIdx.x < 4096) {
+    unsigned long long* d = bnn_fly_dbg + ((size_t)blockIdx.x * 16 + (tid >> 6)) * 8;
+    d[0] = t_entry; d[1] = t_zero; d[2] = t_first; d[3] = FLY_NOW(); d[4] = t_wait; d[5] = t_conv;
+    d[6] = t_pack; d[7] = (n_units << 32) | n_items;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------
 // Tiled unit: the main loop of bconv_sgpr_kernel on a field read from LDS.
 //   MULTI: walk the chunks (C > 32 * CWC, and every 1x1 layer: PASSES = 1, 32 accumulators)
 //   WZ:    zero weights (second scalar stream with the non-zero mask), 4 passes of 8 channels
-//   OBW:   32-channel blocks per unit (one field load, single-chunk layers only)
 // ---------------------------------------------------------------------------------
-template <int KH, int KW, int CWC, bool MULTI, bool WZ, int OBW>
+#ifndef BNN_FLY_ILP  // words per group of the popcount loop (stream_weights<..., ILP>)
+#define BNN_FLY_ILP 2
+#endif
+constexpr int kIlp = BNN_FLY_ILP;
+
+template <int KH, int KW, int CWC, bool MULTI, bool WZ>
 struct TiledUnit {
   static constexpr int T = KH * KW, NW = T * CWC;
   static constexpr int PASSES = WZ ? 4 : (MULTI ? 1 : (T > 1 ? 4 : 1));
   static constexpr int NACC = kOCB / PASSES;
-  static_assert(OBW == 1 || !MULTI, "several blocks per unit: single-chunk layers only");
 
   template <int N>
   __device__ static __forceinline__ void lds_words(const uint32_t* base, unsigned word_off, uint32_t* dst) {
@@ -325,80 +483,82 @@ struct TiledUnit {
     }
   }
 
-  __device__ static __forceinline__ void load_chunk(const FlyGeo& f, const FlyCtx& c, unsigned cell0, int ch,
+  __device__ static __forceinline__ void load_chunk(const FlyCtx& c, unsigned cell0, unsigned chunk_cells, int WP,
                                                     uint32_t (&pr)[NW], uint32_t (&mr)[NW]) {
-    const unsigned base = (unsigned)ch * (unsigned)f.ncell + cell0;
+    const unsigned base = chunk_cells + cell0;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const unsigned wo = (base + (unsigned)((t / KW) * f.WP + (t % KW))) * CWC;
+      const unsigned wo = (base + (unsigned)((t / KW) * WP + (t % KW))) * CWC;
       lds_words<CWC>(c.ldsP, wo, &pr[t * CWC]);
       lds_words<CWC>(c.ldsM, wo, &mr[t * CWC]);
     }
   }
 
-  __device__ static __forceinline__ void run(const Geo& g, const FlyGeo& f, const EpiArgs& epi,
-                                             const uint32_t* __restrict__ W, const uint32_t* __restrict__ Z,
-                                             const Band& B, const FlyCtx& c, int pg, int obu, int lane) {
+  // One unit: passes p0 .. p0+np-1 of pixel group `pg` (pass p = channels (p % PASSES) * NACC .. of block p / PASSES).
+  __device__ static __forceinline__ void run(const FlyPtrs& P, const Geo& g, const FlyGeo& f, const Band& B,
+                                             const FlyCtx& c, int pg, int p0, int np, int lane) {
+#ifdef BNN_FLY_EXP_SKIP_CONV  // experiment: the packing pipeline alone
+    return;
+#endif
+    const EpiArgs epi{P.alpha, P.bias, P.scale, nullptr, nullptr, nullptr, nullptr, P.out,
+                      nullptr, nullptr, nullptr, nullptr, nullptr};
     const int jl = min((pg << 6) + lane, B.npix - 1);  // lanes past the band's last pixel copy it (same stores)
     const Pix px = decode_pixel<true>(g, B.q0 + jl);
-    const unsigned cell0 = (unsigned)(((px.n - B.n0) * f.HPS + (px.oy - B.oy0) * g.sh) * f.WP + px.ox * g.sw);
+    const int WP = f.WP, ncell = f.ncell;
+    const unsigned cell0 = (unsigned)(((px.n - B.n0) * f.HPS + (px.oy - B.oy0) * g.sh) * WP + px.ox * g.sw);
     uint32_t pr[NW], mr[NW];
-    int nz = 0;
-    if constexpr (!MULTI) {
-      load_chunk(f, c, cell0, 0, pr, mr);
-      if constexpr (!WZ) nz = count_nonzero<NW>(pr, mr, 0);
+    int nz = 0;  // non-zero inputs under the window: the per-cell counters of the taps
+    if constexpr (!WZ) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) nz += (int)c.cnt[cell0 + (unsigned)((t / KW) * WP + (t % KW))];
     }
+    if constexpr (!MULTI) load_chunk(c, cell0, 0u, WP, pr, mr);
 #pragma unroll 1
-    for (int obi = 0; obi < OBW; ++obi) {
-      const int ob = obu * OBW + obi;
-      if (ob * kOCB >= g.O) break;
-      const uint32_t* wblk = W + (size_t)ob * g.nchunk * (kOCB * NW);
-      const uint32_t* zblk = WZ ? Z + (size_t)ob * g.nchunk * (kOCB * NW) : nullptr;
+    for (int p = p0; p < p0 + np; ++p) {
+      const int ob = PASSES == 1 ? p : p / PASSES, ps = PASSES == 1 ? 0 : p - ob * PASSES;
+      const uint32_t* wblk = P.W + (size_t)ob * g.nchunk * (kOCB * NW);
+      const uint32_t* zblk = WZ ? P.Z + (size_t)ob * g.nchunk * (kOCB * NW) : nullptr;
       const bool fullb = (ob + 1) * kOCB <= g.O;
-      if constexpr (MULTI) nz = 0;
-#pragma unroll 1
-      for (int ps = 0; ps < PASSES; ++ps) {
-        int acc[NACC];
-        [[maybe_unused]] int nzacc[NACC];
-        float resv[NACC];
-        constexpr bool SEEDED = !WZ && NACC % 2 == 0;
+      int acc[NACC];
+      [[maybe_unused]] int nzacc[NACC];
+      float resv[NACC];
+      constexpr bool SEEDED = !WZ && NACC % 2 == 0;
+#pragma unroll
+      for (int j = 0; j < NACC; ++j) {
+        acc[j] = SEEDED ? (int)kCountSeed : 0;
+        resv[j] = 0.0f;
+        if constexpr (WZ) nzacc[j] = 0;
+      }
+      if constexpr (MULTI) {
+        for (int ch = 0; ch < g.nchunk; ++ch) {
+          load_chunk(c, cell0, (unsigned)(ch * ncell), WP, pr, mr);
+          const size_t woff = ((size_t)ch * kOCB + ps * NACC) * NW;
+          if constexpr (WZ) stream_weights_wz<NW, NACC>(wblk + woff, zblk + woff, pr, mr, acc, nzacc);
+          else stream_weights<NW, NACC, false, false, false, kIlp>(wblk + woff, pr, mr, acc);
+        }
+      } else {
+        const size_t woff = (size_t)ps * (NACC * NW);
+        if constexpr (WZ) stream_weights_wz<NW, NACC>(wblk + woff, zblk + woff, pr, mr, acc, nzacc);
+        else stream_weights<NW, NACC, false, true, false, kIlp>(wblk + woff, pr, mr, acc,
+                                                                SEEDED ? (int)kCountSeed : 0);
+      }
+      const int o0 = ob * kOCB + ps * NACC;
+      uint32_t pbits = 0u, mbits = 0u;  // (no packed output here)
+      if (fullb) {
+        if constexpr (SEEDED) {
+          epilogue<NACC, EP_PLAIN, true, true>(g, px, o0, acc, resv, epi, pbits, mbits, 0, -2.0f, (float)nz);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NACC; ++j) acc[j] = WZ ? nzacc[j] - 2 * acc[j] : nz - 2 * acc[j];
+          epilogue<NACC, EP_PLAIN, true>(g, px, o0, acc, resv, epi, pbits, mbits);
+        }
+      } else {
 #pragma unroll
         for (int j = 0; j < NACC; ++j) {
-          acc[j] = SEEDED ? (int)kCountSeed : 0;
-          resv[j] = 0.0f;
-          if constexpr (WZ) nzacc[j] = 0;
+          if constexpr (SEEDED) acc[j] -= (int)kCountSeed;
+          acc[j] = WZ ? nzacc[j] - 2 * acc[j] : nz - 2 * acc[j];
         }
-        if constexpr (MULTI) {
-          for (int ch = 0; ch < g.nchunk; ++ch) {
-            load_chunk(f, c, cell0, ch, pr, mr);
-            if (!WZ && ps == 0) nz = count_nonzero<NW>(pr, mr, nz);
-            const size_t woff = ((size_t)ch * kOCB + ps * NACC) * NW;
-            if constexpr (WZ) stream_weights_wz<NW, NACC>(wblk + woff, zblk + woff, pr, mr, acc, nzacc);
-            else stream_weights<NW, NACC>(wblk + woff, pr, mr, acc);
-          }
-        } else {
-          const size_t woff = (size_t)ps * (NACC * NW);
-          if constexpr (WZ) stream_weights_wz<NW, NACC>(wblk + woff, zblk + woff, pr, mr, acc, nzacc);
-          else stream_weights<NW, NACC, false, true>(wblk + woff, pr, mr, acc, SEEDED ? (int)kCountSeed : 0);
-        }
-        const int o0 = ob * kOCB + ps * NACC;
-        uint32_t pbits = 0u, mbits = 0u;  // (no packed output here)
-        if (fullb) {
-          if constexpr (SEEDED) {
-            epilogue<NACC, EP_PLAIN, true, true>(g, px, o0, acc, resv, epi, pbits, mbits, 0, -2.0f, (float)nz);
-          } else {
-#pragma unroll
-            for (int j = 0; j < NACC; ++j) acc[j] = WZ ? nzacc[j] - 2 * acc[j] : nz - 2 * acc[j];
-            epilogue<NACC, EP_PLAIN, true>(g, px, o0, acc, resv, epi, pbits, mbits);
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < NACC; ++j) {
-            if constexpr (SEEDED) acc[j] -= (int)kCountSeed;
-            acc[j] = WZ ? nzacc[j] - 2 * acc[j] : nz - 2 * acc[j];
-          }
-          epilogue<NACC, EP_PLAIN>(g, px, o0, acc, resv, epi, pbits, mbits);
-        }
+        epilogue<NACC, EP_PLAIN>(g, px, o0, acc, resv, epi, pbits, mbits);
       }
     }
   }
@@ -406,75 +566,82 @@ struct TiledUnit {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fly_smem[];
 
-#define BNN_FLY_PARAMS                                                                                   \
-  const void *__restrict__ x, const uint32_t *__restrict__ W, const uint32_t *__restrict__ Z,            \
-      const float *__restrict__ alpha, const float *__restrict__ bias, const float *__restrict__ scale,  \
-      void *__restrict__ out, const Geo g, const FlyGeo f
-
-template <int KH, int KW, int CWC, bool MULTI, bool WZ, int OBW>
+template <int KH, int KW, int CWC, bool MULTI, bool WZ>
 __global__ __launch_bounds__(1024) void bconv_fly_kernel(BNN_FLY_PARAMS) {
-  EpiArgs epi{alpha, bias, scale, nullptr, nullptr, nullptr, nullptr, out, nullptr, nullptr, nullptr, nullptr, nullptr};
-  fly_run(g, f, x, fly_smem, [&](const Band& B, const FlyCtx& c, int pg, int obu, int lane) {
-    TiledUnit<KH, KW, CWC, MULTI, WZ, OBW>::run(g, f, epi, W, Z, B, c, pg, obu, lane);
-  });
+  const FlyPtrs P = BNN_FLY_PTRS;
+  fly_run(x, fly_smem,
+          [&](const Geo& g, const FlyGeo& f, const Band& B, const FlyCtx& c, int pg, int p0, int np, int lane) {
+            TiledUnit<KH, KW, CWC, MULTI, WZ>::run(P, g, f, B, c, pg, p0, np, lane);
+          });
 }
 
 // ---------------------------------------------------------------------------------
 // Generic unit: any KH / KW / stride / padding / dilation (the arithmetic of bconv_generic_kernel on the LDS tile).
+// One pass = one 32-channel block (ppb = 1).
 // ---------------------------------------------------------------------------------
-constexpr int kFlyOG = 8;  // output channels per pass of the generic unit
+constexpr int kFlyOG = 8;  // output channels per inner pass of the generic unit
 
 template <bool WZ>
 __global__ __launch_bounds__(1024) void bconv_fly_generic_kernel(BNN_FLY_PARAMS) {
-  EpiArgs epi{alpha, bias, scale, nullptr, nullptr, nullptr, nullptr, out, nullptr, nullptr, nullptr, nullptr, nullptr};
-  fly_run(g, f, x, fly_smem, [&](const Band& B, const FlyCtx& c, int pg, int ob, int lane) {
+  fly_run(x, fly_smem, [&](const Geo& g, const FlyGeo& f, const Band& B, const FlyCtx& c, int pg, int p0, int np,
+                           int lane) {
+    const EpiArgs epi{alpha, bias, scale, nullptr, nullptr, nullptr, nullptr, out,
+                      nullptr, nullptr, nullptr, nullptr, nullptr};
     const int jl = min((pg << 6) + lane, B.npix - 1);
     const Pix px = decode_pixel<true>(g, B.q0 + jl);
     const unsigned cell0 = (unsigned)(((px.n - B.n0) * f.HPS + (px.oy - B.oy0) * g.sh) * f.WP + px.ox * g.sw);
     const int taps = g.KH * g.KW;
     const int per_o = taps * g.cwc;
-    int dotv[kOCB];
+    int nz = 0;
+    if (!WZ) {
+      for (int t = 0; t < taps; ++t) {
+        const int ky = t / g.KW, kx = t - ky * g.KW;
+        nz += (int)c.cnt[cell0 + (unsigned)(ky * g.dh * f.WP + kx * g.dw)];
+      }
+    }
+#pragma unroll 1
+    for (int ob = p0; ob < p0 + np; ++ob) {
+      int dotv[kOCB];
 #pragma unroll
-    for (int j = 0; j < kOCB; ++j) dotv[j] = 0;
+      for (int j = 0; j < kOCB; ++j) dotv[j] = 0;
 #pragma unroll
-    for (int pass = 0; pass < kOCB / kFlyOG; ++pass) {
-      const int j0 = pass * kFlyOG;
-      int acc[kFlyOG], nzw[kFlyOG];
+      for (int pass = 0; pass < kOCB / kFlyOG; ++pass) {
+        const int j0 = pass * kFlyOG;
+        int acc[kFlyOG], nzw[kFlyOG];
 #pragma unroll
-      for (int k = 0; k < kFlyOG; ++k) { acc[k] = 0; nzw[k] = 0; }
-      int nz = 0;
-      if (ob * kOCB + j0 < g.O) {
-        for (int t = 0; t < taps; ++t) {
-          const int ky = t / g.KW, kx = t - ky * g.KW;
-          const unsigned cell = cell0 + (unsigned)(ky * g.dh * f.WP + kx * g.dw);
-          for (int cw = 0; cw < g.cw32; ++cw) {
-            const int ch = cw / g.cwc, ci = cw - ch * g.cwc;
-            const unsigned a = ((unsigned)ch * (unsigned)f.ncell + cell) * (unsigned)g.cwc + (unsigned)ci;
-            const uint32_t pw = c.ldsP[a], mw = c.ldsM[a];
-            if (!WZ) nz += __builtin_popcount(pw | mw);
-            const size_t wbase = ((size_t)(ob * g.nchunk + ch) * kOCB + j0) * per_o + t * g.cwc + ci;
+        for (int k = 0; k < kFlyOG; ++k) { acc[k] = 0; nzw[k] = 0; }
+        if (ob * kOCB + j0 < g.O) {
+          for (int t = 0; t < taps; ++t) {
+            const int ky = t / g.KW, kx = t - ky * g.KW;
+            const unsigned cell = cell0 + (unsigned)(ky * g.dh * f.WP + kx * g.dw);
+            for (int cw = 0; cw < g.cw32; ++cw) {
+              const int ch = cw / g.cwc, ci = cw - ch * g.cwc;
+              const unsigned a = ((unsigned)ch * (unsigned)f.ncell + cell) * (unsigned)g.cwc + (unsigned)ci;
+              const uint32_t pw = c.ldsP[a], mw = c.ldsM[a];
+              const size_t wbase = ((size_t)(ob * g.nchunk + ch) * kOCB + j0) * per_o + t * g.cwc + ci;
 #pragma unroll
-            for (int k = 0; k < kFlyOG; ++k) {
-              const uint32_t w = W[wbase + (size_t)k * per_o];
-              uint32_t d = disagree(w, mw, pw);
-              if (WZ) {
-                const uint32_t z = Z[wbase + (size_t)k * per_o];
-                d &= z;
-                nzw[k] += __builtin_popcount((pw | mw) & z);
+              for (int k = 0; k < kFlyOG; ++k) {
+                const uint32_t w = W[wbase + (size_t)k * per_o];
+                uint32_t d = disagree(w, mw, pw);
+                if (WZ) {
+                  const uint32_t z = Z[wbase + (size_t)k * per_o];
+                  d &= z;
+                  nzw[k] += __builtin_popcount((pw | mw) & z);
+                }
+                acc[k] += __builtin_popcount(d);
               }
-              acc[k] += __builtin_popcount(d);
             }
           }
         }
+#pragma unroll
+        for (int k = 0; k < kFlyOG; ++k) dotv[j0 + k] = (WZ ? nzw[k] : nz) - 2 * acc[k];
       }
+      uint32_t pbits = 0u, mbits = 0u;
+      float resv[kOCB];
 #pragma unroll
-      for (int k = 0; k < kFlyOG; ++k) dotv[j0 + k] = (WZ ? nzw[k] : nz) - 2 * acc[k];
+      for (int j = 0; j < kOCB; ++j) resv[j] = 0.0f;
+      epilogue<kOCB, EP_PLAIN>(g, px, ob * kOCB, dotv, resv, epi, pbits, mbits);
     }
-    uint32_t pbits = 0u, mbits = 0u;
-    float resv[kOCB];
-#pragma unroll
-    for (int j = 0; j < kOCB; ++j) resv[j] = 0.0f;
-    epilogue<kOCB, EP_PLAIN>(g, px, ob * kOCB, dotv, resv, epi, pbits, mbits);
   });
 }
 
@@ -485,6 +652,13 @@ namespace {
 
 constexpr int kLdsBudget = 160 * 1024;   // per CU (MI355X_MICROARCH.md); one workgroup may take all of it
 constexpr int kLdsHalf = 78 * 1024;      // two workgroups per CU
+#ifndef BNN_FLY_FINE_HEAD  // default pixel groups of single-pass units at the start / end of a band
+#define BNN_FLY_FINE_HEAD 2
+#endif
+#ifndef BNN_FLY_FINE_TAIL
+#define BNN_FLY_FINE_TAIL 3
+#endif
+constexpr int kFineHead = BNN_FLY_FINE_HEAD, kFineTail = BNN_FLY_FINE_TAIL;
 
 int slab_rows(const ConvP& p, int BR) { return (BR - 1) * p.sh + (p.KH - 1) * p.dh + 1; }
 
@@ -494,7 +668,8 @@ long long band_in_pixels(const ConvP& p, int kimg, int BR) {
   return (long long)kimg * rows * p.Wd;
 }
 
-long long lds_bytes_for(const ConvP& p, int kimg, int BR, unsigned* off_ready, unsigned* off_P, unsigned* off_M) {
+long long lds_bytes_for(const ConvP& p, int kimg, int BR, unsigned* off_ready = nullptr, unsigned* off_P = nullptr,
+                        unsigned* off_M = nullptr, unsigned* off_cnt = nullptr) {
   const long long ncell = (long long)kimg * slab_rows(p, BR) * (p.Wd + 2 * p.pw);
   const long long nipg = (band_in_pixels(p, kimg, BR) + 63) / 64 + 1;
   const long long ready = 16;
@@ -503,7 +678,8 @@ long long lds_bytes_for(const ConvP& p, int kimg, int BR, unsigned* off_ready, u
   if (off_ready) *off_ready = (unsigned)ready;
   if (off_P) *off_P = (unsigned)P;
   if (off_M) *off_M = (unsigned)(P + plane);
-  return P + 2 * plane;
+  if (off_cnt) *off_cnt = (unsigned)(P + 2 * plane);
+  return (P + 2 * plane + 4 * ncell + 15) / 16 * 16;
 }
 
 }  // namespace
@@ -511,7 +687,7 @@ long long lds_bytes_for(const ConvP& p, int kimg, int BR, unsigned* off_ready, u
 bool fly_supported(const ConvP& p) {
   if (!small_indices(p)) return false;
   // one output row of one image with its halo must fit
-  return lds_bytes_for(p, 1, 1, nullptr, nullptr, nullptr) <= kLdsBudget;
+  return lds_bytes_for(p, 1, 1) <= kLdsBudget;
 }
 
 int fly_default_plan(const ConvP& p, int /*flags*/, bnn_hip_fly_plan* plan) {
@@ -520,7 +696,7 @@ int fly_default_plan(const ConvP& p, int /*flags*/, bnn_hip_fly_plan* plan) {
   const bool single3 = p.KH == 3 && p.KW == 3 && p.dh == 1 && p.dw == 1 && p.nchunk == 1;
   int obw = 1;
   if (single3 && nob >= 2) obw = 2;
-  const long long img = lds_bytes_for(p, 1, p.Ho, nullptr, nullptr, nullptr);
+  const long long img = lds_bytes_for(p, 1, p.Ho);
   int kimg = 1, BR = p.Ho;
   if (img <= kLdsBudget) {
     // whole images: as many as keep two workgroups per CU resident, without starving the chip of bands
@@ -529,7 +705,7 @@ int fly_default_plan(const ConvP& p, int /*flags*/, bnn_hip_fly_plan* plan) {
     while (true) {
       const int k2 = kimg * 2;
       if (k2 > p.N) break;
-      if (lds_bytes_for(p, k2, p.Ho, nullptr, nullptr, nullptr) > kLdsHalf) break;
+      if (lds_bytes_for(p, k2, p.Ho) > kLdsHalf) break;
       if ((p.N + k2 - 1) / k2 < 512) break;
       if (pix * k2 > 128 * 64) break;
       kimg = k2;
@@ -538,16 +714,16 @@ int fly_default_plan(const ConvP& p, int /*flags*/, bnn_hip_fly_plan* plan) {
     // rows of one image: the largest band that still leaves two workgroups per CU; else the largest that fits
     BR = 1;
     for (int r = p.Ho; r >= 1; --r)
-      if (lds_bytes_for(p, 1, r, nullptr, nullptr, nullptr) <= kLdsHalf) { BR = r; break; }
-    if (BR == 1 && lds_bytes_for(p, 1, 1, nullptr, nullptr, nullptr) > kLdsHalf) {
+      if (lds_bytes_for(p, 1, r) <= kLdsHalf) { BR = r; break; }
+    if (BR == 1 && lds_bytes_for(p, 1, 1) > kLdsHalf) {
       for (int r = p.Ho; r >= 1; --r)
-        if (lds_bytes_for(p, 1, r, nullptr, nullptr, nullptr) <= kLdsBudget) { BR = r; break; }
+        if (lds_bytes_for(p, 1, r) <= kLdsBudget) { BR = r; break; }
     }
     // equal bands
     const int nbi = (p.Ho + BR - 1) / BR;
     BR = (p.Ho + nbi - 1) / nbi;
   }
-  const long long lds = lds_bytes_for(p, kimg, BR, nullptr, nullptr, nullptr);
+  const long long lds = lds_bytes_for(p, kimg, BR);
   const long long units = (((long long)kimg * BR * p.Wo + 63) / 64) * ((nob + obw - 1) / obw);
   int waves = lds > kLdsHalf ? 16 : 8;
   while (waves > 1 && waves > units) waves >>= 1;
@@ -555,6 +731,10 @@ int fly_default_plan(const ConvP& p, int /*flags*/, bnn_hip_fly_plan* plan) {
   plan->rows_per_band = BR;
   plan->waves = waves;
   plan->blocks_per_unit = obw;
+  plan->pack_ahead = -1;
+  plan->fine_head = -1;
+  plan->fine_tail = -1;
+  plan->producers = -1;
   plan->lds_bytes = (int32_t)lds;
   plan->n_bands = ((p.N + kimg - 1) / kimg) * ((p.Ho + BR - 1) / BR);
   return BNN_HIP_OK;
@@ -576,14 +756,10 @@ int launch_k(K kernel, const ConvP& p, const void* x, const Geo& g, const FlyGeo
 }
 
 template <int KH, int KW, int CWC, bool MULTI>
-int launch_tiled(const ConvP& p, const void* x, const Geo& g, const FlyGeo& f, int nbands, int waves, int obw,
-                 bool wz, hipStream_t s) {
-  if (wz) return launch_k(bconv_fly_kernel<KH, KW, CWC, MULTI, true, 1>, p, x, g, f, nbands, waves, s);
-  if constexpr (!MULTI) {
-    if (obw == 4) return launch_k(bconv_fly_kernel<KH, KW, CWC, false, false, 4>, p, x, g, f, nbands, waves, s);
-    if (obw == 2) return launch_k(bconv_fly_kernel<KH, KW, CWC, false, false, 2>, p, x, g, f, nbands, waves, s);
-  }
-  return launch_k(bconv_fly_kernel<KH, KW, CWC, MULTI, false, 1>, p, x, g, f, nbands, waves, s);
+int launch_tiled(const ConvP& p, const void* x, const Geo& g, const FlyGeo& f, int nbands, int waves, bool wz,
+                 hipStream_t s) {
+  if (wz) return launch_k(bconv_fly_kernel<KH, KW, CWC, MULTI, true>, p, x, g, f, nbands, waves, s);
+  return launch_k(bconv_fly_kernel<KH, KW, CWC, MULTI, false>, p, x, g, f, nbands, waves, s);
 }
 
 }  // namespace
@@ -604,16 +780,20 @@ int launch_bconv_fly(const ConvP& p, const void* x, int x_half, int flags, const
     plan.rows_per_band = user->rows_per_band;
     plan.waves = user->waves;
     plan.blocks_per_unit = user->blocks_per_unit;
+    plan.pack_ahead = user->pack_ahead;
+    plan.fine_head = user->fine_head;
+    plan.fine_tail = user->fine_tail;
+    plan.producers = user->producers;
     if (plan.images_per_band < 1 || plan.rows_per_band < 1 || plan.rows_per_band > p.Ho) return BNN_HIP_ERR_INVALID_ARG;
     if (plan.images_per_band > 1 && plan.rows_per_band != p.Ho) return BNN_HIP_ERR_INVALID_ARG;
     if (plan.waves < 1 || plan.waves > 16) return BNN_HIP_ERR_INVALID_ARG;
     if (plan.blocks_per_unit != 1 && plan.blocks_per_unit != 2 && plan.blocks_per_unit != 4) return BNN_HIP_ERR_INVALID_ARG;
     plan.images_per_band = std::min(plan.images_per_band, p.N);
   }
-  if (generic || wz || !single3) plan.blocks_per_unit = 1;
+  if (!user && !single3) plan.blocks_per_unit = 1;
   const int kimg = plan.images_per_band, BR = plan.rows_per_band;
-  unsigned off_ready, off_P, off_M;
-  const long long lds = lds_bytes_for(p, kimg, BR, &off_ready, &off_P, &off_M);
+  unsigned off_ready, off_P, off_M, off_cnt;
+  const long long lds = lds_bytes_for(p, kimg, BR, &off_ready, &off_P, &off_M, &off_cnt);
   if (lds > kLdsBudget) return user ? BNN_HIP_ERR_INVALID_ARG : BNN_HIP_ERR_UNSUPPORTED;
 
   const Geo g = make_geo(p);
@@ -636,16 +816,27 @@ int launch_bconv_fly(const ConvP& p, const void* x, int x_half, int flags, const
     f.prr = std::max(0, iy_end) * p.Wd;
   }
   const int nob = (p.O + kOCB - 1) / kOCB;
-  f.nobu = (nob + plan.blocks_per_unit - 1) / plan.blocks_per_unit;
-  f.ahead = (plan.waves + f.nobu - 1) / f.nobu + 1;
+  const bool multi = p.nchunk > 1 || (p.KH == 1 && p.KW == 1);
+  f.ppb = generic ? 1 : (wz ? 4 : (multi ? 1 : 4));  // TiledUnit::PASSES
+  f.npp = nob * f.ppb;
+  f.cpu = plan.blocks_per_unit * f.ppb;
+  f.nobu = (f.npp + f.cpu - 1) / f.cpu;
+  // single passes at both ends of a band (only where a coarse unit is more than one pass)
+  f.fine_head = f.cpu > 1 ? (plan.fine_head >= 0 ? plan.fine_head : kFineHead) : 0;
+  f.fine_tail = f.cpu > 1 ? (plan.fine_tail >= 0 ? plan.fine_tail : kFineTail) : 0;
+  f.ahead = plan.pack_ahead >= 0 ? plan.pack_ahead : (plan.waves + f.nobu - 1) / f.nobu + 1;
+  f.nprod = std::min(plan.waves - 1, plan.producers >= 0 ? plan.producers : plan.waves / 8 + 1);
   f.off_ready = off_ready;
   f.off_P = off_P;
   f.off_M = off_M;
+  f.off_cnt = off_cnt;
   f.lds16 = (unsigned)((lds + 15) / 16);
   div_magic((uint32_t)f.nwords, f.m_nwords, f.s_nwords);
   div_magic((uint32_t)p.Wd, f.m_W, f.s_W);
   div_magic((uint32_t)std::max(1, f.prr), f.m_prr, f.s_prr);
   div_magic((uint32_t)f.nobu, f.m_nobu, f.s_nobu);
+  div_magic((uint32_t)f.cwc, f.m_cwc, f.s_cwc);
+  div_magic((uint32_t)f.npp, f.m_npp, f.s_npp);
   const int nbands = ((p.N + kimg - 1) / kimg) * f.nbi;
   const int waves = plan.waves;
 
@@ -653,10 +844,9 @@ int launch_bconv_fly(const ConvP& p, const void* x, int x_half, int flags, const
     if (wz) return launch_k(bconv_fly_generic_kernel<true>, p, x, g, f, nbands, waves, s);
     return launch_k(bconv_fly_generic_kernel<false>, p, x, g, f, nbands, waves, s);
   }
-  const int obw = plan.blocks_per_unit;
 #define BNN_FLY_PICK(KH_, KW_, C_, M_) \
-  if (p.KH == KH_ && p.KW == KW_ && p.cwc == C_ && (p.nchunk > 1 || KH_ == 1) == M_) \
-    return launch_tiled<KH_, KW_, C_, M_>(p, x, g, f, nbands, waves, obw, wz, s);
+  if (p.KH == KH_ && p.KW == KW_ && p.cwc == C_ && multi == M_) \
+    return launch_tiled<KH_, KW_, C_, M_>(p, x, g, f, nbands, waves, wz, s);
   BNN_FLY_PICK(3, 3, 4, false) BNN_FLY_PICK(3, 3, 4, true) BNN_FLY_PICK(3, 3, 2, false) BNN_FLY_PICK(3, 3, 2, true)
   BNN_FLY_PICK(1, 1, 16, true) BNN_FLY_PICK(1, 1, 8, true) BNN_FLY_PICK(1, 1, 4, true) BNN_FLY_PICK(1, 1, 2, true)
 #undef BNN_FLY_PICK
@@ -665,3 +855,10 @@ int launch_bconv_fly(const ConvP& p, const void* x, int x_half, int flags, const
 }
 
 }  // namespace bnn
+
+#ifdef BNN_FLY_TIMING
+extern "C" int bnn_hip_debug_fly_timing(unsigned long long* host_dst, size_t n_words) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(bnn::bnn_fly_dbg), n_words * sizeof(unsigned long long)) ==
+                 hipSuccess ? 0 : -3;
+}
+#endif

@@ -342,7 +342,9 @@ int bnn_hip_blinear(int B, int F, int O,
  *      the planes are those of the exactly widened values; the output stays fp32, the caller rounds it once);
  *      N*C*H*W < 2^30 elements per launch.
  *   plan: NULL = bnn_hip_bconv2d_direct_plan()'s choice.  A caller's plan (tests, tuning) supplies
- *      images_per_band / rows_per_band / waves / blocks_per_unit; lds_bytes and n_bands are outputs of the planner.
+ *      images_per_band / rows_per_band / waves / blocks_per_unit / pack_ahead / fine_head / fine_tail /
+ *      producers;
+ *      lds_bytes and n_bands are outputs.
  * Returns BNN_HIP_ERR_UNSUPPORTED when not even one output row of one image with its halo fits into the 160 KiB
  * of LDS of a CU (or an index factor leaves the 24-bit multiplies of the tiled kernels): use
  * bnn_hip_pack_act_f32 + bnn_hip_bconv2d (what bnn_hip_bconv2d_f32 does by itself) for those.                   */
@@ -352,8 +354,13 @@ typedef struct bnn_hip_fly_plan {
   int32_t images_per_band;  /* whole images per workgroup (>= 1); > 1 only with rows_per_band == Ho            */
   int32_t rows_per_band;    /* output rows per workgroup: Ho = whole images                                     */
   int32_t waves;            /* wavefronts per workgroup, 1..16                                                  */
-  int32_t blocks_per_unit;  /* 32-channel output blocks per work unit (one load of the field): 1, 2 or 4;
-                               > 1 is honoured by the single-chunk 3x3 kernels only                            */
+  int32_t blocks_per_unit;  /* 32-channel output blocks per (coarse) work unit = per load of the field: 1, 2 or 4 */
+  int32_t pack_ahead;       /* pixel groups (64 pixels) the binarisation is kept in front of the convolution;
+                               < 0 = the planner's default                                                      */
+  int32_t fine_head;        /* pixel groups at the start / end of a band that are split into single-pass units    */
+  int32_t fine_tail;        /* (8 output channels of one block each); < 0 = the planner's default                 */
+  int32_t producers;        /* wavefronts per workgroup that binarise the band front to back before they join the
+                               convolution (0: every wave packs what it needs itself); < 0 = the planner's default */
   int32_t lds_bytes;        /* out: dynamic LDS per workgroup                                                   */
   int32_t n_bands;          /* out: workgroups of the launch                                                    */
 } bnn_hip_fly_plan;

@@ -27,9 +27,10 @@ def _args(case):
     return x, w, b, sc, pw, kw
 
 
-def _plan(images=1, rows=0, waves=8, obw=1):
+def _plan(images=1, rows=0, waves=8, obw=1, ahead=-1, head=-1, tail=-1, prod=-1):
     p = native.FlyPlan()
-    p.images_per_band, p.rows_per_band, p.waves, p.blocks_per_unit = images, rows, waves, obw
+    p.images_per_band, p.rows_per_band, p.waves, p.blocks_per_unit, p.pack_ahead = images, rows, waves, obw, ahead
+    p.fine_head, p.fine_tail, p.producers = head, tail, prod
     return p
 
 
@@ -102,9 +103,10 @@ def test_every_band_plan_gives_the_same_bits(name):
     bt, st = (None if b is None else dev(b)), (None if sc is None else dev(sc))
     base = hipops.bconv2d(hipops.pack_act(xd), pw, bt, st, **kw)
     ho = base.shape[2]
-    plans = [_plan(1, ho, 16, 1), _plan(1, ho, 1, 2), _plan(1, ho, 3, 4), _plan(2, ho, 4, 1), _plan(3, ho, 8, 2),
-             _plan(x.shape[0], ho, 16, 4), _plan(1, 1, 4, 1), _plan(1, 2, 2, 2), _plan(1, max(1, ho // 2), 8, 1),
-             _plan(1, max(1, ho - 1), 5, 2), _plan(1, 3, 16, 4)]
+    plans = [_plan(1, ho, 16, 1), _plan(1, ho, 1, 2, head=0, tail=0), _plan(1, ho, 3, 4, head=1, tail=1),
+             _plan(2, ho, 4, 1), _plan(3, ho, 8, 2, ahead=0, head=5, tail=0), _plan(x.shape[0], ho, 16, 4, tail=100),
+             _plan(1, 1, 4, 1), _plan(1, 2, 2, 2, head=100), _plan(1, max(1, ho // 2), 8, 1, ahead=3),
+             _plan(1, max(1, ho - 1), 5, 2, head=0, tail=2), _plan(1, 3, 16, 4, ahead=50)]
     cw32 = 2 * ((case.C + 63) // 64)
     ran = 0
     for p in plans:

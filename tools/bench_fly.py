@@ -20,6 +20,7 @@ from tests.golden import gen  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--quick", action="store_true")
+ap.add_argument("--c2-only", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 info = native.device_info(0)
@@ -37,9 +38,10 @@ def ev(fn, iters):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def plan(images, rows, waves, obw):
+def plan(images, rows, waves, obw, ahead=-1, head=-1, tail=-1, prod=-1):
     p = native.FlyPlan()
-    p.images_per_band, p.rows_per_band, p.waves, p.blocks_per_unit = images, rows, waves, obw
+    p.images_per_band, p.rows_per_band, p.waves, p.blocks_per_unit, p.pack_ahead = images, rows, waves, obw, ahead
+    p.fine_head, p.fine_tail, p.producers = head, tail, prod
     return p
 
 
@@ -67,25 +69,26 @@ def run_shape(N, C, H, W, O, k, s, p, plans, spin=300, iters=30):
             out = hipops.bconv2d_direct(x, pw, stride=s, padding=p, plan=pl)
         except native.NativeError as e:
             rec["plans"].append({"plan": None if pl is None else [pl.images_per_band, pl.rows_per_band, pl.waves,
-                                                                  pl.blocks_per_unit], "error": str(e)})
+                                                                  pl.blocks_per_unit, pl.pack_ahead, pl.fine_head, pl.fine_tail, pl.producers], "error": str(e)})
             continue
         ok = bool(torch.equal(out, ref))
         for _ in range(spin // 3):
             hipops.bconv2d_direct(x, pw, stride=s, padding=p, plan=pl)
         t = ev(lambda: hipops.bconv2d_direct(x, pw, stride=s, padding=p, plan=pl), iters)
         rec["plans"].append({"plan": "default" if pl is None else [pl.images_per_band, pl.rows_per_band, pl.waves,
-                                                                   pl.blocks_per_unit],
+                                                                   pl.blocks_per_unit, pl.pack_ahead, pl.fine_head, pl.fine_tail, pl.producers],
                              "us": t * 1e6, "frac": lane_ops / t / peak, "bit_identical": ok})
     return rec
 
 
 out = {"device": info, "results": []}
 B = args.batch
-c2_plans = [plan(1, 56, 16, 1), plan(1, 56, 16, 2), plan(1, 56, 16, 4), plan(1, 56, 8, 2), plan(1, 56, 12, 2),
-            plan(1, 28, 8, 2), plan(1, 28, 8, 1), plan(1, 28, 8, 4), plan(1, 14, 8, 2), plan(1, 19, 8, 2),
-            plan(1, 28, 16, 2), plan(1, 8, 7, 2), plan(1, 14, 4, 2)]
+c2_plans = [plan(1, 56, 16, 2, prod=0), plan(1, 56, 16, 2, prod=1), plan(1, 56, 16, 2, prod=2), plan(1, 56, 16, 2, prod=3),
+            plan(1, 56, 16, 2, prod=4), plan(1, 56, 16, 2, prod=6), plan(1, 56, 16, 2, prod=8), plan(1, 56, 16, 1, prod=4),
+            plan(1, 56, 16, 4, prod=4), plan(1, 56, 16, 2, -1, 0, 0, 4), plan(1, 56, 16, 2, -1, 4, 4, 4),
+            plan(1, 56, 16, 4, -1, 3, 6, 4), plan(1, 56, 16, 2, -1, 2, 3, 2), plan(1, 28, 8, 2, prod=2), plan(1, 28, 8, 2, prod=1)]
 out["results"].append(run_shape(B, 128, 56, 56, 128, 3, 1, 1, c2_plans if not args.quick else c2_plans[:3]))
-if not args.quick:
+if not args.quick and not args.c2_only:
     for sh, pls in [
         ((B, 64, 56, 56, 64, 3, 1, 1), [plan(1, 56, 8, 1), plan(1, 56, 8, 2), plan(1, 56, 16, 2), plan(1, 28, 8, 2)]),
         ((B, 64, 56, 56, 128, 3, 2, 1), [plan(1, 28, 8, 2), plan(1, 28, 8, 4), plan(1, 14, 8, 2)]),
