@@ -677,8 +677,8 @@ constexpr int pick_wblock(int total) {
 // ILP: words whose v_bitop3 are issued back to back BEFORE their v_bcnt (1 = each v_bcnt right behind the v_bitop3 it
 // depends on: fine when several waves interleave on the SIMD, but a wave that runs alone — the others blocked on
 // memory, or gone at the tail of a workgroup — then waits out the VALU latency on every pair).
-#ifndef BNN_STREAM_ILP
-#define BNN_STREAM_ILP 1
+#ifndef BNN_STREAM_ILP  // 2: config-2 kernel 208 -> 201 us (0.905 -> 0.936 of the int-ALU roofline), round 3
+#define BNN_STREAM_ILP 2
 #endif
 template <int NW, int NACC, bool NN = false, bool USEED = false, bool ONECHAIN = false, int ILP = BNN_STREAM_ILP>
 __device__ __forceinline__ void stream_weights(const uint32_t* __restrict__ wrun,

@@ -14,7 +14,7 @@
 //         is `taps` ds_read_b128, consecutive lanes = consecutive cells: conflict-free), plus one counter per cell:
 //         its non-zero channels (the window's count is `taps` loads and adds instead of 2 VALU per field word)
 //   * two ticket counters in LDS drive the waves — no barrier after the initial zero fill:
-//       - PACK items   (64 consecutive input pixels x one 32-channel word): lane = pixel, 32 coalesced dword loads
+//       - PACK items   (64 consecutive input pixels x up to four 32-channel words): lane = pixel, 32 coalesced dword loads
 //         (buffer loads: per-channel offset in an SGPR, non-temporal), sign bits by v_alignbit_b32, non-zero bits by
 //         v_cmp_class_f32 + v_addc_co_u32 (NaN / +-0 -> neither plane, denormals keep their sign), two ds_write_b32,
 //         then ready[pixel group] += 1 (release)
@@ -47,6 +47,7 @@ struct FlyGeo {
   int in_half;           // input element type: 0 = fp32, 1 = fp16
   unsigned x_bytes;      // range of the input descriptor
   int nwords;            // 32-channel words per pixel that hold real channels: ceil(C / 32)
+  int wpi, gpi;          // PACK items: words per item (min(4, cwc)), items per input pixel group
   int cwc;               // words per (chunk, cell): the weight layout's chunk width
   int kimg, BR, nbi;     // band: whole images per band | output rows per band, bands per image
   int HPS, WP, ncell;    // LDS slab: rows per image, row pitch (cells), cells per band
@@ -62,8 +63,8 @@ struct FlyGeo {
   int ahead;             // no producer waves: pixel groups the packing is kept in front of a unit
   int nprod;             // producer waves per workgroup
   unsigned off_ready, off_P, off_M, off_cnt, lds16;  // byte offsets into the dynamic LDS; total size / 16
-  uint32_t m_nwords, m_W, m_prr, m_nobu, m_cwc, m_npp;
-  int s_nwords, s_W, s_prr, s_nobu, s_cwc, s_npp;
+  uint32_t m_gpi, m_W, m_prr, m_nobu, m_cwc, m_npp;
+  int s_gpi, s_W, s_prr, s_nobu, s_cwc, s_npp;
 };
 
 // The kernels' arguments: seven pointers (kept as __restrict__ kernel parameters: the compiler must know that the
@@ -239,7 +240,7 @@ __device__ __forceinline__ FlyCtx make_ctx(const FlyGeo& f, const Band& B, unsig
   c.ldsM = reinterpret_cast<uint32_t*>(smem + f.off_M);
   c.cnt = reinterpret_cast<uint32_t*>(smem + f.off_cnt);
   c.lane = lane;
-  c.nitems = B.nipg * f.nwords;
+  c.nitems = B.nipg * f.gpi;
 #ifdef BNN_FLY_EXP_SKIP_PACK
   c.nitems = 0;
 #endif
@@ -278,13 +279,15 @@ __device__ __forceinline__ void pack_word(BufRsrc rx, unsigned voff, int c0, int
 }
 
 // Pack the next item if one is left (synchronously); false when all items have been handed out.
+// An item = 64 consecutive input pixels x a GROUP of `wpi` consecutive 32-channel words (ticket, pixel decode and
+// addresses once per group; measured with one word per item: 250 VALU instructions per word, 96 of them the bits).
 __device__ __forceinline__ bool pack_item(const void* __restrict__ x, const Geo& g, const FlyGeo& f, const Band& B,
                                           const FlyCtx& c) {
   if (__hip_atomic_load(&c.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)c.nitems) return false;
   const uint32_t t = take_ticket(&c.ctl[1], c.lane);
   if (t >= (uint32_t)c.nitems) return false;
-  const int ipg = (int)fast_div(t, f.m_nwords, f.s_nwords);
-  const int w = (int)t - ipg * f.nwords;
+  const int ipg = (int)fast_div(t, f.m_gpi, f.s_gpi);
+  const int w0 = ((int)t - ipg * f.gpi) * f.wpi;  // first word of the group
   const int p = (ipg << 6) + c.lane;
   const bool valid = p < B.in_pix;
   const int pc = valid ? p : B.in_pix - 1;
@@ -303,22 +306,29 @@ __device__ __forceinline__ bool pack_item(const void* __restrict__ x, const Geo&
 #endif
   const unsigned voff = valid ? elem * esz : 0xFFFFFFF0u;  // beyond the descriptor: the hardware returns 0
   const unsigned cell = (unsigned)((slab * f.HPS + (B.iy_lo - B.iy_base) + rowl) * f.WP + ix + g.pw);
+  // the group lies inside one chunk (wpi divides cwc): its words are consecutive in the cell
+  const int wch = (int)fast_div((uint32_t)w0, f.m_cwc, f.s_cwc);
+  const unsigned a0 = ((unsigned)(wch * f.ncell) + cell) * (unsigned)f.cwc + (unsigned)(w0 - wch * f.cwc);
   const BufRsrc rx = make_rsrc_sized(x, f.x_bytes);
-  uint32_t Pw, Mw;
-  if (f.in_half) pack_word<true>(rx, voff, w * 32, f.C, (unsigned)f.HW * 2u, Pw, Mw);
-  else pack_word<false>(rx, voff, w * 32, f.C, (unsigned)f.HW * 4u, Pw, Mw);
-  const int nch = f.C - w * 32;
-  const uint32_t keep = nch >= 32 ? 0xFFFFFFFFu : ((1u << nch) - 1u);
-  Pw &= keep;
-  Mw &= keep;
-  if (valid) {
-    const int wch = (int)fast_div((uint32_t)w, f.m_cwc, f.s_cwc), wi = w - wch * f.cwc;
-    const unsigned a = ((unsigned)(wch * f.ncell) + cell) * (unsigned)f.cwc + (unsigned)wi;
-    c.ldsP[a] = Pw;
-    c.ldsM[a] = Mw;
-    __hip_atomic_fetch_add(&c.cnt[cell], (uint32_t)__builtin_popcount(Pw | Mw), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_WORKGROUP);
+  uint32_t nonzero = 0u;
+#pragma unroll 1
+  for (int k = 0; k < f.wpi; ++k) {
+    const int nch = f.C - (w0 + k) * 32;
+    if (nch <= 0) break;  // words past the last channel stay zero
+    uint32_t Pw, Mw;
+    if (f.in_half) pack_word<true>(rx, voff, (w0 + k) * 32, f.C, (unsigned)f.HW * 2u, Pw, Mw);
+    else pack_word<false>(rx, voff, (w0 + k) * 32, f.C, (unsigned)f.HW * 4u, Pw, Mw);
+    const uint32_t keep = nch >= 32 ? 0xFFFFFFFFu : ((1u << nch) - 1u);
+    Pw &= keep;
+    Mw &= keep;
+    if (valid) {
+      c.ldsP[a0 + (unsigned)k] = Pw;
+      c.ldsM[a0 + (unsigned)k] = Mw;
+    }
+    nonzero += (uint32_t)__builtin_popcount(Pw | Mw);
   }
+  if (valid)
+    __hip_atomic_fetch_add(&c.cnt[cell], nonzero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   // the cell writes of every lane precede the counter update in this wave's LDS instruction stream
   if (c.lane == 0) __hip_atomic_fetch_add(&c.ready[ipg], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   return true;
@@ -328,7 +338,7 @@ __device__ __forceinline__ bool pack_item(const void* __restrict__ x, const Geo&
 __device__ __forceinline__ bool range_ready(const FlyGeo& f, const FlyCtx& c, int lo, int hi) {
   bool missing = false;
   for (int i = lo + c.lane; i <= hi; i += 64)
-    missing |= __hip_atomic_load(&c.ready[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)f.nwords;
+    missing |= __hip_atomic_load(&c.ready[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)f.gpi;
 #if defined(__HIP_DEVICE_COMPILE__)
   if (__builtin_amdgcn_ballot_w64(missing) != 0ull) return false;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -364,7 +374,7 @@ __device__ __forceinline__ void fly_run(const void* __restrict__ x, unsigned cha
     const FlyGeos A = fresh_geo();
     const Band B = make_band(A.g, A.f, blockIdx.x);
     uint32_t* ready = reinterpret_cast<uint32_t*>(smem + A.f.off_ready);
-    for (int i = tid; i < B.nipg; i += blockDim.x) ready[i] = (uint32_t)A.f.nwords;
+    for (int i = tid; i < B.nipg; i += blockDim.x) ready[i] = (uint32_t)A.f.gpi;
     __syncthreads();
   }
 #endif
@@ -414,7 +424,7 @@ __device__ __forceinline__ void fly_run(const void* __restrict__ x, unsigned cha
     uint32_t want = 0u;  // without producer waves: pack tickets that should have been handed out by now
     if (f.nprod == 0) {
       need_range(g, f, B, min(pg + f.ahead, B.npg - 1), lo, hi);
-      want = (uint32_t)min((hi + 1) * f.nwords, c.nitems);
+      want = (uint32_t)min((hi + 1) * f.gpi, c.nitems);
     }
     need_range(g, f, B, pg, lo, hi);  // this unit's own inputs
     [[maybe_unused]] const unsigned long long t_u0 = FLY_NOW();
@@ -653,10 +663,10 @@ namespace {
 constexpr int kLdsBudget = 160 * 1024;   // per CU (MI355X_MICROARCH.md); one workgroup may take all of it
 constexpr int kLdsHalf = 78 * 1024;      // two workgroups per CU
 #ifndef BNN_FLY_FINE_HEAD  // default pixel groups of single-pass units at the start / end of a band
-#define BNN_FLY_FINE_HEAD 2
+#define BNN_FLY_FINE_HEAD 1
 #endif
 #ifndef BNN_FLY_FINE_TAIL
-#define BNN_FLY_FINE_TAIL 3
+#define BNN_FLY_FINE_TAIL 2
 #endif
 constexpr int kFineHead = BNN_FLY_FINE_HEAD, kFineTail = BNN_FLY_FINE_TAIL;
 
@@ -805,6 +815,8 @@ int launch_bconv_fly(const ConvP& p, const void* x, int x_half, int flags, const
   f.x_bytes = (unsigned)((long long)p.N * C * p.H * p.Wd * (x_half ? 2 : 4));
   f.nwords = (C + 31) / 32;
   f.cwc = p.cwc;
+  f.wpi = std::min(4, p.cwc);
+  f.gpi = (f.nwords + f.wpi - 1) / f.wpi;
   f.kimg = kimg;
   f.BR = BR;
   f.nbi = (p.Ho + BR - 1) / BR;
@@ -825,13 +837,13 @@ int launch_bconv_fly(const ConvP& p, const void* x, int x_half, int flags, const
   f.fine_head = f.cpu > 1 ? (plan.fine_head >= 0 ? plan.fine_head : kFineHead) : 0;
   f.fine_tail = f.cpu > 1 ? (plan.fine_tail >= 0 ? plan.fine_tail : kFineTail) : 0;
   f.ahead = plan.pack_ahead >= 0 ? plan.pack_ahead : (plan.waves + f.nobu - 1) / f.nobu + 1;
-  f.nprod = std::min(plan.waves - 1, plan.producers >= 0 ? plan.producers : plan.waves / 8 + 1);
+  f.nprod = std::min(plan.waves - 1, plan.producers >= 0 ? plan.producers : (plan.waves + 7) / 8);
   f.off_ready = off_ready;
   f.off_P = off_P;
   f.off_M = off_M;
   f.off_cnt = off_cnt;
   f.lds16 = (unsigned)((lds + 15) / 16);
-  div_magic((uint32_t)f.nwords, f.m_nwords, f.s_nwords);
+  div_magic((uint32_t)f.gpi, f.m_gpi, f.s_gpi);
   div_magic((uint32_t)p.Wd, f.m_W, f.s_W);
   div_magic((uint32_t)std::max(1, f.prr), f.m_prr, f.s_prr);
   div_magic((uint32_t)f.nobu, f.m_nobu, f.s_nobu);
