@@ -305,6 +305,7 @@ def main():
         barrier()
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
+        timed.local = dt            # this rank's own time (the returned one is the max over ranks)
         if world > 1:
             tt = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -367,13 +368,47 @@ def bench_c2(args, world, rank, device, info, timed):
     return rec
 
 
+def validate_gather(net, gathered, rank_input, B, world, rank, device, fused_kw, n_check=8, layerwise=False):
+    """Un-timed, after the timed region, on EVERY rank: the all-gathered [world * B, 1000] logits must hold rank r's
+    rows in block r — checked by recomputing the first `n_check` images of every rank locally (eager launches of
+    the same fused executor; images are independent and the kernels deterministic, so the bits must be equal).  A
+    mis-ordered or mis-streamed gather on N GPUs cannot print a number (examples/cifar10.py:74-77 gathers the outputs
+    of its replicas the same way; examples/imagenet.py:139-147)."""
+    assert gathered.shape == (world * B, 1000)
+    ref_engine = net if layerwise else FusedResNet(net, **fused_kw)     # the engine the timed steps ran
+    n = min(n_check, B)
+    bad = []
+    for r in range(world):
+        want = ref_engine(rank_input(r, n).contiguous())
+        got = gathered[r * B:r * B + n]
+        if not torch.equal(got, want):
+            bad.append(r)
+    # rank blocks are distinct (different synthetic images per rank): a gather that repeated one rank would show here
+    if world > 1:
+        assert not torch.equal(gathered[:n], gathered[B:B + n]), "rank 0 and rank 1 blocks are identical"
+    ok = torch.tensor([0 if bad else 1], device=device)
+    if dist.is_initialized():
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if bad or int(ok.item()) != 1:
+        raise SystemExit(f"bench.py: rank {rank}: gathered logits differ from a local recomputation for rank "
+                         f"block(s) {bad} — the all-gather is mis-ordered or raced with the graph replay")
+    return {"ranks_checked": world, "images_per_rank": n, "bit_equal": True,
+            "how": "every rank recomputed the first images of every rank's batch and compared with its gathered copy"}
+
+
 def bench_net(args, world, rank, device, info, timed):
     c5 = args.config == "c5"
     B = args.batch or (128 if c5 else 256)
     net = build_model(device, (lambda: ResNet(HBlock, [3, 4, 6, 3])) if c5 else resnet18)
     fused_kw = {"stem_fp16": True} if c5 else {}
-    x = torch.from_numpy(gen.normal(100 + rank, (8, 3, 224, 224))).to(device).repeat(B // 8, 1, 1, 1)
-    x = x + 0.01 * torch.arange(B, device=device, dtype=torch.float32).view(B, 1, 1, 1)  # distinct images
+
+    def rank_input(r, n=B):
+        """Rank r's synthetic batch (first n images): any rank can rebuild any other rank's input, which is what
+        lets every rank check the gathered logits (validate_gather)."""
+        xr = torch.from_numpy(gen.normal(100 + r, (8, 3, 224, 224))).to(device).repeat((n + 7) // 8, 1, 1, 1)[:n]
+        return xr + 0.01 * torch.arange(n, device=device, dtype=torch.float32).view(n, 1, 1, 1)  # distinct images
+
+    x = rank_input(rank)
     n_streams = max(1, args.streams) if args.engine == "graph" else 1
 
     def make_step(n_streams=n_streams, **kw):
@@ -395,6 +430,8 @@ def bench_net(args, world, rank, device, info, timed):
     step = make_step(**fused_kw)
     with torch.no_grad():
         dt, logits = timed(step, args.steps, args.warmup)
+        dt_local = timed.local
+        logits = logits.clone()     # (the gathered buffer of a graph-captured step is rewritten by later replays)
         assert logits.shape == (world * B, 1000) and bool(torch.isfinite(logits).all())
         extras = {}
         if not args.no_extras and args.engine == "graph":
@@ -410,6 +447,15 @@ def bench_net(args, world, rank, device, info, timed):
                     "value": world * B * args.steps / dtx, "ms_per_step": dtx / args.steps * 1e3,
                     "max_abs_logit_diff_vs_default": float((lx - logits).abs().max()),
                     "note": "stem as a k-ordered fp32 fmaf chain on v_mfma_f32_16x16x4_f32 (bit-for-bit IEEE fp32)"}
+        gather_check = validate_gather(net, logits, rank_input, B, world, rank, device, fused_kw,
+                                       layerwise=args.engine == "layerwise") if dist.is_initialized() else None
+    if dist.is_initialized():     # per-rank step times: a straggler shows here, not only in the max
+        mine = torch.tensor([dt_local / args.steps * 1e3], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(t.item()) for t in every]
+    else:
+        per_rank_ms = [dt_local / args.steps * 1e3]
     if rank != 0:
         return None
     value = world * B * args.steps / dt
@@ -429,6 +475,9 @@ def bench_net(args, world, rank, device, info, timed):
                    "global_batch": world * B, "parallelism": f"dp{world} (batch shards, RCCL all-gather of logits)"},
     }
     rec.update(extras)
+    rec["per_rank_ms_per_step"] = {"min": min(per_rank_ms), "max": max(per_rank_ms), "all": per_rank_ms}
+    if gather_check is not None:
+        rec["gather_check"] = gather_check
     if not c5:
         rec["net_int_alu_frac"] = value / world * R18_LANE_OPS_PER_IMG / int_alu_peak(info)
     if not args.no_roofline:

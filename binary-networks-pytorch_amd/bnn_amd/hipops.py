@@ -362,7 +362,8 @@ def bconv2d(a: PackedAct, w: PackedWeight, bias: Optional[torch.Tensor] = None,
         if d.N == 0:
             return out
         # one launch addresses < 2^31 elements: split the batch when a tensor is larger
-        per_img = max(d.O * ho * wo, d.H * d.W)
+        # (the planes are limited to 2^29 uint64 words per launch, half the fp32 element budget: capi.hip check_desc)
+        per_img = max(d.O * ho * wo, 2 * d.H * d.W * ((d.C + 63) // 64), 2 * ho * wo * ((d.O + 63) // 64))
         step = _batch_step(d.N, per_img, max(d.O, (d.C + 63) // 64))
         for n0 in range(0, d.N, step):
             n1 = min(d.N, n0 + step)
@@ -417,7 +418,7 @@ def bconv2d_direct(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor
         out = torch.empty((d.N, d.O, ho, wo), dtype=torch.float32, device=dev)
         if d.N == 0:
             return out
-        per_img = max(d.O * ho * wo, d.C * d.H * d.W)
+        per_img = max(d.O * ho * wo, d.C * d.H * d.W, 2 * ho * wo * ((d.O + 63) // 64))
         step = _batch_step(d.N, per_img, max(d.O, (d.C + 63) // 64))
         dtype = native.DTYPE_F16 if x.dtype == torch.float16 else native.DTYPE_F32
         for n0 in range(0, d.N, step):
@@ -480,7 +481,7 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
             torch.empty((d.N, d.O, ho, wo), dtype=torch.float32, device=dev) if out_f32 else None)
         pk = empty_packed(d.N, d.O, ho, wo, dev) if out_packed else None
         # one launch addresses < 2^31 elements: split the batch when a tensor is larger (like bconv2d)
-        per_img = max(c_total * ho * wo, d.H * d.W, 1)
+        per_img = max(c_total * ho * wo, 2 * d.H * d.W * ((d.C + 63) // 64), 2 * ho * wo * ((d.O + 63) // 64), 1)
         step = _batch_step(d.N, per_img, max(c_total, d.O, (d.C + 63) // 64))
         for n0 in range(0, d.N, step):
             n1 = min(d.N, n0 + step)

@@ -16,6 +16,8 @@ are derived once (call ``refresh()`` after changing parameters).  Eval mode only
 """
 from __future__ import annotations
 
+import itertools
+
 import contextlib
 import os
 from dataclasses import dataclass
@@ -249,7 +251,6 @@ class FusedResNet(nn.Module):
                 self._shortcut(blk, entry)
                 self._blocks.append(entry)
         self._graph = None
-        self._tensors = list(m.parameters()) + list(m.buffers())
         self._sig = self._signature()
 
     def _shortcut(self, blk, entry) -> None:
@@ -384,7 +385,10 @@ class FusedResNet(nn.Module):
     def _signature(self):
         """Changes whenever a parameter or buffer of the wrapped model is replaced or written in place
         (optimizer step, ``load_state_dict``, ``.to()``): the derived data must then be rebuilt."""
-        return tuple((t.data_ptr(), t._version) for t in self._tensors)
+        # a fresh walk every time: a Parameter that was REPLACED (setattr, a swapped sub-module) is a new object with
+        # its own storage, which a list captured at refresh() time would never see
+        return tuple((id(t), t.data_ptr(), t._version)
+                     for t in itertools.chain(self.model.parameters(), self.model.buffers()))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self._signature() != self._sig:        # weights changed since the packed forms were derived

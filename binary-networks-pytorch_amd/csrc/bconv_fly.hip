@@ -735,7 +735,9 @@ int fly_default_plan(const ConvP& p, int /*flags*/, bnn_hip_fly_plan* plan) {
   }
   const long long lds = lds_bytes_for(p, kimg, BR);
   const long long units = (((long long)kimg * BR * p.Wo + 63) / 64) * ((nob + obw - 1) / obw);
-  int waves = lds > kLdsHalf ? 16 : 8;
+  // one 16-wave workgroup per CU (4 waves per SIMD at <= 128 VGPRs) beat two 8-wave workgroups on every ResNet-18
+  // shape (64 ch 56x56: 87 vs 100 us; 512 ch 7x7: 77 vs 85 us), also where the band is small enough for two
+  int waves = 16;
   while (waves > 1 && waves > units) waves >>= 1;
   plan->images_per_band = kimg;
   plan->rows_per_band = BR;

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/bnn_hip.h"
 
 namespace bnn {
@@ -74,6 +76,23 @@ struct ConvP {
   int npix;  // N*Ho*Wo
   int C;     // input channels
 };
+
+// Compute units of the current device (for grids of persistent workgroups).  Cached per device in atomics: a
+// launch must not pay hipGetDeviceProperties (a slow host call in eager mode), and the C-ABI promises re-entrancy.
+inline int current_device_cus() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  const bool cacheable = dev >= 0 && dev < 64;
+  if (cacheable) {
+    const int c = cache[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+  }
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+  if (cacheable) cache[dev].store(cus, std::memory_order_relaxed);
+  return cus;
+}
 
 // host-side launchers (one per .hip file); return a bnn_hip_status
 int choose_cwc(int cw32, int KH, int KW);

@@ -9,11 +9,14 @@
 //     dL/d What[o,c,ky,kx]  = sum_{n,y,x} g[n,o,y,x] * sign(x)[n,c,y+ky-1,x+kx-1]           ("wgrad")
 //
 // Both are GEMMs with ONE real-valued operand (g) and one operand that is exactly {-1,0,+1} (sign(Wc), sign(x)) —
-// the library evaluates them as full fp32 convolutions (157 TF peak).  Here the real operand is split into
-// fp16 hi + lo (22 mantissa bits, |g * alpha| < 65504), the ternary operand is EXACT in fp16, and every product is
-// two v_mfma_f32_16x16x32_f16 with fp32 accumulation: the rounding class of an fp32 convolution at 2/16 of the
-// fp32-MFMA matrix time.  alpha[o] is folded into the real operand (g' = alpha[o] * g, one fp32 multiply when the
-// tile enters LDS), so the weight operand stays ternary.
+// the library evaluates them as full fp32 convolutions (157 TF peak).  Here the real operand is split into THREE
+// bf16 terms hi + mid + lo (3 x 8 = 24 mantissa bits, and bf16 has the EXPONENT RANGE OF fp32: gradients of a
+// mean-reduced loss at batch 256 are 1e-5 .. 1e-9, where an fp16 split — round 2 — lost everything below its 2^-24
+// quantum), the ternary operand is EXACT in bf16, every product of two bf16 values is exact in fp32, and each
+// product of the GEMM is three v_mfma_f32_16x16x32_bf16 with fp32 accumulation: the rounding class of an fp32
+// convolution at any magnitude, at 3/16 of the fp32-MFMA matrix time (the kernels are bound by the VALU work of the
+// fills, not by the matrix pipe).  alpha[o] is folded into the real operand (g' = alpha[o] * g, one fp32 multiply
+// when the tile enters LDS), so the weight operand stays ternary.
 //
 // K-slots.  A row of W <= 64 pixels is given a power-of-two slot (8, 16, 32 or 64 pixels, zero filled); a 64-pixel
 // chunk of the GEMM's pixel dimension is 64/slot consecutive image rows.  An 8-element MFMA fragment never
@@ -43,7 +46,15 @@ constexpr int SROW = 68;         // dgrad output staging: floats per channel row
 }  // namespace grad
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half8 = __attribute__((ext_vector_type(8))) __bf16;   // eight bf16 values: one MFMA fragment (name kept: 16 bytes)
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u16 = unsigned short;                                   // the LDS planes are arrays of 16-bit containers
+constexpr unsigned short kBf16One = 0x3F80, kBf16MinusOne = 0xBF80;
+
+__device__ __forceinline__ half8 bf16_const8(unsigned short v) {
+  const unsigned d = (unsigned)v * 0x00010001u;
+  return __builtin_bit_cast(half8, u32x4{d, d, d, d});
+}
 
 struct GradGeo {
   int N, O, C;
@@ -57,13 +68,30 @@ struct GradGeo {
   int gshift;    // log2(slot / 8): 8-pixel groups per row slot
 };
 
-__device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo) {
+// v = hi + mid + lo (+ at most 2^-24 |v|): each term the TRUNCATION of what is left to bf16 (the remainders are exact
+// in fp32, so the three terms carry the leading 24 mantissa bits; truncation needs no rounding logic and one
+// v_perm_b32 packs two terms into a dword).  NaN / infinities travel in `hi` (the remainder of an infinity is NaN,
+// as in the fp32 product it stands for).
+__device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& mid, half8& lo) {
+  unsigned h[8], m[8], l[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const _Float16 h = (_Float16)v[e];
-    hi[e] = h;
-    lo[e] = (_Float16)(v[e] - (float)h);
+    h[e] = __float_as_uint(v[e]) & 0xFFFF0000u;
+    const float r1 = v[e] - __uint_as_float(h[e]);
+    m[e] = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(m[e]);
+    l[e] = __float_as_uint(r2);
   }
+  u32x4 ph, pm, pl;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {  // the upper halves of two dwords -> one dword
+    ph[e] = __builtin_amdgcn_perm(h[2 * e + 1], h[2 * e], 0x07060302u);
+    pm[e] = __builtin_amdgcn_perm(m[2 * e + 1], m[2 * e], 0x07060302u);
+    pl[e] = __builtin_amdgcn_perm(l[2 * e + 1], l[2 * e], 0x07060302u);
+  }
+  hi = __builtin_bit_cast(half8, ph);
+  mid = __builtin_bit_cast(half8, pm);
+  lo = __builtin_bit_cast(half8, pl);
 }
 
 // ------------------------------------------------------------------------------------------------- weight operand
@@ -84,14 +112,17 @@ __global__ __launch_bounds__(64) void grad_pack_weight_kernel(const float* __res
   const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
   const int cs = blockIdx.x % CS, tap = (blockIdx.x / CS) % T, ob = blockIdx.x / (CS * T);
   const int c = 16 * cs + li;
-  half8 b;
+  unsigned short b[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int o = 32 * ob + 8 * lg + e;
     const float v = (o < O && c < C) ? what[((size_t)o * C + c) * T + tap] : 0.0f;
-    b[e] = (_Float16)(v > 0.0f ? 1.0f : v < 0.0f ? -1.0f : 0.0f);
+    b[e] = v > 0.0f ? kBf16One : v < 0.0f ? kBf16MinusOne : (unsigned short)0;
   }
-  Bp[(size_t)blockIdx.x * 64 + lane] = b;
+  u32x4 pk;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) pk[e] = (unsigned)b[2 * e] | ((unsigned)b[2 * e + 1] << 16);
+  Bp[(size_t)blockIdx.x * 64 + lane] = __builtin_bit_cast(half8, pk);
 }
 
 // ------------------------------------------------------------------------------------------------- dgrad
@@ -109,8 +140,9 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int PD = KS / 2, T = KS * KS;
   const int PW = q.W + 2 * PD, PP = (q.R + 2 * PD) * PW;  // patch width / pixels (halo included)
-  _Float16* pa_hi = reinterpret_cast<_Float16*>(lds_raw);
-  _Float16* pa_lo = pa_hi + (size_t)PP * APIX;
+  u16* pa_hi = reinterpret_cast<u16*>(lds_raw);
+  u16* pa_mid = pa_hi + (size_t)PP * APIX;
+  u16* pa_lo = pa_mid + (size_t)PP * APIX;
   float* stage = reinterpret_cast<float*>(lds_raw);  // reused after the K loop
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -155,9 +187,10 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
         const float av = alpha[ok ? o : 0];
         v[e] = ok ? gv * av : 0.0f;
       }
-      half8 hi, lo;
-      split8(v, hi, lo);
+      half8 hi, mid, lo;
+      split8(v, hi, mid, lo);
       *reinterpret_cast<half8*>(pa_hi + pix * APIX + 8 * og) = hi;
+      *reinterpret_cast<half8*>(pa_mid + pix * APIX + 8 * og) = mid;
       *reinterpret_cast<half8*>(pa_lo + pix * APIX + 8 * og) = lo;
     }
     __syncthreads();
@@ -169,16 +202,18 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
 #pragma unroll
       for (int ns = 0; ns < NSUB; ++ns) {
         const int cs = cs0 + ns;
-        b[ns] = cs < CS ? Bp[((size_t)(ob * T + tap) * CS + cs) * 64 + lane] : half8{0, 0, 0, 0, 0, 0, 0, 0};
+        b[ns] = cs < CS ? Bp[((size_t)(ob * T + tap) * CS + cs) * 64 + lane] : bf16_const8(0);
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const half8 ah = *reinterpret_cast<const half8*>(pa_hi + abase[s] - toff);
+        const half8 am = *reinterpret_cast<const half8*>(pa_mid + abase[s] - toff);
         const half8 al = *reinterpret_cast<const half8*>(pa_lo + abase[s] - toff);
 #pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns) {
-          acc[s][ns] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b[ns], acc[s][ns], 0, 0, 0);
-          acc[s][ns] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b[ns], acc[s][ns], 0, 0, 0);
+        for (int ns = 0; ns < NSUB; ++ns) {  // smallest terms first
+          acc[s][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b[ns], acc[s][ns], 0, 0, 0);
+          acc[s][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, b[ns], acc[s][ns], 0, 0, 0);
+          acc[s][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[ns], acc[s][ns], 0, 0, 0);
         }
       }
     }
@@ -222,9 +257,10 @@ __global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict
   constexpr int PD = KS / 2, T = KS * KS, NJ = NC * T;  // NC 16-channel sub-tiles of input channels per workgroup
   const int BR = ST * q.RR + 2 * PD;         // sign(x) rows per chunk (all row slots + halo, zero where no image row)
   const int BROW = q.slot + 8;               // halves per row (16-byte aligned, bank spreading)
-  _Float16* a_hi = reinterpret_cast<_Float16*>(lds_raw);
-  _Float16* a_lo = a_hi + 64 * AROW;
-  _Float16* bsx = a_lo + 64 * AROW;          // [kx][c 0..16 NC-1][row 0..BR-1][BROW]
+  u16* a_hi = reinterpret_cast<u16*>(lds_raw);
+  u16* a_mid = a_hi + 64 * AROW;
+  u16* a_lo = a_mid + 64 * AROW;
+  u16* bsx = a_lo + 64 * AROW;          // [kx][c 0..16 NC-1][row 0..BR-1][BROW]
   const int bplane = 16 * NC * BR * BROW;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -266,9 +302,10 @@ __global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict
           const float gv = g[ok ? ((size_t)n * q.O + o) * HW + y * q.W + x : 0];
           v[e] = ok ? gv : 0.0f;
         }
-        half8 hi, lo;
-        split8(v, hi, lo);
+        half8 hi, mid, lo;
+        split8(v, hi, mid, lo);
         *reinterpret_cast<half8*>(a_hi + ol * AROW + 8 * g8) = hi;
+        *reinterpret_cast<half8*>(a_mid + ol * AROW + 8 * g8) = mid;
         *reinterpret_cast<half8*>(a_lo + ol * AROW + 8 * g8) = lo;
       }
       // ---- sign(x) rows ST*y0-PD .. of 16 NC input channels, KS copies: copy kx holds sx[ST*p + kx - PD] at slot p
@@ -277,34 +314,36 @@ __global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict
         const int cl = t / BR, pr = t - cl * BR;
         const int c = c0 + cl, y = ST * y0 - PD + pr;
         const bool rowok = c < q.C && (unsigned)y < (unsigned)q.Hx;
-        _Float16 s[8 * ST + 2 * PD];  // sx[ST*8j-PD .. ST*(8j+7)+PD]
+        u16 s[8 * ST + 2 * PD];  // sx[ST*8j-PD .. ST*(8j+7)+PD]
 #pragma unroll
         for (int e = 0; e < 8 * ST + 2 * PD; ++e) {
           const int x = ST * 8 * j - PD + e;
           const bool ok = rowok && (unsigned)x < (unsigned)q.Wx;
           const float xv = xin[ok ? ((size_t)n * q.C + c) * HWx + y * q.Wx + x : 0];
-          s[e] = (_Float16)((ok && xv > 0.0f) ? 1.0f : (ok && xv < 0.0f) ? -1.0f : 0.0f);
+          s[e] = (ok && xv > 0.0f) ? kBf16One : (ok && xv < 0.0f) ? kBf16MinusOne : (unsigned short)0;
         }
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
-          half8 hv;
+          u32x4 hv;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) hv[e] = s[ST * e + kx];
-          *reinterpret_cast<half8*>(bsx + kx * bplane + (cl * BR + pr) * BROW + 8 * j) = hv;
+          for (int e = 0; e < 4; ++e) hv[e] = (unsigned)s[ST * (2 * e) + kx] | ((unsigned)s[ST * (2 * e + 1) + kx] << 16);
+          *reinterpret_cast<u32x4*>(bsx + kx * bplane + (cl * BR + pr) * BROW + 8 * j) = hv;
         }
       }
       __syncthreads();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const half8 ah = *reinterpret_cast<const half8*>(a_hi + a_off[ks]);
+        const half8 am = *reinterpret_cast<const half8*>(a_mid + a_off[ks]);
         const half8 al = *reinterpret_cast<const half8*>(a_lo + a_off[ks]);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int sub = j / T, tap = j - sub * T, ky = tap / KS, kx = tap - ky * KS;
           const half8 b = *reinterpret_cast<const half8*>(bsx + kx * bplane + b_off[ks] +
                                                           (sub * 16 * BR + ky) * BROW);
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, b, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, b, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, b, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b, acc[j], 0, 0, 0);
         }
       }
     }
@@ -366,7 +405,7 @@ static int launch_dgrad_t(const float* g, const float* alpha, const void* packed
   using namespace grad;
   const int PP = (q.R + 2 * (KS / 2)) * (q.W + 2 * (KS / 2));
   const int nsub = q.C > 64 ? 2 : 1;
-  const size_t patch = (size_t)2 * PP * APIX * sizeof(_Float16);
+  const size_t patch = (size_t)3 * PP * APIX * sizeof(u16);
   const size_t stage = (size_t)64 * nsub * SROW * sizeof(float);
   const size_t lds = patch > stage ? patch : stage;
   const dim3 grid((unsigned)(q.N * q.chunks), (unsigned)((q.C + 64 * nsub - 1) / (64 * nsub)));
@@ -406,17 +445,15 @@ int launch_wgrad(const float* g, const float* xin, float* part, int splits, int 
   if ((N + per - 1) / per != splits) return BNN_HIP_ERR_INVALID_ARG;
   const int nc = ks == 3 ? 2 : kWgradNC1;
   const size_t lds =
-      (size_t)(2 * 64 * AROW + ks * 16 * nc * (stride * q.RR + 2 * (ks / 2)) * (q.slot + 8)) * sizeof(_Float16);
+      (size_t)(3 * 64 * AROW + ks * 16 * nc * (stride * q.RR + 2 * (ks / 2)) * (q.slot + 8)) * sizeof(u16);
   const dim3 grid((unsigned)splits, (unsigned)((C + 16 * nc - 1) / (16 * nc)), (unsigned)((O + 63) / 64));
   if (ks == 1) {
     hipLaunchKernelGGL((wgrad_kernel<1, 1, kWgradNC1>), grid, dim3(NT), lds, s, g, xin, part, q, per);
   } else if (stride == 2) {
-    static bool attr_set = false;  // up to 73 KB of dynamic LDS (7x7 outputs): needs the opt-in once
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<2, 3, 2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      attr_set = true;
-    }
+    // up to 82 KB of dynamic LDS (7x7 outputs) needs the opt-in: per device and per kernel, set on every launch
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<2, 3, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+      return BNN_HIP_ERR_LAUNCH;
     hipLaunchKernelGGL((wgrad_kernel<2, 3, 2>), grid, dim3(NT), lds, s, g, xin, part, q, per);
   } else {
     hipLaunchKernelGGL((wgrad_kernel<1, 3, 2>), grid, dim3(NT), lds, s, g, xin, part, q, per);

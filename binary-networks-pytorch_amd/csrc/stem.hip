@@ -276,21 +276,16 @@ static int launch_stem_t(const float* x, const float* w, const float* bn_a, cons
   const int Hp = (Hc + 2 - 3) / 2 + 1, Wp = (Wc + 2 - 3) / 2 + 1;
   const int tiles_y = (Hp + PTH - 1) / PTH, tiles_x = (Wp + PTW - 1) / PTW;
   const long long ntiles = (long long)N * tiles_y * tiles_x;
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-  }
+  const int cus = current_device_cus();
   const int per_xcd = (int)((ntiles + 7) / 8);
   const long long want = cus;  // one resident workgroup (8 waves) per CU
   const unsigned grid = (unsigned)(ntiles < want ? ((ntiles + 7) / 8 * 8) : want);
   const size_t lds_bytes = (size_t)lds_floats(SPLIT) * sizeof(float);
-  static bool attr_set[64] = {false};  // >64 KB of dynamic LDS needs the opt-in, once per device
-  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_bn_relu_pool_pack_kernel<SPLIT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (dev >= 0 && dev < 64) attr_set[dev] = true;
-  }
+  // > 64 KB of dynamic LDS needs the opt-in: per device and per kernel, so it is set on every launch (no mutable
+  // global state in a re-entrant API; the call is a table write on the host)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_bn_relu_pool_pack_kernel<SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds_bytes) != hipSuccess)
+    return BNN_HIP_ERR_LAUNCH;
   hipLaunchKernelGGL(stem_conv_bn_relu_pool_pack_kernel<SPLIT>, dim3(grid), dim3(NT), lds_bytes, stream,
                      x, w, bn_a, bn_b, N, H, W, Hc, Wc, Hp, Wp, tiles_y, tiles_x, per_xcd, out, P, M);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;

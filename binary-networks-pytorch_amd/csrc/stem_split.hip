@@ -418,20 +418,15 @@ static int launch_stem_split_t(const float* x, const float* w, const float* bn_a
   const int Hp = (Hc + 2 - 3) / 2 + 1, Wp = (Wc + 2 - 3) / 2 + 1;
   const int tiles_y = (Hp + PTH - 1) / PTH, tiles_x = (Wp + PTW - 1) / PTW;
   const long long ntiles = (long long)N * tiles_y * tiles_x;
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-  }
+  const int cus = current_device_cus();
   const int per_xcd = (int)((ntiles + 7) / 8);
   const long long want = (long long)cus * (8 / NW);  // 8 waves (two workgroups) per CU
   const unsigned grid = (unsigned)(ntiles < want ? ((ntiles + 7) / 8 * 8) : want);
-  static bool attr_set[64] = {false};  // > 64 KB of dynamic LDS needs the opt-in, once per device
-  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_split_kernel<HALF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (dev >= 0 && dev < 64) attr_set[dev] = true;
-  }
+  // > 64 KB of dynamic LDS needs the opt-in: per device and per kernel, so it is set on every launch (no mutable
+  // global state in a re-entrant API; the call is a table write on the host)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_split_kernel<HALF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          LDS_BYTES) != hipSuccess)
+    return BNN_HIP_ERR_LAUNCH;
   // byte sizes of the output streams (the C-ABI caps every tensor below 2^32 bytes)
   const unsigned out_bytes = (unsigned)((long long)N * COUT * Hp * Wp * 4);
   const unsigned plane_bytes = (unsigned)((long long)N * Hp * Wp * 8);

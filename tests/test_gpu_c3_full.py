@@ -34,9 +34,13 @@ DEV = "cuda:0"
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
-# images (of 256) allowed to differ from the reference in at least one sign(): measured on MI355X
-# (profiles/r02_c3_b256_parity.json) + 2 of slack for driver/compiler changes of the fp32 stem
-MAX_FLIPPED = {"layerwise": 10, "fused": 10, "fused_exact_stem": 10}
+# images (of 256) allowed to differ in at least one sign() from (the reference's fp32 forward, the reference evaluated
+# in fp64): the values measured on MI355X in rounds 2 and 3 (profiles/r03_c3_b256_parity_*.json: 2/3, 6/3, 3/2 — the
+# kernels are deterministic) + 1 for a driver / compiler change of the real-valued stem.  A regression from 2 flipped
+# images to 9 must not pass.
+MAX_FLIPPED = {"layerwise": (3, 4), "fused": (7, 4), "fused_exact_stem": (4, 3)}
+# every flip starts where the reference's own fp32 rounding decides: behind the real-valued stem / first residual sums
+EARLY_LAYERS = ("layer1.", "layer2.0.conv1", "layer2.0.downsample")
 
 
 def _r18(ctor=resnet18):
@@ -123,9 +127,11 @@ def test_c3_batch256_against_reference_forward(path, fixture, images):
     assert ok[~flipped].all() and ok64[~flipped64].all()
     assert rep["max_dev_without_flip"] <= 1e-4 * np.abs(ref).max()
     # (2) how many images saw a sign() decided differently (the reference vs its own fp64 evaluation: 3)
-    assert rep["images_with_a_sign_flip"] <= MAX_FLIPPED[path], rep
-    assert rep64["images_with_a_sign_flip"] <= MAX_FLIPPED[path], rep64
-    assert rep["within_tol"] >= 256 - MAX_FLIPPED[path]
+    assert rep["images_with_a_sign_flip"] <= MAX_FLIPPED[path][0], rep
+    assert rep64["images_with_a_sign_flip"] <= MAX_FLIPPED[path][1], rep64
+    assert rep["within_tol"] >= 256 - MAX_FLIPPED[path][0]
+    for r in (rep, rep64):
+        assert all(n.startswith(EARLY_LAYERS) for n in r["first_diverging_layer_histogram"]), r
 
 
 def test_c3_batch256_properties(images):

@@ -98,4 +98,12 @@ def test_bench_line_plain_vs_one_rank_under_the_launcher():
     assert plain["dist"] == {"world_size": 1, "initialized": False, "launcher": "none"}
     assert launched["dist"]["initialized"] and launched["dist"]["backend"] == "nccl"
     assert launched["dist"]["world_size"] == 1 and launched["dist"]["launcher"] == "torchrun"
+    # the N > 1 run validates itself: every rank recomputes the first images of every rank and compares them with its
+    # gathered copy (here: one rank, through RCCL all the same); per-rank step times are reported
+    assert launched["gather_check"] == {"ranks_checked": 1, "images_per_rank": 8, "bit_equal": True,
+                                        "how": launched["gather_check"]["how"]}
+    assert "gather_check" not in plain
+    for rec in (plain, launched):
+        pr = rec["per_rank_ms_per_step"]
+        assert len(pr["all"]) == 1 and pr["min"] == pr["max"] == pr["all"][0] > 0
     assert 0.5 < launched["value"] / plain["value"] < 2.0

@@ -110,6 +110,7 @@ def test_direct_layer_plans_fit_the_lds_and_cover_the_output():
         st, pl, d = plan(*sh)
         assert st == 0, sh
         assert 0 < pl.lds_bytes <= 160 * 1024 and 1 <= pl.waves <= 16 and pl.blocks_per_unit in (1, 2, 4)
+        assert pl.pack_ahead == pl.fine_head == pl.fine_tail == pl.producers == -1    # the planner's defaults
         ho = (d.H + 2 * d.pad_h - d.dil_h * (d.KH - 1) - 1) // d.stride_h + 1
         assert 1 <= pl.rows_per_band <= ho and (pl.images_per_band == 1 or pl.rows_per_band == ho)
         assert pl.n_bands == -(-d.N // pl.images_per_band) * -(-ho // pl.rows_per_band)

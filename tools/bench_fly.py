@@ -83,20 +83,20 @@ def run_shape(N, C, H, W, O, k, s, p, plans, spin=300, iters=30):
 
 out = {"device": info, "results": []}
 B = args.batch
-c2_plans = [plan(1, 56, 16, 2, prod=0), plan(1, 56, 16, 2, prod=1), plan(1, 56, 16, 2, prod=2), plan(1, 56, 16, 2, prod=3),
-            plan(1, 56, 16, 2, prod=4), plan(1, 56, 16, 2, prod=6), plan(1, 56, 16, 2, prod=8), plan(1, 56, 16, 1, prod=4),
-            plan(1, 56, 16, 4, prod=4), plan(1, 56, 16, 2, -1, 0, 0, 4), plan(1, 56, 16, 2, -1, 4, 4, 4),
-            plan(1, 56, 16, 4, -1, 3, 6, 4), plan(1, 56, 16, 2, -1, 2, 3, 2), plan(1, 28, 8, 2, prod=2), plan(1, 28, 8, 2, prod=1)]
+c2_plans = [plan(1, 56, 16, 2, prod=1), plan(1, 56, 16, 2, prod=2), plan(1, 56, 16, 2, prod=3)]
 out["results"].append(run_shape(B, 128, 56, 56, 128, 3, 1, 1, c2_plans if not args.quick else c2_plans[:3]))
 if not args.quick and not args.c2_only:
     for sh, pls in [
-        ((B, 64, 56, 56, 64, 3, 1, 1), [plan(1, 56, 8, 1), plan(1, 56, 8, 2), plan(1, 56, 16, 2), plan(1, 28, 8, 2)]),
-        ((B, 64, 56, 56, 128, 3, 2, 1), [plan(1, 28, 8, 2), plan(1, 28, 8, 4), plan(1, 14, 8, 2)]),
-        ((B, 128, 28, 28, 128, 3, 1, 1), [plan(1, 28, 8, 2), plan(2, 28, 8, 2), plan(2, 28, 16, 2), plan(4, 28, 16, 2)]),
-        ((B, 64, 28, 28, 128, 1, 1, 0), [plan(1, 28, 8, 1), plan(4, 28, 8, 1)]),
-        ((B, 256, 14, 14, 256, 3, 1, 1), [plan(2, 14, 8, 1), plan(4, 14, 8, 1), plan(4, 14, 16, 1), plan(8, 14, 16, 1)]),
-        ((B, 512, 7, 7, 512, 3, 1, 1), [plan(4, 7, 8, 1), plan(8, 7, 8, 1), plan(8, 7, 16, 1), plan(1, 7, 8, 1)]),
-        ((B, 256, 7, 7, 512, 1, 1, 0), [plan(4, 7, 8, 1), plan(16, 7, 8, 1)]),
+        ((B, 64, 56, 56, 64, 3, 1, 1), [plan(1, 56, 8, 2, prod=1), plan(1, 56, 8, 2, prod=2), plan(1, 56, 16, 2, prod=2), plan(1, 56, 8, 1, prod=1), plan(1, 28, 8, 2, prod=1)]),
+        ((B, 64, 56, 56, 128, 3, 2, 1), [plan(1, 28, 8, 2, prod=1), plan(1, 28, 8, 4, prod=1), plan(1, 28, 16, 2, prod=2), plan(1, 14, 8, 2, prod=1)]),
+        ((B, 128, 28, 28, 128, 3, 1, 1), [plan(1, 28, 8, 2, prod=1), plan(1, 28, 8, 2, prod=0), plan(1, 28, 16, 2, prod=2), plan(1, 28, 8, 4, prod=1), plan(1, 28, 4, 2, prod=1)]),
+        ((B, 64, 28, 28, 128, 1, 1, 0), [plan(1, 28, 8, 1, prod=1), plan(1, 28, 8, 4, prod=1), plan(1, 28, 4, 4, prod=1), plan(1, 28, 8, 2, prod=0)]),
+        ((B, 128, 28, 28, 256, 3, 2, 1), [plan(1, 14, 8, 1, prod=1), plan(1, 14, 8, 2, prod=1), plan(1, 14, 8, 4, prod=1), plan(1, 14, 4, 2, prod=1)]),
+        ((B, 256, 14, 14, 256, 3, 1, 1), [plan(1, 14, 8, 1, prod=1), plan(1, 14, 8, 2, prod=1), plan(1, 14, 8, 1, prod=0), plan(1, 14, 4, 1, prod=1), plan(1, 14, 16, 1, prod=2)]),
+        ((B, 128, 14, 14, 256, 1, 1, 0), [plan(1, 14, 8, 1, prod=1), plan(1, 14, 4, 2, prod=1), plan(1, 14, 4, 4, prod=0)]),
+        ((B, 256, 14, 14, 512, 3, 2, 1), [plan(1, 7, 8, 1, prod=1), plan(1, 7, 4, 1, prod=1), plan(1, 7, 8, 2, prod=1)]),
+        ((B, 512, 7, 7, 512, 3, 1, 1), [plan(1, 7, 8, 1, prod=1), plan(1, 7, 8, 1, prod=0), plan(1, 7, 4, 1, prod=1), plan(1, 7, 8, 2, prod=1), plan(1, 7, 16, 1, prod=2)]),
+        ((B, 256, 7, 7, 512, 1, 1, 0), [plan(1, 7, 8, 1, prod=1), plan(1, 7, 4, 2, prod=1), plan(1, 7, 4, 4, prod=0), plan(1, 7, 2, 4, prod=0)]),
     ]:
         out["results"].append(run_shape(*sh, pls, spin=150, iters=20))
 print(json.dumps(out, indent=1))
