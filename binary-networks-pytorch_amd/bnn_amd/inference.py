@@ -219,45 +219,54 @@ class FusedResNet(nn.Module):
             self._head = (fc.weight.detach().t().contiguous(), None if fc.bias is None else fc.bias.detach())
         for stage in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in stage:
-                if isinstance(blk, nn.AvgPool2d):   # HBlock stages pool in front (bnn_amd/models/resnet.py)
-                    self._blocks.append({"kind": "pool", "mod": blk})
-                    continue
-                if type(blk) is PreBasicBlock:      # BN-conv-act, BN-conv-act, (+id)   (res_block.py:147-152)
-                    entry = {"kind": "pre", "bn1": fold_bn(blk.bn1), "bn2": fold_bn(blk.bn2),
-                             "convs": [self._conv(blk.conv1, None, blk.act1), self._conv(blk.conv2, None, blk.act2)],
-                             "ds": None, "pool": 0}
-                    self._shortcut(blk, entry)
-                    self._blocks.append(entry)
-                    continue
-                if type(blk) is HBlock:             # three BN-act-conv stages, cat, (+id)  (hierarchical_block.py:38-60)
-                    entry = {"kind": "h", "planes": blk.conv1.out_channels * 2,
-                             "bn": [fold_bn(blk.bn1), fold_bn(blk.bn2), fold_bn(blk.bn3)],
-                             "relu": [self._sign_through(a) for a in (blk.act1, blk.act2, blk.act3)],
-                             "convs": [self._conv(c, None, None) for c in (blk.conv1, blk.conv2, blk.conv3)],
-                             "ds": None}
-                    if blk.downsample is not None:  # BN -> binary 1x1 (no BN behind it)
-                        bn, conv = blk.downsample[0], blk.downsample[1]
-                        entry["ds"] = (fold_bn(bn), self._conv(conv, None, None))
-                    self._blocks.append(entry)
-                    continue
-                if type(blk) is BasicBlock:      # conv-BN-act, conv-BN-(+id)-act
-                    convs = [self._conv(blk.conv1, blk.bn1, blk.act1), self._conv(blk.conv2, blk.bn2, blk.act2)]
-                elif type(blk) is Bottleneck:    # 1x1-BN-act, 3x3-BN-act, 1x1-BN-(+id)-act  (res_block.py:98-118)
-                    convs = [self._conv(blk.conv1, blk.bn1, blk.act1), self._conv(blk.conv2, blk.bn2, blk.act2),
-                             self._conv(blk.conv3, blk.bn3, blk.act3)]
-                else:
-                    raise FusionError(f"unsupported block {type(blk).__name__}")
-                entry = {"kind": "post", "convs": convs, "ds": None, "pool": 0}
-                self._shortcut(blk, entry)
-                self._blocks.append(entry)
+                self._add_block(blk)
         self._graph = None
         self._sig = self._signature()
+
+    def _add_block(self, blk) -> None:
+        """Derive the fused form of one residual block (appends to ``self._blocks``)."""
+        if isinstance(blk, nn.AvgPool2d):   # HBlock stages pool in front (bnn_amd/models/resnet.py)
+            self._blocks.append({"kind": "pool", "mod": blk})
+            return
+        if type(blk) is PreBasicBlock:      # BN-conv-act, BN-conv-act, (+id)   (res_block.py:147-152)
+            entry = {"kind": "pre", "bn1": fold_bn(blk.bn1), "bn2": fold_bn(blk.bn2),
+                     "convs": [self._conv(blk.conv1, None, blk.act1), self._conv(blk.conv2, None, blk.act2)],
+                     "ds": None, "pool": 0}
+            self._shortcut(blk, entry)
+            self._blocks.append(entry)
+            return
+        if type(blk) is HBlock:             # three BN-act-conv stages, cat, (+id)  (hierarchical_block.py:38-60)
+            entry = {"kind": "h", "planes": blk.conv1.out_channels * 2,
+                     "bn": [fold_bn(blk.bn1), fold_bn(blk.bn2), fold_bn(blk.bn3)],
+                     "relu": [self._sign_through(a) for a in (blk.act1, blk.act2, blk.act3)],
+                     "convs": [self._conv(c, None, None) for c in (blk.conv1, blk.conv2, blk.conv3)],
+                     "ds": None}
+            if blk.downsample is not None:  # BN -> binary 1x1 (no BN behind it)
+                bn, conv = blk.downsample[0], blk.downsample[1]
+                entry["ds"] = (fold_bn(bn), self._conv(conv, None, None))
+            self._blocks.append(entry)
+            return
+        if type(blk) is BasicBlock:      # conv-BN-act, conv-BN-(+id)-act
+            convs = [self._conv(blk.conv1, blk.bn1, blk.act1), self._conv(blk.conv2, blk.bn2, blk.act2)]
+        elif type(blk) is Bottleneck:    # 1x1-BN-act, 3x3-BN-act, 1x1-BN-(+id)-act  (res_block.py:98-118)
+            convs = [self._conv(blk.conv1, blk.bn1, blk.act1), self._conv(blk.conv2, blk.bn2, blk.act2),
+                     self._conv(blk.conv3, blk.bn3, blk.act3)]
+        else:
+            raise FusionError(f"unsupported block {type(blk).__name__}")
+        entry = {"kind": "post", "convs": convs, "ds": None, "pool": 0}
+        self._shortcut(blk, entry)
+        self._blocks.append(entry)
 
     def _shortcut(self, blk, entry) -> None:
         """AvgPool(ceil) -> binary 1x1 -> BN shortcut of bnn/models/resnet.py:128-133."""
         if blk.downsample is None:
             return
         pool, conv, bn = blk.downsample[0], blk.downsample[1], blk.downsample[2]
+        if _is_float_layer(conv):
+            # a real-valued shortcut convolution (examples/recepies/imagenet-baseline.yaml keeps
+            # layerN.0.downsample.1 out of the binarisation): the branch runs as the torch modules it is
+            entry["ds_float"] = blk.downsample
+            return
         k = pool.kernel_size if isinstance(pool.kernel_size, int) else pool.kernel_size[0]
         if not (isinstance(pool, nn.AvgPool2d) and pool.ceil_mode and not pool.count_include_pad
                 and pool.padding in (0, (0, 0))):
@@ -280,6 +289,15 @@ class FusedResNet(nn.Module):
         else:
             t = m.maxpool(m.relu(m.bn1(m.conv1(x))))
             packed = hipops.pack_act(t)
+        t = self._run_blocks(t, packed)
+        # real-valued head (last layer stays float)
+        if self._head is not None:
+            return hipops.avgpool_fc(t, *self._head)
+        return m.fc(torch.flatten(m.avgpool(t), 1))
+
+    def _run_blocks(self, t, packed):
+        """The residual blocks: ``t`` fp32 NCHW (may be None when only planes exist), ``packed`` its sign planes
+        or None.  Returns the fp32 output of the last block."""
         last = len(self._blocks) - 1
         for i, b in enumerate(self._blocks):
             nxt = self._blocks[i + 1] if i < last else None
@@ -317,6 +335,8 @@ class FusedResNet(nn.Module):
                     packed.P.record_stream(side)
                     sc_in.P.record_stream(side)
                     sc_in.M.record_stream(side)
+            elif b.get("ds_float") is not None:
+                idn = b["ds_float"](t)
             else:
                 idn = t
             for c in b["convs"][:-1]:           # activations travel between binary layers as bit planes
@@ -330,10 +350,7 @@ class FusedResNet(nn.Module):
             dead_f32 = (self.skip_dead_f32 and nxt is not None and nxt["kind"] == "post" and nxt["ds"] is not None
                         and (nxt["pool"] <= 1 or (c2.relu and c2.prelu is None)))
             t, packed = c2.run(packed, residual=idn, out_f32=not dead_f32, out_packed=i != last)
-        # real-valued head (last layer stays float)
-        if self._head is not None:
-            return hipops.avgpool_fc(t, *self._head)
-        return m.fc(torch.flatten(m.avgpool(t), 1))
+        return t
 
     def _side_stream(self, device) -> torch.cuda.Stream:
         key = (device.index, torch.cuda.current_stream(device).cuda_stream)
@@ -349,6 +366,8 @@ class FusedResNet(nn.Module):
         if b["ds"] is not None:
             sc_in = hipops.avgpool_pack(t, b["pool"]) if b["pool"] > 1 else hipops.pack_act(t)
             idn, _ = b["ds"].run(sc_in, out_f32=True, out_packed=False)
+        elif b.get("ds_float") is not None:
+            idn = b["ds_float"](t)
         else:
             idn = t
         c1, c2 = b["convs"]
@@ -428,6 +447,41 @@ class FusedResNet(nn.Module):
             self._gy = self._forward_impl(self._gx)
         self._graph = g
         return self
+
+
+class FusedBlocks(FusedResNet):
+    """The fused executor for a bare ``nn.Sequential`` of residual blocks (``BasicBlock`` / ``Bottleneck`` /
+    ``PreBasicBlock`` / ``HBlock``, optionally ``nn.AvgPool2d`` between them): fp32 NCHW in, fp32 NCHW out, the
+    activations between the binary layers travel as bit planes exactly as inside ``FusedResNet``.  For custom
+    networks that keep their own stem / head, and for testing the cross-block dataflow on its own."""
+
+    def __init__(self, blocks: nn.Sequential, throughput_mode: bool = False, int_thresholds: bool = True) -> None:
+        nn.Module.__init__(self)
+        self.skip_dead_f32 = True
+        self.int_thresholds = int_thresholds
+        self.throughput_mode = throughput_mode
+        self.overlap_shortcut = True
+        self._side = {}
+        self.model = blocks
+        self._blocks = []
+        self._graph = None
+        self.refresh()
+
+    def refresh(self) -> None:
+        native.require()
+        fastpath.invalidate(self.model)
+        if self.model.training:
+            raise FusionError("FusedBlocks is inference-only: call .eval() first")
+        self._blocks = []
+        self._names = {id(mod): name for name, mod in self.model.named_modules()}
+        for blk in self.model:
+            self._add_block(blk)
+        self._graph = None
+        self._sig = self._signature()
+
+    @torch.no_grad()
+    def _forward_impl(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run_blocks(hipops._require_cuda_f32(x, "activation"), None)
 
 
 class PipelinedInference:

@@ -111,3 +111,11 @@ LINEAR_CASES = [
     LinearCase("fc_10_3", 3, 10, 3, act="normal", post="scale"),
     LinearCase("fc_100_70_center", 5, 100, 70, act="sparse", center=True),
 ]
+
+
+def grad_case(name: str) -> LayerCase:
+    """The layer cases of the gradient fixtures (tests/golden/grads.npz, generated from the reference's autograd):
+    N = 2, a per-channel post scale, at most 14 x 14 pixels."""
+    import dataclasses
+    c = LAYER_CASES_BY_NAME[name]
+    return dataclasses.replace(c, N=2, post="scale", H=min(c.H, 14), W=min(c.W, 14))

@@ -31,7 +31,7 @@ from bnn.models.resnet import resnet18 as ref_resnet18  # noqa: E402
 from bnn.models.layers import Bottleneck as RefBottleneck, HBlock as RefHBlock, PreBasicBlock as RefPreBasicBlock  # noqa: E402
 
 from tests.golden import gen  # noqa: E402
-from tests.golden.cases import LAYER_CASES, LINEAR_CASES  # noqa: E402
+from tests.golden.cases import LAYER_CASES, LINEAR_CASES, grad_case  # noqa: E402
 
 assert os.path.realpath(bnn.__file__).startswith(os.path.realpath(REFERENCE)), bnn.__file__
 torch.set_num_threads(8)
@@ -266,10 +266,98 @@ def make_convert():
     print("convert ok")
 
 
+IMAGENET_STEP1_IGNORED = ["_last_", "_first_", "layer2.0.downsample.1", "layer3.0.downsample.1",
+                          "layer4.0.downsample.1"]
+
+
+def imagenet_step1_model():
+    """The reference's OTHER shipping dataflow (examples/imagenet.py:153-155 with step 1 of
+    examples/recepies/imagenet-baseline.yaml:16-31): resnet18(PreBasicBlock, PReLU), BasicInputBinarizer /
+    XNORWeightBinarizer(compute_alpha=False, center_weights=False) / BasicScaleBinarizer, first / last layer and
+    the three down-sampling 1x1 convolutions real-valued.  (BinaryChef itself needs `easydict`, which this
+    container lacks; what it evaluates for step 1 is exactly this prepare_binary_model call: bnn/engine.py:51-75.)"""
+    net = ref_resnet18(stem_type="basic", num_classes=1000, block_type=RefPreBasicBlock, activation=nn.PReLU)
+    cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=BasicScaleBinarizer,
+                      weight_pre_process=XNORWeightBinarizer.with_args(compute_alpha=False, center_weights=False))
+    net = bnn.prepare_binary_model(net, cfg, ignore_layers_name=list(IMAGENET_STEP1_IGNORED))
+    load_state(net, seed=7)
+    return net.eval()
+
+
+def make_prenet():
+    """G7: logits + per-image sign checksums of every binary convolution's input for the pre-activation PReLU
+    ResNet-18 of examples/imagenet.py, at 64x64 and 224x224 (2 images each)."""
+    net = imagenet_step1_model()
+    blob = {}
+    for tag, shape in (("64", (2, 3, 64, 64)), ("224", (2, 3, 224, 224))):
+        x = gen.normal(gen.seed_of("prenet18", tag), shape)
+        y, names, h = _binary_inputs(net, x)
+        blob["logits_" + tag], blob["sign_hash_" + tag] = y, h
+        print("prenet18", tag, y.shape, h.shape, float(np.abs(y).max()))
+    blob["layers"] = np.array(names)
+    blob["state_keys"] = np.array(list(net.state_dict().keys()))
+    blob["float_convs"] = np.array([n for n, m in net.named_modules()
+                                    if type(m) is nn.Conv2d or type(m) is nn.Linear])
+    np.savez_compressed(os.path.join(HERE, "prenet18.npz"), **blob)
+
+
+def make_stacks():
+    """G8: the cross-block packed dataflow of config 5's building blocks: nn.Sequential of three reference
+    HBlock(256, 256) (hierarchical_block.py:38-60) and of two Bottleneck(256, 64) (res_block.py:98-118) at 28x28,
+    outputs + the sign checksums in front of every binary convolution."""
+    blob = {}
+    specs = {
+        "hblock_x3": lambda: nn.Sequential(*[RefHBlock(256, 256, norm_layer=nn.BatchNorm2d) for _ in range(3)]),
+        "bottleneck_x2": lambda: nn.Sequential(*[RefBottleneck(256, 64) for _ in range(2)]),
+    }
+    for name, ctor in specs.items():
+        net = bnn.prepare_binary_model(ctor(), xnor_cfg())
+        load_state(net, seed=gen.seed_of("stack", name))
+        net.eval()
+        x = gen.normal(gen.seed_of("stackx", name), (2, 256, 28, 28))
+        y, names, h = _binary_inputs(net, x)
+        # (fixture size: every 4th output channel in full + the per-channel sums of all of them)
+        blob[name + "/out_c4"], blob[name + "/out_sum"] = y[:, ::4].copy(), y.astype(np.float64).sum((2, 3))
+        blob[name + "/sign_hash"], blob[name + "/layers"] = h, np.array(names)
+        print("stack", name, y.shape, h.shape, float(np.abs(y).max()))
+    np.savez_compressed(os.path.join(HERE, "stacks.npz"), **blob)
+
+
+GRAD_CASES = ("c2_relu", "l2_0_c1_s2", "l3_ds_1x1")
+
+
+def make_grads():
+    """G9: the reference's OWN autograd through one binary layer (straight-through estimator on the activations
+    bnn/ops.py:68-73, on the weights through bnn/ops.py:136, the alpha path bnn/ops.py:116-127, the post scale
+    bnn/ops.py:200-202): dL/dx, dL/dW, dL/d(post alpha) for L = sum(out * G), at N = 2."""
+    blob = {}
+    for name in GRAD_CASES:
+        case = grad_case(name)
+        x, w, b, sc = case.tensors()
+        x = (0.9 * x).astype(np.float32)            # part of the activations inside the STE window |x| < 1
+        conv = nn.Conv2d(case.C, case.O, case.k, stride=case.stride, padding=case.pad, bias=False)
+        conv.weight.data.copy_(t(w))
+        cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=BasicScaleBinarizer,
+                          weight_pre_process=XNORWeightBinarizer)
+        layer = bnn.prepare_binary_model(conv, cfg).train()
+        layer.activation_post_process.alpha.data.copy_(t(sc).view(1, -1, 1, 1))
+        xt = t(x).requires_grad_(True)
+        out = layer(xt)
+        G = gen.normal(gen.seed_of("gradG", name), tuple(out.shape))
+        (out * t(G)).sum().backward()
+        # (x, G and the weights are regenerated by the tests from the same seeds; dW: every 2nd output channel)
+        blob[name + "/dx"] = xt.grad.numpy()
+        blob[name + "/dw_o2"] = layer.weight.grad.numpy()[::2].copy()
+        blob[name + "/dw_sum"] = layer.weight.grad.numpy().astype(np.float64).sum((1, 2, 3))
+        blob[name + "/dscale"] = layer.activation_post_process.alpha.grad.numpy()
+        print("grad", name, out.shape, float(np.abs(blob[name + "/dx"]).max()), float(np.abs(blob[name + "/dw_o2"]).max()))
+    np.savez_compressed(os.path.join(HERE, "grads.npz"), **blob)
+
+
+ALL = {"ref_test_layers": make_ref_test_layers, "layers": make_layers, "resnet18": make_resnet18,
+       "resnet18_b256": make_resnet18_b256, "blocks": make_blocks, "convert": make_convert,
+       "prenet": make_prenet, "stacks": make_stacks, "grads": make_grads}
+
 if __name__ == "__main__":
-    make_ref_test_layers()
-    make_layers()
-    make_resnet18()
-    make_resnet18_b256()
-    make_blocks()
-    make_convert()
+    for which in (sys.argv[1:] or list(ALL)):   # no argument: every fixture
+        ALL[which]()
