@@ -187,6 +187,7 @@ def conv_c2_roofline(device, info, batch=256, iters=50, act_kind="relu", nonneg=
                              "frac": lane_ops / t_both / peak, "kernel": "bconv_fly_kernel<3,3,4>",
                              "algorithmic_bytes": N * C * H * W * 4 + out_bytes + O * K // 8,
                              "GBps": (N * C * H * W * 4 + out_bytes) / t_both / 1e9,
+                             "traffic": fly_traffic()[0], "traffic_note": fly_traffic()[1],
                              "note": "config 2 as BASELINE.json words it, ONE launch (bnn_hip_bconv2d_direct): "
                                      "activations binarised on the fly into LDS, no packed copy in HBM",
                              "two_launch_form": {"us": t_two * 1e6, "frac": lane_ops / t_two / peak,
@@ -206,7 +207,7 @@ def pmc_traffic():
     (profiles/rNN_c2_pmc_counters.json, collected by tools/gpu_profile.sh with separate --pmc runs).
     FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
     (checked on this box: pack_act's 411 MB float4 stream reads as 205 MB)."""
-    for name in ("r02_c2_pmc_counters.json", "r01_c2_pmc_counters.json"):
+    for name in ("r03_c2_pmc_counters.json", "r02_c2_pmc_counters.json", "r01_c2_pmc_counters.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 pmc = json.load(fh)
@@ -214,6 +215,19 @@ def pmc_traffic():
             return (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024, \
                 f"2*FETCH_SIZE + WRITE_SIZE from profiles/{name} (same kernel, same shape)"
         except (OSError, StopIteration, KeyError, ValueError):
+            continue
+    return None, "no PMC summary committed"
+
+
+def fly_traffic():
+    """HBM bytes per launch of the one-launch layer kernel from its committed PMC passes
+    (profiles/rNN_c2_fused_pmc.json: 2*FETCH_SIZE + WRITE_SIZE, KiB, same correction as above)."""
+    for name in ("r03_c2_fused_pmc.json",):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                k = json.load(fh)
+            return (2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024, f"2*FETCH_SIZE + WRITE_SIZE from profiles/{name}"
+        except (OSError, KeyError, ValueError):
             continue
     return None, "no PMC summary committed"
 

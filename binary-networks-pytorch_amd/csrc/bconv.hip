@@ -366,6 +366,12 @@ static unsigned oblocks(const ConvP& p) {
 #define BNN_SGPR_PASSES_MULTI 1
 #endif
 
+#ifndef BNN_SINGLE_GSPLIT  // pieces a 32-channel block of a SINGLE-chunk conv1-type 3x3 layer is split into (1 = off)
+#define BNN_SINGLE_GSPLIT 1
+#endif
+#ifndef BNN_SINGLE_GSPLIT_MAX_WAVES  // ...when the unsplit launch has at most this many waves
+#define BNN_SINGLE_GSPLIT_MAX_WAVES 8192
+#endif
 #ifndef BNN_MULTI_GSPLIT  // pieces a 32-channel block of a multi-chunk 3x3 layer is split into (1 = off)
 #define BNN_MULTI_GSPLIT 2
 #endif
@@ -398,6 +404,18 @@ static void launch_sgpr_t(const ConvP& p, const Geo& g, bool split_ok, hipStream
       if (oblocks(p) >= BNN_SGPR_OBW) {
         const dim3 grid2((unsigned)(8 * g.tiles_per_xcd) * ((oblocks(p) + BNN_SGPR_OBW - 1) / BNN_SGPR_OBW));
         hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, P1, false, false, NN, false, BNN_SGPR_OBW>), grid2,
+                           dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
+        return;
+      }
+    }
+#endif
+#if BNN_SINGLE_GSPLIT > 1
+    // few waves (the stride-2 first convs of a stage at batch 256: 6-12 k waves over ~7 k slots — pure wave
+    // quantisation): the passes of a block become separate waves, each with its own load of the field
+    if constexpr (EP == EP_MID || EP == EP_MIDT) {
+      if (split_ok && (long long)grid.x <= BNN_SINGLE_GSPLIT_MAX_WAVES) {
+        const dim3 grid2(grid.x * BNN_SINGLE_GSPLIT);
+        hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, BNN_SINGLE_GSPLIT, false, true, NN>), grid2,
                            dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
         return;
       }

@@ -8,19 +8,31 @@ import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+import subprocess
+# the GPU box runs a snapshot of the working tree: collect right after the run, from a clean tree, and stamp the commit
+COMMIT = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+DIRTY = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True,
+                            text=True).stdout.strip())
+STAMP = {"commit": COMMIT + ("+uncommitted" if DIRTY else ""), "collected_by": "tools/gpu_profile.sh + tools/collect_profiles.py"}
 src = os.path.join(ROOT, "gpurun_out", "final")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
+def stamped(line, cmd):
+    rec = json.loads(line)
+    rec["provenance"] = dict(STAMP, command=cmd)
+    return json.dumps(rec)
+
+
 line = open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1]
-json.loads(line)
-open(os.path.join(dst, f"{tag}_bench.json"), "w").write(line + "\n")
+open(os.path.join(dst, f"{tag}_bench.json"), "w").write(stamped(line, "python bench.py --steps 20 --warmup 5") + "\n")
 for extra in ("c2", "c5"):
     fn = os.path.join(src, f"bench_{extra}.json")
     if os.path.exists(fn) and open(fn).read().strip():
         ln = open(fn).read().strip().splitlines()[-1]
-        json.loads(ln)
-        open(os.path.join(dst, f"{tag}_bench_{extra}.json"), "w").write(ln + "\n")
+        cmd = {"c2": "python bench.py --config c2 --steps 20 --warmup 5",
+               "c5": "python bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline"}[extra]
+        open(os.path.join(dst, f"{tag}_bench_{extra}.json"), "w").write(stamped(ln, cmd) + "\n")
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
@@ -44,6 +56,7 @@ if sagg:
     if sdur:
         stem["avg_duration_us_profiled"] = round(sum(sdur) / len(sdur), 1)
     stem["kernel"] = "bnn::stem_split_kernel<false>, batch 256, 224x224, fp32 + sign planes out (tools/bench_stem.py)"
+    stem["provenance"] = STAMP
     json.dump(stem, open(os.path.join(dst, f"{tag}_stem_pmc.json"), "w"), indent=1, sort_keys=True)
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -64,7 +77,44 @@ for name, d in agg.items():
     out[name] = {c: int(round(sum(v) / len(v))) for c, v in sorted(d.items())}
     if dur[name]:
         out[name]["avg_duration_us_profiled"] = round(sum(dur[name]) / len(dur[name]), 1)
+out["provenance"] = STAMP
 json.dump(out, open(os.path.join(dst, f"{tag}_c2_pmc_counters.json"), "w"), indent=1, sort_keys=True)
+del out["provenance"]
+
+# the one-launch layer on config 2 (tools/run_fly.py under rocprofv3, separate passes)
+fagg = collections.defaultdict(list)
+fdur = []
+for f in glob.glob(os.path.join(src, "fly_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "bconv_fly" in r["Kernel_Name"]:
+            fagg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for f in glob.glob(os.path.join(src, "fly_sq1", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "bconv_fly" in r["Kernel_Name"]:
+            fdur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+if fagg:
+    fly = {c: int(round(sum(v) / len(v))) for c, v in sorted(fagg.items())}
+    if fdur:
+        fly["avg_duration_us_profiled"] = round(sum(fdur) / len(fdur), 1)
+    fly["kernel"] = ("bnn::bconv_fly_kernel<3,3,4,false,false>: Conv2d 128->128 3x3 pad 1, x [256,128,56,56] fp32 in, "
+                     "fp32 out, default plan (tools/run_fly.py)")
+    if "FETCH_SIZE" in fly and "WRITE_SIZE" in fly:
+        fly["hbm_bytes_per_launch"] = (2 * fly["FETCH_SIZE"] + fly["WRITE_SIZE"]) * 1024
+        fly["algorithmic_bytes"] = 256 * 128 * 56 * 56 * 4 * 2 + 128 * 1152 // 8
+        fly["traffic_over_algorithmic"] = round(fly["hbm_bytes_per_launch"] / fly["algorithmic_bytes"], 3)
+        fly["note"] = "FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950"
+    fly["provenance"] = STAMP
+    json.dump(fly, open(os.path.join(dst, f"{tag}_c2_fused_pmc.json"), "w"), indent=1, sort_keys=True)
+    print("fly", {k: fly.get(k) for k in ("SQ_INSTS_VALU", "SQ_WAVES", "avg_duration_us_profiled", "traffic_over_algorithmic")})
+stats_c2 = glob.glob(os.path.join(src, "stats_c2", "**", "*kernel_stats.csv"), recursive=True)
+if stats_c2:
+    shutil.copy(stats_c2[0], os.path.join(dst, f"{tag}_bench_c2_kernel_stats.csv"))
+for n in ("layerwise", "fused", "fused_exact_stem"):     # written by tests/test_gpu_c3_full.py on the GPU box
+    fn = os.path.join(ROOT, "gpurun_out", f"c3_b256_parity_{n}.json")
+    if os.path.exists(fn):
+        rec = json.load(open(fn))
+        rec["provenance"] = STAMP
+        json.dump(rec, open(os.path.join(dst, f"{tag}_c3_b256_parity_{n}.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(dst)))
 for name, d in out.items():
     print(name[:70], {k: d[k] for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_WAVES", "avg_duration_us_profiled") if k in d})

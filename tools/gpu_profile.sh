@@ -15,6 +15,15 @@ pmc sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTI
 pmc grbm GRBM_GUI_ACTIVE GRBM_COUNT
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
+# the one-launch layer (bconv_fly_kernel) on config 2: the same counter passes, default plan
+fpmc() { n=$1; shift
+  ITERS=4 timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/fly_$n" -o fly_$n -- python "$R/tools/run_fly.py" > "$OUT/fly_$n.log" 2>&1; }
+fpmc sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
+fpmc sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT
+fpmc grbm GRBM_GUI_ACTIVE
+fpmc fetch FETCH_SIZE
+fpmc write WRITE_SIZE
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -o bench_c2 -- python "$R/bench.py" --config c2 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/stats_c2.log" 2>&1
 spmc() { n=$1; shift
   ONLY=default timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/stem_$n" -o stem_$n -- python "$R/tools/bench_stem.py" > "$OUT/stem_$n.log" 2>&1; }
 spmc a SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
@@ -23,5 +32,8 @@ spmc c SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACT
 spmc d GRBM_GUI_ACTIVE
 spmc e FETCH_SIZE
 spmc f WRITE_SIZE
+# VALU instructions per wave of every launch of one forward, from the SAME build (tools/kernel_roofline.py)
+bash "$R/tools/pmc_net.sh" > "$OUT/pmc_net.log" 2>&1
+cd /tmp
 find "$OUT" -name "*kernel_trace.csv" -size +8M -delete
 cut -c1-400 "$OUT/bench.json"; echo; head -8 "$OUT"/stats1/*kernel_stats.csv 2>/dev/null | cut -c1-140
