@@ -186,6 +186,7 @@ __device__ __forceinline__ uint32_t take_ticket(uint32_t* ctr, int lane) {
 }
 
 constexpr int kClassNonzero = kClassPos | kClassNeg;  // finite non-zero or infinite: sign(x) != 0
+constexpr uint32_t kReadyNeg = 0x10000u;  // ready[] = items packed (low half) + kReadyNeg per item with a negative value
 
 #ifndef BNN_FLY_LOAD_AUX  // cache policy of the activation loads: 2 = nt on gfx950 (the tensor is read exactly once;
 #define BNN_FLY_LOAD_AUX 2  // measured on config 2: 254 us with nt, 269 us with the default policy)
@@ -311,6 +312,7 @@ __device__ __forceinline__ bool pack_item(const void* __restrict__ x, const Geo&
   const unsigned a0 = ((unsigned)(wch * f.ncell) + cell) * (unsigned)f.cwc + (unsigned)(w0 - wch * f.cwc);
   const BufRsrc rx = make_rsrc_sized(x, f.x_bytes);
   uint32_t nonzero = 0u;
+  [[maybe_unused]] uint32_t anyneg = 0u;
 #pragma unroll 1
   for (int k = 0; k < f.wpi; ++k) {
     const int nch = f.C - (w0 + k) * 32;
@@ -326,24 +328,37 @@ __device__ __forceinline__ bool pack_item(const void* __restrict__ x, const Geo&
       c.ldsM[a0 + (unsigned)k] = Mw;
     }
     nonzero += (uint32_t)__builtin_popcount(Pw | Mw);
+    anyneg |= Mw;
   }
   if (valid)
     __hip_atomic_fetch_add(&c.cnt[cell], nonzero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  // the cell writes of every lane precede the counter update in this wave's LDS instruction stream
-  if (c.lane == 0) __hip_atomic_fetch_add(&c.ready[ipg], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // the cell writes of every lane precede the counter update in this wave's LDS instruction stream.  The counter's
+  // upper half records whether the item saw a NEGATIVE value: units whose inputs have none (the output of a ReLU —
+  // most binary layers of the reference's nets) run the P-plane-only loop (kReadyNeg).
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t inc = 1u + (__builtin_amdgcn_ballot_w64(valid && anyneg != 0u) != 0ull ? kReadyNeg : 0u);
+#else
+  const uint32_t inc = 1u;
+#endif
+  if (c.lane == 0) __hip_atomic_fetch_add(&c.ready[ipg], inc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   return true;
 }
 
-// True when every input pixel group in [lo, hi] is completely packed.
-__device__ __forceinline__ bool range_ready(const FlyGeo& f, const FlyCtx& c, int lo, int hi) {
-  bool missing = false;
-  for (int i = lo + c.lane; i <= hi; i += 64)
-    missing |= __hip_atomic_load(&c.ready[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)f.gpi;
+// True when every input pixel group in [lo, hi] is completely packed; `anyneg`: some of them hold a negative value.
+__device__ __forceinline__ bool range_ready(const FlyGeo& f, const FlyCtx& c, int lo, int hi, bool& anyneg) {
+  bool missing = false, neg = false;
+  for (int i = lo + c.lane; i <= hi; i += 64) {
+    const uint32_t v = __hip_atomic_load(&c.ready[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    missing |= (v & (kReadyNeg - 1u)) < (uint32_t)f.gpi;
+    neg |= v >= kReadyNeg;
+  }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (__builtin_amdgcn_ballot_w64(missing) != 0ull) return false;
+  anyneg = __builtin_amdgcn_ballot_w64(neg) != 0ull;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   return true;
 #else
+  anyneg = neg;
   return !missing;
 #endif
 }
@@ -356,7 +371,8 @@ __device__ unsigned long long bnn_fly_dbg[8 * 16 * 4096];
 #endif
 
 // The dataflow skeleton: zero fill, producers, then units until the tickets run out.
-// `conv(g, f, B, c, pg, p0, np, lane)` computes one unit: passes p0 .. p0+np-1 of pixel group pg.
+// `conv(g, f, B, c, pg, p0, np, lane, nonneg)` computes one unit: passes p0 .. p0+np-1 of pixel group pg; `nonneg`:
+// no negative value under the unit's receptive fields (M planes all zero).
 template <class ConvUnit>
 __device__ __forceinline__ void fly_run(const void* __restrict__ x, unsigned char* smem, ConvUnit&& conv) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -374,7 +390,7 @@ __device__ __forceinline__ void fly_run(const void* __restrict__ x, unsigned cha
     const FlyGeos A = fresh_geo();
     const Band B = make_band(A.g, A.f, blockIdx.x);
     uint32_t* ready = reinterpret_cast<uint32_t*>(smem + A.f.off_ready);
-    for (int i = tid; i < B.nipg; i += blockDim.x) ready[i] = (uint32_t)A.f.gpi;
+    for (int i = tid; i < B.nipg; i += blockDim.x) ready[i] = (uint32_t)A.f.gpi + kReadyNeg;
     __syncthreads();
   }
 #endif
@@ -428,9 +444,10 @@ __device__ __forceinline__ void fly_run(const void* __restrict__ x, unsigned cha
     }
     need_range(g, f, B, pg, lo, hi);  // this unit's own inputs
     [[maybe_unused]] const unsigned long long t_u0 = FLY_NOW();
+    bool anyneg = true;
     for (unsigned idle = 0;;) {
       if (__hip_atomic_load(&c.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want &&
-          range_ready(f, c, lo, hi))
+          range_ready(f, c, lo, hi, anyneg))
         break;
       if (pack_item(x, g, f, B, c)) {  // whoever waits works
 #ifdef BNN_FLY_TIMING
@@ -448,7 +465,7 @@ __device__ __forceinline__ void fly_run(const void* __restrict__ x, unsigned cha
     if (!t_first) t_first = t_c0;
     t_wait += t_c0 - t_u0;
 #endif
-    conv(g, f, B, c, pg, p0, np, lane);
+    conv(g, f, B, c, pg, p0, np, lane, !anyneg);
 #ifdef BNN_FLY_TIMING
     t_conv += FLY_NOW() - t_c0;
     ++n_units;
@@ -472,6 +489,11 @@ __device__ __forceinline__ void fly_run(const void* __restrict__ x, unsigned cha
 #define BNN_FLY_ILP 2
 #endif
 constexpr int kIlp = BNN_FLY_ILP;
+#ifndef BNN_FLY_NONNEG  // 1: units without a negative input take the P-plane-only loop (v_and + v_bcnt).  Measured on
+#define BNN_FLY_NONNEG 0  // config 2 with a ReLU input: 234.4 us against 227.8 us without it — both loops in one kernel
+#endif                    // (16 waves at different places of two 9 KB loop bodies) cost more than the faster pair gains,
+                          // although the P-only PACKED kernel is the faster one (195 vs 201 us).  Off; tested when on.
+constexpr bool kFlyNonneg = BNN_FLY_NONNEG != 0;
 
 template <int KH, int KW, int CWC, bool MULTI, bool WZ>
 struct TiledUnit {
@@ -493,6 +515,7 @@ struct TiledUnit {
     }
   }
 
+  template <bool NN>
   __device__ static __forceinline__ void load_chunk(const FlyCtx& c, unsigned cell0, unsigned chunk_cells, int WP,
                                                     uint32_t (&pr)[NW], uint32_t (&mr)[NW]) {
     const unsigned base = chunk_cells + cell0;
@@ -500,16 +523,17 @@ struct TiledUnit {
     for (int t = 0; t < T; ++t) {
       const unsigned wo = (base + (unsigned)((t / KW) * WP + (t % KW))) * CWC;
       lds_words<CWC>(c.ldsP, wo, &pr[t * CWC]);
-      lds_words<CWC>(c.ldsM, wo, &mr[t * CWC]);
+      if constexpr (!NN) lds_words<CWC>(c.ldsM, wo, &mr[t * CWC]);
     }
   }
 
   // One unit: passes p0 .. p0+np-1 of pixel group `pg` (pass p = channels (p % PASSES) * NACC .. of block p / PASSES).
-  __device__ static __forceinline__ void run(const FlyPtrs& P, const Geo& g, const FlyGeo& f, const Band& B,
-                                             const FlyCtx& c, int pg, int p0, int np, int lane) {
-#ifdef BNN_FLY_EXP_SKIP_CONV  // experiment: the packing pipeline alone
-    return;
-#endif
+  // NN: no negative value under the unit's windows (the M plane reads all zero): the P plane alone stays in
+  // registers and the loop counts AGREEMENTS, popcount(w & p), with v_and_b32 + v_bcnt_u32_b32 — the pair issues
+  // ~10 % faster than v_bitop3_b32 + v_bcnt_u32_b32 (43.5 vs 39.3 T lane-op/s); dot = 2 * agreements - non-zeros.
+  template <bool NN>
+  __device__ static __forceinline__ void unit(const FlyPtrs& P, const Geo& g, const FlyGeo& f, const Band& B,
+                                              const FlyCtx& c, int pg, int p0, int np, int lane) {
     const EpiArgs epi{P.alpha, P.bias, P.scale, nullptr, nullptr, nullptr, nullptr, P.out,
                       nullptr, nullptr, nullptr, nullptr, nullptr};
     const int jl = min((pg << 6) + lane, B.npix - 1);  // lanes past the band's last pixel copy it (same stores)
@@ -517,12 +541,16 @@ struct TiledUnit {
     const int WP = f.WP, ncell = f.ncell;
     const unsigned cell0 = (unsigned)(((px.n - B.n0) * f.HPS + (px.oy - B.oy0) * g.sh) * WP + px.ox * g.sw);
     uint32_t pr[NW], mr[NW];
+    if constexpr (NN) {
+#pragma unroll
+      for (int i = 0; i < NW; ++i) mr[i] = 0u;
+    }
     int nz = 0;  // non-zero inputs under the window: the per-cell counters of the taps
     if constexpr (!WZ) {
 #pragma unroll
       for (int t = 0; t < T; ++t) nz += (int)c.cnt[cell0 + (unsigned)((t / KW) * WP + (t % KW))];
     }
-    if constexpr (!MULTI) load_chunk(c, cell0, 0u, WP, pr, mr);
+    if constexpr (!MULTI) load_chunk<NN>(c, cell0, 0u, WP, pr, mr);
 #pragma unroll 1
     for (int p = p0; p < p0 + np; ++p) {
       const int ob = PASSES == 1 ? p : p / PASSES, ps = PASSES == 1 ? 0 : p - ob * PASSES;
@@ -541,35 +569,52 @@ struct TiledUnit {
       }
       if constexpr (MULTI) {
         for (int ch = 0; ch < g.nchunk; ++ch) {
-          load_chunk(c, cell0, (unsigned)(ch * ncell), WP, pr, mr);
+          load_chunk<NN>(c, cell0, (unsigned)(ch * ncell), WP, pr, mr);
           const size_t woff = ((size_t)ch * kOCB + ps * NACC) * NW;
           if constexpr (WZ) stream_weights_wz<NW, NACC>(wblk + woff, zblk + woff, pr, mr, acc, nzacc);
-          else stream_weights<NW, NACC, false, false, false, kIlp>(wblk + woff, pr, mr, acc);
+          else stream_weights<NW, NACC, NN, false, false, kIlp>(wblk + woff, pr, mr, acc);
         }
       } else {
         const size_t woff = (size_t)ps * (NACC * NW);
         if constexpr (WZ) stream_weights_wz<NW, NACC>(wblk + woff, zblk + woff, pr, mr, acc, nzacc);
-        else stream_weights<NW, NACC, false, true, false, kIlp>(wblk + woff, pr, mr, acc,
-                                                                SEEDED ? (int)kCountSeed : 0);
+        else stream_weights<NW, NACC, NN, true, false, kIlp>(wblk + woff, pr, mr, acc,
+                                                             SEEDED ? (int)kCountSeed : 0);
       }
       const int o0 = ob * kOCB + ps * NACC;
       uint32_t pbits = 0u, mbits = 0u;  // (no packed output here)
+      auto to_dot = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) acc[j] = WZ ? nzacc[j] - 2 * acc[j] : NN ? 2 * acc[j] - nz : nz - 2 * acc[j];
+      };
       if (fullb) {
         if constexpr (SEEDED) {
-          epilogue<NACC, EP_PLAIN, true, true>(g, px, o0, acc, resv, epi, pbits, mbits, 0, -2.0f, (float)nz);
+          epilogue<NACC, EP_PLAIN, true, true>(g, px, o0, acc, resv, epi, pbits, mbits, 0, NN ? 2.0f : -2.0f,
+                                               NN ? -(float)nz : (float)nz);
         } else {
-#pragma unroll
-          for (int j = 0; j < NACC; ++j) acc[j] = WZ ? nzacc[j] - 2 * acc[j] : nz - 2 * acc[j];
+          to_dot();
           epilogue<NACC, EP_PLAIN, true>(g, px, o0, acc, resv, epi, pbits, mbits);
         }
       } else {
+        if constexpr (SEEDED) {
 #pragma unroll
-        for (int j = 0; j < NACC; ++j) {
-          if constexpr (SEEDED) acc[j] -= (int)kCountSeed;
-          acc[j] = WZ ? nzacc[j] - 2 * acc[j] : nz - 2 * acc[j];
+          for (int j = 0; j < NACC; ++j) acc[j] -= (int)kCountSeed;
         }
+        to_dot();
         epilogue<NACC, EP_PLAIN>(g, px, o0, acc, resv, epi, pbits, mbits);
       }
+    }
+  }
+
+  __device__ static __forceinline__ void run(const FlyPtrs& P, const Geo& g, const FlyGeo& f, const Band& B,
+                                             const FlyCtx& c, int pg, int p0, int np, int lane, bool nonneg) {
+#ifdef BNN_FLY_EXP_SKIP_CONV  // experiment: the packing pipeline alone
+    return;
+#endif
+    if constexpr (WZ || !kFlyNonneg) {
+      unit<false>(P, g, f, B, c, pg, p0, np, lane);
+    } else {
+      if (nonneg) unit<true>(P, g, f, B, c, pg, p0, np, lane);
+      else unit<false>(P, g, f, B, c, pg, p0, np, lane);
     }
   }
 };
@@ -580,9 +625,8 @@ template <int KH, int KW, int CWC, bool MULTI, bool WZ>
 __global__ __launch_bounds__(1024) void bconv_fly_kernel(BNN_FLY_PARAMS) {
   const FlyPtrs P = BNN_FLY_PTRS;
   fly_run(x, fly_smem,
-          [&](const Geo& g, const FlyGeo& f, const Band& B, const FlyCtx& c, int pg, int p0, int np, int lane) {
-            TiledUnit<KH, KW, CWC, MULTI, WZ>::run(P, g, f, B, c, pg, p0, np, lane);
-          });
+          [&](const Geo& g, const FlyGeo& f, const Band& B, const FlyCtx& c, int pg, int p0, int np, int lane,
+              bool nonneg) { TiledUnit<KH, KW, CWC, MULTI, WZ>::run(P, g, f, B, c, pg, p0, np, lane, nonneg); });
 }
 
 // ---------------------------------------------------------------------------------
@@ -594,7 +638,7 @@ constexpr int kFlyOG = 8;  // output channels per inner pass of the generic unit
 template <bool WZ>
 __global__ __launch_bounds__(1024) void bconv_fly_generic_kernel(BNN_FLY_PARAMS) {
   fly_run(x, fly_smem, [&](const Geo& g, const FlyGeo& f, const Band& B, const FlyCtx& c, int pg, int p0, int np,
-                           int lane) {
+                           int lane, bool) {
     const EpiArgs epi{alpha, bias, scale, nullptr, nullptr, nullptr, nullptr, out,
                       nullptr, nullptr, nullptr, nullptr, nullptr};
     const int jl = min((pg << 6) + lane, B.npix - 1);

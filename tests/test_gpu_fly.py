@@ -154,6 +154,32 @@ def test_direct_layer_matches_two_launch_form_at_real_sizes(shape):
     assert torch.equal(one, two)
 
 
+@pytest.mark.parametrize("shape", [(3, 128, 40, 24, 96, 3, 1, 1), (2, 64, 33, 20, 64, 3, 2, 1), (2, 256, 20, 20, 64, 3, 1, 1),
+                                   (3, 200, 19, 19, 48, 1, 1, 0), (2, 32, 30, 30, 16, 5, 1, 2)], ids=str)
+def test_units_with_and_without_negative_inputs_in_one_launch(shape):
+    """A unit whose receptive fields hold no negative value takes the P-plane-only loop (v_and + v_bcnt, agreements);
+    the others the two-plane loop.  Here the sign structure changes inside a launch — whole images, the upper half of
+    an image, single rows and single pixels are non-negative — and every band plan must still give the bits of the
+    two-launch form."""
+    N, C, H, W, O, k, s, p = shape
+    x = gen.activation("normal", gen.seed_of("mixed", shape), (N, C, H, W))
+    x[0] = np.maximum(x[0], 0)                       # image 0: a ReLU output
+    x[1, :, : H // 2] = np.abs(x[1, :, : H // 2])    # image 1: upper half non-negative
+    x[1, :, H // 2 + 3, :] = np.maximum(x[1, :, H // 2 + 3, :], 0)
+    if N > 2:
+        x[2] = np.maximum(x[2], 0)
+        x[2, C // 2, H - 1, W - 1] = -1.0            # image 2: ONE negative value, in the last pixel
+    w = gen.conv_weight("kaiming", gen.seed_of("mixedw", shape), (O, C, k, k))
+    pw = hipops.pack_weight(dev(w))
+    xd = dev(x)
+    two = hipops.bconv2d(hipops.pack_act(xd), pw, stride=s, padding=p)
+    ho = two.shape[2]
+    for pl in (None, _plan(1, ho, 16, 2), _plan(1, ho, 4, 1, prod=0), _plan(N, ho, 8, 4, prod=1),
+               _plan(1, max(1, ho // 3), 8, 2, head=0, tail=0), _plan(1, 1, 2, 1, prod=1), _plan(2, ho, 16, 1, head=9)):
+        assert torch.equal(hipops.bconv2d_direct(xd, pw, stride=s, padding=p, plan=pl), two), \
+            None if pl is None else (pl.images_per_band, pl.rows_per_band, pl.waves, pl.blocks_per_unit)
+
+
 def test_direct_layer_fuzz_against_two_launch_form():
     """Seeded shape fuzz: kernel sizes 1/3/5 (+ a 2x3), strides, paddings, dilations, ragged channel counts,
     zero weights, bias / post-scale — one launch == two launches, bit for bit."""
