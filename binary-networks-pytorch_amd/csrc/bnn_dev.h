@@ -115,6 +115,8 @@ int launch_stem(const float* x, const float* w, const float* bn_a, const float* 
                 int W, int flags, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_stem_split(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                       int W, int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
+int launch_stem_rows(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
+                      int W, int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_avgpool_fc(const float* x, const float* wt, const float* bias, float* out, int N, int C, int HW,
                       int O, hipStream_t stream);
 size_t grad_weight_pack_bytes(int O, int C, int ks);

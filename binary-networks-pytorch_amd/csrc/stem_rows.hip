@@ -1,0 +1,430 @@
+// stem_rows.hip — the fused stem (see stem.hip for the layer) with the max-pool done IN THE ACCUMULATORS.
+// Arithmetic as in stem_split.hip: fp32 operands split into fp16 hi + lo, product = lo*hi + hi*lo + hi*hi on
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation (the rounding class of an fp32 convolution).
+//
+// What is different (round 3; stem_split.hip spent more cycles outside its matrix phase than inside):
+//  * the GEMM is TRANSPOSED: A = weights (16 channels x K), B = patch (K x 16 conv pixels).  A lane's four
+//    accumulator registers are then four CHANNELS of ONE conv pixel, and the 16 lanes of a DPP row are 16
+//    neighbouring conv pixels of one conv row.  The 3x3 / stride-2 max-pool becomes
+//        vertical:   v_max3_f32 over the accumulators of three conv rows (registers of the same lane),
+//        horizontal: two v_max_f32 with row_shr:1 / row_shl:1 DPP operands,
+//    i.e. 4 VALU instructions per pooled value and register — the conv tile is never staged through LDS (the
+//    old kernel: 40 ds_write + 54 ds_read per lane and tile, two more barriers, 1.5 k + 3 k cycles of 13 k);
+//  * a wave walks DOWN its strip one pooled row at a time: two new conv rows (four independent accumulator
+//    chains) + the last row of the previous step, which it keeps — 24 accumulator registers instead of 40;
+//  * a pooled row leaves as soon as it exists (fp32 stores and sign bits sit between the MFMA batches of the
+//    same wave and under the MFMAs of the other wave of the SIMD);
+//  * patch rows hold the hi pairs and, 24 dwords further, the lo pairs; one conv row = two patch rows further
+//    is 384 B further: ONE address register per k-step reaches every fragment of a pooled-row step through the
+//    instruction's immediate offsets (the old kernel: 95 v_add_u32 per tile for LDS addresses);
+//  * the patch is double-buffered in LDS (2 x 22 KB per workgroup): one barrier per tile;
+//  * the patch is fetched with buffer loads (zero padding = an offset beyond the descriptor; a tile-invariant
+//    per-lane offset per load + one wave-uniform offset per tile: no address arithmetic in the loop for the tiles
+//    whose patch lies inside the image); it starts at an EVEN input column (kx slot e = kx + 1, e = 0 carries
+//    zero weights), so that a thread's column pair is one dword of the fp16 planes.
+// Tile: 8 x 7 pooled outputs (17 x 15 conv pixels) per 4-wave workgroup, two workgroups per CU; wave = (pooled-row
+// half, channel half).  56 = 7 * 8: no ragged tiles at 224 x 224.
+#include <type_traits>
+
+#include "bnn_dev.h"
+
+namespace bnn {
+
+namespace stemr {
+constexpr int CIN = 3, KS = 7, COUT = 64;
+constexpr int KSTEPS = 6;                            // 24 k-rows (c, ky) of 8 kx slots; rows 21..23 are zero
+constexpr int PTH = 8, PTW = 7;                      // pooled tile
+constexpr int NT = 256, NW = NT / 64;
+constexpr int QROWS = PTH / 2;                       // pooled rows per wave
+constexpr int CTH = 2 * PTH + 1;                     // 17 conv rows
+constexpr int ITH = 2 * CTH + 5;                     // 39 input rows per channel
+constexpr int NROW = CIN * ITH;                      // 117 patch rows
+constexpr int NPC = 18;                              // fetched column pairs per row (columns 0..35; 36, 37 stay zero)
+constexpr int ROWD = 48, LO_D = 24;                  // dwords per patch row; offset of the lo pairs
+constexpr int RSTEP = NT / NPC;                      // 14 rows per sweep
+constexpr int PER_T = (NROW + RSTEP - 1) / RSTEP;    // 9 column pairs per thread
+constexpr int PATCH_D = NROW * ROWD;                 // dwords per patch buffer
+constexpr int OFF_BITS = 2 * PATCH_D * 4;            // sign words of the tile: [2][56 pixels][2 halves] u32
+constexpr int LDS_BYTES = OFF_BITS + 2 * PTH * PTW * 8;
+constexpr int CONV_ROW_D = 2 * ROWD;                 // one conv row further = two input rows further
+static_assert(CONV_ROW_D * 2 + LO_D + 3 < 256, "three conv rows must stay inside ds_read2_b32's offsets");
+}  // namespace stemr
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+using RowsRsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ RowsRsrc rows_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? (int)bytes : 0, 0x00020000);
+}
+__device__ __forceinline__ float rows_ld(RowsRsrc r, unsigned voff, unsigned soff) {  // out of range reads as 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void rows_st(RowsRsrc r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void rows_st2(RowsRsrc r, unsigned voff, unsigned soff, u32x2 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, 0);
+}
+// One pooled value per lane from the three conv rows a, b, c of its column: v_max3 (vertical), ReLU (max and relu
+// commute; values are >= 0 from here on), then the maximum with the left and the right neighbour inside the 16-lane
+// row as two v_max_f32 with a DPP operand (a missing neighbour reads as 0).  Hand-written: from the builtins hipcc
+// emits v_mov_dpp + a canonicalising v_max + the v_max per neighbour and canonicalises a, b, c; the s_nop covers the
+// two wait states between a VALU write and a DPP read of the same register.
+__device__ __forceinline__ float pool3x3(float a, float b, float c) {
+  float t, v;
+  asm("v_max3_f32 %0, %2, %3, %4\n\t"
+      "v_max_f32_e32 %0, 0, %0\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %1, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %1, %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+      : "=&v"(t), "=&v"(v) : "v"(a), "v"(b), "v"(c));
+  return v;
+}
+// word = 2 * word + (v is a positive number): v_cmp_class + v_addc (the carry-in IS the bit)
+__device__ __forceinline__ void shift_in_pos(uint32_t& word, float v) {
+  asm("v_cmp_class_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(word) : "v"(v), "s"(kClassPos) : "vcc");
+}
+#else  // the host pass of hipcc only parses these
+struct RowsRsrc {};
+__device__ __forceinline__ RowsRsrc rows_rsrc(const void*, unsigned) { return {}; }
+__device__ __forceinline__ float rows_ld(RowsRsrc, unsigned, unsigned) { return 0.0f; }
+__device__ __forceinline__ void rows_st(RowsRsrc, unsigned, unsigned, float) {}
+__device__ __forceinline__ void rows_st2(RowsRsrc, unsigned, unsigned, u32x2) {}
+__device__ __forceinline__ float pool3x3(float a, float, float) { return a; }
+__device__ __forceinline__ void shift_in_pos(uint32_t&, float) {}
+#endif
+constexpr unsigned kRowsOOB = 0xFFFFFFF0u;  // beyond every descriptor's num_records
+
+// HALF: plain fp16 operands, one MFMA per product (BNN_HIP_STEM_FP16).
+template <bool HALF>
+__global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bn_a,
+    const float* __restrict__ bn_b, int N, int H, int W, int Hc, int Wc, int Hp, int Wp, int tiles_y,
+    int tiles_x, int per_xcd, unsigned x_bytes, float* __restrict__ out, uint64_t* __restrict__ P,
+    uint64_t* __restrict__ M, unsigned out_bytes, unsigned plane_bytes) {
+  using namespace stemr;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_rows[];
+  uint32_t* patch = reinterpret_cast<uint32_t*>(lds_rows);
+  uint32_t* bits = reinterpret_cast<uint32_t*>(lds_rows + OFF_BITS);  // double-buffered: tile t's words leave during t + 1
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: what depends on it is uniform
+  const int li = lane & 15, lg = lane >> 4;
+  const int mg = wave & 1, nh = wave >> 1;  // pooled rows 4*mg .. 4*mg + 3, channels 32*nh .. 32*nh + 31
+
+  // ---- once: zero both patch buffers (columns 36, 37 and the row padding are read by the idle pixel column and
+  // by the zero-weight kx slot: they must stay finite)
+  for (int i = tid; i < 2 * PATCH_D; i += NT) patch[i] = 0u;
+
+  // ---- once: A fragments (hi, lo) of this wave's 2 channel tiles x 6 k-steps.
+  // MFMA 16x16x32 A operand: lane holds A[i = li][k = 8*lg + e]  ->  channel 16*tt + li, k-row 4*ks + lg, kx = e - 1.
+  half8 wh[KSTEPS][2], wl[KSTEPS][2];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const int krow = 4 * ks + lg;
+    const int c = krow / KS, ky = krow - c * KS;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int o = 32 * nh + 16 * tt + li;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = (krow < CIN * KS && e >= 1) ? w[((size_t)(o * CIN + c) * KS + ky) * KS + e - 1] : 0.0f;
+        const _Float16 h = (_Float16)v;
+        wh[ks][tt][e] = h;
+        wl[ks][tt][e] = (_Float16)(v - (float)h);
+      }
+    }
+  }
+  // B operand: lane holds B[k = 8*lg + e][j = li] = patch[c][2*cy + ky][2*li + e] of conv pixel (cy, li).
+  // kb[ks]: byte offset of (k-row 4*ks + lg, conv row 8*mg, column pair li); zero-weight k-rows read k-row 20.
+  uint32_t kb[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    int krow = 4 * ks + lg;
+    if (krow >= CIN * KS) krow = CIN * KS - 1;
+    const int c = krow / KS, ky = krow - c * KS;
+    kb[ks] = (uint32_t)((c * ITH + ky + 16 * mg) * ROWD + li) * 4u;
+  }
+  // BN constants of the accumulator layout (register r of tile tt -> channel 32*nh + 16*tt + 4*lg + r)
+  float ba[2][4], bb[2][4];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ba[tt][r] = bn_a[32 * nh + 16 * tt + 4 * lg + r];
+      bb[tt][r] = bn_b[32 * nh + 16 * tt + 4 * lg + r];
+    }
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // waited for HERE: inside the loop the wait would also cover the next patch's loads
+      asm volatile("" : "+v"(ba[tt][r]));
+      asm volatile("" : "+v"(bb[tt][r]));
+    }
+  // fetch role: column pair `fpc` of patch rows frow0 + 14*u.  Buffer loads: zero padding = an offset beyond the
+  // descriptor, one tile-invariant per-lane offset per load + a wave-uniform offset per tile (no address arithmetic
+  // and no exec-mask regions in the tile loop)
+  const int fpc = tid % NPC, frow0 = tid / NPC;
+  const bool fetcher = tid < NPC * RSTEP;
+  unsigned rowoff[PER_T];  // bytes from (channel 0, first patch row, first patch column) of the tile's image
+#pragma unroll
+  for (int u = 0; u < PER_T; ++u) {
+    const int R = frow0 + RSTEP * u;
+    const int c = (R >= 2 * ITH) + (R >= ITH), r = R - c * ITH;
+    rowoff[u] = (fetcher && R < NROW) ? (unsigned)(((c * H + r) * W + 2 * fpc) * 4) : kRowsOOB;
+  }
+  const RowsRsrc r_x = rows_rsrc(x, x_bytes);
+  const RowsRsrc r_out = rows_rsrc(out, out_bytes), r_P = rows_rsrc(P, plane_bytes), r_M = rows_rsrc(M, plane_bytes);
+  // output role: odd pixel columns 1, 3, .. 13 hold pooled columns 0 .. 6 after the horizontal maximum
+  const int plx = li >> 1;
+  const bool pool_lane = (li & 1) && li < 2 * PTW;
+  const unsigned out_lane = (unsigned)((4 * lg * Hp) * Wp + plx) * 4u;      // channel 4*lg (+ r), pooled column plx
+  const unsigned flush_lane = (unsigned)((tid / PTW) * Wp + tid % PTW) * 8u;  // pixel (tid / PTW, tid % PTW) of a tile
+
+  const int ntiles = N * tiles_y * tiles_x;
+  const int nseq = per_xcd * 8;
+  // Tile order: workgroup b sits on XCD b % 8 (observed placement, used for speed only); each XCD walks ONE contiguous
+  // eighth of the tile list, x-neighbours (shared halo) meet in the same L2 within a short time.
+  auto tile_of = [&](int seq) { return (seq & 7) * per_xcd + (seq >> 3); };
+
+  float nx0[PER_T], nx1[PER_T];
+  auto fetch = [&](int tile) {
+    const bool valid = tile < ntiles;
+    const int tl = valid ? tile : 0;
+    const int n = tl / (tiles_y * tiles_x);
+    const int tr = tl - n * tiles_y * tiles_x;
+    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+    const int iy0 = 4 * ty * PTH - 5, ixe = 4 * tx * PTW - 6;  // first input row; first (even) input column
+    const unsigned img = (unsigned)(n * CIN * H * W) * 4u;
+    const int toff = (iy0 * W + ixe) * 4;
+    if (valid && iy0 >= 0 && iy0 + ITH <= H && ixe >= 0 && ixe + 2 * NPC <= W) {  // the patch lies inside the image
+#pragma unroll
+      for (int u = 0; u < PER_T; ++u) {
+        nx0[u] = rows_ld(r_x, rowoff[u], img + (unsigned)toff);
+        nx1[u] = rows_ld(r_x, rowoff[u] + 4u, img + (unsigned)toff);
+      }
+    } else {
+      const int ix = ixe + 2 * fpc;
+      const bool okc0 = valid && (unsigned)ix < (unsigned)W;
+      const bool okc1 = valid && (unsigned)(ix + 1) < (unsigned)W;
+#pragma unroll
+      for (int u = 0; u < PER_T; ++u) {
+        const int R = frow0 + RSTEP * u;
+        const int c = (R >= 2 * ITH) + (R >= ITH), r = R - c * ITH;
+        const bool okr = rowoff[u] != kRowsOOB && (unsigned)(iy0 + r) < (unsigned)H;
+        const unsigned off = rowoff[u] + (unsigned)toff;
+        nx0[u] = rows_ld(r_x, (okr && okc0) ? off : kRowsOOB, img);
+        nx1[u] = rows_ld(r_x, (okr && okc1) ? off + 4u : kRowsOOB, img);
+      }
+    }
+  };
+  auto commit = [&](int pb) {
+    uint32_t* dst = patch + pb * PATCH_D + fpc;
+#pragma unroll
+    for (int u = 0; u < PER_T; ++u) {
+      const int R = frow0 + RSTEP * u;
+      if (fetcher && R < NROW) {
+        half2v h, l;
+        h[0] = (_Float16)nx0[u];
+        h[1] = (_Float16)nx1[u];
+        l[0] = (_Float16)(nx0[u] - (float)h[0]);
+        l[1] = (_Float16)(nx1[u] - (float)h[1]);
+        dst[R * ROWD] = __builtin_bit_cast(uint32_t, h);
+        if constexpr (!HALF) dst[R * ROWD + LO_D] = __builtin_bit_cast(uint32_t, l);
+      }
+    }
+  };
+
+  // sign words of the PREVIOUS tile: its waves left two 32-bit halves per pixel in LDS; PTH*PTW threads send them as
+  // whole 64-bit words
+  int prev_n = -1, prev_py0 = 0, prev_px0 = 0, buf = 0, pb = 0;
+  auto flush_bits = [&](int b) {
+    if (prev_n >= 0 && tid < PTH * PTW) {  // wave 0 only
+      const int ply = tid / PTW, px = tid - ply * PTW;
+      const bool ok = prev_py0 + ply < Hp && prev_px0 + px < Wp;
+      const unsigned soff = (unsigned)((prev_n * Hp + prev_py0) * Wp + prev_px0) * 8u;
+      const u32x2 word = *reinterpret_cast<const u32x2*>(bits + (b * PTH * PTW + tid) * 2);
+      rows_st2(r_P, ok ? flush_lane : kRowsOOB, soff, word);
+      rows_st2(r_M, ok ? flush_lane : kRowsOOB, soff, u32x2{0u, 0u});  // nothing is negative after ReLU
+    }
+  };
+
+  int seq = blockIdx.x;
+  if (seq < nseq) fetch(tile_of(seq));
+  __syncthreads();  // the zero fill is complete
+  if (seq < nseq) commit(0);
+  for (; seq < nseq; seq += gridDim.x) {
+    const int tile = tile_of(seq);
+    const bool valid = tile < ntiles;  // workgroup-uniform
+    __syncthreads();                   // this tile's patch (buffer pb) is in LDS; nobody reads buffer pb ^ 1 any more
+    flush_bits(buf ^ 1);
+    const int seq_next = seq + gridDim.x;
+    if (seq_next < nseq) fetch(tile_of(seq_next));  // global loads fly during the first half of the tile
+    const int tl = valid ? tile : 0;
+    const int n = tl / (tiles_y * tiles_x);
+    const int tr = tl - n * tiles_y * tiles_x;
+    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+    const int py0 = ty * PTH, px0 = tx * PTW;        // pooled origin
+    const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;  // conv origin (pool pad 1)
+    // three quarters of the tiles lie entirely inside the conv output: no range tests there
+    const bool interior = cy0 >= 0 && cx0 >= 0 && cy0 + CTH <= Hc && cx0 + 2 * PTW + 1 <= Wc;  // workgroup-uniform
+    const bool col_in = (unsigned)(cx0 + li) < (unsigned)Wc;
+    const unsigned out_voff = (valid && pool_lane && px0 + plx < Wp) ? out_lane : kRowsOOB;
+    const unsigned out_tile = (unsigned)(((n * COUT + 32 * nh) * Hp + py0 + QROWS * mg) * Wp + px0) * 4u;  // wave-uniform
+    const unsigned chw4 = (unsigned)(Hp * Wp) * 4u;
+
+    uint32_t kq[KSTEPS];  // walks down the strip: + 2 conv rows per pooled row
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) kq[ks] = kb[ks] + (uint32_t)(pb * PATCH_D * 4);
+    float carry[2][4];
+
+    // one pooled row: NR new conv rows starting at wave-relative conv row `row0` (+ the carried one unless FIRST)
+    auto pooled_row = [&](auto nr_tag, int q, int row0) {
+      constexpr int NR = decltype(nr_tag)::value;
+      constexpr bool FIRST = NR == 3;
+      f32x4 acc[NR][2];
+#pragma unroll
+      for (int d = 0; d < NR; ++d)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) acc[d][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(lds_rows + kq[ks]);
+        half8 bh[NR], bl[NR];
+#pragma unroll
+        for (int d = 0; d < NR; ++d) {
+          u32x4 v;
+          v[0] = p[d * CONV_ROW_D + 0]; v[1] = p[d * CONV_ROW_D + 1]; v[2] = p[d * CONV_ROW_D + 2]; v[3] = p[d * CONV_ROW_D + 3];
+          bh[d] = __builtin_bit_cast(half8, v);
+          if constexpr (!HALF) {
+            u32x4 l;
+            l[0] = p[d * CONV_ROW_D + LO_D + 0]; l[1] = p[d * CONV_ROW_D + LO_D + 1];
+            l[2] = p[d * CONV_ROW_D + LO_D + 2]; l[3] = p[d * CONV_ROW_D + LO_D + 3];
+            bl[d] = __builtin_bit_cast(half8, l);
+          }
+        }
+        if constexpr (!HALF) {
+#pragma unroll
+          for (int d = 0; d < NR; ++d)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+              acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks][tt], bl[d], acc[d][tt], 0, 0, 0);
+#pragma unroll
+          for (int d = 0; d < NR; ++d)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+              acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks][tt], bh[d], acc[d][tt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int d = 0; d < NR; ++d)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+            acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks][tt], bh[d], acc[d][tt], 0, 0, 0);
+      }
+      // BN (the ReLU is applied after the max-pool: max and relu commute exactly, padding counts as 0)
+      float y[NR][2][4];
+#pragma unroll
+      for (int d = 0; d < NR; ++d)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[d][tt][r] = fmaf(acc[d][tt][r], ba[tt][r], bb[tt][r]);
+      if (!interior) {
+        // positions outside the conv output are MaxPool padding: 0 never beats a ReLU output
+#pragma unroll
+        for (int d = 0; d < NR; ++d) {
+          const bool in = col_in && (unsigned)(cy0 + 2 * QROWS * mg + row0 + d) < (unsigned)Hc;
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[d][tt][r] = in ? y[d][tt][r] : 0.0f;
+        }
+      }
+      // rows below the image: the stores are dropped (offset beyond the descriptor)
+      const unsigned voff = (py0 + QROWS * mg + q < Hp) ? out_voff : kRowsOOB;
+      // wave-uniform store offset of channel 16*tt + r, walked downwards (kept as ONE running SGPR: as 32 loop
+      // invariants they are spilled to lanes and read back in front of every store)
+      unsigned soff = out_tile + (unsigned)(q * Wp) * 4u + 19u * chw4;
+      uint32_t z = 0;
+#pragma unroll
+      for (int tt = 1; tt >= 0; --tt)
+#pragma unroll
+        for (int r = 3; r >= 0; --r) {
+          const float ya = FIRST ? y[0][tt][r] : carry[tt][r];
+          const float v = pool3x3(ya, y[NR - 2][tt][r], y[NR - 1][tt][r]);  // the pooled value on odd lanes
+          carry[tt][r] = y[NR - 1][tt][r];
+          rows_st(r_out, voff, soff, v);
+          shift_in_pos(z, v);  // bit 4*tt + r
+          soff -= (r == 0 ? 13u : 1u) * chw4;
+          asm volatile("" : "+s"(soff));
+        }
+      if (P != nullptr) {
+        // channel 16*tt + 4*lg + r is bit 16*tt + 4*lg + r of this wave's half of the pixel's word
+        uint32_t wd = ((z & 0xFu) | ((z & 0xF0u) << 12)) << (4 * lg);
+        wd |= (uint32_t)__shfl_xor((int)wd, 16);
+        wd |= (uint32_t)__shfl_xor((int)wd, 32);
+        if (lg == 0 && pool_lane) bits[((buf * PTH + QROWS * mg + q) * PTW + plx) * 2 + nh] = wd;
+      }
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        kq[ks] += (uint32_t)(NR * CONV_ROW_D * 4);
+        asm volatile("" : "+v"(kq[ks]));  // keep the walking base: folded into constants, the offsets leave the immediates' range
+      }
+    };
+
+    if (valid) {
+      pooled_row(std::integral_constant<int, 3>{}, 0, 0);
+      pooled_row(std::integral_constant<int, 2>{}, 1, 3);
+    }
+    if (seq_next < nseq) commit(pb ^ 1);  // next patch: registers -> LDS (fp16 hi/lo), into the other buffer
+    if (valid) {
+      pooled_row(std::integral_constant<int, 2>{}, 2, 5);
+      pooled_row(std::integral_constant<int, 2>{}, 3, 7);
+    }
+    prev_n = valid ? n : -1;
+    prev_py0 = py0;
+    prev_px0 = px0;
+    buf ^= 1;
+    pb ^= 1;
+  }
+  __syncthreads();
+  flush_bits(buf ^ 1);
+}
+
+template <bool HALF>
+static int launch_stem_rows_t(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
+                              int W, float* out, uint64_t* P, uint64_t* M, hipStream_t stream) {
+  using namespace stemr;
+  const int Hc = (H + 6 - KS) / 2 + 1, Wc = (W + 6 - KS) / 2 + 1;
+  const int Hp = (Hc + 2 - 3) / 2 + 1, Wp = (Wc + 2 - 3) / 2 + 1;
+  const int tiles_y = (Hp + PTH - 1) / PTH, tiles_x = (Wp + PTW - 1) / PTW;
+  const long long ntiles = (long long)N * tiles_y * tiles_x;
+  const int cus = current_device_cus();
+  const int per_xcd = (int)((ntiles + 7) / 8);
+  const long long want = (long long)cus * (8 / NW);  // 8 waves (two workgroups) per CU
+  const unsigned grid = (unsigned)(ntiles < want ? ((ntiles + 7) / 8 * 8) : want);
+  // per device and per kernel, so it is set on every launch (no mutable global state in a re-entrant API)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_rows_kernel<HALF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          LDS_BYTES) != hipSuccess)
+    return BNN_HIP_ERR_LAUNCH;
+  // byte sizes of the output streams (the C-ABI caps every tensor below 2^32 bytes)
+  const unsigned out_bytes = (unsigned)((long long)N * COUT * Hp * Wp * 4);
+  const unsigned plane_bytes = (unsigned)((long long)N * Hp * Wp * 8);
+  const unsigned x_bytes = (unsigned)((long long)N * CIN * H * W * 4);
+  hipLaunchKernelGGL(stem_rows_kernel<HALF>, dim3(grid), dim3(NT), LDS_BYTES, stream, x, w, bn_a, bn_b, N, H, W, Hc,
+                     Wc, Hp, Wp, tiles_y, tiles_x, per_xcd, x_bytes, out, P, M, out_bytes, plane_bytes);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+int launch_stem_rows(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H, int W,
+                     int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream) {
+  return half ? launch_stem_rows_t<true>(x, w, bn_a, bn_b, N, H, W, out, P, M, stream)
+              : launch_stem_rows_t<false>(x, w, bn_a, bn_b, N, H, W, out, P, M, stream);
+}
+
+}  // namespace bnn
