@@ -11,7 +11,9 @@
 //    i.e. 4 VALU instructions per pooled value and register — the conv tile is never staged through LDS (the
 //    old kernel: 40 ds_write + 54 ds_read per lane and tile, two more barriers, 1.5 k + 3 k cycles of 13 k);
 //  * a wave walks DOWN its strip one pooled row at a time: two new conv rows (four independent accumulator
-//    chains) + the last row of the previous step, which it keeps — 24 accumulator registers instead of 40;
+//    chains) + the last row of the previous step, which it keeps — 16 accumulator registers instead of 40;
+//  * the B fragments are requested one step (12 MFMAs) ahead of their use, across pooled rows: with two
+//    255-register waves per SIMD an exposed LDS round trip per k-step was most of the time;
 //  * a pooled row leaves as soon as it exists (fp32 stores and sign bits sit between the MFMA batches of the
 //    same wave and under the MFMAs of the other wave of the SIMD);
 //  * patch rows hold the hi pairs and, 24 dwords further, the lo pairs; one conv row = two patch rows further
@@ -27,6 +29,10 @@
 #include <type_traits>
 
 #include "bnn_dev.h"
+
+#ifndef BNN_ROWS_ABL  // timing ablations only (wrong results): 1 matrix, 2 epilogue, 4 fragment reads, 8 fetch + commit,
+#define BNN_ROWS_ABL 0  // 16 fp32 stores, 32 sign words
+#endif
 
 namespace bnn {
 
@@ -45,9 +51,15 @@ constexpr int RSTEP = NT / NPC;                      // 14 rows per sweep
 constexpr int PER_T = (NROW + RSTEP - 1) / RSTEP;    // 9 column pairs per thread
 constexpr int PATCH_D = NROW * ROWD;                 // dwords per patch buffer
 constexpr int OFF_BITS = 2 * PATCH_D * 4;            // sign words of the tile: [2][56 pixels][2 halves] u32
+#ifdef BNN_ROWS_TIMING  // per-phase shader-clock sums of every wave (debug builds): [wave][16 phases][64 lanes] u32 in LDS
+constexpr int OFF_TIME = OFF_BITS + 2 * PTH * PTW * 8;
+constexpr int LDS_BYTES = OFF_TIME + NW * 16 * 64 * 4;
+#else
 constexpr int LDS_BYTES = OFF_BITS + 2 * PTH * PTW * 8;
+#endif
 constexpr int CONV_ROW_D = 2 * ROWD;                 // one conv row further = two input rows further
-static_assert(CONV_ROW_D * 2 + LO_D + 3 < 256, "three conv rows must stay inside ds_read2_b32's offsets");
+static_assert(CONV_ROW_D + LO_D + 3 < 256, "two conv rows must stay inside ds_read2_b32's offsets");
+constexpr int NSTEP = KSTEPS * (QROWS + 1);          // (pass, k-step) steps per tile
 }  // namespace stemr
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -108,6 +120,7 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
     int tiles_x, int per_xcd, unsigned x_bytes, float* __restrict__ out, uint64_t* __restrict__ P,
     uint64_t* __restrict__ M, unsigned out_bytes, unsigned plane_bytes) {
   using namespace stemr;
+  constexpr int AHEAD = HALF ? 3 : 1, RING = AHEAD + 1;  // fragment sets requested ahead (a HALF step is 4 MFMAs long)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_rows[];
   uint32_t* patch = reinterpret_cast<uint32_t*>(lds_rows);
   uint32_t* bits = reinterpret_cast<uint32_t*>(lds_rows + OFF_BITS);  // double-buffered: tile t's words leave during t + 1
@@ -254,6 +267,14 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
     }
   };
 
+#ifdef BNN_ROWS_TIMING
+  uint32_t* tcount = reinterpret_cast<uint32_t*>(lds_rows + OFF_TIME) + wave * 16 * 64 + lane;
+  for (int k = 0; k < 16; ++k) tcount[k * 64] = 0u;
+  uint32_t tlast = (uint32_t)__builtin_readcyclecounter();
+#define ROWS_T(k) { const uint32_t tn = (uint32_t)__builtin_readcyclecounter(); tcount[(k) * 64] += tn - tlast; tlast = tn; }
+#else
+#define ROWS_T(k) {}
+#endif
   int seq = blockIdx.x;
   if (seq < nseq) fetch(tile_of(seq));
   __syncthreads();  // the zero fill is complete
@@ -261,10 +282,12 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
   for (; seq < nseq; seq += gridDim.x) {
     const int tile = tile_of(seq);
     const bool valid = tile < ntiles;  // workgroup-uniform
+    ROWS_T(13)
     __syncthreads();                   // this tile's patch (buffer pb) is in LDS; nobody reads buffer pb ^ 1 any more
+    ROWS_T(0)
     flush_bits(buf ^ 1);
     const int seq_next = seq + gridDim.x;
-    if (seq_next < nseq) fetch(tile_of(seq_next));  // global loads fly during the first half of the tile
+    if (seq_next < nseq && !(BNN_ROWS_ABL & 8)) fetch(tile_of(seq_next));  // global loads fly during the first half of the tile
     const int tl = valid ? tile : 0;
     const int n = tl / (tiles_y * tiles_x);
     const int tr = tl - n * tiles_y * tiles_x;
@@ -278,72 +301,70 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
     const unsigned out_tile = (unsigned)(((n * COUT + 32 * nh) * Hp + py0 + QROWS * mg) * Wp + px0) * 4u;  // wave-uniform
     const unsigned chw4 = (unsigned)(Hp * Wp) * 4u;
 
-    uint32_t kq[KSTEPS];  // walks down the strip: + 2 conv rows per pooled row
+    uint32_t kq[KSTEPS];  // walks down the strip: advanced by the rows a step has read
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) kq[ks] = kb[ks] + (uint32_t)(pb * PATCH_D * 4);
-    float carry[2][4];
 
-    // one pooled row: NR new conv rows starting at wave-relative conv row `row0` (+ the carried one unless FIRST)
-    auto pooled_row = [&](auto nr_tag, int q, int row0) {
-      constexpr int NR = decltype(nr_tag)::value;
-      constexpr bool FIRST = NR == 3;
-      f32x4 acc[NR][2];
+    // The tile is a stream of 30 steps (pass, k-step): pass 0 = the wave's first conv row alone, passes 1..4 = two
+    // conv rows each = one pooled row together with the row kept from the pass before.  The B fragments of step
+    // s + AHEAD are requested BEFORE the MFMAs of step s are issued (ring of AHEAD + 1 fragment sets): with two waves
+    // per SIMD nobody else covers the LDS latency (one exposed round trip per step was most of the kernel's time).
+    half8 fh[RING][2], fl[RING][2];
+    auto request = [&](int s) {  // s is a constant after unrolling
+      const int ks = s % KSTEPS, rows = s < KSTEPS ? 1 : 2;
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(lds_rows + kq[ks]);
 #pragma unroll
-      for (int d = 0; d < NR; ++d)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) acc[d][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(lds_rows + kq[ks]);
-        half8 bh[NR], bl[NR];
-#pragma unroll
-        for (int d = 0; d < NR; ++d) {
-          u32x4 v;
-          v[0] = p[d * CONV_ROW_D + 0]; v[1] = p[d * CONV_ROW_D + 1]; v[2] = p[d * CONV_ROW_D + 2]; v[3] = p[d * CONV_ROW_D + 3];
-          bh[d] = __builtin_bit_cast(half8, v);
-          if constexpr (!HALF) {
-            u32x4 l;
-            l[0] = p[d * CONV_ROW_D + LO_D + 0]; l[1] = p[d * CONV_ROW_D + LO_D + 1];
-            l[2] = p[d * CONV_ROW_D + LO_D + 2]; l[3] = p[d * CONV_ROW_D + LO_D + 3];
-            bl[d] = __builtin_bit_cast(half8, l);
-          }
+      for (int d = 0; d < 2; ++d) {
+        if (d >= rows) continue;
+        if (BNN_ROWS_ABL & 4) {
+          fh[s % RING][d] = wh[ks][d];
+          fl[s % RING][d] = wl[ks][d];
+          continue;
         }
+        u32x4 v;
+        v[0] = p[d * CONV_ROW_D + 0]; v[1] = p[d * CONV_ROW_D + 1]; v[2] = p[d * CONV_ROW_D + 2]; v[3] = p[d * CONV_ROW_D + 3];
+        fh[s % RING][d] = __builtin_bit_cast(half8, v);
         if constexpr (!HALF) {
-#pragma unroll
-          for (int d = 0; d < NR; ++d)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-              acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks][tt], bl[d], acc[d][tt], 0, 0, 0);
-#pragma unroll
-          for (int d = 0; d < NR; ++d)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-              acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks][tt], bh[d], acc[d][tt], 0, 0, 0);
+          u32x4 l;
+          l[0] = p[d * CONV_ROW_D + LO_D + 0]; l[1] = p[d * CONV_ROW_D + LO_D + 1];
+          l[2] = p[d * CONV_ROW_D + LO_D + 2]; l[3] = p[d * CONV_ROW_D + LO_D + 3];
+          fl[s % RING][d] = __builtin_bit_cast(half8, l);
         }
-#pragma unroll
-        for (int d = 0; d < NR; ++d)
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt)
-            acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks][tt], bh[d], acc[d][tt], 0, 0, 0);
       }
+      kq[ks] += (uint32_t)(rows * CONV_ROW_D * 4);
+      asm volatile("" : "+v"(kq[ks]));  // keep the walking base: folded into constants, the offsets leave the immediates' range
+    };
+    float carry[2][4];
+    f32x4 acc[2][2];
+    // BN, padding mask, pooling, stores and sign bits of pass `pass` (0: only the carried row)
+    auto finish = [&](int pass) {
+      const int rows = pass == 0 ? 1 : 2, row0 = pass == 0 ? 0 : 2 * pass - 1, q = pass - 1;
       // BN (the ReLU is applied after the max-pool: max and relu commute exactly, padding counts as 0)
-      float y[NR][2][4];
+      float y[2][2][4];
 #pragma unroll
-      for (int d = 0; d < NR; ++d)
+      for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) y[d][tt][r] = fmaf(acc[d][tt][r], ba[tt][r], bb[tt][r]);
+          for (int r = 0; r < 4; ++r) y[d][tt][r] = d < rows ? fmaf(acc[d][tt][r], ba[tt][r], bb[tt][r]) : 0.0f;
       if (!interior) {
         // positions outside the conv output are MaxPool padding: 0 never beats a ReLU output
 #pragma unroll
-        for (int d = 0; d < NR; ++d) {
+        for (int d = 0; d < 2; ++d) {
+          if (d >= rows) continue;
           const bool in = col_in && (unsigned)(cy0 + 2 * QROWS * mg + row0 + d) < (unsigned)Hc;
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[d][tt][r] = in ? y[d][tt][r] : 0.0f;
         }
+      }
+      if (pass == 0) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) carry[tt][r] = y[0][tt][r];
+        return;
       }
       // rows below the image: the stores are dropped (offset beyond the descriptor)
       const unsigned voff = (py0 + QROWS * mg + q < Hp) ? out_voff : kRowsOOB;
@@ -355,36 +376,65 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
       for (int tt = 1; tt >= 0; --tt)
 #pragma unroll
         for (int r = 3; r >= 0; --r) {
-          const float ya = FIRST ? y[0][tt][r] : carry[tt][r];
-          const float v = pool3x3(ya, y[NR - 2][tt][r], y[NR - 1][tt][r]);  // the pooled value on odd lanes
-          carry[tt][r] = y[NR - 1][tt][r];
-          rows_st(r_out, voff, soff, v);
+          const float v = pool3x3(carry[tt][r], y[0][tt][r], y[1][tt][r]);  // the pooled value on odd lanes
+          carry[tt][r] = y[1][tt][r];
+          if (!(BNN_ROWS_ABL & 16)) rows_st(r_out, voff, soff, v);
           shift_in_pos(z, v);  // bit 4*tt + r
           soff -= (r == 0 ? 13u : 1u) * chw4;
           asm volatile("" : "+s"(soff));
         }
-      if (P != nullptr) {
+      if (P != nullptr && !(BNN_ROWS_ABL & 32)) {
         // channel 16*tt + 4*lg + r is bit 16*tt + 4*lg + r of this wave's half of the pixel's word
         uint32_t wd = ((z & 0xFu) | ((z & 0xF0u) << 12)) << (4 * lg);
         wd |= (uint32_t)__shfl_xor((int)wd, 16);
         wd |= (uint32_t)__shfl_xor((int)wd, 32);
         if (lg == 0 && pool_lane) bits[((buf * PTH + QROWS * mg + q) * PTW + plx) * 2 + nh] = wd;
       }
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        kq[ks] += (uint32_t)(NR * CONV_ROW_D * 4);
-        asm volatile("" : "+v"(kq[ks]));  // keep the walking base: folded into constants, the offsets leave the immediates' range
-      }
     };
 
+    ROWS_T(1)
     if (valid) {
-      pooled_row(std::integral_constant<int, 3>{}, 0, 0);
-      pooled_row(std::integral_constant<int, 2>{}, 1, 3);
-    }
-    if (seq_next < nseq) commit(pb ^ 1);  // next patch: registers -> LDS (fp16 hi/lo), into the other buffer
-    if (valid) {
-      pooled_row(std::integral_constant<int, 2>{}, 2, 5);
-      pooled_row(std::integral_constant<int, 2>{}, 3, 7);
+#pragma unroll
+      for (int s = 0; s < AHEAD; ++s) request(s);
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        if (s + AHEAD < NSTEP) request(s + AHEAD);
+        __builtin_amdgcn_sched_barrier(0);  // requests first: sunk next to their use they are exposed again
+        const int ks = s % KSTEPS, rows = s < KSTEPS ? 1 : 2;
+        if (ks == 0) {
+#pragma unroll
+          for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) acc[d][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // product-type major: the accumulator chains of a step are independent between two MFMAs on the same one
+        if constexpr (!HALF && !(BNN_ROWS_ABL & 1)) {
+#pragma unroll
+          for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+              if (d < rows) acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks][tt], fl[s % RING][d], acc[d][tt], 0, 0, 0);
+#pragma unroll
+          for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+              if (d < rows) acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks][tt], fh[s % RING][d], acc[d][tt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+            if (d < rows && !(BNN_ROWS_ABL & 1))
+              acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks][tt], fh[s % RING][d], acc[d][tt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == KSTEPS - 1) ROWS_T(2 + s / KSTEPS)
+        if (ks == KSTEPS - 1 && !(BNN_ROWS_ABL & 2)) finish(s / KSTEPS);
+        if (ks == KSTEPS - 1) ROWS_T(7 + s / KSTEPS)
+        if (s == 3 * KSTEPS - 1 && seq_next < nseq && !(BNN_ROWS_ABL & 8)) commit(pb ^ 1);
+        if (s == 3 * KSTEPS - 1) ROWS_T(12)  // next patch: registers -> the other LDS buffer
+      }
+    } else if (seq_next < nseq) {
+      commit(pb ^ 1);
     }
     prev_n = valid ? n : -1;
     prev_py0 = py0;
@@ -394,6 +444,11 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
   }
   __syncthreads();
   flush_bits(buf ^ 1);
+#ifdef BNN_ROWS_TIMING
+  __syncthreads();
+  if (lane == 0 && M)
+    for (int k = 0; k < 16; ++k) M[((size_t)blockIdx.x * NW + wave) * 16 + k] = tcount[k * 64];
+#endif
 }
 
 template <bool HALF>
