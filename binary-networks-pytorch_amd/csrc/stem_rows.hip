@@ -1,6 +1,7 @@
 // stem_rows.hip — the fused stem (see stem.hip for the layer) with the max-pool done IN THE ACCUMULATORS.
 // Arithmetic as in stem_split.hip: fp32 operands split into fp16 hi + lo, product = lo*hi + hi*lo + hi*hi on
-// v_mfma_f32_16x16x32_f16 with fp32 accumulation (the rounding class of an fp32 convolution).
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation (the rounding class of an fp32 convolution); results are
+// bit-identical to that kernel's.
 //
 // What is different (round 3; stem_split.hip spent more cycles outside its matrix phase than inside):
 //  * the GEMM is TRANSPOSED: A = weights (16 channels x K), B = patch (K x 16 conv pixels).  A lane's four
@@ -10,22 +11,25 @@
 //        horizontal: two v_max_f32 with row_shr:1 / row_shl:1 DPP operands,
 //    i.e. 4 VALU instructions per pooled value and register — the conv tile is never staged through LDS (the
 //    old kernel: 40 ds_write + 54 ds_read per lane and tile, two more barriers, 1.5 k + 3 k cycles of 13 k);
-//  * a wave walks DOWN its strip one pooled row at a time: two new conv rows (four independent accumulator
-//    chains) + the last row of the previous step, which it keeps — 16 accumulator registers instead of 40;
-//  * the B fragments are requested one step (12 MFMAs) ahead of their use, across pooled rows: with two
-//    255-register waves per SIMD an exposed LDS round trip per k-step was most of the time;
+//  * a wave owns a strip of 7 pooled columns (15 conv columns = one 16-pixel MFMA tile) x 32 channels and walks
+//    DOWN the image: per pooled row two new conv rows (four independent accumulator chains) + the last conv row of
+//    the step before, which it keeps in registers — also across tiles, so that no conv row is computed twice
+//    (the 9th row of a 4-row tile with its own halo was 11 % of the MFMAs); 16 accumulator registers instead of 40;
 //  * a pooled row leaves as soon as it exists (fp32 stores and sign bits sit between the MFMA batches of the
 //    same wave and under the MFMAs of the other wave of the SIMD);
-//  * patch rows hold the hi pairs and, 24 dwords further, the lo pairs; one conv row = two patch rows further
-//    is 384 B further: ONE address register per k-step reaches every fragment of a pooled-row step through the
+//  * the B fragments are requested one step (12 MFMAs) ahead of their use, across pooled rows;
+//  * patch rows hold the hi pairs and, 40 dwords further, the lo pairs; one conv row = two patch rows further
+//    is 640 B further: ONE address register per k-step reaches every fragment of a pooled-row step through the
 //    instruction's immediate offsets (the old kernel: 95 v_add_u32 per tile for LDS addresses);
 //  * the patch is double-buffered in LDS (2 x 22 KB per workgroup): one barrier per tile;
 //  * the patch is fetched with buffer loads (zero padding = an offset beyond the descriptor; a tile-invariant
 //    per-lane offset per load + one wave-uniform offset per tile: no address arithmetic in the loop for the tiles
 //    whose patch lies inside the image); it starts at an EVEN input column (kx slot e = kx + 1, e = 0 carries
-//    zero weights), so that a thread's column pair is one dword of the fp16 planes.
-// Tile: 8 x 7 pooled outputs (17 x 15 conv pixels) per 4-wave workgroup, two workgroups per CU; wave = (pooled-row
-// half, channel half).  56 = 7 * 8: no ragged tiles at 224 x 224.
+//    zero weights), so that a thread's column pair is one dword of the fp16 planes;
+//  * tiles are walked strip-major (image, column strip, row): the next tile is one increment away (the old
+//    kernel: two integer divisions per tile on the scalar unit); the strips of an image are walked side by side by
+//    neighbouring workgroups of one XCD, so that their 56-byte pieces of shared output lines meet in that L2.
+// Tile: 4 x 14 pooled outputs per 4-wave workgroup, two workgroups per CU; wave = (column half, channel half).
 #include <type_traits>
 
 #include "bnn_dev.h"
@@ -39,15 +43,14 @@ namespace bnn {
 namespace stemr {
 constexpr int CIN = 3, KS = 7, COUT = 64;
 constexpr int KSTEPS = 6;                            // 24 k-rows (c, ky) of 8 kx slots; rows 21..23 are zero
-constexpr int PTH = 8, PTW = 7;                      // pooled tile
+constexpr int PTH = 4, PTW = 14, WPW = PTW / 2;      // pooled tile; pooled columns per wave
 constexpr int NT = 256, NW = NT / 64;
-constexpr int QROWS = PTH / 2;                       // pooled rows per wave
-constexpr int CTH = 2 * PTH + 1;                     // 17 conv rows
-constexpr int ITH = 2 * CTH + 5;                     // 39 input rows per channel
-constexpr int NROW = CIN * ITH;                      // 117 patch rows
-constexpr int NPC = 18;                              // fetched column pairs per row (columns 0..35; 36, 37 stay zero)
-constexpr int ROWD = 48, LO_D = 24;                  // dwords per patch row; offset of the lo pairs
-constexpr int RSTEP = NT / NPC;                      // 14 rows per sweep
+constexpr int CTH = 2 * PTH + 1;                     // 9 conv rows: row 0 is the one kept from the tile above
+constexpr int ITH = 2 * CTH + 5;                     // 23 input rows per channel
+constexpr int NROW = CIN * ITH;                      // 69 patch rows
+constexpr int NPC = 32;                              // fetched column pairs per row (columns 0..63; 64, 65 stay zero)
+constexpr int ROWD = 80, LO_D = 40;                  // dwords per patch row (16 mod 64 banks); offset of the lo pairs
+constexpr int RSTEP = NT / NPC;                      // 8 rows per sweep
 constexpr int PER_T = (NROW + RSTEP - 1) / RSTEP;    // 9 column pairs per thread
 constexpr int PATCH_D = NROW * ROWD;                 // dwords per patch buffer
 constexpr int OFF_BITS = 2 * PATCH_D * 4;            // sign words of the tile: [2][56 pixels][2 halves] u32
@@ -59,7 +62,7 @@ constexpr int LDS_BYTES = OFF_BITS + 2 * PTH * PTW * 8;
 #endif
 constexpr int CONV_ROW_D = 2 * ROWD;                 // one conv row further = two input rows further
 static_assert(CONV_ROW_D + LO_D + 3 < 256, "two conv rows must stay inside ds_read2_b32's offsets");
-constexpr int NSTEP = KSTEPS * (QROWS + 1);          // (pass, k-step) steps per tile
+constexpr int NSTEP = KSTEPS * PTH;                  // (pooled row, k-step) steps per tile
 }  // namespace stemr
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -101,6 +104,13 @@ __device__ __forceinline__ float pool3x3(float a, float b, float c) {
 __device__ __forceinline__ void shift_in_pos(uint32_t& word, float v) {
   asm("v_cmp_class_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(word) : "v"(v), "s"(kClassPos) : "vcc");
 }
+// OR of the four 16-lane rows of a wave, in every lane: two lane-swap instructions (no LDS round trip)
+__device__ __forceinline__ uint32_t or_rows(uint32_t w) {
+  const auto a = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  w = a[0] | a[1];
+  const auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+  return b[0] | b[1];
+}
 #else  // the host pass of hipcc only parses these
 struct RowsRsrc {};
 __device__ __forceinline__ RowsRsrc rows_rsrc(const void*, unsigned) { return {}; }
@@ -109,6 +119,7 @@ __device__ __forceinline__ void rows_st(RowsRsrc, unsigned, unsigned, float) {}
 __device__ __forceinline__ void rows_st2(RowsRsrc, unsigned, unsigned, u32x2) {}
 __device__ __forceinline__ float pool3x3(float a, float, float) { return a; }
 __device__ __forceinline__ void shift_in_pos(uint32_t&, float) {}
+__device__ __forceinline__ uint32_t or_rows(uint32_t w) { return w; }
 #endif
 constexpr unsigned kRowsOOB = 0xFFFFFFF0u;  // beyond every descriptor's num_records
 
@@ -117,7 +128,7 @@ template <bool HALF>
 __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bn_a,
     const float* __restrict__ bn_b, int N, int H, int W, int Hc, int Wc, int Hp, int Wp, int tiles_y,
-    int tiles_x, int per_xcd, unsigned x_bytes, float* __restrict__ out, uint64_t* __restrict__ P,
+    int tiles_x, int seg_len, int nseg, unsigned x_bytes, float* __restrict__ out, uint64_t* __restrict__ P,
     uint64_t* __restrict__ M, unsigned out_bytes, unsigned plane_bytes) {
   using namespace stemr;
   constexpr int AHEAD = HALF ? 3 : 1, RING = AHEAD + 1;  // fragment sets requested ahead (a HALF step is 4 MFMAs long)
@@ -128,9 +139,9 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: what depends on it is uniform
   const int li = lane & 15, lg = lane >> 4;
-  const int mg = wave & 1, nh = wave >> 1;  // pooled rows 4*mg .. 4*mg + 3, channels 32*nh .. 32*nh + 31
+  const int mg = wave & 1, nh = wave >> 1;  // pooled columns 7*mg .. 7*mg + 6, channels 32*nh .. 32*nh + 31
 
-  // ---- once: zero both patch buffers (columns 36, 37 and the row padding are read by the idle pixel column and
+  // ---- once: zero both patch buffers (columns 64, 65 and the row padding are read by the idle pixel column and
   // by the zero-weight kx slot: they must stay finite)
   for (int i = tid; i < 2 * PATCH_D; i += NT) patch[i] = 0u;
 
@@ -153,15 +164,15 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
       }
     }
   }
-  // B operand: lane holds B[k = 8*lg + e][j = li] = patch[c][2*cy + ky][2*li + e] of conv pixel (cy, li).
-  // kb[ks]: byte offset of (k-row 4*ks + lg, conv row 8*mg, column pair li); zero-weight k-rows read k-row 20.
+  // B operand: lane holds B[k = 8*lg + e][j = li] = patch[c][2*t + ky][2*(14*mg + li) + e] of conv pixel (t, 14*mg + li).
+  // kb[ks]: byte offset of (k-row 4*ks + lg, conv row 0, column pair 14*mg + li); zero-weight k-rows read k-row 20.
   uint32_t kb[KSTEPS];
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
     int krow = 4 * ks + lg;
     if (krow >= CIN * KS) krow = CIN * KS - 1;
     const int c = krow / KS, ky = krow - c * KS;
-    kb[ks] = (uint32_t)((c * ITH + ky + 16 * mg) * ROWD + li) * 4u;
+    kb[ks] = (uint32_t)((c * ITH + ky) * ROWD + 2 * WPW * mg + li) * 4u;
   }
   // BN constants of the accumulator layout (register r of tile tt -> channel 32*nh + 16*tt + 4*lg + r)
   float ba[2][4], bb[2][4];
@@ -179,43 +190,40 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
       asm volatile("" : "+v"(ba[tt][r]));
       asm volatile("" : "+v"(bb[tt][r]));
     }
-  // fetch role: column pair `fpc` of patch rows frow0 + 14*u.  Buffer loads: zero padding = an offset beyond the
+  // fetch role: column pair `fpc` of patch rows frow0 + 8*u.  Buffer loads: zero padding = an offset beyond the
   // descriptor, one tile-invariant per-lane offset per load + a wave-uniform offset per tile (no address arithmetic
   // and no exec-mask regions in the tile loop)
   const int fpc = tid % NPC, frow0 = tid / NPC;
-  const bool fetcher = tid < NPC * RSTEP;
   unsigned rowoff[PER_T];  // bytes from (channel 0, first patch row, first patch column) of the tile's image
 #pragma unroll
   for (int u = 0; u < PER_T; ++u) {
     const int R = frow0 + RSTEP * u;
     const int c = (R >= 2 * ITH) + (R >= ITH), r = R - c * ITH;
-    rowoff[u] = (fetcher && R < NROW) ? (unsigned)(((c * H + r) * W + 2 * fpc) * 4) : kRowsOOB;
+    rowoff[u] = R < NROW ? (unsigned)(((c * H + r) * W + 2 * fpc) * 4) : kRowsOOB;
   }
   const RowsRsrc r_x = rows_rsrc(x, x_bytes);
   const RowsRsrc r_out = rows_rsrc(out, out_bytes), r_P = rows_rsrc(P, plane_bytes), r_M = rows_rsrc(M, plane_bytes);
   // output role: odd pixel columns 1, 3, .. 13 hold pooled columns 0 .. 6 after the horizontal maximum
   const int plx = li >> 1;
-  const bool pool_lane = (li & 1) && li < 2 * PTW;
+  const bool pool_lane = (li & 1) && li < 2 * WPW;
   const unsigned out_lane = (unsigned)((4 * lg * Hp) * Wp + plx) * 4u;      // channel 4*lg (+ r), pooled column plx
   const unsigned flush_lane = (unsigned)((tid / PTW) * Wp + tid % PTW) * 8u;  // pixel (tid / PTW, tid % PTW) of a tile
 
+  // Tile list: strip-major (image, column strip, row).  A workgroup works through `nseg` segments of `seg_len`
+  // consecutive tiles; segment j of logical workgroup wg starts at tile (wg + j * grid) * seg_len.  With at least
+  // one strip per workgroup a segment is a whole strip: the four strips of an image are then walked by four
+  // workgroups side by side and in step, so that the 56-byte pieces they write into shared cache lines meet in the
+  // L2 (workgroup b sits on XCD b % 8 — observed placement, used for speed only — and logical neighbours share it).
   const int ntiles = N * tiles_y * tiles_x;
-  const int nseq = per_xcd * 8;
-  // Tile order: workgroup b sits on XCD b % 8 (observed placement, used for speed only); each XCD walks ONE contiguous
-  // eighth of the tile list, x-neighbours (shared halo) meet in the same L2 within a short time.
-  auto tile_of = [&](int seq) { return (seq & 7) * per_xcd + (seq >> 3); };
-
+  const int wg = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+  const int seg_stride = (int)gridDim.x * seg_len;
+  const int niter = nseg * seg_len;
   float nx0[PER_T], nx1[PER_T];
-  auto fetch = [&](int tile) {
-    const bool valid = tile < ntiles;
-    const int tl = valid ? tile : 0;
-    const int n = tl / (tiles_y * tiles_x);
-    const int tr = tl - n * tiles_y * tiles_x;
-    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+  auto fetch = [&](int n, int tx, int ty) {
     const int iy0 = 4 * ty * PTH - 5, ixe = 4 * tx * PTW - 6;  // first input row; first (even) input column
     const unsigned img = (unsigned)(n * CIN * H * W) * 4u;
     const int toff = (iy0 * W + ixe) * 4;
-    if (valid && iy0 >= 0 && iy0 + ITH <= H && ixe >= 0 && ixe + 2 * NPC <= W) {  // the patch lies inside the image
+    if (iy0 >= 0 && iy0 + ITH <= H && ixe >= 0 && ixe + 2 * NPC <= W) {  // the patch lies inside the image
 #pragma unroll
       for (int u = 0; u < PER_T; ++u) {
         nx0[u] = rows_ld(r_x, rowoff[u], img + (unsigned)toff);
@@ -223,13 +231,13 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
       }
     } else {
       const int ix = ixe + 2 * fpc;
-      const bool okc0 = valid && (unsigned)ix < (unsigned)W;
-      const bool okc1 = valid && (unsigned)(ix + 1) < (unsigned)W;
+      const bool okc0 = (unsigned)ix < (unsigned)W;
+      const bool okc1 = (unsigned)(ix + 1) < (unsigned)W;
 #pragma unroll
       for (int u = 0; u < PER_T; ++u) {
         const int R = frow0 + RSTEP * u;
         const int c = (R >= 2 * ITH) + (R >= ITH), r = R - c * ITH;
-        const bool okr = rowoff[u] != kRowsOOB && (unsigned)(iy0 + r) < (unsigned)H;
+        const bool okr = R < NROW && (unsigned)(iy0 + r) < (unsigned)H;
         const unsigned off = rowoff[u] + (unsigned)toff;
         nx0[u] = rows_ld(r_x, (okr && okc0) ? off : kRowsOOB, img);
         nx1[u] = rows_ld(r_x, (okr && okc1) ? off + 4u : kRowsOOB, img);
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
 #pragma unroll
     for (int u = 0; u < PER_T; ++u) {
       const int R = frow0 + RSTEP * u;
-      if (fetcher && R < NROW) {
+      if (R < NROW) {
         half2v h, l;
         h[0] = (_Float16)nx0[u];
         h[1] = (_Float16)nx1[u];
@@ -275,99 +283,132 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
 #else
 #define ROWS_T(k) {}
 #endif
-  int seq = blockIdx.x;
-  if (seq < nseq) fetch(tile_of(seq));
+  // position of a tile of the list (divisions: once per segment; inside a segment the walk is ty + 1, tx + 1, n + 1)
+  auto locate = [&](int g, int& n, int& tx, int& ty) {
+    n = g / (tiles_x * tiles_y);
+    const int rem = g - n * tiles_x * tiles_y;
+    tx = rem / tiles_y;
+    ty = rem - tx * tiles_y;
+  };
+  int g = wg * seg_len, n = 0, tx = 0, ty = 0;
+  bool valid = g < ntiles;  // workgroup-uniform
+  if (valid) {
+    locate(g, n, tx, ty);
+    if (!(BNN_ROWS_ABL & 8)) fetch(n, tx, ty);
+  }
   __syncthreads();  // the zero fill is complete
-  if (seq < nseq) commit(0);
-  for (; seq < nseq; seq += gridDim.x) {
-    const int tile = tile_of(seq);
-    const bool valid = tile < ntiles;  // workgroup-uniform
+  if (valid) commit(0);
+  float carry[2][4];  // BN'd conv row above the next pooled row (row 2*py - 1), kept across tiles of a strip
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) carry[tt][r] = 0.0f;
+  for (int it = 0; it < niter && valid; ++it) {
     ROWS_T(13)
     __syncthreads();                   // this tile's patch (buffer pb) is in LDS; nobody reads buffer pb ^ 1 any more
     ROWS_T(0)
     flush_bits(buf ^ 1);
-    const int seq_next = seq + gridDim.x;
-    if (seq_next < nseq && !(BNN_ROWS_ABL & 8)) fetch(tile_of(seq_next));  // global loads fly during the first half of the tile
-    const int tl = valid ? tile : 0;
-    const int n = tl / (tiles_y * tiles_x);
-    const int tr = tl - n * tiles_y * tiles_x;
-    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+    // the next tile: one step down the list, or the first tile of the next segment
+    const bool seg_first = it % seg_len == 0, seg_last = (it + 1) % seg_len == 0;
+    int ng = g + 1, nn = n, ntx = tx, nty = ty + 1;
+    if (seg_last) {
+      ng = g + 1 + seg_stride - seg_len;
+      if (ng < ntiles) locate(ng, nn, ntx, nty);
+    } else if (nty == tiles_y) {
+      nty = 0;
+      if (++ntx == tiles_x) { ntx = 0; ++nn; }
+    }
+    const bool more = it + 1 < niter && ng < ntiles;
+    if (more && !(BNN_ROWS_ABL & 8)) fetch(nn, ntx, nty);  // global loads fly during the first half of the tile
     const int py0 = ty * PTH, px0 = tx * PTW;        // pooled origin
-    const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;  // conv origin (pool pad 1)
-    // three quarters of the tiles lie entirely inside the conv output: no range tests there
+    const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;  // conv origin (pool pad 1): conv row t of the tile is row cy0 + t
+    // most tiles lie entirely inside the conv output: no range tests there
     const bool interior = cy0 >= 0 && cx0 >= 0 && cy0 + CTH <= Hc && cx0 + 2 * PTW + 1 <= Wc;  // workgroup-uniform
-    const bool col_in = (unsigned)(cx0 + li) < (unsigned)Wc;
-    const unsigned out_voff = (valid && pool_lane && px0 + plx < Wp) ? out_lane : kRowsOOB;
-    const unsigned out_tile = (unsigned)(((n * COUT + 32 * nh) * Hp + py0 + QROWS * mg) * Wp + px0) * 4u;  // wave-uniform
+    const bool col_in = (unsigned)(cx0 + 2 * WPW * mg + li) < (unsigned)Wc;
+    const unsigned out_voff = (pool_lane && px0 + WPW * mg + plx < Wp) ? out_lane : kRowsOOB;
+    const unsigned out_tile = (unsigned)(((n * COUT + 32 * nh) * Hp + py0) * Wp + px0 + WPW * mg) * 4u;  // wave-uniform
     const unsigned chw4 = (unsigned)(Hp * Wp) * 4u;
 
     uint32_t kq[KSTEPS];  // walks down the strip: advanced by the rows a step has read
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) kq[ks] = kb[ks] + (uint32_t)(pb * PATCH_D * 4);
 
-    // The tile is a stream of 30 steps (pass, k-step): pass 0 = the wave's first conv row alone, passes 1..4 = two
-    // conv rows each = one pooled row together with the row kept from the pass before.  The B fragments of step
-    // s + AHEAD are requested BEFORE the MFMAs of step s are issued (ring of AHEAD + 1 fragment sets): with two waves
-    // per SIMD nobody else covers the LDS latency (one exposed round trip per step was most of the kernel's time).
     half8 fh[RING][2], fl[RING][2];
-    auto request = [&](int s) {  // s is a constant after unrolling
-      const int ks = s % KSTEPS, rows = s < KSTEPS ? 1 : 2;
+    // fragments of `rows` conv rows at the walking base of k-step ks into ring slot `slot`
+    auto request = [&](int slot, int ks, int rows) {  // constants after unrolling
       const uint32_t* p = reinterpret_cast<const uint32_t*>(lds_rows + kq[ks]);
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
         if (d >= rows) continue;
         if (BNN_ROWS_ABL & 4) {
-          fh[s % RING][d] = wh[ks][d];
-          fl[s % RING][d] = wl[ks][d];
+          fh[slot][d] = wh[ks][d];
+          fl[slot][d] = wl[ks][d];
           continue;
         }
         u32x4 v;
         v[0] = p[d * CONV_ROW_D + 0]; v[1] = p[d * CONV_ROW_D + 1]; v[2] = p[d * CONV_ROW_D + 2]; v[3] = p[d * CONV_ROW_D + 3];
-        fh[s % RING][d] = __builtin_bit_cast(half8, v);
+        fh[slot][d] = __builtin_bit_cast(half8, v);
         if constexpr (!HALF) {
           u32x4 l;
           l[0] = p[d * CONV_ROW_D + LO_D + 0]; l[1] = p[d * CONV_ROW_D + LO_D + 1];
           l[2] = p[d * CONV_ROW_D + LO_D + 2]; l[3] = p[d * CONV_ROW_D + LO_D + 3];
-          fl[s % RING][d] = __builtin_bit_cast(half8, l);
+          fl[slot][d] = __builtin_bit_cast(half8, l);
         }
       }
       kq[ks] += (uint32_t)(rows * CONV_ROW_D * 4);
       asm volatile("" : "+v"(kq[ks]));  // keep the walking base: folded into constants, the offsets leave the immediates' range
     };
-    float carry[2][4];
     f32x4 acc[2][2];
-    // BN, padding mask, pooling, stores and sign bits of pass `pass` (0: only the carried row)
-    auto finish = [&](int pass) {
-      const int rows = pass == 0 ? 1 : 2, row0 = pass == 0 ? 0 : 2 * pass - 1, q = pass - 1;
-      // BN (the ReLU is applied after the max-pool: max and relu commute exactly, padding counts as 0)
-      float y[2][2][4];
+    // the MFMAs of one k-step on `rows` conv rows: product-type major, so that the accumulator chains of a step are
+    // independent between two MFMAs on the same one
+    auto multiply = [&](int slot, int ks, int rows) {
+      if constexpr (!HALF && !(BNN_ROWS_ABL & 1)) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+            if (d < rows) acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks][tt], fl[slot][d], acc[d][tt], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+            if (d < rows) acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks][tt], fh[slot][d], acc[d][tt], 0, 0, 0);
+      }
 #pragma unroll
       for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
+          if (d < rows && !(BNN_ROWS_ABL & 1))
+            acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks][tt], fh[slot][d], acc[d][tt], 0, 0, 0);
+    };
+    auto clear = [&]() {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) y[d][tt][r] = d < rows ? fmaf(acc[d][tt][r], ba[tt][r], bb[tt][r]) : 0.0f;
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) acc[d][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // BN of accumulator row d = conv row t of the tile (the ReLU is applied after the max-pool: max and relu commute
+    // exactly); positions outside the conv output are MaxPool padding: 0 never beats a ReLU output
+    auto bn_row = [&](float (&y)[2][4], int d, int t) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[tt][r] = fmaf(acc[d][tt][r], ba[tt][r], bb[tt][r]);
       if (!interior) {
-        // positions outside the conv output are MaxPool padding: 0 never beats a ReLU output
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          if (d >= rows) continue;
-          const bool in = col_in && (unsigned)(cy0 + 2 * QROWS * mg + row0 + d) < (unsigned)Hc;
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y[d][tt][r] = in ? y[d][tt][r] : 0.0f;
-        }
-      }
-      if (pass == 0) {
+        const bool in = col_in && (unsigned)(cy0 + t) < (unsigned)Hc;
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) carry[tt][r] = y[0][tt][r];
-        return;
+          for (int r = 0; r < 4; ++r) y[tt][r] = in ? y[tt][r] : 0.0f;
       }
+    };
+    // pooled row q of the tile from the kept row and the two rows in the accumulators: pooling, stores, sign bits
+    auto finish = [&](int q) {
+      float y0[2][4], y1[2][4];
+      bn_row(y0, 0, 2 * q + 1);
+      bn_row(y1, 1, 2 * q + 2);
       // rows below the image: the stores are dropped (offset beyond the descriptor)
-      const unsigned voff = (py0 + QROWS * mg + q < Hp) ? out_voff : kRowsOOB;
+      const unsigned voff = (py0 + q < Hp) ? out_voff : kRowsOOB;
       // wave-uniform store offset of channel 16*tt + r, walked downwards (kept as ONE running SGPR: as 32 loop
       // invariants they are spilled to lanes and read back in front of every store)
       unsigned soff = out_tile + (unsigned)(q * Wp) * 4u + 19u * chw4;
@@ -376,8 +417,8 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
       for (int tt = 1; tt >= 0; --tt)
 #pragma unroll
         for (int r = 3; r >= 0; --r) {
-          const float v = pool3x3(carry[tt][r], y[0][tt][r], y[1][tt][r]);  // the pooled value on odd lanes
-          carry[tt][r] = y[1][tt][r];
+          const float v = pool3x3(carry[tt][r], y0[tt][r], y1[tt][r]);  // the pooled value on odd lanes
+          carry[tt][r] = y1[tt][r];
           if (!(BNN_ROWS_ABL & 16)) rows_st(r_out, voff, soff, v);
           shift_in_pos(z, v);  // bit 4*tt + r
           soff -= (r == 0 ? 13u : 1u) * chw4;
@@ -385,62 +426,61 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
         }
       if (P != nullptr && !(BNN_ROWS_ABL & 32)) {
         // channel 16*tt + 4*lg + r is bit 16*tt + 4*lg + r of this wave's half of the pixel's word
-        uint32_t wd = ((z & 0xFu) | ((z & 0xF0u) << 12)) << (4 * lg);
-        wd |= (uint32_t)__shfl_xor((int)wd, 16);
-        wd |= (uint32_t)__shfl_xor((int)wd, 32);
-        if (lg == 0 && pool_lane) bits[((buf * PTH + QROWS * mg + q) * PTW + plx) * 2 + nh] = wd;
+        const uint32_t wd = or_rows(((z & 0xFu) | ((z & 0xF0u) << 12)) << (4 * lg));
+        if (lg == 0 && pool_lane) bits[((buf * PTH + q) * PTW + WPW * mg + plx) * 2 + nh] = wd;
       }
     };
 
-    ROWS_T(1)
-    if (valid) {
+    // The conv row above the tile: kept in registers from the tile above (same strip, previous iteration); MaxPool
+    // padding above the image; computed here (2 accumulator chains only) at the start of a chunk inside a strip.
+    if (cy0 < 0) {
 #pragma unroll
-      for (int s = 0; s < AHEAD; ++s) request(s);
+      for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int s = 0; s < NSTEP; ++s) {
-        if (s + AHEAD < NSTEP) request(s + AHEAD);
-        __builtin_amdgcn_sched_barrier(0);  // requests first: sunk next to their use they are exposed again
-        const int ks = s % KSTEPS, rows = s < KSTEPS ? 1 : 2;
-        if (ks == 0) {
+        for (int r = 0; r < 4; ++r) carry[tt][r] = 0.0f;
+    } else if (seg_first) {
+      clear();
 #pragma unroll
-          for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) acc[d][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        // product-type major: the accumulator chains of a step are independent between two MFMAs on the same one
-        if constexpr (!HALF && !(BNN_ROWS_ABL & 1)) {
-#pragma unroll
-          for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-              if (d < rows) acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks][tt], fl[s % RING][d], acc[d][tt], 0, 0, 0);
-#pragma unroll
-          for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-              if (d < rows) acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks][tt], fh[s % RING][d], acc[d][tt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt)
-            if (d < rows && !(BNN_ROWS_ABL & 1))
-              acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks][tt], fh[s % RING][d], acc[d][tt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ks == KSTEPS - 1) ROWS_T(2 + s / KSTEPS)
-        if (ks == KSTEPS - 1 && !(BNN_ROWS_ABL & 2)) finish(s / KSTEPS);
-        if (ks == KSTEPS - 1) ROWS_T(7 + s / KSTEPS)
-        if (s == 3 * KSTEPS - 1 && seq_next < nseq && !(BNN_ROWS_ABL & 8)) commit(pb ^ 1);
-        if (s == 3 * KSTEPS - 1) ROWS_T(12)  // next patch: registers -> the other LDS buffer
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const uint32_t keep = kq[ks];
+        request(0, ks, 1);
+        kq[ks] = keep;
+        multiply(0, ks, 1);
       }
-    } else if (seq_next < nseq) {
-      commit(pb ^ 1);
+      bn_row(carry, 0, 0);
     }
-    prev_n = valid ? n : -1;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) kq[ks] += (uint32_t)(CONV_ROW_D * 4);  // the stream starts at conv row 1
+    ROWS_T(1)
+    // The tile is a stream of 24 steps (pooled row, k-step) of 12 MFMAs on two conv rows.  The B fragments of step
+    // s + AHEAD are requested BEFORE the MFMAs of step s are issued (ring of AHEAD + 1 fragment sets): with two waves
+    // per SIMD nobody else covers the LDS latency.
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) request(s % RING, s % KSTEPS, 2);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+      if (s + AHEAD < NSTEP) request((s + AHEAD) % RING, (s + AHEAD) % KSTEPS, 2);
+      __builtin_amdgcn_sched_barrier(0);  // requests first: sunk next to their use they are exposed again
+      const int ks = s % KSTEPS;
+      if (ks == 0) clear();
+      multiply(s % RING, ks, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks == KSTEPS - 1) ROWS_T(2 + s / KSTEPS)
+      if (ks == KSTEPS - 1 && !(BNN_ROWS_ABL & 2)) finish(s / KSTEPS);
+      if (ks == KSTEPS - 1) ROWS_T(7 + s / KSTEPS)
+      if (s == 2 * KSTEPS - 1 && more && !(BNN_ROWS_ABL & 8)) commit(pb ^ 1);  // next patch: registers -> the other LDS buffer
+      if (s == 2 * KSTEPS - 1) ROWS_T(12)
+    }
+    prev_n = n;
     prev_py0 = py0;
     prev_px0 = px0;
     buf ^= 1;
     pb ^= 1;
+    g = ng;
+    n = nn;
+    tx = ntx;
+    ty = nty;
+    valid = more;
   }
   __syncthreads();
   flush_bits(buf ^ 1);
@@ -460,19 +500,22 @@ static int launch_stem_rows_t(const float* x, const float* w, const float* bn_a,
   const int tiles_y = (Hp + PTH - 1) / PTH, tiles_x = (Wp + PTW - 1) / PTW;
   const long long ntiles = (long long)N * tiles_y * tiles_x;
   const int cus = current_device_cus();
-  const int per_xcd = (int)((ntiles + 7) / 8);
   const long long want = (long long)cus * (8 / NW);  // 8 waves (two workgroups) per CU
   const unsigned grid = (unsigned)(ntiles < want ? ((ntiles + 7) / 8 * 8) : want);
+  // segments (see the kernel): whole strips round-robin when every workgroup gets at least one, else one chunk each
+  const long long strips = (long long)N * tiles_x;
+  const int seg_len = strips >= grid ? tiles_y : (int)((ntiles + grid - 1) / grid);
+  const int nseg = strips >= grid ? (int)((strips + grid - 1) / grid) : 1;
   // per device and per kernel, so it is set on every launch (no mutable global state in a re-entrant API)
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_rows_kernel<HALF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           LDS_BYTES) != hipSuccess)
     return BNN_HIP_ERR_LAUNCH;
-  // byte sizes of the output streams (the C-ABI caps every tensor below 2^32 bytes)
+  // byte sizes of the streams (the C-ABI caps every tensor below 2^32 bytes)
   const unsigned out_bytes = (unsigned)((long long)N * COUT * Hp * Wp * 4);
   const unsigned plane_bytes = (unsigned)((long long)N * Hp * Wp * 8);
   const unsigned x_bytes = (unsigned)((long long)N * CIN * H * W * 4);
   hipLaunchKernelGGL(stem_rows_kernel<HALF>, dim3(grid), dim3(NT), LDS_BYTES, stream, x, w, bn_a, bn_b, N, H, W, Hc,
-                     Wc, Hp, Wp, tiles_y, tiles_x, per_xcd, x_bytes, out, P, M, out_bytes, plane_bytes);
+                     Wc, Hp, Wp, tiles_y, tiles_x, seg_len, nseg, x_bytes, out, P, M, out_bytes, plane_bytes);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
