@@ -181,9 +181,11 @@ def orpool_packed(a: PackedAct, k: int) -> PackedAct:
 
 
 def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: torch.Tensor,
-            out_f32: bool = True, out_packed: bool = True, exact_fp32: bool = False, fp16: bool = False):
+            out_f32: bool = True, out_packed: bool = True, exact_fp32: bool = False, fp16: bool = False,
+            staged: bool = False):
     """conv 7x7/2/3 (3->64, no bias) -> folded BN -> ReLU -> MaxPool 3/2/1 in one MFMA kernel
-    (bnn/models/resnet.py:93-96,150-153).  Returns (fp32 NCHW | None, PackedAct | None)."""
+    (bnn/models/resnet.py:93-96,150-153).  Returns (fp32 NCHW | None, PackedAct | None).
+    ``staged``: the round-2 kernel (bit-identical, slower; include/bnn_hip.h BNN_HIP_STEM_STAGED) for cross-checks."""
     x = _require_cuda_f32(x, "stem input")
     w = _require_cuda_f32(w.detach(), "stem weight")
     if x.dim() != 4 or x.shape[1] != 3 or tuple(w.shape) != (64, 3, 7, 7):
@@ -199,7 +201,8 @@ def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: 
         pk = empty_packed(N, 64, hp, wp, x.device) if out_packed else None
         native.check(lib.bnn_hip_stem7x7_bn_relu_pool_pack_f32(
             x.data_ptr(), w.data_ptr(), bn_scale.data_ptr(), bn_shift.data_ptr(), N, H, W,
-            native.STEM_EXACT_FP32 if exact_fp32 else (native.STEM_FP16 if fp16 else 0), _ptr(y),
+            native.STEM_EXACT_FP32 if exact_fp32 else ((native.STEM_FP16 if fp16 else 0) | (native.STEM_STAGED if staged else 0)),
+            _ptr(y),
             None if pk is None else pk.P.data_ptr(), None if pk is None else pk.M.data_ptr(),
             _stream(x.device)), "bnn_hip_stem7x7_bn_relu_pool_pack_f32")
     if pk is not None:

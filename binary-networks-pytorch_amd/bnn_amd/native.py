@@ -24,6 +24,7 @@ FLAG_ACT_NONNEG = 32
 FLAG_THROUGHPUT = 64
 STEM_EXACT_FP32 = 1
 STEM_FP16 = 4
+STEM_STAGED = 8
 ABI_VERSION = 10
 DTYPE_F32 = 0
 DTYPE_F16 = 1

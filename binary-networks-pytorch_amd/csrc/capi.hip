@@ -204,6 +204,9 @@ int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w, const 
                                           float* out_f32, uint64_t* P, uint64_t* M, void* stream) {
   if (!x || !w || !bn_scale || !bn_shift || N <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
   if (!out_f32 && !P) return BNN_HIP_ERR_INVALID_ARG;
+  if (flags & ~(BNN_HIP_STEM_EXACT_FP32 | BNN_HIP_STEM_FP16 | BNN_HIP_STEM_STAGED)) return BNN_HIP_ERR_INVALID_ARG;
+  if ((flags & BNN_HIP_STEM_EXACT_FP32) && (flags & (BNN_HIP_STEM_FP16 | BNN_HIP_STEM_STAGED)))
+    return BNN_HIP_ERR_INVALID_ARG;
   if ((P == nullptr) != (M == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
   if (P && (!aligned(P, 8) || !aligned(M, 8))) return BNN_HIP_ERR_INVALID_ARG;
   if ((long long)N * 3 * H * W > kMaxElems || (long long)N * 64 * H * W / 16 > kMaxElems)

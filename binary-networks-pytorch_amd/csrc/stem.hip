@@ -16,8 +16,6 @@
 // conv outputs never touch HBM (the library path writes and re-reads 822 MB at batch 256).  Persistent
 // workgroups (one per CU): weights are staged once; the NEXT tile's input patch is fetched into registers
 // while the matrix phase of the current tile runs; tiles are walked in XCD-contiguous order.
-#include <cstdlib>
-
 #include "bnn_dev.h"
 
 namespace bnn {
@@ -296,8 +294,7 @@ static int launch_stem_t(const float* x, const float* w, const float* bn_a, cons
 int launch_stem(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                 int W, int flags, float* out, uint64_t* P, uint64_t* M, hipStream_t stream) {
   if (flags & BNN_HIP_STEM_EXACT_FP32) return launch_stem_t<false>(x, w, bn_a, bn_b, N, H, W, out, P, M, stream);
-  const char* legacy = getenv("BNN_STEM_LEGACY");  // A/B against the round-2 kernel (staged conv tile)
-  if (legacy && legacy[0] == '1')
+  if (flags & BNN_HIP_STEM_STAGED)  // the round-2 kernel: an independent implementation for cross-checks
     return launch_stem_split(x, w, bn_a, bn_b, N, H, W, (flags & BNN_HIP_STEM_FP16) != 0, out, P, M, stream);
   return launch_stem_rows(x, w, bn_a, bn_b, N, H, W, (flags & BNN_HIP_STEM_FP16) != 0, out, P, M, stream);
 }

@@ -86,17 +86,19 @@ __device__ __forceinline__ void rows_st2(RowsRsrc r, unsigned voff, unsigned sof
   __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, 0);
 }
 // One pooled value per lane from the three conv rows a, b, c of its column: v_max3 (vertical), ReLU (max and relu
-// commute; values are >= 0 from here on), then the maximum with the left and the right neighbour inside the 16-lane
-// row as two v_max_f32 with a DPP operand (a missing neighbour reads as 0).  Hand-written: from the builtins hipcc
-// emits v_mov_dpp + a canonicalising v_max + the v_max per neighbour and canonicalises a, b, c; the s_nop covers the
-// two wait states between a VALU write and a DPP read of the same register.
+// commute; values are >= 0 from here on), then the maximum with the two neighbouring conv columns as two v_max_f32
+// with a DPP operand.  Lanes 0..7 of a 16-lane row hold the EVEN conv columns 0, 2, .. 14 of the wave's strip, lanes
+// 8..15 the odd ones 1, 3, .. 15: pooled column j (centre column 2j + 1) ends up on lane 8 + j, its neighbours sit 8
+// and 7 lanes below (row_shr:8, row_shr:7; a missing source reads as 0) — the seven pooled values of a row leave from
+// seven ADJACENT lanes.  Hand-written: from the builtins hipcc emits v_mov_dpp + a canonicalising v_max + the v_max
+// per neighbour and canonicalises a, b, c; the s_nop covers the two wait states between a VALU write and a DPP read.
 __device__ __forceinline__ float pool3x3(float a, float b, float c) {
   float t, v;
   asm("v_max3_f32 %0, %2, %3, %4\n\t"
       "v_max_f32_e32 %0, 0, %0\n\t"
       "s_nop 1\n\t"
-      "v_max_f32_dpp %1, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-      "v_max_f32_dpp %1, %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+      "v_max_f32_dpp %1, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %1, %0, %1 row_shr:7 row_mask:0xf bank_mask:0xf bound_ctrl:0"
       : "=&v"(t), "=&v"(v) : "v"(a), "v"(b), "v"(c));
   return v;
 }
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: what depends on it is uniform
   const int li = lane & 15, lg = lane >> 4;
+  const int lcol = li < 8 ? 2 * li : 2 * li - 15;  // conv column of the strip held by this lane (see pool3x3)
   const int mg = wave & 1, nh = wave >> 1;  // pooled columns 7*mg .. 7*mg + 6, channels 32*nh .. 32*nh + 31
 
   // ---- once: zero both patch buffers (columns 64, 65 and the row padding are read by the idle pixel column and
@@ -164,15 +167,15 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
       }
     }
   }
-  // B operand: lane holds B[k = 8*lg + e][j = li] = patch[c][2*t + ky][2*(14*mg + li) + e] of conv pixel (t, 14*mg + li).
-  // kb[ks]: byte offset of (k-row 4*ks + lg, conv row 0, column pair 14*mg + li); zero-weight k-rows read k-row 20.
+  // B operand: lane holds B[k = 8*lg + e][j = li] = patch[c][2*t + ky][2*(14*mg + lcol) + e] of conv pixel (t, 14*mg + lcol).
+  // kb[ks]: byte offset of (k-row 4*ks + lg, conv row 0, column pair 14*mg + lcol); zero-weight k-rows read k-row 20.
   uint32_t kb[KSTEPS];
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
     int krow = 4 * ks + lg;
     if (krow >= CIN * KS) krow = CIN * KS - 1;
     const int c = krow / KS, ky = krow - c * KS;
-    kb[ks] = (uint32_t)((c * ITH + ky) * ROWD + 2 * WPW * mg + li) * 4u;
+    kb[ks] = (uint32_t)((c * ITH + ky) * ROWD + 2 * WPW * mg + lcol) * 4u;
   }
   // BN constants of the accumulator layout (register r of tile tt -> channel 32*nh + 16*tt + 4*lg + r)
   float ba[2][4], bb[2][4];
@@ -203,9 +206,9 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
   }
   const RowsRsrc r_x = rows_rsrc(x, x_bytes);
   const RowsRsrc r_out = rows_rsrc(out, out_bytes), r_P = rows_rsrc(P, plane_bytes), r_M = rows_rsrc(M, plane_bytes);
-  // output role: odd pixel columns 1, 3, .. 13 hold pooled columns 0 .. 6 after the horizontal maximum
-  const int plx = li >> 1;
-  const bool pool_lane = (li & 1) && li < 2 * WPW;
+  // output role: lanes 8 .. 14 of a row hold pooled columns 0 .. 6 after the horizontal maximum
+  const int plx = li - 8;
+  const bool pool_lane = li >= 8 && li < 8 + WPW;
   const unsigned out_lane = (unsigned)((4 * lg * Hp) * Wp + plx) * 4u;      // channel 4*lg (+ r), pooled column plx
   const unsigned flush_lane = (unsigned)((tid / PTW) * Wp + tid % PTW) * 8u;  // pixel (tid / PTW, tid % PTW) of a tile
 
@@ -324,8 +327,8 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
     const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;  // conv origin (pool pad 1): conv row t of the tile is row cy0 + t
     // most tiles lie entirely inside the conv output: no range tests there
     const bool interior = cy0 >= 0 && cx0 >= 0 && cy0 + CTH <= Hc && cx0 + 2 * PTW + 1 <= Wc;  // workgroup-uniform
-    const bool col_in = (unsigned)(cx0 + 2 * WPW * mg + li) < (unsigned)Wc;
-    const unsigned out_voff = (pool_lane && px0 + WPW * mg + plx < Wp) ? out_lane : kRowsOOB;
+    const bool col_in = (unsigned)(cx0 + 2 * WPW * mg + lcol) < (unsigned)Wc;
+    const bool out_live = pool_lane && px0 + WPW * mg + plx < Wp;
     const unsigned out_tile = (unsigned)(((n * COUT + 32 * nh) * Hp + py0) * Wp + px0 + WPW * mg) * 4u;  // wave-uniform
     const unsigned chw4 = (unsigned)(Hp * Wp) * 4u;
 
@@ -407,23 +410,34 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
       float y0[2][4], y1[2][4];
       bn_row(y0, 0, 2 * q + 1);
       bn_row(y1, 1, 2 * q + 2);
-      // rows below the image: the stores are dropped (offset beyond the descriptor)
-      const unsigned voff = (py0 + q < Hp) ? out_voff : kRowsOOB;
-      // wave-uniform store offset of channel 16*tt + r, walked downwards (kept as ONE running SGPR: as 32 loop
-      // invariants they are spilled to lanes and read back in front of every store)
-      unsigned soff = out_tile + (unsigned)(q * Wp) * 4u + 19u * chw4;
+      float v[2][4];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[tt][r] = pool3x3(carry[tt][r], y0[tt][r], y1[tt][r]);  // the pooled value on lanes 8 .. 14
+          carry[tt][r] = y1[tt][r];
+        }
+      // fp32 stores under an EXEC mask of the 28 lanes that hold a pooled value (rows below / columns right of the
+      // image dropped): the texture addresser walks the active lanes of a store, not all 64
+      if (out_live && py0 + q < Hp && !(BNN_ROWS_ABL & 16)) {
+        // wave-uniform store offset of channel 16*tt + r, walked upwards (kept as ONE running SGPR: as 32 loop
+        // invariants they are spilled to lanes and read back in front of every store)
+        unsigned soff = out_tile + (unsigned)(q * Wp) * 4u;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            rows_st(r_out, out_lane, soff, v[tt][r]);
+            soff += (r == 3 ? 13u : 1u) * chw4;
+            asm volatile("" : "+s"(soff));
+          }
+      }
       uint32_t z = 0;
 #pragma unroll
       for (int tt = 1; tt >= 0; --tt)
 #pragma unroll
-        for (int r = 3; r >= 0; --r) {
-          const float v = pool3x3(carry[tt][r], y0[tt][r], y1[tt][r]);  // the pooled value on odd lanes
-          carry[tt][r] = y1[tt][r];
-          if (!(BNN_ROWS_ABL & 16)) rows_st(r_out, voff, soff, v);
-          shift_in_pos(z, v);  // bit 4*tt + r
-          soff -= (r == 0 ? 13u : 1u) * chw4;
-          asm volatile("" : "+s"(soff));
-        }
+        for (int r = 3; r >= 0; --r) shift_in_pos(z, v[tt][r]);  // bit 4*tt + r
       if (P != nullptr && !(BNN_ROWS_ABL & 32)) {
         // channel 16*tt + 4*lg + r is bit 16*tt + 4*lg + r of this wave's half of the pixel's word
         const uint32_t wd = or_rows(((z & 0xFu) | ((z & 0xF0u) << 12)) << (4 * lg));

@@ -250,6 +250,10 @@ int bnn_hip_bn_relu_maxpool_pack_f32(const float* x, int N, int C, int H, int W,
 /* Plain fp16 operands, one MFMA per product, fp32 accumulation (the "fp16 MFMA stem" of BASELINE config 5):
  * ~5e-4 relative error instead of ~3e-7, one third of the matrix work.  Opt-in; not with EXACT_FP32.        */
 #define BNN_HIP_STEM_FP16 4
+/* The round-2 kernel of the same arithmetic (conv tile staged through LDS, pooled from there; stem_split.hip) instead
+ * of the default one (max-pool in the MFMA accumulators, stem_rows.hip).  Bit-identical results, ~20 % slower: kept
+ * as an independent implementation the tests compare the default kernel with.  With flags 0 or STEM_FP16 only.   */
+#define BNN_HIP_STEM_STAGED 8
 int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w,
                                           const float* bn_scale, const float* bn_shift,
                                           int N, int H, int W, int flags,

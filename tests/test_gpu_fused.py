@@ -461,6 +461,33 @@ def test_mfma_stem_matches_torch_fp32_sequence(shape, exact):
     assert torch.allclose(y, y2, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("fp16", [False, True], ids=["f16x3", "f16"])
+@pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 64, 64), (1, 3, 32, 32), (2, 3, 50, 38), (1, 3, 97, 131),
+                                   (5, 3, 33, 65), (1, 3, 7, 9), (1, 3, 225, 223), (300, 3, 64, 64), (129, 3, 224, 224)])
+def test_the_two_stem_kernels_agree_bit_for_bit(shape, fp16):
+    """The default kernel (transposed GEMM, max-pool in the accumulators, strips walked down the image with the last
+    conv row kept in registers; stem_rows.hip) against the round-2 kernel (conv tile staged through LDS;
+    BNN_HIP_STEM_STAGED): two independent tilings of the same arithmetic, every fp32 value and sign bit equal.
+    The last two shapes have more strips than workgroups (whole strips round-robin, a partial last round), the
+    small ones fewer tiles than workgroups (one chunk each, chunks starting inside a strip)."""
+    x = dev(gen.normal(gen.seed_of("stem2", shape), (min(shape[0], 6),) + shape[1:]))
+    x = x.repeat((shape[0] + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:shape[0]].contiguous()
+    w = dev(gen.conv_weight("kaiming", 3, (64, 3, 7, 7)))
+    a = dev((0.5 + gen.uniform(1, (64,))).astype(np.float32) * np.where(np.arange(64) % 7 == 0, -1, 1).astype(np.float32))
+    b = dev((0.3 * gen.normal(2, (64,))).astype(np.float32))
+    y0, p0 = hipops.stem7x7(x, w, a, b, fp16=fp16, staged=True)
+    y1, p1 = hipops.stem7x7(x, w, a, b, fp16=fp16)
+    assert torch.equal(y0, y1) and torch.equal(p0.P, p1.P) and torch.equal(p0.M, p1.M)
+    y2, _ = hipops.stem7x7(x, w, a, b, fp16=fp16, out_packed=False)
+    _, p3 = hipops.stem7x7(x, w, a, b, fp16=fp16, out_f32=False)
+    assert torch.equal(y2, y1) and torch.equal(p3.P, p1.P)
+    lib = native.require()
+    bad = lib.bnn_hip_stem7x7_bn_relu_pool_pack_f32(x.data_ptr(), w.data_ptr(), a.data_ptr(), b.data_ptr(), 1, 7, 9,
+                                                    native.STEM_EXACT_FP32 | native.STEM_STAGED, y1.data_ptr(), None,
+                                                    None, None)
+    assert bad == -1          # BNN_HIP_ERR_INVALID_ARG: the staged kernel has no exact-fp32 mode
+
+
 def test_fused_resnet_with_and_without_mfma_stem_agree():
     net = _r18()
     x = dev(gen.normal(gen.seed_of("r18", "64"), (2, 3, 64, 64)))

@@ -23,8 +23,8 @@ for name, kw in (("split", {}), ("fp16", {"fp16": True})):
     us = e0.elapsed_time(e1) * 1e3 / 20
     t = pk.M.cpu().numpy().reshape(-1)[:512 * 4 * 16].astype(np.float64).reshape(512, 4, 16)
     tiles = 28
-    names = ["barrier wait", "flush+fetch issue", "mfma pass0", "mfma pass1", "mfma pass2", "mfma pass3", "mfma pass4",
-             "finish 0", "finish 1", "finish 2", "finish 3", "finish 4", "commit", "loop tail"]
+    names = ["barrier wait", "flush+fetch+row0", "mfma row 0", "mfma row 1", "mfma row 2", "mfma row 3", "-",
+             "finish 0", "finish 1", "finish 2", "finish 3", "-", "commit", "loop tail"]
     print("%s: %.1f us per launch (instrumented); cycles per tile, mean over workgroups, by wave (mg,nh)=(0,0),(1,0),(0,1),(1,1)" % (name, us))
     for k, nm in enumerate(names):
         print("  %-18s" % nm, " ".join("%7.0f" % (t[:, wv, k].mean() / tiles) for wv in range(4)))

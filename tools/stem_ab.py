@@ -1,4 +1,4 @@
-"""Stem kernel A/B: the pooled-in-accumulators kernel (stem_rows.hip) against the round-2 kernel (BNN_STEM_LEGACY=1):
+"""Stem kernel A/B: the pooled-in-accumulators kernel (stem_rows.hip) against the round-2 kernel (stem7x7(staged=True)):
 bitwise comparison of both outputs over ragged shapes, then warm-clock timings of the three output modes."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,8 +10,7 @@ dev = torch.device("cuda:0")
 
 
 def run(legacy, *a, **kw):
-    os.environ["BNN_STEM_LEGACY"] = "1" if legacy else "0"
-    y, pk = hipops.stem7x7(*a, **kw)
+    y, pk = hipops.stem7x7(*a, staged=legacy, **kw)
     torch.cuda.synchronize()
     return y, pk
 
@@ -61,8 +60,7 @@ for _ in range(600):
 torch.cuda.synchronize()
 for rep in range(2):
     for legacy in (True, False):
-        os.environ["BNN_STEM_LEGACY"] = "1" if legacy else "0"
-        for name, kw in (("split", {}), ("fp16", {"fp16": True})):
+        for name, kw in (("split", {"staged": legacy}), ("fp16", {"fp16": True, "staged": legacy})):
             print("%-7s %-6s full %.1f us   packed-only %.1f us   f32-only %.1f us" % (
                 "legacy" if legacy else "rows", name, t(lambda: hipops.stem7x7(x, w, a, b, **kw)),
                 t(lambda: hipops.stem7x7(x, w, a, b, out_f32=False, **kw)),
