@@ -226,11 +226,23 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
     const int iy0 = 4 * ty * PTH - 5, ixe = 4 * tx * PTW - 6;  // first input row; first (even) input column
     const unsigned img = (unsigned)(n * CIN * H * W) * 4u;
     const int toff = (iy0 * W + ixe) * 4;
-    if (iy0 >= 0 && iy0 + ITH <= H && ixe >= 0 && ixe + 2 * NPC <= W) {  // the patch lies inside the image
+    const bool rows_in = iy0 >= 0 && iy0 + ITH <= H;
+    if (rows_in && ixe >= 0 && ixe + 2 * NPC <= W) {  // the patch lies inside the image
 #pragma unroll
       for (int u = 0; u < PER_T; ++u) {
         nx0[u] = rows_ld(r_x, rowoff[u], img + (unsigned)toff);
         nx1[u] = rows_ld(r_x, rowoff[u] + 4u, img + (unsigned)toff);
+      }
+    } else if (rows_in && !(W & 1)) {
+      // left / right edge of an even-width image: a column pair is inside or outside as a whole (the patch starts at
+      // an even column) — one select per load
+      const bool okc = (unsigned)(ixe + 2 * fpc) < (unsigned)W;
+      const unsigned rowpart = img + (unsigned)(iy0 * W * 4);
+#pragma unroll
+      for (int u = 0; u < PER_T; ++u) {
+        const unsigned off = (okc && frow0 + RSTEP * u < NROW) ? rowoff[u] + (unsigned)(ixe * 4) : kRowsOOB;
+        nx0[u] = rows_ld(r_x, off, rowpart);
+        nx1[u] = rows_ld(r_x, off + 4u, rowpart);
       }
     } else {
       const int ix = ixe + 2 * fpc;
