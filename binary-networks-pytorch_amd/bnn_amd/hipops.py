@@ -446,9 +446,14 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
                   weights: Optional[str] = None, residual_after_act: bool = False,
                   pack_before_residual: bool = False, pack_scale=None, pack_shift=None,
                   pack_relu: bool = False, out: Optional[torch.Tensor] = None, out_c_offset: int = 0,
-                  throughput: bool = False, sign_thresholds: Optional[torch.Tensor] = None):
+                  throughput: bool = False, sign_thresholds: Optional[torch.Tensor] = None,
+                  shortcut: Optional[tuple] = None):
     """Binary convolution + fused epilogue (see ``bnn_hip_epilogue``): returns
     ``(y_fp32 | None, PackedAct(sign(p)) | None)``.
+
+    ``shortcut = (PackedAct, PackedWeight, bn_scale, bn_shift)``: the down-sampling block's shortcut branch folded into
+    this launch (``bnn_hip_epilogue.sc_*``): the residual is ``BN(conv1x1(packed))`` computed in the kernel instead of
+    an fp32 tensor; see ``shortcut_fold_supported``.
 
     ``out``: write the fp32 result into channels ``[out_c_offset, out_c_offset + O)`` of this
     preallocated ``[N, C_total, Ho, Wo]`` tensor (``torch.cat`` in place); ``residual`` then has
@@ -477,6 +482,14 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
         residual = _require_cuda_f32(residual, "residual")
         if tuple(residual.shape) != (d.N, c_total, ho, wo):
             raise native.NativeError(f"bnn_amd: residual shape {tuple(residual.shape)} != output")
+    if shortcut is not None:
+        sa, sw, sbn_a, sbn_b = shortcut
+        if residual is not None or not sa.nonneg or tuple(sa.shape) != (d.N, sw.shape[1], ho, wo) \
+                or tuple(sw.shape) != (d.O, sa.shape[1], 1, 1) or sw.has_zero:
+            raise native.NativeError("bnn_amd: folded shortcut: a non-negative packed [N, C, Ho, Wo] input, a 1x1 "
+                                     "[O, C, 1, 1] weight without zeros, and no separate residual")
+        sbn_a = _per_channel(sbn_a, d.O, "shortcut bn_scale")
+        sbn_b = _per_channel(sbn_b, d.O, "shortcut bn_shift")
     eflags = (native.EPI_RES_AFTER_ACT if residual_after_act else 0) | \
         (native.EPI_PACK_BEFORE_RES if pack_before_residual else 0) | (native.EPI_PACK_RELU if pack_relu else 0)
     with torch.cuda.device(dev):
@@ -497,7 +510,9 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
                                 None if pk is None else pk.P[n0:n1].data_ptr(),
                                 None if pk is None else pk.M[n0:n1].data_ptr(), _ptr(pack_scale), _ptr(pack_shift),
                                 out_c_offset if out is not None else 0, c_total if out is not None else 0,
-                                _ptr(sign_thresholds))
+                                _ptr(sign_thresholds),
+                                *((sa.P[n0:n1].data_ptr(), sw.wbits.data_ptr(), sw.alpha.data_ptr(), sbn_a.data_ptr(),
+                                   sbn_b.data_ptr(), sa.shape[1], 0) if shortcut is not None else ()))
             native.check(lib.bnn_hip_bconv2d_fused(ctypes.byref(dd), a.P[n0:n1].data_ptr(), a.M[n0:n1].data_ptr(),
                                                    w.wbits.data_ptr(), w.wnz.data_ptr(),
                                                    ctypes.byref(e), _stream(dev)),
@@ -507,6 +522,15 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
         pk.nonneg = bool(pack_relu) or (bool(relu) and prelu is None and pack_scale is None
                                         and (not late or pack_before_residual))
     return y, pk
+
+
+def shortcut_fold_supported(a: PackedAct, w: PackedWeight, sc_channels: int, stride=1, padding=0, dilation=1,
+                            throughput: bool = False) -> bool:
+    """Whether ``bconv2d_fused(a, w, ..., shortcut=...)`` exists for this convolution and a shortcut 1x1 convolution of
+    ``sc_channels`` input channels (``bnn_hip_shortcut_fold_supported``)."""
+    lib = native.require()
+    d = _desc(a.shape, w.shape, stride, padding, dilation, _flags(w, False, None, a, throughput))
+    return bool(lib.bnn_hip_shortcut_fold_supported(ctypes.byref(d), int(sc_channels)))
 
 
 def grad_supported(x_shape, w_shape, stride, padding, dilation) -> bool:

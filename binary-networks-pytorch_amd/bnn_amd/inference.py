@@ -137,7 +137,7 @@ class FusedResNet(nn.Module):
 
     def __init__(self, model: ResNet, use_mfma_stem: bool = True, overlap_shortcut: bool = True,
                  stem_fp16: bool = False, stem_exact_fp32: bool = False, throughput_mode: bool = False,
-                 int_thresholds: bool = True, skip_dead_f32: bool = True) -> None:
+                 int_thresholds: bool = True, skip_dead_f32: bool = True, fold_shortcut: bool = True) -> None:
         super().__init__()
         # the last conv of a block writes no fp32 tensor when the next block consumes sign planes only
         self.skip_dead_f32 = skip_dead_f32
@@ -149,6 +149,8 @@ class FusedResNet(nn.Module):
         self.use_mfma_stem = use_mfma_stem
         self.stem_exact_fp32 = stem_exact_fp32   # v_mfma_f32_16x16x4_f32: bit-for-bit an fp32 fmaf chain (slower)
         self.overlap_shortcut = overlap_shortcut
+        # a down-sampling block's shortcut conv (AvgPool -> binary 1x1 -> BN) computed inside its last conv
+        self.fold_shortcut = fold_shortcut
         self._side = {}
         if not isinstance(model, ResNet) or model.stem_type != "basic":
             raise FusionError("FusedResNet covers bnn_amd.models.ResNet with the 'basic' stem")
@@ -313,7 +315,16 @@ class FusedResNet(nn.Module):
             if packed is None:
                 packed = hipops.pack_act(t)
             side = None
-            if b["ds"] is not None:
+            fold = None   # (PackedAct, PackedWeight, bn_scale, bn_shift) of a shortcut conv folded into the last conv
+            if b["ds"] is not None and self._fold_applies(b, packed):
+                # the shortcut conv (1x1 over the OR-pooled sign planes) is computed inside the block's last conv: no
+                # fp32 shortcut tensor, no 1x1 launch (bnn_hip_epilogue.sc_*)
+                sc_in = hipops.orpool_packed(packed, b["pool"]) if b["pool"] > 1 else packed
+                if _TAP is not None:
+                    _TAP(b["ds"].name, sc_in)
+                fold = (sc_in, b["ds"].weight, b["ds"].bn_scale, b["ds"].bn_shift)
+                idn = None
+            elif b["ds"] is not None:
                 # the shortcut branch (HBM-bound avg-pool + a small 1x1 conv) is independent of the block's
                 # first convs (ALU-bound): run it on a second stream and join before the residual is needed
                 dev_ = packed.P.device      # (t is None when the previous block skipped its dead fp32 output)
@@ -349,8 +360,38 @@ class FusedResNet(nn.Module):
             c2 = b["convs"][-1]
             dead_f32 = (self.skip_dead_f32 and nxt is not None and nxt["kind"] == "post" and nxt["ds"] is not None
                         and (nxt["pool"] <= 1 or (c2.relu and c2.prelu is None)))
-            t, packed = c2.run(packed, residual=idn, out_f32=not dead_f32, out_packed=i != last)
+            if fold is not None:
+                t, packed = c2.run(packed, out_f32=True, out_packed=True, shortcut=fold)
+            else:
+                t, packed = c2.run(packed, residual=idn, out_f32=not dead_f32, out_packed=i != last)
         return t
+
+    def _fold_applies(self, b, packed) -> bool:
+        """Whether the block's shortcut convolution can be computed inside its last convolution (decided once per
+        block from the first batch: shapes and recipes do not change).  Needs: non-negative sign planes in front of
+        the block (an OR-pool then IS the avg-pool's sign), a bias-free 1x1 / stride-1 shortcut conv without post
+        scale or zero weights, a last conv whose kernel takes the fold (``hipops.shortcut_fold_supported``) and whose
+        fp32 output and sign planes are both wanted (a block in the middle of the net)."""
+        if not self.fold_shortcut:
+            return False
+        if "fold" not in b:
+            ds, c2 = b["ds"], b["convs"][-1]
+            lay = ds.layer
+            ok = (packed.nonneg and lay.bias is None and ds.plan.scale is None and not ds.relu and ds.prelu is None
+                  and tuple(lay.kernel_size) == (1, 1) and tuple(lay.stride) == (1, 1) and tuple(lay.padding) == (0, 0)
+                  and not ds.weight.has_zero and b is not self._blocks[-1] and len(b["convs"]) >= 2
+                  and all(c.relu and c.prelu is None for c in b["convs"][:-1])
+                  and c2.relu and c2.prelu is None and c2.layer.bias is None and c2.plan.scale is None)
+            if ok:
+                N, _, H, W = packed.shape
+                k = max(b["pool"], 1)
+                ho, wo = -(-H // k), -(-W // k)
+                c2l = c2.layer
+                probe = hipops.PackedAct(packed.P, packed.M, (N, c2l.in_channels, ho, wo), nonneg=True)
+                ok = hipops.shortcut_fold_supported(probe, c2.weight, lay.in_channels, c2l.stride, c2l.padding,
+                                                    c2l.dilation, throughput=c2.throughput)
+            b["fold"] = bool(ok)
+        return b["fold"]
 
     def _side_stream(self, device) -> torch.cuda.Stream:
         key = (device.index, torch.cuda.current_stream(device).cuda_stream)
@@ -461,6 +502,7 @@ class FusedBlocks(FusedResNet):
         self.int_thresholds = int_thresholds
         self.throughput_mode = throughput_mode
         self.overlap_shortcut = True
+        self.fold_shortcut = True
         self._side = {}
         self.model = blocks
         self._blocks = []

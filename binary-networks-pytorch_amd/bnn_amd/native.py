@@ -25,7 +25,7 @@ FLAG_THROUGHPUT = 64
 STEM_EXACT_FP32 = 1
 STEM_FP16 = 4
 STEM_STAGED = 8
-ABI_VERSION = 10
+ABI_VERSION = 11
 DTYPE_F32 = 0
 DTYPE_F16 = 1
 
@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_conv_workspace_bytes", "bnn_hip_bconv2d_f32", "bnn_hip_probe_int_alu", "bnn_hip_avgpool_fc_f32", "bnn_hip_sign_thresholds_f32", "bnn_hip_pack_act_f16", "bnn_hip_orpool_packed",
     "bnn_hip_grad_weight_pack_bytes", "bnn_hip_grad_pack_weight_f32", "bnn_hip_bconv_grad_input_f32",
     "bnn_hip_bconv_grad_weight_splits", "bnn_hip_bconv_grad_weight_f32",
-    "bnn_hip_bconv2d_direct", "bnn_hip_bconv2d_direct_plan",
+    "bnn_hip_bconv2d_direct", "bnn_hip_bconv2d_direct_plan", "bnn_hip_shortcut_fold_supported",
 )
 
 
@@ -83,7 +83,11 @@ class Epilogue(ctypes.Structure):
                 ("out_f32", ctypes.c_void_p), ("out_P", ctypes.c_void_p), ("out_M", ctypes.c_void_p),
                 ("pack_scale", ctypes.c_void_p), ("pack_shift", ctypes.c_void_p),
                 ("out_c_offset", ctypes.c_int32), ("out_c_total", ctypes.c_int32),
-                ("sign_thresholds", ctypes.c_void_p)]
+                ("sign_thresholds", ctypes.c_void_p),
+                # ABI 11: the block's shortcut convolution folded into this one (include/bnn_hip.h)
+                ("sc_P", ctypes.c_void_p), ("sc_wbits", ctypes.c_void_p), ("sc_alpha", ctypes.c_void_p),
+                ("sc_bn_scale", ctypes.c_void_p), ("sc_bn_shift", ctypes.c_void_p),
+                ("sc_C", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 EPI_RES_AFTER_ACT = 1
@@ -125,6 +129,8 @@ def _declare(lib: ctypes.CDLL) -> None:
                                                      _vp, _vp, _vp, _vp]
     lib.bnn_hip_pack_weight_f32.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]
     lib.bnn_hip_bconv2d.argtypes = [ctypes.POINTER(ConvDesc)] + [_vp] * 9
+    lib.bnn_hip_shortcut_fold_supported.argtypes = [ctypes.POINTER(ConvDesc), _i]
+    lib.bnn_hip_shortcut_fold_supported.restype = _i
     lib.bnn_hip_bconv2d_fused.argtypes = [ctypes.POINTER(ConvDesc)] + [_vp] * 4 + \
         [ctypes.POINTER(Epilogue), _vp]
     lib.bnn_hip_bconv2d_dot.argtypes = [ctypes.POINTER(ConvDesc)] + [_vp] * 6

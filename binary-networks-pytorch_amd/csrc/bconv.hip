@@ -34,12 +34,14 @@ namespace bnn {
 //   WZ: some weights are exactly zero (BNN_HIP_FLAG_WEIGHT_ZEROS): second scalar stream with the mask `Z`.
 //   OBW: consecutive 32-channel blocks one wave produces from ONE load of its field (single-chunk layers: the
 //        field load, its padding selects and the non-zero count are ~10 % of a block's instructions).
+//   DS: the residual is the block's shortcut convolution, computed here (bconv_core.h, ShortcutArgs) instead of read.
 template <int KH, int KW, int CWC, int EP, int MINW, int PASSES, bool MULTI, bool GSPLIT = false, bool NN = false,
-          bool WZ = false, int OBW = 1>
+          bool WZ = false, int OBW = 1, bool DS = false>
 __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
     const uint32_t* __restrict__ P, const uint32_t* __restrict__ M, const uint32_t* __restrict__ W,
-    const uint32_t* __restrict__ Z, BNN_EPI_PARAMS, const Geo g) {
+    const uint32_t* __restrict__ Z, BNN_EPI_PARAMS, BNN_DS_PARAMS, const Geo g) {
   static_assert(!(WZ && (NN || GSPLIT)), "the zero-weight variant is two-plane, unsplit");
+  static_assert(!DS || (EP == EP_OUT && OBW == 1 && !WZ), "the folded shortcut: conv2-type epilogue only");
   static_assert(OBW == 1 || (!MULTI && !GSPLIT), "several blocks per wave: single-chunk, unsplit kernels only");
   static_assert(!(WZ && EP == EP_MIDT), "the threshold epilogue takes the non-zero count per lane, not per channel");
   constexpr int T = KH * KW;
@@ -58,6 +60,10 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
   const int tile = xcd * g.tiles_per_xcd + (slot - obp * g.tiles_per_xcd);
   if (tile >= g.tiles) return;
   const Pix px = decode_pixel<true>(g, tile * kWave + threadIdx.x);
+  [[maybe_unused]] const ShortcutArgs sc{dsP, dsW, ds_alpha, ds_a, ds_b};
+  [[maybe_unused]] uint32_t dsr[8];
+  [[maybe_unused]] int ds_nz = 0;
+  if constexpr (DS) ds_nz = load_shortcut_field(g, px, sc, dsr);
   uint32_t pr[NW], mr[NW];
   int nz = 0;
   if constexpr (!MULTI) {
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
     // compiler has to wait for vmcnt(0): a residual load issued after the previous pass's stores would make the
     // wave wait for those stores' acknowledgements in every pass.  Loads first, stores only after the last load
     // has been consumed: the stores of a pass are never waited for.  Costs 24 VGPRs (8 -> 6 waves per SIMD).
-    constexpr bool RES_ALL = !MULTI && !GSPLIT && PASSES > 1 && (EP == EP_OUT || EP == EP_LAST);
+    constexpr bool RES_ALL = !DS && !MULTI && !GSPLIT && PASSES > 1 && (EP == EP_OUT || EP == EP_LAST);
     [[maybe_unused]] float resq[RES_ALL ? kOCB : 1];
     if constexpr (RES_ALL) {
       if ((ob + 1) * kOCB <= g.O) prefetch_residual<kOCB, EP, true>(g, px, ob * kOCB, epi, resq);
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       // single-chunk: shortcut values are requested before the popcount loop and land under it.
       // multi-chunk: the field + 32 accumulators already fill the 128-VGPR budget of 4 waves/SIMD;
       // holding NACC more values across the loop spills (39 VGPRs measured), so they are fetched late.
-      constexpr bool RES_EARLY = !RES_ALL && (!MULTI || BNN_MULTI_RES_EARLY);
+      constexpr bool RES_EARLY = !DS && !RES_ALL && (!MULTI || BNN_MULTI_RES_EARLY);
       // wave-uniform; the same for every pass of a block: a block either builds its sign words by shift-in (straight-
       // line epilogue) or by OR-ing bits into place (guarded epilogue), never both
       const bool fullb = (ob + 1) * kOCB <= g.O;
@@ -105,6 +111,10 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
         if (fullb) prefetch_residual<NACC, EP, true>(g, px, ob * kOCB + ps * NACC, epi, resv);
         else prefetch_residual<NACC, EP>(g, px, ob * kOCB + ps * NACC, epi, resv);
       }
+      // the folded shortcut values of the pass.  Single-chunk kernels: BEFORE the popcount loop, whose weight stream needs
+      // the scalar registers (8 values wait in VGPRs); multi-chunk kernels (16 or 32 values, a register file at its
+      // occupancy step): after it
+      if constexpr (DS && !MULTI) shortcut_values<NACC>(g, ob * kOCB + ps * NACC, sc, dsr, ds_nz, resv);
       // compile-time profiles with a float epilogue: the counts are kept as the bit pattern of 2^23 + count (epilogue())
       constexpr bool SEEDED = !WZ && NACC % 2 == 0 && EP != EP_RUNTIME && EP != EP_MIDT;
 #pragma unroll
@@ -128,8 +138,9 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       // ONE branch on `fullb` around everything that differs: with the late shortcut fetch and the epilogue under two
       // separate ifs, the guarded side's 32 per-channel predicates are computed at the common dominator — in front of
       // the first if, on every wave — and spilled to VGPR lanes (215 v_readlane + 123 v_writelane in the 512->512 kernel).
-      constexpr bool RES_LATE_FETCH = !RES_EARLY && !RES_ALL;
+      constexpr bool RES_LATE_FETCH = !DS && !RES_EARLY && !RES_ALL;
       const int o0 = ob * kOCB + ps * NACC;
+      if constexpr (DS && MULTI) shortcut_values<NACC>(g, o0, sc, dsr, ds_nz, resv);
       [[maybe_unused]] int negnz = NN ? -nz : nz;  // EP_MIDT (see its epilogue): dot = +-2*count + negnz
 #if defined(__HIP_DEVICE_COMPILE__)
       if constexpr (EP == EP_MIDT) asm("" : "+v"(negnz));
@@ -351,6 +362,7 @@ __global__ __launch_bounds__(64) void bconv_generic_kernel(
 // ---------------------------------------------------------------------------------
 #define BNN_EPI_ACTUALS \
   p.alpha, p.bias, p.scale, p.bn_a, p.bn_b, p.prelu, p.res, p.out, p.outP, p.outM, p.pack_a, p.pack_b, p.thr
+#define BNN_DS_ACTUALS p.ds_P, p.ds_W, p.ds_alpha, p.ds_a, p.ds_b
 
 // grid.y: one block per 32 output channels; in pack mode also the (all-zero) tail words of the
 // packed output row so that every word of the next layer's input is written.
@@ -404,7 +416,7 @@ static void launch_sgpr_t(const ConvP& p, const Geo& g, bool split_ok, hipStream
       if (oblocks(p) >= BNN_SGPR_OBW) {
         const dim3 grid2((unsigned)(8 * g.tiles_per_xcd) * ((oblocks(p) + BNN_SGPR_OBW - 1) / BNN_SGPR_OBW));
         hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, P1, false, false, NN, false, BNN_SGPR_OBW>), grid2,
-                           dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
+                           dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
         return;
       }
     }
@@ -416,15 +428,22 @@ static void launch_sgpr_t(const ConvP& p, const Geo& g, bool split_ok, hipStream
       if (split_ok && (long long)grid.x <= BNN_SINGLE_GSPLIT_MAX_WAVES) {
         const dim3 grid2(grid.x * BNN_SINGLE_GSPLIT);
         hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, BNN_SINGLE_GSPLIT, false, true, NN>), grid2,
-                           dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
+                           dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
         return;
       }
     }
 #endif
     // conv2-type epilogue on a 128-channel P-only field: 97 VGPRs uncapped, one over the budget of 5 waves per SIMD
     constexpr int MW1 = (NN && CWC == 4 && EP == EP_OUT) ? BNN_OUT4_MINW : 1;
+    if constexpr (EP == EP_OUT && NN) {
+      if (p.ds_P) {  // the block's shortcut convolution folded in (ds_fold_applies() vouches for the shape)
+        hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MW1, P1, false, false, NN, false, 1, true>), grid,
+                           dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
+        return;
+      }
+    }
     hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MW1, P1, false, false, NN>), grid,
-                       dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
+                       dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
     return;
   }
   if constexpr (k3 && CWC == 4) {  // the only shape class with several chunks of a large field
@@ -438,18 +457,40 @@ static void launch_sgpr_t(const ConvP& p, const Geo& g, bool split_ok, hipStream
     // beside another batch (config-5 net at batch 128: 127 k images/s with the split, 119 k without)
     if ((split_ok || grid.x < 2048u) && (long long)grid.x <= BNN_GSPLIT_MAX_WAVES) {
       const dim3 grid2(grid.x * BNN_MULTI_GSPLIT);
+      if constexpr (EP == EP_OUT && NN) {
+        if (p.ds_P) {
+          hipLaunchKernelGGL(
+              (bconv_sgpr_kernel<KH, KW, CWC, EP, MW, BNN_MULTI_GSPLIT, true, true, NN, false, 1, true>), grid2,
+              dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
+          return;
+        }
+      }
       hipLaunchKernelGGL(
           (bconv_sgpr_kernel<KH, KW, CWC, EP, MW, BNN_MULTI_GSPLIT, true, true, NN>), grid2,
-          dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
+          dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
       return;
     }
 #endif
+    if constexpr (EP == EP_OUT && NN) {
+      if (p.ds_P) {
+        hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MW, PM, true, false, NN, false, 1, true>), grid,
+                           dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
+        return;
+      }
+    }
     hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MW, PM, true, false, NN>), grid,
-                       dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
+                       dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
     return;
   }
+  if constexpr (EP == EP_OUT && NN) {
+    if (p.ds_P) {
+      hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, PM, true, false, NN, false, 1, true>), grid,
+                         dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
+      return;
+    }
+  }
   hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, PM, true, false, NN>), grid,
-                     dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
+                     dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
 }
 
 template <int KH, int KW, int CWC, int EP>
@@ -466,10 +507,10 @@ static void launch_sgpr_wz(const ConvP& p, const Geo& g, hipStream_t s) {
   const dim3 grid((unsigned)(8 * g.tiles_per_xcd) * oblocks(p));
   if (KH * KW > 1 && p.nchunk == 1)
     hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, 4, false, false, false, true>), grid,
-                       dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
+                       dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
   else
     hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, 1, 4, true, false, false, true>), grid,
-                       dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, g);
+                       dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
 }
 
 // PROFILES: whether the compile-time epilogue profiles exist for this shape (3x3 only).
@@ -535,6 +576,20 @@ int choose_cwc(int cw32, int KH, int KW) {
 // a vector-broadcast weight path measured 162 us and was removed), so the LDS tile is only taken
 // on request.
 static bool prefer_lds(const ConvP&, int flags) { return (flags & BNN_HIP_FLAG_WEIGHTS_LDS) != 0; }
+
+// Whether launch_bconv() would run this convolution in a kernel that can take the folded shortcut branch (ConvP::ds_*):
+// a tiled 3x3 layer on non-negative activations without zero weights, conv2-type epilogue (BN + residual + ReLU ->
+// fp32 + sign planes), 64 / 128 / 256 shortcut channels.
+bool ds_fold_applies(const ConvP& p, int flags) {
+  if ((flags & (BNN_HIP_FLAG_FORCE_GENERIC | BNN_HIP_FLAG_WEIGHT_ZEROS | BNN_HIP_FLAG_WEIGHTS_LDS)) ||
+      !(flags & BNN_HIP_FLAG_ACT_NONNEG))
+    return false;
+  if (p.KH != 3 || p.KW != 3 || p.dh != 1 || p.dw != 1 || !small_indices(p) || (p.cwc != 2 && p.cwc != 4)) return false;
+  if (p.ds_C != 64 && p.ds_C != 128 && p.ds_C != 256) return false;
+  ConvP q = p;
+  q.ds_P = reinterpret_cast<const uint32_t*>(&q);  // (any non-null value: only the flag word is looked at)
+  return make_geo(q).flags == kFlagsOut;
+}
 
 int launch_bconv(const ConvP& p, int flags, hipStream_t s) {
   const bool wz = (flags & BNN_HIP_FLAG_WEIGHT_ZEROS) != 0;

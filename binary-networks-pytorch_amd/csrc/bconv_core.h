@@ -26,6 +26,7 @@ struct Geo {
   uint32_t m_hw, m_wo, m_tpx;
   int s_hw, s_wo, s_tpx;
   unsigned in_bytes;  // bytes of one packed input plane tensor (P or M): the range of the field loads' descriptor
+  int ds_cw;     // folded shortcut convolution (ShortcutArgs): 32-bit words per pixel of its input plane; 0 = none
 };
 
 enum : int {
@@ -607,6 +608,66 @@ __device__ __forceinline__ void store_packed_part(const Geo& g, const Pix& px, i
 #define BNN_EPI_INIT \
   EpiArgs epi{alpha, bias, scale, bn_a, bn_b, prelu, res, out, outP, outM, pack_a, pack_b, thr}
 
+// The shortcut branch of a down-sampling residual block folded into the block's second convolution (bconv_sgpr_kernel<..,
+// DS = true>): the residual of output channel o at a pixel is not read from an fp32 tensor but computed here,
+//     r = fmaf(fmaf(alpha[o], dot1x1(sign planes sc_P, sc_W[o]), 0), bn_a[o], bn_b[o])
+// with the float operations of the 1x1 convolution's own epilogue (EP_DS) — the fp32 shortcut tensor (103 MB at
+// ResNet-18 layer2, batch 256, written once and read once) and the 1x1 launch disappear.  The shortcut input is the
+// sign plane of an AvgPool of ReLU outputs: non-negative, P plane only, [N, ceil(C/64), Ho, Wo] uint64.
+#define BNN_DS_PARAMS                                                                             \
+  const uint32_t *__restrict__ dsP, const uint32_t *__restrict__ dsW, const float *__restrict__ ds_alpha, \
+      const float *__restrict__ ds_a, const float *__restrict__ ds_b
+struct ShortcutArgs {
+  const uint32_t* P;
+  const uint32_t* W;
+  const float* alpha;
+  const float* a;
+  const float* b;
+};
+
+// The lane's pixel of the shortcut planes (ds_cw <= 8 words; unused registers stay 0) and its non-zero count.
+__device__ __forceinline__ int load_shortcut_field(const Geo& g, const Pix& px, const ShortcutArgs& d, uint32_t (&dsr)[8]) {
+  const unsigned hw = (unsigned)(g.Ho * g.Wo);
+  const unsigned base = (unsigned)px.n * (unsigned)(g.ds_cw >> 1) * hw + (unsigned)px.r;  // uint64 words
+  int nz = 0;
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) {
+    uint2 v{0u, 0u};
+    if (2 * gi < g.ds_cw) v = reinterpret_cast<const uint2*>(d.P)[base + (unsigned)gi * hw];
+    dsr[2 * gi] = v.x;
+    dsr[2 * gi + 1] = v.y;
+    nz += __builtin_popcount(v.x) + __builtin_popcount(v.y);
+  }
+  return nz;
+}
+
+// The shortcut values of channels o0 .. o0+NACC-1 (wave-uniform weights and constants: scalar loads).
+template <int NACC, int CW>
+__device__ __forceinline__ void shortcut_values_cw(const Geo& g, int o0, const ShortcutArgs& d, const uint32_t (&dsr)[8],
+                                                   int nz, float (&resv)[NACC]) {
+#pragma unroll
+  for (int j = 0; j < NACC; ++j) {
+    if (j % 4 == 0) __builtin_amdgcn_sched_barrier(0);  // four channels' weights and constants in scalar registers at a time
+    const int o = o0 + j;
+    float r = 0.0f;
+    if (o < g.O) {
+      int agree = 0;
+#pragma unroll
+      for (int i = 0; i < CW; ++i) agree += __builtin_popcount(d.W[(size_t)o * CW + i] & dsr[i]);
+      const float dot = (float)(2 * agree - nz);           // non-negative input: dot = 2 * agreements - non-zeros
+      r = fmaf(fmaf(d.alpha[o], dot, 0.0f), d.a[o], d.b[o]);  // EP_DS: alpha * dot (no bias), then the folded BatchNorm
+    }
+    resv[j] = r;
+  }
+}
+template <int NACC>
+__device__ __forceinline__ void shortcut_values(const Geo& g, int o0, const ShortcutArgs& d, const uint32_t (&dsr)[8],
+                                                int nz, float (&resv)[NACC]) {
+  if (g.ds_cw == 2) shortcut_values_cw<NACC, 2>(g, o0, d, dsr, nz, resv);
+  else if (g.ds_cw == 4) shortcut_values_cw<NACC, 4>(g, o0, d, dsr, nz, resv);
+  else shortcut_values_cw<NACC, 8>(g, o0, d, dsr, nz, resv);
+}
+
 // ---------------------------------------------------------------------------------
 // Tiled kernel, weights streamed through SGPRs (scalar cache).  Best when all waves in
 // flight share one small weight block (large images, few output channels): BASELINE config 2.
@@ -825,7 +886,7 @@ inline Geo make_geo(const ConvP& p) {
   if (p.bias) f |= EF_BIAS;
   if (p.scale) f |= EF_SCALE;
   if (p.bn_a && p.bn_b) f |= EF_BN;
-  if (p.res) f |= EF_RES;
+  if (p.res || p.ds_P) f |= EF_RES;  // (a folded shortcut convolution supplies the residual in registers)
   if (p.relu) f |= EF_RELU;
   if (p.prelu) f |= EF_PRELU;
   if (p.out) f |= EF_OUTF;
@@ -834,6 +895,7 @@ inline Geo make_geo(const ConvP& p) {
   if (p.res && (p.eflags & BNN_HIP_EPI_RES_AFTER_ACT) && (p.eflags & BNN_HIP_EPI_PACK_BEFORE_RES)) f |= EF_PACK_PRE;
   if (p.pack_a && p.pack_b) f |= EF_PACK_AFF;
   if (p.eflags & BNN_HIP_EPI_PACK_RELU) f |= EF_PACK_RELU;
+  g.ds_cw = p.ds_P ? 2 * ((p.ds_C + 63) / 64) : 0;
   g.c_off = p.c_off;
   g.c_tot = p.c_tot > 0 ? p.c_tot : p.O;
   g.flags = f;

@@ -75,6 +75,14 @@ struct ConvP {
   int cw32, cwc, nchunk;
   int npix;  // N*Ho*Wo
   int C;     // input channels
+  // shortcut convolution folded into this one (bconv_core.h ShortcutArgs): 1x1 / stride 1 over ds_C channels at the
+  // OUTPUT resolution, P plane only; null = none
+  const uint32_t* ds_P;
+  const uint32_t* ds_W;
+  const float* ds_alpha;
+  const float* ds_a;
+  const float* ds_b;
+  int ds_C;
 };
 
 // Compute units of the current device (for grids of persistent workgroups).  Cached per device in atomics: a
@@ -129,6 +137,7 @@ int launch_wgrad(const float* g, const float* xin, float* part, int splits, int 
 int launch_pack_weight(const float* w, int O, int C, int KH, int KW, int center, int compute_alpha,
                        const bnn_hip_wlayout& L, uint32_t* wbits, uint32_t* wnz, float* alpha,
                        int32_t* zero_flag, hipStream_t stream);
+bool ds_fold_applies(const ConvP& p, int flags);
 int launch_bconv(const ConvP& p, int flags, hipStream_t s);
 // bconv_fly.hip: the whole layer in one launch, activations (fp32, or fp16 when x_half) binarised on the fly into LDS.
 // p.P / p.M are unused; p.alpha / bias / scale / out as for launch_bconv.  `plan` may be null (default plan).

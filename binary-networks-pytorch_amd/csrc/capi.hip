@@ -69,6 +69,11 @@ int run_conv(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M, c
   p.cw32 = L.cw32; p.cwc = L.cwc; p.nchunk = L.nchunk;
   p.npix = d->N * Ho * Wo;
   p.C = d->C;
+  if (p.ds_P) {  // folded shortcut convolution (bnn_hip_epilogue sc_*)
+    if (!p.ds_W || !p.ds_alpha || !p.ds_a || !p.ds_b || p.res || p.ds_C <= 0) return BNN_HIP_ERR_INVALID_ARG;
+    if (!aligned(p.ds_P, 8) || !aligned(p.ds_W, 16)) return BNN_HIP_ERR_INVALID_ARG;
+    if (!bnn::ds_fold_applies(p, d->flags)) return BNN_HIP_ERR_UNSUPPORTED;
+  }
   g_launches.fetch_add(1, std::memory_order_relaxed);
   return bnn::launch_bconv(p, d->flags, static_cast<hipStream_t>(stream));
 }
@@ -308,7 +313,33 @@ int bnn_hip_bconv2d_fused(const bnn_hip_conv_desc* d, const uint64_t* P, const u
   if (p.thr && !aligned(p.thr, 4)) return BNN_HIP_ERR_INVALID_ARG;
   p.eflags = e->flags;
   p.c_off = e->out_c_offset; p.c_tot = e->out_c_total;
+  if (e->sc_P || e->sc_wbits || e->sc_alpha || e->sc_bn_scale || e->sc_bn_shift) {
+    if (!e->sc_P) return BNN_HIP_ERR_INVALID_ARG;
+    p.ds_P = reinterpret_cast<const uint32_t*>(e->sc_P);
+    p.ds_W = e->sc_wbits; p.ds_alpha = e->sc_alpha; p.ds_a = e->sc_bn_scale; p.ds_b = e->sc_bn_shift;
+    p.ds_C = e->sc_C;
+  }
   return run_conv(d, P, M, wbits, wnz, p, stream);
+}
+
+int bnn_hip_shortcut_fold_supported(const bnn_hip_conv_desc* d, int sc_C) {
+  int Ho = 0, Wo = 0;
+  if (check_desc(d, &Ho, &Wo) != BNN_HIP_OK) return 0;
+  bnn::ConvP p = empty_convp();
+  bnn_hip_wlayout L;
+  bnn_hip_weight_layout(d->O, d->C, d->KH, d->KW, &L);
+  p.N = d->N; p.H = d->H; p.Wd = d->W; p.Ho = Ho; p.Wo = Wo; p.O = d->O; p.C = d->C;
+  p.KH = d->KH; p.KW = d->KW; p.sh = d->stride_h; p.sw = d->stride_w;
+  p.ph = d->pad_h; p.pw = d->pad_w; p.dh = d->dil_h; p.dw = d->dil_w;
+  p.cw32 = L.cw32; p.cwc = L.cwc; p.nchunk = L.nchunk;
+  p.npix = d->N * Ho * Wo;
+  p.c_off = 0; p.c_tot = d->O;
+  // the epilogue the fold belongs to: BatchNorm + shortcut + ReLU -> fp32 + sign planes (any non-null pointers)
+  const float* f = reinterpret_cast<const float*>(&p);
+  p.alpha = f; p.bn_a = f; p.bn_b = f; p.relu = true; p.out = &p;
+  p.outP = reinterpret_cast<uint32_t*>(&p); p.outM = reinterpret_cast<uint32_t*>(&p);
+  p.ds_C = sc_C;
+  return bnn::ds_fold_applies(p, d->flags) ? 1 : 0;
 }
 
 int bnn_hip_sign_thresholds_f32(const float* alpha, const float* bias, const float* post_scale, const float* bn_scale,

@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 10
+#define BNN_HIP_ABI_VERSION 11
 #define BNN_HIP_OCB 32 /* output channels per weight block (padding granularity of O) */
 
 typedef enum bnn_hip_status {
@@ -146,6 +146,22 @@ typedef struct bnn_hip_epilogue {
                                      scale, residual, fp32 output): the sign bit then comes from an integer compare
                                      of the dot — same bits as the float path, fewer instructions.  Ignored
                                      otherwise.                                                          */
+  /* ABI 11 — the shortcut branch of a down-sampling residual block folded into the block's second convolution
+   * (bnn/models/layers/res_block.py:31-37,52-54: AvgPool2d(2) -> Conv2d 1x1 -> BatchNorm, added before the last ReLU):
+   *     residual[n,o,y,x] = fmaf(fmaf(sc_alpha[o], dot1x1(sc_P[n,:,y,x], sc_wbits[o]), 0), sc_bn_scale[o], sc_bn_shift[o])
+   * is computed inside the kernel with the float operations of the stand-alone 1x1 convolution + BN epilogue (same
+   * bits), instead of being written to and read back from an fp32 tensor.  sc_P: sign plane P of the 1x1 conv's
+   * input at the OUTPUT resolution, [N, ceil(sc_C/64), Ho, Wo] uint64, non-negative activations (its M plane is all
+   * zero and not passed); sc_wbits / sc_alpha: bnn_hip_pack_weight_f32 of the [O, sc_C, 1, 1] weight.  Either all five
+   * pointers or none (then sc_C is ignored); not together with `residual`.  Supported where
+   * bnn_hip_shortcut_fold_supported() says so; BNN_HIP_ERR_UNSUPPORTED otherwise.                                    */
+  const uint64_t* sc_P;
+  const uint32_t* sc_wbits;
+  const float* sc_alpha;
+  const float* sc_bn_scale;
+  const float* sc_bn_shift;
+  int32_t sc_C;
+  int32_t reserved;
 } bnn_hip_epilogue;
 
 /* Per channel the integer dots (|dot| <= kmax = C*KH*KW) whose epilogue value
@@ -320,6 +336,11 @@ int bnn_hip_bconv2d_fused(const bnn_hip_conv_desc* d,
                           const uint64_t* P, const uint64_t* M,
                           const uint32_t* wbits, const uint32_t* wnz,
                           const bnn_hip_epilogue* epi, void* stream);
+
+/* HOST: 1 when bnn_hip_bconv2d_fused() takes a folded shortcut convolution of sc_C input channels (bnn_hip_epilogue
+ * sc_*) for this convolution — 3x3 tiled kernels on non-negative activations (BNN_HIP_FLAG_ACT_NONNEG) without zero
+ * weights, epilogue = BatchNorm + shortcut + ReLU -> fp32 + sign planes, sc_C in {64, 128, 256}; 0 otherwise.       */
+int bnn_hip_shortcut_fold_supported(const bnn_hip_conv_desc* d, int sc_C);
 
 /* Same traversal, raw integer result: dot[n,o,y,x] (int32) — the bit-exact target
  * of the popcount path against the emulated-integer oracle.                        */

@@ -582,10 +582,59 @@ def test_fused_executor_uses_the_head_kernel_and_no_library_gemm():
     x = dev(gen.normal(31, (4, 3, 64, 64)))
     before = native.launch_count()
     y = fused(x)
-    # stem + 16 convs + 3 shortcut convs + 3 OR-pools of sign planes + head
-    assert native.launch_count() - before == 1 + 16 + 3 + 3 + 1
+    # stem + 16 convs (the 3 shortcut convs folded into the last conv of their block) + 3 OR-pools of sign planes + head
+    assert native.launch_count() - before == 1 + 16 + 3 + 1
+    unfolded = FusedResNet(net, fold_shortcut=False)    # (building an executor packs the weights: launches too)
+    before = native.launch_count()
+    y2 = unfolded(x)
+    assert native.launch_count() - before == 1 + 16 + 3 + 3 + 1    # + 3 shortcut convs as launches of their own
+    assert torch.equal(y, y2)
     with torch.no_grad():
         assert torch.allclose(y, net(x), rtol=1e-3, atol=1e-3 * float(y.abs().max()))
+
+
+@pytest.mark.parametrize("throughput", [False, True], ids=["latency", "throughput"])
+@pytest.mark.parametrize("shape", [(3, 64, 128, 29, 27), (2, 128, 256, 14, 14), (2, 256, 512, 7, 7), (1, 64, 96, 9, 11),
+                                   (70, 128, 256, 14, 14)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_folded_shortcut_conv_equals_the_two_launch_form(shape, throughput):
+    """bnn_hip_epilogue.sc_* (ABI 11): the residual of a down-sampling block's last conv computed in the kernel from the
+    OR-pooled sign planes and the packed 1x1 weight — against the stand-alone 1x1 conv + BN launch whose fp32 output
+    is then read as `residual`.  Same float operations: every fp32 value and every sign bit equal.  Shapes: the three
+    ResNet-18 stages (single-chunk, two and four chunks; 64 / 128 / 256 shortcut channels), an output-channel tail
+    (96 = 3 blocks), a batch with more waves than the block split takes."""
+    N, Cs, O, H, W = shape
+    c_mid = O                                   # conv2 of a BasicBlock: O -> O
+    a2 = hipops.pack_act(dev(gen.activation("relu", gen.seed_of("fold", shape), (N, c_mid, H, W)))); a2.nonneg = True
+    sc = hipops.pack_act(dev(gen.activation("relu", gen.seed_of("fold", shape) + 1, (N, Cs, H, W)))); sc.nonneg = True
+    w2 = hipops.pack_weight(dev(gen.conv_weight("kaiming", 21, (O, c_mid, 3, 3))))
+    ws = hipops.pack_weight(dev(gen.conv_weight("kaiming", 22, (O, Cs, 1, 1))))
+    bn = lambda s: (dev((0.5 + gen.uniform(s, (O,))).astype(np.float32) * np.where(np.arange(O) % 5 == 0, -1, 1).astype(np.float32)),
+                    dev((0.3 * gen.normal(s + 1, (O,))).astype(np.float32)))
+    (a2s, b2s), (ass, bss) = bn(31), bn(41)
+    assert hipops.shortcut_fold_supported(a2, w2, Cs, 1, 1, 1, throughput=throughput)
+    idn, _ = hipops.bconv2d_fused(sc, ws, bn_scale=ass, bn_shift=bss, out_f32=True, out_packed=False)
+    kw = dict(bn_scale=a2s, bn_shift=b2s, relu=True, stride=1, padding=1, out_f32=True, out_packed=True,
+              throughput=throughput)
+    y0, p0 = hipops.bconv2d_fused(a2, w2, residual=idn, **kw)
+    y1, p1 = hipops.bconv2d_fused(a2, w2, shortcut=(sc, ws, ass, bss), **kw)
+    assert torch.equal(y0, y1) and torch.equal(p0.P, p1.P) and torch.equal(p0.M, p1.M) and p1.nonneg
+
+
+def test_folded_shortcut_is_refused_where_no_kernel_takes_it():
+    a = hipops.pack_act(dev(gen.activation("normal", 3, (2, 64, 12, 12))))          # signed activations: two planes
+    sc = hipops.pack_act(dev(gen.activation("relu", 4, (2, 64, 12, 12)))); sc.nonneg = True
+    w2 = hipops.pack_weight(dev(gen.conv_weight("kaiming", 21, (64, 64, 3, 3))))
+    ws = hipops.pack_weight(dev(gen.conv_weight("kaiming", 22, (64, 64, 1, 1))))
+    one = dev(np.ones(64, np.float32))
+    assert not hipops.shortcut_fold_supported(a, w2, 64, 1, 1, 1)
+    with pytest.raises(native.NativeError):
+        hipops.bconv2d_fused(a, w2, bn_scale=one, bn_shift=one, relu=True, stride=1, padding=1, out_f32=True,
+                             out_packed=True, shortcut=(sc, ws, one, one))
+    a.nonneg = True                                                                    # (a promise; relu-free data)
+    w1 = hipops.pack_weight(dev(gen.conv_weight("kaiming", 23, (64, 64, 1, 1))))
+    assert not hipops.shortcut_fold_supported(a, w1, 64, 1, 0, 1)                      # a 1x1 last conv (Bottleneck)
+    assert not hipops.shortcut_fold_supported(a, w2, 96, 1, 1, 1)                      # 96 shortcut channels
 
 
 def test_dead_fp32_outputs_are_not_written_and_nothing_changes():
