@@ -45,17 +45,17 @@ sagg = collections.defaultdict(list)
 sdur = []
 for f in glob.glob(os.path.join(src, "stem_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "stem_split_kernel" in r["Kernel_Name"]:
+        if "stem_rows_kernel" in r["Kernel_Name"]:
             sagg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob(os.path.join(src, "stem_a", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "stem_split_kernel" in r["Kernel_Name"]:
+        if "stem_rows_kernel" in r["Kernel_Name"]:
             sdur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 if sagg:
     stem = {c: int(round(sum(v) / len(v))) for c, v in sorted(sagg.items())}
     if sdur:
         stem["avg_duration_us_profiled"] = round(sum(sdur) / len(sdur), 1)
-    stem["kernel"] = "bnn::stem_split_kernel<false>, batch 256, 224x224, fp32 + sign planes out (tools/bench_stem.py)"
+    stem["kernel"] = "bnn::stem_rows_kernel<false>, batch 256, 224x224, fp32 + sign planes out (tools/bench_stem.py)"
     stem["provenance"] = STAMP
     json.dump(stem, open(os.path.join(dst, f"{tag}_stem_pmc.json"), "w"), indent=1, sort_keys=True)
 
