@@ -51,6 +51,53 @@ def test_host_only_entry_points():
     assert lib.bnn_hip_weight_layout(3, 3, 1, 1, None) == -1
 
 
+def test_ctypes_structs_have_the_layout_of_the_c_header(tmp_path):
+    """The structs bnn_amd/native.py mirrors (bnn_hip_conv_desc, bnn_hip_epilogue, bnn_hip_wlayout, bnn_hip_fly_plan)
+    against sizeof / offsetof of include/bnn_hip.h as gcc sees it: a field added on one side only (the epilogue grew
+    by the folded-shortcut fields in ABI 11) would otherwise shift every pointer behind it silently."""
+    import subprocess
+    structs = {"bnn_hip_conv_desc": native.ConvDesc, "bnn_hip_epilogue": native.Epilogue,
+               "bnn_hip_wlayout": native.WLayout, "bnn_hip_fly_plan": native.FlyPlan}
+    lines = []
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "bnn_hip.h"\nint main(void) {\n%s\nreturn 0; }\n'
+                   % "\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_shortcut_fold_query_is_a_host_function():
+    """bnn_hip_shortcut_fold_supported (ABI 11): 3x3 tiled kernels on non-negative activations, 64 / 128 / 256 shortcut
+    channels — answered without a GPU."""
+    lib = native.require()
+    nn = native.FLAG_ACT_NONNEG
+    d = native.ConvDesc(256, 128, 28, 28, 128, 3, 3, 1, 1, 1, 1, 1, 1, nn)
+    assert lib.bnn_hip_shortcut_fold_supported(ctypes.byref(d), 64) == 1
+    assert lib.bnn_hip_shortcut_fold_supported(ctypes.byref(d), 96) == 0          # not a supported channel count
+    d.flags = 0
+    assert lib.bnn_hip_shortcut_fold_supported(ctypes.byref(d), 64) == 0          # two-plane activations
+    d.flags = nn | native.FLAG_WEIGHT_ZEROS
+    assert lib.bnn_hip_shortcut_fold_supported(ctypes.byref(d), 64) == 0
+    d1 = native.ConvDesc(256, 128, 28, 28, 128, 1, 1, 1, 1, 0, 0, 1, 1, nn)
+    assert lib.bnn_hip_shortcut_fold_supported(ctypes.byref(d1), 64) == 0         # a 1x1 last conv (Bottleneck)
+    d5 = native.ConvDesc(2, 512, 7, 7, 512, 3, 3, 1, 1, 1, 1, 1, 1, nn)
+    assert lib.bnn_hip_shortcut_fold_supported(ctypes.byref(d5), 256) == 1        # multi-chunk layer
+    assert lib.bnn_hip_shortcut_fold_supported(None, 64) == 0
+    # the epilogue's shortcut fields are all-or-nothing, and exclusive with `residual`
+    e = native.Epilogue()
+    e.alpha = 16; e.out_f32 = 16; e.sc_wbits = 16
+    assert lib.bnn_hip_bconv2d_fused(ctypes.byref(d), 16, 16, 16, 16, ctypes.byref(e), None) == -1
+
+
 def test_argument_validation_without_touching_the_gpu():
     lib = native.require()
     d = native.ConvDesc(1, 64, 8, 8, 32, 3, 3, 1, 1, 1, 1, 1, 1, 0)
