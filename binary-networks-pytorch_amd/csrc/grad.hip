@@ -34,7 +34,7 @@
 // its MFMA work multiplies zeros).  1x1 / stride 1 convolutions (the shortcut branches behind an AvgPool:
 // 0.4 % of a ResNet-18's MACs) are the same kernels with one tap and no halo; the weight-gradient kernel then
 // takes 128 input channels per workgroup instead of 32 so that a wave still has 8 accumulator tiles per g fragment.
-#include "bnn_dev.h"
+#include "bconv_core.h"  // buffer-descriptor helpers
 
 namespace bnn {
 
@@ -66,6 +66,8 @@ struct GradGeo {
   int R;         // image rows a chunk advances by = min(RR, H)
   int chunks;    // chunks per image = ceil(H / R)
   int gshift;    // log2(slot / 8): 8-pixel groups per row slot
+  unsigned g_bytes;  // bytes of the gradient tensor g (the range of its buffer descriptor)
+  unsigned x_bytes;  // bytes of x / gx
 };
 
 // v = hi + mid + lo (+ at most 2^-24 |v|): each term the TRUNCATION of what is left to bf16 (the remainders are exact
@@ -145,7 +147,9 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
   u16* pa_lo = pa_mid + (size_t)PP * APIX;
   float* stage = reinterpret_cast<float*>(lds_raw);  // reused after the K loop
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (wave index through readfirstlane: what depends on it — channel group, alpha, plane offsets — is then wave-uniform
+  // for the compiler too: scalar registers and scalar loads instead of per-lane copies and waterfall loops)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int n = blockIdx.x / q.chunks, y0 = (blockIdx.x - n * q.chunks) * q.R;
   const int HW = q.H * q.W, HGg = q.Hg * q.Wg;
@@ -168,42 +172,78 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) acc[s][ns] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // ---- fill roles, once per workgroup: wave w fills output channels 8 w .. 8 w + 7 of every 32-channel block (wave-
+  // uniform: alpha and the channel's plane offset are scalar), lane l the patch pixels l, l + 64, ...  The pixel's byte
+  // offset inside a channel plane of g (or "out of range": halo outside the image, odd positions of a zero-upsampled
+  // stride-2 gradient) and its LDS address do not depend on the block: no address arithmetic in the K loop, the eight
+  // loads of an item are buffer loads with a scalar plane offset (round 2/3a: ~60 VALU instructions of index arithmetic
+  // and selects per item, the bulk of the kernel's instructions).
+  constexpr int FK = 4;  // 64-pixel sweeps over the patch: (R + 2) (W + 2) <= 198
+  const BufRsrc r_g = make_rsrc_sized(g, q.g_bytes);
+  unsigned fvoff[FK];
+  int flds[FK];
+#pragma unroll
+  for (int k = 0; k < FK; ++k) {
+    const int pix = lane + 64 * k;
+    const int pr = pix / PW, pc = pix - pr * PW;
+    const int y = y0 - PD + pr, x = pc - PD;
+    // stride 2: g zero-upsampled — only even (y, x) carry a value, g[y/2][x/2]
+    const int yg = q.st == 2 ? y >> 1 : y, xg = q.st == 2 ? x >> 1 : x;
+    const bool in = pix < PP && y >= 0 && x >= 0 && yg < q.Hg && xg < q.Wg && (q.st == 1 || ((y | x) & 1) == 0);
+    fvoff[k] = in ? (unsigned)(yg * q.Wg + xg) * 4u : 0xFFFFFFF0u;
+    flds[k] = pix < PP ? pix * APIX + 8 * wave : -1;
+  }
+  const unsigned plane4 = (unsigned)HGg * 4u;
+
   for (int ob = 0; ob < OB; ++ob) {
     __syncthreads();  // previous block's patch is consumed
-    // ---- fill: item = (patch pixel, group of 8 output channels); 8 loads (coalesced along x across lanes)
-    for (int item = tid; item < PP * 4; item += NT) {
-      const int pix = item % PP, og = item / PP;
-      const int pr = pix / PW, pc = pix - pr * PW;
-      const int y = y0 - PD + pr, x = pc - PD;
-      // stride 2: g zero-upsampled — only even (y, x) carry a value, g[y/2][x/2]
-      const int yg = q.st == 2 ? y >> 1 : y, xg = q.st == 2 ? x >> 1 : x;
-      const bool in = y >= 0 && x >= 0 && yg < q.Hg && xg < q.Wg && (q.st == 1 || ((y | x) & 1) == 0);
+    auto load_w = [&](half8 (&dst)[NSUB], int tap) {
+#pragma unroll
+      for (int ns = 0; ns < NSUB; ++ns) {
+        const int cs = cs0 + ns;
+        dst[ns] = cs < CS ? Bp[((size_t)(ob * T + tap) * CS + cs) * 64 + lane] : bf16_const8(0);
+      }
+    };
+    half8 b[NSUB];
+    load_w(b, 0);
+    const int o0 = 32 * ob + 8 * wave;
+    float av[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) av[e] = o0 + e < q.O ? alpha[o0 + e] : 0.0f;
+    // (all sweeps' loads up front — one round trip per block instead of one per sweep — measured 2-5 % slower: the dead
+    // sweeps of the small patches then issue loads too)
+#pragma unroll
+    for (int k = 0; k < FK; ++k) {
+      if (64 * k >= PP) break;  // workgroup-uniform
       float v[8];
+      unsigned soff = (unsigned)(n * q.O + o0) * plane4;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int o = 32 * ob + 8 * og + e;
-        const bool ok = in && o < q.O;
-        const float gv = g[ok ? ((size_t)n * q.O + o) * HGg + yg * q.Wg + xg : 0];
-        const float av = alpha[ok ? o : 0];
-        v[e] = ok ? gv * av : 0.0f;
+        // channels past O: an out-of-range offset reads 0 (a select, not a branch: behind a branch every load is
+        // waited for before the next one is issued)
+        const unsigned vo = o0 + e < q.O ? fvoff[k] : 0xFFFFFFF0u;
+        v[e] = buf_ld(r_g, vo, o0 + e < q.O ? soff : 0u) * av[e];
+        soff += plane4;
       }
       half8 hi, mid, lo;
       split8(v, hi, mid, lo);
-      *reinterpret_cast<half8*>(pa_hi + pix * APIX + 8 * og) = hi;
-      *reinterpret_cast<half8*>(pa_mid + pix * APIX + 8 * og) = mid;
-      *reinterpret_cast<half8*>(pa_lo + pix * APIX + 8 * og) = lo;
+      if (flds[k] >= 0) {
+        *reinterpret_cast<half8*>(pa_hi + flds[k]) = hi;
+        *reinterpret_cast<half8*>(pa_mid + flds[k]) = mid;
+        *reinterpret_cast<half8*>(pa_lo + flds[k]) = lo;
+      }
     }
     __syncthreads();
 #pragma unroll 1
     for (int tap = 0; tap < T; ++tap) {
       const int ky = tap / KS, kx = tap - ky * KS;
       const int toff = (ky * PW + kx) * APIX;
-      half8 b[NSUB];
+      // the NEXT tap's sign(W) fragments are requested before this tap's MFMAs (tap 0's before the fill): a load in
+      // front of its own MFMAs exposed one L2 round trip per tap, 18 per workgroup at 64 channels
+      half8 bn[NSUB];
 #pragma unroll
-      for (int ns = 0; ns < NSUB; ++ns) {
-        const int cs = cs0 + ns;
-        b[ns] = cs < CS ? Bp[((size_t)(ob * T + tap) * CS + cs) * 64 + lane] : bf16_const8(0);
-      }
+      for (int ns = 0; ns < NSUB; ++ns) bn[ns] = b[ns];
+      if (tap + 1 < T) load_w(bn, tap + 1);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const half8 ah = *reinterpret_cast<const half8*>(pa_hi + abase[s] - toff);
@@ -216,6 +256,8 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
           acc[s][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[ns], acc[s][ns], 0, 0, 0);
         }
       }
+#pragma unroll
+      for (int ns = 0; ns < NSUB; ++ns) b[ns] = bn[ns];
     }
   }
   __syncthreads();  // the patch is dead: its LDS becomes the [channel][pixel] staging tile
@@ -228,16 +270,33 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
       for (int r = 0; r < 4; ++r)
         stage[((wave * NSUB + ns) * 16 + li) * SROW + 16 * s + 4 * lg + r] = acc[s][ns][r];
   __syncthreads();
+  // A thread keeps ONE pixel of the chunk (its lane) and walks the channels wave, wave + 4, ...: the STE operand x of
+  // all its 16 NSUB outputs is requested first (buffer loads: a dead pixel / channel is an out-of-range offset, the
+  // plane offset is scalar), then the values leave — as a guarded load + store per iteration the loop paid one HBM
+  // round trip per channel, 16 or 32 in a row (most of the kernel's time on the 56 x 56 layers).
   const int c_blk = blockIdx.y * 64 * NSUB;
-  for (int item = tid; item < 64 * NSUB * 64; item += NT) {
-    const int m = item & 63, cl = item >> 6;
-    const int ry = m / q.slot, x = m - ry * q.slot;
-    const int c = c_blk + cl, y = y0 + ry;
-    if (x < q.W && ry < q.R && y < q.H && c < q.C) {
-      const size_t o = ((size_t)n * q.C + c) * HW + y * q.W + x;
-      const float v = stage[cl * SROW + m];
-      gx[o] = fabsf(xin[o]) < 1.0f ? v : 0.0f;  // hard-tanh straight-through estimator (NaN x -> 0, like masked_fill)
-    }
+  constexpr int IT = 16 * NSUB;
+  const int ery = lane >> (q.gshift + 3), ex = lane & (q.slot - 1);
+  const bool elive = ex < q.W && ery < q.R && y0 + ery < q.H;
+  const unsigned elane = elive ? (unsigned)((y0 + ery) * q.W + ex) * 4u : 0xFFFFFFF0u;
+  const BufRsrc r_x = make_rsrc_sized(xin, q.x_bytes);
+  [[maybe_unused]] const BufRsrc r_gx = make_rsrc_sized(gx, q.x_bytes);
+  const unsigned xplane4 = (unsigned)HW * 4u;
+  float xv[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = c_blk + wave + 4 * i;  // wave-uniform
+    xv[i] = buf_ld(r_x, c < q.C ? elane : 0xFFFFFFF0u, c < q.C ? (unsigned)(n * q.C + c) * xplane4 : 0u);
+  }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    [[maybe_unused]] const int c = c_blk + wave + 4 * i;
+    const float v = stage[(wave + 4 * i) * SROW + lane];
+    [[maybe_unused]] const float r = fabsf(xv[i]) < 1.0f ? v : 0.0f;  // hard-tanh STE (NaN x -> 0, like masked_fill)
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), r_gx, (int)(c < q.C ? elane : 0xFFFFFFF0u),
+                                          (int)(c < q.C ? (unsigned)(n * q.C + c) * xplane4 : 0u), 0);
+#endif
   }
 }
 
@@ -380,6 +439,10 @@ static bool make_geo(int N, int O, int C, int Hx, int Wx, int st, bool dgrad, Gr
   q->chunks = (q->H + q->R - 1) / q->R;
   q->gshift = 0;
   while ((8 << q->gshift) < slot) ++q->gshift;
+  const unsigned long long gb = (unsigned long long)N * O * q->Hg * q->Wg * 4ull;
+  q->g_bytes = gb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)gb;  // capi.hip keeps every tensor at 2^32 bytes or less
+  const unsigned long long xb = (unsigned long long)N * C * Hx * Wx * 4ull;
+  q->x_bytes = xb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)xb;
   return true;
 }
 
