@@ -344,49 +344,89 @@ __global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict
     b_off[ks] = (li * BR + ST * ry) * BROW + xg;  // + (sub * 16 * BR + ky) * BROW + kx * bplane per sub-tile
   }
 
+  // ---- fill roles, once per workgroup.  Every item a thread fills keeps its place in the tile for all chunks: its byte
+  // offset inside the (image, first channel, first row) block of the tensor and its LDS address are computed HERE; per
+  // chunk a wave-uniform offset moves the block, rows outside the image become out-of-range offsets (which read 0), and
+  // the loads are buffer loads with immediate element offsets — no index arithmetic per element in the chunk loop
+  // (round 2/3a: 64-bit address + select per element, ~20 VALU instructions per loaded element).
+  const BufRsrc r_g = make_rsrc_sized(g, q.g_bytes), r_x = make_rsrc_sized(xin, q.x_bytes);
+  constexpr unsigned kOOB = 0xFFFFFF00u;  // +- a few elements stays out of range (make_geo keeps the tensors below it)
+  // g: 64 channels x 8 groups of 8 k-slots = 512 items; thread t: group t & 7 of channels t >> 3 and (t >> 3) + 32
+  const int g8 = tid & 7, gry = g8 >> q.gshift, gj = g8 & (groups - 1);
+  const int g_nv = q.W - 8 * gj;  // elements of the group inside the row (>= 8: all)
+  unsigned goff[2];
+  int glds[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ol = (tid >> 3) + 32 * i;
+    const bool fix = o0 + ol < q.O && gry < q.R && g_nv > 0;
+    goff[i] = fix ? (unsigned)(ol * HW + gry * q.W + 8 * gj) * 4u : kOOB;
+    glds[i] = ol * AROW + 8 * g8;
+  }
+  // sign(x): (channel, row, 8-pixel group) items, at most four per thread; NE values x[ST*8j - PD .. ] per item
+  constexpr int SI = 4, NE = 8 * ST + 2 * PD;
+  const int sx_items = 16 * NC * BR * groups;
+  int xbase[SI], xlds[SI], xpr[SI], x_nv[SI];
+  bool xfirst[SI];
+#pragma unroll
+  for (int i = 0; i < SI; ++i) {
+    const int item = tid + NT * i;
+    const int j = item & (groups - 1), t = item >> q.gshift;
+    const int cl = t / BR, pr = t - cl * BR;
+    const bool fix = item < sx_items && c0 + cl < q.C;
+    xpr[i] = fix ? pr : -0x40000000;                          // (a row that is never inside the image)
+    xbase[i] = (cl * HWx + pr * q.Wx + ST * 8 * j) * 4;     // element PD of the item: x = ST*8j
+    x_nv[i] = q.Wx - (ST * 8 * j - PD);                       // elements e < x_nv lie left of the row's end
+    xfirst[i] = j == 0;                                       // element 0 is x = -1: zero padding
+    xlds[i] = item < sx_items ? (cl * BR + pr) * BROW + 8 * j : -1;
+  }
+
   for (int n = n_begin; n < n_end; ++n) {
     for (int y0 = 0; y0 < q.H; y0 += q.R) {
       __syncthreads();
       // ---- g rows y0 .. y0+R-1 of 64 output channels
-      for (int item = tid; item < 64 * 8; item += NT) {   // 64 channels x 8 groups of 8 k-slots
-        const int g8 = item & 7, ol = item >> 3;
-        const int ry = g8 >> q.gshift, j = g8 & (groups - 1);
-        const int o = o0 + ol, y = y0 + ry;
-        const bool rowok = o < q.O && ry < q.R && y < q.H;
+      const unsigned g_soff = (unsigned)((n * q.O + o0) * HW + y0 * q.W) * 4u;
+      const bool g_row = y0 + gry < q.H;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned vo = g_row ? goff[i] : kOOB;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int x = 8 * j + e;
-          const bool ok = rowok && x < q.W;
-          const float gv = g[ok ? ((size_t)n * q.O + o) * HW + y * q.W + x : 0];
-          v[e] = ok ? gv : 0.0f;
+          const float gv = buf_ld(r_g, vo + 4u * e, g_soff);
+          v[e] = e < g_nv ? gv : 0.0f;  // (past the row's end the next row would be read)
         }
         half8 hi, mid, lo;
         split8(v, hi, mid, lo);
-        *reinterpret_cast<half8*>(a_hi + ol * AROW + 8 * g8) = hi;
-        *reinterpret_cast<half8*>(a_mid + ol * AROW + 8 * g8) = mid;
-        *reinterpret_cast<half8*>(a_lo + ol * AROW + 8 * g8) = lo;
+        *reinterpret_cast<half8*>(a_hi + glds[i]) = hi;
+        *reinterpret_cast<half8*>(a_mid + glds[i]) = mid;
+        *reinterpret_cast<half8*>(a_lo + glds[i]) = lo;
       }
       // ---- sign(x) rows ST*y0-PD .. of 16 NC input channels, KS copies: copy kx holds sx[ST*p + kx - PD] at slot p
-      for (int item = tid; item < 16 * NC * BR * groups; item += NT) {
-        const int j = item & (groups - 1), t = item >> q.gshift;
-        const int cl = t / BR, pr = t - cl * BR;
-        const int c = c0 + cl, y = ST * y0 - PD + pr;
-        const bool rowok = c < q.C && (unsigned)y < (unsigned)q.Hx;
-        u16 s[8 * ST + 2 * PD];  // sx[ST*8j-PD .. ST*(8j+7)+PD]
+      const unsigned x_soff = (unsigned)((n * q.C + c0) * HWx) * 4u;
+      const int yrow = ST * y0 - PD, x_row4 = yrow * q.Wx * 4;
 #pragma unroll
-        for (int e = 0; e < 8 * ST + 2 * PD; ++e) {
-          const int x = ST * 8 * j - PD + e;
-          const bool ok = rowok && (unsigned)x < (unsigned)q.Wx;
-          const float xv = xin[ok ? ((size_t)n * q.C + c) * HWx + y * q.Wx + x : 0];
-          s[e] = (ok && xv > 0.0f) ? kBf16One : (ok && xv < 0.0f) ? kBf16MinusOne : (unsigned short)0;
+      for (int i = 0; i < SI; ++i) {
+        if (NT * i >= sx_items) break;  // workgroup-uniform
+        const bool rowok = (unsigned)(yrow + xpr[i]) < (unsigned)q.Hx;
+        const unsigned vo = rowok ? (unsigned)(xbase[i] + x_row4) : kOOB;
+        u16 s[NE];  // sx[ST*8j-PD .. ST*(8j+7)+PD]
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          // element e sits (e - PD) floats from the item's base; the one left of a row's first pixel is padding
+          const unsigned ve = e < PD ? (xfirst[i] ? kOOB : vo - 4u * (PD - e)) : vo + 4u * (e - PD);
+          float xv = buf_ld(r_x, ve, x_soff);
+          xv = e < x_nv[i] ? xv : 0.0f;
+          s[e] = xv > 0.0f ? kBf16One : xv < 0.0f ? kBf16MinusOne : (unsigned short)0;
         }
+        if (xlds[i] >= 0) {
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-          u32x4 hv;
+          for (int kx = 0; kx < KS; ++kx) {
+            u32x4 hv;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) hv[e] = (unsigned)s[ST * (2 * e) + kx] | ((unsigned)s[ST * (2 * e + 1) + kx] << 16);
-          *reinterpret_cast<u32x4*>(bsx + kx * bplane + (cl * BR + pr) * BROW + 8 * j) = hv;
+            for (int e = 0; e < 4; ++e) hv[e] = (unsigned)s[ST * (2 * e) + kx] | ((unsigned)s[ST * (2 * e + 1) + kx] << 16);
+            *reinterpret_cast<u32x4*>(bsx + kx * bplane + xlds[i] + 0) = hv;
+          }
         }
       }
       __syncthreads();
@@ -439,10 +479,12 @@ static bool make_geo(int N, int O, int C, int Hx, int Wx, int st, bool dgrad, Gr
   q->chunks = (q->H + q->R - 1) / q->R;
   q->gshift = 0;
   while ((8 << q->gshift) < slot) ++q->gshift;
+  // the kernels address g, x and gx through 32-bit buffer offsets and mark dead elements with offsets >= 0xFFFFFE00
   const unsigned long long gb = (unsigned long long)N * O * q->Hg * q->Wg * 4ull;
-  q->g_bytes = gb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)gb;  // capi.hip keeps every tensor at 2^32 bytes or less
   const unsigned long long xb = (unsigned long long)N * C * Hx * Wx * 4ull;
-  q->x_bytes = xb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)xb;
+  if (gb > 0xFFFFFE00ull || xb > 0xFFFFFE00ull) return false;
+  q->g_bytes = (unsigned)gb;
+  q->x_bytes = (unsigned)xb;
   return true;
 }
 
