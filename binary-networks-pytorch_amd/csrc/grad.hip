@@ -22,12 +22,14 @@
 // chunk of the GEMM's pixel dimension is 64/slot consecutive image rows.  An 8-element MFMA fragment never
 // straddles an image row, and 7x7 .. 56x56 images all use >= 87.5 % of the chunk.
 //
-// Measured (MI355X, ResNet-18 224x224 batch 256, tools/bench_train.py + tools/last_step_profile.py): 13 + 3 wgrad
-// launches 5.8 ms, 16 dgrad launches 4.3 ms per step; the whole training step 33 ms against 42 ms with the
-// library's fp32 gradient convolutions and 48 ms for the pure torch composition.  Both kernels are bound by the
-// VALU work of the fills (index arithmetic, fp32 -> hi/lo / sign conversion: ~10 instructions per loaded element
-// against 72 MFMAs per chunk and wave), not by memory latency: issuing a chunk's loads one iteration ahead
-// (software-pipelined fills) changed nothing (wgrad) or lost occupancy (dgrad) and was dropped.
+// Measured (MI355X, ResNet-18 224x224 batch 256, tools/bench_grad.py / tools/bench_train.py, round 3): dgrad 180-400 us
+// per stride-1 layer (the library's fp32 backward: 530-630), 270-540 on the stride-2 layers (350-440), wgrad 205-335 us
+// (310-705); the whole training step 30.2 ms against 41.7 ms with the library's gradient convolutions and 48.4 ms for
+// the pure torch composition.  Both kernels were bound by HOW they loaded, not by the matrix pipe: guarded loads behind
+// branches are waited for one by one (the dgrad epilogue paid one HBM round trip per output channel: 16-32 in a row),
+// and 64-bit index arithmetic + selects per element were ~20 VALU instructions per loaded element.  Now every fill item
+// keeps its place for the life of the workgroup: per-lane byte offsets computed once, wave-uniform offsets per block /
+// chunk in scalar registers, buffer loads whose out-of-range offsets ARE the zero padding.
 //
 // Stride 2 (the first conv of a down-sampling stage) uses the same kernels: wgrad reads sign(x) at stride 2 (its
 // shifted LDS copies are de-interleaved), dgrad treats g as zero-upsampled by 2 when the patch is filled (3/4 of
