@@ -32,6 +32,11 @@ spmc c SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACT
 spmc d GRBM_GUI_ACTIVE
 spmc e FETCH_SIZE
 spmc f WRITE_SIZE
+# training path: gradient kernels per layer (library backward beside them) and the whole step
+{ timeout 250 python "$R/tools/bench_grad.py" 2>&1 | tail -8; timeout 250 env BATCH=256 python "$R/tools/bench_train.py" 2>&1 | tail -1;
+  timeout 250 python "$R/tools/bench_train.py" 2>&1 | tail -1; } > "$OUT/train.txt" 2>&1
+# the two stem kernels side by side (bit-identity on ragged shapes, then timings)
+timeout 300 python "$R/tools/stem_ab.py" 2>&1 | tail -12 > "$OUT/stem_ab.txt"
 # VALU instructions per wave of every launch of one forward, from the SAME build (tools/kernel_roofline.py)
 bash "$R/tools/pmc_net.sh" > "$OUT/pmc_net.log" 2>&1
 cd /tmp
