@@ -32,8 +32,9 @@
 // chunk in scalar registers, buffer loads whose out-of-range offsets ARE the zero padding.
 //
 // Stride 2 (the first conv of a down-sampling stage) uses the same kernels: wgrad reads sign(x) at stride 2 (its
-// shifted LDS copies are de-interleaved), dgrad treats g as zero-upsampled by 2 when the patch is filled (3/4 of
-// its MFMA work multiplies zeros).  1x1 / stride 1 convolutions (the shortcut branches behind an AvgPool:
+// shifted LDS copies are de-interleaved); dgrad runs the four parity classes of the x pixels as four convolutions over
+// the grid of g with 1, 2, 2 and 4 taps (dgrad_kernel<.., S2 = true>, grid.z = class) — until round 3 it multiplied a
+// zero-upsampled g with all nine taps (3/4 of its MFMAs and of its fill were zeros: 536 -> 380, 276 -> 206, 297 -> 144 us).  1x1 / stride 1 convolutions (the shortcut branches behind an AvgPool:
 // 0.4 % of a ResNet-18's MACs) are the same kernels with one tap and no halo; the weight-gradient kernel then
 // takes 128 input channels per workgroup instead of 32 so that a wave still has 8 accumulator tiles per g fragment.
 #include "bconv_core.h"  // buffer-descriptor helpers
@@ -134,7 +135,13 @@ __global__ __launch_bounds__(64) void grad_pack_weight_kernel(const float* __res
 // 64 * NSUB per workgroup, grid.y blocks), K = (o, tap): loop over blocks of 32 output channels; per block the
 // chunk's rows +- 1 of g' = alpha[o] * g enter LDS as fp16 hi / lo, [pixel][32 o]; 9 taps = 9 k-steps of 32.
 // Epilogue: accumulators -> LDS [c][pixel] -> coalesced NCHW stores with the STE mask 1[|x| < 1].
-template <int NSUB, int KS>
+// S2 (stride 2, 3x3): the four parity classes (py, px) of the x pixels are four convolutions over the GRID OF g —
+//     gx[2a + py, 2b + px] = sum over o and the taps with ky = py + 1, kx = px + 1 (mod 2) of
+//                            g'[o, a + (py + 1 - ky)/2, b + (px + 1 - kx)/2] * sign(W)[o, c, ky, kx]
+// with 1, 2, 2 and 4 taps (class = blockIdx.z; the chunks tile the g grid, the patch has one halo row below and one
+// halo column to the right, the epilogue writes every second pixel of every second row).  Round 2 / 3a multiplied
+// a zero-upsampled g with all nine taps: 3/4 of the MFMAs and of the fill were zeros.
+template <int NSUB, int KS, bool S2 = false>
 __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict__ g,
                                                             const float* __restrict__ alpha,
                                                             const half8* __restrict__ Bp,
@@ -142,8 +149,11 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
                                                             float* __restrict__ gx, const GradGeo q) {
   using namespace grad;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  static_assert(!S2 || KS == 3, "parity classes: 3x3 / stride 2");
   constexpr int PD = KS / 2, T = KS * KS;
-  const int PW = q.W + 2 * PD, PP = (q.R + 2 * PD) * PW;  // patch width / pixels (halo included)
+  constexpr int HALO = S2 ? 1 : 2 * PD;                   // patch rows / columns beyond the chunk's
+  const int PW = q.W + HALO, PP = (q.R + HALO) * PW;     // patch width / pixels (halo included)
+  const int py = S2 ? (int)(blockIdx.z >> 1) : 0, px = S2 ? (int)(blockIdx.z & 1) : 0;
   u16* pa_hi = reinterpret_cast<u16*>(lds_raw);
   u16* pa_mid = pa_hi + (size_t)PP * APIX;
   u16* pa_lo = pa_mid + (size_t)PP * APIX;
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int n = blockIdx.x / q.chunks, y0 = (blockIdx.x - n * q.chunks) * q.R;
-  const int HW = q.H * q.W, HGg = q.Hg * q.Wg;
+  const int HW = q.Hx * q.Wx, HGg = q.Hg * q.Wg;  // pixels of a channel plane of x / gx; of g
   const int CS = (q.C + 15) / 16, OB = (q.O + 31) / 32;
   const int cs0 = (blockIdx.y * 4 + wave) * NSUB;  // first 16-channel group of this wave
 
@@ -165,7 +175,8 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
     const int m = 16 * s + li;
     int ry = m / q.slot, x = m - ry * q.slot;
     if (x >= q.W || ry >= q.R) { ry = 0; x = 0; }  // dead slot: any valid address, result is never stored
-    abase[s] = ((ry + 2 * PD) * PW + (x + 2 * PD)) * APIX + 8 * lg;  // tap (ky,kx) reads patch pixel (ry+2PD-ky, x+2PD-kx)
+    // tap (ky,kx) reads patch pixel (ry+2PD-ky, x+2PD-kx); S2: (ry + dy, x + dx) from the patch's own origin
+    abase[s] = S2 ? (ry * PW + x) * APIX + 8 * lg : ((ry + 2 * PD) * PW + (x + 2 * PD)) * APIX + 8 * lg;
   }
 
   f32x4 acc[4][NSUB];
@@ -188,14 +199,21 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
   for (int k = 0; k < FK; ++k) {
     const int pix = lane + 64 * k;
     const int pr = pix / PW, pc = pix - pr * PW;
-    const int y = y0 - PD + pr, x = pc - PD;
-    // stride 2: g zero-upsampled — only even (y, x) carry a value, g[y/2][x/2]
-    const int yg = q.st == 2 ? y >> 1 : y, xg = q.st == 2 ? x >> 1 : x;
-    const bool in = pix < PP && y >= 0 && x >= 0 && yg < q.Hg && xg < q.Wg && (q.st == 1 || ((y | x) & 1) == 0);
+    // (S2: the chunk's rows of g from its own origin, one halo row / column behind)
+    const int y = S2 ? y0 + pr : y0 - PD + pr, x = S2 ? pc : pc - PD;
+    const int yg = y, xg = x;
+    const bool in = pix < PP && y >= 0 && x >= 0 && yg < q.Hg && xg < q.Wg;
     fvoff[k] = in ? (unsigned)(yg * q.Wg + xg) * 4u : 0xFFFFFFF0u;
     flds[k] = pix < PP ? pix * APIX + 8 * wave : -1;
   }
   const unsigned plane4 = (unsigned)HGg * 4u;
+  // the taps of this launch: all T, or (S2) those of the parity class — ky = 1 | {0, 2}, kx = 1 | {0, 2}
+  const int ntap = S2 ? (1 + py) * (1 + px) : T;
+  auto tap_of = [&](int ti) {  // wave-uniform
+    if (!S2) return ti;
+    const int iy = px ? ti >> 1 : ti, ix = px ? ti & 1 : 0;
+    return (py ? 2 * iy : 1) * KS + (px ? 2 * ix : 1);
+  };
 
   for (int ob = 0; ob < OB; ++ob) {
     __syncthreads();  // previous block's patch is consumed
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
       }
     };
     half8 b[NSUB];
-    load_w(b, 0);
+    load_w(b, tap_of(0));
     const int o0 = 32 * ob + 8 * wave;
     float av[8];
 #pragma unroll
@@ -237,15 +255,17 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
     }
     __syncthreads();
 #pragma unroll 1
-    for (int tap = 0; tap < T; ++tap) {
+    for (int ti = 0; ti < ntap; ++ti) {
+      const int tap = tap_of(ti);
       const int ky = tap / KS, kx = tap - ky * KS;
-      const int toff = (ky * PW + kx) * APIX;
+      // (S2: dy = (py + 1 - ky) / 2, added; else the flipped tap, subtracted)
+      const int toff = S2 ? -((((py + 1 - ky) >> 1) * PW + ((px + 1 - kx) >> 1)) * APIX) : (ky * PW + kx) * APIX;
       // the NEXT tap's sign(W) fragments are requested before this tap's MFMAs (tap 0's before the fill): a load in
       // front of its own MFMAs exposed one L2 round trip per tap, 18 per workgroup at 64 channels
       half8 bn[NSUB];
 #pragma unroll
       for (int ns = 0; ns < NSUB; ++ns) bn[ns] = b[ns];
-      if (tap + 1 < T) load_w(bn, tap + 1);
+      if (ti + 1 < ntap) load_w(bn, tap_of(ti + 1));
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const half8 ah = *reinterpret_cast<const half8*>(pa_hi + abase[s] - toff);
@@ -279,8 +299,10 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
   const int c_blk = blockIdx.y * 64 * NSUB;
   constexpr int IT = 16 * NSUB;
   const int ery = lane >> (q.gshift + 3), ex = lane & (q.slot - 1);
-  const bool elive = ex < q.W && ery < q.R && y0 + ery < q.H;
-  const unsigned elane = elive ? (unsigned)((y0 + ery) * q.W + ex) * 4u : 0xFFFFFFF0u;
+  // (S2: chunk pixel (a, b) of the g grid is x pixel (2a + py, 2b + px))
+  const int eyy = S2 ? 2 * (y0 + ery) + py : y0 + ery, exx = S2 ? 2 * ex + px : ex;
+  const bool elive = ex < q.W && ery < q.R && y0 + ery < q.H && eyy < q.Hx && exx < q.Wx;
+  const unsigned elane = elive ? (unsigned)(eyy * q.Wx + exx) * 4u : 0xFFFFFFF0u;
   const BufRsrc r_x = make_rsrc_sized(xin, q.x_bytes);
   [[maybe_unused]] const BufRsrc r_gx = make_rsrc_sized(gx, q.x_bytes);
   const unsigned xplane4 = (unsigned)HW * 4u;
@@ -470,8 +492,10 @@ static bool make_geo(int N, int O, int C, int Hx, int Wx, int st, bool dgrad, Gr
   q->N = N; q->O = O; q->C = C; q->Hx = Hx; q->Wx = Wx; q->st = st;
   q->Hg = (Hx - 1) / st + 1;
   q->Wg = (Wx - 1) / st + 1;
-  q->H = dgrad ? Hx : q->Hg;
-  q->W = dgrad ? Wx : q->Wg;
+  // the pixel domain the chunks tile: x for a stride-1 dgrad, the grid of g for wgrad and for the stride-2 dgrad
+  // (whose four parity classes are convolutions over that grid)
+  q->H = (dgrad && st == 1) ? Hx : q->Hg;
+  q->W = (dgrad && st == 1) ? Wx : q->Wg;
   if (q->W > 64) return false;
   int slot = 8;
   while (slot < q->W) slot *= 2;
@@ -510,12 +534,25 @@ template <int KS>
 static int launch_dgrad_t(const float* g, const float* alpha, const void* packed, const float* xin, float* gx,
                           const GradGeo& q, hipStream_t s) {
   using namespace grad;
-  const int PP = (q.R + 2 * (KS / 2)) * (q.W + 2 * (KS / 2));
+  const bool s2 = q.st == 2;
+  const int halo = s2 ? 1 : 2 * (KS / 2);
+  const int PP = (q.R + halo) * (q.W + halo);
   const int nsub = q.C > 64 ? 2 : 1;
   const size_t patch = (size_t)3 * PP * APIX * sizeof(u16);
   const size_t stage = (size_t)64 * nsub * SROW * sizeof(float);
   const size_t lds = patch > stage ? patch : stage;
-  const dim3 grid((unsigned)(q.N * q.chunks), (unsigned)((q.C + 64 * nsub - 1) / (64 * nsub)));
+  const dim3 grid((unsigned)(q.N * q.chunks), (unsigned)((q.C + 64 * nsub - 1) / (64 * nsub)), s2 ? 4u : 1u);
+  if constexpr (KS == 3) {
+    if (s2) {  // four parity classes (grid.z)
+      if (nsub == 2)
+        hipLaunchKernelGGL((dgrad_kernel<2, 3, true>), grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed),
+                           xin, gx, q);
+      else
+        hipLaunchKernelGGL((dgrad_kernel<1, 3, true>), grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed),
+                           xin, gx, q);
+      return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+    }
+  }
   if (nsub == 2)
     hipLaunchKernelGGL((dgrad_kernel<2, KS>), grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed), xin,
                        gx, q);

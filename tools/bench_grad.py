@@ -1,5 +1,5 @@
 """Gradient kernels of the binary 3x3 conv, one line per ResNet-18 layer shape at batch 256 (BATCH=...):
-dgrad / wgrad time, fraction of the fp16 MFMA peak (2 products per MAC), and the library's fp32 backward beside it."""
+dgrad / wgrad time, fraction of the bf16 MFMA peak (3 products per MAC), and the library's fp32 backward beside it."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "binary-networks-pytorch_amd")]
@@ -42,8 +42,8 @@ for C, O, H, st in SHAPES:
     packed, al = hipops.grad_pack_weight(what)
     td = t(lambda: hipops.bconv_grad_input(g, x, packed, al, 3, st))
     tw = t(lambda: hipops.bconv_grad_weight(g, x, 3, st))
-    flop = 2.0 * N * C * O * 9 * Ho * Ho * 2  # hi + lo product per MAC
-    fd = flop * (st * st) / (td * 1e-6) / 2.5e15  # dgrad multiplies the zero-upsampled g: st^2 times the MFMA work
+    flop = 2.0 * N * C * O * 9 * Ho * Ho * 3  # three bf16 products per MAC
+    fd = flop / (td * 1e-6) / 2.5e15  # (stride 2: the four parity classes together do exactly these MACs)
     fw = flop / (tw * 1e-6) / 2.5e15
     ld = lw = float("nan")
     if LIB:
