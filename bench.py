@@ -22,6 +22,7 @@ The roofline block times 50 launches of the graded kernel with events after --ro
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import socket
@@ -42,6 +43,7 @@ def self_launch(gpus: int) -> int:
         port = s.getsockname()[1]
     env = dict(os.environ, BNN_BENCH_LAUNCHER="self", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
         "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
@@ -57,9 +59,21 @@ def parse_args():
                          "at --gpus 8), c2 the single 3x3 128->128 56x56 layer, c5 ResNet(HBlock,[3,4,6,3]) with the "
                          "fp16 MFMA stem at 128 images/GPU")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: 256; c5: 128)")
-    ap.add_argument("--engine", choices=("graph", "fused", "layerwise"), default="graph",
-                    help="graph: fused executor replayed as a HIP graph (default); fused: same, eager "
-                         "launches; layerwise: the drop-in per-layer path (pack -> conv -> torch BN/ReLU)")
+    ap.add_argument("--engine", choices=("graph", "graph_fresh", "net_call", "fused", "layerwise"), default="graph",
+                    help="what the headline `value` times.  graph: fused executor replayed as HIP graphs over resident "
+                         "static input buffers (default); graph_fresh: the same with a NEW input tensor every step "
+                         "(stem launch on the caller's tensor + graph of the rest, no staging copy); net_call: the "
+                         "reference's own call `net(x)` on the prepare_binary_model() model with a new tensor every "
+                         "step (bnn_amd AutoFusion); fused: fused executor, eager launches, new tensor every step; "
+                         "layerwise: one launch per binary layer + torch BN/ReLU/add (auto-fusion off).  The other "
+                         "engines are reported beside it in `engines` unless --no-extras")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend.  nccl = RCCL (one rank per GPU, the real thing); gloo: the same bench "
+                         "code with host-staged collectives — lets N ranks share ONE GPU (RCCL refuses that), which is "
+                         "how the N > 1 paths are exercised on a one-GPU box (tests/test_gpu_dist.py)")
+    ap.add_argument("--sustain", type=float, default=3.0,
+                    help="seconds of the same step run (and timed) after the K timed steps: the `sustained` record, "
+                         "with the engine clock sampled right behind it (0 = skip)")
     ap.add_argument("--streams", type=int, default=2,
                     help="graph engine: batches in flight per GPU (graph-captured executors on their own HIP "
                          "streams, replayed round-robin; 1 = strictly one batch at a time)")
@@ -87,10 +101,10 @@ import torch.distributed as dist  # noqa: E402
 
 import bnn_amd as bnn  # noqa: E402
 from bnn_amd import hipops, native  # noqa: E402
-from bnn_amd.inference import FusedResNet, PipelinedInference  # noqa: E402
+from bnn_amd.inference import FusedResNet, PipelinedInference, auto_fusion, per_layer_forward  # noqa: E402
 from bnn_amd.models import HBlock, ResNet, resnet18  # noqa: E402
 from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer  # noqa: E402
-from bnn_amd.parallel import ShardedInference  # noqa: E402
+from bnn_amd.parallel import ShardedInference, all_gather_scalar  # noqa: E402
 from tests.golden import gen  # noqa: E402  (portable synthetic-data generator, no reference code)
 
 # ResNet-18 @224: algorithmic int lane-ops per image over all binary convs (SURVEY §A.2 / BASELINE.md §4)
@@ -270,10 +284,14 @@ def dist_info(world):
            "launcher": os.environ.get("BNN_BENCH_LAUNCHER", "torchrun" if "WORLD_SIZE" in os.environ else "none")}
     if dist.is_initialized():
         rec["backend"] = dist.get_backend()
-        try:
-            rec["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
-        except Exception:  # noqa: BLE001 - informational only
-            rec["rccl_version"] = None
+        if rec["backend"] == "nccl":
+            try:
+                rec["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001 - informational only
+                rec["rccl_version"] = None
+        else:
+            rec["note"] = "host-staged collectives; ranks may share a GPU (exercise of the N > 1 code, not a scaling run)"
+        rec["gpus_visible"] = torch.cuda.device_count()
     assert rec["world_size"] == world
     return rec
 
@@ -285,22 +303,32 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the GPU path has no CPU stand-in)")
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but {n_dev} visible GPU(s) — RCCL needs one GPU per "
+                         "rank (--backend gloo lets ranks share a GPU)")
+    device = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(device)
     if "WORLD_SIZE" in os.environ:     # under a launcher — also at world size 1, so that N = 1 runs the same code
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     native.require()
-    info = native.device_info(local_rank)
+    info = native.device_info(device.index)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    def timed(step, steps, warmup):
+    def max_over_ranks(v: float) -> float:
+        return max(all_gather_scalar(v, device)) if world > 1 else v
+
+    def timed(step, steps, warmup, sustain=0.0):
         # The engine clock of an idle GPU takes a few hundred ms of work to come up (the first timed region after a
         # pause measured ~15 % slow), and W = 5 warm-up steps are 6 ms.  A fixed number of the SAME
         # steps (same count on every rank: the step may contain a collective) runs first; it is reported as
@@ -309,21 +337,33 @@ def main():
             step(i)
         for i in range(warmup):
             out = step(i)
-        torch.cuda.synchronize(device)
-        barrier()
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            out = step(warmup + i)
-        torch.cuda.synchronize(device)
-        barrier()
-        torch.cuda.synchronize(device)
-        dt = time.perf_counter() - t0
+
+        def region(n, first):
+            torch.cuda.synchronize(device)
+            barrier()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for i in range(n):
+                o = step(first + i)
+            torch.cuda.synchronize(device)
+            barrier()
+            torch.cuda.synchronize(device)
+            return time.perf_counter() - t0, o
+        dt, out = region(steps, warmup)
+        if isinstance(out, torch.Tensor):
+            out = out.clone()       # (a graph-replayed step returns its slot's buffer: later steps rewrite it)
         timed.local = dt            # this rank's own time (the returned one is the max over ranks)
-        if world > 1:
-            tt = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+        dt = max_over_ranks(dt)
+        timed.clock_mhz = hipops.probe_clock(device)
+        timed.sustained = None
+        if sustain > 0:
+            # the SAME step for >= `sustain` seconds (the K timed steps of a 1 ms forward are 20 ms — inside the
+            # boost window of a GPU that was idle a second ago): same count on every rank, from the agreed time above
+            n = max(steps, int(sustain / (dt / steps)) + 1)
+            dts, _ = region(n, warmup + steps)
+            mhz = hipops.probe_clock(device)
+            dts = max_over_ranks(dts)
+            timed.sustained = {"seconds": dts, "steps": n, "ms_per_step": dts / n * 1e3, "engine_clock_mhz": round(mhz)}
         return dt, out
 
     if args.config == "c2":
@@ -335,10 +375,42 @@ def main():
         rec["device"] = {k: info[k] for k in ("name", "arch", "compute_units", "clock_khz")}
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
+            if args.config == "c3":     # the small-batch latency regime of config 1, on the GPU, next to its CPU number
+                rec["cpu_baseline"]["c1_resnet18_32x32_b32"]["gpu"] = gpu_c1(device)
         print(json.dumps(rec), flush=True)
     barrier()
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def gpu_c1(device):
+    """Config 1's workload (examples/cifar10.py model: ResNet-18, 32 x 32 inputs, batch 32) through the reference's
+    own call `net(x)` with a new tensor every call — the small-batch regime, where a forward is launch-latency-bound."""
+    net = build_model(device)
+    xs = [torch.from_numpy(gen.normal(40 + j, (32, 3, 32, 32))).to(device) for j in range(4)]
+    with torch.no_grad():
+        for i in range(50):
+            net(xs[i % 4])
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        n = 200
+        for i in range(n):
+            y = net(xs[i % 4])
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / n
+        st = auto_fusion(net).calls
+        with per_layer_forward():
+            for i in range(5):
+                net(xs[i % 4])
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for i in range(20):
+                net(xs[i % 4])
+            torch.cuda.synchronize(device)
+            dtl = (time.perf_counter() - t0) / 20
+    assert y.shape == (32, 1000)
+    return {"value": 32 / dt, "unit": "images/s", "ms_per_batch": dt * 1e3, "engine": "net_call (stem launch + HIP graph)",
+            "calls": dict(st), "layerwise": {"value": 32 / dtl, "ms_per_batch": dtl * 1e3}}
 
 
 def bench_c2(args, world, rank, device, info, timed):
@@ -350,7 +422,8 @@ def bench_c2(args, world, rank, device, info, timed):
 
     def step(i):
         return hipops.bconv2d_direct(x, pw, stride=1, padding=1)
-    dt, out = timed(step, args.steps, args.warmup)
+    dt, out = timed(step, args.steps, args.warmup, sustain=args.sustain)
+    sustained, clock_mhz = timed.sustained, timed.clock_mhz
     assert out.shape == (N, O, H, W)
     # two batches in flight (the way the whole-net headline is run)
     streams = [torch.cuda.Stream(device=device) for _ in range(2)]
@@ -373,8 +446,13 @@ def bench_c2(args, world, rank, device, info, timed):
                                   "relu(N(0,1)), one bnn_hip_bconv2d_direct launch per step (sign(x) on the fly)",
                       "parallelism": f"{world} replicas"},
            "layer_int_alu_frac": lane_ops * args.steps / dt / int_alu_peak(info),
+           "engine_clock_mhz": round(clock_mhz),
            "two_batches_in_flight": {"value": world * N * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3,
                                      "layer_int_alu_frac": lane_ops * args.steps / dt2 / int_alu_peak(info)}}
+    if sustained is not None:
+        sustained["value"] = world * N * sustained["steps"] / sustained["seconds"]
+        sustained["layer_int_alu_frac"] = lane_ops * sustained["steps"] / sustained["seconds"] / int_alu_peak(info)
+        rec["sustained"] = sustained
     if roof is not None:
         rec["roofline"] = roof
         rec["packed_input_only"] = {"images_per_s": roof["images_per_s_kernel"], "us": roof["avg_kernel_us"],
@@ -393,21 +471,35 @@ def validate_gather(net, gathered, rank_input, B, world, rank, device, fused_kw,
     n = min(n_check, B)
     bad = []
     for r in range(world):
-        want = ref_engine(rank_input(r, n).contiguous())
+        with per_layer_forward() if layerwise else contextlib.nullcontext():
+            want = ref_engine(rank_input(r, n).contiguous())
         got = gathered[r * B:r * B + n]
         if not torch.equal(got, want):
             bad.append(r)
     # rank blocks are distinct (different synthetic images per rank): a gather that repeated one rank would show here
     if world > 1:
         assert not torch.equal(gathered[:n], gathered[B:B + n]), "rank 0 and rank 1 blocks are identical"
-    ok = torch.tensor([0 if bad else 1], device=device)
+    ok = 0 if bad else 1
     if dist.is_initialized():
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if bad or int(ok.item()) != 1:
+        ok = int(min(all_gather_scalar(ok, device, torch.int64)))
+    if bad or ok != 1:
         raise SystemExit(f"bench.py: rank {rank}: gathered logits differ from a local recomputation for rank "
                          f"block(s) {bad} — the all-gather is mis-ordered or raced with the graph replay")
     return {"ranks_checked": world, "images_per_rank": n, "bit_equal": True,
             "how": "every rank recomputed the first images of every rank's batch and compared with its gathered copy"}
+
+
+N_FRESH = 3     # distinct resident input tensors the fresh-input engines rotate over (3 x 154 MB at batch 256)
+
+ENGINE_NOTES = {
+    "graph": "HIP-graph replay of the fused executor over resident static input buffers (PipelinedInference)",
+    "graph_fresh": "a NEW input tensor every step: stem launch on the caller's tensor + HIP graph of the rest "
+                   "(PipelinedInference(fresh_input=True)); no staging copy, no re-capture",
+    "net_call": "the reference's own call: net = prepare_binary_model(...).eval(); net(x) under no_grad with a NEW "
+                "tensor every step (examples/cifar10.py:140-149) — bnn_amd AutoFusion: stem launch + HIP graph",
+    "fused": "FusedResNet(net)(x), 21 eager launches per forward, a NEW tensor every step",
+    "layerwise": "net(x) with auto-fusion off: one launch per binary layer + torch/MIOpen stem, BN, ReLU, add",
+}
 
 
 def bench_net(args, world, rank, device, info, timed):
@@ -416,58 +508,97 @@ def bench_net(args, world, rank, device, info, timed):
     net = build_model(device, (lambda: ResNet(HBlock, [3, 4, 6, 3])) if c5 else resnet18)
     fused_kw = {"stem_fp16": True} if c5 else {}
 
-    def rank_input(r, n=B):
-        """Rank r's synthetic batch (first n images): any rank can rebuild any other rank's input, which is what
-        lets every rank check the gathered logits (validate_gather)."""
+    def rank_input(r, n=B, j=0):
+        """Rank r's synthetic batch (first n images; j: which of the rotating fresh tensors): any rank can rebuild any
+        other rank's input, which is what lets every rank check the gathered logits (validate_gather)."""
         xr = torch.from_numpy(gen.normal(100 + r, (8, 3, 224, 224))).to(device).repeat((n + 7) // 8, 1, 1, 1)[:n]
-        return xr + 0.01 * torch.arange(n, device=device, dtype=torch.float32).view(n, 1, 1, 1)  # distinct images
+        return xr + (0.01 * torch.arange(n, device=device, dtype=torch.float32) + 0.003 * j).view(n, 1, 1, 1)
 
     x = rank_input(rank)
-    n_streams = max(1, args.streams) if args.engine == "graph" else 1
+    fresh = None     # the rotating input tensors, made on first use
 
-    def make_step(n_streams=n_streams, **kw):
-        if args.engine == "graph":
+    def fresh_inputs():
+        nonlocal fresh
+        if fresh is None:
+            fresh = [x] + [rank_input(rank, j=j) for j in range(1, N_FRESH)]
+        return fresh
+
+    def make_step(engine, n_streams, **kw):
+        """One step of `engine` -> all ranks' logits (ShardedInference: the all-gather is part of the step)."""
+        if engine == "graph":
             # every stream owns a graph-captured executor whose static input buffer holds its batch (filled by
             # capture): no per-step device-to-device copy of the 154 MB input, and `n_streams` batches in flight
             # (with more than one the executors run in throughput mode: BNN_HIP_FLAG_THROUGHPUT)
             pipe = PipelinedInference(net, x, n_streams=n_streams, **kw)
             models = [ShardedInference(e) for e in pipe.engines]
 
-            def step(i, k_streams=n_streams):
-                k = i % k_streams
+            def step(i):
+                k = i % n_streams
                 with torch.cuda.stream(pipe.streams[k]):
                     return models[k].forward_even(pipe.engines[k].static_input)
             return step
-        model = ShardedInference(net if args.engine == "layerwise" else FusedResNet(net, **kw))
-        return lambda i, k_streams=1: model.forward_even(x)
+        xs = fresh_inputs()
+        if engine == "graph_fresh":
+            pipe = PipelinedInference(net, x, n_streams=n_streams, fresh_input=True, **kw)
+            models = [ShardedInference(_Fresh(e)) for e in pipe.engines]
 
-    step = make_step(**fused_kw)
+            def step(i):
+                k = i % n_streams
+                with torch.cuda.stream(pipe.streams[k]):
+                    return models[k].forward_even(xs[i % N_FRESH])
+            return step
+        if engine == "fused":
+            model = ShardedInference(FusedResNet(net, **kw))
+            return lambda i: model.forward_even(xs[i % N_FRESH])
+        model = ShardedInference(net)               # net_call / layerwise: the reference's own call
+        if engine == "layerwise":
+            def step(i):
+                with per_layer_forward():
+                    return model.forward_even(xs[i % N_FRESH])
+            return step
+        if kw:
+            raise SystemExit("--engine net_call takes the model's default executor options")
+        return lambda i: model.forward_even(xs[i % N_FRESH])
+
+    multi = args.engine in ("graph", "graph_fresh")
+    n_streams = max(1, args.streams) if multi else 1
+    head_kw = {} if args.engine in ("net_call", "layerwise") else fused_kw
+    step = make_step(args.engine, n_streams, **head_kw)
     with torch.no_grad():
-        dt, logits = timed(step, args.steps, args.warmup)
-        dt_local = timed.local
-        logits = logits.clone()     # (the gathered buffer of a graph-captured step is rewritten by later replays)
+        dt, logits = timed(step, args.steps, args.warmup, sustain=args.sustain)
+        dt_local, sustained, clock_mhz = timed.local, timed.sustained, timed.clock_mhz
         assert logits.shape == (world * B, 1000) and bool(torch.isfinite(logits).all())
-        extras = {}
-        if not args.no_extras and args.engine == "graph":
-            if n_streams > 1:   # same steps, strictly one batch at a time (an executor built for that: latency mode)
-                step1 = make_step(n_streams=1, **fused_kw)
-                dt1, _ = timed(step1, args.steps, args.warmup)
-                extras["one_batch_at_a_time"] = {"value": world * B * args.steps / dt1,
-                                                 "ms_per_step": dt1 / args.steps * 1e3}
-            if not c5:          # the same network with the stem in exact fp32 arithmetic (v_mfma_f32_16x16x4_f32)
-                step_x = make_step(stem_exact_fp32=True)
-                dtx, lx = timed(step_x, args.steps, args.warmup)
-                extras["exact_fp32_stem"] = {
-                    "value": world * B * args.steps / dtx, "ms_per_step": dtx / args.steps * 1e3,
-                    "max_abs_logit_diff_vs_default": float((lx - logits).abs().max()),
-                    "note": "stem as a k-ordered fp32 fmaf chain on v_mfma_f32_16x16x4_f32 (bit-for-bit IEEE fp32)"}
-        gather_check = validate_gather(net, logits, rank_input, B, world, rank, device, fused_kw,
-                                       layerwise=args.engine == "layerwise") if dist.is_initialized() else None
+        # which tensor the LAST timed step read (validate_gather recomputes it)
+        last_j = 0 if args.engine == "graph" else (args.warmup + args.steps - 1) % N_FRESH
+        extras, engines = {}, {}
+
+        def measure(engine, streams, **kw):
+            d, out = timed(make_step(engine, streams, **kw), args.steps, args.warmup)
+            return {"value": world * B * args.steps / d, "ms_per_step": d / args.steps * 1e3,
+                    "engine_clock_mhz": round(timed.clock_mhz)}, out
+        if not args.no_extras:
+            head_key = f"{args.engine}_x{n_streams}" if multi else args.engine
+            engines[head_key] = {"value": world * B * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                                 "engine_clock_mhz": round(clock_mhz), "headline": True}
+            for eng, k in (("graph", 2), ("graph", 1), ("graph_fresh", 2), ("graph_fresh", 1), ("net_call", 1),
+                           ("fused", 1), ("layerwise", 1)):
+                key = f"{eng}_x{k}" if eng in ("graph", "graph_fresh") else eng
+                if key in engines or (c5 and eng == "net_call"):    # (c5 asks for the fp16 stem: not the model default)
+                    continue
+                engines[key], _ = measure(eng, k, **({} if eng in ("net_call", "layerwise") else fused_kw))
+            for key, rec_e in engines.items():
+                rec_e["what"] = ENGINE_NOTES[key.split("_x")[0]]
+            if "graph_x1" in engines:
+                extras["one_batch_at_a_time"] = {k: engines["graph_x1"][k] for k in ("value", "ms_per_step")}
+            if not c5 and args.engine == "graph":   # the same network with the stem in exact fp32 arithmetic
+                ex, lx = measure("graph", n_streams, stem_exact_fp32=True)
+                extras["exact_fp32_stem"] = dict(
+                    ex, max_abs_logit_diff_vs_default=float((lx - logits).abs().max()),
+                    note="stem as a k-ordered fp32 fmaf chain on v_mfma_f32_16x16x4_f32 (bit-for-bit IEEE fp32)")
+        gather_check = validate_gather(net, logits, lambda r, n: rank_input(r, n, last_j), B, world, rank, device,
+                                       head_kw, layerwise=args.engine == "layerwise") if dist.is_initialized() else None
     if dist.is_initialized():     # per-rank step times: a straggler shows here, not only in the max
-        mine = torch.tensor([dt_local / args.steps * 1e3], device=device, dtype=torch.float64)
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
-        per_rank_ms = [float(t.item()) for t in every]
+        per_rank_ms = [float(t) for t in all_gather_scalar(dt_local / args.steps * 1e3, device)]
     else:
         per_rank_ms = [dt_local / args.steps * 1e3]
     if rank != 0:
@@ -485,9 +616,17 @@ def bench_net(args, world, rank, device, info, timed):
         "dtype": DTYPE if not c5 else DTYPE.replace("fp32 operands split into fp16 hi+lo", "plain fp16 operands (BNN_HIP_STEM_FP16)"),
         "data": "synthetic",
         "config": {"workload": f"{name} 224x224 full forward, batch {B} per GPU",
-                   "engine": args.engine, "batches_in_flight": n_streams,
+                   "engine": args.engine, "engine_note": ENGINE_NOTES[args.engine], "batches_in_flight": n_streams,
+                   "input": "resident static buffers, one per batch in flight" if args.engine == "graph" else
+                            f"a new tensor every step (rotating over {N_FRESH} resident tensors)",
                    "global_batch": world * B, "parallelism": f"dp{world} (batch shards, RCCL all-gather of logits)"},
+        "engine_clock_mhz": round(clock_mhz),
     }
+    if sustained is not None:
+        sustained["value"] = world * B * sustained["steps"] / sustained["seconds"]
+        rec["sustained"] = sustained
+    if engines:
+        rec["engines"] = engines
     rec.update(extras)
     rec["per_rank_ms_per_step"] = {"min": min(per_rank_ms), "max": max(per_rank_ms), "all": per_rank_ms}
     if gather_check is not None:
@@ -505,6 +644,17 @@ def bench_net(args, world, rank, device, info, timed):
             name: round(hipops.probe_int_alu(4096, device, mode)["lane_ops_per_s"] / 1e12, 2)
             for mode, name in hipops.PROBE_MODES.items()}
     return rec
+
+
+class _Fresh(torch.nn.Module):
+    """`FusedResNet.forward_fresh` (the slot's own output buffer, no clone) as the module ShardedInference wraps."""
+
+    def __init__(self, engine):
+        super().__init__()
+        self.engine = engine
+
+    def forward(self, x):
+        return self.engine.forward_fresh(x, clone=False)
 
 
 if __name__ == "__main__":

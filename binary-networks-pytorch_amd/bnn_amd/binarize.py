@@ -142,4 +142,10 @@ def prepare_binary_model(model: nn.Module, bconfig: BConfig,
     """Convert ``model`` in place and return it (or the new leaf if ``model`` is itself a layer)."""
     todo = get_modules_to_binarize(model, bconfig, modules_mapping, custom_config_layers_name,
                                    ignore_layers_name)
-    return swap_modules_by_name(model, todo, modules_mapping)
+    model = swap_modules_by_name(model, todo, modules_mapping)
+    if modules_mapping is None or all(v in DEFAULT_MODULE_MAPPING for v in modules_mapping.values()):
+        # a ResNet of another package laid out like bnn.models.resnet.ResNet: `model(x)` in eval mode takes the fused
+        # executor like bnn_amd.models.ResNet does (a model it does not cover keeps its own forward)
+        from .inference import install_auto_fusion
+        install_auto_fusion(model)
+    return model

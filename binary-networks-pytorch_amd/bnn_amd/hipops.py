@@ -17,6 +17,8 @@ _MAX_ELEMS = (1 << 30) - 1  # fp32 elements one conv launch addresses (32-bit by
 # the tiled conv kernels multiply indices with 24-bit multiplies (csrc/bconv.hip: small_indices()); a launch whose
 # images x channels factor reaches 2^23 would silently take the slow shape-generic kernel — split the batch first
 _MAX_INDEX_FACTOR = (1 << 23) - 1
+_DIRECT_MIN_PIXELS = 0            # images smaller than this take pack_act + bconv2d (set from tools/bench_linear.py)
+_MAX_DESC_BYTES = 0xFFFFFE00      # tensors addressed through a sized 32-bit buffer descriptor (capi.hip: kMaxDescBytes)
 
 
 def _batch_step(n: int, per_img_elems: int, chan_factor: int) -> int:
@@ -182,10 +184,11 @@ def orpool_packed(a: PackedAct, k: int) -> PackedAct:
 
 def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: torch.Tensor,
             out_f32: bool = True, out_packed: bool = True, exact_fp32: bool = False, fp16: bool = False,
-            staged: bool = False):
+            out: Optional[tuple] = None):
     """conv 7x7/2/3 (3->64, no bias) -> folded BN -> ReLU -> MaxPool 3/2/1 in one MFMA kernel
     (bnn/models/resnet.py:93-96,150-153).  Returns (fp32 NCHW | None, PackedAct | None).
-    ``staged``: the round-2 kernel (bit-identical, slower; include/bnn_hip.h BNN_HIP_STEM_STAGED) for cross-checks."""
+    ``out = (y, PackedAct)``: write into these preallocated results of an earlier call with the same input shape
+    (the static buffers a captured HIP graph of the rest of the network reads: ``FusedResNet.forward_fresh``)."""
     x = _require_cuda_f32(x, "stem input")
     w = _require_cuda_f32(w.detach(), "stem weight")
     if x.dim() != 4 or x.shape[1] != 3 or tuple(w.shape) != (64, 3, 7, 7):
@@ -197,14 +200,26 @@ def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: 
     bn_scale = _per_channel(bn_scale, 64, "bn_scale")
     bn_shift = _per_channel(bn_shift, 64, "bn_shift")
     with torch.cuda.device(x.device):
-        y = torch.empty((N, 64, hp, wp), dtype=torch.float32, device=x.device) if out_f32 else None
-        pk = empty_packed(N, 64, hp, wp, x.device) if out_packed else None
-        native.check(lib.bnn_hip_stem7x7_bn_relu_pool_pack_f32(
-            x.data_ptr(), w.data_ptr(), bn_scale.data_ptr(), bn_shift.data_ptr(), N, H, W,
-            native.STEM_EXACT_FP32 if exact_fp32 else ((native.STEM_FP16 if fp16 else 0) | (native.STEM_STAGED if staged else 0)),
-            _ptr(y),
-            None if pk is None else pk.P.data_ptr(), None if pk is None else pk.M.data_ptr(),
-            _stream(x.device)), "bnn_hip_stem7x7_bn_relu_pool_pack_f32")
+        if out is not None:
+            y, pk = out
+            if (y is not None and (tuple(y.shape) != (N, 64, hp, wp) or y.dtype != torch.float32 or y.device != x.device
+                                   or not y.is_contiguous())) or \
+                    (pk is not None and (tuple(pk.shape) != (N, 64, hp, wp) or pk.P.device != x.device)):
+                raise native.NativeError("bnn_amd: stem7x7: `out` does not belong to this input shape / device")
+        else:
+            y = torch.empty((N, 64, hp, wp), dtype=torch.float32, device=x.device) if out_f32 else None
+            pk = empty_packed(N, 64, hp, wp, x.device) if out_packed else None
+        # the kernel addresses x and out through 32-bit buffer descriptors: a launch stays below 2^32 - 512 bytes per
+        # tensor (include/bnn_hip.h) — larger batches go in several launches
+        step = max(1, min(N, _MAX_DESC_BYTES // max(12 * H * W, 256 * hp * wp)))
+        flags = native.STEM_EXACT_FP32 if exact_fp32 else (native.STEM_FP16 if fp16 else 0)
+        for n0 in range(0, N, step):
+            n1 = min(N, n0 + step)
+            native.check(lib.bnn_hip_stem7x7_bn_relu_pool_pack_f32(
+                x[n0:n1].data_ptr(), w.data_ptr(), bn_scale.data_ptr(), bn_shift.data_ptr(), n1 - n0, H, W, flags,
+                None if y is None else y[n0:n1].data_ptr(),
+                None if pk is None else pk.P[n0:n1].data_ptr(), None if pk is None else pk.M[n0:n1].data_ptr(),
+                _stream(x.device)), "bnn_hip_stem7x7_bn_relu_pool_pack_f32")
     if pk is not None:
         pk.nonneg = True  # ReLU output
     return y, pk
@@ -341,10 +356,9 @@ def _flags(w: PackedWeight, force_generic: bool, weights: Optional[str], a: Opti
         f |= native.FLAG_ACT_NONNEG
     if weights == "sgpr":
         f |= native.FLAG_WEIGHTS_SGPR
-    elif weights == "lds":
-        f |= native.FLAG_WEIGHTS_LDS
     elif weights is not None:
-        raise ValueError("weights must be None, 'sgpr' or 'lds'")
+        raise ValueError("weights must be None or 'sgpr' (the LDS-staged tile is test-only since ABI 12: "
+                         "tests/helpers/legacy.py)")
     return f
 
 
@@ -396,13 +410,25 @@ def direct_plan(x_shape, w: PackedWeight, stride=1, padding=0, dilation=1) -> Op
     return plan
 
 
+def _prefers_two_launches(d) -> bool:
+    """Shapes where ``pack_act`` + ``bconv2d`` beats the one-launch kernel.  That kernel packs 64 consecutive pixels of
+    a band per item: with 1 x 1 images (``Linear`` layers) an item holds ONE valid lane and its loads stride by a
+    whole image — 1/64 lane utilisation (measured: tools/bench_linear.py)."""
+    return d.H * d.W < _DIRECT_MIN_PIXELS
+
+
 def bconv2d_direct(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None,
                    post_scale: Optional[torch.Tensor] = None, stride=1, padding=0, dilation=1,
-                   plan: Optional[native.FlyPlan] = None, force_generic: bool = False) -> torch.Tensor:
+                   plan: Optional[native.FlyPlan] = None, force_generic: bool = False,
+                   route: Optional[str] = None) -> torch.Tensor:
     """``Conv2d.forward`` of the reference (bnn/layers/conv.py:90-97) in ONE launch: fp32 or fp16 NCHW activations in,
     fp32 NCHW out, ``sign(x)`` computed on the fly inside the convolution kernel (csrc/bconv_fly.hip) — no packed
     copy of the activations in HBM.  Geometries the one-launch kernel does not cover (an output row with its halo
-    larger than a CU's LDS) take ``pack_act`` + ``bconv2d``; the results are bit-identical either way."""
+    larger than a CU's LDS) take ``pack_act`` + ``bconv2d``; the results are bit-identical either way.
+
+    ``route``: ``None`` picks per shape (``_prefers_two_launches``); ``"direct"`` / ``"packed"`` force one (tools)."""
+    if route not in (None, "direct", "packed"):
+        raise ValueError("route must be None, 'direct' or 'packed'")
     if x.dtype == torch.float16:
         if not x.is_cuda:
             raise native.NativeError(f"bnn_amd: activation must live on a HIP device, got {x.device}")
@@ -417,6 +443,8 @@ def bconv2d_direct(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor
     dev = x.device
     bias = _per_channel(bias, d.O, "bias")
     post_scale = _per_channel(post_scale, d.O, "post_scale")
+    if d.N and plan is None and (route == "packed" or (route is None and _prefers_two_launches(d))):
+        return bconv2d(pack_act(x), w, bias, post_scale, stride, padding, dilation, force_generic=force_generic)
     with torch.cuda.device(dev):
         out = torch.empty((d.N, d.O, ho, wo), dtype=torch.float32, device=dev)
         if d.N == 0:
@@ -497,8 +525,7 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
             torch.empty((d.N, d.O, ho, wo), dtype=torch.float32, device=dev) if out_f32 else None)
         pk = empty_packed(d.N, d.O, ho, wo, dev) if out_packed else None
         # one launch addresses < 2^31 elements: split the batch when a tensor is larger (like bconv2d)
-        per_img = max(c_total * ho * wo, 2 * d.H * d.W * ((d.C + 63) // 64), 2 * ho * wo * ((d.O + 63) // 64), 1)
-        step = _batch_step(d.N, per_img, max(c_total, d.O, (d.C + 63) // 64))
+        step = fused_launch_images(d.N, d.C, d.H, d.W, d.O, (d.KH, d.KW), stride, padding, dilation, c_total)
         for n0 in range(0, d.N, step):
             n1 = min(d.N, n0 + step)
             dd = native.ConvDesc.from_buffer_copy(d)
@@ -522,6 +549,17 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
         pk.nonneg = bool(pack_relu) or (bool(relu) and prelu is None and pack_scale is None
                                         and (not late or pack_before_residual))
     return y, pk
+
+
+def fused_launch_images(N: int, C: int, H: int, W: int, O: int, kernel_size, stride=1, padding=0, dilation=1,
+                        c_total: Optional[int] = None) -> int:
+    """Images ONE launch of ``bconv2d_fused`` covers for this geometry (a batch whose tensors exceed the kernels'
+    32-bit addressing is split into several launches): what shape-dependent decisions have to be taken on."""
+    kh, kw = _pair(kernel_size)
+    ho, wo = conv_out_hw(H, W, kh, kw, stride, padding, dilation)
+    c_total = O if c_total is None else c_total
+    per_img = max(c_total * ho * wo, 2 * H * W * ((C + 63) // 64), 2 * ho * wo * ((O + 63) // 64), 1)
+    return _batch_step(N, per_img, max(c_total, O, (C + 63) // 64))
 
 
 def shortcut_fold_supported(a: PackedAct, w: PackedWeight, sc_channels: int, stride=1, padding=0, dilation=1,
@@ -599,6 +637,18 @@ def bconv_grad_weight(g: torch.Tensor, x: torch.Tensor, ksize: int = 3, stride: 
 
 PROBE_MODES = {0: "bitop3+bcnt", 1: "xor+bcnt", 2: "bcnt", 3: "bitop3", 4: "xor", 5: "fma_f32",
                6: "add_u32", 7: "and_vgpr", 8: "and_vgpr+bcnt", 9: "xor_vgpr", 10: "and_sgpr+bcnt"}
+
+
+def probe_clock(device: Optional[torch.device] = None, spin_iters: int = 10000) -> float:
+    """Engine clock right now in MHz, sampled on the current stream of ``device`` (bnn_hip_probe_clock)."""
+    lib = native.require()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    mhz = ctypes.c_double()
+    us = ctypes.c_double()
+    with torch.cuda.device(dev):
+        native.check(lib.bnn_hip_probe_clock(spin_iters, ctypes.byref(mhz), ctypes.byref(us), _stream(dev)),
+                     "bnn_hip_probe_clock")
+    return mhz.value
 
 
 def probe_int_alu(iters: int = 4096, device: Optional[torch.device] = None, mode: int = 0) -> dict:

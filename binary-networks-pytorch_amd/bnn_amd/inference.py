@@ -16,10 +16,13 @@ are derived once (call ``refresh()`` after changing parameters).  Eval mode only
 """
 from __future__ import annotations
 
-import itertools
-
+import collections
 import contextlib
+import itertools
 import os
+import threading
+import types
+import warnings
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -122,6 +125,42 @@ def _is_float_layer(conv: nn.Module) -> bool:
             and type(conv.activation_post_process).__name__ == "Identity")
 
 
+_BLOCK_KINDS = {"BasicBlock": BasicBlock, "PreBasicBlock": PreBasicBlock, "Bottleneck": Bottleneck, "HBlock": HBlock}
+_BLOCK_ATTRS = {BasicBlock: ("conv1", "bn1", "act1", "conv2", "bn2", "act2", "downsample"),
+                PreBasicBlock: ("conv1", "bn1", "act1", "conv2", "bn2", "act2", "downsample"),
+                Bottleneck: ("conv1", "bn1", "act1", "conv2", "bn2", "act2", "conv3", "bn3", "act3", "downsample"),
+                HBlock: ("conv1", "bn1", "act1", "conv2", "bn2", "act2", "conv3", "bn3", "act3", "downsample")}
+
+
+def _block_kind(blk: nn.Module):
+    """The block family ``blk`` belongs to: one of this package's classes (exact type), or a class of the same NAME
+    and attribute layout from another package — the reference's own ``bnn.models.layers`` blocks, which these mirror
+    attribute for attribute (res_block.py:8-56,59-118,121-167, hierarchical_block.py:8-60).  Foreign classes are
+    only ever fused after ``AutoFusion`` has checked the fused result against the model's own forward."""
+    t = type(blk)
+    if t in _BLOCK_ATTRS:
+        return t
+    kind = _BLOCK_KINDS.get(t.__name__)
+    if kind is not None and all(hasattr(blk, a) for a in _BLOCK_ATTRS[kind]):
+        return kind
+    return None
+
+
+def is_native_model(model: nn.Module) -> bool:
+    """True when ``model`` and all its residual blocks are this package's classes (their forward is known)."""
+    return isinstance(model, ResNet) and all(
+        type(b) in _BLOCK_ATTRS or isinstance(b, nn.AvgPool2d)
+        for stage in (model.layer1, model.layer2, model.layer3, model.layer4) for b in stage)
+
+
+def resnet_shaped(model: nn.Module) -> bool:
+    """The module layout of the reference's ``bnn.models.resnet.ResNet`` (resnet.py:93-101,147-164)."""
+    return all(isinstance(getattr(model, a, None), nn.Module) for a in
+               ("conv1", "bn1", "maxpool", "layer1", "layer2", "layer3", "layer4", "avgpool", "fc")) and \
+        all(isinstance(getattr(model, a), nn.Sequential) for a in ("layer1", "layer2", "layer3", "layer4")) and \
+        getattr(model, "stem_type", "basic") == "basic"
+
+
 def _activation(act: nn.Module):
     if isinstance(act, nn.ReLU):
         return True, None
@@ -152,11 +191,12 @@ class FusedResNet(nn.Module):
         # a down-sampling block's shortcut conv (AvgPool -> binary 1x1 -> BN) computed inside its last conv
         self.fold_shortcut = fold_shortcut
         self._side = {}
-        if not isinstance(model, ResNet) or model.stem_type != "basic":
-            raise FusionError("FusedResNet covers bnn_amd.models.ResNet with the 'basic' stem")
+        if not resnet_shaped(model):
+            raise FusionError("FusedResNet covers ResNets laid out like bnn.models.resnet.ResNet with the 'basic' stem")
         self.model = model
         self._blocks: List[dict] = []
         self._graph = None
+        self._split = collections.OrderedDict()   # (input shape, stream) -> _Split (forward_fresh)
         self.refresh()
 
     def _conv(self, conv, bn, act) -> _Conv:
@@ -195,6 +235,7 @@ class FusedResNet(nn.Module):
         if dev.type != "cuda":
             raise FusionError("FusedResNet needs the model on a HIP device")
         self._blocks = []
+        self._split.clear()     # graphs behind the stem hold pointers to the derived data rebuilt below
         self._stem = None
         self._names = {id(mod): name for name, mod in m.named_modules()}
         mp = m.maxpool
@@ -230,14 +271,15 @@ class FusedResNet(nn.Module):
         if isinstance(blk, nn.AvgPool2d):   # HBlock stages pool in front (bnn_amd/models/resnet.py)
             self._blocks.append({"kind": "pool", "mod": blk})
             return
-        if type(blk) is PreBasicBlock:      # BN-conv-act, BN-conv-act, (+id)   (res_block.py:147-152)
+        kind = _block_kind(blk)
+        if kind is PreBasicBlock:           # BN-conv-act, BN-conv-act, (+id)   (res_block.py:147-152)
             entry = {"kind": "pre", "bn1": fold_bn(blk.bn1), "bn2": fold_bn(blk.bn2),
                      "convs": [self._conv(blk.conv1, None, blk.act1), self._conv(blk.conv2, None, blk.act2)],
                      "ds": None, "pool": 0}
             self._shortcut(blk, entry)
             self._blocks.append(entry)
             return
-        if type(blk) is HBlock:             # three BN-act-conv stages, cat, (+id)  (hierarchical_block.py:38-60)
+        if kind is HBlock:                  # three BN-act-conv stages, cat, (+id)  (hierarchical_block.py:38-60)
             entry = {"kind": "h", "planes": blk.conv1.out_channels * 2,
                      "bn": [fold_bn(blk.bn1), fold_bn(blk.bn2), fold_bn(blk.bn3)],
                      "relu": [self._sign_through(a) for a in (blk.act1, blk.act2, blk.act3)],
@@ -248,9 +290,9 @@ class FusedResNet(nn.Module):
                 entry["ds"] = (fold_bn(bn), self._conv(conv, None, None))
             self._blocks.append(entry)
             return
-        if type(blk) is BasicBlock:      # conv-BN-act, conv-BN-(+id)-act
+        if kind is BasicBlock:           # conv-BN-act, conv-BN-(+id)-act
             convs = [self._conv(blk.conv1, blk.bn1, blk.act1), self._conv(blk.conv2, blk.bn2, blk.act2)]
-        elif type(blk) is Bottleneck:    # 1x1-BN-act, 3x3-BN-act, 1x1-BN-(+id)-act  (res_block.py:98-118)
+        elif kind is Bottleneck:         # 1x1-BN-act, 3x3-BN-act, 1x1-BN-(+id)-act  (res_block.py:98-118)
             convs = [self._conv(blk.conv1, blk.bn1, blk.act1), self._conv(blk.conv2, blk.bn2, blk.act2),
                      self._conv(blk.conv3, blk.bn3, blk.act3)]
         else:
@@ -279,20 +321,27 @@ class FusedResNet(nn.Module):
 
     @torch.no_grad()
     def _forward_impl(self, x: torch.Tensor) -> torch.Tensor:
+        return self._back(*self._front(x))
+
+    def _front(self, x: torch.Tensor, out=None):
+        """The part that reads the input tensor: the real-valued stem (first layer stays float: examples/cifar10.py:71)
+        -> (fp32 NCHW, sign planes).  ``out``: the results of an earlier call to overwrite (one-kernel stem only)."""
         m = self.model
-        # real-valued stem (first layer stays float: examples/cifar10.py:71): the conv runs in the
-        # vendor library (MFMA), its BN -> ReLU -> MaxPool -> sign tail in one HBM pass
         if self._stem_mfma:
-            t, packed = hipops.stem7x7(x, m.conv1.weight, self._stem[0], self._stem[1],
-                                       exact_fp32=self.stem_exact_fp32, fp16=self.stem_fp16)
-        elif self._stem is not None:
+            return hipops.stem7x7(x, m.conv1.weight, self._stem[0], self._stem[1],
+                                  exact_fp32=self.stem_exact_fp32, fp16=self.stem_fp16, out=out)
+        if out is not None:
+            raise FusionError("only the one-kernel stem writes into preallocated buffers")
+        if self._stem is not None:   # the conv runs in the vendor library, its BN -> ReLU -> MaxPool -> sign tail in one pass
             t = m.conv1(x)
-            t, packed = hipops.bn_relu_maxpool_pack(t, self._stem[0], self._stem[1], True, *self._stem[2])
-        else:
-            t = m.maxpool(m.relu(m.bn1(m.conv1(x))))
-            packed = hipops.pack_act(t)
+            return hipops.bn_relu_maxpool_pack(t, self._stem[0], self._stem[1], True, *self._stem[2])
+        t = m.maxpool(m.relu(m.bn1(m.conv1(x))))
+        return t, hipops.pack_act(t)
+
+    def _back(self, t, packed) -> torch.Tensor:
+        """Everything behind the stem: residual blocks + real-valued head (last layer stays float)."""
+        m = self.model
         t = self._run_blocks(t, packed)
-        # real-valued head (last layer stays float)
         if self._head is not None:
             return hipops.avgpool_fc(t, *self._head)
         return m.fc(torch.flatten(m.avgpool(t), 1))
@@ -367,31 +416,38 @@ class FusedResNet(nn.Module):
         return t
 
     def _fold_applies(self, b, packed) -> bool:
-        """Whether the block's shortcut convolution can be computed inside its last convolution (decided once per
-        block from the first batch: shapes and recipes do not change).  Needs: non-negative sign planes in front of
-        the block (an OR-pool then IS the avg-pool's sign), a bias-free 1x1 / stride-1 shortcut conv without post
-        scale or zero weights, a last conv whose kernel takes the fold (``hipops.shortcut_fold_supported``) and whose
+        """Whether the block's shortcut convolution can be computed inside its last convolution.  The recipe part is
+        decided once per block; the kernel part (``hipops.shortcut_fold_supported``) depends on the geometry — image
+        size and the images one launch covers (large batches are split) — and is cached per geometry.  Needs:
+        non-negative sign planes in front of the block (an OR-pool then IS the avg-pool's sign), a bias-free 1x1 /
+        stride-1 shortcut conv without post scale or zero weights, a last conv whose kernel takes the fold and whose
         fp32 output and sign planes are both wanted (a block in the middle of the net)."""
-        if not self.fold_shortcut:
+        if not self.fold_shortcut or not packed.nonneg:
             return False
-        if "fold" not in b:
-            ds, c2 = b["ds"], b["convs"][-1]
-            lay = ds.layer
-            ok = (packed.nonneg and lay.bias is None and ds.plan.scale is None and not ds.relu and ds.prelu is None
-                  and tuple(lay.kernel_size) == (1, 1) and tuple(lay.stride) == (1, 1) and tuple(lay.padding) == (0, 0)
-                  and not ds.weight.has_zero and b is not self._blocks[-1] and len(b["convs"]) >= 2
-                  and all(c.relu and c.prelu is None for c in b["convs"][:-1])
-                  and c2.relu and c2.prelu is None and c2.layer.bias is None and c2.plan.scale is None)
-            if ok:
-                N, _, H, W = packed.shape
-                k = max(b["pool"], 1)
-                ho, wo = -(-H // k), -(-W // k)
-                c2l = c2.layer
-                probe = hipops.PackedAct(packed.P, packed.M, (N, c2l.in_channels, ho, wo), nonneg=True)
-                ok = hipops.shortcut_fold_supported(probe, c2.weight, lay.in_channels, c2l.stride, c2l.padding,
-                                                    c2l.dilation, throughput=c2.throughput)
-            b["fold"] = bool(ok)
-        return b["fold"]
+        ds, c2 = b["ds"], b["convs"][-1]
+        lay, c2l = ds.layer, c2.layer
+        if "fold_recipe" not in b:
+            b["fold_recipe"] = bool(
+                lay.bias is None and ds.plan.scale is None and not ds.relu and ds.prelu is None
+                and tuple(lay.kernel_size) == (1, 1) and tuple(lay.stride) == (1, 1) and tuple(lay.padding) == (0, 0)
+                and not ds.weight.has_zero and b is not self._blocks[-1] and len(b["convs"]) >= 2
+                and all(c.relu and c.prelu is None for c in b["convs"][:-1])
+                and c2.relu and c2.prelu is None and c2.layer.bias is None and c2.plan.scale is None)
+            b["fold_geo"] = {}
+        if not b["fold_recipe"]:
+            return False
+        N, _, H, W = packed.shape
+        k = max(b["pool"], 1)
+        ho, wo = -(-H // k), -(-W // k)
+        n_launch = hipops.fused_launch_images(N, c2l.in_channels, ho, wo, c2l.out_channels, c2l.kernel_size,
+                                              c2l.stride, c2l.padding, c2l.dilation)
+        key = (n_launch, ho, wo)
+        ok = b["fold_geo"].get(key)
+        if ok is None:
+            probe = hipops.PackedAct(packed.P, packed.M, (n_launch, c2l.in_channels, ho, wo), nonneg=True)
+            ok = b["fold_geo"][key] = bool(hipops.shortcut_fold_supported(
+                probe, c2.weight, lay.in_channels, c2l.stride, c2l.padding, c2l.dilation, throughput=c2.throughput))
+        return ok
 
     def _side_stream(self, device) -> torch.cuda.Stream:
         key = (device.index, torch.cuda.current_stream(device).cuda_stream)
@@ -451,11 +507,7 @@ class FusedResNet(nn.Module):
                      for t in itertools.chain(self.model.parameters(), self.model.buffers()))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if self._signature() != self._sig:        # weights changed since the packed forms were derived
-            recapture = self._graph is not None
-            self.refresh()
-            if recapture:
-                self.capture(self._gx)
+        self._check_current()
         if self._graph is not None and x.shape == self._gx.shape:
             if x.data_ptr() != self._gx.data_ptr():   # callers that fill `static_input` in place skip the copy
                 self._gx.copy_(x, non_blocking=True)
@@ -489,6 +541,74 @@ class FusedResNet(nn.Module):
         self._graph = g
         return self
 
+    # ---- fresh input every call: the stem reads the CALLER's tensor, a HIP graph replays the rest ------------------
+    MAX_SPLIT_GRAPHS = 4
+
+    @property
+    def reads_caller_tensor(self) -> bool:
+        """True when ``forward_fresh`` applies (the stem is the one-kernel MFMA stem)."""
+        return bool(self._stem_mfma)
+
+    def _check_current(self) -> None:
+        if self._signature() != self._sig:        # weights changed since the packed forms were derived
+            recapture = self._graph is not None
+            self.refresh()
+            if recapture:
+                self.capture(self._gx)
+
+    @torch.no_grad()
+    def capture_fresh(self, example: torch.Tensor) -> "_Split":
+        """HIP graph of everything BEHIND the stem for inputs shaped like ``example``.  The stem stays an ordinary
+        launch that reads whatever tensor the caller passes and writes the graph's two static inputs (its fp32 output
+        and sign planes) — so a new input tensor per call costs no staging copy (154 MB at batch 256) and no
+        re-capture, and the host issues two calls per forward instead of 21."""
+        if not self._stem_mfma:
+            raise FusionError("forward_fresh needs the one-kernel stem (7x7/2/3 conv + BN + ReLU + 3/2/1 max-pool)")
+        dev = example.device
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            t0, pk0 = self._front(example)          # allocated on the stream that will replay (the key holds it)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._back(t0, pk0)
+            cur.wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                gy = self._back(t0, pk0)
+        return _Split(g, t0, pk0, gy)
+
+    @torch.no_grad()
+    def forward_fresh(self, x: torch.Tensor, clone: bool = True) -> torch.Tensor:
+        """``forward`` for a caller that brings a NEW tensor every call (the reference's eval loop,
+        examples/cifar10.py:147-149): stem launch on ``x`` + graph replay of the rest.  The graph for an input shape is
+        captured on its first use (per stream; at most ``MAX_SPLIT_GRAPHS`` are kept).  Returns a fresh tensor unless
+        ``clone=False`` (then: the graph's output buffer, overwritten by the next call with this shape)."""
+        self._check_current()
+        x = hipops._require_cuda_f32(x, "stem input")
+        dev = x.device
+        with torch.cuda.device(dev):
+            key = (tuple(x.shape), torch.cuda.current_stream(dev).cuda_stream)
+            sp = self._split.get(key)
+            if sp is None:
+                sp = self._split[key] = self.capture_fresh(x)
+                while len(self._split) > self.MAX_SPLIT_GRAPHS:
+                    self._split.popitem(last=False)
+            else:
+                self._split.move_to_end(key)
+            self._front(x, out=(sp.t0, sp.pk0))
+            sp.graph.replay()
+            return sp.gy.clone() if clone else sp.gy
+
+
+@dataclass
+class _Split:
+    graph: "torch.cuda.CUDAGraph"
+    t0: torch.Tensor            # static fp32 output of the stem
+    pk0: hipops.PackedAct       # static sign planes of the stem
+    gy: torch.Tensor            # static logits
+
 
 class FusedBlocks(FusedResNet):
     """The fused executor for a bare ``nn.Sequential`` of residual blocks (``BasicBlock`` / ``Bottleneck`` /
@@ -507,6 +627,8 @@ class FusedBlocks(FusedResNet):
         self.model = blocks
         self._blocks = []
         self._graph = None
+        self._split = collections.OrderedDict()
+        self._stem_mfma = False
         self.refresh()
 
     def refresh(self) -> None:
@@ -539,19 +661,28 @@ class PipelinedInference:
             logits = pipe.launch(i)                            # valid after pipe.wait(i) / synchronize()
     """
 
-    def __init__(self, model: nn.Module, example: torch.Tensor, n_streams: int = 2, **fused_kwargs) -> None:
+    def __init__(self, model: nn.Module, example: torch.Tensor, n_streams: int = 2, fresh_input: bool = False,
+                 **fused_kwargs) -> None:
+        """``fresh_input``: every ``launch(i, x)`` reads the tensor the caller passes (stem launch on ``x`` + HIP graph
+        of the rest, ``FusedResNet.forward_fresh``) instead of a static input buffer the caller has to fill."""
         if n_streams < 1:
             raise ValueError("n_streams must be >= 1")
         dev = example.device
         env = os.environ.get("BNN_AMD_THROUGHPUT")   # "0" / "1": override for experiments
         fused_kwargs.setdefault("throughput_mode", n_streams > 1 if env is None else env == "1")
+        self.fresh_input = fresh_input
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
         self.engines: List[FusedResNet] = []
         cur = torch.cuda.current_stream(dev)
         for s in self.streams:
             s.wait_stream(cur)
             with torch.cuda.stream(s):
-                self.engines.append(FusedResNet(model, **fused_kwargs).capture(example))
+                eng = FusedResNet(model, **fused_kwargs)
+                if fresh_input:
+                    eng.forward_fresh(example, clone=False)      # captures the graph behind the stem for this stream
+                else:
+                    eng.capture(example)
+                self.engines.append(eng)
         for s in self.streams:
             cur.wait_stream(s)
 
@@ -564,11 +695,20 @@ class PipelinedInference:
     def stream(self, i: int) -> torch.cuda.Stream:
         return self.streams[i % len(self.streams)]
 
-    def launch(self, i: int) -> torch.Tensor:
-        """Replay slot ``i % n`` on its stream with whatever its static input holds; returns the slot's
-        logits buffer (overwritten by the next launch of the same slot)."""
+    def launch(self, i: int, x: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Replay slot ``i % n`` on its stream — with whatever its static input holds, or (``fresh_input``) reading
+        ``x`` directly (the caller keeps ``x`` alive and unchanged until the slot's stream has passed the launch; work
+        that produced ``x`` on another stream must be ordered before it by the caller, e.g.
+        ``pipe.stream(i).wait_stream(...)``).  Returns the slot's logits buffer (overwritten by the next launch of
+        the same slot)."""
         k = i % len(self.engines)
         with torch.cuda.stream(self.streams[k]):
+            if self.fresh_input:
+                if x is None:
+                    raise ValueError("PipelinedInference(fresh_input=True).launch needs the input tensor")
+                return self.engines[k].forward_fresh(x, clone=False)
+            if x is not None:
+                self.engines[k].static_input.copy_(x, non_blocking=True)
             return self.engines[k](self.engines[k].static_input)
 
     def wait(self, i: int) -> None:
@@ -577,6 +717,199 @@ class PipelinedInference:
     def synchronize(self) -> None:
         for s in self.streams:
             s.synchronize()
+
+
+_PER_LAYER = 0
+
+
+@contextlib.contextmanager
+def per_layer_forward():
+    """While active (process-wide), ``model(x)`` never takes the fused executor: every layer runs on its own, the way
+    the reference evaluates a model (tests and ``bench.py --engine layerwise`` compare the two paths with it)."""
+    global _PER_LAYER
+    _PER_LAYER += 1
+    try:
+        yield
+    finally:
+        _PER_LAYER -= 1
+
+
+class AutoFusion:
+    """What makes the reference's own call fast: ``net = prepare_binary_model(...)``, ``net.eval()``, ``net(x)`` under
+    ``torch.no_grad()`` (examples/cifar10.py:71,140-149) runs the fused executor instead of one launch per layer plus
+    torch BatchNorm / ReLU / add round trips through HBM.
+
+    One instance lives in ``model.__dict__['_bnn_auto']`` (not a sub-module: ``state_dict`` and ``repr`` are those of
+    the reference).  ``run(model, x)`` returns the logits, or ``None`` when the call has to take the model's own
+    per-layer forward: training mode or autograd recording, CPU / non-fp32 input, a ``DataParallel`` replica (its
+    parameters are re-broadcast every forward), forward hooks registered on inner modules (they would not fire), a
+    model the executor does not cover (``FusionError``, remembered until the parameters change), or
+    ``BNN_AMD_AUTOFUSE=0``.
+
+    Policy: the first batch of a given shape runs the fused launches eagerly (21 for ResNet-18); from the second one
+    on the stem reads the caller's tensor and a HIP graph replays the rest (``FusedResNet.forward_fresh``) — the last,
+    ragged batch of an epoch never pays for a capture.  A model built from classes of another package (same names
+    and layout: the reference's ``bnn.models``) is fused only after its first fused result has been checked against
+    its own forward on the same input (logits within ``VERIFY_TOL`` relative to the largest one)."""
+
+    VERIFY_TOL = 2e-2       # a flipped sign() moves a logit by a few per cent (DESIGN.md section 2); a wrong graph by O(1)
+    CAPTURE_AFTER = 1       # eager calls of a shape before its graph is captured
+
+    def __init__(self) -> None:
+        self.engine: Optional[FusedResNet] = None
+        self.failed_sig = None          # parameter signature for which fusion was refused
+        self.reason: Optional[str] = None
+        self.verified = False
+        self.seen = collections.Counter()
+        self.lock = threading.Lock()
+        self.calls = {"graph": 0, "eager": 0, "declined": 0}
+
+    def __deepcopy__(self, memo):       # copy.deepcopy(model): the copy derives its own executor
+        return AutoFusion()
+
+    def __reduce__(self):               # pickling / torch.save(model): derived data is not saved
+        return (AutoFusion, ())
+
+    def reset(self) -> None:
+        with self.lock:
+            self.engine, self.failed_sig, self.reason, self.verified = None, None, None, False
+            self.seen.clear()
+
+    @staticmethod
+    def enabled() -> bool:
+        return _PER_LAYER == 0 and os.environ.get("BNN_AMD_AUTOFUSE", "1") != "0"
+
+    @staticmethod
+    def _hooked(model: nn.Module) -> bool:
+        import torch.nn.modules.module as _mm
+        if _mm._global_forward_hooks or _mm._global_forward_pre_hooks:
+            return True
+        return any(m._forward_hooks or m._forward_pre_hooks for m in model.modules() if m is not model)
+
+    def run(self, model: nn.Module, x: torch.Tensor) -> Optional[torch.Tensor]:
+        if (model.training or torch.is_grad_enabled() or not isinstance(x, torch.Tensor) or not x.is_cuda
+                or x.dtype != torch.float32 or x.dim() != 4 or x.shape[0] == 0
+                or getattr(model, "_is_replica", False) or not self.enabled() or not native.available()):
+            self.calls["declined"] += 1
+            return None
+        with self.lock:
+            eng = self.engine
+            if eng is None:
+                sig = _param_signature(model)
+                if self.failed_sig == sig:
+                    self.calls["declined"] += 1
+                    return None
+                try:
+                    eng = FusedResNet(model)
+                except FusionError as exc:
+                    self.failed_sig, self.reason = sig, str(exc)
+                    self.calls["declined"] += 1
+                    return None
+                self.engine, self.verified = eng, is_native_model(model)
+            if eng.model.fc.weight.device != x.device or self._hooked(model):
+                self.calls["declined"] += 1
+                return None
+            try:
+                return self._run_locked(eng, model, x)
+            except FusionError as exc:      # e.g. parameters moved to the CPU since the executor was built
+                self.engine, self.failed_sig, self.reason = None, _param_signature(model), str(exc)
+                self.calls["declined"] += 1
+                return None
+
+    def _run_locked(self, eng: "FusedResNet", model: nn.Module, x: torch.Tensor) -> torch.Tensor:
+        if not self.verified:
+            y = eng(x)
+            n = min(2, x.shape[0])
+            want = getattr(type(model), "_bnn_base", type(model)).forward(model, x[:n])   # the class's OWN forward
+            err = float((y[:n] - want).abs().max() / want.abs().max().clamp_min(1e-30))
+            if not err <= self.VERIFY_TOL:
+                self.engine, self.failed_sig = None, _param_signature(model)
+                self.reason = f"fused result differs from the model's own forward (relative {err:.3g})"
+                warnings.warn(f"bnn_amd: {type(model).__name__}: {self.reason}; keeping the per-layer path",
+                              RuntimeWarning)
+                self.calls["declined"] += 1
+                return None
+            self.verified = True
+            self.calls["eager"] += 1
+            self.seen[(tuple(x.shape), torch.cuda.current_stream(x.device).cuda_stream)] += 1
+            return y
+        key = (tuple(x.shape), torch.cuda.current_stream(x.device).cuda_stream)
+        if eng.reads_caller_tensor and (key in eng._split or self.seen[key] >= self.CAPTURE_AFTER):
+            self.calls["graph"] += 1
+            return eng.forward_fresh(x)
+        self.seen[key] += 1
+        if len(self.seen) > 64:
+            self.seen.clear()
+        self.calls["eager"] += 1
+        return eng(x)
+
+
+def _param_signature(model: nn.Module):
+    return tuple((id(t), t.data_ptr(), t._version) for t in itertools.chain(model.parameters(), model.buffers()))
+
+
+def auto_fusion(model: nn.Module) -> AutoFusion:
+    """The model's ``AutoFusion`` state (created on first use)."""
+    st = model.__dict__.get("_bnn_auto")
+    if st is None:
+        st = model.__dict__["_bnn_auto"] = AutoFusion()
+    return st
+
+
+def auto_forward(model: nn.Module, x: torch.Tensor) -> Optional[torch.Tensor]:
+    """Called at the top of ``bnn_amd.models.ResNet.forward``: fused logits, or None -> the caller's own forward."""
+    return auto_fusion(model).run(model, x)
+
+
+_AUTO_CLASSES: dict = {}
+
+
+def _auto_class(base: type) -> type:
+    """``base`` with the dispatch of ``bnn_amd.models.ResNet.forward`` in front of its own ``forward``: a subclass made
+    on the fly (one per base class), the way ``torch.nn.utils.parametrize`` injects behaviour into a module instance.
+    A class — not an instance attribute — so that ``DataParallel`` replicas (``replicate`` copies ``__dict__``), deep
+    copies and pickles of the model each dispatch on THEMSELVES; name, module and repr stay those of ``base``."""
+    dyn = _AUTO_CLASSES.get(base)
+    if dyn is None:
+        def forward(self, x, *args, **kwargs):
+            if not args and not kwargs and isinstance(x, torch.Tensor) and x.is_cuda and not self.training \
+                    and not torch.is_grad_enabled():
+                y = auto_forward(self, x)
+                if y is not None:
+                    return y
+            return base.forward(self, x, *args, **kwargs)
+
+        def __reduce_ex__(self, protocol):      # pickle / deepcopy: rebuilt from the importable base class
+            return (_rebuild_auto, (base,), self.__dict__)
+
+        dyn = type(base.__name__, (base,), {"forward": forward, "__reduce_ex__": __reduce_ex__, "_bnn_base": base,
+                                            "__module__": base.__module__, "__qualname__": base.__qualname__,
+                                            "__doc__": base.__doc__})
+        _AUTO_CLASSES[base] = dyn
+    return dyn
+
+
+def _rebuild_auto(base: type):
+    cls = _auto_class(base)
+    return cls.__new__(cls)
+
+
+def install_auto_fusion(model: nn.Module) -> bool:
+    """Give a ResNet of ANOTHER package (laid out like the reference's ``bnn.models.resnet.ResNet``) the same
+    dispatch ``bnn_amd.models.ResNet.forward`` has: "fused executor when it applies, else the class's own forward".
+    ``prepare_binary_model`` calls this for the model it converted; returns whether the model was recognised (and was
+    not dispatching already).  Undo with ``uninstall_auto_fusion``."""
+    if isinstance(model, ResNet) or hasattr(type(model), "_bnn_base") or not resnet_shaped(model):
+        return False
+    model.__class__ = _auto_class(type(model))
+    return True
+
+
+def uninstall_auto_fusion(model: nn.Module) -> None:
+    base = getattr(type(model), "_bnn_base", None)
+    if base is not None:
+        model.__class__ = base
+    model.__dict__.pop("_bnn_auto", None)
 
 
 def optimize_for_inference(model: nn.Module) -> nn.Module:

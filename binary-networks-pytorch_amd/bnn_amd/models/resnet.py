@@ -19,6 +19,11 @@ import torch.nn as nn
 from .blocks import BasicBlock, Bottleneck, HBlock, PreBasicBlock, PreBottleneck, conv1x1
 
 
+def _auto_forward(model, x):
+    from ..inference import auto_forward      # (inference imports this module)
+    return auto_forward(model, x)
+
+
 class DaBNNStem(nn.Module):
     """Cheaper stem of daBNN (``resnet.py:10-47``): 3x3-s2 -> (1x1 -> 3x3-s2 | maxpool) -> 1x1."""
 
@@ -131,6 +136,12 @@ class ResNet(nn.Module):
         return nn.Sequential(*stage)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        # eval + no_grad on a HIP device: the fused executor (bnn_amd/inference.py: AutoFusion) — what makes the
+        # reference's own call `outputs = net(inputs)` (examples/cifar10.py:140-149) the fast path.  None -> per layer.
+        if not self.training and x.is_cuda and not torch.is_grad_enabled():
+            y = _auto_forward(self, x)
+            if y is not None:
+                return y
         x = self.conv1(x)
         if self.stem_type == "basic":
             x = self.maxpool(self.relu(self.bn1(x)))

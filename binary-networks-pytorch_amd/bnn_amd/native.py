@@ -19,13 +19,11 @@ OCB = 32
 FLAG_FORCE_GENERIC = 1
 FLAG_WEIGHT_ZEROS = 2
 FLAG_WEIGHTS_SGPR = 4
-FLAG_WEIGHTS_LDS = 8
 FLAG_ACT_NONNEG = 32
 FLAG_THROUGHPUT = 64
 STEM_EXACT_FP32 = 1
 STEM_FP16 = 4
-STEM_STAGED = 8
-ABI_VERSION = 11
+ABI_VERSION = 12
 DTYPE_F32 = 0
 DTYPE_F16 = 1
 
@@ -40,6 +38,7 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_grad_weight_pack_bytes", "bnn_hip_grad_pack_weight_f32", "bnn_hip_bconv_grad_input_f32",
     "bnn_hip_bconv_grad_weight_splits", "bnn_hip_bconv_grad_weight_f32",
     "bnn_hip_bconv2d_direct", "bnn_hip_bconv2d_direct_plan", "bnn_hip_shortcut_fold_supported",
+    "bnn_hip_probe_clock",
 )
 
 
@@ -151,6 +150,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_bconv_grad_weight_f32.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
     lib.bnn_hip_probe_int_alu.argtypes = [_i, _i, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), _vp]
+    lib.bnn_hip_probe_clock.argtypes = [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _vp]
 
 
 def load() -> Optional[ctypes.CDLL]:

@@ -29,6 +29,37 @@ def shard_batch(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     return x[lo:hi]
 
 
+def _host_staged(group) -> bool:
+    """gloo moves host memory: device tensors are staged through the host around the collective.  Only tests and
+    ``bench.py --backend gloo`` (several ranks on ONE GPU, which RCCL refuses) come this way; it synchronises the
+    stream, which the RCCL path never does."""
+    return dist.get_backend(group) == "gloo"
+
+
+def all_gather_rows(y: torch.Tensor, group=None) -> torch.Tensor:
+    """``[n, ...]`` per rank -> ``[world * n, ...]`` on every rank, rank r's rows in block r: ONE collective
+    (``all_gather_into_tensor`` — RCCL ``ncclAllGather`` on the current stream)."""
+    world = dist.get_world_size(group)
+    if y.is_cuda and _host_staged(group):
+        host = y.cpu()
+        out = host.new_empty((world * host.shape[0],) + tuple(host.shape[1:]))
+        dist.all_gather_into_tensor(out, host, group=group)
+        return out.to(y.device)
+    out = y.new_empty((world * y.shape[0],) + tuple(y.shape[1:]))
+    dist.all_gather_into_tensor(out, y, group=group)
+    return out
+
+
+def all_gather_scalar(value, device, dtype=torch.float64, group=None) -> list:
+    """One number per rank -> the list of all ranks' numbers (bench bookkeeping: step times, shard sizes)."""
+    world = dist.get_world_size(group)
+    dev = torch.device("cpu") if _host_staged(group) else device
+    mine = torch.tensor([value], device=dev, dtype=dtype)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
+    return [t.item() for t in every]
+
+
 class ShardedInference(nn.Module):
     """Wraps a (replicated) model: ``forward(local_batch)`` returns the logits of ALL ranks."""
 
@@ -49,17 +80,12 @@ class ShardedInference(nn.Module):
         world = dist.get_world_size(self.group)
         if world == 1:
             return y
-        sizes = [None] * world
         # ragged shards (batch not divisible by world) are padded to the largest shard
-        n_local = torch.tensor([y.shape[0]], device=y.device, dtype=torch.int64)
-        all_n = [torch.zeros_like(n_local) for _ in range(world)]
-        dist.all_gather(all_n, n_local, group=self.group)
-        sizes = [int(t.item()) for t in all_n]
+        sizes = [int(n) for n in all_gather_scalar(y.shape[0], y.device, torch.int64, self.group)]
         n_max = max(sizes)
         if y.shape[0] < n_max:
             y = torch.cat([y, y.new_zeros((n_max - y.shape[0],) + y.shape[1:])], 0)
-        out = y.new_empty((world * n_max,) + y.shape[1:])
-        dist.all_gather_into_tensor(out, y, group=self.group)
+        out = all_gather_rows(y, self.group)
         if all(s == n_max for s in sizes):
             return out
         return torch.cat([out[r * n_max: r * n_max + sizes[r]] for r in range(world)], 0)
@@ -71,6 +97,4 @@ class ShardedInference(nn.Module):
         if not (dist.is_available() and dist.is_initialized()) or \
                 (dist.get_world_size(self.group) == 1 and not self.force_collective):
             return y
-        out = y.new_empty((dist.get_world_size(self.group) * y.shape[0],) + y.shape[1:])
-        dist.all_gather_into_tensor(out, y, group=self.group)
-        return out
+        return all_gather_rows(y, self.group)

@@ -208,86 +208,6 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
 }
 
 // ---------------------------------------------------------------------------------
-// Tiled kernel, weights staged in LDS.  A workgroup = 4 waves = 256 pixels sharing one
-// (ob, chunk) weight tile; every wave reads the tile with wave-uniform (broadcast)
-// ds_read_b128.  Best when many output-channel blocks are in flight at once (small images,
-// wide layers: ResNet layer3/layer4), where the scalar cache thrashes and every s_load pays
-// an L2 round trip.
-// ---------------------------------------------------------------------------------
-constexpr int kLdsWaves = 4;
-
-template <int KH, int KW, int CWC>
-__global__ __launch_bounds__(kLdsWaves* kWave) void bconv_lds_kernel(
-    const uint32_t* __restrict__ P, const uint32_t* __restrict__ M, const uint32_t* __restrict__ W,
-    BNN_EPI_PARAMS, const Geo g) {
-  constexpr int T = KH * KW;
-  constexpr int NW = T * CWC;
-  constexpr int TILE = kOCB * NW;          // words per (ob, chunk) weight tile
-  constexpr int NV = (TILE + 3) / 4;       // uint4 pieces
-  constexpr int NT = kLdsWaves * kWave;    // threads
-  constexpr int PER = (NV + NT - 1) / NT;  // pieces per thread
-  __shared__ __attribute__((aligned(16))) uint32_t wl[2][NV * 4];
-  BNN_EPI_INIT;
-  const Pix px = decode_pixel(g, blockIdx.x * NT + threadIdx.x);
-  const int ob = blockIdx.y;
-  const bool active = ob * kOCB < g.O;
-
-  int acc[kOCB];
-#pragma unroll
-  for (int j = 0; j < kOCB; ++j) acc[j] = 0;
-  int nz = 0;
-
-  if (active) {
-    const uint4* wsrc = reinterpret_cast<const uint4*>(W + (size_t)ob * g.nchunk * TILE);
-    uint4 stage[PER];
-    auto fetch = [&](int ch) {
-#pragma unroll
-      for (int k = 0; k < PER; ++k) {
-        const int v = threadIdx.x + k * NT;
-        if (v < NV) stage[k] = wsrc[(size_t)ch * NV + v];
-      }
-    };
-    auto commit = [&](int buf) {
-#pragma unroll
-      for (int k = 0; k < PER; ++k) {
-        const int v = threadIdx.x + k * NT;
-        if (v < NV) reinterpret_cast<uint4*>(wl[buf])[v] = stage[k];
-      }
-    };
-    fetch(0);
-    commit(0);
-    for (int ch = 0; ch < g.nchunk; ++ch) {
-      const int buf = ch & 1;
-      __syncthreads();  // tile `ch` is in wl[buf]; everyone is done reading wl[buf^1]
-      if (ch + 1 < g.nchunk) fetch(ch + 1);  // global -> registers, lands during the VALU work
-      uint32_t pr[NW], mr[NW];
-      load_field<KH, KW, CWC>(g, px, ch, P, M, pr, mr);
-      nz = count_nonzero<NW>(pr, mr, nz);
-      const uint32_t* wt = wl[buf];
-#pragma unroll
-      for (int j = 0; j < kOCB; ++j) {
-        int t0 = 0, t1 = 0;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-          const uint32_t d = disagree(wt[j * NW + i], mr[i], pr[i]);  // uniform address: broadcast
-          if (i & 1) t1 = popc_acc(d, t1);
-          else t0 = popc_acc(d, t0);
-        }
-        acc[j] += t0 + t1;
-      }
-      if (ch + 1 < g.nchunk) commit(buf ^ 1);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < kOCB; ++j) acc[j] = nz - 2 * acc[j];  // dot = non-zero count - 2 * disagreements
-  uint32_t pbits = 0u, mbits = 0u;
-  float resv[kOCB];
-  prefetch_residual<kOCB, EP_RUNTIME>(g, px, ob * kOCB, epi, resv);
-  epilogue<kOCB, EP_RUNTIME>(g, px, ob * kOCB, acc, resv, epi, pbits, mbits);
-  store_packed(g, px, ob, pbits, mbits, epi);
-}
-
-// ---------------------------------------------------------------------------------
 // Generic kernel: any KH/KW/stride/pad/dilation/cwc, optional zero-weight mask.
 // One lane = one output pixel, one wave = 64 pixels x 32 output channels in 4 passes of 8.
 // ---------------------------------------------------------------------------------
@@ -360,17 +280,6 @@ __global__ __launch_bounds__(64) void bconv_generic_kernel(
 // ---------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------
-#define BNN_EPI_ACTUALS \
-  p.alpha, p.bias, p.scale, p.bn_a, p.bn_b, p.prelu, p.res, p.out, p.outP, p.outM, p.pack_a, p.pack_b, p.thr
-#define BNN_DS_ACTUALS p.ds_P, p.ds_W, p.ds_alpha, p.ds_a, p.ds_b
-
-// grid.y: one block per 32 output channels; in pack mode also the (all-zero) tail words of the
-// packed output row so that every word of the next layer's input is written.
-static unsigned oblocks(const ConvP& p) {
-  const unsigned nb = (p.O + kOCB - 1) / kOCB;
-  return (p.outP && p.outM) ? (unsigned)(2 * ((p.O + 63) / 64)) : nb;
-}
-
 #ifndef BNN_SGPR_PASSES  // passes per 32-channel block, single-chunk 3x3 layers
 #define BNN_SGPR_PASSES 4
 #endif
@@ -541,14 +450,6 @@ static void launch_sgpr(const ConvP& p, int flags, hipStream_t s) {
   else launch_sgpr_e<KH, KW, CWC, EP_PLAIN>(p, g, nn, so, s);
 }
 
-template <int KH, int KW, int CWC>
-static void launch_lds(const ConvP& p, hipStream_t s) {
-  constexpr int NT = kLdsWaves * kWave;
-  const dim3 grid((p.npix + NT - 1) / NT, oblocks(p));
-  hipLaunchKernelGGL((bconv_lds_kernel<KH, KW, CWC>), grid, dim3(NT), 0, s, p.P, p.M, p.W,
-                     BNN_EPI_ACTUALS, make_geo(p));
-}
-
 static void launch_generic(const ConvP& p, bool wz, hipStream_t s) {
   const dim3 grid((p.npix + kWave - 1) / kWave, oblocks(p));
   if (wz)
@@ -571,17 +472,16 @@ int choose_cwc(int cw32, int KH, int KW) {
   return 2;
 }
 
-// Weight source.  Measured on MI355X (tools/bench_conv.py, tools/exp_l4.py): the SGPR stream
-// beats the LDS-staged tile on every ResNet-18 shape (512->512 7x7 b256: 100 us SGPR, 216 us LDS;
-// a vector-broadcast weight path measured 162 us and was removed), so the LDS tile is only taken
-// on request.
-static bool prefer_lds(const ConvP&, int flags) { return (flags & BNN_HIP_FLAG_WEIGHTS_LDS) != 0; }
+// Weight source: the scalar-cache stream into SGPRs.  The alternative north_star names — weight tiles staged in LDS per
+// 4-wave workgroup — was built and measured slower on every ResNet-18 shape (512->512 7x7 b256: 216 vs 100 us; a
+// vector-broadcast weight path measured 162 us); it lives on as a test-only cross-check in csrc/legacy/bconv_lds.hip
+// (libbnn_hip_legacy.so), not in this library.
 
 // Whether launch_bconv() would run this convolution in a kernel that can take the folded shortcut branch (ConvP::ds_*):
 // a tiled 3x3 layer on non-negative activations without zero weights, conv2-type epilogue (BN + residual + ReLU ->
 // fp32 + sign planes), 64 / 128 / 256 shortcut channels.
 bool ds_fold_applies(const ConvP& p, int flags) {
-  if ((flags & (BNN_HIP_FLAG_FORCE_GENERIC | BNN_HIP_FLAG_WEIGHT_ZEROS | BNN_HIP_FLAG_WEIGHTS_LDS)) ||
+  if ((flags & (BNN_HIP_FLAG_FORCE_GENERIC | BNN_HIP_FLAG_WEIGHT_ZEROS)) ||
       !(flags & BNN_HIP_FLAG_ACT_NONNEG))
     return false;
   if (p.KH != 3 || p.KW != 3 || p.dh != 1 || p.dw != 1 || !small_indices(p) || (p.cwc != 2 && p.cwc != 4)) return false;
@@ -596,12 +496,10 @@ int launch_bconv(const ConvP& p, int flags, hipStream_t s) {
   const bool generic = (flags & BNN_HIP_FLAG_FORCE_GENERIC) || p.dh != 1 || p.dw != 1 || !small_indices(p);
   bool done = false;
   if (!generic) {
-    const bool lds = prefer_lds(p, flags);
     done = true;
 #define BNN_PICK(KH_, KW_, C_, PROF_)                           \
   if (p.KH == KH_ && p.KW == KW_ && p.cwc == C_) {              \
-    if (lds && PROF_ && !wz) launch_lds<KH_, KW_, C_>(p, s);    \
-    else launch_sgpr<KH_, KW_, C_, PROF_>(p, flags, s);         \
+    launch_sgpr<KH_, KW_, C_, PROF_>(p, flags, s);              \
   } else
     BNN_PICK(3, 3, 4, true) BNN_PICK(3, 3, 2, true) BNN_PICK(1, 1, 16, false)
     BNN_PICK(1, 1, 8, false) BNN_PICK(1, 1, 4, false) BNN_PICK(1, 1, 2, false) { done = false; }

@@ -850,6 +850,18 @@ __device__ __forceinline__ void stream_weights_wz(const uint32_t* __restrict__ w
 // ---------------------------------------------------------------------------------
 // q / d for 0 <= q < 2^31 as (q * m) >> (32 + s)  (Granlund & Montgomery: m = ceil(2^(31+l) / d), l = ceil(log2 d),
 // s = l - 1; m < 2^32 for d >= 2); d == 1 is flagged with s = -1.
+// host-side launch helpers shared by bconv.hip and legacy/bconv_lds.hip
+#define BNN_EPI_ACTUALS \
+  p.alpha, p.bias, p.scale, p.bn_a, p.bn_b, p.prelu, p.res, p.out, p.outP, p.outM, p.pack_a, p.pack_b, p.thr
+#define BNN_DS_ACTUALS p.ds_P, p.ds_W, p.ds_alpha, p.ds_a, p.ds_b
+
+// grid.y: one block per 32 output channels; in pack mode also the (all-zero) tail words of the
+// packed output row so that every word of the next layer's input is written.
+inline unsigned oblocks(const ConvP& p) {
+  const unsigned nb = (p.O + kOCB - 1) / kOCB;
+  return (p.outP && p.outM) ? (unsigned)(2 * ((p.O + 63) / 64)) : nb;
+}
+
 inline void div_magic(uint32_t d, uint32_t& m, int& s) {
   if (d <= 1) { m = 0; s = -1; return; }
   int l = 0;

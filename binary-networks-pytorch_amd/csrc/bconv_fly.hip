@@ -802,9 +802,11 @@ template <class K>
 int launch_k(K kernel, const ConvP& p, const void* x, const Geo& g, const FlyGeo& f, int nbands, int waves,
              hipStream_t s) {
   const size_t lds = (size_t)f.lds16 * 16;
-  // per device and per kernel: set on every launch (cheap, and correct in a process that drives several GPUs)
+  // per device and per kernel: set on every launch (cheap, and correct in a process that drives several GPUs) — to
+  // ONE constant, the CU's whole LDS, never to this launch's own size: two threads launching different layer shapes
+  // must not be able to lower each other's limit between the set and the launch
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds) != hipSuccess)
+                          kMaxDynamicLds) != hipSuccess)
     return BNN_HIP_ERR_LAUNCH;
   hipLaunchKernelGGL(kernel, dim3((unsigned)nbands), dim3((unsigned)waves * kWave), lds, s, x, p.W, p.Z, p.alpha,
                      p.bias, p.scale, p.out, g, f);

@@ -11,6 +11,10 @@
 namespace bnn {
 
 constexpr int kWave = 64;          // CDNA wavefront
+// hipFuncAttributeMaxDynamicSharedMemorySize for every kernel that can ask for more than 64 KB of dynamic LDS: ONE
+// constant (the CU's whole LDS), never a launch's own size — a per-launch value set from two threads could be lowered
+// between one thread's set and its launch.
+constexpr int kMaxDynamicLds = 160 * 1024;
 constexpr int kOCB = BNN_HIP_OCB;  // output channels per weight block
 
 // Disagreement word of 32 ternary activations against 32 binary weights.
@@ -121,8 +125,10 @@ int launch_bn_relu_maxpool_pack(const float* x, int N, int C, int H, int W, cons
                                 uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_stem(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                 int W, int flags, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
+// csrc/legacy/ (libbnn_hip_legacy.so, test-only): the round-2 stem kernel and the LDS-staged weight tile
 int launch_stem_split(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                       int W, int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
+int launch_bconv_lds(const ConvP& p, hipStream_t s);
 int launch_stem_rows(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                       int W, int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_avgpool_fc(const float* x, const float* wt, const float* bias, float* out, int N, int C, int HW,
@@ -145,5 +151,6 @@ bool fly_supported(const ConvP& p);
 int fly_default_plan(const ConvP& p, int flags, bnn_hip_fly_plan* plan);
 int launch_bconv_fly(const ConvP& p, const void* x, int x_half, int flags, const bnn_hip_fly_plan* plan, hipStream_t s);
 int launch_probe_int_alu(int mode, int iters, double* lane_ops_per_s, double* elapsed_ms, hipStream_t s);
+int launch_probe_clock(int spin_iters, double* shader_mhz, double* elapsed_us, hipStream_t s);
 
 }  // namespace bnn

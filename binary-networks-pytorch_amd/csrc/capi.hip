@@ -1,7 +1,10 @@
 // capi.hip — the extern "C" boundary declared in include/bnn_hip.h.
 // Argument validation, geometry, workspace carving and launch bookkeeping live here;
 // kernels live in pack_act.hip / pack_weight.hip / bconv.hip.
+#include <dlfcn.h>
+
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 
 #include "bnn_dev.h"
@@ -9,6 +12,36 @@
 namespace {
 
 std::atomic<uint64_t> g_launches{0};
+
+// roctx ranges around every launching entry point (the reference's users profile with named ranges):
+// off unless BNN_HIP_ROCTX=1 is in the environment when the first entry point runs.  The marker library is dlopen'ed —
+// libbnn_hip.so has no link-time dependency on a profiler — and a box without it silently runs without ranges.
+// rocprofv3 --marker-trace shows one range per C-ABI call, named after it.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* e = std::getenv("BNN_HIP_ROCTX");
+    if (!e || e[0] != '1') return;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (push && pop) return;
+        push = nullptr; pop = nullptr;
+      }
+    }
+  }
+};
+const Roctx& roctx() { static const Roctx r; return r; }
+struct Range {
+  bool on;
+  explicit Range(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+  ~Range() { if (on) roctx().pop(); }
+  Range(const Range&) = delete;
+  Range& operator=(const Range&) = delete;
+};
+#define BNN_RANGE() Range bnn_range_(__func__)
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -18,6 +51,9 @@ constexpr long long kMaxElems = (1LL << 31) - 1;
 // of one launch stay below 2^30 elements, packed planes (uint64 per 64 channels per pixel) below 2^29 words
 constexpr long long kMaxConvElems = (1LL << 30) - 1;
 constexpr long long kMaxPlaneWords = (1LL << 29) - 1;
+// tensors addressed through a sized 32-bit buffer descriptor (stem input / output, one-launch layer input): the
+// out-of-range marker offsets the kernels use for dead lanes (0xFFFFFFF0 + small immediates) must stay out of range
+constexpr long long kMaxDescBytes = 0xFFFFFE00LL;
 
 int out_dim(int in, int k, int s, int p, int d) { return (in + 2 * p - d * (k - 1) - 1) / s + 1; }
 
@@ -75,6 +111,8 @@ int run_conv(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M, c
     if (!bnn::ds_fold_applies(p, d->flags)) return BNN_HIP_ERR_UNSUPPORTED;
   }
   g_launches.fetch_add(1, std::memory_order_relaxed);
+  Range range(p.raw ? "bnn_hip_bconv2d_dot" : p.ds_P ? "bnn_hip_bconv2d_fused+shortcut"
+              : (p.bn_a || p.res || p.outP || p.relu || p.prelu) ? "bnn_hip_bconv2d_fused" : "bnn_hip_bconv2d");
   return bnn::launch_bconv(p, d->flags, static_cast<hipStream_t>(stream));
 }
 
@@ -143,6 +181,7 @@ int bnn_hip_pack_act_f32(const float* x, int N, int C, int H, int W, uint64_t* P
   if ((C + 63) / 64 > 65535) return BNN_HIP_ERR_UNSUPPORTED;  // grid.y limit
   if (!aligned(P, 8) || !aligned(M, 8) || !aligned(x, 4)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
   return bnn::launch_pack_act(x, N, C, H, W, P, M, static_cast<hipStream_t>(stream));
 }
 
@@ -153,6 +192,7 @@ int bnn_hip_pack_act_f16(const void* x, int N, int C, int H, int W, uint64_t* P,
   if ((C + 63) / 64 > 65535) return BNN_HIP_ERR_UNSUPPORTED;  // grid.y limit
   if (!aligned(P, 8) || !aligned(M, 8) || !aligned(x, 2)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
   return bnn::launch_pack_act_f16(x, N, C, H, W, P, M, static_cast<hipStream_t>(stream));
 }
 
@@ -164,6 +204,7 @@ int bnn_hip_bn_act_pack_f32(const float* x, int N, int C, int H, int W, const fl
   if ((C + 63) / 64 > 65535) return BNN_HIP_ERR_UNSUPPORTED;  // grid.y limit
   if (!aligned(P, 8) || !aligned(M, 8) || !aligned(x, 4)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
   return bnn::launch_bn_act_pack(x, N, C, H, W, bn_scale, bn_shift, relu, P, M,
                                  static_cast<hipStream_t>(stream));
 }
@@ -175,6 +216,7 @@ int bnn_hip_avgpool_pack_f32(const float* x, int N, int C, int H, int W, int k, 
   if (2 * ((C + 63) / 64) > 65535) return BNN_HIP_ERR_UNSUPPORTED;
   if (!aligned(P, 8) || !aligned(M, 8)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
   return bnn::launch_avgpool_pack(x, N, C, H, W, k, P, M, static_cast<hipStream_t>(stream));
 }
 
@@ -184,6 +226,7 @@ int bnn_hip_orpool_packed(const uint64_t* P, int N, int C, int H, int W, int k, 
   if ((long long)N * ((C + 63) / 64) * H * W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
   if (!aligned(P, 8) || !aligned(out_P, 8) || !aligned(out_M, 8)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
   return bnn::launch_orpool_packed(P, N, C, H, W, k, out_P, out_M, static_cast<hipStream_t>(stream));
 }
 
@@ -200,6 +243,7 @@ int bnn_hip_bn_relu_maxpool_pack_f32(const float* x, int N, int C, int H, int W,
   if ((long long)N * C * H * W > 4 * kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
   if (P && (!aligned(P, 8) || !aligned(M, 8))) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
   return bnn::launch_bn_relu_maxpool_pack(x, N, C, H, W, bn_scale, bn_shift, relu, k, stride, pad,
                                           out_f32, P, M, static_cast<hipStream_t>(stream));
 }
@@ -209,14 +253,20 @@ int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w, const 
                                           float* out_f32, uint64_t* P, uint64_t* M, void* stream) {
   if (!x || !w || !bn_scale || !bn_shift || N <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
   if (!out_f32 && !P) return BNN_HIP_ERR_INVALID_ARG;
-  if (flags & ~(BNN_HIP_STEM_EXACT_FP32 | BNN_HIP_STEM_FP16 | BNN_HIP_STEM_STAGED)) return BNN_HIP_ERR_INVALID_ARG;
-  if ((flags & BNN_HIP_STEM_EXACT_FP32) && (flags & (BNN_HIP_STEM_FP16 | BNN_HIP_STEM_STAGED)))
-    return BNN_HIP_ERR_INVALID_ARG;
+  if (flags & ~(BNN_HIP_STEM_EXACT_FP32 | BNN_HIP_STEM_FP16)) return BNN_HIP_ERR_INVALID_ARG;
+  if ((flags & BNN_HIP_STEM_EXACT_FP32) && (flags & BNN_HIP_STEM_FP16)) return BNN_HIP_ERR_INVALID_ARG;
   if ((P == nullptr) != (M == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
   if (P && (!aligned(P, 8) || !aligned(M, 8))) return BNN_HIP_ERR_INVALID_ARG;
-  if ((long long)N * 3 * H * W > kMaxElems || (long long)N * 64 * H * W / 16 > kMaxElems)
-    return BNN_HIP_ERR_TOO_LARGE;
+  // the stem kernels address x and out through 32-bit buffer descriptors (range-checked loads are the zero padding,
+  // out-of-range stores are dropped): every tensor of a launch stays below 2^32 - 16 bytes (4 GiB: ~7100 images of
+  // 224 x 224 in, ~5300 out) — larger batches are split by the caller (hipops.stem7x7 does)
+  {
+    const long long hc = (H - 1) / 2 + 1, wc = (W - 1) / 2 + 1, hp = (hc - 1) / 2 + 1, wp = (wc - 1) / 2 + 1;
+    if ((long long)N * 3 * H * W * 4 > kMaxDescBytes || (long long)N * 64 * hp * wp * 4 > kMaxDescBytes)
+      return BNN_HIP_ERR_TOO_LARGE;
+  }
   g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
   return bnn::launch_stem(x, w, bn_scale, bn_shift, N, H, W, flags, out_f32, P, M,
                           static_cast<hipStream_t>(stream));
 }
@@ -227,6 +277,7 @@ int bnn_hip_avgpool_fc_f32(const float* x, int N, int C, int HW, const float* w_
   if (!aligned(x, 4) || !aligned(w_t, 4) || !aligned(out, 4)) return BNN_HIP_ERR_INVALID_ARG;
   if ((long long)N * C * HW > 4 * kMaxElems || (long long)N * O > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
   g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
   return bnn::launch_avgpool_fc(x, w_t, bias, out, N, C, HW, O, static_cast<hipStream_t>(stream));
 }
 
@@ -242,6 +293,7 @@ int bnn_hip_grad_pack_weight_f32(const float* w_hat, int O, int C, int ksize, vo
   if (!grad_ks_ok(ksize)) return BNN_HIP_ERR_UNSUPPORTED;
   if (!aligned(packed, 16)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(2, std::memory_order_relaxed);
+  BNN_RANGE();
   return bnn::launch_grad_pack_weight(w_hat, O, C, ksize, packed, alpha, static_cast<hipStream_t>(stream));
 }
 
@@ -260,6 +312,7 @@ int bnn_hip_bconv_grad_input_f32(const float* g, const float* alpha, const void*
   if (st != BNN_HIP_OK) return st;
   if (!aligned(packed, 16)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
   return bnn::launch_dgrad(g, alpha, packed, x, gx, N, O, C, H, W, ksize, stride, static_cast<hipStream_t>(stream));
 }
 
@@ -274,6 +327,7 @@ int bnn_hip_bconv_grad_weight_f32(const float* g, const float* x, float* partial
   const int st = check_grad_shape(N, O, C, H, W, ksize, stride);
   if (st != BNN_HIP_OK) return st;
   g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
   return bnn::launch_wgrad(g, x, partial, splits, N, O, C, H, W, ksize, stride, static_cast<hipStream_t>(stream));
 }
 
@@ -285,6 +339,7 @@ int bnn_hip_pack_weight_f32(const float* w, int O, int C, int KH, int KW, int ce
   const int st = bnn_hip_weight_layout(O, C, KH, KW, &L);
   if (st != BNN_HIP_OK) return st;
   g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
   return bnn::launch_pack_weight(w, O, C, KH, KW, center, compute_alpha, L, wbits, wnz, alpha,
                                  zero_flag, static_cast<hipStream_t>(stream));
 }
@@ -348,6 +403,7 @@ int bnn_hip_sign_thresholds_f32(const float* alpha, const float* bias, const flo
   if ((bn_scale == nullptr) != (bn_shift == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
   if (!aligned(thresholds, 4)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
   return bnn::launch_sign_thresholds(alpha, bias, post_scale, bn_scale, bn_shift, O, kmax, thresholds,
                                      static_cast<hipStream_t>(stream));
 }
@@ -376,6 +432,10 @@ static int fly_convp(const bnn_hip_conv_desc* d, bnn::ConvP* out) {
   const int st = check_desc(d, &Ho, &Wo);
   if (st != BNN_HIP_OK) return st;
   if ((long long)d->N * d->C * d->H * d->W > kMaxConvElems) return BNN_HIP_ERR_TOO_LARGE;
+  // the kernel reads x through a sized buffer descriptor and marks dead lanes with offset 0xFFFFFFF0 (+ soffset): a
+  // tensor within a few elements of 2^32 bytes would bring the marker in range.  UNSUPPORTED, not TOO_LARGE: the
+  // two-launch form (pack_act + conv) of the same layer has no such limit and callers fall back to it
+  if ((long long)d->N * d->C * d->H * d->W * 4 > kMaxDescBytes) return BNN_HIP_ERR_UNSUPPORTED;
   bnn::ConvP p = empty_convp();
   bnn_hip_wlayout L;
   bnn_hip_weight_layout(d->O, d->C, d->KH, d->KW, &L);
@@ -410,6 +470,7 @@ int bnn_hip_bconv2d_direct(const bnn_hip_conv_desc* d, const void* x, int x_dtyp
   if (st != BNN_HIP_OK) return st;
   p.W = wbits; p.Z = wnz; p.alpha = alpha; p.bias = bias; p.scale = post_scale; p.out = out;
   g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
   return bnn::launch_bconv_fly(p, x, x_dtype == BNN_HIP_DTYPE_F16, d->flags, plan, static_cast<hipStream_t>(stream));
 }
 
@@ -450,6 +511,11 @@ int bnn_hip_probe_int_alu(int mode, int iters, double* lane_ops_per_s, double* e
   if (iters <= 0 || !lane_ops_per_s) return BNN_HIP_ERR_INVALID_ARG;
   return bnn::launch_probe_int_alu(mode, iters, lane_ops_per_s, elapsed_ms,
                                    static_cast<hipStream_t>(stream));
+}
+
+int bnn_hip_probe_clock(int spin_iters, double* shader_mhz, double* elapsed_us, void* stream) {
+  if (spin_iters <= 0 || spin_iters > (1 << 24) || !shader_mhz) return BNN_HIP_ERR_INVALID_ARG;
+  return bnn::launch_probe_clock(spin_iters, shader_mhz, elapsed_us, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -594,12 +594,17 @@ int launch_wgrad(const float* g, const float* xin, float* part, int splits, int 
   if (ks == 1) {
     hipLaunchKernelGGL((wgrad_kernel<1, 1, kWgradNC1>), grid, dim3(NT), lds, s, g, xin, part, q, per);
   } else if (stride == 2) {
-    // up to 82 KB of dynamic LDS (7x7 outputs) needs the opt-in: per device and per kernel, set on every launch
+    // more than 64 KB of dynamic LDS (82 KB for 7x7 outputs) needs the opt-in: per device and per kernel, set on every
+    // launch, always to the same constant (the CU's whole LDS)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<2, 3, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds) != hipSuccess)
       return BNN_HIP_ERR_LAUNCH;
     hipLaunchKernelGGL((wgrad_kernel<2, 3, 2>), grid, dim3(NT), lds, s, g, xin, part, q, per);
   } else {
+    // three bf16 planes: 69 KB at widths 33..64 (the 56x56 layers)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1, 3, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds) != hipSuccess)
+      return BNN_HIP_ERR_LAUNCH;
     hipLaunchKernelGGL((wgrad_kernel<1, 3, 2>), grid, dim3(NT), lds, s, g, xin, part, q, per);
   }
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;

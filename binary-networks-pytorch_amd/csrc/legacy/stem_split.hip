@@ -1,3 +1,6 @@
+// TEST-ONLY since round 4 (libbnn_hip_legacy.so; never loaded by the product path): the round-2 stem kernel, kept as an
+// independent implementation that tests/test_gpu_fused.py compares the default kernel (csrc/stem_rows.hip) with,
+// bit for bit.  Until ABI 11 it rode in libbnn_hip.so behind BNN_HIP_STEM_STAGED.
 // stem_split.hip — default arithmetic of the fused stem (see stem.hip for the layer and the exact mode):
 // fp32 operands split into fp16 hi + lo, product = hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with
 // fp32 accumulation (measured 3e-7 relative to an fp64 reference: the rounding class of an fp32 conv).
@@ -22,7 +25,7 @@
 //  * max-pool reads each staged conv value ~3x instead of 9x: a thread owns one pooled COLUMN of one
 //    channel (9 row maxima -> 4 outputs); the sign bits of 8 channels are gathered with one ballot and
 //    leave as whole 64-bit words one tile later (byte stores from several waves into one word are slow).
-#include "bnn_dev.h"
+#include "../bnn_dev.h"
 
 #ifndef BNN_STEM_ABL  // timing ablations only (wrong results): 1 matrix, 2 epilogue, 4 pooling, 8 fetch
 #define BNN_STEM_ABL 0

@@ -129,4 +129,38 @@ int launch_probe_int_alu(int mode, int iters, double* lane_ops_per_s, double* el
   return st;
 }
 
+// Engine (shader) clock right now: one wave reads the shader-clock counter (s_memtime) and the constant-rate
+// counter (s_memrealtime, hipDeviceAttributeWallClockRate kHz) around a dependent ALU chain; their ratio is the
+// clock the SIMDs ran at.  bench.py calls it straight after a timed region, on the same stream: DVFS moves on a
+// millisecond scale, so the ~30 us sample is the clock the preceding kernels had.
+__global__ __launch_bounds__(64) void clock_probe_kernel(int iters, unsigned long long* out) {
+  uint32_t a = threadIdx.x;
+  const unsigned long long c0 = clock64(), r0 = wall_clock64();
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int i = 0; i < iters; ++i) asm volatile("v_add_u32 %0, %0, %0\n\tv_add_u32 %0, %0, %0" : "+v"(a));
+#endif
+  const unsigned long long c1 = clock64(), r1 = wall_clock64();
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; out[2] = a; }
+}
+
+int launch_probe_clock(int spin_iters, double* shader_mhz, double* elapsed_us, hipStream_t s) {
+  int dev = 0, wall_khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return BNN_HIP_ERR_NO_DEVICE;
+  if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || wall_khz <= 0)
+    return BNN_HIP_ERR_UNSUPPORTED;
+  unsigned long long* out = nullptr;
+  if (hipHostMalloc(reinterpret_cast<void**>(&out), 3 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess)
+    return BNN_HIP_ERR_LAUNCH;
+  out[0] = out[1] = 0;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, s, spin_iters, out);
+  int st = (hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess) ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+  if (st == BNN_HIP_OK && out[1] == 0) st = BNN_HIP_ERR_UNSUPPORTED;
+  if (st == BNN_HIP_OK) {
+    *shader_mhz = (double)out[0] / (double)out[1] * (double)wall_khz * 1e-3;
+    if (elapsed_us) *elapsed_us = (double)out[1] / (double)wall_khz * 1e3;
+  }
+  (void)hipHostFree(out);
+  return st;
+}
+
 }  // namespace bnn

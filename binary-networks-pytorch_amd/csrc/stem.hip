@@ -294,8 +294,6 @@ static int launch_stem_t(const float* x, const float* w, const float* bn_a, cons
 int launch_stem(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                 int W, int flags, float* out, uint64_t* P, uint64_t* M, hipStream_t stream) {
   if (flags & BNN_HIP_STEM_EXACT_FP32) return launch_stem_t<false>(x, w, bn_a, bn_b, N, H, W, out, P, M, stream);
-  if (flags & BNN_HIP_STEM_STAGED)  // the round-2 kernel: an independent implementation for cross-checks
-    return launch_stem_split(x, w, bn_a, bn_b, N, H, W, (flags & BNN_HIP_STEM_FP16) != 0, out, P, M, stream);
   return launch_stem_rows(x, w, bn_a, bn_b, N, H, W, (flags & BNN_HIP_STEM_FP16) != 0, out, P, M, stream);
 }
 

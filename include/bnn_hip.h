@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define BNN_HIP_ABI_VERSION 11
+#define BNN_HIP_ABI_VERSION 12
 #define BNN_HIP_OCB 32 /* output channels per weight block (padding granularity of O) */
 
 typedef enum bnn_hip_status {
@@ -88,7 +88,8 @@ typedef struct bnn_hip_conv_desc {
 #define BNN_HIP_FLAG_FORCE_GENERIC 1 /* use the shape-generic kernel even if a tiled one exists */
 #define BNN_HIP_FLAG_WEIGHT_ZEROS 2  /* some sign(W) == 0: honour the wnz mask (slower kernel)  */
 #define BNN_HIP_FLAG_WEIGHTS_SGPR 4  /* tiled kernel: force the scalar-cache weight stream       */
-#define BNN_HIP_FLAG_WEIGHTS_LDS 8   /* tiled kernel: force the LDS-staged weight tile           */
+/* bit 8 (BNN_HIP_FLAG_WEIGHTS_LDS until ABI 11: the LDS-staged weight tile, 2x slower than the scalar-cache stream on
+ * every shape) is ignored since ABI 12; that kernel is a test-only cross-check now (csrc/legacy/).            */
 #define BNN_HIP_FLAG_ACT_NONNEG 32   /* caller vouches that the M plane is ALL ZERO (activations
                                         out of a ReLU / max-pool of a ReLU are {0,+1}): 3x3 kernels
                                         then keep only the P plane in registers.  M must still be a
@@ -266,10 +267,10 @@ int bnn_hip_bn_relu_maxpool_pack_f32(const float* x, int N, int C, int H, int W,
 /* Plain fp16 operands, one MFMA per product, fp32 accumulation (the "fp16 MFMA stem" of BASELINE config 5):
  * ~5e-4 relative error instead of ~3e-7, one third of the matrix work.  Opt-in; not with EXACT_FP32.        */
 #define BNN_HIP_STEM_FP16 4
-/* The round-2 kernel of the same arithmetic (conv tile staged through LDS, pooled from there; stem_split.hip) instead
- * of the default one (max-pool in the MFMA accumulators, stem_rows.hip).  Bit-identical results, ~20 % slower: kept
- * as an independent implementation the tests compare the default kernel with.  With flags 0 or STEM_FP16 only.   */
-#define BNN_HIP_STEM_STAGED 8
+/* (flag 8, BNN_HIP_STEM_STAGED until ABI 11 — the round-2 kernel of the same arithmetic — is rejected since ABI 12:
+ * that kernel is a test-only cross-check now, csrc/legacy/stem_split.hip in libbnn_hip_legacy.so.)
+ * Every tensor of a launch stays below 2^32 - 512 bytes (32-bit buffer descriptors): BNN_HIP_ERR_TOO_LARGE above
+ * that — split the batch (~7100 images of 224 x 224 per launch).                                                    */
 int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w,
                                           const float* bn_scale, const float* bn_shift,
                                           int N, int H, int W, int flags,
@@ -413,6 +414,12 @@ int bnn_hip_bconv2d_f32(const bnn_hip_conv_desc* d, const float* x,
  * Synchronous (hipEvents on `stream`, temporary hipMalloc); not part of the inference path. */
 int bnn_hip_probe_int_alu(int mode, int iters, double* lane_ops_per_s, double* elapsed_ms,
                           void* stream);
+
+/* The engine (shader) clock at this moment, MHz: one wave reads the shader-clock counter (s_memtime) and the
+ * constant-rate counter (s_memrealtime) around `spin_iters` dependent ALU steps (10000 ~ 20 us).  Issued on `stream`
+ * right behind a timed region it reports the clock those kernels ran at (DVFS moves on a millisecond scale) — the
+ * figure bench.py prints next to every sustained number.  Synchronous; not part of the inference path.            */
+int bnn_hip_probe_clock(int spin_iters, double* shader_mhz, double* elapsed_us, void* stream);
 
 #ifdef __cplusplus
 }

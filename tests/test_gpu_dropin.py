@@ -1,0 +1,245 @@
+"""The reference's own call at the speed the bench quotes:
+
+    net = prepare_binary_model(resnet18(), bconfig, custom_config_layers_name={'conv1': BConfig(), 'fc': BConfig()})
+    net.eval();  with torch.no_grad(): outputs = net(inputs)           # examples/cifar10.py:61-71,140-149
+
+takes the fused executor — first batch of a shape as eager launches (21 for ResNet-18), from the second one on as
+"stem launch on the caller's tensor + HIP graph of the rest" (bnn_amd/inference.py: AutoFusion, forward_fresh) — and
+is bit-identical to FusedResNet(net)(x).  Everything that has to keep the per-layer path (training, autograd, hooks on
+inner modules, uncovered models, foreign classes whose fused result does not check out) is covered too."""
+import copy
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import bnn_amd as bnn
+from bnn_amd import fastpath, native
+from bnn_amd.inference import (AutoFusion, FusedResNet, PipelinedInference, auto_fusion, install_auto_fusion,
+                               per_layer_forward)
+from bnn_amd.models import PreBasicBlock, resnet18
+from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer
+from tests.golden import gen
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(a).to(DEV)
+
+
+def _cfg():
+    return bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
+                       weight_pre_process=XNORWeightBinarizer)
+
+
+def _load(net, seed=1):
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in gen.model_state(shapes, seed).items()})
+    return net.to(DEV).eval()
+
+
+def _r18(**kw):
+    net = bnn.prepare_binary_model(resnet18(**kw), _cfg(), custom_config_layers_name={
+        "conv1": bnn.BConfig(), "fc": bnn.BConfig()})
+    return _load(net)
+
+
+def test_net_call_runs_the_fused_executor_and_equals_it_bit_for_bit():
+    net = _r18()
+    xs = [dev(gen.normal(70 + i, (8, 3, 64, 64))) for i in range(4)]      # a NEW tensor every call
+    want = [FusedResNet(net)(x).clone() for x in xs]
+    st = auto_fusion(net)
+    with torch.no_grad():
+        per_layer0, launches0 = fastpath.stats()["conv2d"], native.launch_count()
+        y0 = net(xs[0])
+        # first batch of this shape: the 21 eager launches of the fused executor (stem, 16 convs with the shortcut
+        # convs folded in, 3 OR-pools, head) — and nothing through the per-layer path
+        assert native.launch_count() - launches0 == 21 and fastpath.stats()["conv2d"] == per_layer0
+        assert st.calls == {"graph": 0, "eager": 1, "declined": 0} and st.engine is not None
+        ys = [y0]
+        for x in xs[1:]:
+            launches0 = native.launch_count()
+            ys.append(net(x))
+            # the stem reads the caller's tensor (the capture call runs the network's launches eagerly first)
+            assert native.launch_count() - launches0 >= 1
+        assert st.calls["graph"] == 3 and len(st.engine._split) == 1
+        launches0 = native.launch_count()
+        y_again = net(xs[1])
+        assert native.launch_count() - launches0 == 1        # steady state: ONE launch through the C-ABI + a graph replay
+    for y, w in zip(ys, want):
+        assert torch.equal(y, w)                             # results are the caller's own tensors: later calls did
+    assert torch.equal(y_again, want[1])                     # not overwrite earlier ones
+    assert len({y.data_ptr() for y in ys}) == len(ys)
+    assert fastpath.stats()["conv2d"] == per_layer0
+
+
+def test_ragged_last_batch_and_other_shapes_take_eager_fused_launches():
+    net = _r18()
+    fused = FusedResNet(net)
+    with torch.no_grad():
+        for shape in [(8, 3, 64, 64), (8, 3, 64, 64), (5, 3, 64, 64), (2, 3, 96, 80), (8, 3, 64, 64)]:
+            x = dev(gen.normal(sum(shape), shape))
+            assert torch.equal(net(x), fused(x))
+    st = auto_fusion(net)
+    assert st.calls == {"graph": 2, "eager": 3, "declined": 0}
+
+
+def test_what_keeps_the_per_layer_path():
+    net = _r18()
+    x = dev(gen.normal(5, (4, 3, 64, 64)))
+    st = auto_fusion(net)
+    n0 = fastpath.stats()["conv2d"]
+    y_grad = net(x)                                  # autograd recording: the per-layer path (training kernels)
+    assert st.calls["declined"] == 0 and st.engine is None      # (ResNet.forward does not even ask)
+    with torch.no_grad():
+        with per_layer_forward():
+            y_layer = net(x)
+        assert fastpath.stats()["conv2d"] == n0 + 19 and st.calls["declined"] == 1
+        handle = net.layer2[0].conv1.register_forward_hook(lambda m, i, o: None)
+        y_fused = net(x)                             # builds the executor, then sees the hook: declined
+        assert fastpath.stats()["conv2d"] == n0 + 38 and st.calls["declined"] == 2
+        handle.remove()
+        y_fused = net(x)
+        assert st.calls["eager"] == 1 and fastpath.stats()["conv2d"] == n0 + 38
+        net.train()
+        net(x)
+        net.eval()
+        assert st.calls["eager"] == 1
+    assert torch.allclose(y_fused, y_layer, rtol=1e-3, atol=1e-3 * float(y_layer.abs().max()))
+    assert torch.allclose(y_grad.detach(), y_layer, rtol=1e-3, atol=1e-3 * float(y_layer.abs().max()))
+
+
+def test_parameter_updates_are_seen_by_the_next_call():
+    net = _r18()
+    x = dev(gen.normal(6, (4, 3, 64, 64)))
+    with torch.no_grad():
+        y0 = net(x)
+        y0b = net(x)                                  # graph captured
+        assert torch.equal(y0, y0b)
+        _load(net, seed=2)                            # load_state_dict writes in place: version counters move
+        y1 = net(x)
+        assert not torch.equal(y0, y1)
+        assert torch.equal(y1, FusedResNet(net)(x))
+        assert torch.equal(net(x), y1)
+        with per_layer_forward():
+            y_layer = net(x)
+    assert torch.allclose(y1, y_layer, rtol=1e-3, atol=1e-3 * float(y_layer.abs().max()))
+
+
+def test_data_parallel_wrapper_and_deepcopy_and_state_dict():
+    net = _r18()
+    keys = list(net.state_dict().keys())
+    x = dev(gen.normal(8, (4, 3, 64, 64)))
+    with torch.no_grad():
+        y = net(x)
+        wrapped = nn.DataParallel(net, device_ids=[0])          # examples/cifar10.py:74-77 on a one-GPU box
+        assert torch.equal(wrapped(x), y)
+        twin = copy.deepcopy(net)
+        assert auto_fusion(twin) is not auto_fusion(net) and auto_fusion(twin).engine is None
+        assert torch.equal(twin(x), y)
+    assert list(net.state_dict().keys()) == keys and "_bnn_auto" not in repr(net)
+
+
+def test_uncovered_model_keeps_its_own_forward_silently():
+    net = bnn.prepare_binary_model(resnet18(stem_type="dabnn"), _cfg(), ignore_layers_name=["_first_", "_last_"])
+    net = net.to(DEV).eval()
+    x = dev(gen.normal(9, (2, 3, 64, 64)))
+    with torch.no_grad():
+        y = net(x)
+        y2 = net(x)
+    st = auto_fusion(net)
+    assert st.engine is None and st.reason and st.calls["declined"] == 2 and torch.equal(y, y2)
+
+
+# ---- a ResNet of ANOTHER package, laid out like the reference's bnn.models.resnet.ResNet ---------------------------
+
+def _foreign_classes(residual: bool):
+    from tests.helpers import foreign_resnet
+    return lambda: foreign_resnet.ResNet(residual)
+
+
+def test_foreign_resnet_gets_the_dispatch_from_prepare_binary_model():
+    net = bnn.prepare_binary_model(_foreign_classes(True)(), _cfg(), custom_config_layers_name={
+        "conv1": bnn.BConfig(), "fc": bnn.BConfig()})
+    assert hasattr(type(net), "_bnn_base") and type(net).__name__ == "ResNet"     # install_auto_fusion ran
+    assert not install_auto_fusion(net)                  # ... once
+    net = _load(net)
+    x = dev(gen.normal(11, (4, 3, 64, 64)))
+    # same state_dict keys as bnn_amd's resnet18: the same weights give the same logits
+    ours = _r18()
+    with torch.no_grad():
+        n0 = fastpath.stats()["conv2d"]
+        y = net(x)                                       # fused + checked against the class's own forward on 2 images
+        st = auto_fusion(net)
+        assert st.verified and st.calls["eager"] == 1 and fastpath.stats()["conv2d"] == n0 + 19
+        n0, l0 = fastpath.stats()["conv2d"], native.launch_count()
+        y2 = net(x)
+        assert fastpath.stats()["conv2d"] == n0 and st.calls["graph"] == 1
+        assert torch.equal(y, y2) and torch.equal(y, FusedResNet(ours)(x))
+        with per_layer_forward():
+            y_layer = net(x)
+    assert torch.allclose(y, y_layer, rtol=1e-3, atol=1e-3 * float(y_layer.abs().max()))
+
+
+def test_foreign_class_with_the_same_names_but_other_arithmetic_is_not_fused():
+    net = bnn.prepare_binary_model(_foreign_classes(False)(), _cfg(), custom_config_layers_name={
+        "conv1": bnn.BConfig(), "fc": bnn.BConfig()})
+    net = _load(net)
+    x = dev(gen.normal(12, (4, 3, 64, 64)))
+    with torch.no_grad():
+        with per_layer_forward():
+            want = net(x)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            y = net(x)
+        assert any("differs from the model's own forward" in str(m.message) for m in w)
+        st = auto_fusion(net)
+        assert st.engine is None and not st.verified
+        assert torch.equal(y, want) and torch.equal(net(x), want)      # its own forward, now and later
+
+
+def test_prebasicblock_prelu_net_through_the_model_call():
+    """The reference's other shipping dataflow (examples/imagenet.py:153-155) through `net(x)`."""
+    net = bnn.prepare_binary_model(resnet18(block_type=PreBasicBlock, activation=nn.PReLU), _cfg(),
+                                   ignore_layers_name=["_first_", "_last_"])
+    net = _load(net)
+    x = dev(gen.normal(13, (4, 3, 64, 64)))
+    with torch.no_grad():
+        y = net(x)
+        assert auto_fusion(net).calls["eager"] == 1
+        assert torch.equal(net(x), y) and torch.equal(y, FusedResNet(net)(x))
+        with per_layer_forward():
+            y_layer = net(x)
+    assert torch.allclose(y, y_layer, rtol=1e-3, atol=1e-3 * float(y_layer.abs().max()))
+
+
+def test_pipelined_inference_with_fresh_inputs():
+    """Two batches in flight where every launch reads a NEW caller tensor (no static input buffer, no copy)."""
+    net = _r18()
+    xs = [dev(gen.normal(80 + i, (8, 3, 64, 64))) for i in range(5)]
+    single = FusedResNet(net)
+    want = [single(x).clone() for x in xs]
+    pipe = PipelinedInference(net, xs[0], n_streams=2, fresh_input=True)
+    got = []
+    for i, x in enumerate(xs):
+        y = pipe.launch(i, x)
+        with torch.cuda.stream(pipe.stream(i)):
+            got.append(y.clone())
+    pipe.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+
+
+def test_forward_fresh_keeps_a_bounded_number_of_graphs():
+    net = _r18()
+    eng = FusedResNet(net)
+    eager = FusedResNet(net)
+    for n in range(1, 8):
+        x = dev(gen.normal(n, (n, 3, 32, 32)))
+        assert torch.equal(eng.forward_fresh(x), eager(x))
+    assert len(eng._split) == FusedResNet.MAX_SPLIT_GRAPHS
+    assert isinstance(auto_fusion(net), AutoFusion)

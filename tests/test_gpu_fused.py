@@ -9,8 +9,19 @@ import oracle
 from bnn_amd import hipops, native
 from tests.golden import gen
 from tests.golden.cases import LAYER_CASES, LAYER_CASES_BY_NAME, LayerCase
+from tests.helpers import legacy
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _net_call_means_per_layer():
+    """In this module `net(x)` means the per-layer drop-in path (one launch per binary layer + torch BN / ReLU / add);
+    the fused executor is built explicitly (`FusedResNet(net)`).  What `net(x)` does by default — the fused executor,
+    bnn_amd/inference.py: AutoFusion — is tested in tests/test_gpu_dropin.py."""
+    from bnn_amd.inference import per_layer_forward
+    with per_layer_forward():
+        yield
 DEV = "cuda:0"
 
 
@@ -25,18 +36,22 @@ def u64(t):
 TILED = [c for c in LAYER_CASES if c.k in (1, 3) and c.dilation == 1 and c.winit != "withzeros"]
 
 
-@pytest.mark.parametrize("weights", ["sgpr", "lds"])
 @pytest.mark.parametrize("case", TILED, ids=lambda c: c.name)
-def test_weight_source_variants_bit_exact(case, weights):
-    """Scalar-cache weight stream and LDS-staged weight tile compute the same integers."""
+def test_weight_source_variants_bit_exact(case):
+    """Scalar-cache weight stream (the product kernel) and, for the 3x3 shapes, the LDS-staged weight tile (test-only
+    since ABI 12: csrc/legacy/bconv_lds.hip through tests/helpers/legacy.py) compute the same integers."""
     x, w, b, sc = case.tensors()
     act = hipops.pack_act(dev(x))
     pw = hipops.pack_weight(dev(w), case.center, case.compute_alpha)
     dot = hipops.bconv2d(act, pw, stride=case.stride, padding=case.pad, raw_dot=True,
-                         weights=weights).cpu().numpy()
+                         weights="sgpr").cpu().numpy()
     _, ref_dot = oracle.binary_conv2d_int(x, w, None, None, case.stride, case.pad, case.dilation,
                                           case.center, case.compute_alpha)
     assert np.array_equal(dot, ref_dot)
+    if case.k == 3:
+        got = legacy.bconv2d_lds(act, pw, stride=case.stride, padding=case.pad)
+        want = hipops.bconv2d(act, pw, stride=case.stride, padding=case.pad)
+        assert torch.equal(got, want)       # alpha * dot: same float bits
 
 
 EPI_CASES = [
@@ -466,8 +481,9 @@ def test_mfma_stem_matches_torch_fp32_sequence(shape, exact):
                                    (5, 3, 33, 65), (1, 3, 7, 9), (1, 3, 225, 223), (300, 3, 64, 64), (129, 3, 224, 224)])
 def test_the_two_stem_kernels_agree_bit_for_bit(shape, fp16):
     """The default kernel (transposed GEMM, max-pool in the accumulators, strips walked down the image with the last
-    conv row kept in registers; stem_rows.hip) against the round-2 kernel (conv tile staged through LDS;
-    BNN_HIP_STEM_STAGED): two independent tilings of the same arithmetic, every fp32 value and sign bit equal.
+    conv row kept in registers; stem_rows.hip) against the round-2 kernel (conv tile staged through LDS; test-only
+    since ABI 12: csrc/legacy/stem_split.hip): two independent tilings of the same arithmetic, every fp32 value and
+    sign bit equal.
     The last two shapes have more strips than workgroups (whole strips round-robin, a partial last round), the
     small ones fewer tiles than workgroups (one chunk each, chunks starting inside a strip)."""
     x = dev(gen.normal(gen.seed_of("stem2", shape), (min(shape[0], 6),) + shape[1:]))
@@ -475,17 +491,18 @@ def test_the_two_stem_kernels_agree_bit_for_bit(shape, fp16):
     w = dev(gen.conv_weight("kaiming", 3, (64, 3, 7, 7)))
     a = dev((0.5 + gen.uniform(1, (64,))).astype(np.float32) * np.where(np.arange(64) % 7 == 0, -1, 1).astype(np.float32))
     b = dev((0.3 * gen.normal(2, (64,))).astype(np.float32))
-    y0, p0 = hipops.stem7x7(x, w, a, b, fp16=fp16, staged=True)
+    y0, p0 = legacy.stem_staged(x, w, a, b, fp16=fp16)
     y1, p1 = hipops.stem7x7(x, w, a, b, fp16=fp16)
     assert torch.equal(y0, y1) and torch.equal(p0.P, p1.P) and torch.equal(p0.M, p1.M)
     y2, _ = hipops.stem7x7(x, w, a, b, fp16=fp16, out_packed=False)
     _, p3 = hipops.stem7x7(x, w, a, b, fp16=fp16, out_f32=False)
     assert torch.equal(y2, y1) and torch.equal(p3.P, p1.P)
     lib = native.require()
-    bad = lib.bnn_hip_stem7x7_bn_relu_pool_pack_f32(x.data_ptr(), w.data_ptr(), a.data_ptr(), b.data_ptr(), 1, 7, 9,
-                                                    native.STEM_EXACT_FP32 | native.STEM_STAGED, y1.data_ptr(), None,
-                                                    None, None)
-    assert bad == -1          # BNN_HIP_ERR_INVALID_ARG: the staged kernel has no exact-fp32 mode
+    for flags in (8, native.STEM_EXACT_FP32 | native.STEM_FP16):     # 8: BNN_HIP_STEM_STAGED of ABI <= 11, gone
+        bad = lib.bnn_hip_stem7x7_bn_relu_pool_pack_f32(x.data_ptr(), w.data_ptr(), a.data_ptr(), b.data_ptr(), 1, 7,
+                                                        9, flags, y1.data_ptr(), None, None, None)
+        assert bad == -1      # BNN_HIP_ERR_INVALID_ARG
+    assert legacy.stem_staged(x[:1], w, a, b, flags=native.STEM_EXACT_FP32) == -1   # no exact-fp32 mode there
 
 
 def test_fused_resnet_with_and_without_mfma_stem_agree():

@@ -21,6 +21,16 @@ from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer
 from tests.golden import gen
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _net_call_means_per_layer():
+    """In this module `net(x)` means the per-layer drop-in path (one launch per binary layer + torch BN / ReLU / add);
+    the fused executor is built explicitly (`FusedResNet(net)`).  What `net(x)` does by default — the fused executor,
+    bnn_amd/inference.py: AutoFusion — is tested in tests/test_gpu_dropin.py."""
+    from bnn_amd.inference import per_layer_forward
+    with per_layer_forward():
+        yield
 DEV = "cuda:0"
 
 

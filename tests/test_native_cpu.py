@@ -28,9 +28,28 @@ def test_library_exports_every_declared_symbol():
     assert set(native.EXPORTED_SYMBOLS) == set(syms)
 
 
+def test_legacy_kernels_live_in_their_own_test_only_library():
+    """ABI 12: the round-2 stem kernel and the LDS-staged weight tile are cross-check material, not product code —
+    libbnn_hip.so does not contain them, libbnn_hip_legacy.so (loaded only by tests/helpers/legacy.py) does."""
+    import subprocess
+    legacy = os.path.join(os.path.dirname(native.lib_path()), "libbnn_hip_legacy.so")
+    assert os.path.exists(legacy), "build with __graft_entry__.build() first"
+    ll = ctypes.CDLL(legacy)
+    assert hasattr(ll, "bnn_hip_legacy_stem_staged") and hasattr(ll, "bnn_hip_legacy_bconv2d_lds")
+    product = ctypes.CDLL(native.lib_path())
+    assert not hasattr(product, "bnn_hip_legacy_stem_staged")
+    names = subprocess.run(["strings", "-n", "12", native.lib_path()], capture_output=True, text=True).stdout
+    assert "stem_split_kernel" not in names and "bconv_lds_kernel" not in names
+    assert "stem_rows_kernel" in names and "bconv_sgpr_kernel" in names
+    src = os.path.join(ROOT, "binary-networks-pytorch_amd", "bnn_amd")
+    for fn in os.listdir(src):
+        if fn.endswith(".py"):
+            assert "libbnn_hip_legacy" not in open(os.path.join(src, fn)).read(), fn
+
+
 def test_require_loads_and_reports_abi():
     lib = native.require()
-    assert lib.bnn_hip_abi_version() == native.ABI_VERSION == 11
+    assert lib.bnn_hip_abi_version() == native.ABI_VERSION == 12
     assert lib.bnn_hip_status_string(0) == b"ok"
     assert b"invalid" in lib.bnn_hip_status_string(-1)
     assert isinstance(native.launch_count(), int)

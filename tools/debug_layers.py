@@ -40,7 +40,7 @@ pw = fastpath.packed_weight(m, plan); print("has_zero", pw.has_zero)
 wb, wz, al, anyz = oracle.pack_weight(w, True, True)
 print("bits eq", np.array_equal(pw.wbits.cpu().numpy().view(np.uint32), wb), "alpha eq", np.array_equal(pw.alpha.cpu().numpy(), al), anyz)
 act = hipops.pack_act(a_in.cuda())
-for kw in (dict(), dict(force_generic=True), dict(weights="lds")):
+for kw in (dict(), dict(force_generic=True)):
     o = hipops.bconv2d(act, pw, None, plan.scale, **kw).cpu().numpy()
     print(kw, np.abs(o - ref).max())
 o = hipops.bconv2d(act, pw, None, None).cpu().numpy() * sc.reshape(1, -1, 1, 1)
