@@ -159,6 +159,9 @@ def packed_weight(layer, plan: Plan, sync: bool = True, fresh: bool = False) -> 
     travels to pinned host memory asynchronously.  It is resolved by the NEXT call for this layer — a training
     call checks the previous step's flag (long since on the host), an inference call (``sync=True``) waits for
     it — and a layer that ever showed a zero is packed synchronously (mask-aware kernel) from then on."""
+    master = layer.__dict__.get("_bnn_master")
+    if master is not None:          # a DataParallel replica: cached on the layer it was replicated from
+        return _replica_packed_weight(layer, master, plan)
     w = layer.weight
     key = (w.data_ptr(), w._version, str(w.device), tuple(w.shape), plan.center, plan.compute_alpha)
     cached = layer.__dict__.get("_bnn_packed")
@@ -184,6 +187,26 @@ def packed_weight(layer, plan: Plan, sync: bool = True, fresh: bool = False) -> 
     return pw
 
 
+def _replica_packed_weight(layer, master, plan: Plan) -> hipops.PackedWeight:
+    """Packed weights of a ``DataParallel`` replica.  Its ``weight`` is a broadcast copy that is new on every forward
+    (new storage, version 0), so the replica's own pointer / version say nothing; the values are those of the layer it
+    was replicated from.  The pack is therefore keyed on the MASTER's weight (pointer, version, recipe) and kept on the
+    master per replica device: one pack — and one host round trip for the zero-weight flag — per device and weight
+    version instead of one per forward."""
+    mw = master.weight
+    w = layer.weight
+    key = (mw.data_ptr(), mw._version, tuple(mw.shape), plan.center, plan.compute_alpha)
+    cache = master.__dict__.setdefault("_bnn_packed_replicas", {})
+    dev = str(w.device)
+    hit = cache.get(dev)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    pw = hipops.pack_weight(w, plan.center, plan.compute_alpha, sync=True)
+    cache[dev] = (key, pw)
+    _bump("weight_packs")
+    return pw
+
+
 def invalidate(module: nn.Module) -> int:
     """Drop every cached packed weight under ``module`` (returns how many).  Needed after writing weights
     through ``.data`` (weight clipping ``p.data.clamp_(-1, 1)``, EMA swaps ``p.data.copy_(ema)``, hand-written
@@ -193,6 +216,7 @@ def invalidate(module: nn.Module) -> int:
     for m in module.modules():
         if m.__dict__.pop("_bnn_packed", None) is not None:
             n += 1
+        m.__dict__.pop("_bnn_packed_replicas", None)
     return n
 
 

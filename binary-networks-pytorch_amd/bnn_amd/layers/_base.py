@@ -29,6 +29,17 @@ class BinaryLayerMixin:
         self.activation_post_process = bconfig.activation_post_process(self)
         self.weight_pre_process = bconfig.weight_pre_process()
 
+    def _replicate_for_data_parallel(self):
+        """``nn.DataParallel`` (examples/cifar10.py:74-77) makes its per-device replicas with this on EVERY forward:
+        ``__dict__`` is copied shallowly and the parameters are replaced by freshly broadcast copies.  The replica
+        remembers the layer it was made from, so that the packed weights it needs are cached there per device and
+        weight version (``fastpath.packed_weight``) instead of being re-derived — with a blocking read of the
+        zero-weight flag — on every forward of every replica."""
+        replica = super()._replicate_for_data_parallel()
+        replica.__dict__["_bnn_master"] = self.__dict__.get("_bnn_master", self)
+        replica.__dict__.pop("_bnn_packed", None)       # (device 0's entry, copied with __dict__)
+        return replica
+
     @classmethod
     def _ctor_kwargs(cls, mod: nn.Module) -> dict:  # pragma: no cover - overridden
         raise NotImplementedError

@@ -1,7 +1,13 @@
 """The exact multi-GPU bench path on ONE GPU: a one-rank RCCL process group (backend "nccl" is RCCL on ROCm),
 PipelinedInference (HIP-graph replay on two streams) + ShardedInference.forward_even with the all-gather
 issued on the stream that computed the batch — so the code an 8-GPU node runs has been through RCCL before
-it ever sees one.  Plus bench.py itself under torch.distributed.run (world size 1) vs the plain run."""
+it ever sees one.  Plus bench.py itself under torch.distributed.run (world size 1) vs the plain run.
+
+Round 4: the N > 1 code itself on the one GPU there is — TWO ranks sharing cuda:0 under gloo (RCCL refuses two ranks
+on one device): `bench.py --gpus 2 --backend gloo` (validate_gather with world = 2, the distinct-blocks assertion,
+per-rank timing gather, self-launch) in three engines, tests/helpers/dist_worker.py (even + ragged shards through
+net(x) and the HIP executors, two streams + collective ordering, DDP gradients == single process), and a one-rank
+RCCL DDP training step.  The first 8-GPU run is then only new in link topology."""
 import json
 import os
 import socket
@@ -107,3 +113,123 @@ def test_bench_line_plain_vs_one_rank_under_the_launcher():
         pr = rec["per_rank_ms_per_step"]
         assert len(pr["all"]) == 1 and pr["min"] == pr["max"] == pr["all"][0] > 0
     assert 0.5 < launched["value"] / plain["value"] < 2.0
+
+
+# ---- round 4: two ranks on ONE GPU (gloo), DDP over RCCL ------------------------------------------------------------
+
+@pytest.mark.parametrize("engine", ["graph", "graph_fresh", "net_call", "layerwise"])
+def test_bench_with_two_ranks_sharing_the_gpu(engine):
+    """`bench.py --gpus 2 --backend gloo`: self-launch of two ranks, each a full copy of the bench on cuda:0; the line
+    must carry the world-2 gather check (every rank recomputed both ranks' first images and compared them with its
+    gathered copy, and the two rank blocks are distinct) and one step time per rank."""
+    rec = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--engine", engine, "--steps", "3",
+                      "--warmup", "1", "--spinup", "2", "--batch", "16", "--sustain", "0", "--no-cpu-baseline",
+                      "--no-roofline", "--no-extras"])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 32 and rec["config"]["engine"] == engine
+    assert rec["dist"]["world_size"] == 2 and rec["dist"]["backend"] == "gloo" and rec["dist"]["launcher"] == "self"
+    assert rec["dist"]["gpus_visible"] >= 1
+    assert rec["gather_check"]["ranks_checked"] == 2 and rec["gather_check"]["bit_equal"] is True
+    pr = rec["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 2 and 0 < pr["min"] <= pr["max"]
+    assert rec["value"] > 0 and rec["scaling"] == "weak"
+
+
+def _run_worker(what):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "helpers", "dist_worker.py"), what]
+    out = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="4"), capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0 and "DIST_WORKER_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_two_ranks_even_and_ragged_shards_through_the_hip_executors():
+    """tests/helpers/dist_worker.py `inference`: gathered logits == one process's logits bit for bit, for even and
+    ragged shards through `net(x)` (AutoFusion -> fused HIP executor) and for two batches in flight with the gather of
+    each batch issued on its own stream (same host order on both ranks)."""
+    _run_worker("inference")
+
+
+def test_two_ranks_ddp_gradients_with_hip_kernels_equal_one_process():
+    _run_worker("ddp")
+
+
+def test_ddp_training_step_over_rccl_world1(rccl_world1):
+    """`training.make_ddp` on the GPU over RCCL (examples/imagenet.py:146-147): a DDP-wrapped binary ResNet-18 does one
+    SGD step with the HIP forward + HIP gradient kernels; gradients and updated weights equal the un-wrapped model's
+    (one rank: the all-reduce is the identity)."""
+    from bnn_amd import fastpath, training
+    x = torch.from_numpy(gen.normal(77, (4, 3, 64, 64))).to(DEV)
+    t = torch.tensor([1, 5, 9, 13], device=DEV)
+
+    def step(model, params):
+        opt = torch.optim.SGD(params, lr=0.1, momentum=0.9)
+        before = fastpath.stats()["conv2d_train"]
+        loss = torch.nn.functional.cross_entropy(model(x), t)
+        loss.backward()
+        assert fastpath.stats()["conv2d_train"] == before + 19
+        grads = [p.grad.clone() for p in params]
+        opt.step()
+        return float(loss), grads
+
+    ref = _r18().train()
+    ddp_net = _r18().train()
+    ddp = training.make_ddp(ddp_net, torch.device(DEV))
+    assert type(ddp).__name__ == "DistributedDataParallel" and dist.get_backend() == "nccl"
+    l0, g0 = step(ref, list(ref.parameters()))
+    l1, g1 = step(ddp, list(ddp_net.parameters()))
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    for a, b in zip(g0, g1):        # (library BatchNorm backward may reduce with atomics: tight tolerance, not bits)
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(a.abs().max()) + 1e-12)
+    for p, q in zip(ref.parameters(), ddp_net.parameters()):
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-6 * float(p.abs().max()) + 1e-12)
+
+
+def test_data_parallel_replicas_share_packed_weights_per_device_and_version():
+    """`nn.DataParallel` (examples/cifar10.py:74-77) replicates the model on EVERY forward: `__dict__` copied shallowly,
+    parameters replaced by broadcast copies.  A replica's forward must not re-pack (and block on the zero-weight flag)
+    every time: packs are cached on the master layer per (device, weight version)."""
+    import torch.nn as nn
+    from bnn_amd import fastpath
+    conv = nn.Conv2d(64, 64, 3, padding=1, bias=False)
+    cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
+                      weight_pre_process=XNORWeightBinarizer)
+    layer = bnn.prepare_binary_model(conv, cfg).to(DEV).eval()
+    x = torch.from_numpy(gen.normal(3, (2, 64, 12, 12))).to(DEV)
+
+    def replica_forward():
+        # what torch.nn.parallel.replicate does for one module: shallow copy + a NEW tensor holding the same values
+        r = layer._replicate_for_data_parallel()
+        r._parameters = {}
+        r.weight = layer.weight.detach().clone()
+        r.bias = None
+        with torch.no_grad():
+            return r(x), r
+    with torch.no_grad():
+        want = layer(x)
+    packs = fastpath.stats()["weight_packs"]
+    y1, r1 = replica_forward()
+    assert fastpath.stats()["weight_packs"] == packs + 1 and torch.equal(y1, want)
+    assert r1.__dict__["_bnn_master"] is layer and "_bnn_packed" not in r1.__dict__
+    for _ in range(3):                                       # later forwards: new replicas, new storage — no re-pack
+        y, r = replica_forward()
+        assert torch.equal(y, want)
+    assert fastpath.stats()["weight_packs"] == packs + 1
+    r2 = r._replicate_for_data_parallel()                    # a replica of a replica still points at the master
+    assert r2.__dict__["_bnn_master"] is layer
+    with torch.no_grad():
+        layer.weight.neg_()                                  # optimiser step on the master: version counter moves
+    y, _ = replica_forward()
+    assert fastpath.stats()["weight_packs"] == packs + 2 and torch.equal(y, -want)
+    # the real thing on the devices there are: DataParallel's replicate() onto [0], and the wrapper on one GPU
+    net = _r18()
+    xs = torch.from_numpy(gen.normal(5, (4, 3, 64, 64))).to(DEV)
+    with torch.no_grad():
+        want = FusedResNet(net)(xs)
+        rep = nn.parallel.replicate(net, [0])[0]
+        assert getattr(rep, "_is_replica", False)
+        y_rep = rep(xs)                                      # replicas take the per-layer path (parameters are re-broadcast)
+        packs = fastpath.stats()["weight_packs"]
+        y_rep2 = nn.parallel.replicate(net, [0])[0](xs)
+        assert fastpath.stats()["weight_packs"] == packs and torch.equal(y_rep, y_rep2)
+        assert torch.allclose(y_rep, want, rtol=1e-3, atol=1e-3 * float(want.abs().max()))
+        assert torch.equal(nn.DataParallel(net, device_ids=[0])(xs), want)
