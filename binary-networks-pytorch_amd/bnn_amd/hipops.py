@@ -17,7 +17,7 @@ _MAX_ELEMS = (1 << 30) - 1  # fp32 elements one conv launch addresses (32-bit by
 # the tiled conv kernels multiply indices with 24-bit multiplies (csrc/bconv.hip: small_indices()); a launch whose
 # images x channels factor reaches 2^23 would silently take the slow shape-generic kernel — split the batch first
 _MAX_INDEX_FACTOR = (1 << 23) - 1
-_DIRECT_MIN_PIXELS = 0            # images smaller than this take pack_act + bconv2d (set from tools/bench_linear.py)
+_DIRECT_MIN_PIXELS = 16           # images up to this many pixels may take pack_act + bconv2d (_prefers_two_launches)
 _MAX_DESC_BYTES = 0xFFFFFE00      # tensors addressed through a sized 32-bit buffer descriptor (capi.hip: kMaxDescBytes)
 
 
@@ -413,8 +413,12 @@ def direct_plan(x_shape, w: PackedWeight, stride=1, padding=0, dilation=1) -> Op
 def _prefers_two_launches(d) -> bool:
     """Shapes where ``pack_act`` + ``bconv2d`` beats the one-launch kernel.  That kernel packs 64 consecutive pixels of
     a band per item: with 1 x 1 images (``Linear`` layers) an item holds ONE valid lane and its loads stride by a
-    whole image — 1/64 lane utilisation (measured: tools/bench_linear.py)."""
-    return d.H * d.W < _DIRECT_MIN_PIXELS
+    whole image — 1/64 lane utilisation.  Measured on MI355X (tools/bench_linear.py, us one-launch vs
+    two launches): 1x1 images N=1024 C=512 49 vs 30, N=256 C=4096 450 vs 48, N=64 C=2048 69 vs 29, N=32768 C=256 105 vs
+    85; 3x3 on 2x2 / 4x4 images 76 vs 30 / 77 vs 37 — but N=256 C=512 1x1 26 vs 31, 1x1 conv on 2x2 images 18 vs 29,
+    3x3 on 7x7 30 vs 33: tiny images go the two-launch way when the kernel is larger than 1x1 or the input is wide or
+    the batch large."""
+    return d.H * d.W <= _DIRECT_MIN_PIXELS and (d.KH * d.KW > 1 or d.C >= 1024 or d.N * d.C >= (1 << 19))
 
 
 def bconv2d_direct(x: torch.Tensor, w: PackedWeight, bias: Optional[torch.Tensor] = None,
