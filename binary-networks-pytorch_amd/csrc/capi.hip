@@ -55,7 +55,21 @@ constexpr long long kMaxPlaneWords = (1LL << 29) - 1;
 // out-of-range marker offsets the kernels use for dead lanes (0xFFFFFFF0 + small immediates) must stay out of range
 constexpr long long kMaxDescBytes = 0xFFFFFE00LL;
 
-int out_dim(int in, int k, int s, int p, int d) { return (in + 2 * p - d * (k - 1) - 1) / s + 1; }
+// Size arithmetic on caller-supplied 32-bit integers: products of up to five of them.  Computed in 64 bits with
+// saturation (all factors are checked positive first), so that a hostile descriptor cannot wrap a limit check
+// (found by tools/fuzz/capi_fuzz.hip under UBSan: N * H * W * words overflowed `long long` for N = H = W = 2^24).
+constexpr long long kSat = 1LL << 62;
+inline long long mulc(long long a, long long b) { return (a <= 0 || b <= 0) ? 0 : (a > kSat / b ? kSat : a * b); }
+inline long long mulc(long long a, long long b, long long c) { return mulc(mulc(a, b), c); }
+inline long long mulc(long long a, long long b, long long c, long long d) { return mulc(mulc(a, b, c), d); }
+
+// output extent of a convolution dimension, or 0 when it is empty / does not fit an int
+int out_dim(int in, int k, int s, int p, int d) {
+  const long long span = (long long)in + 2LL * p - (long long)d * (k - 1) - 1;
+  if (span < 0) return 0;
+  const long long o = span / s + 1;
+  return o > 0x7fffffffLL ? 0 : (int)o;
+}
 
 int check_desc(const bnn_hip_conv_desc* d, int* Ho, int* Wo) {
   if (!d) return BNN_HIP_ERR_INVALID_ARG;
@@ -67,9 +81,12 @@ int check_desc(const bnn_hip_conv_desc* d, int* Ho, int* Wo) {
   const int ho = out_dim(d->H, d->KH, d->stride_h, d->pad_h, d->dil_h);
   const int wo = out_dim(d->W, d->KW, d->stride_w, d->pad_w, d->dil_w);
   if (ho <= 0 || wo <= 0) return BNN_HIP_ERR_INVALID_ARG;
-  if ((long long)d->N * d->H * d->W * ((d->C + 63) / 64) > kMaxPlaneWords) return BNN_HIP_ERR_TOO_LARGE;
-  if ((long long)d->N * ho * wo * ((d->O + 63) / 64) > kMaxPlaneWords) return BNN_HIP_ERR_TOO_LARGE;
-  if ((long long)d->N * d->O * ho * wo > kMaxConvElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (mulc(d->N, d->H, d->W, ((long long)d->C + 63) / 64) > kMaxPlaneWords) return BNN_HIP_ERR_TOO_LARGE;
+  if (mulc(d->N, ho, wo, ((long long)d->O + 63) / 64) > kMaxPlaneWords) return BNN_HIP_ERR_TOO_LARGE;
+  if (mulc(d->N, d->O, ho, wo) > kMaxConvElems) return BNN_HIP_ERR_TOO_LARGE;
+  // weight words of the layer (o_pad x taps x cw32) and the receptive field must be addressable too
+  if (mulc(((long long)d->O + 31) / 32 * 32, d->KH, d->KW, 2 * (((long long)d->C + 63) / 64)) > kMaxElems)
+    return BNN_HIP_ERR_TOO_LARGE;
   *Ho = ho;
   *Wo = wo;
   return BNN_HIP_OK;
@@ -88,8 +105,8 @@ int run_conv(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M, c
   if ((p.outP == nullptr) != (p.outM == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
   if ((p.pack_a == nullptr) != (p.pack_b == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
   if (p.c_tot == 0) { p.c_off = 0; p.c_tot = d->O; }
-  if (p.c_off < 0 || p.c_off + d->O > p.c_tot) return BNN_HIP_ERR_INVALID_ARG;
-  if ((long long)d->N * p.c_tot * Ho * Wo > kMaxConvElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (p.c_off < 0 || p.c_tot <= 0 || (long long)p.c_off + d->O > p.c_tot) return BNN_HIP_ERR_INVALID_ARG;
+  if (mulc(d->N, p.c_tot, Ho, Wo) > kMaxConvElems) return BNN_HIP_ERR_TOO_LARGE;
   if ((d->flags & BNN_HIP_FLAG_WEIGHT_ZEROS) && !wnz) return BNN_HIP_ERR_INVALID_ARG;
   if (!aligned(P, 16) || !aligned(M, 16) || !aligned(wbits, 16)) return BNN_HIP_ERR_INVALID_ARG;
   if (p.outP && (!aligned(p.outP, 8) || !aligned(p.outM, 8))) return BNN_HIP_ERR_INVALID_ARG;
@@ -160,25 +177,30 @@ int bnn_hip_device_info(int device, bnn_hip_devinfo* out) {
   return BNN_HIP_OK;
 }
 
-int bnn_hip_act_words(int C) { return C > 0 ? (C + 63) / 64 : BNN_HIP_ERR_INVALID_ARG; }
+int bnn_hip_act_words(int C) { return C > 0 ? (int)(((long long)C + 63) / 64) : BNN_HIP_ERR_INVALID_ARG; }
 
 int bnn_hip_weight_layout(int O, int C, int KH, int KW, bnn_hip_wlayout* out) {
   if (!out || O <= 0 || C <= 0 || KH <= 0 || KW <= 0) return BNN_HIP_ERR_INVALID_ARG;
-  out->cw32 = 2 * ((C + 63) / 64);
+  const long long cw32 = 2 * (((long long)C + 63) / 64), o_pad = ((long long)O + BNN_HIP_OCB - 1) / BNN_HIP_OCB * BNN_HIP_OCB;
+  const long long taps = mulc(KH, KW);
+  // the packed weight (one bit per weight) addresses words with 31-bit indices; taps and the padded channel count
+  // are ints of the layout struct
+  if (taps > 0x7fffffffLL || o_pad > 0x7fffffffLL || mulc(o_pad, taps, cw32) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  out->cw32 = (int32_t)cw32;
   out->cwc = bnn::choose_cwc(out->cw32, KH, KW);
   out->nchunk = out->cw32 / out->cwc;
-  out->taps = KH * KW;
-  out->o_pad = (O + BNN_HIP_OCB - 1) / BNN_HIP_OCB * BNN_HIP_OCB;
+  out->taps = (int32_t)taps;
+  out->o_pad = (int32_t)o_pad;
   out->reserved = 0;
-  out->n_words = (int64_t)out->o_pad * out->taps * out->cw32;
+  out->n_words = o_pad * taps * cw32;
   return BNN_HIP_OK;
 }
 
 int bnn_hip_pack_act_f32(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
                          void* stream) {
   if (!x || !P || !M || N <= 0 || C <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
-  if ((long long)N * H * W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
-  if ((C + 63) / 64 > 65535) return BNN_HIP_ERR_UNSUPPORTED;  // grid.y limit
+  if (mulc(N, H, W) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (((long long)C + 63) / 64 > 65535) return BNN_HIP_ERR_UNSUPPORTED;  // grid.y limit
   if (!aligned(P, 8) || !aligned(M, 8) || !aligned(x, 4)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
   BNN_RANGE();
@@ -188,8 +210,8 @@ int bnn_hip_pack_act_f32(const float* x, int N, int C, int H, int W, uint64_t* P
 int bnn_hip_pack_act_f16(const void* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M,
                          void* stream) {
   if (!x || !P || !M || N <= 0 || C <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
-  if ((long long)N * H * W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
-  if ((C + 63) / 64 > 65535) return BNN_HIP_ERR_UNSUPPORTED;  // grid.y limit
+  if (mulc(N, H, W) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (((long long)C + 63) / 64 > 65535) return BNN_HIP_ERR_UNSUPPORTED;  // grid.y limit
   if (!aligned(P, 8) || !aligned(M, 8) || !aligned(x, 2)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
   BNN_RANGE();
@@ -200,8 +222,8 @@ int bnn_hip_bn_act_pack_f32(const float* x, int N, int C, int H, int W, const fl
                             const float* bn_shift, int relu, uint64_t* P, uint64_t* M, void* stream) {
   if (!x || !P || !M || N <= 0 || C <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
   if ((bn_scale == nullptr) != (bn_shift == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
-  if ((long long)N * H * W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
-  if ((C + 63) / 64 > 65535) return BNN_HIP_ERR_UNSUPPORTED;  // grid.y limit
+  if (mulc(N, H, W) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (((long long)C + 63) / 64 > 65535) return BNN_HIP_ERR_UNSUPPORTED;  // grid.y limit
   if (!aligned(P, 8) || !aligned(M, 8) || !aligned(x, 4)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
   BNN_RANGE();
@@ -212,8 +234,8 @@ int bnn_hip_bn_act_pack_f32(const float* x, int N, int C, int H, int W, const fl
 int bnn_hip_avgpool_pack_f32(const float* x, int N, int C, int H, int W, int k, uint64_t* P,
                              uint64_t* M, void* stream) {
   if (!x || !P || !M || N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0) return BNN_HIP_ERR_INVALID_ARG;
-  if ((long long)N * H * W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
-  if (2 * ((C + 63) / 64) > 65535) return BNN_HIP_ERR_UNSUPPORTED;
+  if (mulc(N, H, W) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (2 * (((long long)C + 63) / 64) > 65535) return BNN_HIP_ERR_UNSUPPORTED;
   if (!aligned(P, 8) || !aligned(M, 8)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
   BNN_RANGE();
@@ -223,7 +245,7 @@ int bnn_hip_avgpool_pack_f32(const float* x, int N, int C, int H, int W, int k, 
 int bnn_hip_orpool_packed(const uint64_t* P, int N, int C, int H, int W, int k, uint64_t* out_P,
                           uint64_t* out_M, void* stream) {
   if (!P || !out_P || !out_M || N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0) return BNN_HIP_ERR_INVALID_ARG;
-  if ((long long)N * ((C + 63) / 64) * H * W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (mulc(N, ((long long)C + 63) / 64, H, W) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
   if (!aligned(P, 8) || !aligned(out_P, 8) || !aligned(out_M, 8)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
   BNN_RANGE();
@@ -239,8 +261,8 @@ int bnn_hip_bn_relu_maxpool_pack_f32(const float* x, int N, int C, int H, int W,
   if (!out_f32 && !P) return BNN_HIP_ERR_INVALID_ARG;
   if ((P == nullptr) != (M == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
   if ((bn_scale == nullptr) != (bn_shift == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
-  if (2 * pad > k || H + 2 * pad < k || W + 2 * pad < k) return BNN_HIP_ERR_INVALID_ARG;
-  if ((long long)N * C * H * W > 4 * kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (2LL * pad > k || (long long)H + 2LL * pad < k || (long long)W + 2LL * pad < k) return BNN_HIP_ERR_INVALID_ARG;
+  if (mulc(N, C, H, W) > 4 * kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
   if (P && (!aligned(P, 8) || !aligned(M, 8))) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
   BNN_RANGE();
@@ -262,7 +284,7 @@ int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w, const 
   // 224 x 224 in, ~5300 out) — larger batches are split by the caller (hipops.stem7x7 does)
   {
     const long long hc = (H - 1) / 2 + 1, wc = (W - 1) / 2 + 1, hp = (hc - 1) / 2 + 1, wp = (wc - 1) / 2 + 1;
-    if ((long long)N * 3 * H * W * 4 > kMaxDescBytes || (long long)N * 64 * hp * wp * 4 > kMaxDescBytes)
+    if (mulc(N, 12, H, W) > kMaxDescBytes || mulc(N, 256, hp, wp) > kMaxDescBytes)
       return BNN_HIP_ERR_TOO_LARGE;
   }
   g_launches.fetch_add(1, std::memory_order_relaxed);
@@ -275,7 +297,7 @@ int bnn_hip_avgpool_fc_f32(const float* x, int N, int C, int HW, const float* w_
                            float* out, void* stream) {
   if (!x || !w_t || !out || N <= 0 || C <= 0 || HW <= 0 || O <= 0) return BNN_HIP_ERR_INVALID_ARG;
   if (!aligned(x, 4) || !aligned(w_t, 4) || !aligned(out, 4)) return BNN_HIP_ERR_INVALID_ARG;
-  if ((long long)N * C * HW > 4 * kMaxElems || (long long)N * O > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (mulc(N, C, HW) > 4 * kMaxElems || mulc(N, O) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
   g_launches.fetch_add(1, std::memory_order_relaxed);
   BNN_RANGE();
   return bnn::launch_avgpool_fc(x, w_t, bias, out, N, C, HW, O, static_cast<hipStream_t>(stream));
@@ -301,7 +323,7 @@ static int check_grad_shape(int N, int O, int C, int H, int W, int ksize, int st
   if (N <= 0 || O <= 0 || C <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
   if (!grad_ks_ok(ksize) || (stride != 1 && stride != 2) || (ksize == 1 && stride != 1)) return BNN_HIP_ERR_UNSUPPORTED;
   if (W > 64) return BNN_HIP_ERR_UNSUPPORTED;
-  if ((long long)N * O * H * W > kMaxElems || (long long)N * C * H * W > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (mulc(N, O, H, W) > kMaxElems || mulc(N, C, H, W) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
   return BNN_HIP_OK;
 }
 
@@ -431,11 +453,11 @@ static int fly_convp(const bnn_hip_conv_desc* d, bnn::ConvP* out) {
   int Ho = 0, Wo = 0;
   const int st = check_desc(d, &Ho, &Wo);
   if (st != BNN_HIP_OK) return st;
-  if ((long long)d->N * d->C * d->H * d->W > kMaxConvElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (mulc(d->N, d->C, d->H, d->W) > kMaxConvElems) return BNN_HIP_ERR_TOO_LARGE;
   // the kernel reads x through a sized buffer descriptor and marks dead lanes with offset 0xFFFFFFF0 (+ soffset): a
   // tensor within a few elements of 2^32 bytes would bring the marker in range.  UNSUPPORTED, not TOO_LARGE: the
   // two-launch form (pack_act + conv) of the same layer has no such limit and callers fall back to it
-  if ((long long)d->N * d->C * d->H * d->W * 4 > kMaxDescBytes) return BNN_HIP_ERR_UNSUPPORTED;
+  if (mulc(d->N, d->C, d->H, d->W) * 4 > kMaxDescBytes) return BNN_HIP_ERR_UNSUPPORTED;
   bnn::ConvP p = empty_convp();
   bnn_hip_wlayout L;
   bnn_hip_weight_layout(d->O, d->C, d->KH, d->KW, &L);
@@ -480,7 +502,8 @@ static bool direct_applies(const bnn_hip_conv_desc* d) {
 }
 
 size_t bnn_hip_conv_workspace_bytes(const bnn_hip_conv_desc* d) {
-  if (!d || d->N <= 0 || d->C <= 0 || d->H <= 0 || d->W <= 0) return 0;
+  int Ho = 0, Wo = 0;
+  if (check_desc(d, &Ho, &Wo) != BNN_HIP_OK) return 0;   // (bnn_hip_bconv2d_f32 rejects such a descriptor itself)
   if (direct_applies(d)) return 0;
   const size_t npix = (size_t)d->N * d->H * d->W;
   return 2 * align_up(npix * ((d->C + 63) / 64) * sizeof(uint64_t), 256);

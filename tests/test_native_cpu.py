@@ -47,6 +47,23 @@ def test_legacy_kernels_live_in_their_own_test_only_library():
             assert "libbnn_hip_legacy" not in open(os.path.join(src, fn)).read(), fn
 
 
+def test_capi_validators_survive_an_argument_fuzz_under_asan_and_ubsan():
+    """tools/fuzz/capi_fuzz.hip: csrc/capi.hip compiled HOST-ONLY with AddressSanitizer + UBSan against stub launchers
+    that check the contract the kernels rely on (tensor sizes below the 32-bit addressing limits, alignments, a
+    consistent weight layout).  Edge-value integers and null / misaligned pointers at every entry point: no crash, no
+    signed overflow in the size arithmetic, no launcher reached with arguments that break the contract.  (Round 4:
+    this found three overflowing limit checks — N*H*W*words in check_desc, o_pad*taps in bnn_hip_weight_layout,
+    2*pad in the max-pool entry — and an unbounded bnn_hip_conv_workspace_bytes.)"""
+    import subprocess
+    csrc = os.path.join(ROOT, "binary-networks-pytorch_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "fuzz"], check=True, capture_output=True)
+    exe = os.path.join(ROOT, "build", "fuzz", "capi_fuzz")
+    for seed in ("0", "1", "2"):
+        out = subprocess.run([exe, "150000", seed], capture_output=True, text=True,
+                             env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+        assert out.returncode == 0 and "CAPI_FUZZ_OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
 def test_require_loads_and_reports_abi():
     lib = native.require()
     assert lib.bnn_hip_abi_version() == native.ABI_VERSION == 12

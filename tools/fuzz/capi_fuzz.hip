@@ -1,0 +1,263 @@
+// capi_fuzz.hip — argument fuzz of the C-ABI's validators (csrc/capi.hip) under AddressSanitizer + UBSan, HOST ONLY.
+//
+// Built by `make -C binary-networks-pytorch_amd/csrc fuzz` (hipcc --cuda-host-only -fsanitize=address,undefined): capi.hip
+// is compiled as it is, the kernels' launchers (bnn::launch_*) are replaced by the stubs below, which never touch a
+// pointer and instead CHECK what the kernels rely on — the contract capi.hip has to enforce before it launches:
+//   * every tensor of a conv launch below 2^30 fp32 elements / 2^29 plane words, stem and one-launch-layer tensors
+//     below the 32-bit buffer-descriptor limit, alignments, consistent weight layout, positive geometry.
+// The driver throws edge-value integers and null / misaligned / plausible pointers at every entry point: no call may
+// crash, overflow a signed integer, read out of bounds, or reach a launcher with arguments that break the contract.
+// Test infrastructure (tests/test_native_cpu.py runs it); nothing here ships in libbnn_hip.so.
+#include <cinttypes>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../binary-networks-pytorch_amd/csrc/bnn_dev.h"
+
+namespace {
+unsigned long long g_reached = 0, g_calls = 0;
+uint64_t g_rng = 0x9E3779B97F4A7C15ull;
+uint64_t rnd() { g_rng ^= g_rng << 13; g_rng ^= g_rng >> 7; g_rng ^= g_rng << 17; return g_rng; }
+
+[[noreturn]] void broken(const char* what) {
+  std::fprintf(stderr, "CONTRACT BROKEN: %s\n", what);
+  std::abort();
+}
+#define REQUIRE(c) do { if (!(c)) broken(#c); } while (0)
+bool al(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+constexpr long long kConvElems = (1LL << 30) - 1, kPlaneWords = (1LL << 29) - 1, kDesc = 0xFFFFFE00LL;
+}  // namespace
+
+namespace bnn {
+int choose_cwc(int cw32, int KH, int KW) {  // same rule as csrc/bconv.hip
+  if (KH == 3 && KW == 3) return (cw32 % 4 == 0) ? 4 : 2;
+  if (KH == 1 && KW == 1) return cw32 % 16 == 0 ? 16 : cw32 % 8 == 0 ? 8 : cw32 % 4 == 0 ? 4 : 2;
+  return 2;
+}
+static void check_convp(const ConvP& p) {
+  REQUIRE(p.N > 0 && p.C > 0 && p.H > 0 && p.Wd > 0 && p.O > 0 && p.KH > 0 && p.KW > 0 && p.Ho > 0 && p.Wo > 0);
+  REQUIRE(p.sh > 0 && p.sw > 0 && p.ph >= 0 && p.pw >= 0 && p.dh > 0 && p.dw > 0);
+  REQUIRE(p.cw32 == 2 * ((p.C + 63) / 64) && p.cwc > 0 && p.cwc * p.nchunk == p.cw32);
+  REQUIRE((long long)p.N * p.Ho * p.Wo == p.npix);
+  const long long ctot = p.c_tot > 0 ? p.c_tot : p.O;
+  REQUIRE(p.c_off >= 0 && p.c_off + p.O <= ctot);
+  REQUIRE((long long)p.N * ctot * p.Ho * p.Wo <= kConvElems);
+  REQUIRE((long long)p.N * p.Ho * p.Wo * ((p.O + 63) / 64) <= kPlaneWords);
+}
+int launch_bconv(const ConvP& p, int flags, hipStream_t) {
+  ++g_reached;
+  check_convp(p);
+  REQUIRE((long long)p.N * p.H * p.Wd * ((p.C + 63) / 64) <= kPlaneWords);
+  REQUIRE(p.P && p.M && p.W && al(p.P, 16) && al(p.M, 16) && al(p.W, 16));
+  REQUIRE(p.out || (p.outP && p.outM));
+  REQUIRE(p.raw || p.alpha);
+  REQUIRE((p.bn_a == nullptr) == (p.bn_b == nullptr) && (p.outP == nullptr) == (p.outM == nullptr));
+  REQUIRE((p.pack_a == nullptr) == (p.pack_b == nullptr));
+  REQUIRE(!(flags & BNN_HIP_FLAG_WEIGHT_ZEROS) || p.Z);
+  REQUIRE(!p.outP || (al(p.outP, 8) && al(p.outM, 8)));
+  REQUIRE(!p.ds_P || (p.ds_W && p.ds_alpha && p.ds_a && p.ds_b && !p.res && p.ds_C > 0 && al(p.ds_P, 8) && al(p.ds_W, 16)));
+  return BNN_HIP_OK;
+}
+bool ds_fold_applies(const ConvP& p, int flags) { return p.KH == 3 && p.KW == 3 && (flags & BNN_HIP_FLAG_ACT_NONNEG); }
+bool fly_supported(const ConvP& p) { return p.KH * p.KW <= 49; }
+int fly_default_plan(const ConvP& p, int, bnn_hip_fly_plan* plan) {
+  check_convp(p);
+  std::memset(plan, 0, sizeof(*plan));
+  return fly_supported(p) ? BNN_HIP_OK : BNN_HIP_ERR_UNSUPPORTED;
+}
+int launch_bconv_fly(const ConvP& p, const void* x, int half, int flags, const bnn_hip_fly_plan*, hipStream_t) {
+  ++g_reached;
+  check_convp(p);
+  REQUIRE(x && p.W && p.alpha && p.out && al(x, half ? 2 : 4) && al(p.W, 16) && al(p.out, 4));
+  REQUIRE((long long)p.N * p.C * p.H * p.Wd * (half ? 2 : 4) <= kDesc);
+  REQUIRE(!(flags & BNN_HIP_FLAG_WEIGHT_ZEROS) || p.Z);
+  return BNN_HIP_OK;
+}
+static void check_planes(const void* x, int N, int C, int H, int W, const void* P, const void* M, int xal) {
+  REQUIRE(x && P && M && N > 0 && C > 0 && H > 0 && W > 0 && al(x, xal) && al(P, 8) && al(M, 8));
+  REQUIRE((long long)N * H * W <= (1LL << 31) - 1 && (C + 63) / 64 <= 65535);
+}
+int launch_pack_act(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M, hipStream_t) {
+  ++g_reached; check_planes(x, N, C, H, W, P, M, 4); return BNN_HIP_OK;
+}
+int launch_pack_act_f16(const void* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M, hipStream_t) {
+  ++g_reached; check_planes(x, N, C, H, W, P, M, 2); return BNN_HIP_OK;
+}
+int launch_bn_act_pack(const float* x, int N, int C, int H, int W, const float* a, const float* b, int, uint64_t* P,
+                       uint64_t* M, hipStream_t) {
+  ++g_reached; check_planes(x, N, C, H, W, P, M, 4); REQUIRE((a == nullptr) == (b == nullptr)); return BNN_HIP_OK;
+}
+int launch_avgpool_pack(const float* x, int N, int C, int H, int W, int k, uint64_t* P, uint64_t* M, hipStream_t) {
+  ++g_reached; REQUIRE(x && P && M && N > 0 && C > 0 && H > 0 && W > 0 && k > 0 && al(P, 8) && al(M, 8)); return BNN_HIP_OK;
+}
+int launch_orpool_packed(const uint64_t* P, int N, int C, int H, int W, int k, uint64_t* oP, uint64_t* oM, hipStream_t) {
+  ++g_reached; REQUIRE(P && oP && oM && N > 0 && C > 0 && H > 0 && W > 0 && k > 0 && al(P, 8) && al(oP, 8) && al(oM, 8));
+  return BNN_HIP_OK;
+}
+int launch_bn_relu_maxpool_pack(const float* x, int N, int C, int H, int W, const float* a, const float* b, int, int k,
+                                int stride, int pad, float* out, uint64_t* P, uint64_t* M, hipStream_t) {
+  ++g_reached;
+  REQUIRE(x && N > 0 && C > 0 && H > 0 && W > 0 && k > 0 && stride > 0 && pad >= 0 && (out || P));
+  REQUIRE((P == nullptr) == (M == nullptr) && (a == nullptr) == (b == nullptr) && 2 * pad <= k);
+  return BNN_HIP_OK;
+}
+int launch_stem(const float* x, const float* w, const float* a, const float* b, int N, int H, int W, int flags, float* out,
+                uint64_t* P, uint64_t* M, hipStream_t) {
+  ++g_reached;
+  REQUIRE(x && w && a && b && N > 0 && H > 0 && W > 0 && (out || P) && (P == nullptr) == (M == nullptr));
+  REQUIRE(!(flags & ~(BNN_HIP_STEM_EXACT_FP32 | BNN_HIP_STEM_FP16)));
+  const long long hc = (H - 1) / 2 + 1, wc = (W - 1) / 2 + 1, hp = (hc - 1) / 2 + 1, wp = (wc - 1) / 2 + 1;
+  REQUIRE((long long)N * 3 * H * W * 4 <= kDesc && (long long)N * 64 * hp * wp * 4 <= kDesc);
+  REQUIRE(!P || (al(P, 8) && al(M, 8)));
+  return BNN_HIP_OK;
+}
+int launch_avgpool_fc(const float* x, const float* wt, const float*, float* out, int N, int C, int HW, int O, hipStream_t) {
+  ++g_reached; REQUIRE(x && wt && out && N > 0 && C > 0 && HW > 0 && O > 0); return BNN_HIP_OK;
+}
+size_t grad_weight_pack_bytes(int O, int C, int ks) { REQUIRE(O > 0 && C > 0 && (ks == 1 || ks == 3)); return 16; }
+int launch_grad_pack_weight(const float* w, int O, int C, int ks, void* packed, float* alpha, hipStream_t) {
+  ++g_reached; REQUIRE(w && packed && alpha && O > 0 && C > 0 && (ks == 1 || ks == 3) && al(packed, 16)); return BNN_HIP_OK;
+}
+static void check_grad(int N, int O, int C, int H, int W, int ks, int stride) {
+  REQUIRE(N > 0 && O > 0 && C > 0 && H > 0 && W > 0 && W <= 64 && (ks == 1 || ks == 3) && (stride == 1 || stride == 2));
+  REQUIRE((long long)N * O * H * W <= (1LL << 31) - 1 && (long long)N * C * H * W <= (1LL << 31) - 1);
+}
+int launch_dgrad(const float* g, const float* alpha, const void* packed, const float* x, float* gx, int N, int O, int C,
+                 int H, int W, int ks, int stride, hipStream_t) {
+  ++g_reached; REQUIRE(g && alpha && packed && x && gx); check_grad(N, O, C, H, W, ks, stride); return BNN_HIP_OK;
+}
+int grad_wgrad_splits(int N, int O, int C, int ks) { REQUIRE(N > 0 && O > 0 && C > 0 && (ks == 1 || ks == 3)); return 1; }
+int launch_wgrad(const float* g, const float* x, float* part, int, int N, int O, int C, int H, int W, int ks, int stride,
+                 hipStream_t) {
+  ++g_reached; REQUIRE(g && x && part); check_grad(N, O, C, H, W, ks, stride); return BNN_HIP_OK;
+}
+int launch_pack_weight(const float* w, int O, int C, int KH, int KW, int, int, const bnn_hip_wlayout& L, uint32_t* wb,
+                       uint32_t* wz, float* alpha, int32_t* flag, hipStream_t) {
+  ++g_reached;
+  REQUIRE(w && wb && wz && alpha && flag && O > 0 && C > 0 && KH > 0 && KW > 0);
+  REQUIRE(L.cw32 == 2 * ((C + 63) / 64) && L.cwc * L.nchunk == L.cw32 && L.o_pad >= O && L.o_pad % 32 == 0);
+  REQUIRE(L.n_words == (int64_t)L.o_pad * KH * KW * L.cw32);
+  return BNN_HIP_OK;
+}
+int launch_sign_thresholds(const float* alpha, const float*, const float*, const float* a, const float* b, int O, int kmax,
+                           int32_t* thr, hipStream_t) {
+  ++g_reached; REQUIRE(alpha && thr && O > 0 && kmax > 0 && kmax < (1 << 24) && (a == nullptr) == (b == nullptr) && al(thr, 4));
+  return BNN_HIP_OK;
+}
+int launch_probe_int_alu(int mode, int iters, double* r, double*, hipStream_t) { REQUIRE(iters > 0 && r); (void)mode; return BNN_HIP_OK; }
+int launch_probe_clock(int it, double* mhz, double*, hipStream_t) { REQUIRE(it > 0 && mhz); return BNN_HIP_OK; }
+}  // namespace bnn
+
+namespace {
+const int kInts[] = {INT_MIN, -65536, -1, 0, 1, 2, 3, 7, 8, 31, 32, 33, 63, 64, 65, 127, 128, 129, 224, 255, 256, 1000, 4096,
+                     65535, 65536, (1 << 20), (1 << 23), (1 << 24) - 1, (1 << 24), (1 << 28), (1 << 30) - 1, (1 << 30), INT_MAX};
+const int kSmall[] = {1, 1, 1, 2, 3, 3, 4, 7, 8, 14, 16, 28, 56, 64, 112, 128, 224, 256, 512};
+int pick_int() {
+  const uint64_t r = rnd();
+  if (r % 4 == 0) return kInts[(r >> 8) % (sizeof(kInts) / sizeof(int))];
+  if (r % 4 == 1) return (int)(r >> 33) % 3000 - 10;
+  return kSmall[(r >> 8) % (sizeof(kSmall) / sizeof(int))];       // mostly plausible: reach the launchers
+}
+template <class T>
+T* pick_ptr() {
+  static const uintptr_t kPtrs[] = {0, 0x10000, 0x10000, 0x10000, 0x10001, 0x10002, 0x10004, 0x10008, 0x7fff0000fff0ull};
+  return reinterpret_cast<T*>(kPtrs[rnd() % (sizeof(kPtrs) / sizeof(uintptr_t))]);
+}
+bnn_hip_conv_desc pick_desc() {
+  bnn_hip_conv_desc d;
+  int* f = reinterpret_cast<int*>(&d);
+  for (size_t i = 0; i < sizeof(d) / sizeof(int); ++i) f[i] = pick_int();
+  if (rnd() % 2) { d.KH = d.KW = (rnd() % 2) ? 3 : 1; d.stride_h = d.stride_w = 1 + (int)(rnd() % 2); d.dil_h = d.dil_w = 1;
+                   d.pad_h = d.pad_w = d.KH / 2; }
+  d.flags = (int)(rnd() % 128);
+  return d;
+}
+bool status_ok(int st) { return st <= 0 && st >= -5; }
+}  // namespace
+
+int main(int argc, char** argv) {
+  const long iters = argc > 1 ? std::atol(argv[1]) : 200000;
+  if (argc > 2) g_rng ^= (uint64_t)std::atoll(argv[2]) * 0xD1342543DE82EF95ull + 1;
+  void* stream = nullptr;
+  for (long it = 0; it < iters; ++it) {
+    ++g_calls;
+    int st = 0;
+    switch (rnd() % 20) {
+      case 0: { bnn_hip_conv_desc d = pick_desc();
+        st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
+                             pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
+        break; }
+      case 1: { bnn_hip_conv_desc d = pick_desc(); bnn_hip_epilogue e; std::memset(&e, 0, sizeof(e));
+        e.alpha = pick_ptr<float>(); e.bias = pick_ptr<float>(); e.post_scale = pick_ptr<float>(); e.bn_scale = pick_ptr<float>();
+        e.bn_shift = pick_ptr<float>(); e.residual = pick_ptr<float>(); e.prelu = pick_ptr<float>(); e.relu = pick_int();
+        e.flags = (int)(rnd() % 8); e.out_f32 = pick_ptr<float>(); e.out_P = pick_ptr<uint64_t>(); e.out_M = pick_ptr<uint64_t>();
+        e.pack_scale = pick_ptr<float>(); e.pack_shift = pick_ptr<float>(); e.out_c_offset = pick_int(); e.out_c_total = pick_int();
+        e.sign_thresholds = pick_ptr<int32_t>();
+        if (rnd() % 3 == 0) { e.sc_P = pick_ptr<uint64_t>(); e.sc_wbits = pick_ptr<uint32_t>(); e.sc_alpha = pick_ptr<float>();
+                              e.sc_bn_scale = pick_ptr<float>(); e.sc_bn_shift = pick_ptr<float>(); e.sc_C = pick_int(); }
+        st = bnn_hip_bconv2d_fused(&d, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(),
+                                   rnd() % 16 ? &e : nullptr, stream);
+        break; }
+      case 2: { bnn_hip_conv_desc d = pick_desc();
+        st = bnn_hip_bconv2d_dot(&d, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(),
+                                 pick_ptr<int32_t>(), stream);
+        break; }
+      case 3: { bnn_hip_conv_desc d = pick_desc(); bnn_hip_fly_plan plan; std::memset(&plan, 0, sizeof(plan));
+        st = bnn_hip_bconv2d_direct(&d, pick_ptr<float>(), (int)(rnd() % 3), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(),
+                                    pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(),
+                                    rnd() % 2 ? &plan : nullptr, stream);
+        break; }
+      case 4: { bnn_hip_conv_desc d = pick_desc(); bnn_hip_fly_plan plan;
+        st = bnn_hip_bconv2d_direct_plan(rnd() % 16 ? &d : nullptr, rnd() % 16 ? &plan : nullptr);
+        break; }
+      case 5: { bnn_hip_conv_desc d = pick_desc();
+        const size_t ws = bnn_hip_conv_workspace_bytes(&d);
+        if (ws > (size_t)1 << 40) broken("workspace size overflow");
+        st = bnn_hip_bconv2d_f32(&d, pick_ptr<float>(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(), pick_ptr<float>(),
+                                 pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<char>(), stream);
+        break; }
+      case 6: st = bnn_hip_pack_act_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_ptr<uint64_t>(),
+                                        pick_ptr<uint64_t>(), stream); break;
+      case 7: st = bnn_hip_pack_act_f16(pick_ptr<char>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_ptr<uint64_t>(),
+                                        pick_ptr<uint64_t>(), stream); break;
+      case 8: st = bnn_hip_bn_act_pack_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_ptr<float>(),
+                                           pick_ptr<float>(), pick_int(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), stream); break;
+      case 9: st = bnn_hip_avgpool_pack_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(),
+                                            pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), stream); break;
+      case 10: st = bnn_hip_orpool_packed(pick_ptr<uint64_t>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(),
+                                          pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), stream); break;
+      case 11: st = bnn_hip_bn_relu_maxpool_pack_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(),
+                                                     pick_ptr<float>(), pick_ptr<float>(), pick_int(), pick_int(), pick_int(),
+                                                     pick_int(), pick_ptr<float>(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), stream); break;
+      case 12: st = bnn_hip_stem7x7_bn_relu_pool_pack_f32(pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(),
+                                                          pick_int(), pick_int(), pick_int(), (int)(rnd() % 16), pick_ptr<float>(),
+                                                          pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), stream); break;
+      case 13: st = bnn_hip_avgpool_fc_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_ptr<float>(), pick_ptr<float>(),
+                                           pick_int(), pick_ptr<float>(), stream); break;
+      case 14: { bnn_hip_wlayout L;
+        st = bnn_hip_weight_layout(pick_int(), pick_int(), pick_int(), pick_int(), rnd() % 16 ? &L : nullptr);
+        if (st == BNN_HIP_OK && (L.n_words <= 0 || L.cwc * L.nchunk != L.cw32)) broken("weight layout");
+        break; }
+      case 15: st = bnn_hip_pack_weight_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(),
+                                            pick_ptr<uint32_t>(), pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<int32_t>(), stream); break;
+      case 16: st = bnn_hip_bconv_grad_input_f32(pick_ptr<float>(), pick_ptr<float>(), pick_ptr<char>(), pick_ptr<float>(),
+                                                 pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(),
+                                                 (int)(rnd() % 5), (int)(rnd() % 4), stream); break;
+      case 17: st = bnn_hip_bconv_grad_weight_f32(pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_int(), pick_int(),
+                                                  pick_int(), pick_int(), pick_int(), pick_int(), (int)(rnd() % 5), (int)(rnd() % 4), stream); break;
+      case 18: st = bnn_hip_sign_thresholds_f32(pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(),
+                                                pick_ptr<float>(), pick_int(), pick_int(), pick_ptr<int32_t>(), stream); break;
+      default: { bnn_hip_conv_desc d = pick_desc();
+        (void)bnn_hip_shortcut_fold_supported(rnd() % 16 ? &d : nullptr, pick_int());
+        st = bnn_hip_blinear(pick_int(), pick_int(), pick_int(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
+                             pick_ptr<uint32_t>(), pick_int(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(),
+                             pick_ptr<float>(), stream);
+        break; }
+    }
+    if (!status_ok(st)) { std::fprintf(stderr, "unknown status %d\n", st); return 2; }
+  }
+  std::printf("CAPI_FUZZ_OK calls=%llu reached_launchers=%llu\n", g_calls, g_reached);
+  return g_reached > g_calls / 200 ? 0 : 3;     // the fuzz must actually get past the validators often enough
+}
