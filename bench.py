@@ -59,13 +59,15 @@ def parse_args():
                          "at --gpus 8), c2 the single 3x3 128->128 56x56 layer, c5 ResNet(HBlock,[3,4,6,3]) with the "
                          "fp16 MFMA stem at 128 images/GPU")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: 256; c5: 128)")
-    ap.add_argument("--engine", choices=("graph", "graph_fresh", "net_call", "fused", "layerwise"), default="graph",
+    ap.add_argument("--engine", choices=("graph", "graph_fresh", "net_call", "fused", "blockwise", "layerwise"), default="graph",
                     help="what the headline `value` times.  graph: fused executor replayed as HIP graphs over resident "
                          "static input buffers (default); graph_fresh: the same with a NEW input tensor every step "
                          "(stem launch on the caller's tensor + graph of the rest, no staging copy); net_call: the "
                          "reference's own call `net(x)` on the prepare_binary_model() model with a new tensor every "
                          "step (bnn_amd AutoFusion); fused: fused executor, eager launches, new tensor every step; "
-                         "layerwise: one launch per binary layer + torch BN/ReLU/add (auto-fusion off).  The other "
+                         "blockwise: whole-model fusion off, every residual block fuses itself (what a network that is "
+                         "not laid out like the reference's ResNet gets); layerwise: one launch per binary layer + torch "
+                         "BN/ReLU/add (all fusion off).  The other "
                          "engines are reported beside it in `engines` unless --no-extras")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend.  nccl = RCCL (one rank per GPU, the real thing); gloo: the same bench "
@@ -101,7 +103,8 @@ import torch.distributed as dist  # noqa: E402
 
 import bnn_amd as bnn  # noqa: E402
 from bnn_amd import hipops, native  # noqa: E402
-from bnn_amd.inference import FusedResNet, PipelinedInference, auto_fusion, per_layer_forward  # noqa: E402
+from bnn_amd.inference import (FusedResNet, PipelinedInference, auto_fusion, no_model_fusion,  # noqa: E402
+                               per_layer_forward)
 from bnn_amd.models import HBlock, ResNet, resnet18  # noqa: E402
 from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer  # noqa: E402
 from bnn_amd.parallel import ShardedInference, all_gather_scalar  # noqa: E402
@@ -471,7 +474,8 @@ def validate_gather(net, gathered, rank_input, B, world, rank, device, fused_kw,
     n = min(n_check, B)
     bad = []
     for r in range(world):
-        with per_layer_forward() if layerwise else contextlib.nullcontext():
+        ctx = {"layerwise": per_layer_forward, "blockwise": no_model_fusion}.get(layerwise, contextlib.nullcontext)
+        with ctx():
             want = ref_engine(rank_input(r, n).contiguous())
         got = gathered[r * B:r * B + n]
         if not torch.equal(got, want):
@@ -498,7 +502,10 @@ ENGINE_NOTES = {
     "net_call": "the reference's own call: net = prepare_binary_model(...).eval(); net(x) under no_grad with a NEW "
                 "tensor every step (examples/cifar10.py:140-149) — bnn_amd AutoFusion: stem launch + HIP graph",
     "fused": "FusedResNet(net)(x), 21 eager launches per forward, a NEW tensor every step",
-    "layerwise": "net(x) with auto-fusion off: one launch per binary layer + torch/MIOpen stem, BN, ReLU, add",
+    "blockwise": "net(x) with whole-model fusion off: torch/MIOpen stem and head, every residual block as its own fused "
+                 "executor (pack_act + convs with BN / ReLU / residual in their epilogues) — the tier a custom network "
+                 "built from bnn_amd.models blocks gets",
+    "layerwise": "net(x) with all fusion off: one launch per binary layer + torch/MIOpen stem, BN, ReLU, add",
 }
 
 
@@ -551,9 +558,9 @@ def bench_net(args, world, rank, device, info, timed):
             model = ShardedInference(FusedResNet(net, **kw))
             return lambda i: model.forward_even(xs[i % N_FRESH])
         model = ShardedInference(net)               # net_call / layerwise: the reference's own call
-        if engine == "layerwise":
+        if engine in ("layerwise", "blockwise"):
             def step(i):
-                with per_layer_forward():
+                with per_layer_forward() if engine == "layerwise" else no_model_fusion():
                     return model.forward_even(xs[i % N_FRESH])
             return step
         if kw:
@@ -562,7 +569,7 @@ def bench_net(args, world, rank, device, info, timed):
 
     multi = args.engine in ("graph", "graph_fresh")
     n_streams = max(1, args.streams) if multi else 1
-    head_kw = {} if args.engine in ("net_call", "layerwise") else fused_kw
+    head_kw = {} if args.engine in ("net_call", "layerwise", "blockwise") else fused_kw
     step = make_step(args.engine, n_streams, **head_kw)
     with torch.no_grad():
         dt, logits = timed(step, args.steps, args.warmup, sustain=args.sustain)
@@ -581,11 +588,11 @@ def bench_net(args, world, rank, device, info, timed):
             engines[head_key] = {"value": world * B * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
                                  "engine_clock_mhz": round(clock_mhz), "headline": True}
             for eng, k in (("graph", 2), ("graph", 1), ("graph_fresh", 2), ("graph_fresh", 1), ("net_call", 1),
-                           ("fused", 1), ("layerwise", 1)):
+                           ("fused", 1), ("blockwise", 1), ("layerwise", 1)):
                 key = f"{eng}_x{k}" if eng in ("graph", "graph_fresh") else eng
                 if key in engines or (c5 and eng == "net_call"):    # (c5 asks for the fp16 stem: not the model default)
                     continue
-                engines[key], _ = measure(eng, k, **({} if eng in ("net_call", "layerwise") else fused_kw))
+                engines[key], _ = measure(eng, k, **({} if eng in ("net_call", "layerwise", "blockwise") else fused_kw))
             for key, rec_e in engines.items():
                 rec_e["what"] = ENGINE_NOTES[key.split("_x")[0]]
             if "graph_x1" in engines:
@@ -596,7 +603,8 @@ def bench_net(args, world, rank, device, info, timed):
                     ex, max_abs_logit_diff_vs_default=float((lx - logits).abs().max()),
                     note="stem as a k-ordered fp32 fmaf chain on v_mfma_f32_16x16x4_f32 (bit-for-bit IEEE fp32)")
         gather_check = validate_gather(net, logits, lambda r, n: rank_input(r, n, last_j), B, world, rank, device,
-                                       head_kw, layerwise=args.engine == "layerwise") if dist.is_initialized() else None
+                                       head_kw, layerwise=args.engine if args.engine in ("layerwise", "blockwise") else False) \
+            if dist.is_initialized() else None
     if dist.is_initialized():     # per-rank step times: a straggler shows here, not only in the max
         per_rank_ms = [float(t) for t in all_gather_scalar(dt_local / args.steps * 1e3, device)]
     else:

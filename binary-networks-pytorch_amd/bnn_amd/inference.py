@@ -23,6 +23,7 @@ import os
 import threading
 import types
 import warnings
+import weakref
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -155,10 +156,10 @@ def is_native_model(model: nn.Module) -> bool:
 
 def resnet_shaped(model: nn.Module) -> bool:
     """The module layout of the reference's ``bnn.models.resnet.ResNet`` (resnet.py:93-101,147-164)."""
-    return all(isinstance(getattr(model, a, None), nn.Module) for a in
-               ("conv1", "bn1", "maxpool", "layer1", "layer2", "layer3", "layer4", "avgpool", "fc")) and \
-        all(isinstance(getattr(model, a), nn.Sequential) for a in ("layer1", "layer2", "layer3", "layer4")) and \
-        getattr(model, "stem_type", "basic") == "basic"
+    stem = getattr(model, "stem_type", "basic")
+    need = ("conv1", "maxpool", "layer1", "layer2", "layer3", "layer4", "avgpool", "fc") + (("bn1",) if stem == "basic" else ())
+    return stem in ("basic", "dabnn") and all(isinstance(getattr(model, a, None), nn.Module) for a in need) and \
+        all(isinstance(getattr(model, a), nn.Sequential) for a in ("layer1", "layer2", "layer3", "layer4"))
 
 
 def _activation(act: nn.Module):
@@ -192,7 +193,7 @@ class FusedResNet(nn.Module):
         self.fold_shortcut = fold_shortcut
         self._side = {}
         if not resnet_shaped(model):
-            raise FusionError("FusedResNet covers ResNets laid out like bnn.models.resnet.ResNet with the 'basic' stem")
+            raise FusionError("FusedResNet covers ResNets laid out like bnn.models.resnet.ResNet")
         self.model = model
         self._blocks: List[dict] = []
         self._graph = None
@@ -239,7 +240,9 @@ class FusedResNet(nn.Module):
         self._stem = None
         self._names = {id(mod): name for name, mod in m.named_modules()}
         mp = m.maxpool
-        if isinstance(mp, nn.MaxPool2d) and isinstance(m.bn1, nn.BatchNorm2d) and mp.dilation in (1, (1, 1)) \
+        self._stem_module = getattr(m, "stem_type", "basic") != "basic"   # daBNN stem (resnet.py:10-47): m.conv1 is all of it
+        if not self._stem_module and isinstance(mp, nn.MaxPool2d) and isinstance(m.bn1, nn.BatchNorm2d) \
+                and mp.dilation in (1, (1, 1)) \
                 and not mp.ceil_mode and isinstance(mp.kernel_size, int) and isinstance(mp.stride, int) \
                 and isinstance(mp.padding, int):
             self._stem = (*fold_bn(m.bn1), (mp.kernel_size, mp.stride, mp.padding))
@@ -335,7 +338,9 @@ class FusedResNet(nn.Module):
         if self._stem is not None:   # the conv runs in the vendor library, its BN -> ReLU -> MaxPool -> sign tail in one pass
             t = m.conv1(x)
             return hipops.bn_relu_maxpool_pack(t, self._stem[0], self._stem[1], True, *self._stem[2])
-        t = m.maxpool(m.relu(m.bn1(m.conv1(x))))
+        # any other stem runs as the torch modules it is (binary layers inside it one launch each); the residual blocks
+        # behind it are fused all the same
+        t = m.conv1(x) if self._stem_module else m.maxpool(m.relu(m.bn1(m.conv1(x))))
         return t, hipops.pack_act(t)
 
     def _back(self, t, packed) -> torch.Tensor:
@@ -734,6 +739,85 @@ def per_layer_forward():
         _PER_LAYER -= 1
 
 
+_NO_MODEL_FUSION = 0
+
+
+@contextlib.contextmanager
+def no_model_fusion():
+    """While active, whole-model fusion (``AutoFusion``) is off but residual blocks still fuse themselves
+    (``BlockFusion``): what a network that is NOT laid out like the reference's ResNet gets (``bench.py --engine
+    blockwise``)."""
+    global _NO_MODEL_FUSION
+    _NO_MODEL_FUSION += 1
+    try:
+        yield
+    finally:
+        _NO_MODEL_FUSION -= 1
+
+
+class BlockFusion:
+    """The second tier of the drop-in dispatch: a residual block of ``bnn_amd.models`` (``BasicBlock``, ``Bottleneck``,
+    ``PreBasicBlock``, ``HBlock``) called on its own — inside a network that is not laid out like the reference's
+    ``ResNet`` (a CIFAR-style three-stage ResNet-20, a custom backbone), or behind a stem the whole-model executor does
+    not cover — evaluates itself as ``FusedBlocks([block])``: fp32 NCHW in -> ``pack_act`` -> the block's convolutions
+    with BatchNorm / activation / residual add in their epilogues (activations between them as bit planes) -> fp32 NCHW
+    out; 3 launches and 3 fp32 passes over HBM for a ``BasicBlock`` instead of 8 kernels and 13 passes.  Same conditions
+    as ``AutoFusion`` (eval, no autograd, fp32 on a HIP device, no hooks on inner modules, not a replica); one instance
+    per block in ``block.__dict__['_bnn_auto_block']``."""
+
+    def __init__(self) -> None:
+        self.engine: Optional["FusedBlocks"] = None
+        self.failed_sig = None
+        self.calls = {"fused": 0, "declined": 0}
+        self.lock = threading.Lock()
+
+    def __deepcopy__(self, memo):
+        return BlockFusion()
+
+    def __reduce__(self):
+        return (BlockFusion, ())
+
+    def run(self, block: nn.Module, x: torch.Tensor) -> Optional[torch.Tensor]:
+        if (block.training or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4
+                or x.shape[0] == 0 or getattr(block, "_is_replica", False) or _PER_LAYER
+                or os.environ.get("BNN_AMD_AUTOFUSE", "1") == "0" or not native.available()):
+            self.calls["declined"] += 1
+            return None
+        with self.lock:
+            eng = self.engine
+            if eng is None:
+                sig = _param_signature(block)
+                if self.failed_sig == sig:
+                    self.calls["declined"] += 1
+                    return None
+                try:
+                    eng = self.engine = FusedBlocks(nn.Sequential(block))
+                except FusionError:
+                    self.failed_sig = sig
+                    self.calls["declined"] += 1
+                    return None
+            if AutoFusion._hooked(block) or next(block.parameters()).device != x.device:
+                self.calls["declined"] += 1
+                return None
+        try:
+            y = eng(x)
+        except FusionError:
+            with self.lock:
+                self.engine, self.failed_sig = None, _param_signature(block)
+            self.calls["declined"] += 1
+            return None
+        self.calls["fused"] += 1
+        return y
+
+
+def auto_block_forward(block: nn.Module, x: torch.Tensor) -> Optional[torch.Tensor]:
+    """Called at the top of the residual blocks' ``forward``: the fused block's output, or None -> its own forward."""
+    st = block.__dict__.get("_bnn_auto_block")
+    if st is None:
+        st = block.__dict__["_bnn_auto_block"] = BlockFusion()
+    return st.run(block, x)
+
+
 class AutoFusion:
     """What makes the reference's own call fast: ``net = prepare_binary_model(...)``, ``net.eval()``, ``net(x)`` under
     ``torch.no_grad()`` (examples/cifar10.py:71,140-149) runs the fused executor instead of one launch per layer plus
@@ -741,8 +825,8 @@ class AutoFusion:
 
     One instance lives in ``model.__dict__['_bnn_auto']`` (not a sub-module: ``state_dict`` and ``repr`` are those of
     the reference).  ``run(model, x)`` returns the logits, or ``None`` when the call has to take the model's own
-    per-layer forward: training mode or autograd recording, CPU / non-fp32 input, a ``DataParallel`` replica (its
-    parameters are re-broadcast every forward), forward hooks registered on inner modules (they would not fire), a
+    per-layer forward: training mode or autograd recording, CPU / non-fp32 input, forward hooks registered on inner
+    modules (they would not fire), a
     model the executor does not cover (``FusionError``, remembered until the parameters change), or
     ``BNN_AMD_AUTOFUSE=0``.
 
@@ -750,12 +834,17 @@ class AutoFusion:
     on the stem reads the caller's tensor and a HIP graph replays the rest (``FusedResNet.forward_fresh``) — the last,
     ragged batch of an epoch never pays for a capture.  A model built from classes of another package (same names
     and layout: the reference's ``bnn.models``) is fused only after its first fused result has been checked against
-    its own forward on the same input (logits within ``VERIFY_TOL`` relative to the largest one)."""
+    its own forward on the same input (logits within ``VERIFY_TOL`` relative to the largest one).
+
+    ``nn.DataParallel`` (examples/cifar10.py:74-77) replicates the model on every forward; the replicas share this object
+    (``replicate`` copies ``__dict__``) and get ONE executor per device, derived from the first replica seen there
+    and valid until a parameter of the master changes — so the reference's multi-GPU script runs the fused executor on
+    every GPU, not the per-layer path."""
 
     VERIFY_TOL = 2e-2       # a flipped sign() moves a logit by a few per cent (DESIGN.md section 2); a wrong graph by O(1)
     CAPTURE_AFTER = 1       # eager calls of a shape before its graph is captured
 
-    def __init__(self) -> None:
+    def __init__(self, owner: Optional[nn.Module] = None) -> None:
         self.engine: Optional[FusedResNet] = None
         self.failed_sig = None          # parameter signature for which fusion was refused
         self.reason: Optional[str] = None
@@ -763,6 +852,10 @@ class AutoFusion:
         self.seen = collections.Counter()
         self.lock = threading.Lock()
         self.calls = {"graph": 0, "eager": 0, "declined": 0}
+        # the model this state belongs to.  nn.DataParallel replicas (``replicate`` copies ``__dict__`` shallowly) share
+        # the object with the model they were made from: their executors live here, one per device
+        self.owner = None if owner is None else weakref.ref(owner)
+        self.replica_engines = {}       # device -> (master parameter signature, FusedResNet of the first replica there)
 
     def __deepcopy__(self, memo):       # copy.deepcopy(model): the copy derives its own executor
         return AutoFusion()
@@ -774,10 +867,11 @@ class AutoFusion:
         with self.lock:
             self.engine, self.failed_sig, self.reason, self.verified = None, None, None, False
             self.seen.clear()
+            self.replica_engines.clear()
 
     @staticmethod
     def enabled() -> bool:
-        return _PER_LAYER == 0 and os.environ.get("BNN_AMD_AUTOFUSE", "1") != "0"
+        return _PER_LAYER == 0 and _NO_MODEL_FUSION == 0 and os.environ.get("BNN_AMD_AUTOFUSE", "1") != "0"
 
     @staticmethod
     def _hooked(model: nn.Module) -> bool:
@@ -786,62 +880,96 @@ class AutoFusion:
             return True
         return any(m._forward_hooks or m._forward_pre_hooks for m in model.modules() if m is not model)
 
+    def _decline(self):
+        self.calls["declined"] += 1
+        return None
+
+    def _engine_for(self, model: nn.Module, x: torch.Tensor) -> Optional["FusedResNet"]:
+        """The executor for this call (built on first use), or None.  Called with the lock held."""
+        if getattr(model, "_is_replica", False):
+            # a DataParallel replica (examples/cifar10.py:74-77): its parameters are broadcast copies that are new on
+            # every forward, but their VALUES are the master's — one executor per device, derived from the first
+            # replica seen there (which it keeps alive), valid until a master parameter changes
+            master = self.owner() if self.owner is not None else None
+            if master is None or master is model:
+                return None
+            sig = _param_signature(master)
+            if self.failed_sig == sig:
+                return None
+            ent = self.replica_engines.get(x.device)
+            if ent is not None and ent[0] == sig:
+                return ent[1]
+            try:
+                eng = FusedResNet(model)
+            except FusionError as exc:
+                self.failed_sig, self.reason = sig, str(exc)
+                return None
+            self.replica_engines[x.device] = (sig, eng)
+            if not is_native_model(master) and not self.verified:
+                return None     # a foreign class is verified on the master first (one un-replicated call)
+            return eng
+        eng = self.engine
+        if eng is None:
+            sig = _param_signature(model)
+            if self.failed_sig == sig:
+                return None
+            try:
+                eng = FusedResNet(model)
+            except FusionError as exc:
+                self.failed_sig, self.reason = sig, str(exc)
+                return None
+            self.engine = eng
+            self.verified = self.verified or is_native_model(model)
+            if self.owner is None:
+                self.owner = weakref.ref(model)
+        return eng
+
     def run(self, model: nn.Module, x: torch.Tensor) -> Optional[torch.Tensor]:
         if (model.training or torch.is_grad_enabled() or not isinstance(x, torch.Tensor) or not x.is_cuda
                 or x.dtype != torch.float32 or x.dim() != 4 or x.shape[0] == 0
-                or getattr(model, "_is_replica", False) or not self.enabled() or not native.available()):
-            self.calls["declined"] += 1
-            return None
-        with self.lock:
-            eng = self.engine
-            if eng is None:
-                sig = _param_signature(model)
-                if self.failed_sig == sig:
-                    self.calls["declined"] += 1
-                    return None
-                try:
-                    eng = FusedResNet(model)
-                except FusionError as exc:
-                    self.failed_sig, self.reason = sig, str(exc)
-                    self.calls["declined"] += 1
-                    return None
-                self.engine, self.verified = eng, is_native_model(model)
-            if eng.model.fc.weight.device != x.device or self._hooked(model):
-                self.calls["declined"] += 1
-                return None
-            try:
-                return self._run_locked(eng, model, x)
-            except FusionError as exc:      # e.g. parameters moved to the CPU since the executor was built
+                or not self.enabled() or not native.available()):
+            return self._decline()
+        try:
+            with self.lock:     # lookup / build / verification / graph capture; the steady-state launches run outside
+                eng = self._engine_for(model, x)
+                if eng is None or eng.model.fc.weight.device != x.device or self._hooked(model):
+                    return self._decline()
+                if not self.verified:
+                    return self._verify(eng, model, x)
+                key = (tuple(x.shape), torch.cuda.current_stream(x.device).cuda_stream)
+                graph = eng.reads_caller_tensor and (key in eng._split or self.seen[(id(eng),) + key] >= self.CAPTURE_AFTER)
+                if graph:
+                    self.calls["graph"] += 1
+                    if key not in eng._split:
+                        return eng.forward_fresh(x)          # captures: under the lock
+                else:
+                    self.seen[(id(eng),) + key] += 1
+                    if len(self.seen) > 64:
+                        self.seen.clear()
+                    self.calls["eager"] += 1
+            return eng.forward_fresh(x) if graph else eng(x)
+        except FusionError as exc:      # e.g. parameters moved to the CPU since the executor was built
+            with self.lock:
                 self.engine, self.failed_sig, self.reason = None, _param_signature(model), str(exc)
-                self.calls["declined"] += 1
-                return None
+                self.replica_engines.clear()
+            return self._decline()
 
-    def _run_locked(self, eng: "FusedResNet", model: nn.Module, x: torch.Tensor) -> torch.Tensor:
-        if not self.verified:
-            y = eng(x)
-            n = min(2, x.shape[0])
-            want = getattr(type(model), "_bnn_base", type(model)).forward(model, x[:n])   # the class's OWN forward
-            err = float((y[:n] - want).abs().max() / want.abs().max().clamp_min(1e-30))
-            if not err <= self.VERIFY_TOL:
-                self.engine, self.failed_sig = None, _param_signature(model)
-                self.reason = f"fused result differs from the model's own forward (relative {err:.3g})"
-                warnings.warn(f"bnn_amd: {type(model).__name__}: {self.reason}; keeping the per-layer path",
-                              RuntimeWarning)
-                self.calls["declined"] += 1
-                return None
-            self.verified = True
-            self.calls["eager"] += 1
-            self.seen[(tuple(x.shape), torch.cuda.current_stream(x.device).cuda_stream)] += 1
-            return y
-        key = (tuple(x.shape), torch.cuda.current_stream(x.device).cuda_stream)
-        if eng.reads_caller_tensor and (key in eng._split or self.seen[key] >= self.CAPTURE_AFTER):
-            self.calls["graph"] += 1
-            return eng.forward_fresh(x)
-        self.seen[key] += 1
-        if len(self.seen) > 64:
-            self.seen.clear()
+    def _verify(self, eng: "FusedResNet", model: nn.Module, x: torch.Tensor) -> Optional[torch.Tensor]:
+        """First fused call of a model built from another package's classes: check it against the class's own forward."""
+        y = eng(x)
+        n = min(2, x.shape[0])
+        want = getattr(type(model), "_bnn_base", type(model)).forward(model, x[:n])   # the class's OWN forward
+        err = float((y[:n] - want).abs().max() / want.abs().max().clamp_min(1e-30))
+        if not err <= self.VERIFY_TOL:
+            self.engine, self.failed_sig = None, _param_signature(model)
+            self.reason = f"fused result differs from the model's own forward (relative {err:.3g})"
+            warnings.warn(f"bnn_amd: {type(model).__name__}: {self.reason}; keeping the per-layer path",
+                          RuntimeWarning)
+            return self._decline()
+        self.verified = True
         self.calls["eager"] += 1
-        return eng(x)
+        self.seen[(id(eng), tuple(x.shape), torch.cuda.current_stream(x.device).cuda_stream)] += 1
+        return y
 
 
 def _param_signature(model: nn.Module):
@@ -852,7 +980,7 @@ def auto_fusion(model: nn.Module) -> AutoFusion:
     """The model's ``AutoFusion`` state (created on first use)."""
     st = model.__dict__.get("_bnn_auto")
     if st is None:
-        st = model.__dict__["_bnn_auto"] = AutoFusion()
+        st = model.__dict__["_bnn_auto"] = AutoFusion(model)
     return st
 
 
@@ -882,7 +1010,12 @@ def _auto_class(base: type) -> type:
         def __reduce_ex__(self, protocol):      # pickle / deepcopy: rebuilt from the importable base class
             return (_rebuild_auto, (base,), self.__dict__)
 
+        def _replicate_for_data_parallel(self):  # replicas share the master's AutoFusion (one executor per device)
+            auto_fusion(self)
+            return base._replicate_for_data_parallel(self)
+
         dyn = type(base.__name__, (base,), {"forward": forward, "__reduce_ex__": __reduce_ex__, "_bnn_base": base,
+                                            "_replicate_for_data_parallel": _replicate_for_data_parallel,
                                             "__module__": base.__module__, "__qualname__": base.__qualname__,
                                             "__doc__": base.__doc__})
         _AUTO_CLASSES[base] = dyn

@@ -27,11 +27,27 @@ def _act(activation, channels: int) -> nn.Module:
     return activation(inplace=True) if activation == nn.ReLU else activation(num_parameters=channels)
 
 
+def _fused(block, x):
+    from ..inference import auto_block_forward      # (inference imports this module)
+    return auto_block_forward(block, x)
+
+
 class _Residual(nn.Module):
+    """Base of the residual blocks.  ``forward`` is the reference's op sequence (``_forward``), except that a block
+    evaluated for inference on a HIP device first offers itself to the fused block executor
+    (``bnn_amd/inference.py: BlockFusion``) — the blocks of a ``ResNet`` are normally fused as part of the whole model
+    (``AutoFusion``) and never get here."""
     expansion = 1
 
     def _shortcut(self, x: torch.Tensor) -> torch.Tensor:
         return x if self.downsample is None else self.downsample(x)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.training and x.is_cuda and not torch.is_grad_enabled():
+            y = _fused(self, x)
+            if y is not None:
+                return y
+        return self._forward(x)
 
 
 class BasicBlock(_Residual):
@@ -57,7 +73,7 @@ class BasicBlock(_Residual):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
         y = self.act1(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
         y += self._shortcut(x)
@@ -87,7 +103,7 @@ class PreBasicBlock(_Residual):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
         y = self.act1(self.conv1(self.bn1(x)))
         y = self.act2(self.conv2(self.bn2(y)))
         y += self._shortcut(x)
@@ -117,7 +133,7 @@ class Bottleneck(_Residual):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
         y = self.act1(self.bn1(self.conv1(x)))
         y = self.act2(self.bn2(self.conv2(y)))
         y = self.bn3(self.conv3(y))
@@ -148,7 +164,7 @@ class PreBottleneck(_Residual):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
         y = self.act1(self.conv1(self.bn1(x)))
         y = self.act2(self.conv2(self.bn2(y)))
         y = self.act3(self.conv3(self.bn3(y)))
@@ -186,7 +202,7 @@ class HBlock(_Residual):
         self.act3 = _act(activation, quarter)
         self.downsample = downsample
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
         o1 = self.conv1(self.act1(self.bn1(x)))
         o2 = self.conv2(self.act2(self.bn2(o1)))
         o3 = self.conv3(self.act3(self.bn3(o2)))

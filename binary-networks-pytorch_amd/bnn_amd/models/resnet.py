@@ -135,6 +135,13 @@ class ResNet(nn.Module):
         self.outplanes = out_ch
         return nn.Sequential(*stage)
 
+    def _replicate_for_data_parallel(self):
+        # nn.DataParallel replicas share the master's AutoFusion state (`replicate` copies __dict__): it must exist
+        # before the copy is made, or every replica of every forward would start from scratch
+        from ..inference import auto_fusion
+        auto_fusion(self)
+        return super()._replicate_for_data_parallel()
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         # eval + no_grad on a HIP device: the fused executor (bnn_amd/inference.py: AutoFusion) — what makes the
         # reference's own call `outputs = net(inputs)` (examples/cifar10.py:140-149) the fast path.  None -> per layer.

@@ -225,11 +225,28 @@ def test_data_parallel_replicas_share_packed_weights_per_device_and_version():
     xs = torch.from_numpy(gen.normal(5, (4, 3, 64, 64))).to(DEV)
     with torch.no_grad():
         want = FusedResNet(net)(xs)
+        from bnn_amd.inference import auto_fusion, per_layer_forward
         rep = nn.parallel.replicate(net, [0])[0]
-        assert getattr(rep, "_is_replica", False)
-        y_rep = rep(xs)                                      # replicas take the per-layer path (parameters are re-broadcast)
+        assert getattr(rep, "_is_replica", False) and rep.__dict__["_bnn_auto"] is auto_fusion(net)
+        per_layer0 = fastpath.stats()["conv2d"]
+        y_rep = rep(xs)                                      # the replica runs the fused executor of ITS device ...
+        st = auto_fusion(net)
+        assert torch.equal(y_rep, want) and fastpath.stats()["conv2d"] == per_layer0
+        assert list(st.replica_engines) == [xs.device] and st.engine is None
+        eng = st.replica_engines[xs.device][1]
         packs = fastpath.stats()["weight_packs"]
-        y_rep2 = nn.parallel.replicate(net, [0])[0](xs)
-        assert fastpath.stats()["weight_packs"] == packs and torch.equal(y_rep, y_rep2)
-        assert torch.allclose(y_rep, want, rtol=1e-3, atol=1e-3 * float(want.abs().max()))
-        assert torch.equal(nn.DataParallel(net, device_ids=[0])(xs), want)
+        for _ in range(2):                                   # ... and so do the replicas of later forwards: same executor
+            assert torch.equal(nn.parallel.replicate(net, [0])[0](xs), want)
+        assert st.replica_engines[xs.device][1] is eng and fastpath.stats()["weight_packs"] == packs
+        assert st.calls["graph"] >= 1
+        net.layer3[0].conv1.weight.neg_()                    # a master parameter changes: the executor is re-derived
+        y_new = nn.parallel.replicate(net, [0])[0](xs)
+        assert st.replica_engines[xs.device][1] is not eng and not torch.equal(y_new, want)
+        assert torch.equal(y_new, FusedResNet(net)(xs))
+        with per_layer_forward():                            # the per-layer path of a replica: packs cached on the master
+            y_lw = nn.parallel.replicate(net, [0])[0](xs)
+            packs = fastpath.stats()["weight_packs"]
+            y_lw2 = nn.parallel.replicate(net, [0])[0](xs)
+        assert fastpath.stats()["weight_packs"] == packs and torch.equal(y_lw, y_lw2)
+        assert torch.allclose(y_lw, y_new, rtol=1e-3, atol=1e-3 * float(y_new.abs().max()))
+        assert torch.equal(nn.DataParallel(net, device_ids=[0])(xs), y_new)

@@ -17,9 +17,9 @@ import torch.nn as nn
 
 import bnn_amd as bnn
 from bnn_amd import fastpath, native
-from bnn_amd.inference import (AutoFusion, FusedResNet, PipelinedInference, auto_fusion, install_auto_fusion,
-                               per_layer_forward)
-from bnn_amd.models import PreBasicBlock, resnet18
+from bnn_amd.inference import (AutoFusion, FusedBlocks, FusedResNet, PipelinedInference, auto_fusion,
+                               install_auto_fusion, no_model_fusion, per_layer_forward)
+from bnn_amd.models import BasicBlock, Bottleneck, HBlock, PreBasicBlock, resnet18
 from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer
 from tests.golden import gen
 
@@ -103,11 +103,14 @@ def test_what_keeps_the_per_layer_path():
             y_layer = net(x)
         assert fastpath.stats()["conv2d"] == n0 + 19 and st.calls["declined"] == 1
         handle = net.layer2[0].conv1.register_forward_hook(lambda m, i, o: None)
-        y_fused = net(x)                             # builds the executor, then sees the hook: declined
-        assert fastpath.stats()["conv2d"] == n0 + 38 and st.calls["declined"] == 2
+        y_hooked = net(x)                            # builds the executor, then sees the hook: declined as a whole —
+        # the model's own forward runs, in which every block WITHOUT a hook fuses itself (BlockFusion) and the hooked
+        # block runs layer by layer: its two convs and its shortcut conv are the only per-layer calls
+        assert fastpath.stats()["conv2d"] == n0 + 19 + 3 and st.calls["declined"] == 2
+        assert torch.allclose(y_hooked, y_layer, rtol=1e-3, atol=1e-3 * float(y_layer.abs().max()))
         handle.remove()
         y_fused = net(x)
-        assert st.calls["eager"] == 1 and fastpath.stats()["conv2d"] == n0 + 38
+        assert st.calls["eager"] == 1 and fastpath.stats()["conv2d"] == n0 + 22
         net.train()
         net(x)
         net.eval()
@@ -147,8 +150,27 @@ def test_data_parallel_wrapper_and_deepcopy_and_state_dict():
     assert list(net.state_dict().keys()) == keys and "_bnn_auto" not in repr(net)
 
 
-def test_uncovered_model_keeps_its_own_forward_silently():
+def test_dabnn_stem_runs_as_modules_in_front_of_fused_blocks():
+    """The cheaper stem of daBNN (bnn/models/resnet.py:10-47): the stem runs as the torch modules it is, the residual
+    blocks behind it are fused (no graph: the part that reads the caller's tensor is not one kernel)."""
     net = bnn.prepare_binary_model(resnet18(stem_type="dabnn"), _cfg(), ignore_layers_name=["_first_", "_last_"])
+    net = _load(net)
+    x = dev(gen.normal(14, (4, 3, 64, 64)))
+    with torch.no_grad():
+        n0 = fastpath.stats()["conv2d"]
+        y = net(x)
+        st = auto_fusion(net)
+        assert st.engine is not None and not st.engine.reads_caller_tensor and st.calls["eager"] == 1
+        assert fastpath.stats()["conv2d"] - n0 == 3          # the stem's three binary convs (its first conv stays float)
+        assert torch.equal(net(x), y) and st.calls == {"graph": 0, "eager": 2, "declined": 0}
+        with per_layer_forward():
+            y_layer = net(x)
+    assert torch.allclose(y, y_layer, rtol=1e-3, atol=1e-3 * float(y_layer.abs().max()))
+
+
+def test_uncovered_model_keeps_its_own_forward_silently():
+    net = bnn.prepare_binary_model(resnet18(norm_layer=lambda c: nn.InstanceNorm2d(c, affine=True)), _cfg(),
+                                   ignore_layers_name=["_first_", "_last_"])
     net = net.to(DEV).eval()
     x = dev(gen.normal(9, (2, 3, 64, 64)))
     with torch.no_grad():
@@ -246,3 +268,93 @@ def test_forward_fresh_keeps_a_bounded_number_of_graphs():
         assert torch.equal(eng.forward_fresh(x), eager(x))
     assert len(eng._split) == FusedResNet.MAX_SPLIT_GRAPHS
     assert isinstance(auto_fusion(net), AutoFusion)
+
+
+# ---- second tier: residual blocks fuse themselves when the whole model is not covered -------------------------------
+
+class Cifar20(nn.Module):
+    """A CIFAR-style three-stage ResNet (the "ResNet-20" BASELINE.json's config 1 names; 16 / 32 / 64 channels, no
+    max-pool): built from bnn_amd's BasicBlock but NOT laid out like the reference's ImageNet ResNet."""
+
+    def __init__(self, n=3, width=16):
+        super().__init__()
+        self.stem = nn.Sequential(nn.Conv2d(3, width, 3, padding=1, bias=False), nn.BatchNorm2d(width), nn.ReLU())
+        blocks, inp = [], width
+        for planes, stride in ((width, 1), (2 * width, 2), (4 * width, 2)):
+            for i in range(n):
+                ds = None
+                if i == 0 and (stride != 1 or inp != planes):
+                    ds = nn.Sequential(nn.AvgPool2d(stride, stride, ceil_mode=True, count_include_pad=False),
+                                       nn.Conv2d(inp, planes, 1, bias=False), nn.BatchNorm2d(planes))
+                blocks.append(BasicBlock(inp, planes, stride if i == 0 else 1, ds))
+                inp = planes
+        self.blocks = nn.Sequential(*blocks)
+        self.head = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(inp, 10))
+
+    def forward(self, x):
+        return self.head(self.blocks(self.stem(x)))
+
+
+def test_blocks_of_a_custom_network_fuse_themselves():
+    net = bnn.prepare_binary_model(Cifar20(), _cfg(), ignore_layers_name=["_first_", "_last_"])
+    assert "_bnn_auto" not in net.__dict__ and not hasattr(type(net), "_bnn_base")     # not ResNet-shaped: no model dispatch
+    net = _load(net)
+    x = dev(gen.normal(21, (16, 3, 32, 32)))
+    with torch.no_grad():
+        with per_layer_forward():
+            n0 = fastpath.stats()["conv2d"]
+            want = net(x)
+            assert fastpath.stats()["conv2d"] - n0 == 9 * 2 + 2          # every binary conv on its own
+        n0, l0 = fastpath.stats()["conv2d"], native.launch_count()
+        y = net(x)
+        assert fastpath.stats()["conv2d"] == n0                          # nothing through the per-layer path
+        y2 = net(x)
+    blocks = list(net.blocks)
+    assert all(b.__dict__["_bnn_auto_block"].calls == {"fused": 2, "declined": 0} for b in blocks)
+    assert torch.equal(y, y2)
+    assert torch.allclose(y, want, rtol=1e-3, atol=1e-3 * float(want.abs().max()))
+    # one block on its own == the executor for a Sequential of it, bit for bit
+    blk = blocks[3]
+    t = dev(gen.activation("relu", 22, (4, 16, 32, 32)))
+    with torch.no_grad():
+        assert torch.equal(blk(t), FusedBlocks(nn.Sequential(blk))(t))
+    assert list(net.state_dict().keys()) == [k for k in net.state_dict().keys() if "_bnn" not in k]
+
+
+@pytest.mark.parametrize("kind", ["bottleneck", "prebasic", "hblock"])
+def test_other_block_families_fuse_themselves_too(kind):
+    if kind == "bottleneck":
+        blk = Bottleneck(64, 16)
+    elif kind == "prebasic":
+        blk = PreBasicBlock(64, 64, activation=nn.PReLU)
+    else:
+        blk = HBlock(64, 64)
+    blk = _load(bnn.prepare_binary_model(blk, _cfg()))
+    x = dev(gen.normal(23, (4, 64, 14, 14)))
+    with torch.no_grad():
+        with per_layer_forward():
+            want = blk(x)
+        n0 = fastpath.stats()["conv2d"]
+        y = blk(x)
+        assert fastpath.stats()["conv2d"] == n0 and blk.__dict__["_bnn_auto_block"].calls["fused"] == 1
+        with no_model_fusion():                 # (switches whole-model fusion off, not the blocks)
+            assert torch.equal(blk(x), y)
+        blk.train()
+        blk(x)
+        blk.eval()
+        assert blk.__dict__["_bnn_auto_block"].calls["fused"] == 2
+    assert torch.allclose(y, want, rtol=1e-3, atol=1e-3 * float(want.abs().max()))
+
+
+def test_resnet_with_model_fusion_off_runs_blockwise():
+    net = _r18()
+    x = dev(gen.normal(24, (4, 3, 64, 64)))
+    with torch.no_grad():
+        want = net(x)
+        n0 = fastpath.stats()["conv2d"]
+        with no_model_fusion():
+            y = net(x)                          # torch stem + 8 self-fused blocks + torch head
+        assert fastpath.stats()["conv2d"] == n0
+        assert all(b.__dict__["_bnn_auto_block"].calls["fused"] == 1 for st_ in (net.layer1, net.layer2, net.layer3, net.layer4)
+                   for b in st_)
+    assert torch.allclose(y, want, rtol=1e-3, atol=1e-3 * float(want.abs().max()))
