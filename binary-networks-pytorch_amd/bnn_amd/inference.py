@@ -791,7 +791,9 @@ class BlockFusion:
                     self.calls["declined"] += 1
                     return None
                 try:
-                    eng = self.engine = FusedBlocks(nn.Sequential(block))
+                    seq = nn.Sequential(block)
+                    seq.training = False            # (a new container starts in training mode; the block is in eval mode)
+                    eng = self.engine = FusedBlocks(seq)
                 except FusionError:
                     self.failed_sig = sig
                     self.calls["declined"] += 1
@@ -850,7 +852,8 @@ class AutoFusion:
         self.reason: Optional[str] = None
         self.verified = False
         self.seen = collections.Counter()
-        self.lock = threading.Lock()
+        self.lock = threading.RLock()   # re-entrant: the first-call check runs the model's own forward under it
+        self._verifying = False
         self.calls = {"graph": 0, "eager": 0, "declined": 0}
         # the model this state belongs to.  nn.DataParallel replicas (``replicate`` copies ``__dict__`` shallowly) share
         # the object with the model they were made from: their executors live here, one per device
@@ -905,7 +908,8 @@ class AutoFusion:
                 self.failed_sig, self.reason = sig, str(exc)
                 return None
             self.replica_engines[x.device] = (sig, eng)
-            if not is_native_model(master) and not self.verified:
+            self.verified = self.verified or is_native_model(master)
+            if not self.verified:
                 return None     # a foreign class is verified on the master first (one un-replicated call)
             return eng
         eng = self.engine
@@ -931,6 +935,8 @@ class AutoFusion:
             return self._decline()
         try:
             with self.lock:     # lookup / build / verification / graph capture; the steady-state launches run outside
+                if self._verifying:         # the model's own forward, run by _verify: not a call to dispatch
+                    return self._decline()
                 eng = self._engine_for(model, x)
                 if eng is None or eng.model.fc.weight.device != x.device or self._hooked(model):
                     return self._decline()
@@ -958,7 +964,11 @@ class AutoFusion:
         """First fused call of a model built from another package's classes: check it against the class's own forward."""
         y = eng(x)
         n = min(2, x.shape[0])
-        want = getattr(type(model), "_bnn_base", type(model)).forward(model, x[:n])   # the class's OWN forward
+        self._verifying = True
+        try:
+            want = getattr(type(model), "_bnn_base", type(model)).forward(model, x[:n])   # the class's OWN forward
+        finally:
+            self._verifying = False
         err = float((y[:n] - want).abs().max() / want.abs().max().clamp_min(1e-30))
         if not err <= self.VERIFY_TOL:
             self.engine, self.failed_sig = None, _param_signature(model)

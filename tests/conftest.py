@@ -12,6 +12,10 @@ for p in (ROOT, PKG_DIR):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a hung test (a deadlock, a kernel that never returns) must fail, not sit on the GPU box until the caller's own
+    # limit: pytest-timeout is in the image; without it the option below does not exist and nothing changes
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 600
 
 
 def pytest_collection_modifyitems(config, items):
