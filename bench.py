@@ -224,7 +224,8 @@ def pmc_traffic():
     (profiles/rNN_c2_pmc_counters.json, collected by tools/gpu_profile.sh with separate --pmc runs).
     FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
     (checked on this box: pack_act's 411 MB float4 stream reads as 205 MB)."""
-    for name in ("r03_c2_pmc_counters.json", "r02_c2_pmc_counters.json", "r01_c2_pmc_counters.json"):
+    for name in ("r04_c2_pmc_counters.json", "r03_c2_pmc_counters.json", "r02_c2_pmc_counters.json",
+                 "r01_c2_pmc_counters.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 pmc = json.load(fh)
@@ -239,7 +240,7 @@ def pmc_traffic():
 def fly_traffic():
     """HBM bytes per launch of the one-launch layer kernel from its committed PMC passes
     (profiles/rNN_c2_fused_pmc.json: 2*FETCH_SIZE + WRITE_SIZE, KiB, same correction as above)."""
-    for name in ("r03_c2_fused_pmc.json",):
+    for name in ("r04_c2_fused_pmc.json", "r03_c2_fused_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 k = json.load(fh)
@@ -428,16 +429,17 @@ def bench_c2(args, world, rank, device, info, timed):
     dt, out = timed(step, args.steps, args.warmup, sustain=args.sustain)
     sustained, clock_mhz = timed.sustained, timed.clock_mhz
     assert out.shape == (N, O, H, W)
-    # two batches in flight (the way the whole-net headline is run)
-    streams = [torch.cuda.Stream(device=device) for _ in range(2)]
-    xs = [x, x.clone()]
+    dt2 = None
+    if not args.no_extras:      # two batches in flight (the way the whole-net headline is run)
+        streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+        xs = [x, x.clone()]
 
-    def step2(i):
-        with torch.cuda.stream(streams[i & 1]):
-            return hipops.bconv2d_direct(xs[i & 1], pw, stride=1, padding=1)
-    for st in streams:
-        st.wait_stream(torch.cuda.current_stream(device))
-    dt2, _ = timed(step2, args.steps, args.warmup)
+        def step2(i):
+            with torch.cuda.stream(streams[i & 1]):
+                return hipops.bconv2d_direct(xs[i & 1], pw, stride=1, padding=1)
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream(device))
+        dt2, _ = timed(step2, args.steps, args.warmup)
     roof = None if args.no_roofline else conv_c2_roofline(device, info, batch=N, act_kind="relu")
     lane_ops = 2.0 * ((C * 9 + 31) // 32) * N * O * H * W
     rec = {"metric": "images/sec single 3x3 binary Conv2d 128->128 56x56 (fp32 NCHW in -> fp32 NCHW out)",
@@ -449,9 +451,10 @@ def bench_c2(args, world, rank, device, info, timed):
                                   "relu(N(0,1)), one bnn_hip_bconv2d_direct launch per step (sign(x) on the fly)",
                       "parallelism": f"{world} replicas"},
            "layer_int_alu_frac": lane_ops * args.steps / dt / int_alu_peak(info),
-           "engine_clock_mhz": round(clock_mhz),
-           "two_batches_in_flight": {"value": world * N * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3,
-                                     "layer_int_alu_frac": lane_ops * args.steps / dt2 / int_alu_peak(info)}}
+           "engine_clock_mhz": round(clock_mhz)}
+    if dt2 is not None:
+        rec["two_batches_in_flight"] = {"value": world * N * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3,
+                                        "layer_int_alu_frac": lane_ops * args.steps / dt2 / int_alu_peak(info)}
     if sustained is not None:
         sustained["value"] = world * N * sustained["steps"] / sustained["seconds"]
         sustained["layer_int_alu_frac"] = lane_ops * sustained["steps"] / sustained["seconds"] / int_alu_peak(info)

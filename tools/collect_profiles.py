@@ -116,6 +116,14 @@ if fagg:
 stats_c2 = glob.glob(os.path.join(src, "stats_c2", "**", "*kernel_stats.csv"), recursive=True)
 if stats_c2:
     shutil.copy(stats_c2[0], os.path.join(dst, f"{tag}_bench_c2_kernel_stats.csv"))
+stats_c2_1 = glob.glob(os.path.join(src, "stats_c2_1", "**", "*kernel_stats.csv"), recursive=True)
+if stats_c2_1:      # one launch at a time, nothing else in the process: the clean average of bconv_fly_kernel
+    shutil.copy(stats_c2_1[0], os.path.join(dst, f"{tag}_bench_c2_kernel_stats_1stream.csv"))
+    ln = [l for l in open(os.path.join(src, "stats_c2_1.log")).read().splitlines() if l.startswith("{")]
+    if ln:
+        open(os.path.join(dst, f"{tag}_bench_c2_1stream.json"), "w").write(stamped(
+            ln[-1], "rocprofv3 --kernel-trace --stats -- python bench.py --config c2 --steps 20 --warmup 5 --sustain 0 "
+                    "--no-extras --no-roofline --no-cpu-baseline") + "\n")
 for n in ("layerwise", "fused", "fused_exact_stem"):     # written by tests/test_gpu_c3_full.py on the GPU box
     fn = os.path.join(ROOT, "gpurun_out", f"c3_b256_parity_{n}.json")
     if os.path.exists(fn):

@@ -4,10 +4,17 @@
 # conv kernel and of the stem kernel.  Run on the GPU box:   gpurun --timeout 1500 -- 'bash tools/gpu_profile.sh'
 R="${GRAFT_REPO_ROOT:-$(pwd)}"; OUT="$R/gpurun_out/final"; rm -rf "$OUT"; mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
 timeout 900 python "$R/bench.py" --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/bench.json"
+# full-size parity records (gpurun_out/c3_b256_parity_*.json) of the same build
+( cd "$R" && timeout 600 python -m pytest tests/test_gpu_c3_full.py -q --timeout 300 2>&1 | tail -2 > "$OUT/c3_full.txt" )
 timeout 300 python "$R/bench.py" --config c2 --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/bench_c2.json"
 timeout 600 python "$R/bench.py" --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > "$OUT/bench_c5.json"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python "$R/bench.py" --steps 20 --warmup 5 --no-extras --no-cpu-baseline > "$OUT/stats.log" 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -o bench1 -- python "$R/bench.py" --steps 20 --warmup 5 --streams 1 --no-extras --no-cpu-baseline --no-roofline > "$OUT/stats1.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python "$R/bench.py" --steps 20 --warmup 5 --sustain 0 --no-extras --no-cpu-baseline > "$OUT/stats.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -o bench1 -- python "$R/bench.py" --steps 20 --warmup 5 --sustain 0 --streams 1 --no-extras --no-cpu-baseline --no-roofline > "$OUT/stats1.log" 2>&1
+if [ "${QUICK:-0}" = "1" ]; then   # bench lines, kernel-trace stats and the c2 one-stream CSV only (no PMC, training, stem A/B)
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2_1" -o bench_c2_1 -- python "$R/bench.py" --config c2 --steps 20 --warmup 5 --sustain 0 --no-extras --no-roofline --no-cpu-baseline > "$OUT/stats_c2_1.log" 2>&1
+  find "$OUT" -name "*kernel_trace.csv" -size +8M -delete
+  cut -c1-300 "$OUT/bench.json"; echo; head -6 "$OUT"/stats_c2_1/*kernel_stats.csv | cut -c1-160; exit 0
+fi
 pmc() { n=$1; shift
   ONLY=c2 ITERS=3 timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$n" -o $n -- python "$R/tools/bench_conv.py" > "$OUT/$n.log" 2>&1; }
 pmc sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
@@ -23,7 +30,11 @@ fpmc sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INS
 fpmc grbm GRBM_GUI_ACTIVE
 fpmc fetch FETCH_SIZE
 fpmc write WRITE_SIZE
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -o bench_c2 -- python "$R/bench.py" --config c2 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/stats_c2.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -o bench_c2 -- python "$R/bench.py" --config c2 --steps 20 --warmup 5 --sustain 0 --no-cpu-baseline > "$OUT/stats_c2.log" 2>&1
+# the same line strictly one launch at a time and without the roofline block's packed-kernel / two-launch legs: the clean
+# per-launch average of bconv_fly_kernel (the CSV above mixes in the two-stream leg)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2_1" -o bench_c2_1 -- python "$R/bench.py" --config c2 --steps 20 --warmup 5 --sustain 0 --no-extras --no-roofline --no-cpu-baseline > "$OUT/stats_c2_1.log" 2>&1
+cp "$OUT/stats_c2_1.log" "$OUT/bench_c2_1stream.log" 2>/dev/null
 spmc() { n=$1; shift
   ONLY=default timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/stem_$n" -o stem_$n -- python "$R/tools/bench_stem.py" > "$OUT/stem_$n.log" 2>&1; }
 spmc a SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
