@@ -8,13 +8,17 @@
                g_W through the weight hook's own autograd graph (sign STE + alpha = mean|W|)
 
 Each gradient GEMM has ONE real operand (``g_y``) and one that is exactly ternary (``sign(Wc)``, ``sign(x)``).
-For the 3x3 / padding 1 layers of stride 1 or 2 (16 of the 19 binary convs of a ResNet-18, 99 % of its MACs) both run
-on hand-written MFMA kernels (``csrc/grad.hip``: g split into fp16 hi + lo, the ternary side exact in fp16, two
-``v_mfma_f32_16x16x32_f16`` per product, fp32 accumulation — the rounding class of an fp32 convolution at 1/8 of
-its matrix time), with the STE mask fused into the input-gradient store.  1x1 (shortcut) layers use the library
-(``aten::convolution_backward``).  ``W_hat = weight_pre_process(W)`` is computed by the hook under autograd, which
-makes the weight gradient flow exactly as in the reference composition; the forward kernel re-derives the packed
-form of the same weights on every training forward (``fastpath.packed_weight(..., fresh=True)``).
+For the 3x3 / padding 1 layers of stride 1 or 2 and the 1x1 / stride 1 (shortcut) layers — all 19 binary convs of a
+ResNet-18 — both run on hand-written MFMA kernels (``csrc/grad.hip``: g split into THREE bf16 terms hi + mid + lo — 24
+mantissa bits and the exponent range of fp32, so gradients of a mean-reduced loss at batch 256 (1e-5 .. 1e-9) keep
+fp32 accuracy — the ternary side exact in bf16, three ``v_mfma_f32_16x16x32_bf16`` per product, fp32 accumulation), with
+the STE mask fused into the input-gradient store; any other geometry uses ``aten::convolution_backward``.
+``W_hat = weight_pre_process(W)`` is computed by the hook under autograd, which makes the weight gradient flow exactly
+as in the reference composition; the forward kernel re-derives the packed form of the same weights on every training
+forward (``fastpath.packed_weight(..., fresh=True)``).  The forward is ONE launch (``bnn_hip_bconv2d_direct``:
+``sign(x)`` on the fly in LDS, no packed copy of the activations in HBM); what it keeps for the backward is the fp32
+``x`` (sign and STE mask are re-derived from it by the gradient kernels — a 3-bit-per-element form is the open item of
+DESIGN.md section 7).
 
 Data-parallel training is ordinary ``DistributedDataParallel`` over RCCL (backend ``"nccl"``), one
 process per GPU: the binary layers are ``nn.Module``s with ordinary fp32 Parameters, so gradient
@@ -34,8 +38,7 @@ BINARY_GRADS = True  # False: library fp32 gradient convolutions for every layer
 class BinaryConv2dTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_hat, bias, layer, plan, packed):
-        act = hipops.pack_act(x)
-        out = hipops.bconv2d(act, packed, bias, None, layer.stride, layer.padding, layer.dilation)
+        out = hipops.bconv2d_direct(x, packed, bias, None, layer.stride, layer.padding, layer.dilation)   # one launch
         ctx.save_for_backward(x, w_hat)
         ctx.conf = (tuple(layer.stride), tuple(layer.padding), tuple(layer.dilation), bias is not None,
                     None if bias is None else tuple(bias.shape))
