@@ -600,7 +600,36 @@ def grad_pack_weight(w_hat: torch.Tensor):
     return packed, alpha
 
 
-def _grad_shapes(g: torch.Tensor, x: torch.Tensor, stride: int):
+@dataclass
+class SavedAct:
+    """What the backward of a binary convolution needs from its fp32 input, in 3 bits per element: the sign planes
+    (``sign``: P = x > 0, M = x < 0) and the straight-through mask ``T`` = |x| < 1, int64 ``[N, ceil(C/64), H, W]`` each
+    (csrc/pack_ste.hip).  The reference's autograd keeps the fp32 ``x`` and an fp32 ``sign(x)`` instead."""
+    sign: "PackedAct"
+    T: torch.Tensor
+    shape: Tuple[int, int, int, int]
+
+    def nbytes(self) -> int:
+        return 3 * self.T.numel() * 8
+
+
+def pack_act_ste(x: torch.Tensor) -> SavedAct:
+    """``bnn_hip_pack_act_ste_f32``: one pass over ``x`` -> the three bit planes of ``SavedAct``."""
+    x = _require_cuda_f32(x, "activation")
+    if x.dim() != 4:
+        raise native.NativeError(f"bnn_amd: pack_act_ste expects NCHW, got shape {tuple(x.shape)}")
+    lib = native.require()
+    N, C, H, W = x.shape
+    with torch.cuda.device(x.device):
+        a = empty_packed(N, C, H, W, x.device)
+        T = torch.empty_like(a.P)
+        if N:
+            native.check(lib.bnn_hip_pack_act_ste_f32(x.data_ptr(), N, C, H, W, a.P.data_ptr(), a.M.data_ptr(),
+                                                      T.data_ptr(), _stream(x.device)), "bnn_hip_pack_act_ste_f32")
+    return SavedAct(a, T, (N, C, H, W))
+
+
+def _grad_shapes(g: torch.Tensor, x, stride: int):
     N, C, H, W = x.shape
     O = g.shape[1]
     if tuple(g.shape) != (N, O, (H - 1) // stride + 1, (W - 1) // stride + 1):
@@ -609,12 +638,21 @@ def _grad_shapes(g: torch.Tensor, x: torch.Tensor, stride: int):
     return N, O, C, H, W
 
 
-def bconv_grad_input(g: torch.Tensor, x: torch.Tensor, packed: torch.Tensor, alpha: torch.Tensor,
+def bconv_grad_input(g: torch.Tensor, x, packed: torch.Tensor, alpha: torch.Tensor,
                      ksize: int = 3, stride: int = 1) -> torch.Tensor:
-    """dL/dx of the binary 3x3/p1 or 1x1/p0 conv incl. the hard-tanh STE mask (bnn/ops.py:68-73)."""
+    """dL/dx of the binary 3x3/p1 or 1x1/p0 conv incl. the hard-tanh STE mask (bnn/ops.py:68-73).  ``x``: the fp32
+    input, or its ``SavedAct`` (the mask plane is all this kernel needs of it) — same bits either way."""
     g = _require_cuda_f32(g, "grad_output")
-    x = _require_cuda_f32(x, "input")
     lib = native.require()
+    if isinstance(x, SavedAct):
+        N, O, C, H, W = _grad_shapes(g, x, stride)
+        with torch.cuda.device(g.device):
+            gx = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device)
+            native.check(lib.bnn_hip_bconv_grad_input_packed_f32(
+                g.data_ptr(), alpha.data_ptr(), packed.data_ptr(), x.T.data_ptr(), gx.data_ptr(), N, O, C, H, W, ksize,
+                stride, _stream(g.device)), "bnn_hip_bconv_grad_input_packed_f32")
+        return gx
+    x = _require_cuda_f32(x, "input")
     N, O, C, H, W = _grad_shapes(g, x, stride)
     with torch.cuda.device(g.device):
         gx = torch.empty_like(x)
@@ -624,18 +662,25 @@ def bconv_grad_input(g: torch.Tensor, x: torch.Tensor, packed: torch.Tensor, alp
     return gx
 
 
-def bconv_grad_weight(g: torch.Tensor, x: torch.Tensor, ksize: int = 3, stride: int = 1) -> torch.Tensor:
-    """dL/dWhat [O,C,k,k] of the binary 3x3/p1 or 1x1/p0 conv: correlation of g with sign(x)."""
+def bconv_grad_weight(g: torch.Tensor, x, ksize: int = 3, stride: int = 1) -> torch.Tensor:
+    """dL/dWhat [O,C,k,k] of the binary 3x3/p1 or 1x1/p0 conv: correlation of g with sign(x).  ``x``: the fp32 input, or
+    its ``SavedAct`` (the sign planes are all this kernel needs of it) — same bits either way."""
     g = _require_cuda_f32(g, "grad_output")
-    x = _require_cuda_f32(x, "input")
+    if not isinstance(x, SavedAct):
+        x = _require_cuda_f32(x, "input")
     lib = native.require()
     N, O, C, H, W = _grad_shapes(g, x, stride)
     splits = int(lib.bnn_hip_bconv_grad_weight_splits(N, O, C, ksize))
     with torch.cuda.device(g.device):
         part = torch.empty((splits, O, C, ksize, ksize), dtype=torch.float32, device=g.device)
-        native.check(lib.bnn_hip_bconv_grad_weight_f32(g.data_ptr(), x.data_ptr(), part.data_ptr(), splits,
-                                                       N, O, C, H, W, ksize, stride, _stream(g.device)),
-                     "bnn_hip_bconv_grad_weight_f32")
+        if isinstance(x, SavedAct):
+            native.check(lib.bnn_hip_bconv_grad_weight_packed_f32(
+                g.data_ptr(), x.sign.P.data_ptr(), x.sign.M.data_ptr(), part.data_ptr(), splits, N, O, C, H, W, ksize,
+                stride, _stream(g.device)), "bnn_hip_bconv_grad_weight_packed_f32")
+        else:
+            native.check(lib.bnn_hip_bconv_grad_weight_f32(g.data_ptr(), x.data_ptr(), part.data_ptr(), splits,
+                                                           N, O, C, H, W, ksize, stride, _stream(g.device)),
+                         "bnn_hip_bconv_grad_weight_f32")
         return part[0] if splits == 1 else part.sum(0)
 
 

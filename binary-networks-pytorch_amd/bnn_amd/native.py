@@ -38,7 +38,8 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_grad_weight_pack_bytes", "bnn_hip_grad_pack_weight_f32", "bnn_hip_bconv_grad_input_f32",
     "bnn_hip_bconv_grad_weight_splits", "bnn_hip_bconv_grad_weight_f32",
     "bnn_hip_bconv2d_direct", "bnn_hip_bconv2d_direct_plan", "bnn_hip_shortcut_fold_supported",
-    "bnn_hip_probe_clock",
+    "bnn_hip_probe_clock", "bnn_hip_pack_act_ste_f32", "bnn_hip_bconv_grad_input_packed_f32",
+    "bnn_hip_bconv_grad_weight_packed_f32",
 )
 
 
@@ -148,6 +149,9 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_bconv_grad_input_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]
     lib.bnn_hip_bconv_grad_weight_splits.argtypes = [_i, _i, _i, _i]
     lib.bnn_hip_bconv_grad_weight_f32.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
+    lib.bnn_hip_pack_act_ste_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]
+    lib.bnn_hip_bconv_grad_input_packed_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]
+    lib.bnn_hip_bconv_grad_weight_packed_f32.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
     lib.bnn_hip_probe_int_alu.argtypes = [_i, _i, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), _vp]
     lib.bnn_hip_probe_clock.argtypes = [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _vp]

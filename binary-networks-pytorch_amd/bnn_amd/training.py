@@ -16,9 +16,10 @@ the STE mask fused into the input-gradient store; any other geometry uses ``aten
 ``W_hat = weight_pre_process(W)`` is computed by the hook under autograd, which makes the weight gradient flow exactly
 as in the reference composition; the forward kernel re-derives the packed form of the same weights on every training
 forward (``fastpath.packed_weight(..., fresh=True)``).  The forward is ONE launch (``bnn_hip_bconv2d_direct``:
-``sign(x)`` on the fly in LDS, no packed copy of the activations in HBM); what it keeps for the backward is the fp32
-``x`` (sign and STE mask are re-derived from it by the gradient kernels — a 3-bit-per-element form is the open item of
-DESIGN.md section 7).
+``sign(x)`` on the fly in LDS, no packed copy of the activations in HBM); what it keeps for the backward is THREE BITS
+per input element — the sign planes and the mask ``|x| < 1`` (``bnn_hip_pack_act_ste_f32``, one extra pass over x) —
+instead of the fp32 ``x`` and fp32 ``sign(x)`` the reference's autograd keeps alive: the gradient kernels read the
+planes (``bnn_hip_bconv_grad_*_packed_f32``) and return the same bits as from the fp32 tensor.
 
 Data-parallel training is ordinary ``DistributedDataParallel`` over RCCL (backend ``"nccl"``), one
 process per GPU: the binary layers are ``nn.Module``s with ordinary fp32 Parameters, so gradient
@@ -33,23 +34,37 @@ from . import hipops
 
 ENABLED = True  # set False to force the torch composition in training (tests compare the two)
 BINARY_GRADS = True  # False: library fp32 gradient convolutions for every layer (tests / A-B timing)
+PACKED_STATE = True  # keep 3 bits per input element for the backward instead of the fp32 input (False: tests / A-B)
 
 
 class BinaryConv2dTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_hat, bias, layer, plan, packed):
         out = hipops.bconv2d_direct(x, packed, bias, None, layer.stride, layer.padding, layer.dilation)   # one launch
-        ctx.save_for_backward(x, w_hat)
-        ctx.conf = (tuple(layer.stride), tuple(layer.padding), tuple(layer.dilation), bias is not None,
-                    None if bias is None else tuple(bias.shape))
+        stride, padding, dilation = tuple(layer.stride), tuple(layer.padding), tuple(layer.dilation)
+        ctx.x_shape = None
+        if PACKED_STATE and BINARY_GRADS and hipops.grad_supported(x.shape, w_hat.shape, stride, padding, dilation):
+            # the gradient kernels need sign(x) and the mask |x| < 1: three bit planes (3/32 of the fp32 tensor the
+            # reference's autograd keeps alive until the backward)
+            sv = hipops.pack_act_ste(x)
+            ctx.save_for_backward(sv.sign.P, sv.sign.M, sv.T, w_hat)
+            ctx.x_shape = tuple(x.shape)
+        else:
+            ctx.save_for_backward(x, w_hat)
+        ctx.conf = (stride, padding, dilation, bias is not None, None if bias is None else tuple(bias.shape))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, w_hat = ctx.saved_tensors
         stride, padding, dilation, has_bias, bias_shape = ctx.conf
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
-        if BINARY_GRADS and hipops.grad_supported(x.shape, w_hat.shape, stride, padding, dilation):
+        if ctx.x_shape is not None:
+            P, M, T, w_hat = ctx.saved_tensors
+            x = hipops.SavedAct(hipops.PackedAct(P, M, ctx.x_shape), T, ctx.x_shape)
+        else:
+            x, w_hat = ctx.saved_tensors
+        if ctx.x_shape is not None or (
+                BINARY_GRADS and hipops.grad_supported(x.shape, w_hat.shape, stride, padding, dilation)):
             g = g.contiguous()
             gx = gw = gb = None
             if need_x:

@@ -135,11 +135,13 @@ int launch_avgpool_fc(const float* x, const float* wt, const float* bias, float*
                       int O, hipStream_t stream);
 size_t grad_weight_pack_bytes(int O, int C, int ks);
 int launch_grad_pack_weight(const float* what, int O, int C, int ks, void* packed, float* alpha, hipStream_t s);
-int launch_dgrad(const float* g, const float* alpha, const void* packed, const float* xin, float* gx, int N, int O,
-                 int C, int H, int W, int ks, int stride, hipStream_t s);
+int launch_dgrad(const float* g, const float* alpha, const void* packed, const void* xin, int x_planes, float* gx, int N,
+                 int O, int C, int H, int W, int ks, int stride, hipStream_t s);
 int grad_wgrad_splits(int N, int O, int C, int ks);
-int launch_wgrad(const float* g, const float* xin, float* part, int splits, int N, int O, int C, int H, int W, int ks,
-                 int stride, hipStream_t s);
+int launch_wgrad(const float* g, const void* xin, const void* xin2, int x_planes, float* part, int splits, int N, int O,
+                 int C, int H, int W, int ks, int stride, hipStream_t s);
+int launch_pack_ste(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M, uint64_t* T,
+                    hipStream_t stream);
 int launch_pack_weight(const float* w, int O, int C, int KH, int KW, int center, int compute_alpha,
                        const bnn_hip_wlayout& L, uint32_t* wbits, uint32_t* wnz, float* alpha,
                        int32_t* zero_flag, hipStream_t stream);

@@ -332,10 +332,33 @@ int bnn_hip_bconv_grad_input_f32(const float* g, const float* alpha, const void*
   if (!g || !alpha || !packed || !x || !gx) return BNN_HIP_ERR_INVALID_ARG;
   const int st = check_grad_shape(N, O, C, H, W, ksize, stride);
   if (st != BNN_HIP_OK) return st;
-  if (!aligned(packed, 16)) return BNN_HIP_ERR_INVALID_ARG;
+  if (!aligned(packed, 16) || !aligned(x, 4) || !aligned(g, 4) || !aligned(gx, 4)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
   BNN_RANGE();
-  return bnn::launch_dgrad(g, alpha, packed, x, gx, N, O, C, H, W, ksize, stride, static_cast<hipStream_t>(stream));
+  return bnn::launch_dgrad(g, alpha, packed, x, 0, gx, N, O, C, H, W, ksize, stride, static_cast<hipStream_t>(stream));
+}
+
+int bnn_hip_bconv_grad_input_packed_f32(const float* g, const float* alpha, const void* packed, const uint64_t* T,
+                                        float* gx, int N, int O, int C, int H, int W, int ksize, int stride,
+                                        void* stream) {
+  if (!g || !alpha || !packed || !T || !gx) return BNN_HIP_ERR_INVALID_ARG;
+  const int st = check_grad_shape(N, O, C, H, W, ksize, stride);
+  if (st != BNN_HIP_OK) return st;
+  if (!aligned(packed, 16) || !aligned(T, 8) || !aligned(g, 4) || !aligned(gx, 4)) return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_dgrad(g, alpha, packed, T, 1, gx, N, O, C, H, W, ksize, stride, static_cast<hipStream_t>(stream));
+}
+
+int bnn_hip_pack_act_ste_f32(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M, uint64_t* T,
+                             void* stream) {
+  if (!x || !P || !M || !T || N <= 0 || C <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (mulc(N, H, W) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (((long long)C + 63) / 64 > 65535) return BNN_HIP_ERR_UNSUPPORTED;  // grid.y limit
+  if (!aligned(P, 8) || !aligned(M, 8) || !aligned(T, 8) || !aligned(x, 4)) return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_pack_ste(x, N, C, H, W, P, M, T, static_cast<hipStream_t>(stream));
 }
 
 int bnn_hip_bconv_grad_weight_splits(int N, int O, int C, int ksize) {
@@ -345,12 +368,24 @@ int bnn_hip_bconv_grad_weight_splits(int N, int O, int C, int ksize) {
 
 int bnn_hip_bconv_grad_weight_f32(const float* g, const float* x, float* partial, int splits, int N, int O, int C,
                                   int H, int W, int ksize, int stride, void* stream) {
-  if (!g || !x || !partial) return BNN_HIP_ERR_INVALID_ARG;
+  if (!g || !x || !partial || !aligned(g, 4) || !aligned(x, 4) || !aligned(partial, 4)) return BNN_HIP_ERR_INVALID_ARG;
   const int st = check_grad_shape(N, O, C, H, W, ksize, stride);
   if (st != BNN_HIP_OK) return st;
   g_launches.fetch_add(1, std::memory_order_relaxed);
   BNN_RANGE();
-  return bnn::launch_wgrad(g, x, partial, splits, N, O, C, H, W, ksize, stride, static_cast<hipStream_t>(stream));
+  return bnn::launch_wgrad(g, x, nullptr, 0, partial, splits, N, O, C, H, W, ksize, stride,
+                           static_cast<hipStream_t>(stream));
+}
+
+int bnn_hip_bconv_grad_weight_packed_f32(const float* g, const uint64_t* P, const uint64_t* M, float* partial, int splits,
+                                         int N, int O, int C, int H, int W, int ksize, int stride, void* stream) {
+  if (!g || !P || !M || !partial || !aligned(P, 8) || !aligned(M, 8) || !aligned(g, 4) || !aligned(partial, 4))
+    return BNN_HIP_ERR_INVALID_ARG;
+  const int st = check_grad_shape(N, O, C, H, W, ksize, stride);
+  if (st != BNN_HIP_OK) return st;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_wgrad(g, P, M, 1, partial, splits, N, O, C, H, W, ksize, stride, static_cast<hipStream_t>(stream));
 }
 
 int bnn_hip_pack_weight_f32(const float* w, int O, int C, int KH, int KW, int center,

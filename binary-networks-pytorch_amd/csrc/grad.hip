@@ -71,6 +71,8 @@ struct GradGeo {
   int gshift;    // log2(slot / 8): 8-pixel groups per row slot
   unsigned g_bytes;  // bytes of the gradient tensor g (the range of its buffer descriptor)
   unsigned x_bytes;  // bytes of x / gx
+  int cw64;          // XP kernels: 64-channel groups of the bit planes that stand for x (csrc/pack_ste.hip)
+  unsigned p_bytes;  // bytes of one such plane, [N][cw64][Hx][Wx] uint64
 };
 
 // v = hi + mid + lo (+ at most 2^-24 |v|): each term the TRUNCATION of what is left to bf16 (the remainders are exact
@@ -141,7 +143,9 @@ __global__ __launch_bounds__(64) void grad_pack_weight_kernel(const float* __res
 // with 1, 2, 2 and 4 taps (class = blockIdx.z; the chunks tile the g grid, the patch has one halo row below and one
 // halo column to the right, the epilogue writes every second pixel of every second row).  Round 2 / 3a multiplied
 // a zero-upsampled g with all nine taps: 3/4 of the MFMAs and of the fill were zeros.
-template <int NSUB, int KS, bool S2 = false>
+// XP: `xin` is not the fp32 input but its straight-through mask as a bit plane, T = |x| < 1 ([N][C/64][H][W] uint64,
+// csrc/pack_ste.hip): what a training step keeps of x for this kernel is 1 bit per element instead of 32.  Same results.
+template <int NSUB, int KS, bool S2 = false, bool XP = false>
 __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict__ g,
                                                             const float* __restrict__ alpha,
                                                             const half8* __restrict__ Bp,
@@ -303,24 +307,49 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
   const int eyy = S2 ? 2 * (y0 + ery) + py : y0 + ery, exx = S2 ? 2 * ex + px : ex;
   const bool elive = ex < q.W && ery < q.R && y0 + ery < q.H && eyy < q.Hx && exx < q.Wx;
   const unsigned elane = elive ? (unsigned)(eyy * q.Wx + exx) * 4u : 0xFFFFFFF0u;
-  const BufRsrc r_x = make_rsrc_sized(xin, q.x_bytes);
   [[maybe_unused]] const BufRsrc r_gx = make_rsrc_sized(gx, q.x_bytes);
   const unsigned xplane4 = (unsigned)HW * 4u;
-  float xv[IT];
+  if constexpr (XP) {
+    // the mask bits of this thread's pixel for channels c_blk .. c_blk + 64 NSUB - 1: one dword per 32 channels
+    const BufRsrc r_t = make_rsrc_sized(xin, q.p_bytes);
+    const unsigned tlane = elive ? (unsigned)(eyy * q.Wx + exx) * 8u : 0xFFFFFFF0u;
+    unsigned tw[2 * NSUB];
 #pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    const int c = c_blk + wave + 4 * i;  // wave-uniform
-    xv[i] = buf_ld(r_x, c < q.C ? elane : 0xFFFFFFF0u, c < q.C ? (unsigned)(n * q.C + c) * xplane4 : 0u);
-  }
+    for (int h = 0; h < 2 * NSUB; ++h) {
+      const int ch = c_blk + 32 * h;  // workgroup-uniform
+      const bool ok = ch < 64 * q.cw64;
+      tw[h] = __float_as_uint(buf_ld(r_t, ok ? tlane : 0xFFFFFFF0u,
+                                     ok ? (unsigned)((n * q.cw64 + (ch >> 6)) * HW) * 8u + 4u * ((ch >> 5) & 1) : 0u));
+    }
 #pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    [[maybe_unused]] const int c = c_blk + wave + 4 * i;
-    const float v = stage[(wave + 4 * i) * SROW + lane];
-    [[maybe_unused]] const float r = fabsf(xv[i]) < 1.0f ? v : 0.0f;  // hard-tanh STE (NaN x -> 0, like masked_fill)
+    for (int i = 0; i < IT; ++i) {
+      [[maybe_unused]] const int c = c_blk + wave + 4 * i;  // wave-uniform
+      const float v = stage[(wave + 4 * i) * SROW + lane];
+      const int lc = wave + 4 * i;                          // channel within the block: dword lc >> 5, bit lc & 31
+      [[maybe_unused]] const float r = ((tw[lc >> 5] >> (lc & 31)) & 1u) ? v : 0.0f;
 #if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), r_gx, (int)(c < q.C ? elane : 0xFFFFFFF0u),
-                                          (int)(c < q.C ? (unsigned)(n * q.C + c) * xplane4 : 0u), 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), r_gx, (int)(c < q.C ? elane : 0xFFFFFFF0u),
+                                            (int)(c < q.C ? (unsigned)(n * q.C + c) * xplane4 : 0u), 0);
 #endif
+    }
+  } else {
+    const BufRsrc r_x = make_rsrc_sized(xin, q.x_bytes);
+    float xv[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = c_blk + wave + 4 * i;  // wave-uniform
+      xv[i] = buf_ld(r_x, c < q.C ? elane : 0xFFFFFFF0u, c < q.C ? (unsigned)(n * q.C + c) * xplane4 : 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      [[maybe_unused]] const int c = c_blk + wave + 4 * i;
+      const float v = stage[(wave + 4 * i) * SROW + lane];
+      [[maybe_unused]] const float r = fabsf(xv[i]) < 1.0f ? v : 0.0f;  // hard-tanh STE (NaN x -> 0, like masked_fill)
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), r_gx, (int)(c < q.C ? elane : 0xFFFFFFF0u),
+                                            (int)(c < q.C ? (unsigned)(n * q.C + c) * xplane4 : 0u), 0);
+#endif
+    }
   }
 }
 
@@ -330,9 +359,12 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
 // chunks of its share of the images (split-K over grid.x; partial sums are added by the caller).
 // Per chunk: g (fp16 hi / lo, [o][64 slots]) and sign(x) with one halo row above and below, stored THREE times,
 // shifted by kx - 1 pixels, so that every tap's 8-pixel fragment is a 16-byte aligned LDS read.
-template <int ST, int KS, int NC>
+// XP: sign(x) comes from the bit planes P = x > 0 (`xin`) and M = x < 0 (`xin2`), [N][C/64][Hx][Wx] uint64, instead
+// of the fp32 tensor: 2 bits per element of saved state and of traffic.  Same values, same results.
+template <int ST, int KS, int NC, bool XP = false>
 __global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict__ g,
                                                             const float* __restrict__ xin,
+                                                            const float* __restrict__ xin2,
                                                             float* __restrict__ part, const GradGeo q,
                                                             int imgs_per_split) {
   using namespace grad;
@@ -373,7 +405,9 @@ __global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict
   // chunk a wave-uniform offset moves the block, rows outside the image become out-of-range offsets (which read 0), and
   // the loads are buffer loads with immediate element offsets — no index arithmetic per element in the chunk loop
   // (round 2/3a: 64-bit address + select per element, ~20 VALU instructions per loaded element).
-  const BufRsrc r_g = make_rsrc_sized(g, q.g_bytes), r_x = make_rsrc_sized(xin, q.x_bytes);
+  const BufRsrc r_g = make_rsrc_sized(g, q.g_bytes), r_x = make_rsrc_sized(xin, XP ? q.p_bytes : q.x_bytes);
+  [[maybe_unused]] const BufRsrc r_x2 = make_rsrc_sized(XP ? xin2 : xin, XP ? q.p_bytes : q.x_bytes);
+  constexpr int XB = XP ? 8 : 4;          // bytes from one pixel to the next in the tensor that stands for x
   constexpr unsigned kOOB = 0xFFFFFF00u;  // +- a few elements stays out of range (make_geo keeps the tensors below it)
   // g: 64 channels x 8 groups of 8 k-slots = 512 items; thread t: group t & 7 of channels t >> 3 and (t >> 3) + 32
   const int g8 = tid & 7, gry = g8 >> q.gshift, gj = g8 & (groups - 1);
@@ -391,6 +425,7 @@ __global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict
   constexpr int SI = 4, NE = 8 * ST + 2 * PD;
   const int sx_items = 16 * NC * BR * groups;
   int xbase[SI], xlds[SI], xpr[SI], x_nv[SI];
+  [[maybe_unused]] int xbit[SI];              // XP: the item's channel as a bit of its 32-channel plane dword
   bool xfirst[SI];
 #pragma unroll
   for (int i = 0; i < SI; ++i) {
@@ -399,7 +434,13 @@ __global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict
     const int cl = t / BR, pr = t - cl * BR;
     const bool fix = item < sx_items && c0 + cl < q.C;
     xpr[i] = fix ? pr : -0x40000000;                          // (a row that is never inside the image)
-    xbase[i] = (cl * HWx + pr * q.Wx + ST * 8 * j) * 4;     // element PD of the item: x = ST*8j
+    if constexpr (XP) {   // planes: [group of 64 channels][pixel] uint64; the channel is bit (c & 31) of dword (c >> 5) & 1
+      const int c = c0 + cl;
+      xbase[i] = (((c >> 6) - (c0 >> 6)) * HWx + pr * q.Wx + ST * 8 * j) * 8 + 4 * ((c >> 5) & 1);
+      xbit[i] = c & 31;
+    } else {
+      xbase[i] = (cl * HWx + pr * q.Wx + ST * 8 * j) * 4;   // element PD of the item: x = ST*8j
+    }
     x_nv[i] = q.Wx - (ST * 8 * j - PD);                       // elements e < x_nv lie left of the row's end
     xfirst[i] = j == 0;                                       // element 0 is x = -1: zero padding
     xlds[i] = item < sx_items ? (cl * BR + pr) * BROW + 8 * j : -1;
@@ -427,8 +468,8 @@ __global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict
         *reinterpret_cast<half8*>(a_lo + glds[i]) = lo;
       }
       // ---- sign(x) rows ST*y0-PD .. of 16 NC input channels, KS copies: copy kx holds sx[ST*p + kx - PD] at slot p
-      const unsigned x_soff = (unsigned)((n * q.C + c0) * HWx) * 4u;
-      const int yrow = ST * y0 - PD, x_row4 = yrow * q.Wx * 4;
+      const unsigned x_soff = XP ? (unsigned)((n * q.cw64 + (c0 >> 6)) * HWx) * 8u : (unsigned)((n * q.C + c0) * HWx) * 4u;
+      const int yrow = ST * y0 - PD, x_row4 = yrow * q.Wx * XB;
 #pragma unroll
       for (int i = 0; i < SI; ++i) {
         if (NT * i >= sx_items) break;  // workgroup-uniform
@@ -438,10 +479,17 @@ __global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
           // element e sits (e - PD) floats from the item's base; the one left of a row's first pixel is padding
-          const unsigned ve = e < PD ? (xfirst[i] ? kOOB : vo - 4u * (PD - e)) : vo + 4u * (e - PD);
-          float xv = buf_ld(r_x, ve, x_soff);
-          xv = e < x_nv[i] ? xv : 0.0f;
-          s[e] = xv > 0.0f ? kBf16One : xv < 0.0f ? kBf16MinusOne : (unsigned short)0;
+          const unsigned ve = e < PD ? (xfirst[i] ? kOOB : vo - (unsigned)XB * (PD - e)) : vo + (unsigned)XB * (e - PD);
+          if constexpr (XP) {
+            const unsigned pw = __float_as_uint(buf_ld(r_x, ve, x_soff)), mw = __float_as_uint(buf_ld(r_x2, ve, x_soff));
+            const bool in = e < x_nv[i];
+            s[e] = (in && ((pw >> xbit[i]) & 1u)) ? kBf16One : (in && ((mw >> xbit[i]) & 1u)) ? kBf16MinusOne
+                                                                                              : (unsigned short)0;
+          } else {
+            float xv = buf_ld(r_x, ve, x_soff);
+            xv = e < x_nv[i] ? xv : 0.0f;
+            s[e] = xv > 0.0f ? kBf16One : xv < 0.0f ? kBf16MinusOne : (unsigned short)0;
+          }
         }
         if (xlds[i] >= 0) {
 #pragma unroll
@@ -511,6 +559,8 @@ static bool make_geo(int N, int O, int C, int Hx, int Wx, int st, bool dgrad, Gr
   if (gb > 0xFFFFFE00ull || xb > 0xFFFFFE00ull) return false;
   q->g_bytes = (unsigned)gb;
   q->x_bytes = (unsigned)xb;
+  q->cw64 = (C + 63) / 64;
+  q->p_bytes = (unsigned)((unsigned long long)N * q->cw64 * Hx * Wx * 8ull);   // <= x_bytes / 4
   return true;
 }
 
@@ -530,7 +580,7 @@ int launch_grad_pack_weight(const float* what, int O, int C, int ks, void* packe
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
-template <int KS>
+template <int KS, bool XP>
 static int launch_dgrad_t(const float* g, const float* alpha, const void* packed, const float* xin, float* gx,
                           const GradGeo& q, hipStream_t s) {
   using namespace grad;
@@ -545,28 +595,31 @@ static int launch_dgrad_t(const float* g, const float* alpha, const void* packed
   if constexpr (KS == 3) {
     if (s2) {  // four parity classes (grid.z)
       if (nsub == 2)
-        hipLaunchKernelGGL((dgrad_kernel<2, 3, true>), grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed),
+        hipLaunchKernelGGL((dgrad_kernel<2, 3, true, XP>), grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed),
                            xin, gx, q);
       else
-        hipLaunchKernelGGL((dgrad_kernel<1, 3, true>), grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed),
+        hipLaunchKernelGGL((dgrad_kernel<1, 3, true, XP>), grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed),
                            xin, gx, q);
       return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
     }
   }
   if (nsub == 2)
-    hipLaunchKernelGGL((dgrad_kernel<2, KS>), grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed), xin,
+    hipLaunchKernelGGL((dgrad_kernel<2, KS, false, XP>), grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed), xin,
                        gx, q);
   else
-    hipLaunchKernelGGL((dgrad_kernel<1, KS>), grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed), xin,
+    hipLaunchKernelGGL((dgrad_kernel<1, KS, false, XP>), grid, dim3(NT), lds, s, g, alpha, static_cast<const half8*>(packed), xin,
                        gx, q);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
-int launch_dgrad(const float* g, const float* alpha, const void* packed, const float* xin, float* gx, int N, int O,
-                 int C, int H, int W, int ks, int stride, hipStream_t s) {
+int launch_dgrad(const float* g, const float* alpha, const void* packed, const void* xin, int x_planes, float* gx, int N,
+                 int O, int C, int H, int W, int ks, int stride, hipStream_t s) {
   GradGeo q;
   if (!ks_ok(ks, stride) || !make_geo(N, O, C, H, W, stride, true, &q)) return BNN_HIP_ERR_UNSUPPORTED;
-  return ks == 3 ? launch_dgrad_t<3>(g, alpha, packed, xin, gx, q, s) : launch_dgrad_t<1>(g, alpha, packed, xin, gx, q, s);
+  const float* xf = static_cast<const float*>(xin);   // (XP: the T plane, read as dwords)
+  if (x_planes)
+    return ks == 3 ? launch_dgrad_t<3, true>(g, alpha, packed, xf, gx, q, s) : launch_dgrad_t<1, true>(g, alpha, packed, xf, gx, q, s);
+  return ks == 3 ? launch_dgrad_t<3, false>(g, alpha, packed, xf, gx, q, s) : launch_dgrad_t<1, false>(g, alpha, packed, xf, gx, q, s);
 }
 
 int grad_wgrad_splits(int N, int O, int C, int ks) {
@@ -579,8 +632,21 @@ int grad_wgrad_splits(int N, int O, int C, int ks) {
   return (N + per - 1) / per;
 }
 
-int launch_wgrad(const float* g, const float* xin, float* part, int splits, int N, int O, int C, int H, int W, int ks,
-                 int stride, hipStream_t s) {
+template <int ST, int KS, int NC, bool XP>
+static int launch_wgrad_k(const dim3& grid, size_t lds, hipStream_t s, const float* g, const float* x1, const float* x2,
+                          float* part, const GradGeo& q, int per) {
+  // more than 64 KB of dynamic LDS (82 KB for 7x7 outputs at stride 2, 69 KB for the 56x56 layers) needs the opt-in:
+  // per device and per kernel, set on every launch, always to the same constant (the CU's whole LDS)
+  if (KS == 3 && hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<ST, KS, NC, XP>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds) != hipSuccess)
+    return BNN_HIP_ERR_LAUNCH;
+  hipLaunchKernelGGL((wgrad_kernel<ST, KS, NC, XP>), grid, dim3(grad::NT), lds, s, g, x1, x2, part, q, per);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+// x_planes == 0: `xin` is the fp32 input (xin2 unused); else `xin` / `xin2` are its sign planes P / M.
+int launch_wgrad(const float* g, const void* xin, const void* xin2, int x_planes, float* part, int splits, int N, int O,
+                 int C, int H, int W, int ks, int stride, hipStream_t s) {
   using namespace grad;
   GradGeo q;
   if (!ks_ok(ks, stride) || !make_geo(N, O, C, H, W, stride, false, &q)) return BNN_HIP_ERR_UNSUPPORTED;
@@ -591,23 +657,16 @@ int launch_wgrad(const float* g, const float* xin, float* part, int splits, int 
   const size_t lds =
       (size_t)(3 * 64 * AROW + ks * 16 * nc * (stride * q.RR + 2 * (ks / 2)) * (q.slot + 8)) * sizeof(u16);
   const dim3 grid((unsigned)splits, (unsigned)((C + 16 * nc - 1) / (16 * nc)), (unsigned)((O + 63) / 64));
-  if (ks == 1) {
-    hipLaunchKernelGGL((wgrad_kernel<1, 1, kWgradNC1>), grid, dim3(NT), lds, s, g, xin, part, q, per);
-  } else if (stride == 2) {
-    // more than 64 KB of dynamic LDS (82 KB for 7x7 outputs) needs the opt-in: per device and per kernel, set on every
-    // launch, always to the same constant (the CU's whole LDS)
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<2, 3, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds) != hipSuccess)
-      return BNN_HIP_ERR_LAUNCH;
-    hipLaunchKernelGGL((wgrad_kernel<2, 3, 2>), grid, dim3(NT), lds, s, g, xin, part, q, per);
-  } else {
-    // three bf16 planes: 69 KB at widths 33..64 (the 56x56 layers)
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1, 3, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds) != hipSuccess)
-      return BNN_HIP_ERR_LAUNCH;
-    hipLaunchKernelGGL((wgrad_kernel<1, 3, 2>), grid, dim3(NT), lds, s, g, xin, part, q, per);
+  const float* x1 = static_cast<const float*>(xin);
+  const float* x2 = static_cast<const float*>(xin2);
+  if (x_planes) {
+    if (ks == 1) return launch_wgrad_k<1, 1, kWgradNC1, true>(grid, lds, s, g, x1, x2, part, q, per);
+    if (stride == 2) return launch_wgrad_k<2, 3, 2, true>(grid, lds, s, g, x1, x2, part, q, per);
+    return launch_wgrad_k<1, 3, 2, true>(grid, lds, s, g, x1, x2, part, q, per);
   }
-  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+  if (ks == 1) return launch_wgrad_k<1, 1, kWgradNC1, false>(grid, lds, s, g, x1, x2, part, q, per);
+  if (stride == 2) return launch_wgrad_k<2, 3, 2, false>(grid, lds, s, g, x1, x2, part, q, per);
+  return launch_wgrad_k<1, 3, 2, false>(grid, lds, s, g, x1, x2, part, q, per);
 }
 
 }  // namespace bnn

@@ -323,6 +323,19 @@ int bnn_hip_bconv_grad_weight_splits(int N, int O, int C, int ksize);
 int bnn_hip_bconv_grad_weight_f32(const float* g, const float* x, float* partial, int splits,
                                   int N, int O, int C, int H, int W, int ksize, int stride, void* stream);
 
+/* ABI 12: the same two gradients from 3 BITS per input element instead of the fp32 tensor — what a training step has
+ * to keep of x between forward and backward (the reference's autograd keeps the fp32 x and the fp32 sign(x),
+ * bnn/ops.py:63-73).  bnn_hip_pack_act_ste_f32 writes, in one pass over x, the sign planes P = x > 0, M = x < 0 (the
+ * format of bnn_hip_pack_act_f32) and the straight-through mask T = |x| < 1 (NaN -> 0); the *_packed_* kernels read T
+ * (input gradient) resp. P and M (weight gradient).  Results are bit-identical to the fp32-x entry points.            */
+int bnn_hip_pack_act_ste_f32(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M, uint64_t* T,
+                             void* stream);
+int bnn_hip_bconv_grad_input_packed_f32(const float* g, const float* alpha, const void* packed_w, const uint64_t* T,
+                                        float* gx, int N, int O, int C, int H, int W, int ksize, int stride,
+                                        void* stream);
+int bnn_hip_bconv_grad_weight_packed_f32(const float* g, const uint64_t* P, const uint64_t* M, float* partial, int splits,
+                                         int N, int O, int C, int H, int W, int ksize, int stride, void* stream);
+
 /* Binary convolution on packed operands.  out: float32 [N,O,Ho,Wo] contiguous.
  *   out[n,o,y,x] = fmaf(alpha[o], dot, bias ? bias[o] : 0) * (post_scale ? post_scale[o] : 1)
  * wnz may be NULL unless BNN_HIP_FLAG_WEIGHT_ZEROS is set.                         */

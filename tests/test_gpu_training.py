@@ -298,3 +298,100 @@ def test_binary_gradient_kernels_are_used_and_can_be_switched_off():
     assert torch.allclose(gx1, gx0, rtol=1e-4, atol=2e-5 * float(gx0.abs().max()))
     for n in gp0:
         assert torch.allclose(gp1[n], gp0[n], rtol=1e-3, atol=1e-4 * float(gp0[n].abs().max()) + 1e-7), n
+
+
+@pytest.mark.parametrize("ks,stride", [(3, 1), (3, 2), (1, 1)], ids=["3x3s1", "3x3s2", "1x1"])
+@pytest.mark.parametrize("shape", GRAD_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_gradients_from_three_bits_per_element_equal_those_from_the_fp32_input(shape, ks, stride):
+    """Round 4: what a training step keeps of x for the backward is the sign planes + the mask |x| < 1 (3 bits per
+    element, csrc/pack_ste.hip) instead of the fp32 tensor; the gradient kernels read the planes
+    (bnn_hip_bconv_grad_*_packed_f32) and must return THE SAME BITS as from the fp32 input — special values included
+    (the reference's STE: grad * 1[|x| < 1] with NaN -> 0, bnn/ops.py:68-73; sign(+-0) = sign(NaN) = 0)."""
+    import oracle
+    from bnn_amd import hipops
+    N, O, C, H, W = shape
+    pad = ks // 2
+    xn = (gen.normal(gen.seed_of("px", shape), (N, C, H, W)) * 0.9).astype(np.float32)
+    flat = xn.reshape(-1)
+    flat[::7] = 0.0
+    flat[3::11] = -0.0
+    flat[5::13] = np.nan
+    flat[1::17] = 1.0          # |x| == 1 is outside the mask
+    flat[2::19] = -1.0
+    flat[4::23] = np.float32(1e-45)
+    flat[6::29] = np.inf
+    x = dev(xn)
+    g = dev(gen.normal(gen.seed_of("pg", shape), (N, O, (H - 1) // stride + 1, (W - 1) // stride + 1)))
+    w_hat = dev(np.sign(gen.normal(gen.seed_of("pw", shape), (O, C, ks, ks))).astype(np.float32) *
+                (0.5 + gen.uniform(gen.seed_of("pa", shape), (O, 1, 1, 1))).astype(np.float32))
+    sv = hipops.pack_act_ste(x)
+    # the planes themselves: P / M are pack_act's (== the oracle's), T is |x| < 1
+    ref = hipops.pack_act(x)
+    assert torch.equal(sv.sign.P, ref.P) and torch.equal(sv.sign.M, ref.M)
+    Pr, Mr = oracle.pack_act(xn)
+    assert np.array_equal(sv.sign.P.cpu().numpy().view(np.uint64), Pr)
+    t_bits = np.zeros((N, (C + 63) // 64, H, W), np.uint64)
+    with np.errstate(invalid="ignore"):
+        inside = np.abs(xn) < 1.0
+    for c in range(C):
+        t_bits[:, c // 64] |= inside[:, c].astype(np.uint64) << np.uint64(c % 64)
+    assert np.array_equal(sv.T.cpu().numpy().view(np.uint64), t_bits)
+    assert sv.nbytes() * 32 == 3 * x.numel() * 4 * ((C + 63) // 64 * 64) // C      # 3 bits per (padded) element
+    packed, alpha = hipops.grad_pack_weight(w_hat)
+    gx_f = hipops.bconv_grad_input(g, x, packed, alpha, ks, stride)
+    gx_p = hipops.bconv_grad_input(g, sv, packed, alpha, ks, stride)
+    assert torch.equal(gx_f.nan_to_num(0.0), gx_p.nan_to_num(0.0)) and torch.equal(gx_f.isnan(), gx_p.isnan())
+    gw_f = hipops.bconv_grad_weight(g, x, ks, stride)
+    gw_p = hipops.bconv_grad_weight(g, sv, ks, stride)
+    assert torch.equal(gw_f, gw_p)
+    assert pad in (0, 1)
+
+
+def _r18_train():
+    cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
+                      weight_pre_process=XNORWeightBinarizer)
+    net = bnn.prepare_binary_model(resnet18(), cfg, custom_config_layers_name={"conv1": bnn.BConfig(), "fc": bnn.BConfig()})
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in gen.model_state(shapes, 1).items()})
+    return net.to(DEV).train()
+
+
+def test_training_forward_keeps_three_bits_per_element_for_the_backward():
+    """Saved-for-backward bytes of the binary convolutions of one ResNet-18 training forward, counted with
+    torch.autograd.graph.saved_tensors_hooks: packed state (default) against the fp32 input the reference's autograd
+    keeps — at least 5x less — with the same gradients."""
+    net = _r18_train()
+    x = dev(gen.normal(91, (4, 3, 64, 64)))
+    t = torch.tensor([1, 5, 9, 13], device=DEV)
+
+    def step(packed):
+        training.PACKED_STATE = packed
+        saved = {"int64": 0, "fp32_act": 0}
+        act_shapes = set()
+
+        def pack(tn):
+            if tn.dtype == torch.int64 and tn.dim() == 4:
+                saved["int64"] += tn.numel() * 8
+            elif tn.dtype == torch.float32 and tn.dim() == 4 and tuple(tn.shape) in act_shapes:
+                saved["fp32_act"] += tn.numel() * 4
+            return tn
+        hooks = [m.register_forward_pre_hook(lambda mod, inp: act_shapes.add(tuple(inp[0].shape)))
+                 for m in net.modules() if isinstance(m, bnn.layers.Conv2d) and fastpath._recognise(m, m.out_channels)]
+        try:
+            net.zero_grad()
+            with torch.autograd.graph.saved_tensors_hooks(pack, lambda v: v):
+                loss = torch.nn.functional.cross_entropy(net(x), t)
+            loss.backward()
+        finally:
+            for h in hooks:
+                h.remove()
+            training.PACKED_STATE = True
+        return saved, [p.grad.clone() for p in net.parameters()], float(loss)
+    s_packed, g_packed, l_packed = step(True)
+    s_fp32, g_fp32, l_fp32 = step(False)
+    assert abs(l_packed - l_fp32) <= 1e-6 * abs(l_fp32)
+    for a, b in zip(g_packed, g_fp32):      # (library BatchNorm backward may reduce with atomics: tight tolerance)
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(b.abs().max()) + 1e-12)
+    assert s_fp32["int64"] == 0 and s_packed["int64"] > 0
+    # every binary conv saved its input as fp32 before (torch may count a tensor shared with BN / ReLU once per save)
+    assert s_fp32["fp32_act"] >= 5 * s_packed["int64"], (s_fp32, s_packed)

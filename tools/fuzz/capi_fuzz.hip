@@ -124,14 +124,19 @@ static void check_grad(int N, int O, int C, int H, int W, int ks, int stride) {
   REQUIRE(N > 0 && O > 0 && C > 0 && H > 0 && W > 0 && W <= 64 && (ks == 1 || ks == 3) && (stride == 1 || stride == 2));
   REQUIRE((long long)N * O * H * W <= (1LL << 31) - 1 && (long long)N * C * H * W <= (1LL << 31) - 1);
 }
-int launch_dgrad(const float* g, const float* alpha, const void* packed, const float* x, float* gx, int N, int O, int C,
-                 int H, int W, int ks, int stride, hipStream_t) {
-  ++g_reached; REQUIRE(g && alpha && packed && x && gx); check_grad(N, O, C, H, W, ks, stride); return BNN_HIP_OK;
+int launch_dgrad(const float* g, const float* alpha, const void* packed, const void* x, int planes, float* gx, int N, int O,
+                 int C, int H, int W, int ks, int stride, hipStream_t) {
+  ++g_reached; REQUIRE(g && alpha && packed && x && gx && al(x, planes ? 8 : 4)); check_grad(N, O, C, H, W, ks, stride);
+  return BNN_HIP_OK;
+}
+int launch_pack_ste(const float* x, int N, int C, int H, int W, uint64_t* P, uint64_t* M, uint64_t* T, hipStream_t) {
+  ++g_reached; check_planes(x, N, C, H, W, P, M, 4); REQUIRE(T && al(T, 8)); return BNN_HIP_OK;
 }
 int grad_wgrad_splits(int N, int O, int C, int ks) { REQUIRE(N > 0 && O > 0 && C > 0 && (ks == 1 || ks == 3)); return 1; }
-int launch_wgrad(const float* g, const float* x, float* part, int, int N, int O, int C, int H, int W, int ks, int stride,
-                 hipStream_t) {
-  ++g_reached; REQUIRE(g && x && part); check_grad(N, O, C, H, W, ks, stride); return BNN_HIP_OK;
+int launch_wgrad(const float* g, const void* x, const void* x2, int planes, float* part, int, int N, int O, int C, int H,
+                 int W, int ks, int stride, hipStream_t) {
+  ++g_reached; REQUIRE(g && x && part && (!planes || (x2 && al(x, 8) && al(x2, 8)))); check_grad(N, O, C, H, W, ks, stride);
+  return BNN_HIP_OK;
 }
 int launch_pack_weight(const float* w, int O, int C, int KH, int KW, int, int, const bnn_hip_wlayout& L, uint32_t* wb,
                        uint32_t* wz, float* alpha, int32_t* flag, hipStream_t) {
@@ -184,7 +189,7 @@ int main(int argc, char** argv) {
   for (long it = 0; it < iters; ++it) {
     ++g_calls;
     int st = 0;
-    switch (rnd() % 20) {
+    switch (rnd() % 23) {
       case 0: { bnn_hip_conv_desc d = pick_desc();
         st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
                              pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
@@ -249,6 +254,14 @@ int main(int argc, char** argv) {
                                                   pick_int(), pick_int(), pick_int(), pick_int(), (int)(rnd() % 5), (int)(rnd() % 4), stream); break;
       case 18: st = bnn_hip_sign_thresholds_f32(pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(),
                                                 pick_ptr<float>(), pick_int(), pick_int(), pick_ptr<int32_t>(), stream); break;
+      case 19: st = bnn_hip_pack_act_ste_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_ptr<uint64_t>(),
+                                             pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), stream); break;
+      case 20: st = bnn_hip_bconv_grad_input_packed_f32(pick_ptr<float>(), pick_ptr<float>(), pick_ptr<char>(), pick_ptr<uint64_t>(),
+                                                        pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(),
+                                                        (int)(rnd() % 5), (int)(rnd() % 4), stream); break;
+      case 21: st = bnn_hip_bconv_grad_weight_packed_f32(pick_ptr<float>(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<float>(),
+                                                         pick_int(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(),
+                                                         (int)(rnd() % 5), (int)(rnd() % 4), stream); break;
       default: { bnn_hip_conv_desc d = pick_desc();
         (void)bnn_hip_shortcut_fold_supported(rnd() % 16 ? &d : nullptr, pick_int());
         st = bnn_hip_blinear(pick_int(), pick_int(), pick_int(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
