@@ -16,16 +16,19 @@ the STE mask fused into the input-gradient store; any other geometry uses ``aten
 ``W_hat = weight_pre_process(W)`` is computed by the hook under autograd, which makes the weight gradient flow exactly
 as in the reference composition; the forward kernel re-derives the packed form of the same weights on every training
 forward (``fastpath.packed_weight(..., fresh=True)``).  The forward is ONE launch (``bnn_hip_bconv2d_direct``:
-``sign(x)`` on the fly in LDS, no packed copy of the activations in HBM); what it keeps for the backward is THREE BITS
-per input element — the sign planes and the mask ``|x| < 1`` (``bnn_hip_pack_act_ste_f32``, one extra pass over x) —
-instead of the fp32 ``x`` and fp32 ``sign(x)`` the reference's autograd keeps alive: the gradient kernels read the
-planes (``bnn_hip_bconv_grad_*_packed_f32``) and return the same bits as from the fp32 tensor.
+``sign(x)`` on the fly in LDS, no packed copy of the activations in HBM).  What it keeps for the backward is the fp32
+``x`` by default, or — ``PACKED_STATE`` — THREE BITS per input element: the sign planes and the mask ``|x| < 1``
+(``bnn_hip_pack_act_ste_f32``, one extra pass over x) instead of the fp32 ``x`` and fp32 ``sign(x)`` the reference's
+autograd keeps alive; the gradient kernels read the planes (``bnn_hip_bconv_grad_*_packed_f32``) and return the same
+bits as from the fp32 tensor.
 
 Data-parallel training is ordinary ``DistributedDataParallel`` over RCCL (backend ``"nccl"``), one
 process per GPU: the binary layers are ``nn.Module``s with ordinary fp32 Parameters, so gradient
 bucketing / all-reduce needs nothing special (``make_ddp``).
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.nn as nn
@@ -34,7 +37,24 @@ from . import hipops
 
 ENABLED = True  # set False to force the torch composition in training (tests compare the two)
 BINARY_GRADS = True  # False: library fp32 gradient convolutions for every layer (tests / A-B timing)
-PACKED_STATE = True  # keep 3 bits per input element for the backward instead of the fp32 input (False: tests / A-B)
+# Keep 3 bits per input element for the backward (sign planes + STE mask) instead of the fp32 input: 10.7x less saved
+# state per binary convolution, same gradients bit for bit, +8 % step time on ResNet-18 at batch 256 (32.0 vs 29.5 ms:
+# the weight-gradient kernel's fill extracts bits and issues two plane loads per element).  Off by default (speed);
+# BNN_AMD_TRAIN_PACKED_STATE=1 or `training.PACKED_STATE = True` turns it on (memory).
+PACKED_STATE = os.environ.get("BNN_AMD_TRAIN_PACKED_STATE", "0") == "1"
+
+
+_saved_bytes = 0     # bytes of layer INPUT state the binary convolutions have kept for their backward since the last reset
+
+
+def saved_input_bytes(reset: bool = False) -> int:
+    """Bytes of input state (fp32 ``x``, or its three bit planes) the training forwards of the binary convolutions have
+    saved for the backward since the last reset — what ``PACKED_STATE`` shrinks (tests, tools/bench_train.py)."""
+    global _saved_bytes
+    n = _saved_bytes
+    if reset:
+        _saved_bytes = 0
+    return n
 
 
 class BinaryConv2dTrainFn(torch.autograd.Function):
@@ -49,8 +69,12 @@ class BinaryConv2dTrainFn(torch.autograd.Function):
             sv = hipops.pack_act_ste(x)
             ctx.save_for_backward(sv.sign.P, sv.sign.M, sv.T, w_hat)
             ctx.x_shape = tuple(x.shape)
+            kept = sv.nbytes()
         else:
             ctx.save_for_backward(x, w_hat)
+            kept = x.numel() * x.element_size()
+        global _saved_bytes
+        _saved_bytes += kept
         ctx.conf = (stride, padding, dilation, bias is not None, None if bias is None else tuple(bias.shape))
         return out
 

@@ -430,8 +430,21 @@ __global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < SI; ++i) {
     const int item = tid + NT * i;
-    const int j = item & (groups - 1), t = item >> q.gshift;
-    const int cl = t / BR, pr = t - cl * BR;
+    int j, cl, pr;
+    if constexpr (XP) {
+      // channel fastest: the 16 NC channels of a pixel are bits of the same one or two plane dwords, so the lanes of a
+      // wave ask for 2-4 addresses per load instead of 64 (with the fp32 order — group fastest — every lane of a plane
+      // load hit its own 64-byte segment and the texture addresser became the kernel's bound: 617 vs 333 us)
+      cl = item % (16 * NC);
+      const int rest = item / (16 * NC);
+      j = rest & (groups - 1);
+      pr = rest >> q.gshift;
+    } else {
+      j = item & (groups - 1);
+      const int t = item >> q.gshift;
+      cl = t / BR;
+      pr = t - cl * BR;
+    }
     const bool fix = item < sx_items && c0 + cl < q.C;
     xpr[i] = fix ? pr : -0x40000000;                          // (a row that is never inside the image)
     if constexpr (XP) {   // planes: [group of 64 channels][pixel] uint64; the channel is bit (c & 31) of dword (c >> 5) & 1
@@ -478,9 +491,11 @@ __global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict
         u16 s[NE];  // sx[ST*8j-PD .. ST*(8j+7)+PD]
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-          // element e sits (e - PD) floats from the item's base; the one left of a row's first pixel is padding
+          // element e sits (e - PD) pixels from the item's base; the one left of a row's first pixel is padding
           const unsigned ve = e < PD ? (xfirst[i] ? kOOB : vo - (unsigned)XB * (PD - e)) : vo + (unsigned)XB * (e - PD);
           if constexpr (XP) {
+            // (one dword per pixel and plane: 16-byte loads of two pixels measured 5 % faster and returned wrong data —
+            // hipcc 7.2 mis-lowers the multi-dword buffer-load builtins, see csrc/bconv_core.h)
             const unsigned pw = __float_as_uint(buf_ld(r_x, ve, x_soff)), mw = __float_as_uint(buf_ld(r_x2, ve, x_soff));
             const bool in = e < x_nv[i];
             s[e] = (in && ((pw >> xbit[i]) & 1u)) ? kBf16One : (in && ((mw >> xbit[i]) & 1u)) ? kBf16MinusOne

@@ -42,6 +42,12 @@ for C, O, H, st in SHAPES:
     packed, al = hipops.grad_pack_weight(what)
     td = t(lambda: hipops.bconv_grad_input(g, x, packed, al, 3, st))
     tw = t(lambda: hipops.bconv_grad_weight(g, x, 3, st))
+    if os.environ.get("PACKED") == "1":   # the same gradients from the 3-bit saved state (round 4)
+        sv = hipops.pack_act_ste(x)
+        print("   packed state: pack_ste %.1f us (pack_act %.1f)   dgrad %.1f (fp32 x: %.1f)   wgrad %.1f (fp32 x: %.1f)" % (
+            t(lambda: hipops.pack_act_ste(x)), t(lambda: hipops.pack_act(x)),
+            t(lambda: hipops.bconv_grad_input(g, sv, packed, al, 3, st)), td,
+            t(lambda: hipops.bconv_grad_weight(g, sv, 3, st)), tw))
     flop = 2.0 * N * C * O * 9 * Ho * Ho * 3  # three bf16 products per MAC
     fd = flop / (td * 1e-6) / 2.5e15  # (stride 2: the four parity classes together do exactly these MACs)
     fw = flop / (tw * 1e-6) / 2.5e15

@@ -27,9 +27,18 @@ def run(enabled, steps=6, binary_grads=True):
         loss.backward(); opt.step()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
+if os.environ.get("PACKED") is not None:     # PACKED=0: keep the fp32 input for the backward (round 3), 1: three bit planes
+    training.PACKED_STATE = os.environ["PACKED"] == "1"
 if os.environ.get("ONLY") == "mfma":
     print("batch %d: HIP forward + MFMA gradient kernels %.1f ms" % (B, run(True)))
     sys.exit(0)
+if os.environ.get("PACKED") is None:   # both forms of the saved input state, with the bytes they keep per step
+    training.PACKED_STATE = True
+    training.saved_input_bytes(reset=True); ap = run(True, steps=4); kp = training.saved_input_bytes(reset=True) / 6
+    training.PACKED_STATE = False
+    training.saved_input_bytes(reset=True); af = run(True, steps=4); kf = training.saved_input_bytes(reset=True) / 6
+    print("batch %d: saved input state of the 19 binary convs per step: fp32 x %.0f MB (step %.1f ms) | 3 bits per element "
+          "(BNN_AMD_TRAIN_PACKED_STATE=1) %.0f MB (step %.1f ms): %.1fx less" % (B, kf / 1e6, af, kp / 1e6, ap, kf / kp))
 a = run(True); a2 = run(True, binary_grads=False); b = run(False)
 print("batch %d: training step  HIP forward + MFMA gradient kernels %.1f ms (%.0f img/s) | HIP forward + library backward "
       "%.1f ms (%.0f img/s) | composition %.1f ms (%.0f img/s)" % (B, a, B / a * 1e3, a2, B / a2 * 1e3, b, B / b * 1e3))
