@@ -503,7 +503,10 @@ ENGINE_NOTES = {
     "graph_fresh": "a NEW input tensor every step: stem launch on the caller's tensor + HIP graph of the rest "
                    "(PipelinedInference(fresh_input=True)); no staging copy, no re-capture",
     "net_call": "the reference's own call: net = prepare_binary_model(...).eval(); net(x) under no_grad with a NEW "
-                "tensor every step (examples/cifar10.py:140-149) — bnn_amd AutoFusion: stem launch + HIP graph",
+                "tensor every step (examples/cifar10.py:140-149) — bnn_amd AutoFusion: the batch in two halves on two "
+                "streams, each a stem launch on its part of the caller's tensor + HIP graph of the rest",
+    "net_call_single": "the same call with BNN_AMD_SPLIT_BATCH=0: the whole batch as ONE stem launch + HIP graph, "
+                       "strictly one batch at a time",
     "fused": "FusedResNet(net)(x), 21 eager launches per forward, a NEW tensor every step",
     "blockwise": "net(x) with whole-model fusion off: torch/MIOpen stem and head, every residual block as its own fused "
                  "executor (pack_act + convs with BN / ReLU / residual in their epilogues) — the tier a custom network "
@@ -568,6 +571,14 @@ def bench_net(args, world, rank, device, info, timed):
             return step
         if kw:
             raise SystemExit("--engine net_call takes the model's default executor options")
+        if engine == "net_call_single":
+            def step(i):
+                os.environ["BNN_AMD_SPLIT_BATCH"] = "0"
+                try:
+                    return model.forward_even(xs[i % N_FRESH])
+                finally:
+                    os.environ.pop("BNN_AMD_SPLIT_BATCH", None)
+            return step
         return lambda i: model.forward_even(xs[i % N_FRESH])
 
     multi = args.engine in ("graph", "graph_fresh")
@@ -591,13 +602,14 @@ def bench_net(args, world, rank, device, info, timed):
             engines[head_key] = {"value": world * B * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
                                  "engine_clock_mhz": round(clock_mhz), "headline": True}
             for eng, k in (("graph", 2), ("graph", 1), ("graph_fresh", 2), ("graph_fresh", 1), ("net_call", 1),
-                           ("fused", 1), ("blockwise", 1), ("layerwise", 1)):
+                           ("net_call_single", 1), ("fused", 1), ("blockwise", 1), ("layerwise", 1)):
                 key = f"{eng}_x{k}" if eng in ("graph", "graph_fresh") else eng
-                if key in engines or (c5 and eng == "net_call"):    # (c5 asks for the fp16 stem: not the model default)
+                if key in engines or (c5 and eng.startswith("net_call")):   # (c5 asks for the fp16 stem: not the model default)
                     continue
-                engines[key], _ = measure(eng, k, **({} if eng in ("net_call", "layerwise", "blockwise") else fused_kw))
+                engines[key], _ = measure(eng, k, **({} if eng in ("net_call", "net_call_single", "layerwise", "blockwise") else fused_kw))
             for key, rec_e in engines.items():
                 rec_e["what"] = ENGINE_NOTES[key.split("_x")[0]]
+            auto_fusion(net).reset()        # (its executors and graphs are not needed any more)
             if "graph_x1" in engines:
                 extras["one_batch_at_a_time"] = {k: engines["graph_x1"][k] for k in ("value", "ms_per_step")}
             if not c5 and args.engine == "graph":   # the same network with the stem in exact fp32 arithmetic

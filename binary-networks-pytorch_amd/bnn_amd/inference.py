@@ -739,6 +739,52 @@ def per_layer_forward():
         _PER_LAYER -= 1
 
 
+class TwoHalves:
+    """One call, two batches in flight: ``model(x)`` with the batch cut in two halves that run on two HIP streams,
+    each as "stem launch on its half of the caller's tensor + HIP graph of the rest" (``FusedResNet.forward_fresh``) on
+    an executor in throughput mode.  A forward is a chain of kernels bound by different units (stem: matrix cores, the
+    64-channel convs: HBM, the rest: integer ALU) with a tail after every launch; a second half-batch fills what the
+    first leaves idle — what ``PipelinedInference`` does across calls, done inside one call, so that the reference's
+    own ``net(x)`` loop (examples/cifar10.py:147-149) gets it without knowing.  Bit-identical logits (images are
+    independent).  ``AutoFusion`` uses it from ``MIN_BATCH`` images on (``BNN_AMD_SPLIT_BATCH=0`` turns it off)."""
+
+    MIN_BATCH = 64
+
+    def __init__(self, model: nn.Module, device: torch.device) -> None:
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+        self.engines = []
+        cur = torch.cuda.current_stream(device)
+        for st in self.streams:
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                self.engines.append(FusedResNet(model, throughput_mode=True))
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    @staticmethod
+    def wanted(n: int) -> bool:
+        return n >= TwoHalves.MIN_BATCH and os.environ.get("BNN_AMD_SPLIT_BATCH", "1") != "0"
+
+    def captured(self, x: torch.Tensor) -> bool:
+        h = (x.shape[0] + 1) // 2
+        keys = [((n,) + tuple(x.shape[1:]), st.cuda_stream) for n, st in zip((h, x.shape[0] - h), self.streams)]
+        return all(k in e._split for k, e in zip(keys, self.engines))
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        dev = x.device
+        cur = torch.cuda.current_stream(dev)
+        h = (x.shape[0] + 1) // 2
+        ys = []
+        for eng, st, part in zip(self.engines, self.streams, (x[:h], x[h:])):
+            st.wait_stream(cur)                      # the caller's tensor is ready on the caller's stream
+            with torch.cuda.stream(st):
+                ys.append(eng.forward_fresh(part, clone=False))
+        for st in self.streams:
+            cur.wait_stream(st)                      # (also orders the caller's later reuse of x behind both halves)
+        return torch.cat(ys, 0)
+
+
 _NO_MODEL_FUSION = 0
 
 
@@ -859,6 +905,7 @@ class AutoFusion:
         # the object with the model they were made from: their executors live here, one per device
         self.owner = None if owner is None else weakref.ref(owner)
         self.replica_engines = {}       # device -> (master parameter signature, FusedResNet of the first replica there)
+        self.halves = {}                # id(engine) -> TwoHalves of the same model (large batches: two halves in flight)
 
     def __deepcopy__(self, memo):       # copy.deepcopy(model): the copy derives its own executor
         return AutoFusion()
@@ -871,6 +918,7 @@ class AutoFusion:
             self.engine, self.failed_sig, self.reason, self.verified = None, None, None, False
             self.seen.clear()
             self.replica_engines.clear()
+            self.halves.clear()
 
     @staticmethod
     def enabled() -> bool:
@@ -944,7 +992,16 @@ class AutoFusion:
                     return self._verify(eng, model, x)
                 key = (tuple(x.shape), torch.cuda.current_stream(x.device).cuda_stream)
                 graph = eng.reads_caller_tensor and (key in eng._split or self.seen[(id(eng),) + key] >= self.CAPTURE_AFTER)
-                if graph:
+                if graph and TwoHalves.wanted(x.shape[0]):
+                    eng._check_current()                     # (a parameter change drops the half-batch executors too)
+                    two = self.halves.get(id(eng))
+                    if two is None or two.engines[0]._sig != eng._sig:
+                        two = self.halves[id(eng)] = TwoHalves(eng.model, x.device)
+                    self.calls["graph"] += 1
+                    if not two.captured(x):
+                        return two(x)                        # captures: under the lock
+                    graph = two
+                elif graph:
                     self.calls["graph"] += 1
                     if key not in eng._split:
                         return eng.forward_fresh(x)          # captures: under the lock
@@ -953,11 +1010,14 @@ class AutoFusion:
                     if len(self.seen) > 64:
                         self.seen.clear()
                     self.calls["eager"] += 1
+            if isinstance(graph, TwoHalves):
+                return graph(x)
             return eng.forward_fresh(x) if graph else eng(x)
         except FusionError as exc:      # e.g. parameters moved to the CPU since the executor was built
             with self.lock:
                 self.engine, self.failed_sig, self.reason = None, _param_signature(model), str(exc)
                 self.replica_engines.clear()
+                self.halves.clear()
             return self._decline()
 
     def _verify(self, eng: "FusedResNet", model: nn.Module, x: torch.Tensor) -> Optional[torch.Tensor]:

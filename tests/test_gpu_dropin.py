@@ -359,3 +359,32 @@ def test_resnet_with_model_fusion_off_runs_blockwise():
         assert all(b.__dict__["_bnn_auto_block"].calls["fused"] == 1 for st_ in (net.layer1, net.layer2, net.layer3, net.layer4)
                    for b in st_)
     assert torch.allclose(y, want, rtol=1e-3, atol=1e-3 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("n", [64, 65])
+def test_large_batches_run_as_two_halves_in_flight(n):
+    """From TwoHalves.MIN_BATCH images on, `net(x)` cuts the batch in two halves on two streams (each: stem launch on
+    its part of the caller's tensor + HIP graph of the rest): same bits, a new tensor every call, odd batches too."""
+    from bnn_amd.inference import TwoHalves
+    net = _r18()
+    eng = FusedResNet(net)
+    xs = [dev(gen.normal(120 + i, (n, 3, 32, 32))) for i in range(3)]
+    want = [eng(x).clone() for x in xs]
+    with torch.no_grad():
+        ys = [net(x) for x in xs]                  # eager, capture (two halves), replay
+        st = auto_fusion(net)
+        assert st.calls == {"graph": 2, "eager": 1, "declined": 0} and len(st.halves) == 1
+        two = next(iter(st.halves.values()))
+        assert isinstance(two, TwoHalves) and two.captured(xs[0]) and all(e.throughput_mode for e in two.engines)
+        launches0 = native.launch_count()
+        y = net(xs[0])
+        assert native.launch_count() - launches0 == 2            # two stem launches + two graph replays
+        import os
+        os.environ["BNN_AMD_SPLIT_BATCH"] = "0"
+        try:
+            y_single = net(xs[1])
+        finally:
+            del os.environ["BNN_AMD_SPLIT_BATCH"]
+    for a, b in zip(ys, want):
+        assert torch.equal(a, b)
+    assert torch.equal(y, want[0]) and torch.equal(y_single, want[1])
