@@ -59,7 +59,8 @@ def parse_args():
                          "at --gpus 8), c2 the single 3x3 128->128 56x56 layer, c5 ResNet(HBlock,[3,4,6,3]) with the "
                          "fp16 MFMA stem at 128 images/GPU")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: 256; c5: 128)")
-    ap.add_argument("--engine", choices=("graph", "graph_fresh", "net_call", "fused", "blockwise", "layerwise"), default="graph",
+    ap.add_argument("--engine", choices=("graph", "graph_fresh", "net_call", "net_call_single", "fused", "blockwise", "layerwise"),
+                    default="graph",
                     help="what the headline `value` times.  graph: fused executor replayed as HIP graphs over resident "
                          "static input buffers (default); graph_fresh: the same with a NEW input tensor every step "
                          "(stem launch on the caller's tensor + graph of the rest, no staging copy); net_call: the "
@@ -583,7 +584,7 @@ def bench_net(args, world, rank, device, info, timed):
 
     multi = args.engine in ("graph", "graph_fresh")
     n_streams = max(1, args.streams) if multi else 1
-    head_kw = {} if args.engine in ("net_call", "layerwise", "blockwise") else fused_kw
+    head_kw = {} if args.engine in ("net_call", "net_call_single", "layerwise", "blockwise") else fused_kw
     step = make_step(args.engine, n_streams, **head_kw)
     with torch.no_grad():
         dt, logits = timed(step, args.steps, args.warmup, sustain=args.sustain)
