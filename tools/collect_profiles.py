@@ -15,6 +15,15 @@ DIRTY = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untr
                             text=True).stdout.strip())
 STAMP = {"commit": COMMIT + ("+uncommitted" if DIRTY else ""), "collected_by": "tools/gpu_profile.sh + tools/collect_profiles.py"}
 src = os.path.join(ROOT, "gpurun_out", "final")
+# gpurun MERGES what a visit wrote into the local gpurun_out/: files of an earlier visit stay.  Remove the local
+# gpurun_out/final BEFORE the visit (tools/gpu_profile.sh removes it on the GPU side only), or summaries of an old build
+# get this commit's stamp.  Guard: everything that is summarised must be younger than the bench line of this visit.
+_t0 = os.path.getmtime(os.path.join(src, "bench.json")) - 3600
+
+
+def fresh(paths):
+    return [f for f in paths if os.path.getmtime(f) >= _t0]
+
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
@@ -42,7 +51,7 @@ if stats1:
 
 for name in ("train.txt", "stem_ab.txt"):
     fn = os.path.join(src, name)
-    if os.path.exists(fn) and open(fn).read().strip():
+    if os.path.exists(fn) and fresh([fn]) and open(fn).read().strip():
         body = "\n".join(l for l in open(fn).read().splitlines() if "amdgpu.ids" not in l)
         open(os.path.join(dst, f"{tag}_{name}"), "w").write(
             f"# {name}: tools/gpu_profile.sh, commit {STAMP['commit']}\n" + body + "\n")
@@ -50,11 +59,11 @@ for name in ("train.txt", "stem_ab.txt"):
 # stem kernel: counters of tools/bench_stem.py (ONLY=default), separate passes
 sagg = collections.defaultdict(list)
 sdur = []
-for f in glob.glob(os.path.join(src, "stem_*", "**", "*counter_collection.csv"), recursive=True):
+for f in fresh(glob.glob(os.path.join(src, "stem_*", "**", "*counter_collection.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):
         if "stem_rows_kernel" in r["Kernel_Name"]:
             sagg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for f in glob.glob(os.path.join(src, "stem_a", "**", "*kernel_trace.csv"), recursive=True):
+for f in fresh(glob.glob(os.path.join(src, "stem_a", "**", "*kernel_trace.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):
         if "stem_rows_kernel" in r["Kernel_Name"]:
             sdur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
@@ -68,13 +77,13 @@ if sagg:
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
-for f in [g for g in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recursive=True)
+for f in [g for g in fresh(glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recursive=True))
           if os.sep + "stem_" not in g]:
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0]
         if "bnn::" in name:
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for f in glob.glob(os.path.join(src, "sq1", "**", "*kernel_trace.csv"), recursive=True):
+for f in fresh(glob.glob(os.path.join(src, "sq1", "**", "*kernel_trace.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0]
         if "bnn::" in name:
@@ -84,18 +93,19 @@ for name, d in agg.items():
     out[name] = {c: int(round(sum(v) / len(v))) for c, v in sorted(d.items())}
     if dur[name]:
         out[name]["avg_duration_us_profiled"] = round(sum(dur[name]) / len(dur[name]), 1)
-out["provenance"] = STAMP
-json.dump(out, open(os.path.join(dst, f"{tag}_c2_pmc_counters.json"), "w"), indent=1, sort_keys=True)
-del out["provenance"]
+if out:      # (QUICK visits have no PMC passes: write nothing rather than an empty summary)
+    out["provenance"] = STAMP
+    json.dump(out, open(os.path.join(dst, f"{tag}_c2_pmc_counters.json"), "w"), indent=1, sort_keys=True)
+    del out["provenance"]
 
 # the one-launch layer on config 2 (tools/run_fly.py under rocprofv3, separate passes)
 fagg = collections.defaultdict(list)
 fdur = []
-for f in glob.glob(os.path.join(src, "fly_*", "**", "*counter_collection.csv"), recursive=True):
+for f in fresh(glob.glob(os.path.join(src, "fly_*", "**", "*counter_collection.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):
         if "bconv_fly" in r["Kernel_Name"]:
             fagg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for f in glob.glob(os.path.join(src, "fly_sq1", "**", "*kernel_trace.csv"), recursive=True):
+for f in fresh(glob.glob(os.path.join(src, "fly_sq1", "**", "*kernel_trace.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):
         if "bconv_fly" in r["Kernel_Name"]:
             fdur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
