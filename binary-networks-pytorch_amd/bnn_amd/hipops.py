@@ -684,6 +684,52 @@ def bconv_grad_weight(g: torch.Tensor, x, ksize: int = 3, stride: int = 1) -> to
         return part[0] if splits == 1 else part.sum(0)
 
 
+def bn_train_forward(x: torch.Tensor, gamma, beta, running_mean, running_var, momentum: float, eps: float,
+                     relu: bool = False, residual: Optional[torch.Tensor] = None):
+    """``relu?(batch_norm(x, training=True) (+ residual))`` in three launches (csrc/bn_train.hip).  Updates the running
+    statistics in place (unbiased variance, momentum) like ``torch.nn.BatchNorm2d`` in training mode.  Returns
+    ``(y, save_mean, save_invstd)``."""
+    x = _require_cuda_f32(x, "BatchNorm input")
+    if x.dim() != 4:
+        raise native.NativeError(f"bnn_amd: bn_train_forward expects NCHW, got shape {tuple(x.shape)}")
+    lib = native.require()
+    N, C, H, W = x.shape
+    if residual is not None:
+        residual = _require_cuda_f32(residual, "residual")
+        if residual.shape != x.shape:
+            raise native.NativeError("bnn_amd: residual shape differs from the BatchNorm input's")
+    with torch.cuda.device(x.device):
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(int(lib.bnn_hip_bn_train_workspace_bytes(N, C, H * W)), dtype=torch.uint8, device=x.device)
+        native.check(lib.bnn_hip_bn_train_forward_f32(
+            x.data_ptr(), N, C, H * W, _ptr(gamma), _ptr(beta), _ptr(residual), int(bool(relu)), float(eps),
+            float(momentum), _ptr(running_mean), _ptr(running_var), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+            ws.data_ptr(), _stream(x.device)), "bnn_hip_bn_train_forward_f32")
+    return y, mean, invstd
+
+
+def bn_train_backward(gy: torch.Tensor, y: Optional[torch.Tensor], x: torch.Tensor, mean: torch.Tensor,
+                      invstd: torch.Tensor, gamma, want_dres: bool = False):
+    """Backward of ``bn_train_forward``: ``(dx, dgamma, dbeta, dres | None)``.  ``y``: the forward's output when a ReLU
+    was fused (its mask), else None."""
+    gy = _require_cuda_f32(gy, "grad_output")
+    lib = native.require()
+    N, C, H, W = x.shape
+    with torch.cuda.device(x.device):
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if want_dres else None
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(int(lib.bnn_hip_bn_train_workspace_bytes(N, C, H * W)), dtype=torch.uint8, device=x.device)
+        native.check(lib.bnn_hip_bn_train_backward_f32(
+            gy.data_ptr(), _ptr(y), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma), N, C, H * W,
+            dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream(x.device)),
+            "bnn_hip_bn_train_backward_f32")
+    return dx, dgamma, dbeta, dres
+
+
 PROBE_MODES = {0: "bitop3+bcnt", 1: "xor+bcnt", 2: "bcnt", 3: "bitop3", 4: "xor", 5: "fma_f32",
                6: "add_u32", 7: "and_vgpr", 8: "and_vgpr+bcnt", 9: "xor_vgpr", 10: "and_sgpr+bcnt"}
 

@@ -32,6 +32,19 @@ def _fused(block, x):
     return auto_block_forward(block, x)
 
 
+def _bn_act(x, bn, act=None, residual=None):
+    """``act(bn(x) (+ residual))``: on a HIP device in training mode one fused op (bnn_amd/training.py: bn_act — batch
+    statistics, normalisation, residual add and ReLU in three launches instead of four library passes), else the
+    modules themselves in the reference's order."""
+    if x.is_cuda and bn.training:
+        from .. import training
+        return training.bn_act(x, bn, act, residual)
+    y = bn(x)
+    if residual is not None:
+        y += residual
+    return y if act is None else act(y)
+
+
 class _Residual(nn.Module):
     """Base of the residual blocks.  ``forward`` is the reference's op sequence (``_forward``), except that a block
     evaluated for inference on a HIP device first offers itself to the fused block executor
@@ -40,7 +53,13 @@ class _Residual(nn.Module):
     expansion = 1
 
     def _shortcut(self, x: torch.Tensor) -> torch.Tensor:
-        return x if self.downsample is None else self.downsample(x)
+        ds = self.downsample
+        if ds is None:
+            return x
+        if (isinstance(ds, nn.Sequential) and len(ds) == 3 and isinstance(ds[2], nn.BatchNorm2d)
+                and not ds._forward_hooks and not ds._forward_pre_hooks):
+            return _bn_act(ds[1](ds[0](x)), ds[2])       # AvgPool -> conv1x1 -> BN (bnn/models/resnet.py:128-133)
+        return ds(x)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.training and x.is_cuda and not torch.is_grad_enabled():
@@ -74,10 +93,8 @@ class BasicBlock(_Residual):
         self.stride = stride
 
     def _forward(self, x: torch.Tensor) -> torch.Tensor:
-        y = self.act1(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
-        y += self._shortcut(x)
-        return self.act2(y)
+        y = _bn_act(self.conv1(x), self.bn1, self.act1)
+        return _bn_act(self.conv2(y), self.bn2, self.act2, residual=self._shortcut(x))
 
 
 class PreBasicBlock(_Residual):
@@ -134,11 +151,9 @@ class Bottleneck(_Residual):
         self.stride = stride
 
     def _forward(self, x: torch.Tensor) -> torch.Tensor:
-        y = self.act1(self.bn1(self.conv1(x)))
-        y = self.act2(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        y += self._shortcut(x)
-        return self.act3(y)
+        y = _bn_act(self.conv1(x), self.bn1, self.act1)
+        y = _bn_act(self.conv2(y), self.bn2, self.act2)
+        return _bn_act(self.conv3(y), self.bn3, self.act3, residual=self._shortcut(x))
 
 
 class PreBottleneck(_Residual):

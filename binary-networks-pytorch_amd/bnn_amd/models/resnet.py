@@ -16,7 +16,7 @@ from typing import Any, Callable, List, Optional, Type
 import torch
 import torch.nn as nn
 
-from .blocks import BasicBlock, Bottleneck, HBlock, PreBasicBlock, PreBottleneck, conv1x1
+from .blocks import BasicBlock, Bottleneck, HBlock, PreBasicBlock, PreBottleneck, _bn_act, conv1x1
 
 
 def _auto_forward(model, x):
@@ -151,7 +151,7 @@ class ResNet(nn.Module):
                 return y
         x = self.conv1(x)
         if self.stem_type == "basic":
-            x = self.maxpool(self.relu(self.bn1(x)))
+            x = self.maxpool(_bn_act(x, self.bn1, self.relu))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = torch.flatten(self.avgpool(x), 1)
         return self.fc(x)

@@ -39,7 +39,8 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_bconv_grad_weight_splits", "bnn_hip_bconv_grad_weight_f32",
     "bnn_hip_bconv2d_direct", "bnn_hip_bconv2d_direct_plan", "bnn_hip_shortcut_fold_supported",
     "bnn_hip_probe_clock", "bnn_hip_pack_act_ste_f32", "bnn_hip_bconv_grad_input_packed_f32",
-    "bnn_hip_bconv_grad_weight_packed_f32",
+    "bnn_hip_bconv_grad_weight_packed_f32", "bnn_hip_bn_train_workspace_bytes", "bnn_hip_bn_train_forward_f32",
+    "bnn_hip_bn_train_backward_f32",
 )
 
 
@@ -152,6 +153,11 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_pack_act_ste_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]
     lib.bnn_hip_bconv_grad_input_packed_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]
     lib.bnn_hip_bconv_grad_weight_packed_f32.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]
+    lib.bnn_hip_bn_train_workspace_bytes.restype = ctypes.c_size_t
+    lib.bnn_hip_bn_train_workspace_bytes.argtypes = [_i, _i, _i]
+    _f = ctypes.c_float
+    lib.bnn_hip_bn_train_forward_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.bnn_hip_bn_train_backward_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bnn_hip_probe_int_alu.argtypes = [_i, _i, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), _vp]
     lib.bnn_hip_probe_clock.argtypes = [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _vp]

@@ -1,0 +1,311 @@
+// bn_train.hip — training-mode BatchNorm2d fused with what surrounds it in the reference's residual blocks.
+//
+// The step "after" the binary-conv path: in training mode every binary convolution of the
+// reference's ResNets is followed by   bnN(...)  [+ identity]  [-> ReLU]   (bnn/models/layers/res_block.py:40-56,
+// bnn/models/resnet.py:150-153), evaluated by the library as separate passes over the fp32 tensor (BatchNorm statistics,
+// normalisation, add, ReLU: 5-8 HBM passes forward, 8 backward).  Of the 29.5 ms ResNet-18 training step at batch 256,
+// 9.1 ms were the library's BatchNorm kernels (4x off the HBM roofline) and 6 ms its element-wise kernels.  Here:
+//
+//   forward :  stats  (1 read)     per-channel sum / sum of squares, fp64 accumulation, deterministic two-stage reduction
+//              apply  (1-2 reads, 1 write)   y = relu( x * scale[c] + shift[c] (+ residual) ), running statistics updated
+//   backward:  reduce (3 reads)    dbeta = sum g, dgamma = sum g * xhat,   g = gy * 1[y > 0]
+//              dx     (3 reads, 1-2 writes)  dx = gamma * invstd * (g - dbeta / m - xhat * dgamma / m),  dres = g
+//
+// Semantics of torch.nn.BatchNorm2d in training mode (biased variance for the normalisation, unbiased for
+// running_var, momentum update), of ReLU and of `out += identity`; fp32 tensors, NCHW.  The statistics are accumulated
+// in double precision (the library: fp32 Welford), so results agree with the library to fp32 rounding, not bit for bit.
+// HBM-bound kernels: float4 accesses along the contiguous HW axis of a (image, channel) row.
+#include "bnn_dev.h"
+
+namespace bnn {
+
+namespace bnt {
+constexpr int NT = 256;
+constexpr int MAX_SPLITS = 64;
+}  // namespace bnt
+
+// sum over a block of (a, b) in double: wave shuffles, then LDS
+__device__ __forceinline__ void block_sum2(double& a, double& b) {
+  __shared__ double sa[bnt::NT / 64], sb[bnt::NT / 64];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off);
+    b += __shfl_xor(b, off);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) { sa[wave] = a; sb[wave] = b; }
+  __syncthreads();
+  a = 0.0; b = 0.0;
+#pragma unroll
+  for (int w = 0; w < bnt::NT / 64; ++w) { a += sa[w]; b += sb[w]; }   // fixed order: deterministic
+}
+
+// partial[c][s] = (sum, sum of squares) of channel c over the images of split s.  The block walks the flattened
+// (image, unit) index space of its images (unit = float4 or float of the contiguous HW axis), so that 7x7 images keep
+// all 256 threads busy too.
+template <int VEC>
+__global__ __launch_bounds__(bnt::NT) void bn_stats_kernel(const float* __restrict__ x, int N, int C, int HW, int per,
+                                                           double* __restrict__ partial) {
+  const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+  const int n0 = s * per, n1 = min(N, n0 + per);
+  const int upr = HW / VEC;                       // units per (image, channel) row
+  const int total = (n1 - n0) * upr;
+  double a = 0.0, b = 0.0;
+  for (int idx = threadIdx.x; idx < total; idx += bnt::NT) {
+    const int dn = idx / upr, u = idx - dn * upr;
+    const float* p = x + ((size_t)(n0 + dn) * C + c) * HW + (size_t)u * VEC;
+    if constexpr (VEC == 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p);
+      a += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      b += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    } else {
+      const float v = *p;
+      a += (double)v;
+      b += (double)v * v;
+    }
+  }
+  block_sum2(a, b);
+  if (threadIdx.x == 0) {
+    partial[((size_t)c * S + s) * 2 + 0] = a;
+    partial[((size_t)c * S + s) * 2 + 1] = b;
+  }
+}
+
+// one thread per channel: partials -> mean, invstd, scale = gamma * invstd, shift = beta - mean * scale; running statistics
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ partial, int S, int C, double count,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, float momentum, float* __restrict__ running_mean,
+                                                         float* __restrict__ running_var, float* __restrict__ mean_out,
+                                                         float* __restrict__ invstd_out, float* __restrict__ scale_out,
+                                                         float* __restrict__ shift_out) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < S; ++s) {               // fixed order: deterministic
+    a += partial[((size_t)c * S + s) * 2 + 0];
+    b += partial[((size_t)c * S + s) * 2 + 1];
+  }
+  const double mean = a / count;
+  double var = b / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+  const float scale = g * invstd;
+  mean_out[c] = (float)mean;
+  invstd_out[c] = invstd;
+  scale_out[c] = scale;
+  shift_out[c] = (float)((double)bt - mean * (double)scale);
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * running_mean[c] + (double)momentum * mean);
+    running_var[c] = (float)((1.0 - (double)momentum) * running_var[c] + (double)momentum * unbiased);
+  }
+}
+
+// y = relu( x * scale[c] + shift[c] (+ res) ): flat over the tensor in units of VEC floats (a unit never straddles a row)
+template <int VEC, bool RELU, bool RES>
+__global__ __launch_bounds__(bnt::NT) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale_c,
+                                                           const float* __restrict__ shift_c, const float* __restrict__ res,
+                                                           float* __restrict__ y, long long units, int C, int upr) {
+  const long long u = (long long)blockIdx.x * bnt::NT + threadIdx.x;
+  if (u >= units) return;
+  const int c = (int)((u / upr) % C);
+  const float scale = scale_c[c], shift = shift_c[c];
+  const size_t i0 = (size_t)u * VEC;
+  if constexpr (VEC == 4) {
+    float4 v = *reinterpret_cast<const float4*>(x + i0);
+    v.x = fmaf(v.x, scale, shift); v.y = fmaf(v.y, scale, shift); v.z = fmaf(v.z, scale, shift); v.w = fmaf(v.w, scale, shift);
+    if constexpr (RES) {
+      const float4 r = *reinterpret_cast<const float4*>(res + i0);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if constexpr (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(y + i0) = v;
+  } else {
+    float v = fmaf(x[i0], scale, shift);
+    if constexpr (RES) v += res[i0];
+    if constexpr (RELU) v = fmaxf(v, 0.f);
+    y[i0] = v;
+  }
+}
+
+// partial[c][s] = (sum g, sum g * xhat) over the images of split s;  g = gy * 1[y > 0] when RELU
+template <int VEC, bool RELU>
+__global__ __launch_bounds__(bnt::NT) void bn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                                const float* __restrict__ x,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, int N, int C, int HW,
+                                                                int per, double* __restrict__ partial) {
+  const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+  const int n0 = s * per, n1 = min(N, n0 + per);
+  const int upr = HW / VEC;
+  const int total = (n1 - n0) * upr;
+  const float mu = mean[c], is = invstd[c];
+  double a = 0.0, b = 0.0;
+  for (int idx = threadIdx.x; idx < total; idx += bnt::NT) {
+    const int dn = idx / upr, u = idx - dn * upr;
+    const size_t i0 = ((size_t)(n0 + dn) * C + c) * HW + (size_t)u * VEC;
+    if constexpr (VEC == 4) {
+      float4 g = *reinterpret_cast<const float4*>(gy + i0);
+      const float4 xv = *reinterpret_cast<const float4*>(x + i0);
+      if constexpr (RELU) {
+        const float4 yv = *reinterpret_cast<const float4*>(y + i0);
+        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+      }
+      a += (double)g.x + (double)g.y + (double)g.z + (double)g.w;
+      b += (double)g.x * ((xv.x - mu) * is) + (double)g.y * ((xv.y - mu) * is) + (double)g.z * ((xv.z - mu) * is) +
+           (double)g.w * ((xv.w - mu) * is);
+    } else {
+      float g = gy[i0];
+      if constexpr (RELU) g = y[i0] > 0.f ? g : 0.f;
+      a += (double)g;
+      b += (double)g * ((x[i0] - mu) * is);
+    }
+  }
+  block_sum2(a, b);
+  if (threadIdx.x == 0) {
+    partial[((size_t)c * S + s) * 2 + 0] = a;
+    partial[((size_t)c * S + s) * 2 + 1] = b;
+  }
+}
+
+// one thread per channel: dbeta, dgamma and the three coefficients of dx = k * (g - mb - (x - mean) * kg)
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int S, int C, double count,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double sb = 0.0, sg = 0.0;
+  for (int s = 0; s < S; ++s) {
+    sb += partial[((size_t)c * S + s) * 2 + 0];
+    sg += partial[((size_t)c * S + s) * 2 + 1];
+  }
+  if (dbeta) dbeta[c] = (float)sb;
+  if (dgamma) dgamma[c] = (float)sg;
+  const float is = invstd[c];
+  coef[3 * c + 0] = (gamma ? gamma[c] : 1.0f) * is;      // k
+  coef[3 * c + 1] = (float)(sb / count);                  // mb
+  coef[3 * c + 2] = is * (float)(sg / count);             // kg: xhat * dgamma / m = (x - mean) * invstd * (sg / m)
+}
+
+// dx = k * (g - mb - (x - mean) * kg);  dres = g (the gradient of the residual branch)
+template <int VEC, bool RELU, bool RES>
+__global__ __launch_bounds__(bnt::NT) void bn_bwd_dx_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                            const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ coef, float* __restrict__ dx,
+                                                            float* __restrict__ dres, long long units, int C, int upr) {
+  const long long u = (long long)blockIdx.x * bnt::NT + threadIdx.x;
+  if (u >= units) return;
+  const int c = (int)((u / upr) % C);
+  const float mu = mean[c], k = coef[3 * c], mb = coef[3 * c + 1], kg = coef[3 * c + 2];
+  const size_t i0 = (size_t)u * VEC;
+  if constexpr (VEC == 4) {
+    float4 g = *reinterpret_cast<const float4*>(gy + i0);
+    const float4 xv = *reinterpret_cast<const float4*>(x + i0);
+    if constexpr (RELU) {
+      const float4 yv = *reinterpret_cast<const float4*>(y + i0);
+      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+    }
+    if constexpr (RES) *reinterpret_cast<float4*>(dres + i0) = g;
+    float4 d;
+    d.x = k * (g.x - mb - (xv.x - mu) * kg);
+    d.y = k * (g.y - mb - (xv.y - mu) * kg);
+    d.z = k * (g.z - mb - (xv.z - mu) * kg);
+    d.w = k * (g.w - mb - (xv.w - mu) * kg);
+    *reinterpret_cast<float4*>(dx + i0) = d;
+  } else {
+    float g = gy[i0];
+    if constexpr (RELU) g = y[i0] > 0.f ? g : 0.f;
+    if constexpr (RES) dres[i0] = g;
+    dx[i0] = k * (g - mb - (x[i0] - mu) * kg);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- host side
+int bn_train_splits(int N, int C, int HW) {
+  // enough blocks to fill the chip (~4 per CU), at most one split per image
+  int s = (1024 + C - 1) / C;
+  if (s > bnt::MAX_SPLITS) s = bnt::MAX_SPLITS;
+  if (s > N) s = N;
+  if (s < 1) s = 1;
+  const int per = (N + s - 1) / s;
+  (void)HW;
+  return (N + per - 1) / per;
+}
+
+static bool vec4(const void* a, const void* b, const void* c, const void* d, int HW) {
+  auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return HW % 4 == 0 && al(a) && al(b) && al(c) && al(d);
+}
+
+int launch_bn_stats(const float* x, int N, int C, int HW, int splits, double* partial, hipStream_t s) {
+  const int per = (N + splits - 1) / splits;
+  const dim3 grid((unsigned)C, (unsigned)splits);
+  if (vec4(x, nullptr, nullptr, nullptr, HW))
+    hipLaunchKernelGGL(bn_stats_kernel<4>, grid, dim3(bnt::NT), 0, s, x, N, C, HW, per, partial);
+  else
+    hipLaunchKernelGGL(bn_stats_kernel<1>, grid, dim3(bnt::NT), 0, s, x, N, C, HW, per, partial);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+// finalize (statistics, running statistics, scale / shift into `work` = [scale C | shift C]) + the apply pass
+int launch_bn_apply(const float* x, const double* partial, int splits, const float* gamma, const float* beta,
+                    const float* res, int relu, float* y, int N, int C, int HW, float eps, float momentum, float* rm,
+                    float* rv, float* mean_out, float* invstd_out, float* work, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, partial, splits, C,
+                     (double)N * HW, gamma, beta, eps, momentum, rm, rv, mean_out, invstd_out, work, work + C);
+  const bool v4 = vec4(x, res, y, nullptr, HW);
+  const int vec = v4 ? 4 : 1;
+  const long long units = (long long)N * C * HW / vec;
+  const dim3 grid((unsigned)((units + bnt::NT - 1) / bnt::NT));
+  const int upr = HW / vec;
+#define BNN_APPLY(V_, R_, S_)   hipLaunchKernelGGL((bn_apply_kernel<V_, R_, S_>), grid, dim3(bnt::NT), 0, s, x, work, work + C, res, y, units, C, upr)
+  if (v4) {
+    if (relu && res) BNN_APPLY(4, true, true); else if (relu) BNN_APPLY(4, true, false);
+    else if (res) BNN_APPLY(4, false, true); else BNN_APPLY(4, false, false);
+  } else {
+    if (relu && res) BNN_APPLY(1, true, true); else if (relu) BNN_APPLY(1, true, false);
+    else if (res) BNN_APPLY(1, false, true); else BNN_APPLY(1, false, false);
+  }
+#undef BNN_APPLY
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+int launch_bn_bwd_reduce(const float* gy, const float* y, const float* x, const float* mean, const float* invstd, int N,
+                         int C, int HW, int splits, double* partial, hipStream_t s) {
+  const int per = (N + splits - 1) / splits;
+  const dim3 grid((unsigned)C, (unsigned)splits);
+  const bool v4 = vec4(gy, y, x, nullptr, HW);
+  if (v4 && y) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true>), grid, dim3(bnt::NT), 0, s, gy, y, x, mean, invstd, N, C, HW, per, partial);
+  else if (v4) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, false>), grid, dim3(bnt::NT), 0, s, gy, y, x, mean, invstd, N, C, HW, per, partial);
+  else if (y) hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, true>), grid, dim3(bnt::NT), 0, s, gy, y, x, mean, invstd, N, C, HW, per, partial);
+  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, false>), grid, dim3(bnt::NT), 0, s, gy, y, x, mean, invstd, N, C, HW, per, partial);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+// finalize (dgamma, dbeta, coefficients into `work` = [3 C]) + the dx pass
+int launch_bn_bwd_dx(const float* gy, const float* y, const float* x, const float* mean, const float* invstd,
+                     const float* gamma, const double* partial, int splits, float* dx, float* dres, float* dgamma,
+                     float* dbeta, int N, int C, int HW, float* work, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, partial, splits, C,
+                     (double)N * HW, gamma, invstd, dgamma, dbeta, work);
+  const bool v4 = vec4(gy, y, x, dx, HW) && vec4(dres, nullptr, nullptr, nullptr, HW);
+  const int vec = v4 ? 4 : 1;
+  const long long units = (long long)N * C * HW / vec;
+  const dim3 grid((unsigned)((units + bnt::NT - 1) / bnt::NT));
+  const int upr = HW / vec;
+#define BNN_DX(V_, R_, S_)   hipLaunchKernelGGL((bn_bwd_dx_kernel<V_, R_, S_>), grid, dim3(bnt::NT), 0, s, gy, y, x, mean, work, dx, dres, units, C, upr)
+  if (v4) {
+    if (y && dres) BNN_DX(4, true, true); else if (y) BNN_DX(4, true, false);
+    else if (dres) BNN_DX(4, false, true); else BNN_DX(4, false, false);
+  } else {
+    if (y && dres) BNN_DX(1, true, true); else if (y) BNN_DX(1, true, false);
+    else if (dres) BNN_DX(1, false, true); else BNN_DX(1, false, false);
+  }
+#undef BNN_DX
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+}  // namespace bnn

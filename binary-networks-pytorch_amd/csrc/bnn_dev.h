@@ -152,6 +152,17 @@ int launch_bconv(const ConvP& p, int flags, hipStream_t s);
 bool fly_supported(const ConvP& p);
 int fly_default_plan(const ConvP& p, int flags, bnn_hip_fly_plan* plan);
 int launch_bconv_fly(const ConvP& p, const void* x, int x_half, int flags, const bnn_hip_fly_plan* plan, hipStream_t s);
+// bn_train.hip: training-mode BatchNorm (+ residual) (+ ReLU), forward and backward
+int bn_train_splits(int N, int C, int HW);
+int launch_bn_stats(const float* x, int N, int C, int HW, int splits, double* partial, hipStream_t s);
+int launch_bn_apply(const float* x, const double* partial, int splits, const float* gamma, const float* beta,
+                    const float* res, int relu, float* y, int N, int C, int HW, float eps, float momentum, float* rm,
+                    float* rv, float* mean_out, float* invstd_out, float* work, hipStream_t s);
+int launch_bn_bwd_reduce(const float* gy, const float* y, const float* x, const float* mean, const float* invstd, int N,
+                         int C, int HW, int splits, double* partial, hipStream_t s);
+int launch_bn_bwd_dx(const float* gy, const float* y, const float* x, const float* mean, const float* invstd,
+                     const float* gamma, const double* partial, int splits, float* dx, float* dres, float* dgamma,
+                     float* dbeta, int N, int C, int HW, float* work, hipStream_t s);
 int launch_probe_int_alu(int mode, int iters, double* lane_ops_per_s, double* elapsed_ms, hipStream_t s);
 int launch_probe_clock(int spin_iters, double* shader_mhz, double* elapsed_us, hipStream_t s);
 

@@ -571,6 +571,61 @@ int bnn_hip_probe_int_alu(int mode, int iters, double* lane_ops_per_s, double* e
                                    static_cast<hipStream_t>(stream));
 }
 
+// ---- training-mode BatchNorm (+ residual) (+ ReLU): csrc/bn_train.hip
+static int check_bn(int N, int C, int HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (mulc(N, C, HW) > 4 * kMaxElems || mulc(N, HW) > kMaxElems || C > (1 << 20)) return BNN_HIP_ERR_TOO_LARGE;
+  return BNN_HIP_OK;
+}
+
+size_t bnn_hip_bn_train_workspace_bytes(int N, int C, int HW) {
+  if (check_bn(N, C, HW) != BNN_HIP_OK) return 0;
+  // [C][splits][2] doubles of partial sums + 3 C floats of per-channel coefficients
+  return align_up((size_t)C * bnn::bn_train_splits(N, C, HW) * 2 * sizeof(double), 256) + (size_t)3 * C * sizeof(float);
+}
+
+int bnn_hip_bn_train_forward_f32(const float* x, int N, int C, int HW, const float* gamma, const float* beta,
+                                 const float* residual, int relu, float eps, float momentum, float* running_mean,
+                                 float* running_var, float* y, float* save_mean, float* save_invstd, void* workspace,
+                                 void* stream) {
+  if (!x || !y || !save_mean || !save_invstd || !workspace) return BNN_HIP_ERR_INVALID_ARG;
+  const int st = check_bn(N, C, HW);
+  if (st != BNN_HIP_OK) return st;
+  if ((running_mean == nullptr) != (running_var == nullptr) || !(eps >= 0.0f)) return BNN_HIP_ERR_INVALID_ARG;
+  if (!aligned(x, 4) || !aligned(y, 4) || (residual && !aligned(residual, 4)) || !aligned(workspace, 8))
+    return BNN_HIP_ERR_INVALID_ARG;
+  const int S = bnn::bn_train_splits(N, C, HW);
+  double* partial = static_cast<double*>(workspace);
+  float* work = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)C * S * 2 * sizeof(double), 256));
+  g_launches.fetch_add(3, std::memory_order_relaxed);
+  BNN_RANGE();
+  const int st2 = bnn::launch_bn_stats(x, N, C, HW, S, partial, static_cast<hipStream_t>(stream));
+  if (st2 != BNN_HIP_OK) return st2;
+  return bnn::launch_bn_apply(x, partial, S, gamma, beta, residual, relu, y, N, C, HW, eps, momentum, running_mean,
+                              running_var, save_mean, save_invstd, work, static_cast<hipStream_t>(stream));
+}
+
+int bnn_hip_bn_train_backward_f32(const float* gy, const float* y, const float* x, const float* save_mean,
+                                  const float* save_invstd, const float* gamma, int N, int C, int HW, float* dx,
+                                  float* dres, float* dgamma, float* dbeta, void* workspace, void* stream) {
+  if (!gy || !x || !save_mean || !save_invstd || !dx || !workspace) return BNN_HIP_ERR_INVALID_ARG;
+  const int st = check_bn(N, C, HW);
+  if (st != BNN_HIP_OK) return st;
+  if (!aligned(gy, 4) || !aligned(x, 4) || !aligned(dx, 4) || (y && !aligned(y, 4)) || (dres && !aligned(dres, 4)) ||
+      !aligned(workspace, 8))
+    return BNN_HIP_ERR_INVALID_ARG;
+  const int S = bnn::bn_train_splits(N, C, HW);
+  double* partial = static_cast<double*>(workspace);
+  float* work = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)C * S * 2 * sizeof(double), 256));
+  g_launches.fetch_add(3, std::memory_order_relaxed);
+  BNN_RANGE();
+  const int st2 = bnn::launch_bn_bwd_reduce(gy, y, x, save_mean, save_invstd, N, C, HW, S, partial,
+                                            static_cast<hipStream_t>(stream));
+  if (st2 != BNN_HIP_OK) return st2;
+  return bnn::launch_bn_bwd_dx(gy, y, x, save_mean, save_invstd, gamma, partial, S, dx, dres, dgamma, dbeta, N, C, HW, work,
+                               static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_probe_clock(int spin_iters, double* shader_mhz, double* elapsed_us, void* stream) {
   if (spin_iters <= 0 || spin_iters > (1 << 24) || !shader_mhz) return BNN_HIP_ERR_INVALID_ARG;
   return bnn::launch_probe_clock(spin_iters, shader_mhz, elapsed_us, static_cast<hipStream_t>(stream));

@@ -419,6 +419,24 @@ int bnn_hip_bconv2d_f32(const bnn_hip_conv_desc* d, const float* x,
                         const float* alpha, const float* bias, const float* post_scale,
                         float* out, void* workspace, void* stream);
 
+/* Training-mode BatchNorm2d fused with what follows it in the reference's residual blocks:
+ *     y = relu?( batch_norm_train(x) (+ residual) )          bnn/models/layers/res_block.py:40-56, resnet.py:150-153
+ * x, y, residual: fp32 [N, C, HW] (NCHW with HW = H * W).  forward: per-channel batch statistics (fp64 accumulation,
+ * deterministic), y, save_mean / save_invstd [C] for the backward, and — when running_mean / running_var are given —
+ * their momentum update (unbiased variance), exactly torch.nn.BatchNorm2d's training semantics to fp32 rounding.
+ * backward: g = gy * 1[y > 0] when `y` is given (a fused ReLU; pass NULL otherwise); dgamma = sum g * xhat, dbeta = sum g,
+ * dx = gamma * invstd * (g - dbeta / m - xhat * dgamma / m), and dres = g (the residual branch's gradient) when dres
+ * is given.  gamma / beta may be NULL (1 / 0).  `workspace`: bnn_hip_bn_train_workspace_bytes(N, C, HW) bytes,
+ * 8-byte aligned, not shared between concurrent calls.  Three launches each, no synchronisation.                     */
+size_t bnn_hip_bn_train_workspace_bytes(int N, int C, int HW);
+int bnn_hip_bn_train_forward_f32(const float* x, int N, int C, int HW, const float* gamma, const float* beta,
+                                 const float* residual, int relu, float eps, float momentum, float* running_mean,
+                                 float* running_var, float* y, float* save_mean, float* save_invstd, void* workspace,
+                                 void* stream);
+int bnn_hip_bn_train_backward_f32(const float* gy, const float* y, const float* x, const float* save_mean,
+                                  const float* save_invstd, const float* gamma, int N, int C, int HW, float* dx,
+                                  float* dres, float* dgamma, float* dbeta, void* workspace, void* stream);
+
 /* Roofline calibration: runs a register-only instruction stream on every CU at full
  * occupancy and reports the sustained 32-bit lane-ops/s.  mode: 0 = v_bitop3_b32 +
  * v_bcnt_u32_b32 (the hot loop's pair), 1 = v_xor_b32 + v_bcnt_u32_b32, 2 = bcnt only,

@@ -386,3 +386,91 @@ def test_training_forward_keeps_three_bits_per_element_for_the_backward():
                          128 * 4 * 4 + 256 * 4 * 4 + 3 * 512 * 2 * 2 + 256 * 2 * 2)
     assert k_fp32 == want_fp32 and k_packed * 32 == k_fp32 * 3
     assert k_fp32 >= 5 * k_packed
+
+
+# ---- round 4: training-mode BatchNorm (+ residual) (+ ReLU) as one fused op (csrc/bn_train.hip) ----------------------
+
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)],
+                         ids=["bn_relu", "bn_add_relu", "bn", "bn_add"])
+@pytest.mark.parametrize("shape", [(8, 64, 56, 56), (4, 512, 7, 7), (3, 96, 9, 17), (2, 40, 1, 1), (16, 128, 28, 28)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_fused_batchnorm_training_op_matches_the_library(shape, relu, res):
+    """training.bn_act == act(bn(x) (+ identity)) of torch.nn.BatchNorm2d in training mode (the reference's blocks,
+    bnn/models/layers/res_block.py:40-56): output, saved statistics, running statistics (unbiased variance, momentum,
+    num_batches_tracked) and all four gradients, to fp32 rounding (the statistics here are accumulated in fp64)."""
+    N, C, H, W = shape
+    x0 = dev((gen.normal(gen.seed_of("bnx", shape), shape) * 1.7 + 0.3).astype(np.float32))
+    r0 = dev(gen.normal(gen.seed_of("bnr", shape), shape)) if res else None
+    gy = dev(gen.normal(gen.seed_of("bng", shape), shape))
+
+    def make():
+        bn = nn.BatchNorm2d(C).to(DEV).train()
+        with torch.no_grad():
+            bn.weight.copy_(dev((0.5 + gen.uniform(1, (C,))).astype(np.float32)))
+            bn.bias.copy_(dev((0.3 * gen.normal(2, (C,))).astype(np.float32)))
+            bn.running_mean.copy_(dev((0.5 * gen.normal(3, (C,))).astype(np.float32)))
+            bn.running_var.copy_(dev((0.5 + gen.uniform(4, (C,))).astype(np.float32)))
+        return bn
+
+    def run(fused):
+        bn, act = make(), (nn.ReLU(inplace=True) if relu else None)
+        x = x0.clone().requires_grad_(True)
+        r = None if r0 is None else r0.clone().requires_grad_(True)
+        training.FUSED_BN = fused
+        try:
+            assert training.bn_act_applies(bn, act, x) == fused
+            y = training.bn_act(x, bn, act, r)
+        finally:
+            training.FUSED_BN = True
+        y.backward(gy)
+        return (y.detach(), x.grad, bn.weight.grad, bn.bias.grad, None if r is None else r.grad,
+                bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked))
+    got, want = run(True), run(False)
+    assert got[7] == want[7] == 1
+    for name, a, b, tol in (("y", got[0], want[0], 2e-5), ("dx", got[1], want[1], 2e-4), ("dgamma", got[2], want[2], 2e-4),
+                            ("dbeta", got[3], want[3], 2e-4), ("running_mean", got[5], want[5], 1e-5),
+                            ("running_var", got[6], want[6], 1e-5)):
+        assert torch.allclose(a, b, rtol=tol, atol=tol * float(b.abs().max())), (name, float((a - b).abs().max()))
+    if res:
+        assert torch.allclose(got[4], want[4], rtol=1e-6, atol=0)
+
+
+def test_residual_blocks_train_with_the_fused_batchnorm_and_match_the_unfused_step():
+    """A BasicBlock with a down-sampling shortcut and a whole ResNet-18: one training step with the fused BN ops
+    (default) against the same step with the library's BatchNorm / ReLU / add — loss, gradients, running statistics."""
+    def step(fused, what):
+        training.FUSED_BN = fused
+        try:
+            if what == "block":
+                from bnn_amd.models import BasicBlock
+                from bnn_amd.models.blocks import conv1x1
+                ds = nn.Sequential(nn.AvgPool2d(2, 2, ceil_mode=True, count_include_pad=False), conv1x1(64, 128), nn.BatchNorm2d(128))
+                cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
+                                  weight_pre_process=XNORWeightBinarizer)
+                net = bnn.prepare_binary_model(BasicBlock(64, 128, 2, ds), cfg)
+                shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+                net.load_state_dict({k: torch.from_numpy(v) for k, v in gen.model_state(shapes, 3).items()})
+                net = net.to(DEV).train()
+                x = dev(gen.activation("relu", 5, (4, 64, 28, 28))).requires_grad_(True)
+                loss = (net(x) * dev(gen.normal(6, (4, 128, 14, 14)))).sum()
+            else:
+                net = _r18_train()
+                x = dev(gen.normal(91, (8, 3, 64, 64))).requires_grad_(True)
+                loss = torch.nn.functional.cross_entropy(net(x), torch.arange(8, device=DEV) * 7)
+            loss.backward()
+            return (float(loss.detach()), x.grad, [p.grad for p in net.parameters()],
+                    [b.clone() for n, b in net.named_buffers() if "running" in n])
+        finally:
+            training.FUSED_BN = True
+    for what in ("block", "r18"):
+        l1, gx1, gp1, rb1 = step(True, what)
+        l0, gx0, gp0, rb0 = step(False, what)
+        assert abs(l1 - l0) <= 1e-4 * abs(l0), what
+        for a, b in zip(rb1, rb0):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+        # binarised nets are discontinuous: a batch-statistics difference of 1e-7 can flip a sign(); compare in norm
+        def close(a, b, tol):
+            return float((a - b).norm()) <= tol * float(b.norm()) + 1e-12
+        assert close(gx1, gx0, 2e-2 if what == "r18" else 1e-3), what
+        for a, b in zip(gp1, gp0):
+            assert close(a, b, 5e-2 if what == "r18" else 2e-3), what

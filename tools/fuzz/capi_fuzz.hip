@@ -151,6 +151,29 @@ int launch_sign_thresholds(const float* alpha, const float*, const float*, const
   ++g_reached; REQUIRE(alpha && thr && O > 0 && kmax > 0 && kmax < (1 << 24) && (a == nullptr) == (b == nullptr) && al(thr, 4));
   return BNN_HIP_OK;
 }
+int bn_train_splits(int N, int C, int) { int s = (1024 + C - 1) / C; s = s > 64 ? 64 : s; s = s > N ? N : s; return s < 1 ? 1 : s; }
+static void check_bn_args(int N, int C, int HW) {
+  REQUIRE(N > 0 && C > 0 && HW > 0 && (long long)N * C * HW <= 4 * ((1LL << 31) - 1));
+}
+int launch_bn_stats(const float* x, int N, int C, int HW, int S, double* partial, hipStream_t) {
+  ++g_reached; check_bn_args(N, C, HW); REQUIRE(x && partial && S >= 1 && S <= N && al(partial, 8)); return BNN_HIP_OK;
+}
+int launch_bn_apply(const float* x, const double* partial, int S, const float*, const float*, const float*, int, float* y,
+                    int N, int C, int HW, float eps, float, float* rm, float* rv, float* mo, float* io, float* work,
+                    hipStream_t) {
+  ++g_reached; check_bn_args(N, C, HW);
+  REQUIRE(x && partial && y && mo && io && work && S >= 1 && eps >= 0.0f && (rm == nullptr) == (rv == nullptr) && al(work, 4));
+  return BNN_HIP_OK;
+}
+int launch_bn_bwd_reduce(const float* gy, const float*, const float* x, const float* m, const float* is, int N, int C, int HW,
+                         int S, double* partial, hipStream_t) {
+  ++g_reached; check_bn_args(N, C, HW); REQUIRE(gy && x && m && is && partial && S >= 1); return BNN_HIP_OK;
+}
+int launch_bn_bwd_dx(const float* gy, const float*, const float* x, const float* m, const float* is, const float*,
+                     const double* partial, int S, float* dx, float*, float*, float*, int N, int C, int HW, float* work,
+                     hipStream_t) {
+  ++g_reached; check_bn_args(N, C, HW); REQUIRE(gy && x && m && is && partial && dx && work && S >= 1); return BNN_HIP_OK;
+}
 int launch_probe_int_alu(int mode, int iters, double* r, double*, hipStream_t) { REQUIRE(iters > 0 && r); (void)mode; return BNN_HIP_OK; }
 int launch_probe_clock(int it, double* mhz, double*, hipStream_t) { REQUIRE(it > 0 && mhz); return BNN_HIP_OK; }
 }  // namespace bnn
@@ -189,7 +212,7 @@ int main(int argc, char** argv) {
   for (long it = 0; it < iters; ++it) {
     ++g_calls;
     int st = 0;
-    switch (rnd() % 23) {
+    switch (rnd() % 25) {
       case 0: { bnn_hip_conv_desc d = pick_desc();
         st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
                              pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
@@ -262,6 +285,16 @@ int main(int argc, char** argv) {
       case 21: st = bnn_hip_bconv_grad_weight_packed_f32(pick_ptr<float>(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<float>(),
                                                          pick_int(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(),
                                                          (int)(rnd() % 5), (int)(rnd() % 4), stream); break;
+      case 22: { const int N = pick_int(), C = pick_int(), HW = pick_int();
+        if (bnn_hip_bn_train_workspace_bytes(N, C, HW) > ((size_t)1 << 40)) broken("bn workspace size");
+        st = bnn_hip_bn_train_forward_f32(pick_ptr<float>(), N, C, HW, pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(),
+                                          pick_int(), (float)(pick_int() % 3) * 1e-5f, 0.1f, pick_ptr<float>(), pick_ptr<float>(),
+                                          pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<double>(), stream);
+        break; }
+      case 23: st = bnn_hip_bn_train_backward_f32(pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(),
+                                                  pick_ptr<float>(), pick_ptr<float>(), pick_int(), pick_int(), pick_int(),
+                                                  pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(),
+                                                  pick_ptr<double>(), stream); break;
       default: { bnn_hip_conv_desc d = pick_desc();
         (void)bnn_hip_shortcut_fold_supported(rnd() % 16 ? &d : nullptr, pick_int());
         st = bnn_hip_blinear(pick_int(), pick_int(), pick_int(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
