@@ -392,7 +392,7 @@ def test_training_forward_keeps_three_bits_per_element_for_the_backward():
 
 @pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)],
                          ids=["bn_relu", "bn_add_relu", "bn", "bn_add"])
-@pytest.mark.parametrize("shape", [(8, 64, 56, 56), (4, 512, 7, 7), (3, 96, 9, 17), (2, 40, 1, 1), (16, 128, 28, 28)],
+@pytest.mark.parametrize("shape", [(8, 64, 56, 56), (4, 512, 7, 7), (3, 96, 9, 17), (2, 40, 3, 3), (16, 128, 28, 28)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_fused_batchnorm_training_op_matches_the_library(shape, relu, res):
     """training.bn_act == act(bn(x) (+ identity)) of torch.nn.BatchNorm2d in training mode (the reference's blocks,
