@@ -418,7 +418,10 @@ def test_unsupported_models_are_left_alone():
     cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
                       weight_pre_process=XNORWeightBinarizer)
     dab = bnn.prepare_binary_model(resnet18(stem_type="dabnn"), cfg).to(DEV).eval()
-    assert optimize_for_inference(dab) is dab          # other stems: per-layer path only
+    assert isinstance(optimize_for_inference(dab), FusedResNet)   # round 4: the stem runs as modules, the blocks fused
+    inorm = bnn.prepare_binary_model(resnet18(norm_layer=lambda c: torch.nn.InstanceNorm2d(c, affine=True)), cfg)
+    inorm = inorm.to(DEV).eval()
+    assert optimize_for_inference(inorm) is inorm      # no BatchNorm to fold: per-layer path only
     with pytest.raises(FusionError):
         FusedResNet(_r18().train())
     with pytest.raises(FusionError):
