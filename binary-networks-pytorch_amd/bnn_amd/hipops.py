@@ -730,6 +730,44 @@ def bn_train_backward(gy: torch.Tensor, y: Optional[torch.Tensor], x: torch.Tens
     return dx, dgamma, dbeta, dres
 
 
+def bn_relu_maxpool_train_forward(x: torch.Tensor, gamma, beta, running_mean, running_var, momentum: float, eps: float):
+    """``maxpool3x3/2/1(relu(batch_norm(x, training=True)))`` without writing the normalised tensor (csrc/bn_train.hip):
+    returns ``(pooled, code uint8, save_mean, save_invstd)``; ``code`` = which of the 9 window positions won."""
+    x = _require_cuda_f32(x, "BatchNorm input")
+    lib = native.require()
+    N, C, H, W = x.shape
+    hp, wp = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    with torch.cuda.device(x.device):
+        p = torch.empty((N, C, hp, wp), dtype=torch.float32, device=x.device)
+        code = torch.empty((N, C, hp, wp), dtype=torch.uint8, device=x.device)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(int(lib.bnn_hip_bn_train_workspace_bytes(N, C, H * W)), dtype=torch.uint8, device=x.device)
+        native.check(lib.bnn_hip_bn_relu_maxpool_train_forward_f32(
+            x.data_ptr(), N, C, H, W, _ptr(gamma), _ptr(beta), float(eps), float(momentum), _ptr(running_mean),
+            _ptr(running_var), p.data_ptr(), code.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(),
+            _stream(x.device)), "bnn_hip_bn_relu_maxpool_train_forward_f32")
+    return p, code, mean, invstd
+
+
+def bn_relu_maxpool_train_backward(gy: torch.Tensor, p: torch.Tensor, code: torch.Tensor, x: torch.Tensor,
+                                   mean: torch.Tensor, invstd: torch.Tensor, gamma):
+    """Backward of ``bn_relu_maxpool_train_forward``: ``(dx, dgamma, dbeta)``."""
+    gy = _require_cuda_f32(gy, "grad_output")
+    lib = native.require()
+    N, C, H, W = x.shape
+    with torch.cuda.device(x.device):
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(int(lib.bnn_hip_bn_train_workspace_bytes(N, C, H * W)), dtype=torch.uint8, device=x.device)
+        native.check(lib.bnn_hip_bn_relu_maxpool_train_backward_f32(
+            gy.data_ptr(), p.data_ptr(), code.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
+            N, C, H, W, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream(x.device)),
+            "bnn_hip_bn_relu_maxpool_train_backward_f32")
+    return dx, dgamma, dbeta
+
+
 PROBE_MODES = {0: "bitop3+bcnt", 1: "xor+bcnt", 2: "bcnt", 3: "bitop3", 4: "xor", 5: "fma_f32",
                6: "add_u32", 7: "and_vgpr", 8: "and_vgpr+bcnt", 9: "xor_vgpr", 10: "and_sgpr+bcnt"}
 

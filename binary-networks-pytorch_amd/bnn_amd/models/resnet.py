@@ -16,7 +16,7 @@ from typing import Any, Callable, List, Optional, Type
 import torch
 import torch.nn as nn
 
-from .blocks import BasicBlock, Bottleneck, HBlock, PreBasicBlock, PreBottleneck, _bn_act, conv1x1
+from .blocks import BasicBlock, Bottleneck, HBlock, PreBasicBlock, PreBottleneck, conv1x1
 
 
 def _auto_forward(model, x):
@@ -151,7 +151,11 @@ class ResNet(nn.Module):
                 return y
         x = self.conv1(x)
         if self.stem_type == "basic":
-            x = self.maxpool(_bn_act(x, self.bn1, self.relu))
+            if x.is_cuda and self.bn1.training:      # training on a HIP device: bn1 -> relu -> maxpool as one fused op
+                from .. import training
+                x = training.stem_tail(x, self.bn1, self.relu, self.maxpool)
+            else:
+                x = self.maxpool(self.relu(self.bn1(x)))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = torch.flatten(self.avgpool(x), 1)
         return self.fc(x)

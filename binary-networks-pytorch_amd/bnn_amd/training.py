@@ -165,6 +165,39 @@ def bn_act(x: torch.Tensor, bn: nn.BatchNorm2d, act=None, residual=None) -> torc
     return y if act is None else act(y)
 
 
+class StemTailFn(torch.autograd.Function):
+    """``maxpool(relu(bn1(x)))`` of the stem (bnn/models/resnet.py:150-153), training mode: the normalised tensor is
+    never written; one byte per pooled output routes the gradient back (csrc/bn_train.hip, "stem tail")."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn):
+        p, code, mean, invstd = hipops.bn_relu_maxpool_train_forward(x, weight, bias, bn.running_mean, bn.running_var,
+                                                                    _momentum(bn), bn.eps)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        ctx.save_for_backward(x, p, code, mean, invstd, weight)
+        ctx.mark_non_differentiable(code)
+        return p, code
+
+    @staticmethod
+    def backward(ctx, gp, _gcode):
+        x, p, code, mean, invstd, weight = ctx.saved_tensors
+        dx, dgamma, dbeta = hipops.bn_relu_maxpool_train_backward(gp.contiguous(), p, code, x, mean, invstd, weight)
+        return (dx if ctx.needs_input_grad[0] else None, dgamma if ctx.needs_input_grad[1] else None,
+                dbeta if ctx.needs_input_grad[2] else None, None)
+
+
+def stem_tail(x: torch.Tensor, bn: nn.Module, act: nn.Module, pool: nn.Module) -> torch.Tensor:
+    """``pool(act(bn(x)))`` — one fused op when it is BatchNorm2d (training) -> ReLU -> MaxPool2d(3, 2, 1) on a HIP
+    device, else the modules themselves."""
+    if (bn_act_applies(bn, act, x) and act is not None and type(pool) is nn.MaxPool2d
+            and pool.kernel_size in (3, (3, 3)) and pool.stride in (2, (2, 2)) and pool.padding in (1, (1, 1))
+            and pool.dilation in (1, (1, 1)) and not pool.ceil_mode and not pool.return_indices
+            and not pool._forward_hooks and not pool._forward_pre_hooks):
+        return StemTailFn.apply(x, bn.weight, bn.bias, bn)[0]
+    return pool(bn_act(x, bn, act))
+
+
 def conv2d_train(layer: nn.Module, x: torch.Tensor, plan, packed) -> torch.Tensor:
     """``bnn.layers.Conv2d.forward`` with autograd recording: HIP forward, library backward."""
     w_hat = layer.weight_pre_process(layer.weight)          # autograd edge to W (sign STE, alpha)

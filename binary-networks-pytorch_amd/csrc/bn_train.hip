@@ -223,6 +223,116 @@ __global__ __launch_bounds__(bnt::NT) void bn_bwd_dx_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------- stem tail
+// bn1 -> relu -> maxpool(3, stride 2, pad 1) of the reference's ResNet stem (bnn/models/resnet.py:150-153) in training
+// mode.  The library evaluates it as BatchNorm (3 passes over the 822 MB conv output at batch 256), ReLU, max-pool
+// (+ 410 MB of int64 indices), and backward as max-pool backward (1.56 ms), ReLU backward, BatchNorm backward — 3.5 ms
+// of a 22.8 ms step.  Here the normalised tensor is never written: the forward pools relu(x * scale + shift) straight
+// from x and keeps ONE BYTE per pooled output (which of the 9 window positions won); the backward routes gy through
+// those codes inside the BatchNorm reductions.
+//   forward : p[w] = max over the window of relu(fma(x, scale, shift)),  code[w] = 3 * dy + dx of the first maximum
+//   backward: g[pix] = sum of gy[w] over the windows w whose winner is pix and whose p[w] > 0   (ReLU: a winner of value
+//             0 passes nothing — so ties at 0 need no tie-breaking rule),  then BatchNorm's dbeta / dgamma / dx on g.
+__global__ __launch_bounds__(bnt::NT) void bn_relu_pool_fwd_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ scale_c,
+                                                                   const float* __restrict__ shift_c,
+                                                                   float* __restrict__ p, unsigned char* __restrict__ code,
+                                                                   long long total, int C, int H, int W, int Hp, int Wp) {
+  const long long o = (long long)blockIdx.x * bnt::NT + threadIdx.x;
+  if (o >= total) return;
+  const int px = (int)(o % Wp);
+  const long long t = o / Wp;
+  const int py = (int)(t % Hp);
+  const long long row = t / Hp;                 // n * C + c
+  const int c = (int)(row % C);
+  const float scale = scale_c[c], shift = shift_c[c];
+  const float* xb = x + (size_t)row * H * W;
+  float best = -1.0f;                           // below every ReLU output: the first in-range position always wins first
+  int bc = 0;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int r = 2 * py - 1 + dy;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int q = 2 * px - 1 + dx;
+      if ((unsigned)r < (unsigned)H && (unsigned)q < (unsigned)W) {
+        const float v = fmaxf(fmaf(xb[(size_t)r * W + q], scale, shift), 0.0f);
+        if (v > best) { best = v; bc = 3 * dy + dx; }
+      }
+    }
+  }
+  p[o] = best;
+  code[o] = (unsigned char)bc;
+}
+
+// partial[c][s] = (sum g, sum g * xhat) over the images of split s, from the pooled outputs: g is non-zero only at winners
+__global__ __launch_bounds__(bnt::NT) void bn_pool_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ p,
+                                                                     const unsigned char* __restrict__ code,
+                                                                     const float* __restrict__ x,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd, int N, int C, int H,
+                                                                     int W, int Hp, int Wp, int per,
+                                                                     double* __restrict__ partial) {
+  const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+  const int n0 = s * per, n1 = min(N, n0 + per);
+  const int hwp = Hp * Wp;
+  const int total = (n1 - n0) * hwp;
+  const float mu = mean[c], is = invstd[c];
+  double a = 0.0, b = 0.0;
+  for (int idx = threadIdx.x; idx < total; idx += bnt::NT) {
+    const int dn = idx / hwp, w = idx - dn * hwp;
+    const size_t row = (size_t)(n0 + dn) * C + c;
+    const size_t o = row * hwp + w;
+    const float g = p[o] > 0.0f ? gy[o] : 0.0f;
+    const int py = w / Wp, px = w - py * Wp, cd = code[o];
+    const int r = 2 * py - 1 + cd / 3, q = 2 * px - 1 + cd % 3;
+    const float xv = x[row * H * W + (size_t)r * W + q];
+    a += (double)g;
+    b += (double)g * ((xv - mu) * is);
+  }
+  block_sum2(a, b);
+  if (threadIdx.x == 0) {
+    partial[((size_t)c * S + s) * 2 + 0] = a;
+    partial[((size_t)c * S + s) * 2 + 1] = b;
+  }
+}
+
+// dx over the conv pixels: g gathered from the (at most four) windows a pixel belongs to
+__global__ __launch_bounds__(bnt::NT) void bn_pool_bwd_dx_kernel(const float* __restrict__ gy, const float* __restrict__ p,
+                                                                 const unsigned char* __restrict__ code,
+                                                                 const float* __restrict__ x, const float* __restrict__ mean,
+                                                                 const float* __restrict__ coef, float* __restrict__ dx,
+                                                                 long long total, int C, int H, int W, int Hp, int Wp) {
+  const long long i = (long long)blockIdx.x * bnt::NT + threadIdx.x;
+  if (i >= total) return;
+  const int q = (int)(i % W);
+  const long long t = i / W;
+  const int r = (int)(t % H);
+  const long long row = t / H;
+  const int c = (int)(row % C);
+  const size_t pb = (size_t)row * Hp * Wp;
+  float g = 0.0f;
+  // windows (py, px) with 2 py - 1 <= r <= 2 py + 1: py in {ceil((r - 1) / 2) .. floor((r + 1) / 2)}; same for columns
+  const int py0 = r >> 1, py1 = (r + 1) >> 1, px0 = q >> 1, px1 = (q + 1) >> 1;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int py = a ? py1 : py0;
+    if (a && py1 == py0) continue;
+    if (py >= Hp) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int px = b ? px1 : px0;
+      if (b && px1 == px0) continue;
+      if (px >= Wp) continue;
+      const size_t o = pb + (size_t)py * Wp + px;
+      const int want = 3 * (r - (2 * py - 1)) + (q - (2 * px - 1));
+      if (code[o] == want && p[o] > 0.0f) g += gy[o];
+    }
+  }
+  const float mu = mean[c], k = coef[3 * c], mb = coef[3 * c + 1], kg = coef[3 * c + 2];
+  dx[i] = k * (g - mb - (x[i] - mu) * kg);
+}
+
 // ------------------------------------------------------------------------------------------------- host side
 int bn_train_splits(int N, int C, int HW) {
   // enough blocks to fill the chip (~4 per CU), at most one split per image
@@ -305,6 +415,34 @@ int launch_bn_bwd_dx(const float* gy, const float* y, const float* x, const floa
     else if (dres) BNN_DX(1, false, true); else BNN_DX(1, false, false);
   }
 #undef BNN_DX
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+// stem tail forward: statistics + finalize as launch_bn_apply, then the pooling pass instead of the apply pass
+int launch_bn_relu_pool_fwd(const float* x, const double* partial, int splits, const float* gamma, const float* beta,
+                            float* p, unsigned char* code, int N, int C, int H, int W, float eps, float momentum, float* rm,
+                            float* rv, float* mean_out, float* invstd_out, float* work, hipStream_t s) {
+  const int Hp = (H - 1) / 2 + 1, Wp = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, partial, splits, C,
+                     (double)N * H * W, gamma, beta, eps, momentum, rm, rv, mean_out, invstd_out, work, work + C);
+  const long long total = (long long)N * C * Hp * Wp;
+  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3((unsigned)((total + bnt::NT - 1) / bnt::NT)), dim3(bnt::NT), 0, s, x,
+                     work, work + C, p, code, total, C, H, W, Hp, Wp);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+int launch_bn_relu_pool_bwd(const float* gy, const float* p, const unsigned char* code, const float* x, const float* mean,
+                            const float* invstd, const float* gamma, int N, int C, int H, int W, int splits,
+                            double* partial, float* work, float* dx, float* dgamma, float* dbeta, hipStream_t s) {
+  const int Hp = (H - 1) / 2 + 1, Wp = (W - 1) / 2 + 1;
+  const int per = (N + splits - 1) / splits;
+  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3((unsigned)C, (unsigned)splits), dim3(bnt::NT), 0, s, gy, p, code, x, mean,
+                     invstd, N, C, H, W, Hp, Wp, per, partial);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, partial, splits, C,
+                     (double)N * H * W, gamma, invstd, dgamma, dbeta, work);
+  const long long total = (long long)N * C * H * W;
+  hipLaunchKernelGGL(bn_pool_bwd_dx_kernel, dim3((unsigned)((total + bnt::NT - 1) / bnt::NT)), dim3(bnt::NT), 0, s, gy, p,
+                     code, x, mean, work, dx, total, C, H, W, Hp, Wp);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 

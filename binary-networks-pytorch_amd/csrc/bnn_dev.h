@@ -163,6 +163,12 @@ int launch_bn_bwd_reduce(const float* gy, const float* y, const float* x, const 
 int launch_bn_bwd_dx(const float* gy, const float* y, const float* x, const float* mean, const float* invstd,
                      const float* gamma, const double* partial, int splits, float* dx, float* dres, float* dgamma,
                      float* dbeta, int N, int C, int HW, float* work, hipStream_t s);
+int launch_bn_relu_pool_fwd(const float* x, const double* partial, int splits, const float* gamma, const float* beta,
+                            float* p, unsigned char* code, int N, int C, int H, int W, float eps, float momentum, float* rm,
+                            float* rv, float* mean_out, float* invstd_out, float* work, hipStream_t s);
+int launch_bn_relu_pool_bwd(const float* gy, const float* p, const unsigned char* code, const float* x, const float* mean,
+                            const float* invstd, const float* gamma, int N, int C, int H, int W, int splits,
+                            double* partial, float* work, float* dx, float* dgamma, float* dbeta, hipStream_t s);
 int launch_probe_int_alu(int mode, int iters, double* lane_ops_per_s, double* elapsed_ms, hipStream_t s);
 int launch_probe_clock(int spin_iters, double* shader_mhz, double* elapsed_us, hipStream_t s);
 

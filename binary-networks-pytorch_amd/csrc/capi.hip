@@ -626,6 +626,45 @@ int bnn_hip_bn_train_backward_f32(const float* gy, const float* y, const float* 
                                static_cast<hipStream_t>(stream));
 }
 
+int bnn_hip_bn_relu_maxpool_train_forward_f32(const float* x, int N, int C, int H, int W, const float* gamma,
+                                              const float* beta, float eps, float momentum, float* running_mean,
+                                              float* running_var, float* pooled, uint8_t* code, float* save_mean,
+                                              float* save_invstd, void* workspace, void* stream) {
+  if (!x || !pooled || !code || !save_mean || !save_invstd || !workspace || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  const int st = check_bn(N, C, (int)(mulc(H, W) > 0x7fffffffLL ? 0 : (long long)H * W));
+  if (st != BNN_HIP_OK) return st;
+  if ((running_mean == nullptr) != (running_var == nullptr) || !(eps >= 0.0f)) return BNN_HIP_ERR_INVALID_ARG;
+  if (!aligned(x, 4) || !aligned(pooled, 4) || !aligned(workspace, 8)) return BNN_HIP_ERR_INVALID_ARG;
+  const int HW = H * W, S = bnn::bn_train_splits(N, C, HW);
+  double* partial = static_cast<double*>(workspace);
+  float* work = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)C * S * 2 * sizeof(double), 256));
+  g_launches.fetch_add(3, std::memory_order_relaxed);
+  BNN_RANGE();
+  const int st2 = bnn::launch_bn_stats(x, N, C, HW, S, partial, static_cast<hipStream_t>(stream));
+  if (st2 != BNN_HIP_OK) return st2;
+  return bnn::launch_bn_relu_pool_fwd(x, partial, S, gamma, beta, pooled, code, N, C, H, W, eps, momentum, running_mean,
+                                      running_var, save_mean, save_invstd, work, static_cast<hipStream_t>(stream));
+}
+
+int bnn_hip_bn_relu_maxpool_train_backward_f32(const float* gy, const float* pooled, const uint8_t* code, const float* x,
+                                               const float* save_mean, const float* save_invstd, const float* gamma,
+                                               int N, int C, int H, int W, float* dx, float* dgamma, float* dbeta,
+                                               void* workspace, void* stream) {
+  if (!gy || !pooled || !code || !x || !save_mean || !save_invstd || !dx || !workspace || H <= 0 || W <= 0)
+    return BNN_HIP_ERR_INVALID_ARG;
+  const int st = check_bn(N, C, (int)(mulc(H, W) > 0x7fffffffLL ? 0 : (long long)H * W));
+  if (st != BNN_HIP_OK) return st;
+  if (!aligned(gy, 4) || !aligned(pooled, 4) || !aligned(x, 4) || !aligned(dx, 4) || !aligned(workspace, 8))
+    return BNN_HIP_ERR_INVALID_ARG;
+  const int HW = H * W, S = bnn::bn_train_splits(N, C, HW);
+  double* partial = static_cast<double*>(workspace);
+  float* work = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)C * S * 2 * sizeof(double), 256));
+  g_launches.fetch_add(3, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_bn_relu_pool_bwd(gy, pooled, code, x, save_mean, save_invstd, gamma, N, C, H, W, S, partial, work, dx,
+                                      dgamma, dbeta, static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_probe_clock(int spin_iters, double* shader_mhz, double* elapsed_us, void* stream) {
   if (spin_iters <= 0 || spin_iters > (1 << 24) || !shader_mhz) return BNN_HIP_ERR_INVALID_ARG;
   return bnn::launch_probe_clock(spin_iters, shader_mhz, elapsed_us, static_cast<hipStream_t>(stream));

@@ -437,6 +437,21 @@ int bnn_hip_bn_train_backward_f32(const float* gy, const float* y, const float* 
                                   const float* save_invstd, const float* gamma, int N, int C, int HW, float* dx,
                                   float* dres, float* dgamma, float* dbeta, void* workspace, void* stream);
 
+/* The stem tail in training mode:  maxpool3x3/2/1( relu( batch_norm_train(x) ) )   (bnn/models/resnet.py:150-153) without
+ * ever writing the normalised tensor: `pooled` [N, C, Hp, Wp] (Hp = (H - 1) / 2 + 1) and ONE BYTE per pooled output,
+ * `code` = 3 * dy + dx of the winning window position, are all the forward leaves behind (the library: the fp32
+ * BatchNorm output, the ReLU output and int64 pooling indices).  The backward routes gy through the codes inside the
+ * BatchNorm reductions (a winner of value 0 passes nothing: ReLU).  Workspace: bnn_hip_bn_train_workspace_bytes(N, C,
+ * H * W).  Same statistics semantics as bnn_hip_bn_train_forward_f32.                                                   */
+int bnn_hip_bn_relu_maxpool_train_forward_f32(const float* x, int N, int C, int H, int W, const float* gamma,
+                                              const float* beta, float eps, float momentum, float* running_mean,
+                                              float* running_var, float* pooled, uint8_t* code, float* save_mean,
+                                              float* save_invstd, void* workspace, void* stream);
+int bnn_hip_bn_relu_maxpool_train_backward_f32(const float* gy, const float* pooled, const uint8_t* code, const float* x,
+                                               const float* save_mean, const float* save_invstd, const float* gamma,
+                                               int N, int C, int H, int W, float* dx, float* dgamma, float* dbeta,
+                                               void* workspace, void* stream);
+
 /* Roofline calibration: runs a register-only instruction stream on every CU at full
  * occupancy and reports the sustained 32-bit lane-ops/s.  mode: 0 = v_bitop3_b32 +
  * v_bcnt_u32_b32 (the hot loop's pair), 1 = v_xor_b32 + v_bcnt_u32_b32, 2 = bcnt only,

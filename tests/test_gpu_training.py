@@ -474,3 +474,36 @@ def test_residual_blocks_train_with_the_fused_batchnorm_and_match_the_unfused_st
         assert close(gx1, gx0, 2e-2 if what == "r18" else 1e-3), what
         for a, b in zip(gp1, gp0):
             assert close(a, b, 5e-2 if what == "r18" else 2e-3), what
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 112, 112), (3, 16, 17, 23), (2, 8, 7, 7), (5, 64, 32, 32), (2, 3, 1, 1)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_fused_stem_tail_matches_batchnorm_relu_maxpool_of_the_library(shape):
+    """training.stem_tail == maxpool3x3/2/1(relu(bn1(x))) in training mode (bnn/models/resnet.py:150-153): pooled output,
+    running statistics, and dx / dgamma / dbeta — without writing the normalised tensor (one byte per pooled output
+    routes the gradient).  Odd sizes: windows cut by the border; ReLU zeros: ties whose winner passes nothing."""
+    N, C, H, W = shape
+    x0 = dev((gen.normal(gen.seed_of("stx", shape), shape) * 1.3 - 0.2).astype(np.float32))
+    hp, wp = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    gy = dev(gen.normal(gen.seed_of("stg", shape), (N, C, hp, wp)))
+
+    def run(fused):
+        bn = nn.BatchNorm2d(C).to(DEV).train()
+        with torch.no_grad():
+            bn.weight.copy_(dev(((0.5 + gen.uniform(1, (C,))) * np.where(np.arange(C) % 5 == 0, -1, 1)).astype(np.float32)))
+            bn.bias.copy_(dev((0.3 * gen.normal(2, (C,))).astype(np.float32)))
+        act, pool = nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1)
+        x = x0.clone().requires_grad_(True)
+        training.FUSED_BN = fused
+        try:
+            y = training.stem_tail(x, bn, act, pool)
+        finally:
+            training.FUSED_BN = True
+        y.backward(gy)
+        return y.detach(), x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()
+    got, want = run(True), run(False)
+    assert got[0].shape == (N, C, hp, wp)
+    for name, a, b, tol in (("y", got[0], want[0], 2e-5), ("dx", got[1], want[1], 3e-4), ("dgamma", got[2], want[2], 3e-4),
+                            ("dbeta", got[3], want[3], 3e-4), ("running_mean", got[4], want[4], 1e-5),
+                            ("running_var", got[5], want[5], 1e-5)):
+        assert torch.allclose(a, b, rtol=tol, atol=tol * float(b.abs().max()) + 1e-7), (name, float((a - b).abs().max()))

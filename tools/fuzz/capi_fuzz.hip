@@ -174,6 +174,20 @@ int launch_bn_bwd_dx(const float* gy, const float*, const float* x, const float*
                      hipStream_t) {
   ++g_reached; check_bn_args(N, C, HW); REQUIRE(gy && x && m && is && partial && dx && work && S >= 1); return BNN_HIP_OK;
 }
+int launch_bn_relu_pool_fwd(const float* x, const double* partial, int S, const float*, const float*, float* p, unsigned char* code,
+                            int N, int C, int H, int W, float eps, float, float* rm, float* rv, float* mo, float* io, float* work,
+                            hipStream_t) {
+  ++g_reached; REQUIRE(H > 0 && W > 0 && (long long)H * W <= 0x7fffffffLL); check_bn_args(N, C, H * W);
+  REQUIRE(x && partial && p && code && mo && io && work && S >= 1 && eps >= 0.0f && (rm == nullptr) == (rv == nullptr));
+  return BNN_HIP_OK;
+}
+int launch_bn_relu_pool_bwd(const float* gy, const float* p, const unsigned char* code, const float* x, const float* m,
+                            const float* is, const float*, int N, int C, int H, int W, int S, double* partial, float* work,
+                            float* dx, float*, float*, hipStream_t) {
+  ++g_reached; REQUIRE(H > 0 && W > 0 && (long long)H * W <= 0x7fffffffLL); check_bn_args(N, C, H * W);
+  REQUIRE(gy && p && code && x && m && is && partial && work && dx && S >= 1);
+  return BNN_HIP_OK;
+}
 int launch_probe_int_alu(int mode, int iters, double* r, double*, hipStream_t) { REQUIRE(iters > 0 && r); (void)mode; return BNN_HIP_OK; }
 int launch_probe_clock(int it, double* mhz, double*, hipStream_t) { REQUIRE(it > 0 && mhz); return BNN_HIP_OK; }
 }  // namespace bnn
@@ -212,7 +226,7 @@ int main(int argc, char** argv) {
   for (long it = 0; it < iters; ++it) {
     ++g_calls;
     int st = 0;
-    switch (rnd() % 25) {
+    switch (rnd() % 27) {
       case 0: { bnn_hip_conv_desc d = pick_desc();
         st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
                              pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
@@ -295,6 +309,15 @@ int main(int argc, char** argv) {
                                                   pick_ptr<float>(), pick_ptr<float>(), pick_int(), pick_int(), pick_int(),
                                                   pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(),
                                                   pick_ptr<double>(), stream); break;
+      case 24: st = bnn_hip_bn_relu_maxpool_train_forward_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(),
+                                                              pick_ptr<float>(), pick_ptr<float>(), 1e-5f, 0.1f, pick_ptr<float>(),
+                                                              pick_ptr<float>(), pick_ptr<float>(), pick_ptr<uint8_t>(),
+                                                              pick_ptr<float>(), pick_ptr<float>(), pick_ptr<double>(), stream); break;
+      case 25: st = bnn_hip_bn_relu_maxpool_train_backward_f32(pick_ptr<float>(), pick_ptr<float>(), pick_ptr<uint8_t>(),
+                                                               pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(),
+                                                               pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(),
+                                                               pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(),
+                                                               pick_ptr<double>(), stream); break;
       default: { bnn_hip_conv_desc d = pick_desc();
         (void)bnn_hip_shortcut_fold_supported(rnd() % 16 ? &d : nullptr, pick_int());
         st = bnn_hip_blinear(pick_int(), pick_int(), pick_int(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
