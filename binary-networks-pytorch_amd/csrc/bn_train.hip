@@ -297,40 +297,64 @@ __global__ __launch_bounds__(bnt::NT) void bn_pool_bwd_reduce_kernel(const float
   }
 }
 
-// dx over the conv pixels: g gathered from the (at most four) windows a pixel belongs to
+// dx over the conv pixels.  A wave owns one image row of one (image, channel) plane, a lane up to four consecutive pixels
+// of it (no per-element divisions: the row index is wave-uniform); the gradient arrives from the <= 2 x 3 windows that
+// can have their winner among those pixels — each window's code is decoded once and its gy added to the pixel it names.
+template <int VEC>
 __global__ __launch_bounds__(bnt::NT) void bn_pool_bwd_dx_kernel(const float* __restrict__ gy, const float* __restrict__ p,
                                                                  const unsigned char* __restrict__ code,
                                                                  const float* __restrict__ x, const float* __restrict__ mean,
                                                                  const float* __restrict__ coef, float* __restrict__ dx,
-                                                                 long long total, int C, int H, int W, int Hp, int Wp) {
-  const long long i = (long long)blockIdx.x * bnt::NT + threadIdx.x;
-  if (i >= total) return;
-  const int q = (int)(i % W);
-  const long long t = i / W;
-  const int r = (int)(t % H);
-  const long long row = t / H;
-  const int c = (int)(row % C);
-  const size_t pb = (size_t)row * Hp * Wp;
-  float g = 0.0f;
-  // windows (py, px) with 2 py - 1 <= r <= 2 py + 1: py in {ceil((r - 1) / 2) .. floor((r + 1) / 2)}; same for columns
-  const int py0 = r >> 1, py1 = (r + 1) >> 1, px0 = q >> 1, px1 = (q + 1) >> 1;
+                                                                 long long rows, int C, int H, int W, int Hp, int Wp,
+                                                                 int lpr_shift) {
+  // lanes per row = 2^lpr_shift (the smallest power of two >= W / VEC, at most 64): a wave covers 64 >> lpr_shift
+  // image rows at a time, so that narrow images (112 pixels: 28 float4s) keep the lanes busy
+  const int wave = (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int rpw = 64 >> lpr_shift, lpr = 1 << lpr_shift;
+  const long long gr = ((long long)blockIdx.x * (bnt::NT / 64) + wave) * rpw + (lane >> lpr_shift);
+  if (gr >= rows) return;
+  const long long plane = gr / H;                                         // n * C + c
+  const int r = (int)(gr - plane * H), c = (int)(plane % C);
+  const float mu = mean[c], k = coef[3 * c], mb = coef[3 * c + 1], kg = coef[3 * c + 2];
+  const float* xr = x + (size_t)gr * W;
+  float* dr = dx + (size_t)gr * W;
+  const size_t pb = (size_t)plane * Hp * Wp;
+  const int py0 = r >> 1, py1 = (r + 1) >> 1;                             // pooled rows whose windows contain row r
+  for (int q = (lane & (lpr - 1)) * VEC; q < W; q += lpr * VEC) {
+    float g[VEC];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int py = a ? py1 : py0;
-    if (a && py1 == py0) continue;
-    if (py >= Hp) continue;
+    for (int e = 0; e < VEC; ++e) g[e] = 0.0f;
+    // pooled columns whose windows reach pixels q .. q + VEC - 1: floor(q / 2) .. floor((q + VEC) / 2)
+    const int pxa = q >> 1, pxb = min((q + VEC) >> 1, Wp - 1);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int px = b ? px1 : px0;
-      if (b && px1 == px0) continue;
-      if (px >= Wp) continue;
-      const size_t o = pb + (size_t)py * Wp + px;
-      const int want = 3 * (r - (2 * py - 1)) + (q - (2 * px - 1));
-      if (code[o] == want && p[o] > 0.0f) g += gy[o];
+    for (int a = 0; a < 2; ++a) {
+      const int py = a ? py1 : py0;
+      if ((a && py1 == py0) || py >= Hp) continue;
+      const int dy = r - (2 * py - 1);                                    // the window row that IS image row r
+      for (int px = pxa; px <= pxb; ++px) {
+        const size_t o = pb + (size_t)py * Wp + px;
+        const int cd = code[o];
+        const int wy = cd / 3, wx = cd - 3 * wy;
+        const int e = 2 * px - 1 + wx - q;                                // the winner's position among this lane's pixels
+        if (wy == dy && (unsigned)e < (unsigned)VEC && p[o] > 0.0f) {
+          const float gv = gy[o];
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) g[j] += (j == e) ? gv : 0.0f;
+        }
+      }
+    }
+    if constexpr (VEC == 4) {
+      const float4 xv = *reinterpret_cast<const float4*>(xr + q);
+      float4 d;
+      d.x = k * (g[0] - mb - (xv.x - mu) * kg);
+      d.y = k * (g[1] - mb - (xv.y - mu) * kg);
+      d.z = k * (g[2] - mb - (xv.z - mu) * kg);
+      d.w = k * (g[3] - mb - (xv.w - mu) * kg);
+      *reinterpret_cast<float4*>(dr + q) = d;
+    } else {
+      dr[q] = k * (g[0] - mb - (xr[q] - mu) * kg);
     }
   }
-  const float mu = mean[c], k = coef[3 * c], mb = coef[3 * c + 1], kg = coef[3 * c + 2];
-  dx[i] = k * (g - mb - (x[i] - mu) * kg);
 }
 
 // ------------------------------------------------------------------------------------------------- host side
@@ -440,9 +464,18 @@ int launch_bn_relu_pool_bwd(const float* gy, const float* p, const unsigned char
                      invstd, N, C, H, W, Hp, Wp, per, partial);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, partial, splits, C,
                      (double)N * H * W, gamma, invstd, dgamma, dbeta, work);
-  const long long total = (long long)N * C * H * W;
-  hipLaunchKernelGGL(bn_pool_bwd_dx_kernel, dim3((unsigned)((total + bnt::NT - 1) / bnt::NT)), dim3(bnt::NT), 0, s, gy, p,
-                     code, x, mean, work, dx, total, C, H, W, Hp, Wp);
+  const long long rows = (long long)N * C * H;
+  const bool v4 = W % 4 == 0 && vec4(x, dx, nullptr, nullptr, 4);
+  int lpr_shift = 0;
+  while ((1 << lpr_shift) < (v4 ? W / 4 : W) && lpr_shift < 6) ++lpr_shift;
+  const long long rows_per_block = (long long)(bnt::NT / 64) * (64 >> lpr_shift);
+  const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
+  if (v4)
+    hipLaunchKernelGGL(bn_pool_bwd_dx_kernel<4>, grid, dim3(bnt::NT), 0, s, gy, p, code, x, mean, work, dx, rows, C, H, W, Hp,
+                       Wp, lpr_shift);
+  else
+    hipLaunchKernelGGL(bn_pool_bwd_dx_kernel<1>, grid, dim3(bnt::NT), 0, s, gy, p, code, x, mean, work, dx, rows, C, H, W, Hp,
+                       Wp, lpr_shift);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
