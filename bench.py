@@ -178,6 +178,7 @@ def conv_c2_roofline(device, info, batch=256, iters=50, act_kind="relu", nonneg=
     for _ in range(ARGS.roofline_spinup):
         hipops.bconv2d(act, pw, stride=1, padding=1)
     t_conv = _event_time(lambda: hipops.bconv2d(act, pw, stride=1, padding=1), iters, device)
+    clock_mhz = hipops.probe_clock(device)      # the engine clock those launches ran at (the peak is quoted at nominal)
     t_pack = _event_time(lambda: hipops.pack_act(x), iters, device)        # HBM-bound
 
     for _ in range(min(200, ARGS.roofline_spinup)):
@@ -200,6 +201,7 @@ def conv_c2_roofline(device, info, batch=256, iters=50, act_kind="relu", nonneg=
         "frac": lane_ops / t_conv / peak, "traffic": traffic, "traffic_note": traffic_note,
         "algorithmic_bytes": in_bytes + out_bytes + O * K // 8,
         "avg_kernel_us": t_conv * 1e6, "images_per_s_kernel": N / t_conv, "timed_launches": iters,
+        "engine_clock_mhz": round(clock_mhz),
         "spinup_launches": ARGS.roofline_spinup,
         "fp32_in_fp32_out": {"us": t_both * 1e6, "images_per_s": N / t_both,
                              "frac": lane_ops / t_both / peak, "kernel": "bconv_fly_kernel<3,3,4>",

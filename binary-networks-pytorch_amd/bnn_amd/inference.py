@@ -760,6 +760,8 @@ class TwoHalves:
                 self.engines.append(FusedResNet(model, throughput_mode=True))
         for st in self.streams:
             cur.wait_stream(st)
+        self._lock = threading.Lock()       # one call at a time enqueues its two halves (callers on different streams)
+        self._done: Optional[torch.cuda.Event] = None   # the previous call has read both halves' output buffers
 
     @staticmethod
     def wanted(n: int) -> bool:
@@ -776,13 +778,19 @@ class TwoHalves:
         cur = torch.cuda.current_stream(dev)
         h = (x.shape[0] + 1) // 2
         ys = []
-        for eng, st, part in zip(self.engines, self.streams, (x[:h], x[h:])):
-            st.wait_stream(cur)                      # the caller's tensor is ready on the caller's stream
-            with torch.cuda.stream(st):
-                ys.append(eng.forward_fresh(part, clone=False))
-        for st in self.streams:
-            cur.wait_stream(st)                      # (also orders the caller's later reuse of x behind both halves)
-        return torch.cat(ys, 0)
+        with self._lock:
+            for eng, st, part in zip(self.engines, self.streams, (x[:h], x[h:])):
+                st.wait_stream(cur)                  # the caller's tensor is ready on the caller's stream
+                if self._done is not None:           # a caller on ANOTHER stream may still be reading the halves' static
+                    st.wait_event(self._done)        # output buffers (its torch.cat): overwrite them only behind it
+                with torch.cuda.stream(st):
+                    ys.append(eng.forward_fresh(part, clone=False))
+            for st in self.streams:
+                cur.wait_stream(st)                  # (also orders the caller's later reuse of x behind both halves)
+            out = torch.cat(ys, 0)
+            self._done = torch.cuda.Event()
+            self._done.record(cur)
+        return out
 
 
 _NO_MODEL_FUSION = 0

@@ -44,7 +44,7 @@ spmc d GRBM_GUI_ACTIVE
 spmc e FETCH_SIZE
 spmc f WRITE_SIZE
 # training path: gradient kernels per layer (library backward beside them) and the whole step
-{ timeout 250 python "$R/tools/bench_grad.py" 2>&1 | tail -8; timeout 250 env BATCH=256 python "$R/tools/bench_train.py" 2>&1 | tail -1;
+{ timeout 250 python "$R/tools/bench_grad.py" 2>&1 | tail -8; timeout 250 env BATCH=256 python "$R/tools/bench_train.py" 2>&1 | tail -2;
   timeout 250 python "$R/tools/bench_train.py" 2>&1 | tail -1; } > "$OUT/train.txt" 2>&1
 # the two stem kernels side by side (bit-identity on ragged shapes, then timings)
 timeout 300 python "$R/tools/stem_ab.py" 2>&1 | tail -12 > "$OUT/stem_ab.txt"
