@@ -121,8 +121,8 @@ class PreBasicBlock(_Residual):
         self.stride = stride
 
     def _forward(self, x: torch.Tensor) -> torch.Tensor:
-        y = self.act1(self.conv1(self.bn1(x)))
-        y = self.act2(self.conv2(self.bn2(y)))
+        y = self.act1(self.conv1(_bn_act(x, self.bn1)))
+        y = self.act2(self.conv2(_bn_act(y, self.bn2)))
         y += self._shortcut(x)
         return y
 
@@ -218,9 +218,9 @@ class HBlock(_Residual):
         self.downsample = downsample
 
     def _forward(self, x: torch.Tensor) -> torch.Tensor:
-        o1 = self.conv1(self.act1(self.bn1(x)))
-        o2 = self.conv2(self.act2(self.bn2(o1)))
-        o3 = self.conv3(self.act3(self.bn3(o2)))
+        o1 = self.conv1(_bn_act(x, self.bn1, self.act1))
+        o2 = self.conv2(_bn_act(o1, self.bn2, self.act2))
+        o3 = self.conv3(_bn_act(o2, self.bn3, self.act3))
         y = torch.cat((o1, o2, o3), 1)
         y += self._shortcut(x)
         return y

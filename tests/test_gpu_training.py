@@ -453,6 +453,17 @@ def test_residual_blocks_train_with_the_fused_batchnorm_and_match_the_unfused_st
                 net = net.to(DEV).train()
                 x = dev(gen.activation("relu", 5, (4, 64, 28, 28))).requires_grad_(True)
                 loss = (net(x) * dev(gen.normal(6, (4, 128, 14, 14)))).sum()
+            elif what in ("pre", "h"):
+                from bnn_amd.models import HBlock, PreBasicBlock
+                cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
+                                  weight_pre_process=XNORWeightBinarizer)
+                blk = PreBasicBlock(64, 64, activation=nn.PReLU) if what == "pre" else HBlock(64, 64)
+                net = bnn.prepare_binary_model(blk, cfg)
+                shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+                net.load_state_dict({k: torch.from_numpy(v) for k, v in gen.model_state(shapes, 3).items()})
+                net = net.to(DEV).train()
+                x = dev(gen.normal(5, (4, 64, 14, 14))).requires_grad_(True)
+                loss = (net(x) * dev(gen.normal(6, (4, 64, 14, 14)))).sum()
             else:
                 net = _r18_train()
                 x = dev(gen.normal(91, (8, 3, 64, 64))).requires_grad_(True)
@@ -462,7 +473,7 @@ def test_residual_blocks_train_with_the_fused_batchnorm_and_match_the_unfused_st
                     [b.clone() for n, b in net.named_buffers() if "running" in n])
         finally:
             training.FUSED_BN = True
-    for what in ("block", "r18"):
+    for what in ("block", "pre", "h", "r18"):
         l1, gx1, gp1, rb1 = step(True, what)
         l0, gx0, gp0, rb0 = step(False, what)
         assert abs(l1 - l0) <= 1e-4 * abs(l0), what
