@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Binary ResNet-18 inference with the recipe of the reference's examples/cifar10.py:61-71 (XNOR weights, sign
-activations, first and last layer real-valued) on one MI355X, three ways:
+activations, first and last layer real-valued) on one MI355X:
 
-  1. drop-in      model(x)                     every binary layer = pack -> XNOR/popcount conv -> fp32
-  2. fused        FusedResNet(model)(x)        BN / ReLU / residual / re-pack in the conv epilogue
-  3. pipelined    PipelinedInference(...)      HIP-graph replay, two batches in flight
+  1. drop-in      model(x)                     the reference's own call: the fused executor by itself (AutoFusion: stem
+                                               launch on the caller's tensor + HIP graph of the rest, two halves in flight)
+  2. per layer    per_layer_forward()          every binary layer = one launch, torch BatchNorm / ReLU / add
+  3. fused        FusedResNet(model)(x)        the executor, explicitly, eager launches
+  4. pipelined    PipelinedInference(...)      HIP-graph replay, two batches in flight
 
     python examples/infer_resnet18.py [--batch 256] [--checkpoint model.bnnpack]
 """
@@ -20,7 +22,7 @@ import torch  # noqa: E402
 
 import bnn_amd as bnn  # noqa: E402
 from bnn_amd import checkpoint  # noqa: E402
-from bnn_amd.inference import FusedResNet, PipelinedInference  # noqa: E402
+from bnn_amd.inference import FusedResNet, PipelinedInference, per_layer_forward  # noqa: E402
 from bnn_amd.models import resnet18  # noqa: E402
 from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer  # noqa: E402
 
@@ -62,9 +64,13 @@ def main():
         return args.batch * n / (time.perf_counter() - t0)
 
     with torch.no_grad():
-        y_ref = model(x)
-        print("drop-in    %9.0f images/s" % rate(lambda: model(x), 5))
+        with per_layer_forward():
+            y_ref = model(x)
+            print("per layer  %9.0f images/s" % rate(lambda: model(x), 5))
+        print("drop-in    %9.0f images/s   (model(x), a new tensor every call)" % rate(
+            lambda: model(torch.empty_like(x).copy_(x)), 20))
         fused = FusedResNet(model)
+        assert torch.equal(model(x), fused(x))       # the call and the explicit executor: same bits
         # folded BatchNorm (one fma) and torch's BatchNorm round differently; an activation that lands within an
         # ulp of 0 can therefore binarise differently and move that image's logits — a handful per thousand
         close = ((fused(x) - y_ref).abs().amax(dim=1) <= 1e-3 * y_ref.abs().max()).float().mean().item()

@@ -169,7 +169,7 @@ def test_ddp_training_step_over_rccl_world1(rccl_world1):
         assert fastpath.stats()["conv2d_train"] == before + 19
         grads = [p.grad.clone() for p in params]
         opt.step()
-        return float(loss), grads
+        return float(loss.detach()), grads
 
     ref = _r18().train()
     ddp_net = _r18().train()

@@ -375,7 +375,7 @@ def test_training_forward_keeps_three_bits_per_element_for_the_backward():
             loss.backward()
         finally:
             training.PACKED_STATE = False
-        return kept, [p.grad.clone() for p in net.parameters()], float(loss)
+        return kept, [p.grad.clone() for p in net.parameters()], float(loss.detach())
     k_fp32, g_fp32, l_fp32 = step(False)
     k_packed, g_packed, l_packed = step(True)
     assert abs(l_packed - l_fp32) <= 1e-6 * abs(l_fp32)
