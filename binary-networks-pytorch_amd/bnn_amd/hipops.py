@@ -684,6 +684,36 @@ def bconv_grad_weight(g: torch.Tensor, x, ksize: int = 3, stride: int = 1) -> to
         return part[0] if splits == 1 else part.sum(0)
 
 
+def xnor_what(w: torch.Tensor, center: bool, compute_alpha: bool) -> torch.Tensor:
+    """``XNORWeightBinarizer.forward`` value (bnn/ops.py:129-140) in one kernel: ``sign(Wc) * alpha`` as an fp32 tensor
+    (no autograd graph).  Same centring / alpha reductions as ``pack_weight``."""
+    w = _require_cuda_f32(w.detach(), "weight")
+    lib = native.require()
+    O, C = w.shape[0], w.shape[1]
+    kh, kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
+    with torch.cuda.device(w.device):
+        what = torch.empty_like(w)
+        native.check(lib.bnn_hip_xnor_weight_forward_f32(w.data_ptr(), O, C, kh, kw, int(center), int(compute_alpha),
+                                                         what.data_ptr(), None, _stream(w.device)),
+                     "bnn_hip_xnor_weight_forward_f32")
+    return what
+
+
+def xnor_weight_backward(w: torch.Tensor, dwhat: torch.Tensor, center: bool, compute_alpha: bool) -> torch.Tensor:
+    """dL/dW from dL/dWhat through ``XNORWeightBinarizer`` (sign STE, alpha = mean|Wc|, centring) in one kernel."""
+    w = _require_cuda_f32(w.detach(), "weight")
+    dwhat = _require_cuda_f32(dwhat, "weight gradient")
+    lib = native.require()
+    O, C = w.shape[0], w.shape[1]
+    kh, kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
+    with torch.cuda.device(w.device):
+        dw = torch.empty_like(w)
+        native.check(lib.bnn_hip_xnor_weight_backward_f32(w.data_ptr(), dwhat.data_ptr(), O, C, kh, kw, int(center),
+                                                          int(compute_alpha), dw.data_ptr(), _stream(w.device)),
+                     "bnn_hip_xnor_weight_backward_f32")
+    return dw
+
+
 def bn_train_forward(x: torch.Tensor, gamma, beta, running_mean, running_var, momentum: float, eps: float,
                      relu: bool = False, residual: Optional[torch.Tensor] = None):
     """``relu?(batch_norm(x, training=True) (+ residual))`` in three launches (csrc/bn_train.hip).  Updates the running

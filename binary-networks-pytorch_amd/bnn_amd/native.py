@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_probe_clock", "bnn_hip_pack_act_ste_f32", "bnn_hip_bconv_grad_input_packed_f32",
     "bnn_hip_bconv_grad_weight_packed_f32", "bnn_hip_bn_train_workspace_bytes", "bnn_hip_bn_train_forward_f32",
     "bnn_hip_bn_train_backward_f32", "bnn_hip_bn_relu_maxpool_train_forward_f32",
-    "bnn_hip_bn_relu_maxpool_train_backward_f32",
+    "bnn_hip_bn_relu_maxpool_train_backward_f32", "bnn_hip_xnor_weight_forward_f32", "bnn_hip_xnor_weight_backward_f32",
 )
 
 
@@ -161,6 +161,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_bn_train_backward_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bnn_hip_bn_relu_maxpool_train_forward_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _f, _f] + [_vp] * 8
     lib.bnn_hip_bn_relu_maxpool_train_backward_f32.argtypes = [_vp] * 7 + [_i, _i, _i, _i] + [_vp] * 5
+    lib.bnn_hip_xnor_weight_forward_f32.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]
+    lib.bnn_hip_xnor_weight_backward_f32.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]
     lib.bnn_hip_probe_int_alu.argtypes = [_i, _i, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), _vp]
     lib.bnn_hip_probe_clock.argtypes = [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _vp]

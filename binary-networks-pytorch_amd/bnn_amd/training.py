@@ -198,8 +198,74 @@ def stem_tail(x: torch.Tensor, bn: nn.Module, act: nn.Module, pool: nn.Module) -
     return pool(bn_act(x, bn, act))
 
 
+# The weight hook of a training step as two kernels instead of torch's ~14 per layer (csrc/xnor_train.hip): the forward
+# needs no fp32 What at all (the conv reads the packed weights), the backward derives What for the input-gradient
+# kernel and maps dL/dWhat to dL/dW (sign STE, alpha = mean|Wc|, centring) in one kernel each.
+FUSED_WEIGHT_HOOK = os.environ.get("BNN_AMD_TRAIN_FUSED_WEIGHT_HOOK", "1") == "1"
+
+
+class BinaryConv2dTrainFusedFn(torch.autograd.Function):
+    """``BinaryConv2dTrainFn`` with the XNORWeightBinarizer inside: inputs are x and the LATENT weight W."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, layer, plan, packed):
+        out = hipops.bconv2d_direct(x, packed, bias, None, layer.stride, layer.padding, layer.dilation)   # one launch
+        stride, padding, dilation = tuple(layer.stride), tuple(layer.padding), tuple(layer.dilation)
+        ctx.x_shape = None
+        if PACKED_STATE and BINARY_GRADS and hipops.grad_supported(x.shape, w.shape, stride, padding, dilation):
+            sv = hipops.pack_act_ste(x)
+            ctx.save_for_backward(sv.sign.P, sv.sign.M, sv.T, w)
+            ctx.x_shape = tuple(x.shape)
+            kept = sv.nbytes()
+        else:
+            ctx.save_for_backward(x, w)
+            kept = x.numel() * x.element_size()
+        global _saved_bytes
+        _saved_bytes += kept
+        ctx.conf = (stride, padding, dilation, bias is not None, None if bias is None else tuple(bias.shape),
+                    bool(plan.center), bool(plan.compute_alpha))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        stride, padding, dilation, has_bias, bias_shape, center, compute_alpha = ctx.conf
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
+        if ctx.x_shape is not None:
+            P, M, T, w = ctx.saved_tensors
+            x = hipops.SavedAct(hipops.PackedAct(P, M, ctx.x_shape), T, ctx.x_shape)
+        else:
+            x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gwhat = gb = None
+        if ctx.x_shape is not None or (
+                BINARY_GRADS and hipops.grad_supported(x.shape, w.shape, stride, padding, dilation)):
+            if need_x:
+                packed, alpha = hipops.grad_pack_weight(hipops.xnor_what(w, center, compute_alpha))
+                gx = hipops.bconv_grad_input(g, x, packed, alpha, w.shape[2], stride[0])       # STE mask fused
+            if need_w:
+                gwhat = hipops.bconv_grad_weight(g, x, w.shape[2], stride[0])
+            if need_b:
+                gb = g.sum(dim=(0, 2, 3))
+        else:
+            w_hat = hipops.xnor_what(w, center, compute_alpha)
+            gx, gwhat, gb = torch.ops.aten.convolution_backward(
+                g, torch.sign(x), w_hat, list(bias_shape) if has_bias else None, list(stride), list(padding),
+                list(dilation), False, [0, 0], 1, [bool(need_x), bool(need_w), bool(need_b)])
+            if need_x:
+                gx = gx.masked_fill(x.abs() >= 1, 0)   # hard-tanh STE (bnn/ops.py:68-73)
+        gw = hipops.xnor_weight_backward(w, gwhat, center, compute_alpha) if need_w else None
+        return (gx if need_x else None, gw, gb if need_b else None, None, None, None)
+
+
 def conv2d_train(layer: nn.Module, x: torch.Tensor, plan, packed) -> torch.Tensor:
     """``bnn.layers.Conv2d.forward`` with autograd recording: HIP forward, library backward."""
+    w = layer.weight
+    if (FUSED_WEIGHT_HOOK and w.dim() == 4 and w.is_contiguous() and w.shape[2] * w.shape[3] <= 1024
+            and not layer.weight_pre_process._forward_hooks and not layer.weight_pre_process._forward_pre_hooks):
+        out = BinaryConv2dTrainFusedFn.apply(x, w, layer.bias, layer, plan, packed)
+        if plan.scale is not None:                          # BasicScaleBinarizer (bnn/ops.py:200-202)
+            out = out * plan.scale
+        return out
     w_hat = layer.weight_pre_process(layer.weight)          # autograd edge to W (sign STE, alpha)
     out = BinaryConv2dTrainFn.apply(x, w_hat, layer.bias, layer, plan, packed)
     if plan.scale is not None:                              # BasicScaleBinarizer (bnn/ops.py:200-202)

@@ -152,6 +152,11 @@ int launch_bconv(const ConvP& p, int flags, hipStream_t s);
 bool fly_supported(const ConvP& p);
 int fly_default_plan(const ConvP& p, int flags, bnn_hip_fly_plan* plan);
 int launch_bconv_fly(const ConvP& p, const void* x, int x_half, int flags, const bnn_hip_fly_plan* plan, hipStream_t s);
+// xnor_train.hip: XNORWeightBinarizer under autograd, value and backward
+int launch_xnor_what(const float* w, int O, int C, int taps, int center, int compute_alpha, float* what, float* alpha,
+                     hipStream_t s);
+int launch_xnor_weight_bwd(const float* w, const float* dwhat, int O, int C, int taps, int center, int compute_alpha,
+                           float* dw, hipStream_t s);
 // bn_train.hip: training-mode BatchNorm (+ residual) (+ ReLU), forward and backward
 int bn_train_splits(int N, int C, int HW);
 int launch_bn_stats(const float* x, int N, int C, int HW, int splits, double* partial, hipStream_t s);

@@ -571,6 +571,30 @@ int bnn_hip_probe_int_alu(int mode, int iters, double* lane_ops_per_s, double* e
                                    static_cast<hipStream_t>(stream));
 }
 
+// ---- XNORWeightBinarizer under autograd: csrc/xnor_train.hip
+int bnn_hip_xnor_weight_forward_f32(const float* w, int O, int C, int KH, int KW, int center, int compute_alpha,
+                                    float* what, float* alpha, void* stream) {
+  if (!w || !what || O <= 0 || C <= 0 || KH <= 0 || KW <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (mulc(KH, KW) > 1024) return BNN_HIP_ERR_UNSUPPORTED;
+  if (mulc(O, C, KH, KW) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (!aligned(w, 4) || !aligned(what, 4)) return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_xnor_what(w, O, C, KH * KW, center != 0, compute_alpha != 0, what, alpha, static_cast<hipStream_t>(stream));
+}
+
+int bnn_hip_xnor_weight_backward_f32(const float* w, const float* dwhat, int O, int C, int KH, int KW, int center,
+                                     int compute_alpha, float* dw, void* stream) {
+  if (!w || !dwhat || !dw || O <= 0 || C <= 0 || KH <= 0 || KW <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (mulc(KH, KW) > 1024) return BNN_HIP_ERR_UNSUPPORTED;
+  if (mulc(O, C, KH, KW) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (!aligned(w, 4) || !aligned(dwhat, 4) || !aligned(dw, 4)) return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_xnor_weight_bwd(w, dwhat, O, C, KH * KW, center != 0, compute_alpha != 0, dw,
+                                     static_cast<hipStream_t>(stream));
+}
+
 // ---- training-mode BatchNorm (+ residual) (+ ReLU): csrc/bn_train.hip
 static int check_bn(int N, int C, int HW) {
   if (N <= 0 || C <= 0 || HW <= 0) return BNN_HIP_ERR_INVALID_ARG;

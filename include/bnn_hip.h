@@ -419,6 +419,17 @@ int bnn_hip_bconv2d_f32(const bnn_hip_conv_desc* d, const float* x,
                         const float* alpha, const float* bias, const float* post_scale,
                         float* out, void* workspace, void* stream);
 
+/* XNORWeightBinarizer.forward under autograd (bnn/ops.py:129-140 with the STE of bnn/ops.py:68-73), value and backward
+ * as one kernel each (torch: ~14 small kernels per layer and step).  w, what, dwhat, dw: fp32 [O, C, KH, KW].
+ *   forward :  what = sign(Wc) * alpha[o],  Wc = w - mean over C (center),  alpha = mean |Wc| (compute_alpha) or 1;
+ *              alpha (may be NULL) receives alpha[O] — the same reductions as bnn_hip_pack_weight_f32.
+ *   backward:  dw from dwhat = dL/dwhat:  dWc = dwhat * alpha * 1[|Wc| < 1] + sign(Wc) * sum(dwhat * sign(Wc)) / (C KH KW),
+ *              dw = dWc - mean over C of dWc when centred.                                                            */
+int bnn_hip_xnor_weight_forward_f32(const float* w, int O, int C, int KH, int KW, int center, int compute_alpha,
+                                    float* what, float* alpha, void* stream);
+int bnn_hip_xnor_weight_backward_f32(const float* w, const float* dwhat, int O, int C, int KH, int KW, int center,
+                                     int compute_alpha, float* dw, void* stream);
+
 /* Training-mode BatchNorm2d fused with what follows it in the reference's residual blocks:
  *     y = relu?( batch_norm_train(x) (+ residual) )          bnn/models/layers/res_block.py:40-56, resnet.py:150-153
  * x, y, residual: fp32 [N, C, HW] (NCHW with HW = H * W).  forward: per-channel batch statistics (fp64 accumulation,

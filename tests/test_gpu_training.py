@@ -518,3 +518,45 @@ def test_fused_stem_tail_matches_batchnorm_relu_maxpool_of_the_library(shape):
                             ("dbeta", got[3], want[3], 3e-4), ("running_mean", got[4], want[4], 1e-5),
                             ("running_var", got[5], want[5], 1e-5)):
         assert torch.allclose(a, b, rtol=tol, atol=tol * float(b.abs().max()) + 1e-7), (name, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("center,compute_alpha", [(False, True), (True, True), (False, False), (True, False)],
+                         ids=["xnor", "xnor_centered", "sign_only", "sign_centered"])
+@pytest.mark.parametrize("shape", [(64, 64, 3, 3), (40, 70, 3, 3), (128, 96, 1, 1), (8, 200, 5, 5), (512, 512, 3, 3)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_fused_weight_hook_matches_the_binarizer_under_autograd(shape, center, compute_alpha):
+    """csrc/xnor_train.hip against XNORWeightBinarizer evaluated by torch autograd (bnn/ops.py:129-140 with the STE of
+    bnn/ops.py:68-73): What and dL/dW from an arbitrary dL/dWhat, incl. weights outside (-1, 1), exact zeros, centring."""
+    from bnn_amd import hipops
+    wn = gen.normal(gen.seed_of("wh", shape), shape).astype(np.float32) * 0.8
+    wn.reshape(-1)[::9] = 0.0
+    wn.reshape(-1)[4::13] *= 2.5          # |w| >= 1: the STE blocks these
+    w = dev(wn).requires_grad_(True)
+    g = dev(gen.normal(gen.seed_of("wg", shape), shape))
+    hook = XNORWeightBinarizer(compute_alpha=compute_alpha, center_weights=center)
+    want = hook(w)
+    want.backward(g)
+    what = hipops.xnor_what(w, center, compute_alpha)
+    assert torch.allclose(what, want.detach(), rtol=1e-6, atol=1e-7)
+    dw = hipops.xnor_weight_backward(w, g, center, compute_alpha)
+    assert torch.allclose(dw, w.grad, rtol=1e-4, atol=1e-5 * float(w.grad.abs().max())), float((dw - w.grad).abs().max())
+
+
+def test_training_step_with_and_without_the_fused_weight_hook():
+    net_x = dev(gen.normal(91, (8, 3, 64, 64)))
+    t = torch.arange(8, device=DEV) * 7
+
+    def step(fused):
+        training.FUSED_WEIGHT_HOOK = fused
+        try:
+            net = _r18_train()
+            loss = torch.nn.functional.cross_entropy(net(net_x), t)
+            loss.backward()
+            return float(loss.detach()), [p.grad for p in net.parameters()]
+        finally:
+            training.FUSED_WEIGHT_HOOK = True
+    l1, g1 = step(True)
+    l0, g0 = step(False)
+    assert l1 == l0                                         # the forward does not depend on the hook's form
+    for a, b in zip(g1, g0):
+        assert float((a - b).norm()) <= 1e-3 * float(b.norm()) + 1e-12

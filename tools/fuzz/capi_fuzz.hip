@@ -151,6 +151,14 @@ int launch_sign_thresholds(const float* alpha, const float*, const float*, const
   ++g_reached; REQUIRE(alpha && thr && O > 0 && kmax > 0 && kmax < (1 << 24) && (a == nullptr) == (b == nullptr) && al(thr, 4));
   return BNN_HIP_OK;
 }
+int launch_xnor_what(const float* w, int O, int C, int taps, int, int, float* what, float*, hipStream_t) {
+  ++g_reached; REQUIRE(w && what && O > 0 && C > 0 && taps > 0 && taps <= 1024 && (long long)O * C * taps <= (1LL << 31) - 1);
+  return BNN_HIP_OK;
+}
+int launch_xnor_weight_bwd(const float* w, const float* g, int O, int C, int taps, int, int, float* dw, hipStream_t) {
+  ++g_reached; REQUIRE(w && g && dw && O > 0 && C > 0 && taps > 0 && taps <= 1024 && (long long)O * C * taps <= (1LL << 31) - 1);
+  return BNN_HIP_OK;
+}
 int bn_train_splits(int N, int C, int) { int s = (1024 + C - 1) / C; s = s > 64 ? 64 : s; s = s > N ? N : s; return s < 1 ? 1 : s; }
 static void check_bn_args(int N, int C, int HW) {
   REQUIRE(N > 0 && C > 0 && HW > 0 && (long long)N * C * HW <= 4 * ((1LL << 31) - 1));
@@ -226,7 +234,7 @@ int main(int argc, char** argv) {
   for (long it = 0; it < iters; ++it) {
     ++g_calls;
     int st = 0;
-    switch (rnd() % 27) {
+    switch (rnd() % 29) {
       case 0: { bnn_hip_conv_desc d = pick_desc();
         st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
                              pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
@@ -318,6 +326,10 @@ int main(int argc, char** argv) {
                                                                pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(),
                                                                pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(),
                                                                pick_ptr<double>(), stream); break;
+      case 26: st = bnn_hip_xnor_weight_forward_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(),
+                                                    pick_int(), pick_ptr<float>(), pick_ptr<float>(), stream); break;
+      case 27: st = bnn_hip_xnor_weight_backward_f32(pick_ptr<float>(), pick_ptr<float>(), pick_int(), pick_int(), pick_int(),
+                                                     pick_int(), pick_int(), pick_int(), pick_ptr<float>(), stream); break;
       default: { bnn_hip_conv_desc d = pick_desc();
         (void)bnn_hip_shortcut_fold_supported(rnd() % 16 ? &d : nullptr, pick_int());
         st = bnn_hip_blinear(pick_int(), pick_int(), pick_int(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
