@@ -61,6 +61,11 @@
 extern "C" {
 #endif
 
+/* ABI 12 (round 4): + bnn_hip_probe_clock; + the training-side entry points bnn_hip_pack_act_ste_f32,
+ * bnn_hip_bconv_grad_{input,weight}_packed_f32 (3-bit saved state), bnn_hip_bn_train_{workspace_bytes,forward,backward}_f32,
+ * bnn_hip_bn_relu_maxpool_train_{forward,backward}_f32, bnn_hip_xnor_weight_{forward,backward}_f32;
+ * - BNN_HIP_STEM_STAGED and BNN_HIP_FLAG_WEIGHTS_LDS (those kernels are test-only now: csrc/legacy/);
+ * stem tensors capped at the 32-bit buffer-descriptor range; size arithmetic of all validators saturating.          */
 #define BNN_HIP_ABI_VERSION 12
 #define BNN_HIP_OCB 32 /* output channels per weight block (padding granularity of O) */
 
