@@ -71,6 +71,8 @@ class ShardedInference(nn.Module):
         # issue the all-gather even in a one-rank group (tests: the RCCL call, its stream ordering and its
         # behaviour next to graph replays are then exercised on a single GPU)
         self.force_collective = force_collective
+        self._pending = None      # forward_even(overlap=True): the previous step's collective (torch.distributed Work)
+        self._out = None
 
     @torch.no_grad()
     def forward(self, x_local: torch.Tensor) -> torch.Tensor:
@@ -91,10 +93,32 @@ class ShardedInference(nn.Module):
         return torch.cat([out[r * n_max: r * n_max + sizes[r]] for r in range(world)], 0)
 
     @torch.no_grad()
-    def forward_even(self, x_local: torch.Tensor) -> torch.Tensor:
-        """Fast path when every rank holds the same number of images: exactly one collective."""
+    def forward_even(self, x_local: torch.Tensor, overlap: bool = False) -> torch.Tensor:
+        """Fast path when every rank holds the same number of images: exactly one collective.
+
+        ``overlap=True`` (throughput loops: ``bench.py``): the all-gather is issued asynchronously — RCCL runs it on
+        its own stream behind the kernels that produced the logits, and the calling stream goes straight on to its next
+        batch instead of idling through a latency-bound 1 MB-per-rank collective.  The returned tensor is valid after
+        ``wait()`` (or a device synchronisation); the NEXT ``forward_even`` of this object waits for the collective
+        before the model may overwrite the buffers it reads."""
+        if overlap and self._pending is not None:
+            self._pending.wait()
+            self._pending = None
         y = self.model(x_local).contiguous()
         if not (dist.is_available() and dist.is_initialized()) or \
                 (dist.get_world_size(self.group) == 1 and not self.force_collective):
             return y
-        return all_gather_rows(y, self.group)
+        if not overlap or (y.is_cuda and _host_staged(self.group)):
+            return all_gather_rows(y, self.group)
+        world = dist.get_world_size(self.group)
+        shape = (world * y.shape[0],) + tuple(y.shape[1:])
+        if self._out is None or tuple(self._out.shape) != shape or self._out.device != y.device:
+            self._out = y.new_empty(shape)
+        self._pending = dist.all_gather_into_tensor(self._out, y, group=self.group, async_op=True)
+        return self._out
+
+    def wait(self) -> None:
+        """Make the current stream wait for the collective of the last ``forward_even(overlap=True)``."""
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None

@@ -76,6 +76,21 @@ def test_pipelined_sharded_inference_over_rccl_world1(rccl_world1):
     pipe.synchronize()
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+    # the overlapped form bench.py uses: the gather is asynchronous, the slot's next launch waits for it
+    models = [ShardedInference(e, force_collective=True) for e in pipe.engines]
+    outs = []
+    for rep in range(3):
+        for i, x in enumerate(xs):
+            k = i % 2
+            with torch.cuda.stream(pipe.stream(i)):
+                pipe.input(i).copy_(x)
+                out = models[k].forward_even(pipe.engines[k].static_input, overlap=True)
+                if rep == 2 and i >= 2:            # the last launch of each slot: read after wait()
+                    models[k].wait()
+                    outs.append((i, out.clone()))
+    pipe.synchronize()
+    for i, o in outs:
+        assert torch.equal(o, want[i])
     # the ragged path (sizes exchanged first) through RCCL as well
     y = ShardedInference(single, force_collective=True)(xs[0][:5].contiguous())
     assert torch.equal(y, single(xs[0][:5].contiguous()))
