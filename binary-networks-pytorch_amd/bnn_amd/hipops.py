@@ -514,12 +514,20 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
         residual = _require_cuda_f32(residual, "residual")
         if tuple(residual.shape) != (d.N, c_total, ho, wo):
             raise native.NativeError(f"bnn_amd: residual shape {tuple(residual.shape)} != output")
+    sc_in_hw = 0
     if shortcut is not None:
         sa, sw, sbn_a, sbn_b = shortcut
-        if residual is not None or not sa.nonneg or tuple(sa.shape) != (d.N, sw.shape[1], ho, wo) \
+        # the shortcut planes at the output resolution, or UN-POOLED at twice it (the kernel ORs the 2 x 2 windows)
+        pooled = tuple(sa.shape) == (d.N, sw.shape[1], ho, wo)
+        unpooled = (sa.shape[0] == d.N and sa.shape[1] == sw.shape[1] and (sa.shape[2] + 1) // 2 == ho
+                    and (sa.shape[3] + 1) // 2 == wo and max(sa.shape[2], sa.shape[3]) < 65536)
+        if residual is not None or not sa.nonneg or not (pooled or unpooled) \
                 or tuple(sw.shape) != (d.O, sa.shape[1], 1, 1) or sw.has_zero:
-            raise native.NativeError("bnn_amd: folded shortcut: a non-negative packed [N, C, Ho, Wo] input, a 1x1 "
-                                     "[O, C, 1, 1] weight without zeros, and no separate residual")
+            raise native.NativeError("bnn_amd: folded shortcut: a non-negative packed [N, C, Ho, Wo] (or un-pooled "
+                                     "[N, C, ~2 Ho, ~2 Wo]) input, a 1x1 [O, C, 1, 1] weight without zeros, and no "
+                                     "separate residual")
+        if not pooled:
+            sc_in_hw = (sa.shape[2] << 16) | sa.shape[3]
         sbn_a = _per_channel(sbn_a, d.O, "shortcut bn_scale")
         sbn_b = _per_channel(sbn_b, d.O, "shortcut bn_shift")
     eflags = (native.EPI_RES_AFTER_ACT if residual_after_act else 0) | \
@@ -543,7 +551,7 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
                                 out_c_offset if out is not None else 0, c_total if out is not None else 0,
                                 _ptr(sign_thresholds),
                                 *((sa.P[n0:n1].data_ptr(), sw.wbits.data_ptr(), sw.alpha.data_ptr(), sbn_a.data_ptr(),
-                                   sbn_b.data_ptr(), sa.shape[1], 0) if shortcut is not None else ()))
+                                   sbn_b.data_ptr(), sa.shape[1], sc_in_hw) if shortcut is not None else ()))
             native.check(lib.bnn_hip_bconv2d_fused(ctypes.byref(dd), a.P[n0:n1].data_ptr(), a.M[n0:n1].data_ptr(),
                                                    w.wbits.data_ptr(), w.wnz.data_ptr(),
                                                    ctypes.byref(e), _stream(dev)),

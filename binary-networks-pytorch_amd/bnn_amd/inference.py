@@ -373,9 +373,10 @@ class FusedResNet(nn.Module):
             if b["ds"] is not None and self._fold_applies(b, packed):
                 # the shortcut conv (1x1 over the OR-pooled sign planes) is computed inside the block's last conv: no
                 # fp32 shortcut tensor, no 1x1 launch (bnn_hip_epilogue.sc_*)
-                sc_in = hipops.orpool_packed(packed, b["pool"]) if b["pool"] > 1 else packed
+                # (pool 2: the kernel ORs the 2 x 2 windows of the block's input planes itself — no OR-pool launch)
+                sc_in = packed if b["pool"] in (0, 1, 2) else hipops.orpool_packed(packed, b["pool"])
                 if _TAP is not None:
-                    _TAP(b["ds"].name, sc_in)
+                    _TAP(b["ds"].name, hipops.orpool_packed(packed, b["pool"]) if b["pool"] > 1 else packed)
                 fold = (sc_in, b["ds"].weight, b["ds"].bn_scale, b["ds"].bn_shift)
                 idn = None
             elif b["ds"] is not None:

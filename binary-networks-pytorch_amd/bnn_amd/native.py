@@ -89,7 +89,7 @@ class Epilogue(ctypes.Structure):
                 # ABI 11: the block's shortcut convolution folded into this one (include/bnn_hip.h)
                 ("sc_P", ctypes.c_void_p), ("sc_wbits", ctypes.c_void_p), ("sc_alpha", ctypes.c_void_p),
                 ("sc_bn_scale", ctypes.c_void_p), ("sc_bn_shift", ctypes.c_void_p),
-                ("sc_C", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("sc_C", ctypes.c_int32), ("sc_in_hw", ctypes.c_int32)]
 
 
 EPI_RES_AFTER_ACT = 1

@@ -27,6 +27,8 @@ struct Geo {
   int s_hw, s_wo, s_tpx;
   unsigned in_bytes;  // bytes of one packed input plane tensor (P or M): the range of the field loads' descriptor
   int ds_cw;     // folded shortcut convolution (ShortcutArgs): 32-bit words per pixel of its input plane; 0 = none
+  int ds_h, ds_w;  // > 0: the shortcut plane is given UN-POOLED at ds_h x ds_w (= the block's input) and the kernel ORs
+                   // the 2 x 2 window of an output pixel itself (AvgPool2d(2, ceil) of non-negative values -> sign)
 };
 
 enum : int {
@@ -627,9 +629,34 @@ struct ShortcutArgs {
 
 // The lane's pixel of the shortcut planes (ds_cw <= 8 words; unused registers stay 0) and its non-zero count.
 __device__ __forceinline__ int load_shortcut_field(const Geo& g, const Pix& px, const ShortcutArgs& d, uint32_t (&dsr)[8]) {
+  int nz = 0;
+  if (g.ds_w > 0) {
+    // un-pooled plane: sign(AvgPool2d(2, ceil_mode, count_include_pad=False)(x)) of x >= 0 is the OR of the window's
+    // sign bits (what bnn_hip_orpool_packed writes) — four loads and three ORs per word here instead of a launch
+    const unsigned hw = (unsigned)(g.ds_h * g.ds_w);
+    const int y0 = 2 * px.oy, x0 = 2 * px.ox;
+    const bool x1 = x0 + 1 < g.ds_w, y1 = y0 + 1 < g.ds_h;
+    const unsigned base = (unsigned)px.n * (unsigned)(g.ds_cw >> 1) * hw + (unsigned)(y0 * g.ds_w + x0);
+    const uint2* P2 = reinterpret_cast<const uint2*>(d.P);
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      uint2 v{0u, 0u};
+      if (2 * gi < g.ds_cw) {
+        const unsigned b = base + (unsigned)gi * hw;
+        v = P2[b];
+        const uint2 a = P2[x1 ? b + 1 : b], c = P2[y1 ? b + (unsigned)g.ds_w : b],
+                    e = P2[(x1 && y1) ? b + (unsigned)g.ds_w + 1 : b];
+        v.x |= a.x | c.x | e.x;
+        v.y |= a.y | c.y | e.y;
+      }
+      dsr[2 * gi] = v.x;
+      dsr[2 * gi + 1] = v.y;
+      nz += __builtin_popcount(v.x) + __builtin_popcount(v.y);
+    }
+    return nz;
+  }
   const unsigned hw = (unsigned)(g.Ho * g.Wo);
   const unsigned base = (unsigned)px.n * (unsigned)(g.ds_cw >> 1) * hw + (unsigned)px.r;  // uint64 words
-  int nz = 0;
 #pragma unroll
   for (int gi = 0; gi < 4; ++gi) {
     uint2 v{0u, 0u};
@@ -908,6 +935,8 @@ inline Geo make_geo(const ConvP& p) {
   if (p.pack_a && p.pack_b) f |= EF_PACK_AFF;
   if (p.eflags & BNN_HIP_EPI_PACK_RELU) f |= EF_PACK_RELU;
   g.ds_cw = p.ds_P ? 2 * ((p.ds_C + 63) / 64) : 0;
+  g.ds_h = p.ds_P ? p.ds_inH : 0;
+  g.ds_w = p.ds_P ? p.ds_inW : 0;
   g.c_off = p.c_off;
   g.c_tot = p.c_tot > 0 ? p.c_tot : p.O;
   g.flags = f;

@@ -87,6 +87,8 @@ struct ConvP {
   const float* ds_a;
   const float* ds_b;
   int ds_C;
+  int ds_inH, ds_inW;  // 0: ds_P is at the output resolution; else ds_P is un-pooled [N, C/64, ds_inH, ds_inW] and the kernel
+                   // ORs the 2 x 2 window itself (ceil(ds_inH / 2) == Ho, ceil(ds_inW / 2) == Wo)
 };
 
 // Compute units of the current device (for grids of persistent workgroups).  Cached per device in atomics: a

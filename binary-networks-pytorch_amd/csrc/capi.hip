@@ -126,6 +126,8 @@ int run_conv(const bnn_hip_conv_desc* d, const uint64_t* P, const uint64_t* M, c
     if (!p.ds_W || !p.ds_alpha || !p.ds_a || !p.ds_b || p.res || p.ds_C <= 0) return BNN_HIP_ERR_INVALID_ARG;
     if (!aligned(p.ds_P, 8) || !aligned(p.ds_W, 16)) return BNN_HIP_ERR_INVALID_ARG;
     if (!bnn::ds_fold_applies(p, d->flags)) return BNN_HIP_ERR_UNSUPPORTED;
+    if (p.ds_inW > 0 && ((p.ds_inH + 1) / 2 != Ho || (p.ds_inW + 1) / 2 != Wo)) return BNN_HIP_ERR_INVALID_ARG;
+    if (p.ds_inW > 0 && mulc(d->N, ((long long)p.ds_C + 63) / 64, p.ds_inH, p.ds_inW) > kMaxPlaneWords) return BNN_HIP_ERR_TOO_LARGE;
   }
   g_launches.fetch_add(1, std::memory_order_relaxed);
   Range range(p.raw ? "bnn_hip_bconv2d_dot" : p.ds_P ? "bnn_hip_bconv2d_fused+shortcut"
@@ -430,6 +432,11 @@ int bnn_hip_bconv2d_fused(const bnn_hip_conv_desc* d, const uint64_t* P, const u
     p.ds_P = reinterpret_cast<const uint32_t*>(e->sc_P);
     p.ds_W = e->sc_wbits; p.ds_alpha = e->sc_alpha; p.ds_a = e->sc_bn_scale; p.ds_b = e->sc_bn_shift;
     p.ds_C = e->sc_C;
+    if (e->sc_in_hw != 0) {      // un-pooled shortcut plane: (H << 16) | W of it; the kernel ORs the 2 x 2 windows
+      p.ds_inH = (int)((uint32_t)e->sc_in_hw >> 16);
+      p.ds_inW = (int)((uint32_t)e->sc_in_hw & 0xFFFFu);
+      if (p.ds_inH <= 0 || p.ds_inW <= 0) return BNN_HIP_ERR_INVALID_ARG;
+    }
   }
   return run_conv(d, P, M, wbits, wnz, p, stream);
 }

@@ -160,14 +160,18 @@ typedef struct bnn_hip_epilogue {
    * input at the OUTPUT resolution, [N, ceil(sc_C/64), Ho, Wo] uint64, non-negative activations (its M plane is all
    * zero and not passed); sc_wbits / sc_alpha: bnn_hip_pack_weight_f32 of the [O, sc_C, 1, 1] weight.  Either all five
    * pointers or none (then sc_C is ignored); not together with `residual`.  Supported where
-   * bnn_hip_shortcut_fold_supported() says so; BNN_HIP_ERR_UNSUPPORTED otherwise.                                    */
+   * bnn_hip_shortcut_fold_supported() says so; BNN_HIP_ERR_UNSUPPORTED otherwise.
+   * ABI 12 — sc_in_hw != 0: sc_P is the UN-POOLED plane of the block's input, [N, ceil(sc_C/64), H, W] with
+   * sc_in_hw = (H << 16) | W, ceil(H/2) == Ho, ceil(W/2) == Wo: the kernel ORs the 2 x 2 window of every output pixel
+   * itself (sign of AvgPool2d(2, ceil_mode=True, count_include_pad=False) of non-negative values) — no
+   * bnn_hip_orpool_packed launch, same bits.  0 (the field was `reserved` until ABI 11): sc_P at the output resolution. */
   const uint64_t* sc_P;
   const uint32_t* sc_wbits;
   const float* sc_alpha;
   const float* sc_bn_scale;
   const float* sc_bn_shift;
   int32_t sc_C;
-  int32_t reserved;
+  int32_t sc_in_hw;
 } bnn_hip_epilogue;
 
 /* Per channel the integer dots (|dot| <= kmax = C*KH*KW) whose epilogue value

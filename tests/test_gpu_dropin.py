@@ -59,9 +59,9 @@ def test_net_call_runs_the_fused_executor_and_equals_it_bit_for_bit():
         assert st.calls == {"graph": 0, "eager": 1, "declined": 0} and st.engine is not None
         launches0 = native.launch_count()
         y0 = net(xs[0])
-        # first batch of this shape: the 21 eager launches of the fused executor (stem, 16 convs with the shortcut
-        # convs folded in, 3 OR-pools, head) — and nothing through the per-layer path
-        assert native.launch_count() - launches0 == 21 and fastpath.stats()["conv2d"] == per_layer0
+        # first batch of this shape: the 18 eager launches of the fused executor (stem, 16 convs with the shortcut
+        # convs and their OR-pools folded in, head) — and nothing through the per-layer path
+        assert native.launch_count() - launches0 == 18 and fastpath.stats()["conv2d"] == per_layer0
         assert st.calls == {"graph": 0, "eager": 2, "declined": 0}
         ys = [y0]
         for x in xs[1:]:

@@ -602,8 +602,9 @@ def test_fused_executor_uses_the_head_kernel_and_no_library_gemm():
     x = dev(gen.normal(31, (4, 3, 64, 64)))
     before = native.launch_count()
     y = fused(x)
-    # stem + 16 convs (the 3 shortcut convs folded into the last conv of their block) + 3 OR-pools of sign planes + head
-    assert native.launch_count() - before == 1 + 16 + 3 + 1
+    # stem + 16 convs (the 3 shortcut convs AND, since ABI 12, the OR-pools of their inputs folded into the last conv of
+    # their block) + head
+    assert native.launch_count() - before == 1 + 16 + 1
     unfolded = FusedResNet(net, fold_shortcut=False)    # (building an executor packs the weights: launches too)
     before = native.launch_count()
     y2 = unfolded(x)
@@ -639,6 +640,17 @@ def test_folded_shortcut_conv_equals_the_two_launch_form(shape, throughput):
     y0, p0 = hipops.bconv2d_fused(a2, w2, residual=idn, **kw)
     y1, p1 = hipops.bconv2d_fused(a2, w2, shortcut=(sc, ws, ass, bss), **kw)
     assert torch.equal(y0, y1) and torch.equal(p0.P, p1.P) and torch.equal(p0.M, p1.M) and p1.nonneg
+    # ABI 12 (sc_in_hw): the shortcut planes given UN-POOLED at twice the resolution (even and odd sizes: ceil-mode
+    # windows cut by the border) — the kernel ORs the 2 x 2 windows itself, no bnn_hip_orpool_packed launch
+    for hh, ww in ((2 * H, 2 * W), (2 * H - 1, 2 * W), (2 * H, 2 * W - 1), (2 * H - 1, 2 * W - 1)):
+        big = hipops.pack_act(dev(gen.activation("relu", gen.seed_of("fold", shape) + 2, (N, Cs, hh, ww)))); big.nonneg = True
+        pooled = hipops.orpool_packed(big, 2)
+        assert tuple(pooled.shape) == (N, Cs, H, W)
+        ya, pa = hipops.bconv2d_fused(a2, w2, shortcut=(pooled, ws, ass, bss), **kw)
+        launches = native.launch_count()
+        yb, pb = hipops.bconv2d_fused(a2, w2, shortcut=(big, ws, ass, bss), **kw)
+        assert native.launch_count() == launches + 1
+        assert torch.equal(ya, yb) and torch.equal(pa.P, pb.P)
 
 
 def test_folded_shortcut_is_refused_where_no_kernel_takes_it():
