@@ -510,7 +510,7 @@ ENGINE_NOTES = {
                 "streams, each a stem launch on its part of the caller's tensor + HIP graph of the rest",
     "net_call_single": "the same call with BNN_AMD_SPLIT_BATCH=0: the whole batch as ONE stem launch + HIP graph, "
                        "strictly one batch at a time",
-    "fused": "FusedResNet(net)(x), 21 eager launches per forward, a NEW tensor every step",
+    "fused": "FusedResNet(net)(x), 18 eager launches per forward, a NEW tensor every step",
     "blockwise": "net(x) with whole-model fusion off: torch/MIOpen stem and head, every residual block as its own fused "
                  "executor (pack_act + convs with BN / ReLU / residual in their epilogues) — the tier a custom network "
                  "built from bnn_amd.models blocks gets",

@@ -3,7 +3,7 @@
     net = prepare_binary_model(resnet18(), bconfig, custom_config_layers_name={'conv1': BConfig(), 'fc': BConfig()})
     net.eval();  with torch.no_grad(): outputs = net(inputs)           # examples/cifar10.py:61-71,140-149
 
-takes the fused executor — first batch of a shape as eager launches (21 for ResNet-18), from the second one on as
+takes the fused executor — first batch of a shape as eager launches (18 for ResNet-18), from the second one on as
 "stem launch on the caller's tensor + HIP graph of the rest" (bnn_amd/inference.py: AutoFusion, forward_fresh) — and
 is bit-identical to FusedResNet(net)(x).  Everything that has to keep the per-layer path (training, autograd, hooks on
 inner modules, uncovered models, foreign classes whose fused result does not check out) is covered too."""
