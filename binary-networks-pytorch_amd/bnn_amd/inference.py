@@ -796,9 +796,11 @@ class TwoHalves:
     64-channel convs: HBM, the rest: integer ALU) with a tail after every launch; a second half-batch fills what the
     first leaves idle — what ``PipelinedInference`` does across calls, done inside one call, so that the reference's
     own ``net(x)`` loop (examples/cifar10.py:147-149) gets it without knowing.  Bit-identical logits (images are
-    independent).  ``AutoFusion`` uses it from ``MIN_BATCH`` images on (``BNN_AMD_SPLIT_BATCH=0`` turns it off)."""
+    independent).  ``AutoFusion`` uses it from ``MIN_PIXELS`` input pixels on (``BNN_AMD_SPLIT_BATCH=0`` turns it off)."""
 
-    MIN_BATCH = 64
+    # from this many input pixels on (batch x height x width): measured on MI355X at 224 x 224 (k images/s, two halves vs
+    # one batch) — batch 64: 132 vs 143, batch 128: 183 vs 175, batch 256: 227 vs 213
+    MIN_PIXELS = 128 * 224 * 224
 
     def __init__(self, model: nn.Module, device: torch.device) -> None:
         self.streams = [torch.cuda.Stream(device=device) for _ in range(2)]
@@ -814,8 +816,9 @@ class TwoHalves:
         self._done: Optional[torch.cuda.Event] = None   # the previous call has read both halves' output buffers
 
     @staticmethod
-    def wanted(n: int) -> bool:
-        return n >= TwoHalves.MIN_BATCH and os.environ.get("BNN_AMD_SPLIT_BATCH", "1") != "0"
+    def wanted(x: torch.Tensor) -> bool:
+        return (x.shape[0] >= 2 and x.shape[0] * x.shape[2] * x.shape[3] >= TwoHalves.MIN_PIXELS
+                and os.environ.get("BNN_AMD_SPLIT_BATCH", "1") != "0")
 
     def captured(self, x: torch.Tensor) -> bool:
         h = (x.shape[0] + 1) // 2
@@ -1051,7 +1054,7 @@ class AutoFusion:
                     return self._verify(eng, model, x)
                 key = (tuple(x.shape), torch.cuda.current_stream(x.device).cuda_stream)
                 graph = eng.reads_caller_tensor and (key in eng._split or self.seen[(id(eng),) + key] >= self.CAPTURE_AFTER)
-                if graph and TwoHalves.wanted(x.shape[0]):
+                if graph and TwoHalves.wanted(x):
                     eng._check_current()                     # (a parameter change drops the half-batch executors too)
                     two = self.halves.get(id(eng))
                     if two is None or two.engines[0]._sig != eng._sig:

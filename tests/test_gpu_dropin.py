@@ -363,9 +363,18 @@ def test_resnet_with_model_fusion_off_runs_blockwise():
 
 @pytest.mark.parametrize("n", [64, 65])
 def test_large_batches_run_as_two_halves_in_flight(n):
-    """From TwoHalves.MIN_BATCH images on, `net(x)` cuts the batch in two halves on two streams (each: stem launch on
-    its part of the caller's tensor + HIP graph of the rest): same bits, a new tensor every call, odd batches too."""
+    """From TwoHalves.MIN_PIXELS input pixels on, `net(x)` cuts the batch in two halves on two streams (each: stem launch
+    on its part of the caller's tensor + HIP graph of the rest): same bits, a new tensor every call, odd batches too."""
     from bnn_amd.inference import TwoHalves
+    monkey = TwoHalves.MIN_PIXELS
+    TwoHalves.MIN_PIXELS = 64 * 32 * 32            # (the test's images are small)
+    try:
+        _two_halves_case(n, TwoHalves)
+    finally:
+        TwoHalves.MIN_PIXELS = monkey
+
+
+def _two_halves_case(n, TwoHalves):
     net = _r18()
     eng = FusedResNet(net)
     xs = [dev(gen.normal(120 + i, (n, 3, 32, 32))) for i in range(3)]
