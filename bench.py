@@ -15,7 +15,8 @@ the timed region.  Weak scaling: every rank processes its own batch; for the net
 [B,1000] logits of all ranks are all-gathered over RCCL at the end of every step (the only exchange
 the path has).  Prints ONE JSON line on rank 0.
 
-Timing: --spinup untimed steps (default ~0.25 s of work; the clocks of an idle GPU need that long to come up),
+Timing: --spinup untimed steps (default ~1 s of work: the clocks of an idle GPU come up within a few hundred ms and
+settle over the first second — with 0.25 s the 20 timed steps read 2-5 % below the 3 s sustained figure of the same run),
 then W warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides, max over ranks.
 The roofline block times 50 launches of the graded kernel with events after --roofline-spinup launches of it.
 """
@@ -82,15 +83,17 @@ def parse_args():
                          "streams, replayed round-robin; 1 = strictly one batch at a time)")
     ap.add_argument("--spinup", type=int, default=-1,
                     help="untimed steps in front of the warm-up steps that bring the GPU clocks up from idle "
-                         "(default: about 0.25 s of work: 200 for the nets, 750 for c2; 0 = none)")
+                         "(default: about 1 s of work: 1000 for the nets — 150 / 250 for the slow layerwise / blockwise "
+                         "engines — and 4000 for c2; 0 = none)")
     ap.add_argument("--roofline-spinup", type=int, default=1000,
                     help="untimed launches of the graded kernel in front of its event-timed launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-fp32-stem and one-batch-at-a-time lines")
     a = ap.parse_args()
+    a.spinup_default = a.spinup < 0
     if a.spinup < 0:
-        a.spinup = 750 if a.config == "c2" else 200
+        a.spinup = 4000 if a.config == "c2" else 1000
     return a
 
 
@@ -335,12 +338,12 @@ def main():
     def max_over_ranks(v: float) -> float:
         return max(all_gather_scalar(v, device)) if world > 1 else v
 
-    def timed(step, steps, warmup, sustain=0.0):
+    def timed(step, steps, warmup, sustain=0.0, spinup=None):
         # The engine clock of an idle GPU takes a few hundred ms of work to come up (the first timed region after a
         # pause measured ~15 % slow), and W = 5 warm-up steps are 6 ms.  A fixed number of the SAME
         # steps (same count on every rank: the step may contain a collective) runs first; it is reported as
         # "spinup_steps" in the JSON line and is outside both the W warm-up steps and the K timed steps.
-        for i in range(args.spinup):
+        for i in range(args.spinup if spinup is None else spinup):
             step(i)
         for i in range(warmup):
             out = step(i)
@@ -590,15 +593,21 @@ def bench_net(args, world, rank, device, info, timed):
     head_kw = {} if args.engine in ("net_call", "net_call_single", "layerwise", "blockwise") else fused_kw
     step = make_step(args.engine, n_streams, **head_kw)
     with torch.no_grad():
-        dt, logits = timed(step, args.steps, args.warmup, sustain=args.sustain)
+        head_spin = min(args.spinup, {"layerwise": 150, "blockwise": 250}.get(args.engine, args.spinup)) \
+            if args.spinup_default else args.spinup
+        dt, logits = timed(step, args.steps, args.warmup, sustain=args.sustain, spinup=head_spin)
         dt_local, sustained, clock_mhz = timed.local, timed.sustained, timed.clock_mhz
         assert logits.shape == (world * B, 1000) and bool(torch.isfinite(logits).all())
         # which tensor the LAST timed step read (validate_gather recomputes it)
         last_j = 0 if args.engine == "graph" else (args.warmup + args.steps - 1) % N_FRESH
         extras, engines = {}, {}
 
+        def spin_of(engine):     # ~1 s of work for every engine (same count on every rank)
+            slow = {"layerwise": 150, "blockwise": 250}
+            return min(args.spinup, slow.get(engine, args.spinup)) if args.spinup_default else args.spinup
+
         def measure(engine, streams, **kw):
-            d, out = timed(make_step(engine, streams, **kw), args.steps, args.warmup)
+            d, out = timed(make_step(engine, streams, **kw), args.steps, args.warmup, spinup=spin_of(engine))
             return {"value": world * B * args.steps / d, "ms_per_step": d / args.steps * 1e3,
                     "engine_clock_mhz": round(timed.clock_mhz)}, out
         if not args.no_extras:
@@ -637,7 +646,7 @@ def bench_net(args, world, rank, device, info, timed):
         "metric": "images/sec binary ResNet-18 224x224 forward" if not c5 else
                   "images/sec binary hierarchical-block ResNet-[3,4,6,3] 224x224 forward",
         "value": value, "unit": "images/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps": args.spinup,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps": head_spin,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
         "dtype": DTYPE if not c5 else DTYPE.replace("fp32 operands split into fp16 hi+lo", "plain fp16 operands (BNN_HIP_STEM_FP16)"),
