@@ -60,7 +60,8 @@ def parse_args():
                          "at --gpus 8), c2 the single 3x3 128->128 56x56 layer, c5 ResNet(HBlock,[3,4,6,3]) with the "
                          "fp16 MFMA stem at 128 images/GPU")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: 256; c5: 128)")
-    ap.add_argument("--engine", choices=("graph", "graph_fresh", "net_call", "net_call_single", "fused", "blockwise", "layerwise"),
+    ap.add_argument("--engine", choices=("graph", "graph_fresh", "net_call", "net_call_single", "fused", "blockwise", "layerwise",
+                                        "layerwise_library"),
                     default="graph",
                     help="what the headline `value` times.  graph: fused executor replayed as HIP graphs over resident "
                          "static input buffers (default); graph_fresh: the same with a NEW input tensor every step "
@@ -68,8 +69,9 @@ def parse_args():
                          "reference's own call `net(x)` on the prepare_binary_model() model with a new tensor every "
                          "step (bnn_amd AutoFusion); fused: fused executor, eager launches, new tensor every step; "
                          "blockwise: whole-model fusion off, every residual block fuses itself (what a network that is "
-                         "not laid out like the reference's ResNet gets); layerwise: one launch per binary layer + torch "
-                         "BN/ReLU/add (all fusion off).  The other "
+                         "not laid out like the reference's ResNet gets); layerwise: all fusion off — one launch per binary layer, "
+                         "one per BatchNorm(+add)(+ReLU) tail, the stem kernel; layerwise_library: the same with torch's "
+                         "own stem / BN / ReLU / add.  The other "
                          "engines are reported beside it in `engines` unless --no-extras")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend.  nccl = RCCL (one rank per GPU, the real thing); gloo: the same bench "
@@ -83,8 +85,8 @@ def parse_args():
                          "streams, replayed round-robin; 1 = strictly one batch at a time)")
     ap.add_argument("--spinup", type=int, default=-1,
                     help="untimed steps in front of the warm-up steps that bring the GPU clocks up from idle "
-                         "(default: about 1 s of work: 1000 for the nets — 150 / 250 for the slow layerwise / blockwise "
-                         "engines — and 4000 for c2; 0 = none)")
+                         "(default: about 1 s of work: 1000 for the nets — 150 ... 400 for the layerwise / blockwise "
+                         "engines, SLOW_SPIN — and 4000 for c2; 0 = none)")
     ap.add_argument("--roofline-spinup", type=int, default=1000,
                     help="untimed launches of the graded kernel in front of its event-timed launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -107,8 +109,8 @@ import torch.distributed as dist  # noqa: E402
 
 import bnn_amd as bnn  # noqa: E402
 from bnn_amd import hipops, native  # noqa: E402
-from bnn_amd.inference import (FusedResNet, PipelinedInference, auto_fusion, no_model_fusion,  # noqa: E402
-                               per_layer_forward)
+from bnn_amd.inference import (FusedResNet, PipelinedInference, auto_fusion, library_tails,  # noqa: E402
+                               no_model_fusion, per_layer_forward)
 from bnn_amd.models import HBlock, ResNet, resnet18  # noqa: E402
 from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer  # noqa: E402
 from bnn_amd.parallel import ShardedInference, all_gather_scalar  # noqa: E402
@@ -472,6 +474,12 @@ def bench_c2(args, world, rank, device, info, timed):
     return rec
 
 
+@contextlib.contextmanager
+def _library_layerwise():
+    with per_layer_forward(), library_tails():
+        yield
+
+
 def validate_gather(net, gathered, rank_input, B, world, rank, device, fused_kw, n_check=8, layerwise=False):
     """Un-timed, after the timed region, on EVERY rank: the all-gathered [world * B, 1000] logits must hold rank r's
     rows in block r — checked by recomputing the first `n_check` images of every rank locally (eager launches of
@@ -483,7 +491,8 @@ def validate_gather(net, gathered, rank_input, B, world, rank, device, fused_kw,
     n = min(n_check, B)
     bad = []
     for r in range(world):
-        ctx = {"layerwise": per_layer_forward, "blockwise": no_model_fusion}.get(layerwise, contextlib.nullcontext)
+        ctx = {"layerwise": per_layer_forward, "blockwise": no_model_fusion,
+               "layerwise_library": _library_layerwise}.get(layerwise, contextlib.nullcontext)
         with ctx():
             want = ref_engine(rank_input(r, n).contiguous())
         got = gathered[r * B:r * B + n]
@@ -502,6 +511,8 @@ def validate_gather(net, gathered, rank_input, B, world, rank, device, fused_kw,
             "how": "every rank recomputed the first images of every rank's batch and compared with its gathered copy"}
 
 
+NET_ENGINES = ("net_call", "net_call_single", "layerwise", "layerwise_library", "blockwise")   # net(x) itself
+SLOW_SPIN = {"layerwise": 400, "layerwise_library": 150, "blockwise": 400}    # spin-up steps of the slower engines (~1 s)
 N_FRESH = 3     # distinct resident input tensors the fresh-input engines rotate over (3 x 154 MB at batch 256)
 
 ENGINE_NOTES = {
@@ -514,10 +525,13 @@ ENGINE_NOTES = {
     "net_call_single": "the same call with BNN_AMD_SPLIT_BATCH=0: the whole batch as ONE stem launch + HIP graph, "
                        "strictly one batch at a time",
     "fused": "FusedResNet(net)(x), 18 eager launches per forward, a NEW tensor every step",
-    "blockwise": "net(x) with whole-model fusion off: torch/MIOpen stem and head, every residual block as its own fused "
-                 "executor (pack_act + convs with BN / ReLU / residual in their epilogues) — the tier a custom network "
+    "blockwise": "net(x) with whole-model fusion off: the stem as its MFMA kernel, torch head, every residual block as its "
+                 "own fused executor (pack_act + convs with BN / ReLU / residual in their epilogues) — the tier a custom network "
                  "built from bnn_amd.models blocks gets",
-    "layerwise": "net(x) with all fusion off: one launch per binary layer + torch/MIOpen stem, BN, ReLU, add",
+    "layerwise": "net(x) with all fusion off: one launch per binary layer, one per BatchNorm (+ residual add) (+ ReLU) "
+                 "tail of a block (bnn_hip_bn_act_f32), the stem as its MFMA kernel; torch avgpool + fc",
+    "layerwise_library": "the same with BNN_AMD_EVAL_TAILS=0: one launch per binary layer + torch/MIOpen stem, BN, ReLU, "
+                         "add (what 'layerwise' meant until round 3)",
 }
 
 
@@ -571,9 +585,10 @@ def bench_net(args, world, rank, device, info, timed):
             model = ShardedInference(FusedResNet(net, **kw))
             return lambda i: model.forward_even(xs[i % N_FRESH])
         model = ShardedInference(net)               # net_call / layerwise: the reference's own call
-        if engine in ("layerwise", "blockwise"):
+        if engine in ("layerwise", "layerwise_library", "blockwise"):
             def step(i):
-                with per_layer_forward() if engine == "layerwise" else no_model_fusion():
+                with no_model_fusion() if engine == "blockwise" else per_layer_forward(), \
+                        library_tails() if engine == "layerwise_library" else contextlib.nullcontext():
                     return model.forward_even(xs[i % N_FRESH])
             return step
         if kw:
@@ -590,11 +605,10 @@ def bench_net(args, world, rank, device, info, timed):
 
     multi = args.engine in ("graph", "graph_fresh")
     n_streams = max(1, args.streams) if multi else 1
-    head_kw = {} if args.engine in ("net_call", "net_call_single", "layerwise", "blockwise") else fused_kw
+    head_kw = {} if args.engine in NET_ENGINES else fused_kw
     step = make_step(args.engine, n_streams, **head_kw)
     with torch.no_grad():
-        head_spin = min(args.spinup, {"layerwise": 150, "blockwise": 250}.get(args.engine, args.spinup)) \
-            if args.spinup_default else args.spinup
+        head_spin = min(args.spinup, SLOW_SPIN.get(args.engine, args.spinup)) if args.spinup_default else args.spinup
         dt, logits = timed(step, args.steps, args.warmup, sustain=args.sustain, spinup=head_spin)
         dt_local, sustained, clock_mhz = timed.local, timed.sustained, timed.clock_mhz
         assert logits.shape == (world * B, 1000) and bool(torch.isfinite(logits).all())
@@ -603,8 +617,7 @@ def bench_net(args, world, rank, device, info, timed):
         extras, engines = {}, {}
 
         def spin_of(engine):     # ~1 s of work for every engine (same count on every rank)
-            slow = {"layerwise": 150, "blockwise": 250}
-            return min(args.spinup, slow.get(engine, args.spinup)) if args.spinup_default else args.spinup
+            return min(args.spinup, SLOW_SPIN.get(engine, args.spinup)) if args.spinup_default else args.spinup
 
         def measure(engine, streams, **kw):
             d, out = timed(make_step(engine, streams, **kw), args.steps, args.warmup, spinup=spin_of(engine))
@@ -615,13 +628,14 @@ def bench_net(args, world, rank, device, info, timed):
             engines[head_key] = {"value": world * B * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
                                  "engine_clock_mhz": round(clock_mhz), "headline": True}
             for eng, k in (("graph", 2), ("graph", 1), ("graph_fresh", 2), ("graph_fresh", 1), ("net_call", 1),
-                           ("net_call_single", 1), ("fused", 1), ("blockwise", 1), ("layerwise", 1)):
+                           ("net_call_single", 1), ("fused", 1), ("blockwise", 1), ("layerwise", 1),
+                           ("layerwise_library", 1)):
                 key = f"{eng}_x{k}" if eng in ("graph", "graph_fresh") else eng
                 if key in engines or (c5 and eng.startswith("net_call")):   # (c5 asks for the fp16 stem: not the model default)
                     continue
-                engines[key], _ = measure(eng, k, **({} if eng in ("net_call", "net_call_single", "layerwise", "blockwise") else fused_kw))
+                engines[key], _ = measure(eng, k, **({} if eng in NET_ENGINES else fused_kw))
             for key, rec_e in engines.items():
-                rec_e["what"] = ENGINE_NOTES[key.split("_x")[0]]
+                rec_e["what"] = ENGINE_NOTES[key[:-3] if key[-3:-1] == "_x" else key]
             auto_fusion(net).reset()        # (its executors and graphs are not needed any more)
             if "graph_x1" in engines:
                 extras["one_batch_at_a_time"] = {k: engines["graph_x1"][k] for k in ("value", "ms_per_step")}
@@ -631,7 +645,7 @@ def bench_net(args, world, rank, device, info, timed):
                     ex, max_abs_logit_diff_vs_default=float((lx - logits).abs().max()),
                     note="stem as a k-ordered fp32 fmaf chain on v_mfma_f32_16x16x4_f32 (bit-for-bit IEEE fp32)")
         gather_check = validate_gather(net, logits, lambda r, n: rank_input(r, n, last_j), B, world, rank, device,
-                                       head_kw, layerwise=args.engine if args.engine in ("layerwise", "blockwise") else False) \
+                                       head_kw, layerwise=args.engine if args.engine in SLOW_SPIN else False) \
             if dist.is_initialized() else None
     if dist.is_initialized():     # per-rank step times: a straggler shows here, not only in the max
         per_rank_ms = [float(t) for t in all_gather_scalar(dt_local / args.steps * 1e3, device)]

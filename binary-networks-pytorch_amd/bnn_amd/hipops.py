@@ -722,6 +722,31 @@ def xnor_weight_backward(w: torch.Tensor, dwhat: torch.Tensor, center: bool, com
     return dw
 
 
+def bn_act(x: torch.Tensor, bn_scale: torch.Tensor, bn_shift: torch.Tensor, relu: bool = False,
+           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``relu?(fma(x, scale[c], shift[c]) (+ residual))``: eval-mode BatchNorm with folded constants + the residual add +
+    ReLU of a residual block as ONE launch (include/bnn_hip.h: bnn_hip_bn_act_f32) — the tail of the per-layer path; the
+    same float operations as the fused convolution epilogue."""
+    x = _require_cuda_f32(x, "BatchNorm input")
+    if x.dim() != 4:
+        raise native.NativeError(f"bnn_amd: bn_act expects NCHW, got shape {tuple(x.shape)}")
+    lib = native.require()
+    N, C, H, W = x.shape
+    bn_scale = _per_channel(bn_scale, C, "bn_scale")
+    bn_shift = _per_channel(bn_shift, C, "bn_shift")
+    if residual is not None:
+        residual = _require_cuda_f32(residual, "residual")
+        if residual.shape != x.shape:
+            raise native.NativeError("bnn_amd: residual shape differs from the BatchNorm input's")
+    with torch.cuda.device(x.device):
+        y = torch.empty_like(x)
+        if x.numel():
+            native.check(lib.bnn_hip_bn_act_f32(x.data_ptr(), N, C, H * W, bn_scale.data_ptr(), bn_shift.data_ptr(),
+                                                _ptr(residual), int(bool(relu)), y.data_ptr(), _stream(x.device)),
+                         "bnn_hip_bn_act_f32")
+    return y
+
+
 def bn_train_forward(x: torch.Tensor, gamma, beta, running_mean, running_var, momentum: float, eps: float,
                      relu: bool = False, residual: Optional[torch.Tensor] = None):
     """``relu?(batch_norm(x, training=True) (+ residual))`` in three launches (csrc/bn_train.hip).  Updates the running

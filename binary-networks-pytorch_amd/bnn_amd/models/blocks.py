@@ -34,11 +34,17 @@ def _fused(block, x):
 
 def _bn_act(x, bn, act=None, residual=None):
     """``act(bn(x) (+ residual))``: on a HIP device in training mode one fused op (bnn_amd/training.py: bn_act — batch
-    statistics, normalisation, residual add and ReLU in three launches instead of four library passes), else the
-    modules themselves in the reference's order."""
+    statistics, normalisation, residual add and ReLU in three launches instead of four library passes), in eval mode
+    without autograd one launch (bnn_amd/inference.py: eval_tail), else the modules themselves in the reference's
+    order."""
     if x.is_cuda and bn.training:
         from .. import training
         return training.bn_act(x, bn, act, residual)
+    if x.is_cuda and not torch.is_grad_enabled():
+        from ..inference import eval_tail           # (inference imports this module)
+        y = eval_tail(x, bn, act, residual)
+        if y is not None:
+            return y
     y = bn(x)
     if residual is not None:
         y += residual

@@ -142,20 +142,30 @@ class ResNet(nn.Module):
         auto_fusion(self)
         return super()._replicate_for_data_parallel()
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        # eval + no_grad on a HIP device: the fused executor (bnn_amd/inference.py: AutoFusion) — what makes the
-        # reference's own call `outputs = net(inputs)` (examples/cifar10.py:140-149) the fast path.  None -> per layer.
-        if not self.training and x.is_cuda and not torch.is_grad_enabled():
-            y = _auto_forward(self, x)
+    def _stem(self, x: torch.Tensor, inference: bool) -> torch.Tensor:
+        """conv1 -> bn1 -> relu -> maxpool (the daBNN stem is all in conv1)."""
+        if inference:                                # the per-layer / per-block tiers: the stem as its MFMA kernel
+            from ..inference import eval_stem
+            y = eval_stem(self, x)
             if y is not None:
                 return y
         x = self.conv1(x)
-        if self.stem_type == "basic":
-            if x.is_cuda and self.bn1.training:      # training on a HIP device: bn1 -> relu -> maxpool as one fused op
-                from .. import training
-                x = training.stem_tail(x, self.bn1, self.relu, self.maxpool)
-            else:
-                x = self.maxpool(self.relu(self.bn1(x)))
+        if self.stem_type != "basic":
+            return x
+        if x.is_cuda and self.bn1.training:          # training on a HIP device: bn1 -> relu -> maxpool as one fused op
+            from .. import training
+            return training.stem_tail(x, self.bn1, self.relu, self.maxpool)
+        return self.maxpool(self.relu(self.bn1(x)))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        # eval + no_grad on a HIP device: the fused executor (bnn_amd/inference.py: AutoFusion) — what makes the
+        # reference's own call `outputs = net(inputs)` (examples/cifar10.py:140-149) the fast path.  None -> per layer.
+        inference = not self.training and x.is_cuda and not torch.is_grad_enabled()
+        if inference:
+            y = _auto_forward(self, x)
+            if y is not None:
+                return y
+        x = self._stem(x, inference)
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = torch.flatten(self.avgpool(x), 1)
         return self.fc(x)

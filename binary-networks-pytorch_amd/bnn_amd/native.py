@@ -23,7 +23,7 @@ FLAG_ACT_NONNEG = 32
 FLAG_THROUGHPUT = 64
 STEM_EXACT_FP32 = 1
 STEM_FP16 = 4
-ABI_VERSION = 12
+ABI_VERSION = 13
 DTYPE_F32 = 0
 DTYPE_F16 = 1
 
@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_bconv_grad_weight_packed_f32", "bnn_hip_bn_train_workspace_bytes", "bnn_hip_bn_train_forward_f32",
     "bnn_hip_bn_train_backward_f32", "bnn_hip_bn_relu_maxpool_train_forward_f32",
     "bnn_hip_bn_relu_maxpool_train_backward_f32", "bnn_hip_xnor_weight_forward_f32", "bnn_hip_xnor_weight_backward_f32",
+    "bnn_hip_bn_act_f32",
 )
 
 
@@ -157,6 +158,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_bn_train_workspace_bytes.restype = ctypes.c_size_t
     lib.bnn_hip_bn_train_workspace_bytes.argtypes = [_i, _i, _i]
     _f = ctypes.c_float
+    lib.bnn_hip_bn_act_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]
+    lib.bnn_hip_bn_act_f32.restype = _i
     lib.bnn_hip_bn_train_forward_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bnn_hip_bn_train_backward_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.bnn_hip_bn_relu_maxpool_train_forward_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _f, _f] + [_vp] * 8

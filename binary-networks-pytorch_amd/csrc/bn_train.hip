@@ -120,12 +120,14 @@ __global__ __launch_bounds__(bnt::NT) void bn_apply_kernel(const float* __restri
       const float4 r = *reinterpret_cast<const float4*>(res + i0);
       v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
     }
-    if constexpr (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if constexpr (RELU) {  // (x < 0 ? 0 : x keeps NaN, like torch.relu; fmaxf would return 0)
+      v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+    }
     *reinterpret_cast<float4*>(y + i0) = v;
   } else {
     float v = fmaf(x[i0], scale, shift);
     if constexpr (RES) v += res[i0];
-    if constexpr (RELU) v = fmaxf(v, 0.f);
+    if constexpr (RELU) v = v < 0.f ? 0.f : v;
     y[i0] = v;
   }
 }
@@ -384,18 +386,15 @@ int launch_bn_stats(const float* x, int N, int C, int HW, int splits, double* pa
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
-// finalize (statistics, running statistics, scale / shift into `work` = [scale C | shift C]) + the apply pass
-int launch_bn_apply(const float* x, const double* partial, int splits, const float* gamma, const float* beta,
-                    const float* res, int relu, float* y, int N, int C, int HW, float eps, float momentum, float* rm,
-                    float* rv, float* mean_out, float* invstd_out, float* work, hipStream_t s) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, partial, splits, C,
-                     (double)N * HW, gamma, beta, eps, momentum, rm, rv, mean_out, invstd_out, work, work + C);
+// the apply pass: y = relu?( fma(x, scale[c], shift[c]) (+ res) )
+static int apply_pass(const float* x, const float* scale, const float* shift, const float* res, int relu, float* y, int N,
+                      int C, int HW, hipStream_t s) {
   const bool v4 = vec4(x, res, y, nullptr, HW);
   const int vec = v4 ? 4 : 1;
   const long long units = (long long)N * C * HW / vec;
   const dim3 grid((unsigned)((units + bnt::NT - 1) / bnt::NT));
   const int upr = HW / vec;
-#define BNN_APPLY(V_, R_, S_)   hipLaunchKernelGGL((bn_apply_kernel<V_, R_, S_>), grid, dim3(bnt::NT), 0, s, x, work, work + C, res, y, units, C, upr)
+#define BNN_APPLY(V_, R_, S_)   hipLaunchKernelGGL((bn_apply_kernel<V_, R_, S_>), grid, dim3(bnt::NT), 0, s, x, scale, shift, res, y, units, C, upr)
   if (v4) {
     if (relu && res) BNN_APPLY(4, true, true); else if (relu) BNN_APPLY(4, true, false);
     else if (res) BNN_APPLY(4, false, true); else BNN_APPLY(4, false, false);
@@ -405,6 +404,21 @@ int launch_bn_apply(const float* x, const double* partial, int splits, const flo
   }
 #undef BNN_APPLY
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+// finalize (statistics, running statistics, scale / shift into `work` = [scale C | shift C]) + the apply pass
+int launch_bn_apply(const float* x, const double* partial, int splits, const float* gamma, const float* beta,
+                    const float* res, int relu, float* y, int N, int C, int HW, float eps, float momentum, float* rm,
+                    float* rv, float* mean_out, float* invstd_out, float* work, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, partial, splits, C,
+                     (double)N * HW, gamma, beta, eps, momentum, rm, rv, mean_out, invstd_out, work, work + C);
+  return apply_pass(x, work, work + C, res, relu, y, N, C, HW, s);
+}
+
+// eval-mode BatchNorm with folded constants (+ residual) (+ ReLU): the apply pass alone
+int launch_bn_act(const float* x, const float* scale, const float* shift, const float* res, int relu, float* y, int N,
+                  int C, int HW, hipStream_t s) {
+  return apply_pass(x, scale, shift, res, relu, y, N, C, HW, s);
 }
 
 int launch_bn_bwd_reduce(const float* gy, const float* y, const float* x, const float* mean, const float* invstd, int N,

@@ -165,6 +165,8 @@ int launch_bn_stats(const float* x, int N, int C, int HW, int splits, double* pa
 int launch_bn_apply(const float* x, const double* partial, int splits, const float* gamma, const float* beta,
                     const float* res, int relu, float* y, int N, int C, int HW, float eps, float momentum, float* rm,
                     float* rv, float* mean_out, float* invstd_out, float* work, hipStream_t s);
+int launch_bn_act(const float* x, const float* scale, const float* shift, const float* res, int relu, float* y, int N,
+                  int C, int HW, hipStream_t s);
 int launch_bn_bwd_reduce(const float* gy, const float* y, const float* x, const float* mean, const float* invstd, int N,
                          int C, int HW, int splits, double* partial, hipStream_t s);
 int launch_bn_bwd_dx(const float* gy, const float* y, const float* x, const float* mean, const float* invstd,

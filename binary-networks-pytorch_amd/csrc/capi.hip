@@ -636,6 +636,18 @@ int bnn_hip_bn_train_forward_f32(const float* x, int N, int C, int HW, const flo
                               running_var, save_mean, save_invstd, work, static_cast<hipStream_t>(stream));
 }
 
+int bnn_hip_bn_act_f32(const float* x, int N, int C, int HW, const float* scale, const float* shift, const float* residual,
+                       int relu, float* y, void* stream) {
+  if (!x || !y || !scale || !shift) return BNN_HIP_ERR_INVALID_ARG;
+  const int st = check_bn(N, C, HW);
+  if (st != BNN_HIP_OK) return st;
+  if (!aligned(x, 4) || !aligned(y, 4) || !aligned(scale, 4) || !aligned(shift, 4) || (residual && !aligned(residual, 4)))
+    return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_bn_act(x, scale, shift, residual, relu, y, N, C, HW, static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_bn_train_backward_f32(const float* gy, const float* y, const float* x, const float* save_mean,
                                   const float* save_invstd, const float* gamma, int N, int C, int HW, float* dx,
                                   float* dres, float* dgamma, float* dbeta, void* workspace, void* stream) {

@@ -61,12 +61,13 @@
 extern "C" {
 #endif
 
-/* ABI 12 (round 4): + bnn_hip_probe_clock; + the training-side entry points bnn_hip_pack_act_ste_f32,
+/* ABI 13 (round 4): + bnn_hip_bn_act_f32 (eval-mode BatchNorm + residual + ReLU tail of the per-layer path).
+ * ABI 12 (round 4): + bnn_hip_probe_clock; + the training-side entry points bnn_hip_pack_act_ste_f32,
  * bnn_hip_bconv_grad_{input,weight}_packed_f32 (3-bit saved state), bnn_hip_bn_train_{workspace_bytes,forward,backward}_f32,
  * bnn_hip_bn_relu_maxpool_train_{forward,backward}_f32, bnn_hip_xnor_weight_{forward,backward}_f32;
  * - BNN_HIP_STEM_STAGED and BNN_HIP_FLAG_WEIGHTS_LDS (those kernels are test-only now: csrc/legacy/);
  * stem tensors capped at the 32-bit buffer-descriptor range; size arithmetic of all validators saturating.          */
-#define BNN_HIP_ABI_VERSION 12
+#define BNN_HIP_ABI_VERSION 13
 #define BNN_HIP_OCB 32 /* output channels per weight block (padding granularity of O) */
 
 typedef enum bnn_hip_status {
@@ -456,6 +457,16 @@ int bnn_hip_bn_train_forward_f32(const float* x, int N, int C, int HW, const flo
 int bnn_hip_bn_train_backward_f32(const float* gy, const float* y, const float* x, const float* save_mean,
                                   const float* save_invstd, const float* gamma, int N, int C, int HW, float* dx,
                                   float* dres, float* dgamma, float* dbeta, void* workspace, void* stream);
+
+/* Eval-mode BatchNorm2d with folded constants, fused with what follows it in the reference's residual blocks:
+ *     y = relu?( fmaf(x, scale[c], shift[c]) (+ residual) )     bnn/models/layers/res_block.py:40-56 under .eval()
+ * x, y, residual: fp32 [N, C, HW]; scale, shift: fp32 [C] (scale = weight / sqrt(running_var + eps), shift = bias -
+ * running_mean * scale, rounded as the caller wishes — the host side rounds them as ATen's CPU kernel does).  The same
+ * float operations in the same order as the BN / residual / ReLU epilogue of bnn_hip_bconv2d_fused, so a network run
+ * layer by layer and the fused executor agree bit for bit.  ReLU keeps NaN (torch.relu).  One launch.  y must not
+ * alias x or residual.  (ABI 13)                                                                                      */
+int bnn_hip_bn_act_f32(const float* x, int N, int C, int HW, const float* scale, const float* shift, const float* residual,
+                       int relu, float* y, void* stream);
 
 /* The stem tail in training mode:  maxpool3x3/2/1( relu( batch_norm_train(x) ) )   (bnn/models/resnet.py:150-153) without
  * ever writing the normalised tensor: `pooled` [N, C, Hp, Wp] (Hp = (H - 1) / 2 + 1) and ONE BYTE per pooled output,

@@ -397,3 +397,106 @@ def _two_halves_case(n, TwoHalves):
     for a, b in zip(ys, want):
         assert torch.equal(a, b)
     assert torch.equal(y, want[0]) and torch.equal(y_single, want[1])
+
+
+# ---- the per-layer path's tails (bnn_amd/inference.py: eval_tail, eval_stem; include/bnn_hip.h: bnn_hip_bn_act_f32) ----
+@pytest.mark.parametrize("shape", [(3, 64, 14, 14), (2, 40, 7, 5), (5, 3, 1, 1), (1, 130, 9, 9)])
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("res", [False, True])
+def test_the_batchnorm_tail_is_the_modules_arithmetic(shape, relu, res):
+    """relu?(bn(x) (+ residual)) in one launch == fma(x, scale, shift) with the constants rounded as ATen's CPU kernel
+    rounds them (fold_bn), then the add, then the clamp — bit for bit; and the library's own modules to rounding."""
+    from bnn_amd.inference import cached_fold
+    from bnn_amd.models.blocks import _bn_act
+    N, C, H, W = shape
+    bn = nn.BatchNorm2d(C).to(DEV).eval()
+    with torch.no_grad():
+        bn.running_mean.copy_(dev(gen.normal(1, (C,))) * 0.5)
+        bn.running_var.copy_(dev(gen.normal(2, (C,))).abs() + 0.3)
+        bn.weight.copy_(dev(gen.normal(3, (C,))))
+        bn.bias.copy_(dev(gen.normal(4, (C,))))
+    x = dev(gen.normal(5, shape)) * 2.0
+    x[0, 0, 0, 0] = float("nan")
+    r = dev(gen.normal(6, shape)) if res else None
+    act = nn.ReLU(inplace=True) if relu else None
+    with torch.no_grad():
+        n0 = native.launch_count()
+        y = _bn_act(x, bn, act, r)
+        assert native.launch_count() == n0 + 1
+        scale, shift = cached_fold(bn)
+        want = (x.double() * scale.double().view(1, C, 1, 1) + shift.double().view(1, C, 1, 1)).float()   # one rounding: fma
+        if res:
+            want = want + r
+        if relu:
+            want = torch.relu(want)
+        lib = bn(x)
+        if res:
+            lib = lib + r
+        if relu:
+            lib = torch.relu(lib)
+    assert torch.isnan(y[0, 0, 0, 0]) and torch.isnan(want[0, 0, 0, 0])      # ReLU keeps NaN, like torch.relu
+    assert torch.equal(torch.nan_to_num(y, nan=7.0), torch.nan_to_num(want, nan=7.0))
+    assert torch.allclose(torch.nan_to_num(y, nan=7.0), torch.nan_to_num(lib, nan=7.0), rtol=1e-5, atol=1e-5)
+
+
+def test_the_fold_on_the_module_follows_its_tensors():
+    from bnn_amd.inference import cached_fold
+    bn = nn.BatchNorm2d(8).to(DEV).eval()
+    a = cached_fold(bn)
+    assert cached_fold(bn) is a
+    with torch.no_grad():
+        bn.running_var.mul_(4.0)
+    b = cached_fold(bn)
+    assert b is not a and torch.allclose(b[0], a[0] * 0.5, rtol=1e-3)
+    bn.weight = nn.Parameter(torch.full((8,), 3.0, device=DEV))
+    assert torch.allclose(cached_fold(bn)[0], b[0] * 3.0, rtol=1e-6)
+
+
+def test_the_per_layer_path_runs_its_tails_as_single_launches_and_agrees_with_the_fused_executor():
+    from bnn_amd import hipops
+    from bnn_amd.inference import library_tails
+    net = _r18()
+    x = dev(gen.normal(31, (6, 3, 96, 96)))
+    calls = {"bn_act": 0, "stem": 0}
+    real_bn, real_stem = hipops.bn_act, hipops.stem7x7
+
+    def bn_act(*a, **k):
+        calls["bn_act"] += 1
+        return real_bn(*a, **k)
+
+    def stem(*a, **k):
+        calls["stem"] += 1
+        return real_stem(*a, **k)
+    try:
+        hipops.bn_act, hipops.stem7x7 = bn_act, stem
+        with torch.no_grad(), per_layer_forward():
+            n0 = fastpath.stats()["conv2d"]
+            y = net(x)
+            assert fastpath.stats()["conv2d"] - n0 == 19                  # every binary conv on its own
+            assert calls == {"bn_act": 16 + 3, "stem": 1}                 # 16 block tails + 3 shortcut BatchNorms, the stem
+            with library_tails():
+                y_lib = net(x)
+            assert calls == {"bn_act": 19, "stem": 1}                     # the library's modules: none of ours
+    finally:
+        hipops.bn_act, hipops.stem7x7 = real_bn, real_stem
+    with torch.no_grad():
+        y_fused = FusedResNet(net)(x)
+    # the same float operations as the fused executor's epilogues up to the head (avgpool + fc: the library's kernels
+    # here, one fused kernel there): the logits agree to the head's rounding; the library's BatchNorm rounds differently
+    assert torch.allclose(y, y_fused, rtol=1e-5, atol=2e-6 * float(y_fused.abs().max()))
+    assert torch.allclose(y, y_lib, rtol=1e-3, atol=1e-3 * float(y_lib.abs().max()))
+
+
+def test_a_hook_on_a_batchnorm_keeps_that_module_a_module():
+    net = _r18()
+    x = dev(gen.normal(32, (2, 3, 64, 64)))
+    seen = []
+    h = net.layer1[0].bn2.register_forward_hook(lambda m, i, o: seen.append(tuple(o.shape)))
+    try:
+        with torch.no_grad():
+            y = net(x)                      # (hooks inside: the model tier declines, the block tier declines for layer1[0])
+    finally:
+        h.remove()
+    assert seen == [(2, 64, 16, 16)]
+    with torch.no_grad():
+        assert torch.allclose(y, net(x), rtol=1e-3, atol=1e-3 * float(y.abs().max()))

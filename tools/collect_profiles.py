@@ -134,7 +134,7 @@ if stats_c2_1:      # one launch at a time, nothing else in the process: the cle
         open(os.path.join(dst, f"{tag}_bench_c2_1stream.json"), "w").write(stamped(
             ln[-1], "rocprofv3 --kernel-trace --stats -- python bench.py --config c2 --steps 20 --warmup 5 --sustain 0 "
                     "--no-extras --no-roofline --no-cpu-baseline") + "\n")
-for n in ("layerwise", "fused", "fused_exact_stem"):     # written by tests/test_gpu_c3_full.py on the GPU box
+for n in ("layerwise_library", "layerwise", "fused", "fused_exact_stem"):     # written by tests/test_gpu_c3_full.py on the GPU box
     fn = os.path.join(ROOT, "gpurun_out", f"c3_b256_parity_{n}.json")
     if os.path.exists(fn):
         rec = json.load(open(fn))

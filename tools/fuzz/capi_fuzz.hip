@@ -166,6 +166,12 @@ static void check_bn_args(int N, int C, int HW) {
 int launch_bn_stats(const float* x, int N, int C, int HW, int S, double* partial, hipStream_t) {
   ++g_reached; check_bn_args(N, C, HW); REQUIRE(x && partial && S >= 1 && S <= N && al(partial, 8)); return BNN_HIP_OK;
 }
+int launch_bn_act(const float* x, const float* scale, const float* shift, const float* res, int, float* y, int N, int C,
+                  int HW, hipStream_t) {
+  ++g_reached; check_bn_args(N, C, HW);
+  REQUIRE(x && scale && shift && y && al(x, 4) && al(y, 4) && al(scale, 4) && al(shift, 4) && al(res, 4));
+  return BNN_HIP_OK;
+}
 int launch_bn_apply(const float* x, const double* partial, int S, const float*, const float*, const float*, int, float* y,
                     int N, int C, int HW, float eps, float, float* rm, float* rv, float* mo, float* io, float* work,
                     hipStream_t) {
@@ -234,7 +240,7 @@ int main(int argc, char** argv) {
   for (long it = 0; it < iters; ++it) {
     ++g_calls;
     int st = 0;
-    switch (rnd() % 29) {
+    switch (rnd() % 30) {
       case 0: { bnn_hip_conv_desc d = pick_desc();
         st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
                              pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
@@ -330,6 +336,8 @@ int main(int argc, char** argv) {
                                                     pick_int(), pick_ptr<float>(), pick_ptr<float>(), stream); break;
       case 27: st = bnn_hip_xnor_weight_backward_f32(pick_ptr<float>(), pick_ptr<float>(), pick_int(), pick_int(), pick_int(),
                                                      pick_int(), pick_int(), pick_int(), pick_ptr<float>(), stream); break;
+      case 28: st = bnn_hip_bn_act_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_ptr<float>(), pick_ptr<float>(),
+                                       pick_ptr<float>(), pick_int(), pick_ptr<float>(), stream); break;
       default: { bnn_hip_conv_desc d = pick_desc();
         (void)bnn_hip_shortcut_fold_supported(rnd() % 16 ? &d : nullptr, pick_int());
         st = bnn_hip_blinear(pick_int(), pick_int(), pick_int(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
