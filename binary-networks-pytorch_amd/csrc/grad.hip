@@ -361,8 +361,10 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
 // shifted by kx - 1 pixels, so that every tap's 8-pixel fragment is a 16-byte aligned LDS read.
 // XP: sign(x) comes from the bit planes P = x > 0 (`xin`) and M = x < 0 (`xin2`), [N][C/64][Hx][Wx] uint64, instead
 // of the fp32 tensor: 2 bits per element of saved state and of traffic.  Same values, same results.
-template <int ST, int KS, int NC, bool XP = false>
-__global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict__ g,
+// SI: sign(x) fill items per thread, ceil(16 NC BR groups / 256) — a template parameter so that the fill loops are
+// straight-line code (a run-time trip count puts the loaded values behind phi copies, which wait for the loads).
+template <int ST, int KS, int NC, bool XP, int SI>
+__global__ __launch_bounds__(grad::NT, 2) void wgrad_kernel(const float* __restrict__ g,
                                                             const float* __restrict__ xin,
                                                             const float* __restrict__ xin2,
                                                             float* __restrict__ part, const GradGeo q,
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict
     glds[i] = ol * AROW + 8 * g8;
   }
   // sign(x): (channel, row, 8-pixel group) items, at most four per thread; NE values x[ST*8j - PD .. ] per item
-  constexpr int SI = 4, NE = 8 * ST + 2 * PD;
+  constexpr int NE = 8 * ST + 2 * PD;
   const int sx_items = 16 * NC * BR * groups;
   int xbase[SI], xlds[SI], xpr[SI], x_nv[SI];
   [[maybe_unused]] int xbit[SI];              // XP: the item's channel as a bit of its 32-channel plane dword
@@ -459,80 +461,135 @@ __global__ __launch_bounds__(grad::NT) void wgrad_kernel(const float* __restrict
     xlds[i] = item < sx_items ? (cl * BR + pr) * BROW + 8 * j : -1;
   }
 
-  for (int n = n_begin; n < n_end; ++n) {
-    for (int y0 = 0; y0 < q.H; y0 += q.R) {
-      __syncthreads();
-      // ---- g rows y0 .. y0+R-1 of 64 output channels
-      const unsigned g_soff = (unsigned)((n * q.O + o0) * HW + y0 * q.W) * 4u;
-      const bool g_row = y0 + gry < q.H;
+  // ---- the chunk loop, software-pipelined: the loads of chunk i + 1 are issued BEFORE the MFMAs of chunk i and land under
+  // them (raw values wait in registers: 16 of g, 10 per sign(x) item of the fp32 tensor — the kernel is held to two workgroups per
+  // CU by its LDS, so up to 256 registers cost no occupancy); split / sign + LDS writes ("commit") follow the next
+  // barrier.  Until round 4 a chunk was load -> wait -> commit -> barrier -> MFMA, and the matrix pipe idled through every
+  // HBM round trip (0.22-0.25 of the bf16 peak at three products per MAC).
+  float gq[2][8];                                   // raw g values of the chunk in flight
+  [[maybe_unused]] float xq[XP ? 1 : SI][XP ? 1 : NE];          // raw x values (fp32 tensor)
+  int cn = 0, cy0 = 0;                              // XP: the chunk being committed (its plane loads are not pipelined:
+                                                    // 2 x 40 more registers would spill at two waves per SIMD)
+  auto issue = [&](int n, int y0, unsigned kill) __attribute__((always_inline)) {   // kill: 0, or kOOB = load nothing
+    // g rows y0 .. y0+R-1 of 64 output channels
+    const unsigned g_soff = (unsigned)((n * q.O + o0) * HW + y0 * q.W) * 4u;
+    const bool g_row = y0 + gry < q.H;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const unsigned vo = g_row ? goff[i] : kOOB;
-        float v[8];
+    for (int i = 0; i < 2; ++i) {
+      const unsigned vo = (g_row ? goff[i] : kOOB) | kill;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float gv = buf_ld(r_g, vo + 4u * e, g_soff);
-          v[e] = e < g_nv ? gv : 0.0f;  // (past the row's end the next row would be read)
-        }
-        half8 hi, mid, lo;
-        split8(v, hi, mid, lo);
-        *reinterpret_cast<half8*>(a_hi + glds[i]) = hi;
-        *reinterpret_cast<half8*>(a_mid + glds[i]) = mid;
-        *reinterpret_cast<half8*>(a_lo + glds[i]) = lo;
-      }
-      // ---- sign(x) rows ST*y0-PD .. of 16 NC input channels, KS copies: copy kx holds sx[ST*p + kx - PD] at slot p
-      const unsigned x_soff = XP ? (unsigned)((n * q.cw64 + (c0 >> 6)) * HWx) * 8u : (unsigned)((n * q.C + c0) * HWx) * 4u;
+      for (int e = 0; e < 8; ++e) gq[i][e] = buf_ld(r_g, vo + 4u * e, g_soff);
+    }
+    if constexpr (!XP) {   // sign(x) rows ST*y0-PD .. of 16 NC input channels
+      const unsigned x_soff = (unsigned)((n * q.C + c0) * HWx) * 4u;
       const int yrow = ST * y0 - PD, x_row4 = yrow * q.Wx * XB;
 #pragma unroll
       for (int i = 0; i < SI; ++i) {
-        if (NT * i >= sx_items) break;  // workgroup-uniform
         const bool rowok = (unsigned)(yrow + xpr[i]) < (unsigned)q.Hx;
-        const unsigned vo = rowok ? (unsigned)(xbase[i] + x_row4) : kOOB;
-        u16 s[NE];  // sx[ST*8j-PD .. ST*(8j+7)+PD]
+        const unsigned vo = (rowok ? (unsigned)(xbase[i] + x_row4) : kOOB) | kill;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
           // element e sits (e - PD) pixels from the item's base; the one left of a row's first pixel is padding
           const unsigned ve = e < PD ? (xfirst[i] ? kOOB : vo - (unsigned)XB * (PD - e)) : vo + (unsigned)XB * (e - PD);
-          if constexpr (XP) {
-            // (one dword per pixel and plane: 16-byte loads of two pixels measured 5 % faster and returned wrong data —
-            // hipcc 7.2 mis-lowers the multi-dword buffer-load builtins, see csrc/bconv_core.h)
-            const unsigned pw = __float_as_uint(buf_ld(r_x, ve, x_soff)), mw = __float_as_uint(buf_ld(r_x2, ve, x_soff));
-            const bool in = e < x_nv[i];
-            s[e] = (in && ((pw >> xbit[i]) & 1u)) ? kBf16One : (in && ((mw >> xbit[i]) & 1u)) ? kBf16MinusOne
-                                                                                              : (unsigned short)0;
-          } else {
-            float xv = buf_ld(r_x, ve, x_soff);
-            xv = e < x_nv[i] ? xv : 0.0f;
-            s[e] = xv > 0.0f ? kBf16One : xv < 0.0f ? kBf16MinusOne : (unsigned short)0;
-          }
-        }
-        if (xlds[i] >= 0) {
-#pragma unroll
-          for (int kx = 0; kx < KS; ++kx) {
-            u32x4 hv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hv[e] = (unsigned)s[ST * (2 * e) + kx] | ((unsigned)s[ST * (2 * e + 1) + kx] << 16);
-            *reinterpret_cast<u32x4*>(bsx + kx * bplane + xlds[i] + 0) = hv;
-          }
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const half8 ah = *reinterpret_cast<const half8*>(a_hi + a_off[ks]);
-        const half8 am = *reinterpret_cast<const half8*>(a_mid + a_off[ks]);
-        const half8 al = *reinterpret_cast<const half8*>(a_lo + a_off[ks]);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int sub = j / T, tap = j - sub * T, ky = tap / KS, kx = tap - ky * KS;
-          const half8 b = *reinterpret_cast<const half8*>(bsx + kx * bplane + b_off[ks] +
-                                                          (sub * 16 * BR + ky) * BROW);
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, b, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b, acc[j], 0, 0, 0);
+          xq[i][e] = buf_ld(r_x, ve, x_soff);
         }
       }
     }
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = e < g_nv ? gq[i][e] : 0.0f;  // (past the row's end the next row was read)
+      half8 hi, mid, lo;
+      split8(v, hi, mid, lo);
+      *reinterpret_cast<half8*>(a_hi + glds[i]) = hi;
+      *reinterpret_cast<half8*>(a_mid + glds[i]) = mid;
+      *reinterpret_cast<half8*>(a_lo + glds[i]) = lo;
+    }
+    // KS copies of sign(x): copy kx holds sx[ST*p + kx - PD] at slot p
+#pragma unroll
+    for (int i = 0; i < SI; ++i) {
+      u16 sv[NE];  // sx[ST*8j-PD .. ST*(8j+7)+PD]
+      [[maybe_unused]] unsigned vo = 0u, x_soff = 0u;
+      if constexpr (XP) {
+        x_soff = (unsigned)((cn * q.cw64 + (c0 >> 6)) * HWx) * 8u;
+        const int yrow = ST * cy0 - PD;
+        vo = (unsigned)(yrow + xpr[i]) < (unsigned)q.Hx ? (unsigned)(xbase[i] + yrow * q.Wx * XB) : kOOB;
+      }
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const bool in = e < x_nv[i];
+        if constexpr (XP) {
+          // (one dword per pixel and plane: 16-byte loads of two pixels measured 5 % faster and returned wrong data —
+          // hipcc 7.2 mis-lowers the multi-dword buffer-load builtins, see csrc/bconv_core.h)
+          const unsigned ve = e < PD ? (xfirst[i] ? kOOB : vo - (unsigned)XB * (PD - e)) : vo + (unsigned)XB * (e - PD);
+          const unsigned pw = __float_as_uint(buf_ld(r_x, ve, x_soff)), mw = __float_as_uint(buf_ld(r_x2, ve, x_soff));
+          sv[e] = (in && ((pw >> xbit[i]) & 1u)) ? kBf16One : (in && ((mw >> xbit[i]) & 1u)) ? kBf16MinusOne
+                                                                                             : (unsigned short)0;
+        } else {
+          const float xv = in ? xq[i][e] : 0.0f;
+          sv[e] = xv > 0.0f ? kBf16One : xv < 0.0f ? kBf16MinusOne : (unsigned short)0;
+        }
+      }
+      if (xlds[i] >= 0) {
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          u32x4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[e] = (unsigned)sv[ST * (2 * e) + kx] | ((unsigned)sv[ST * (2 * e + 1) + kx] << 16);
+          *reinterpret_cast<u32x4*>(bsx + kx * bplane + xlds[i] + 0) = hv;
+        }
+      }
+    }
+  };
+  // The loads of chunk i + 1 are issued in front of the MFMAs of chunk i and consumed behind them IN THE SAME ITERATION
+  // (values that are live around the back edge meet the first chunk's in phi copies, and a copy waits for its load —
+  // measured in the ISA: the pipelining was gone).
+  const int per_img = (q.H + q.R - 1) / q.R, total = (n_end - n_begin) * per_img;
+  int n = n_begin, y0 = 0;       // the chunk whose loads are issued next
+  auto advance = [&]() __attribute__((always_inline)) {
+    cn = n; cy0 = y0;
+    y0 += q.R;
+    if (y0 >= q.H) { y0 = 0; ++n; }
+  };
+  if (total > 0) {
+    issue(n, y0, 0u);
+    advance();
+    commit();
+    __syncthreads();
+  }
+  for (int it = 0; it < total; ++it) {
+    // straight-line body: behind the last chunk the loads are all out of range (they return 0 without touching memory)
+    // and the commit fills tiles nobody reads — a branch around them puts the loaded registers behind copies again
+    issue(n, y0, it + 1 < total ? 0u : kOOB);
+    if (it + 1 < total) advance();
+    __builtin_amdgcn_sched_barrier(0);   // (the scheduler pulls the first selects of commit() — and their vmcnt wait — up here)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const half8 ah = *reinterpret_cast<const half8*>(a_hi + a_off[ks]);
+      const half8 am = *reinterpret_cast<const half8*>(a_mid + a_off[ks]);
+      const half8 al = *reinterpret_cast<const half8*>(a_lo + a_off[ks]);
+      // B fragments one sub-tile ahead: the LDS round trip of fragment j + 1 runs under the three MFMAs of fragment j
+      auto bfrag = [&](int j) __attribute__((always_inline)) {
+        const int sub = j / T, tap = j - sub * T, ky = tap / KS, kx = tap - ky * KS;
+        return *reinterpret_cast<const half8*>(bsx + kx * bplane + b_off[ks] + (sub * 16 * BR + ky) * BROW);
+      };
+      half8 b = bfrag(0);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const half8 bn = bfrag(j + 1 < NJ ? j + 1 : j);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, b, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b, acc[j], 0, 0, 0);
+        b = bn;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();            // every wave is done with the tiles of chunk `it`
+    commit();
+    __syncthreads();
   }
   // D layout: column = li (input channel within the half), row = 4 lg + r (output channel within the wave's 16)
   float* dst = part + (size_t)blockIdx.x * q.O * q.C * T;
@@ -647,16 +704,29 @@ int grad_wgrad_splits(int N, int O, int C, int ks) {
   return (N + per - 1) / per;
 }
 
+template <int ST, int KS, int NC, bool XP, int SI>
+static int launch_wgrad_si(const dim3& grid, size_t lds, hipStream_t s, const float* g, const float* x1, const float* x2,
+                           float* part, const GradGeo& q, int per) {
+  // more than 64 KB of dynamic LDS (82 KB for 7x7 outputs at stride 2, 69 KB for the 56x56 layers) needs the opt-in:
+  // per device and per kernel, set on every launch, always to the same constant (the CU's whole LDS)
+  if (KS == 3 && hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<ST, KS, NC, XP, SI>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds) != hipSuccess)
+    return BNN_HIP_ERR_LAUNCH;
+  hipLaunchKernelGGL((wgrad_kernel<ST, KS, NC, XP, SI>), grid, dim3(grad::NT), lds, s, g, x1, x2, part, q, per);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
 template <int ST, int KS, int NC, bool XP>
 static int launch_wgrad_k(const dim3& grid, size_t lds, hipStream_t s, const float* g, const float* x1, const float* x2,
                           float* part, const GradGeo& q, int per) {
-  // more than 64 KB of dynamic LDS (82 KB for 7x7 outputs at stride 2, 69 KB for the 56x56 layers) needs the opt-in:
-  // per device and per kernel, set on every launch, always to the same constant (the CU's whole LDS)
-  if (KS == 3 && hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<ST, KS, NC, XP>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynamicLds) != hipSuccess)
-    return BNN_HIP_ERR_LAUNCH;
-  hipLaunchKernelGGL((wgrad_kernel<ST, KS, NC, XP>), grid, dim3(grad::NT), lds, s, g, x1, x2, part, q, per);
-  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+  const int items = 16 * NC * (ST * q.RR + 2 * (KS / 2)) * (q.slot / 8);   // sign(x) fill items of a chunk
+  switch ((items + grad::NT - 1) / grad::NT) {
+    case 1: return launch_wgrad_si<ST, KS, NC, XP, 1>(grid, lds, s, g, x1, x2, part, q, per);
+    case 2: return launch_wgrad_si<ST, KS, NC, XP, 2>(grid, lds, s, g, x1, x2, part, q, per);
+    case 3: return launch_wgrad_si<ST, KS, NC, XP, 3>(grid, lds, s, g, x1, x2, part, q, per);
+    case 4: return launch_wgrad_si<ST, KS, NC, XP, 4>(grid, lds, s, g, x1, x2, part, q, per);
+    default: return BNN_HIP_ERR_UNSUPPORTED;    // (make_geo's slots keep a chunk at <= 1024 items)
+  }
 }
 
 // x_planes == 0: `xin` is the fp32 input (xin2 unused); else `xin` / `xin2` are its sign planes P / M.

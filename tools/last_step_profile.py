@@ -9,10 +9,10 @@ sel = [r for r in rows if end - win <= int(r["Start_Timestamp"]) and int(r["End_
 agg = collections.defaultdict(lambda: [0, 0])
 for r in sel:
     n = r["Kernel_Name"]
-    n = n.replace("void ", "").replace("bnn::", "").split("(")[0][:90]
+    n = n.replace("void ", "").replace("bnn::", "").split("(")[0].replace("at::native::", "")[:110]
     agg[n][0] += 1
     agg[n][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 tot = sum(v[1] for v in agg.values())
 print("kernels in the last %.1f ms: %d, busy %.2f ms" % (win / 1e6, len(sel), tot / 1e6))
-for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:32]:
+for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:48]:
     print("%8.3f ms %5d  %s" % (t / 1e6, c, n))
