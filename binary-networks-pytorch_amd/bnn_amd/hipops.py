@@ -670,9 +670,10 @@ def bconv_grad_input(g: torch.Tensor, x, packed: torch.Tensor, alpha: torch.Tens
     return gx
 
 
-def bconv_grad_weight(g: torch.Tensor, x, ksize: int = 3, stride: int = 1) -> torch.Tensor:
+def bconv_grad_weight(g: torch.Tensor, x, ksize: int = 3, stride: int = 1, reduce: bool = True) -> torch.Tensor:
     """dL/dWhat [O,C,k,k] of the binary 3x3/p1 or 1x1/p0 conv: correlation of g with sign(x).  ``x``: the fp32 input, or
-    its ``SavedAct`` (the sign planes are all this kernel needs of it) — same bits either way."""
+    its ``SavedAct`` (the sign planes are all this kernel needs of it) — same bits either way.  ``reduce=False``: the
+    kernel's split-K partial slabs ``[splits, O, C, k, k]`` as they are (``xnor_weight_backward`` adds them itself)."""
     g = _require_cuda_f32(g, "grad_output")
     if not isinstance(x, SavedAct):
         x = _require_cuda_f32(x, "input")
@@ -689,6 +690,8 @@ def bconv_grad_weight(g: torch.Tensor, x, ksize: int = 3, stride: int = 1) -> to
             native.check(lib.bnn_hip_bconv_grad_weight_f32(g.data_ptr(), x.data_ptr(), part.data_ptr(), splits,
                                                            N, O, C, H, W, ksize, stride, _stream(g.device)),
                          "bnn_hip_bconv_grad_weight_f32")
+        if not reduce:
+            return part
         return part[0] if splits == 1 else part.sum(0)
 
 
@@ -708,17 +711,23 @@ def xnor_what(w: torch.Tensor, center: bool, compute_alpha: bool) -> torch.Tenso
 
 
 def xnor_weight_backward(w: torch.Tensor, dwhat: torch.Tensor, center: bool, compute_alpha: bool) -> torch.Tensor:
-    """dL/dW from dL/dWhat through ``XNORWeightBinarizer`` (sign STE, alpha = mean|Wc|, centring) in one kernel."""
+    """dL/dW from dL/dWhat through ``XNORWeightBinarizer`` (sign STE, alpha = mean|Wc|, centring) in one kernel.
+    ``dwhat``: the gradient (``w``'s shape), or the split-K partial slabs ``[splits, *w.shape]`` of
+    ``bconv_grad_weight(..., reduce=False)`` — added inside the kernel, in slab order."""
     w = _require_cuda_f32(w.detach(), "weight")
     dwhat = _require_cuda_f32(dwhat, "weight gradient")
+    if dwhat.dim() == w.dim():
+        dwhat = dwhat.unsqueeze(0)
+    if tuple(dwhat.shape[1:]) != tuple(w.shape):
+        raise native.NativeError(f"bnn_amd: weight gradient {tuple(dwhat.shape)} does not belong to weight {tuple(w.shape)}")
     lib = native.require()
     O, C = w.shape[0], w.shape[1]
     kh, kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
     with torch.cuda.device(w.device):
         dw = torch.empty_like(w)
-        native.check(lib.bnn_hip_xnor_weight_backward_f32(w.data_ptr(), dwhat.data_ptr(), O, C, kh, kw, int(center),
-                                                          int(compute_alpha), dw.data_ptr(), _stream(w.device)),
-                     "bnn_hip_xnor_weight_backward_f32")
+        native.check(lib.bnn_hip_xnor_weight_backward_f32(w.data_ptr(), dwhat.data_ptr(), int(dwhat.shape[0]), O, C, kh, kw,
+                                                          int(center), int(compute_alpha), dw.data_ptr(),
+                                                          _stream(w.device)), "bnn_hip_xnor_weight_backward_f32")
     return dw
 
 

@@ -165,7 +165,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_bn_relu_maxpool_train_forward_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _f, _f] + [_vp] * 8
     lib.bnn_hip_bn_relu_maxpool_train_backward_f32.argtypes = [_vp] * 7 + [_i, _i, _i, _i] + [_vp] * 5
     lib.bnn_hip_xnor_weight_forward_f32.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]
-    lib.bnn_hip_xnor_weight_backward_f32.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]
+    lib.bnn_hip_xnor_weight_backward_f32.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]
     lib.bnn_hip_probe_int_alu.argtypes = [_i, _i, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), _vp]
     lib.bnn_hip_probe_clock.argtypes = [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _vp]

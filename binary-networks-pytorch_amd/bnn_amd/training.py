@@ -243,7 +243,11 @@ class BinaryConv2dTrainFusedFn(torch.autograd.Function):
                 packed, alpha = hipops.grad_pack_weight(hipops.xnor_what(w, center, compute_alpha))
                 gx = hipops.bconv_grad_input(g, x, packed, alpha, w.shape[2], stride[0])       # STE mask fused
             if need_w:
-                gwhat = hipops.bconv_grad_weight(g, x, w.shape[2], stride[0])
+                # the split-K slabs: up to 16 are added inside the hook's kernel (one workgroup per output channel walks them),
+                # the hundreds of a 64-channel layer by the library's parallel reduction
+                gwhat = hipops.bconv_grad_weight(g, x, w.shape[2], stride[0], reduce=False)
+                if gwhat.shape[0] > 16:
+                    gwhat = gwhat.sum(0)
             if need_b:
                 gb = g.sum(dim=(0, 2, 3))
         else:

@@ -157,8 +157,8 @@ int launch_bconv_fly(const ConvP& p, const void* x, int x_half, int flags, const
 // xnor_train.hip: XNORWeightBinarizer under autograd, value and backward
 int launch_xnor_what(const float* w, int O, int C, int taps, int center, int compute_alpha, float* what, float* alpha,
                      hipStream_t s);
-int launch_xnor_weight_bwd(const float* w, const float* dwhat, int O, int C, int taps, int center, int compute_alpha,
-                           float* dw, hipStream_t s);
+int launch_xnor_weight_bwd(const float* w, const float* dwhat, int splits, int O, int C, int taps, int center,
+                           int compute_alpha, float* dw, hipStream_t s);
 // bn_train.hip: training-mode BatchNorm (+ residual) (+ ReLU), forward and backward
 int bn_train_splits(int N, int C, int HW);
 int launch_bn_stats(const float* x, int N, int C, int HW, int splits, double* partial, hipStream_t s);

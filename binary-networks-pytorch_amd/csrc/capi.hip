@@ -590,15 +590,15 @@ int bnn_hip_xnor_weight_forward_f32(const float* w, int O, int C, int KH, int KW
   return bnn::launch_xnor_what(w, O, C, KH * KW, center != 0, compute_alpha != 0, what, alpha, static_cast<hipStream_t>(stream));
 }
 
-int bnn_hip_xnor_weight_backward_f32(const float* w, const float* dwhat, int O, int C, int KH, int KW, int center,
-                                     int compute_alpha, float* dw, void* stream) {
-  if (!w || !dwhat || !dw || O <= 0 || C <= 0 || KH <= 0 || KW <= 0) return BNN_HIP_ERR_INVALID_ARG;
+int bnn_hip_xnor_weight_backward_f32(const float* w, const float* dwhat, int splits, int O, int C, int KH, int KW,
+                                     int center, int compute_alpha, float* dw, void* stream) {
+  if (!w || !dwhat || !dw || O <= 0 || C <= 0 || KH <= 0 || KW <= 0 || splits <= 0) return BNN_HIP_ERR_INVALID_ARG;
   if (mulc(KH, KW) > 1024) return BNN_HIP_ERR_UNSUPPORTED;
-  if (mulc(O, C, KH, KW) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (mulc(O, C, KH, KW) > kMaxElems || mulc(mulc(O, C, KH, KW), splits) > 4 * kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
   if (!aligned(w, 4) || !aligned(dwhat, 4) || !aligned(dw, 4)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);
   BNN_RANGE();
-  return bnn::launch_xnor_weight_bwd(w, dwhat, O, C, KH * KW, center != 0, compute_alpha != 0, dw,
+  return bnn::launch_xnor_weight_bwd(w, dwhat, splits, O, C, KH * KW, center != 0, compute_alpha != 0, dw,
                                      static_cast<hipStream_t>(stream));
 }
 

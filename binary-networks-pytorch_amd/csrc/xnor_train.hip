@@ -4,8 +4,9 @@
 //     Wc = W - mean_c(W)            (center_weights)          alpha = mean |Wc| per output channel (bnn/ops.py:116-127)
 //     What = SignActivation(Wc) * alpha                        SignActivation.backward: grad * 1[|Wc| < 1] (bnn/ops.py:68-73)
 // which torch runs as ~6 element-wise / reduction kernels forward and ~8 backward per layer (19 layers: 1.2 ms of a
-// 21 ms ResNet-18 step).  Here: one wave per output channel, reductions in double with the fixed order of
-// pack_weight.hip (lane-strided partial sums + xor butterfly), so What carries the same alpha the forward kernels use.
+// 21 ms ResNet-18 step).  Here: one workgroup per output channel, reductions in double in a fixed order (thread-strided
+// partial sums, xor butterfly per wave, the wave sums in wave order): deterministic; alpha agrees with pack_weight.hip's
+// to the last bit or two of the double sum (both round the same mean to fp32).
 //     forward :  What[o,c,t] = sign(Wc) * alpha[o]
 //     backward:  dWc = dWhat * alpha * 1[|Wc| < 1] + sign(Wc) * (sum_{c,t} dWhat * sign(Wc)) / K        (compute_alpha)
 //                dWc = dWhat * 1[|Wc| < 1]                                                              (otherwise)
@@ -16,89 +17,112 @@ namespace bnn {
 
 namespace xt {
 constexpr int kMaxTaps = 1024;
-__device__ __forceinline__ double wave_sum(double v) {
+constexpr int NT = 256;  // one 4-wave workgroup per output channel (round 4a: one wave — 64 waves on 1024 SIMDs for a
+                         // 64-channel layer, every load a serial round trip: 15-26 us for 0.15-9 MB)
+// sum over the workgroup, every thread gets it: lane-strided partials -> xor butterfly per wave -> the four wave sums added
+// in wave order (a fixed order: deterministic)
+__device__ __forceinline__ double block_sum(double v, double* red) {
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
-  return v;
+  __syncthreads();                         // `red` may still be read from the sum before
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
 }
 __device__ __forceinline__ float sgn(float v) { return is_pos(v) ? 1.0f : is_neg(v) ? -1.0f : 0.0f; }
 
 // mean[t] over the input channels (0 when not centred) into LDS; returns alpha
 __device__ __forceinline__ float centre_and_alpha(const float* __restrict__ wo, int C, int taps, int center,
-                                                  int compute_alpha, float* mean) {
-  const int lane = threadIdx.x, K = C * taps;
-  for (int t = 0; t < taps; ++t) {
-    float m = 0.0f;
-    if (center) {
+                                                  int compute_alpha, float* mean, double* red) {
+  const int tid = threadIdx.x, K = C * taps;
+  if (center) {
+    for (int t = 0; t < taps; ++t) {
       double s = 0.0;
-      for (int c = lane; c < C; c += kWave) s += (double)wo[(size_t)c * taps + t];
-      m = (float)(wave_sum(s) / (double)C);
+      for (int c = tid; c < C; c += NT) s += (double)wo[(size_t)c * taps + t];
+      const float m = (float)(block_sum(s, red) / (double)C);
+      if (tid == 0) mean[t] = m;
     }
-    if (lane == 0) mean[t] = m;
+  } else {
+    for (int t = tid; t < taps; t += NT) mean[t] = 0.0f;
   }
   __syncthreads();
   if (!compute_alpha) return 1.0f;
   double s = 0.0;
-  for (int k = lane; k < K; k += kWave) s += (double)fabsf(wo[k] - mean[k % taps]);
-  return (float)(wave_sum(s) / (double)K);
+  for (int k = tid, t = tid % taps; k < K; k += NT, t = (t + NT) % taps) s += (double)fabsf(wo[k] - mean[t]);
+  return (float)(block_sum(s, red) / (double)K);
 }
 }  // namespace xt
 
-__global__ __launch_bounds__(64) void xnor_what_kernel(const float* __restrict__ w, int C, int taps, int center,
-                                                       int compute_alpha, float* __restrict__ what,
-                                                       float* __restrict__ alpha_out) {
+__global__ __launch_bounds__(xt::NT) void xnor_what_kernel(const float* __restrict__ w, int C, int taps, int center,
+                                                           int compute_alpha, float* __restrict__ what,
+                                                           float* __restrict__ alpha_out) {
   __shared__ float mean[xt::kMaxTaps];
-  const int o = blockIdx.x, lane = threadIdx.x, K = C * taps;
+  __shared__ double red[4];
+  const int o = blockIdx.x, tid = threadIdx.x, K = C * taps;
   const float* wo = w + (size_t)o * K;
-  const float alpha = xt::centre_and_alpha(wo, C, taps, center, compute_alpha, mean);
-  if (lane == 0 && alpha_out) alpha_out[o] = alpha;
-  for (int k = lane; k < K; k += kWave) what[(size_t)o * K + k] = xt::sgn(wo[k] - mean[k % taps]) * alpha;
+  const float alpha = xt::centre_and_alpha(wo, C, taps, center, compute_alpha, mean, red);
+  if (tid == 0 && alpha_out) alpha_out[o] = alpha;
+  for (int k = tid, t = tid % taps; k < K; k += xt::NT, t = (t + xt::NT) % taps)
+    what[(size_t)o * K + k] = xt::sgn(wo[k] - mean[t]) * alpha;
 }
 
-__global__ __launch_bounds__(64) void xnor_weight_bwd_kernel(const float* __restrict__ w, const float* __restrict__ dwhat,
-                                                             int C, int taps, int center, int compute_alpha,
-                                                             float* __restrict__ dw) {
+// dwhat: `splits` partial slabs [splits][O][C][taps] (the split-K partial sums of the weight-gradient kernel, added here
+// in slab order — one pass less than summing them first), or the gradient itself with splits == 1.
+__global__ __launch_bounds__(xt::NT) void xnor_weight_bwd_kernel(const float* __restrict__ w, const float* __restrict__ dwhat,
+                                                                 int splits, size_t slab, int C, int taps, int center,
+                                                                 int compute_alpha, float* __restrict__ dw) {
   __shared__ float mean[xt::kMaxTaps];
   __shared__ float dmean[xt::kMaxTaps];
-  const int o = blockIdx.x, lane = threadIdx.x, K = C * taps;
+  __shared__ double red[4];
+  const int o = blockIdx.x, tid = threadIdx.x, K = C * taps;
   const float* wo = w + (size_t)o * K;
-  const float* go = dwhat + (size_t)o * K;
   float* dwo = dw + (size_t)o * K;
-  const float alpha = xt::centre_and_alpha(wo, C, taps, center, compute_alpha, mean);
+  // dL/dWhat of this channel, summed over the slabs, parked in dw (every element is read back by the thread that wrote
+  // it, or behind a barrier)
+  for (int k = tid; k < K; k += xt::NT) {
+    const float* p = dwhat + (size_t)o * K + k;
+    float a = p[0];
+    for (int s = 1; s < splits; ++s) a += p[(size_t)s * slab];
+    dwo[k] = a;
+  }
+  const float alpha = xt::centre_and_alpha(wo, C, taps, center, compute_alpha, mean, red);   // (barriers inside)
   float gk = 0.0f;      // (sum dWhat * sign(Wc)) / K: the gradient that reaches Wc through alpha
   if (compute_alpha) {
     double s = 0.0;
-    for (int k = lane; k < K; k += kWave) s += (double)go[k] * (double)xt::sgn(wo[k] - mean[k % taps]);
-    gk = (float)(xt::wave_sum(s) / (double)K);
+    for (int k = tid, t = tid % taps; k < K; k += xt::NT, t = (t + xt::NT) % taps)
+      s += (double)dwo[k] * (double)xt::sgn(wo[k] - mean[t]);
+    gk = (float)(xt::block_sum(s, red) / (double)K);
   }
-  auto dvc = [&](int k) {
-    const float v = wo[k] - mean[k % taps];
-    const float ste = fabsf(v) < 1.0f ? go[k] * alpha : 0.0f;
+  auto dvc = [&](int k, int t) {
+    const float v = wo[k] - mean[t];
+    const float ste = fabsf(v) < 1.0f ? dwo[k] * alpha : 0.0f;
     return ste + xt::sgn(v) * gk;
   };
   if (center) {      // dW = dWc - mean over the input channels of dWc, per tap
     for (int t = 0; t < taps; ++t) {
       double s = 0.0;
-      for (int c = lane; c < C; c += kWave) s += (double)dvc(c * taps + t);
-      const float m = (float)(xt::wave_sum(s) / (double)C);
-      if (lane == 0) dmean[t] = m;
+      for (int c = tid; c < C; c += xt::NT) s += (double)dvc(c * taps + t, t);
+      const float m = (float)(xt::block_sum(s, red) / (double)C);
+      if (tid == 0) dmean[t] = m;
     }
     __syncthreads();
   }
-  for (int k = lane; k < K; k += kWave) dwo[k] = dvc(k) - (center ? dmean[k % taps] : 0.0f);
+  for (int k = tid, t = tid % taps; k < K; k += xt::NT, t = (t + xt::NT) % taps)
+    dwo[k] = dvc(k, t) - (center ? dmean[t] : 0.0f);
 }
 
 int launch_xnor_what(const float* w, int O, int C, int taps, int center, int compute_alpha, float* what, float* alpha,
                      hipStream_t s) {
   if (taps > xt::kMaxTaps) return BNN_HIP_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(xnor_what_kernel, dim3((unsigned)O), dim3(64), 0, s, w, C, taps, center, compute_alpha, what, alpha);
+  hipLaunchKernelGGL(xnor_what_kernel, dim3((unsigned)O), dim3(xt::NT), 0, s, w, C, taps, center, compute_alpha, what, alpha);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
-int launch_xnor_weight_bwd(const float* w, const float* dwhat, int O, int C, int taps, int center, int compute_alpha,
-                           float* dw, hipStream_t s) {
+int launch_xnor_weight_bwd(const float* w, const float* dwhat, int splits, int O, int C, int taps, int center,
+                           int compute_alpha, float* dw, hipStream_t s) {
   if (taps > xt::kMaxTaps) return BNN_HIP_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(xnor_weight_bwd_kernel, dim3((unsigned)O), dim3(64), 0, s, w, dwhat, C, taps, center, compute_alpha, dw);
+  hipLaunchKernelGGL(xnor_weight_bwd_kernel, dim3((unsigned)O), dim3(xt::NT), 0, s, w, dwhat, splits,
+                     (size_t)O * C * taps, C, taps, center, compute_alpha, dw);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 

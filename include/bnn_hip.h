@@ -61,7 +61,8 @@
 extern "C" {
 #endif
 
-/* ABI 13 (round 4): + bnn_hip_bn_act_f32 (eval-mode BatchNorm + residual + ReLU tail of the per-layer path).
+/* ABI 13 (round 4): + bnn_hip_bn_act_f32 (eval-mode BatchNorm + residual + ReLU tail of the per-layer path);
+ * bnn_hip_xnor_weight_backward_f32 takes `splits` partial slabs.
  * ABI 12 (round 4): + bnn_hip_probe_clock; + the training-side entry points bnn_hip_pack_act_ste_f32,
  * bnn_hip_bconv_grad_{input,weight}_packed_f32 (3-bit saved state), bnn_hip_bn_train_{workspace_bytes,forward,backward}_f32,
  * bnn_hip_bn_relu_maxpool_train_{forward,backward}_f32, bnn_hip_xnor_weight_{forward,backward}_f32;
@@ -432,13 +433,16 @@ int bnn_hip_bconv2d_f32(const bnn_hip_conv_desc* d, const float* x,
 /* XNORWeightBinarizer.forward under autograd (bnn/ops.py:129-140 with the STE of bnn/ops.py:68-73), value and backward
  * as one kernel each (torch: ~14 small kernels per layer and step).  w, what, dwhat, dw: fp32 [O, C, KH, KW].
  *   forward :  what = sign(Wc) * alpha[o],  Wc = w - mean over C (center),  alpha = mean |Wc| (compute_alpha) or 1;
- *              alpha (may be NULL) receives alpha[O] — the same reductions as bnn_hip_pack_weight_f32.
+ *              alpha (may be NULL) receives alpha[O] (fp64 sums in a fixed order; bnn_hip_pack_weight_f32's alpha to the
+ *              rounding of that sum).
  *   backward:  dw from dwhat = dL/dwhat:  dWc = dwhat * alpha * 1[|Wc| < 1] + sign(Wc) * sum(dwhat * sign(Wc)) / (C KH KW),
- *              dw = dWc - mean over C of dWc when centred.                                                            */
+ *              dw = dWc - mean over C of dWc when centred.  dwhat: `splits` >= 1 slabs [splits][O][C][KH][KW] that are
+ *              added here in slab order (ABI 13: the split-K partial sums of bnn_hip_bconv_grad_weight_f32 go in as they
+ *              are — no separate reduction pass); splits == 1: the gradient itself.                                    */
 int bnn_hip_xnor_weight_forward_f32(const float* w, int O, int C, int KH, int KW, int center, int compute_alpha,
                                     float* what, float* alpha, void* stream);
-int bnn_hip_xnor_weight_backward_f32(const float* w, const float* dwhat, int O, int C, int KH, int KW, int center,
-                                     int compute_alpha, float* dw, void* stream);
+int bnn_hip_xnor_weight_backward_f32(const float* w, const float* dwhat, int splits, int O, int C, int KH, int KW,
+                                     int center, int compute_alpha, float* dw, void* stream);
 
 /* Training-mode BatchNorm2d fused with what follows it in the reference's residual blocks:
  *     y = relu?( batch_norm_train(x) (+ residual) )          bnn/models/layers/res_block.py:40-56, resnet.py:150-153

@@ -49,12 +49,15 @@ stats1 = glob.glob(os.path.join(src, "stats1", "**", "*kernel_stats.csv"), recur
 if stats1:
     shutil.copy(stats1[0], os.path.join(dst, f"{tag}_bench_kernel_stats_1stream.csv"))
 
-for name in ("train.txt", "stem_ab.txt"):
+for name in ("train.txt", "stem_ab.txt", "grad_pmc.txt", "train_last_step.txt"):
     fn = os.path.join(src, name)
     if os.path.exists(fn) and fresh([fn]) and open(fn).read().strip():
         body = "\n".join(l for l in open(fn).read().splitlines() if "amdgpu.ids" not in l)
         open(os.path.join(dst, f"{tag}_{name}"), "w").write(
             f"# {name}: tools/gpu_profile.sh, commit {STAMP['commit']}\n" + body + "\n")
+
+for f in fresh(glob.glob(os.path.join(src, "roctx", "**", "*marker_api_stats.csv"), recursive=True))[:1]:
+    shutil.copy(f, os.path.join(dst, f"{tag}_roctx_marker_stats.csv"))
 
 # stem kernel: counters of tools/bench_stem.py (ONLY=default), separate passes
 sagg = collections.defaultdict(list)

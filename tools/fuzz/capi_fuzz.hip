@@ -155,8 +155,9 @@ int launch_xnor_what(const float* w, int O, int C, int taps, int, int, float* wh
   ++g_reached; REQUIRE(w && what && O > 0 && C > 0 && taps > 0 && taps <= 1024 && (long long)O * C * taps <= (1LL << 31) - 1);
   return BNN_HIP_OK;
 }
-int launch_xnor_weight_bwd(const float* w, const float* g, int O, int C, int taps, int, int, float* dw, hipStream_t) {
-  ++g_reached; REQUIRE(w && g && dw && O > 0 && C > 0 && taps > 0 && taps <= 1024 && (long long)O * C * taps <= (1LL << 31) - 1);
+int launch_xnor_weight_bwd(const float* w, const float* g, int splits, int O, int C, int taps, int, int, float* dw, hipStream_t) {
+  ++g_reached; REQUIRE(w && g && dw && splits > 0 && O > 0 && C > 0 && taps > 0 && taps <= 1024 && (long long)O * C * taps <= (1LL << 31) - 1 &&
+                       (long long)O * C * taps * splits <= 4 * ((1LL << 31) - 1));
   return BNN_HIP_OK;
 }
 int bn_train_splits(int N, int C, int) { int s = (1024 + C - 1) / C; s = s > 64 ? 64 : s; s = s > N ? N : s; return s < 1 ? 1 : s; }
@@ -334,7 +335,7 @@ int main(int argc, char** argv) {
                                                                pick_ptr<double>(), stream); break;
       case 26: st = bnn_hip_xnor_weight_forward_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(),
                                                     pick_int(), pick_ptr<float>(), pick_ptr<float>(), stream); break;
-      case 27: st = bnn_hip_xnor_weight_backward_f32(pick_ptr<float>(), pick_ptr<float>(), pick_int(), pick_int(), pick_int(),
+      case 27: st = bnn_hip_xnor_weight_backward_f32(pick_ptr<float>(), pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(),
                                                      pick_int(), pick_int(), pick_int(), pick_ptr<float>(), stream); break;
       case 28: st = bnn_hip_bn_act_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_ptr<float>(), pick_ptr<float>(),
                                        pick_ptr<float>(), pick_int(), pick_ptr<float>(), stream); break;

@@ -46,6 +46,11 @@ spmc f WRITE_SIZE
 # training path: gradient kernels per layer (library backward beside them) and the whole step
 { timeout 250 python "$R/tools/bench_grad.py" 2>&1 | tail -8; timeout 250 env BATCH=256 python "$R/tools/bench_train.py" 2>&1 | tail -2;
   timeout 250 python "$R/tools/bench_train.py" 2>&1 | tail -1; } > "$OUT/train.txt" 2>&1
+# counters of the gradient kernels (64->64 56x56 and 128->128 28x28) and the kernel breakdown of the last training step
+( cd "$R" && ONLY=0,2 bash tools/pmc_grad.sh > "$OUT/grad_pmc.txt" 2>&1; bash tools/r04_train_prof.sh > /dev/null 2>&1; cp gpurun_out/r4train/last_step.txt "$OUT/train_last_step.txt" 2>/dev/null )
+# roctx ranges of the C-ABI entry points in a marker trace (BNN_HIP_ROCTX=1)
+BNN_HIP_ROCTX=1 timeout 300 rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d "$OUT/roctx" -o roctx -- python "$R/bench.py" --engine fused --batch 32 --steps 3 --warmup 1 --spinup 2 --sustain 0 --no-extras --no-cpu-baseline --no-roofline > "$OUT/roctx.log" 2>&1
+cd /tmp
 # the two stem kernels side by side (bit-identity on ragged shapes, then timings)
 timeout 300 python "$R/tools/stem_ab.py" 2>&1 | tail -12 > "$OUT/stem_ab.txt"
 # VALU instructions per wave of every launch of one forward, from the SAME build (tools/kernel_roofline.py)

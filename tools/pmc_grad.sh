@@ -13,8 +13,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "grad3x3" not in k: continue
-        agg[(k.split("(")[0][-28:], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "grad_kernel" not in k: continue
+        agg[(k.split("(")[0].replace("void bnn::", "")[:40], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(agg.items()):
     print(k)
     for c, v in sorted(d.items()):
