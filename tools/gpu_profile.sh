@@ -9,7 +9,7 @@ timeout 900 python "$R/bench.py" --steps 20 --warmup 5 2>/dev/null | tail -1 > "
 timeout 300 python "$R/bench.py" --config c2 --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/bench_c2.json"
 timeout 600 python "$R/bench.py" --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > "$OUT/bench_c5.json"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python "$R/bench.py" --steps 20 --warmup 5 --sustain 0 --no-extras --no-cpu-baseline > "$OUT/stats.log" 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -o bench1 -- python "$R/bench.py" --steps 20 --warmup 5 --sustain 0 --streams 1 --no-extras --no-cpu-baseline --no-roofline > "$OUT/stats1.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -o bench1 -- python "$R/bench.py" --steps 20 --warmup 5 --spinup 200 --sustain 0 --streams 1 --no-extras --no-cpu-baseline --no-roofline > "$OUT/stats1.log" 2>&1   # (200 spin-up steps: the TRACE of this run is what tools/kernel_roofline.py reads, and traces above 8 MB are deleted below)
 if [ "${QUICK:-0}" = "1" ]; then   # bench lines, kernel-trace stats and the c2 one-stream CSV only (no PMC, training, stem A/B)
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2_1" -o bench_c2_1 -- python "$R/bench.py" --config c2 --steps 20 --warmup 5 --sustain 0 --no-extras --no-roofline --no-cpu-baseline > "$OUT/stats_c2_1.log" 2>&1
   find "$OUT" -name "*kernel_trace.csv" -size +8M -delete
