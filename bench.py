@@ -633,7 +633,13 @@ def bench_net(args, world, rank, device, info, timed):
                 key = f"{eng}_x{k}" if eng in ("graph", "graph_fresh") else eng
                 if key in engines or (c5 and eng.startswith("net_call")):   # (c5 asks for the fp16 stem: not the model default)
                     continue
+                if eng.startswith("net_call"):
+                    auto_fusion(net).calls.update(graph=0, eager=0, declined=0)
                 engines[key], _ = measure(eng, k, **({} if eng in NET_ENGINES else fused_kw))
+                if eng.startswith("net_call"):      # which tier the calls of this measurement took (and why not, if declined)
+                    engines[key]["calls"] = dict(auto_fusion(net).calls)
+                    if auto_fusion(net).reason:
+                        engines[key]["declined_because"] = auto_fusion(net).reason
             for key, rec_e in engines.items():
                 rec_e["what"] = ENGINE_NOTES[key[:-3] if key[-3:-1] == "_x" else key]
             auto_fusion(net).reset()        # (its executors and graphs are not needed any more)
