@@ -255,10 +255,7 @@ class FusedResNet(nn.Module):
                            and _is_float_layer(c1))
         # real-valued head (avgpool -> flatten -> fc, resnet.py:160-164) as one kernel when it is the canonical one
         fc, ap = m.fc, m.avgpool
-        fc_float = type(fc) is nn.Linear or (
-            isinstance(fc, nn.Linear) and type(getattr(fc, "activation_pre_process", None)) is nn.Identity
-            and type(getattr(fc, "weight_pre_process", None)) is nn.Identity
-            and type(getattr(fc, "activation_post_process", None)).__name__ == "Identity")
+        fc_float = _is_float_layer_linear(fc)
         self._head = None
         if fc_float and isinstance(ap, nn.AdaptiveAvgPool2d) and ap.output_size in (1, (1, 1)) \
                 and fc.weight.dtype == torch.float32 and fc.in_features * 16 <= 160 * 1024:
@@ -923,6 +920,35 @@ def eval_stem(model: nn.Module, x: torch.Tensor) -> Optional[torch.Tensor]:
     scale, shift = cached_fold(bn)
     y, _ = hipops.stem7x7(x, conv.weight, scale, shift, out_f32=True, out_packed=False)
     return y
+
+
+def eval_head(model: nn.Module, x: torch.Tensor) -> Optional[torch.Tensor]:
+    """``fc(flatten(avgpool(x), 1))`` of a ``ResNet`` (resnet.py:160-164) as the head kernel (``bnn_hip_avgpool_fc_f32``:
+    global average pool + real-valued Linear in one launch), or None (not applicable).  The transposed weight is kept on
+    the module until the weight is written or replaced."""
+    if not _tails_wanted(x):
+        return None
+    ap, fc = model.avgpool, model.fc
+    if (not isinstance(ap, nn.AdaptiveAvgPool2d) or ap.output_size not in (1, (1, 1)) or not isinstance(fc, nn.Linear)
+            or not _is_float_layer_linear(fc) or fc.weight.dtype != torch.float32 or fc.in_features != x.shape[1]
+            or fc.in_features * 16 > 160 * 1024 or not _no_hooks(ap, fc)):
+        return None
+    w = fc.weight
+    key = (id(w), w._version, w.data_ptr())
+    c = fc.__dict__.get("_bnn_head_wt")
+    if c is None or c[0] != key:
+        c = (key, w.detach().t().contiguous())
+        fc.__dict__["_bnn_head_wt"] = c
+    return hipops.avgpool_fc(x, c[1], None if fc.bias is None else fc.bias.detach())
+
+
+def _is_float_layer_linear(fc: nn.Module) -> bool:
+    """A stock ``nn.Linear``, or a binary-class Linear whose recipe is all-Identity (examples/cifar10.py:71 keeps ``fc``
+    real-valued that way)."""
+    return type(fc) is nn.Linear or (
+        isinstance(fc, nn.Linear) and type(getattr(fc, "activation_pre_process", None)) is nn.Identity
+        and type(getattr(fc, "weight_pre_process", None)) is nn.Identity
+        and type(getattr(fc, "activation_post_process", None)).__name__ == "Identity")
 
 
 def _pair2(v):
