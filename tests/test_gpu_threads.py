@@ -113,8 +113,12 @@ def test_two_threads_drive_the_two_slots_of_a_pipelined_executor():
                 with torch.cuda.stream(pipe.stream(k)):
                     pipe.input(k).copy_(batches[k][r], non_blocking=True)
                 out = pipe.launch(k)
+                # the slot's buffer is overwritten by the slot's next launch: copy it out IN THE SLOT'S STREAM ORDER (a
+                # clone on the thread's default stream can sit behind the other slot's replay in a shared hardware queue
+                # and read the buffer after the next launch has rewritten it)
+                with torch.cuda.stream(pipe.stream(k)):
+                    got[k][r] = out.clone()
                 pipe.stream(k).synchronize()
-                got[k][r] = out.clone()
         return run
     _run_threads([worker(0), worker(1)])
     for k in range(2):
