@@ -870,14 +870,19 @@ def _no_hooks(*mods) -> bool:
     return not any(m is not None and (m._forward_hooks or m._forward_pre_hooks) for m in mods)
 
 
+# derived constants of the tails, per module: kept OUTSIDE the modules (weak keys), so that `state_dict()`, pickling and
+# `copy.deepcopy` of a model see nothing of them
+_FOLDS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+_HEAD_WEIGHTS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
 def cached_fold(bn: nn.BatchNorm2d):
-    """``fold_bn(bn)`` on ``bn``'s device, kept on the module until one of its four tensors is written or replaced."""
+    """``fold_bn(bn)`` on ``bn``'s device, kept until one of the module's four tensors is written or replaced."""
     ts = (bn.running_mean, bn.running_var, bn.weight, bn.bias)
     key = tuple((id(t), t._version, t.data_ptr()) if t is not None else None for t in ts) + (bn.eps,)
-    c = bn.__dict__.get("_bnn_fold")
+    c = _FOLDS.get(bn)
     if c is None or c[0] != key:
-        c = (key, fold_bn(bn))
-        bn.__dict__["_bnn_fold"] = c
+        c = _FOLDS[bn] = (key, fold_bn(bn))
     return c[1]
 
 
@@ -924,8 +929,8 @@ def eval_stem(model: nn.Module, x: torch.Tensor) -> Optional[torch.Tensor]:
 
 def eval_head(model: nn.Module, x: torch.Tensor) -> Optional[torch.Tensor]:
     """``fc(flatten(avgpool(x), 1))`` of a ``ResNet`` (resnet.py:160-164) as the head kernel (``bnn_hip_avgpool_fc_f32``:
-    global average pool + real-valued Linear in one launch), or None (not applicable).  The transposed weight is kept on
-    the module until the weight is written or replaced."""
+    global average pool + real-valued Linear in one launch), or None (not applicable).  The transposed weight is kept
+    until the weight is written or replaced."""
     if not _tails_wanted(x):
         return None
     ap, fc = model.avgpool, model.fc
@@ -935,10 +940,9 @@ def eval_head(model: nn.Module, x: torch.Tensor) -> Optional[torch.Tensor]:
         return None
     w = fc.weight
     key = (id(w), w._version, w.data_ptr())
-    c = fc.__dict__.get("_bnn_head_wt")
+    c = _HEAD_WEIGHTS.get(fc)
     if c is None or c[0] != key:
-        c = (key, w.detach().t().contiguous())
-        fc.__dict__["_bnn_head_wt"] = c
+        c = _HEAD_WEIGHTS[fc] = (key, w.detach().t().contiguous())
     return hipops.avgpool_fc(x, c[1], None if fc.bias is None else fc.bias.detach())
 
 

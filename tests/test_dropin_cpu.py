@@ -68,3 +68,36 @@ def test_foreign_resnet_class_swap_is_invisible_copyable_and_reversible():
     assert type(net) is foreign_resnet.ResNet and repr(net) == text
     # a model that is not laid out like the reference's ResNet is left alone
     assert not install_auto_fusion(torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3)))
+
+
+def test_the_cached_batchnorm_fold_follows_its_tensors_and_stays_out_of_the_module():
+    """bnn_amd/inference.py: cached_fold — the eval-mode BatchNorm constants of the per-layer tails are derived once per
+    state of the module's four tensors and live outside the module (nothing in __dict__ / state_dict / pickles)."""
+    import copy
+    import pickle
+    import torch
+    import torch.nn as nn
+    from bnn_amd.inference import cached_fold, fold_bn
+    bn = nn.BatchNorm2d(6).eval()
+    with torch.no_grad():
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.running_mean.normal_()
+        bn.weight.normal_()
+        bn.bias.normal_()
+    keys0 = set(bn.__dict__)
+    a = cached_fold(bn)
+    assert cached_fold(bn) is a and set(bn.__dict__) == keys0
+    x = torch.randn(3, 6, 4, 4)
+    want = bn(x)
+    got = torch.addcmul(a[1].view(1, 6, 1, 1), x, a[0].view(1, 6, 1, 1))
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-6)
+    with torch.no_grad():
+        bn.running_var.mul_(4.0)                                  # in-place write: version counter
+    b = cached_fold(bn)
+    assert b is not a and torch.allclose(b[0], a[0] * 0.5, rtol=1e-4)
+    bn.bias = nn.Parameter(torch.zeros(6))                        # replaced tensor: identity
+    c = cached_fold(bn)
+    assert c is not b and torch.equal(c[0], b[0]) and torch.allclose(c[1], -bn.running_mean * c[0], rtol=1e-6, atol=1e-7)
+    clone = pickle.loads(pickle.dumps(copy.deepcopy(bn)))
+    assert set(clone.state_dict()) == set(bn.state_dict())
+    assert all(torch.equal(u, v) for u, v in zip(cached_fold(clone), fold_bn(bn)))
