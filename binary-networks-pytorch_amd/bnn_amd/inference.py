@@ -1067,6 +1067,11 @@ class BlockFusion:
             return None
         with self.lock:
             eng = self.engine
+            # (inside a caller's own graph capture nothing may be built or re-derived: an executor that is ready runs —
+            # its launches are plain kernels on the capturing stream — anything else falls to the per-layer path)
+            if torch.cuda.is_current_stream_capturing() and (eng is None or not eng._unchanged()):
+                self.calls["declined"] += 1
+                return None
             if eng is None:
                 sig = _param_signature(block)
                 if self.failed_sig == sig:
@@ -1225,6 +1230,14 @@ class AutoFusion:
                 if eng is None or eng.model.fc.weight.device != x.device or (
                         eng.hooked() if eng.model is model else self._hooked(model)):
                     return self._decline()
+                if torch.cuda.is_current_stream_capturing():
+                    # the caller is capturing a HIP graph of its own around `net(x)`: no graph replay inside a capture, no
+                    # second stream, nothing that synchronises — the executor's eager launches are plain kernels on the
+                    # capturing stream (an executor that is not built and checked yet cannot be built here: per layer)
+                    if not self.verified or eng._sig is None or not eng._unchanged():
+                        return self._decline()
+                    self.calls["eager"] += 1
+                    return eng._forward_impl(x)
                 if not self.verified:
                     return self._verify(eng, model, x)
                 key = (tuple(x.shape), torch.cuda.current_stream(x.device).cuda_stream)

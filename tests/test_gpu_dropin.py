@@ -503,3 +503,33 @@ def test_a_hook_on_a_batchnorm_keeps_that_module_a_module():
     assert seen == [(2, 64, 16, 16)]
     with torch.no_grad():
         assert torch.allclose(y, net(x), rtol=1e-3, atol=1e-3 * float(y.abs().max()))
+
+
+@pytest.mark.parametrize("tier", ["model", "block", "layer"])
+def test_net_call_inside_a_callers_own_graph_capture(tier):
+    """A caller that captures `net(x)` into a HIP graph of its own (after the usual warm-up calls): no graph replay inside
+    a capture, no second stream, nothing built or synchronised — the ready executor's launches (model / block tier) or the
+    per-layer launches are recorded, and the caller's graph replays to the same logits."""
+    from bnn_amd.inference import no_model_fusion
+    import contextlib
+    net = _r18()
+    xs = [dev(gen.normal(60 + i, (4, 3, 64, 64))) for i in range(3)]
+    want = [FusedResNet(net)(x).clone() for x in xs]
+    ctx = {"model": contextlib.nullcontext, "block": no_model_fusion, "layer": per_layer_forward}[tier]
+    static_x = xs[0].clone()
+    side = torch.cuda.Stream()
+    with torch.no_grad(), ctx():
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                net(static_x)                              # warm-up on a side stream, as for any captured callable
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = net(static_x)
+    for x, w in zip(xs, want):
+        static_x.copy_(x)
+        g.replay()
+        assert torch.equal(y, w)
+    if tier == "model":
+        assert auto_fusion(net).calls["eager"] >= 2         # the first call + the captured one
