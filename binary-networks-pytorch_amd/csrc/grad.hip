@@ -133,8 +133,8 @@ __global__ __launch_bounds__(64) void grad_pack_weight_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------- dgrad
-// GEMM: M = pixels (one 64-slot chunk of one image per workgroup), N = input channels c (16 * NSUB per wave,
-// 64 * NSUB per workgroup, grid.y blocks), K = (o, tap): loop over blocks of 32 output channels; per block the
+// GEMM: M = pixels (one 64-slot chunk of one image per workgroup; 32 slots per wave), N = input channels c (32 * NSUB
+// per wave, 64 * NSUB per workgroup, grid.y blocks), K = (o, tap): loop over blocks of 32 output channels; per block the
 // chunk's rows +- 1 of g' = alpha[o] * g enter LDS as fp16 hi / lo, [pixel][32 o]; 9 taps = 9 k-steps of 32.
 // Epilogue: accumulators -> LDS [c][pixel] -> coalesced NCHW stores with the STE mask 1[|x| < 1].
 // S2 (stride 2, 3x3): the four parity classes (py, px) of the x pixels are four convolutions over the GRID OF g —
@@ -170,24 +170,31 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
   const int n = blockIdx.x / q.chunks, y0 = (blockIdx.x - n * q.chunks) * q.R;
   const int HW = q.Hx * q.Wx, HGg = q.Hg * q.Wg;  // pixels of a channel plane of x / gx; of g
   const int CS = (q.C + 15) / 16, OB = (q.O + 31) / 32;
-  const int cs0 = (blockIdx.y * 4 + wave) * NSUB;  // first 16-channel group of this wave
+  // 2 x 2 register blocking: a wave owns TWO of the four 16-pixel sub-tiles and HALF of the workgroup's 4 NSUB channel
+  // groups — 6 A-fragment reads (hi / mid / lo x 2 sub-tiles) per tap for 12 NSUB MFMAs.  (Until late round 4: all four
+  // sub-tiles x a quarter of the channel groups, 12 reads for the same MFMAs — with 64 channels one 16-byte LDS read per
+  // lane and MFMA, 256 B/clk per CU at the full matrix rate against the LDS's 128 B/clk: matrix pipe 27 % busy, LDS 61 %.)
+  constexpr int NB = 2 * NSUB;                            // channel groups (B fragments) per wave
+  const int ph = wave & 1, chh = wave >> 1;               // pixel half, channel half
+  const int cs0 = blockIdx.y * 4 * NSUB + chh * NB;       // first 16-channel group of this wave
 
   // A-fragment base addresses of the 4 pixel sub-tiles: pixel m = 16 s + li -> (row ry, column x) of the chunk
-  int abase[4];
+  int abase[2];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
+  for (int i = 0; i < 2; ++i) {
+    const int s = 2 * ph + i;
     const int m = 16 * s + li;
     int ry = m / q.slot, x = m - ry * q.slot;
     if (x >= q.W || ry >= q.R) { ry = 0; x = 0; }  // dead slot: any valid address, result is never stored
     // tap (ky,kx) reads patch pixel (ry+2PD-ky, x+2PD-kx); S2: (ry + dy, x + dx) from the patch's own origin
-    abase[s] = S2 ? (ry * PW + x) * APIX + 8 * lg : ((ry + 2 * PD) * PW + (x + 2 * PD)) * APIX + 8 * lg;
+    abase[i] = S2 ? (ry * PW + x) * APIX + 8 * lg : ((ry + 2 * PD) * PW + (x + 2 * PD)) * APIX + 8 * lg;
   }
 
-  f32x4 acc[4][NSUB];
+  f32x4 acc[2][NB];
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int ns = 0; ns < NSUB; ++ns) acc[s][ns] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ns = 0; ns < NB; ++ns) acc[i][ns] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- fill roles, once per workgroup: wave w fills output channels 8 w .. 8 w + 7 of every 32-channel block (wave-
   // uniform: alpha and the channel's plane offset are scalar), lane l the patch pixels l, l + 64, ...  The pixel's byte
@@ -221,14 +228,14 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
 
   for (int ob = 0; ob < OB; ++ob) {
     __syncthreads();  // previous block's patch is consumed
-    auto load_w = [&](half8 (&dst)[NSUB], int tap) {
+    auto load_w = [&](half8 (&dst)[NB], int tap) {
 #pragma unroll
-      for (int ns = 0; ns < NSUB; ++ns) {
+      for (int ns = 0; ns < NB; ++ns) {
         const int cs = cs0 + ns;
         dst[ns] = cs < CS ? Bp[((size_t)(ob * T + tap) * CS + cs) * 64 + lane] : bf16_const8(0);
       }
     };
-    half8 b[NSUB];
+    half8 b[NB];
     load_w(b, tap_of(0));
     const int o0 = 32 * ob + 8 * wave;
     float av[8];
@@ -266,35 +273,35 @@ __global__ __launch_bounds__(grad::NT) void dgrad_kernel(const float* __restrict
       const int toff = S2 ? -((((py + 1 - ky) >> 1) * PW + ((px + 1 - kx) >> 1)) * APIX) : (ky * PW + kx) * APIX;
       // the NEXT tap's sign(W) fragments are requested before this tap's MFMAs (tap 0's before the fill): a load in
       // front of its own MFMAs exposed one L2 round trip per tap, 18 per workgroup at 64 channels
-      half8 bn[NSUB];
+      half8 bn[NB];
 #pragma unroll
-      for (int ns = 0; ns < NSUB; ++ns) bn[ns] = b[ns];
+      for (int ns = 0; ns < NB; ++ns) bn[ns] = b[ns];
       if (ti + 1 < ntap) load_w(bn, tap_of(ti + 1));
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const half8 ah = *reinterpret_cast<const half8*>(pa_hi + abase[s] - toff);
-        const half8 am = *reinterpret_cast<const half8*>(pa_mid + abase[s] - toff);
-        const half8 al = *reinterpret_cast<const half8*>(pa_lo + abase[s] - toff);
+      for (int i = 0; i < 2; ++i) {
+        const half8 ah = *reinterpret_cast<const half8*>(pa_hi + abase[i] - toff);
+        const half8 am = *reinterpret_cast<const half8*>(pa_mid + abase[i] - toff);
+        const half8 al = *reinterpret_cast<const half8*>(pa_lo + abase[i] - toff);
 #pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns) {  // smallest terms first
-          acc[s][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b[ns], acc[s][ns], 0, 0, 0);
-          acc[s][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, b[ns], acc[s][ns], 0, 0, 0);
-          acc[s][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[ns], acc[s][ns], 0, 0, 0);
+        for (int ns = 0; ns < NB; ++ns) {  // smallest terms first
+          acc[i][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b[ns], acc[i][ns], 0, 0, 0);
+          acc[i][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, b[ns], acc[i][ns], 0, 0, 0);
+          acc[i][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[ns], acc[i][ns], 0, 0, 0);
         }
       }
 #pragma unroll
-      for (int ns = 0; ns < NSUB; ++ns) b[ns] = bn[ns];
+      for (int ns = 0; ns < NB; ++ns) b[ns] = bn[ns];
     }
   }
   __syncthreads();  // the patch is dead: its LDS becomes the [channel][pixel] staging tile
   // D layout: column = li (channel within the 16-group), row = 4 lg + r (pixel within the sub-tile)
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int ns = 0; ns < NSUB; ++ns)
+    for (int ns = 0; ns < NB; ++ns)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        stage[((wave * NSUB + ns) * 16 + li) * SROW + 16 * s + 4 * lg + r] = acc[s][ns][r];
+        stage[((chh * NB + ns) * 16 + li) * SROW + 16 * (2 * ph + i) + 4 * lg + r] = acc[i][ns][r];
   __syncthreads();
   // A thread keeps ONE pixel of the chunk (its lane) and walks the channels wave, wave + 4, ...: the STE operand x of
   // all its 16 NSUB outputs is requested first (buffer loads: a dead pixel / channel is an out-of-range offset, the
