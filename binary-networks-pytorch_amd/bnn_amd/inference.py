@@ -13,6 +13,20 @@ binary layers as bit planes and only the residual stream is ever written in fp32
 
 ``FusedResNet`` shares the weights of the model it wraps; packed weights and folded BN constants
 are derived once (call ``refresh()`` after changing parameters).  Eval mode only.
+
+What is in this module, top to bottom:
+
+    fold_bn, tap_binary_inputs          eval-mode BatchNorm as one fma per channel (ATen's rounding); debug tap
+    FusedResNet / FusedBlocks           the executors: 18 launches per ResNet-18 forward, eager or as HIP graphs
+                                        (``capture``: whole forward over a static input; ``forward_fresh``: stem launch
+                                        on the caller's tensor + graph of the rest)
+    concurrent_streams                  streams that are checked to really run beside each other
+    PipelinedInference                  several batches in flight across calls (what ``bench.py`` replays)
+    per_layer_forward, no_model_fusion  switches for the tiers below (tests, bench engines)
+    eval_tail / eval_stem / eval_head   the per-layer path's one-launch tails (``library_tails`` switches them off)
+    TwoHalves                           two halves of one batch in flight inside one call
+    BlockFusion, AutoFusion             what ``block(x)`` / ``model(x)`` dispatch to by themselves (the drop-in tiers)
+    install_auto_fusion                 the same dispatch for ResNets of other packages (``prepare_binary_model``)
 """
 from __future__ import annotations
 
