@@ -101,3 +101,28 @@ def test_the_cached_batchnorm_fold_follows_its_tensors_and_stays_out_of_the_modu
     clone = pickle.loads(pickle.dumps(copy.deepcopy(bn)))
     assert set(clone.state_dict()) == set(bn.state_dict())
     assert all(torch.equal(u, v) for u, v in zip(cached_fold(clone), fold_bn(bn)))
+
+
+def test_the_folded_batchnorm_is_the_reference_forward_bit_for_bit():
+    """bnn_amd/inference.py: fold_bn — `fma(x, scale, shift)` with the constants rounded as ATen's CPU kernel rounds them
+    IS the reference's eval-mode BatchNorm (torch on the host, what `examples/cifar10.py` evaluates): every element equal,
+    2.6 M of them over four shapes incl. small variances.  (A last-bit difference in front of a sign() is a flipped
+    activation: the HIP epilogues and the one-launch tails evaluate exactly this expression.)"""
+    import torch
+    import torch.nn as nn
+    from bnn_amd.inference import fold_bn
+    torch.manual_seed(0)
+    for C, H in ((64, 56), (128, 28), (512, 7), (3, 33)):
+        bn = nn.BatchNorm2d(C).eval()
+        with torch.no_grad():
+            bn.running_var.uniform_(0.05, 4.0)
+            bn.running_mean.normal_()
+            bn.weight.normal_()
+            bn.bias.normal_()
+        x = torch.randn(8, C, H, H) * 3
+        with torch.no_grad():
+            want = bn(x)
+        scale, shift = fold_bn(bn)
+        # the product of two fp32 values is exact in fp64; one rounding to fp32 behind the sum: an fma
+        got = (x.double() * scale.double().view(1, C, 1, 1) + shift.double().view(1, C, 1, 1)).float()
+        assert torch.equal(got, want), (C, H, int((got != want).sum()))
