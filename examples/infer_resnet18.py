@@ -4,7 +4,8 @@ activations, first and last layer real-valued) on one MI355X:
 
   1. drop-in      model(x)                     the reference's own call: the fused executor by itself (AutoFusion: stem
                                                launch on the caller's tensor + HIP graph of the rest, two halves in flight)
-  2. per layer    per_layer_forward()          every binary layer = one launch, torch BatchNorm / ReLU / add
+  2. per layer    per_layer_forward()          every binary layer = one launch, every BatchNorm (+ add) (+ ReLU) tail one
+                                               launch, stem and head their kernels; library_tails(): torch's own modules
   3. fused        FusedResNet(model)(x)        the executor, explicitly, eager launches
   4. pipelined    PipelinedInference(...)      HIP-graph replay, two batches in flight
 
@@ -22,7 +23,7 @@ import torch  # noqa: E402
 
 import bnn_amd as bnn  # noqa: E402
 from bnn_amd import checkpoint  # noqa: E402
-from bnn_amd.inference import FusedResNet, PipelinedInference, per_layer_forward  # noqa: E402
+from bnn_amd.inference import FusedResNet, PipelinedInference, library_tails, per_layer_forward  # noqa: E402
 from bnn_amd.models import resnet18  # noqa: E402
 from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer  # noqa: E402
 
@@ -65,19 +66,23 @@ def main():
 
     with torch.no_grad():
         with per_layer_forward():
-            y_ref = model(x)
+            y_layer = model(x)
             print("per layer  %9.0f images/s" % rate(lambda: model(x), 5))
+            with library_tails():                    # the reference's own formulation: torch stem / BatchNorm / ReLU / add
+                y_ref = model(x)
+                print("  (library tails %9.0f images/s)" % rate(lambda: model(x), 3))
         xs = [x, x + 0.01, x - 0.01]                 # a NEW tensor every call, as an eval loop delivers them
         it = iter(range(10 ** 9))
         print("drop-in    %9.0f images/s   (model(x), a new tensor every call)" % rate(
             lambda: model(xs[next(it) % 3]), 20))
         fused = FusedResNet(model)
         assert torch.equal(model(x), fused(x))       # the call and the explicit executor: same bits
+        assert torch.equal(y_layer, fused(x))        # ... and the per-layer path with its one-launch tails
         # folded BatchNorm (one fma) and torch's BatchNorm round differently; an activation that lands within an
         # ulp of 0 can therefore binarise differently and move that image's logits — a handful per thousand
         close = ((fused(x) - y_ref).abs().amax(dim=1) <= 1e-3 * y_ref.abs().max()).float().mean().item()
         assert close > 0.95, close
-        print("fused == drop-in to 1e-3 on %.1f %% of the images" % (100 * close))
+        print("fused == library composition to 1e-3 on %.1f %% of the images" % (100 * close))
         print("fused      %9.0f images/s" % rate(lambda: fused(x), 20))
         pipe = PipelinedInference(model, x)
         it = iter(range(10 ** 9))
