@@ -126,3 +126,51 @@ def test_the_folded_batchnorm_is_the_reference_forward_bit_for_bit():
         # the product of two fp32 values is exact in fp64; one rounding to fp32 behind the sum: an fma
         got = (x.double() * scale.double().view(1, C, 1, 1) + shift.double().view(1, C, 1, 1)).float()
         assert torch.equal(got, want), (C, H, int((got != want).sum()))
+
+
+def test_the_one_launch_tails_keep_out_of_everything_they_do_not_cover():
+    """bnn_amd/inference.py: eval_tail / eval_stem / eval_head return None — the caller then runs the modules themselves —
+    for CPU tensors, under autograd, with the library switch on, and for modules that carry hooks; the helpers that decide
+    it are plain host logic."""
+    import torch
+    import torch.nn as nn
+    import bnn_amd as bnn
+    from bnn_amd import inference
+    from bnn_amd.models import resnet18
+    from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer
+    cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
+                      weight_pre_process=XNORWeightBinarizer)
+    net = bnn.prepare_binary_model(resnet18(num_classes=10), cfg, custom_config_layers_name={
+        "conv1": bnn.BConfig(), "fc": bnn.BConfig()}).eval()
+    x = torch.randn(2, 3, 32, 32)
+    bn, act = net.layer1[0].bn1, net.layer1[0].act1
+    with torch.no_grad():
+        assert inference.eval_tail(torch.randn(2, 64, 8, 8), bn, act) is None        # not on a HIP device
+        assert inference.eval_stem(net, x) is None and inference.eval_head(net, torch.randn(2, 512, 1, 1)) is None
+        y = net(x)                                                                    # the modules themselves
+    assert y.shape == (2, 10)
+    # real-valued layers kept by an all-Identity recipe count as float layers; binary ones do not
+    assert inference._is_float_layer(net.conv1) and inference._is_float_layer_linear(net.fc)
+    assert not inference._is_float_layer(net.layer1[0].conv1)
+    assert inference._is_float_layer(nn.Conv2d(3, 8, 3)) and inference._is_float_layer_linear(nn.Linear(4, 4))
+    # hooks: on the module itself, or global ones
+    assert inference._no_hooks(bn, act, None)
+    h = bn.register_forward_hook(lambda m, i, o: None)
+    assert not inference._no_hooks(bn, act)
+    h.remove()
+    g = nn.modules.module.register_module_forward_hook(lambda m, i, o: None)
+    assert not inference._no_hooks(bn)
+    g.remove()
+    assert inference._no_hooks(bn)
+    # the library switch nests
+    assert inference._LIBRARY_TAILS == 0
+    with inference.library_tails():
+        with inference.library_tails():
+            assert inference._LIBRARY_TAILS == 2
+        assert inference._LIBRARY_TAILS == 1
+    assert inference._LIBRARY_TAILS == 0
+    # two halves in flight: from 128 images of 224 x 224 on, by pixel count
+    assert inference.TwoHalves.wanted(torch.empty(128, 3, 224, 224, device="meta"))
+    assert not inference.TwoHalves.wanted(torch.empty(127, 3, 224, 224, device="meta"))
+    assert inference.TwoHalves.wanted(torch.empty(512, 3, 112, 112, device="meta"))
+    assert not inference.TwoHalves.wanted(torch.empty(1, 3, 4096, 4096, device="meta"))
