@@ -161,7 +161,7 @@ def packed_weight(layer, plan: Plan, sync: bool = True, fresh: bool = False) -> 
     it — and a layer that ever showed a zero is packed synchronously (mask-aware kernel) from then on."""
     master = layer.__dict__.get("_bnn_master")
     if master is not None:          # a DataParallel replica: cached on the layer it was replicated from
-        return _replica_packed_weight(layer, master, plan)
+        return _replica_packed_weight(layer, master, plan, fresh)
     w = layer.weight
     key = (w.data_ptr(), w._version, str(w.device), tuple(w.shape), plan.center, plan.compute_alpha)
     cached = layer.__dict__.get("_bnn_packed")
@@ -187,7 +187,7 @@ def packed_weight(layer, plan: Plan, sync: bool = True, fresh: bool = False) -> 
     return pw
 
 
-def _replica_packed_weight(layer, master, plan: Plan) -> hipops.PackedWeight:
+def _replica_packed_weight(layer, master, plan: Plan, fresh: bool = False) -> hipops.PackedWeight:
     """Packed weights of a ``DataParallel`` replica.  Its ``weight`` is a broadcast copy that is new on every forward
     (new storage, version 0), so the replica's own pointer / version say nothing; the values are those of the layer it
     was replicated from.  The pack is therefore keyed on the MASTER's weight (pointer, version, recipe) and kept on the
@@ -199,8 +199,10 @@ def _replica_packed_weight(layer, master, plan: Plan) -> hipops.PackedWeight:
     cache = master.__dict__.setdefault("_bnn_packed_replicas", {})
     dev = str(w.device)
     hit = cache.get(dev)
-    if hit is not None and hit[0] == key:
+    if hit is not None and hit[0] == key and not fresh:
         return hit[1]
+    # ``fresh`` (the training forward): never trust the cache — a ``.data`` write on the master does not move its
+    # version counter, and the fused backward re-derives What from the current values (forward and backward must agree)
     pw = hipops.pack_weight(w, plan.center, plan.compute_alpha, sync=True)
     cache[dev] = (key, pw)
     _bump("weight_packs")

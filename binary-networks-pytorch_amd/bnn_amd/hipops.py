@@ -227,7 +227,8 @@ def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: 
 
 def sign_thresholds(w: PackedWeight, bn_scale: torch.Tensor, bn_shift: torch.Tensor, bias=None, post_scale=None):
     """Integer form of ``sign(relu(bn(alpha * dot + bias)))`` for ``bconv2d_fused(..., sign_thresholds=...)``:
-    int32 ``[O, 2]`` = (bound T, flip word of the channel's 32-channel block), ``bit = (dot >= T) ^ flip``, derived on
+    int32 ``[O, 4]`` = (bound T, flip word of the channel's 32-channel block, the two comparands of the kernels'
+    two-instruction form of the test), ``bit = (dot >= T) ^ flip``, derived on
     the device with the epilogue's own float operations
     (include/bnn_hip.h: bnn_hip_sign_thresholds_f32).  Valid for THIS weight pack and THESE BatchNorm constants."""
     lib = native.require()
@@ -238,16 +239,18 @@ def sign_thresholds(w: PackedWeight, bn_scale: torch.Tensor, bn_shift: torch.Ten
     bias = _per_channel(bias, O, "bias")
     post_scale = _per_channel(post_scale, O, "post_scale")
     with torch.cuda.device(dev):
-        thr = torch.empty((O, 2), dtype=torch.int32, device=dev)
+        thr = torch.empty((O, 4), dtype=torch.int32, device=dev)
         native.check(lib.bnn_hip_sign_thresholds_f32(w.alpha.data_ptr(), _ptr(bias), _ptr(post_scale), bn_scale.data_ptr(),
                                                      bn_shift.data_ptr(), O, C * KH * KW, thr.data_ptr(), _stream(dev)),
                      "bnn_hip_sign_thresholds_f32")
     return thr
 
 
-def avgpool_fc(x: torch.Tensor, w_t: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    """``fc(flatten(avgpool(x)))`` of bnn/models/resnet.py:160-164 in one kernel.  ``x``: fp32 ``[N,C,H,W]``,
-    ``w_t``: the Linear weight transposed to ``[C,O]`` (contiguous), ``bias``: ``[O]`` or None."""
+def avgpool_fc(x: torch.Tensor, w_t: torch.Tensor, bias: Optional[torch.Tensor], one_kernel: bool = False) -> torch.Tensor:
+    """``fc(flatten(avgpool(x)))`` of bnn/models/resnet.py:160-164.  ``x``: fp32 ``[N,C,H,W]``,
+    ``w_t``: the Linear weight transposed to ``[C,O]`` (contiguous), ``bias``: ``[O]`` or None.
+    Two streaming launches through a workspace (``bnn_hip_avgpool_fc_ws_f32``); ``one_kernel``: the round-2 single
+    kernel (``bnn_hip_avgpool_fc_f32``: same means, another summation order of the product)."""
     x = _require_cuda_f32(x, "head input")
     w_t = _require_cuda_f32(w_t.detach(), "head weight")
     if x.dim() != 4 or w_t.dim() != 2 or w_t.shape[0] != x.shape[1]:
@@ -258,9 +261,15 @@ def avgpool_fc(x: torch.Tensor, w_t: torch.Tensor, bias: Optional[torch.Tensor])
     bias = _per_channel(bias, O, "head bias")
     with torch.cuda.device(x.device):
         out = torch.empty((N, O), dtype=torch.float32, device=x.device)
-        if N:
+        if N and one_kernel:
             native.check(lib.bnn_hip_avgpool_fc_f32(x.data_ptr(), N, C, H * W, w_t.data_ptr(), _ptr(bias), O,
                                                     out.data_ptr(), _stream(x.device)), "bnn_hip_avgpool_fc_f32")
+        elif N:
+            nbytes = int(lib.bnn_hip_avgpool_fc_workspace_bytes(N, C))
+            ws = torch.empty((max(nbytes, 16) + 3) // 4, dtype=torch.float32, device=x.device)
+            native.check(lib.bnn_hip_avgpool_fc_ws_f32(x.data_ptr(), N, C, H * W, w_t.data_ptr(), _ptr(bias), O,
+                                                       out.data_ptr(), ws.data_ptr(), nbytes, _stream(x.device)),
+                         "bnn_hip_avgpool_fc_ws_f32")
     return out
 
 

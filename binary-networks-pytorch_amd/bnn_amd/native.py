@@ -23,7 +23,7 @@ FLAG_ACT_NONNEG = 32
 FLAG_THROUGHPUT = 64
 STEM_EXACT_FP32 = 1
 STEM_FP16 = 4
-ABI_VERSION = 13
+ABI_VERSION = 14
 DTYPE_F32 = 0
 DTYPE_F16 = 1
 
@@ -42,7 +42,7 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_bconv_grad_weight_packed_f32", "bnn_hip_bn_train_workspace_bytes", "bnn_hip_bn_train_forward_f32",
     "bnn_hip_bn_train_backward_f32", "bnn_hip_bn_relu_maxpool_train_forward_f32",
     "bnn_hip_bn_relu_maxpool_train_backward_f32", "bnn_hip_xnor_weight_forward_f32", "bnn_hip_xnor_weight_backward_f32",
-    "bnn_hip_bn_act_f32",
+    "bnn_hip_bn_act_f32", "bnn_hip_avgpool_fc_workspace_bytes", "bnn_hip_avgpool_fc_ws_f32",
 )
 
 
@@ -145,6 +145,9 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_bconv2d_direct.argtypes = [ctypes.POINTER(ConvDesc), _vp, _i] + [_vp] * 6 + \
         [ctypes.POINTER(FlyPlan), _vp]
     lib.bnn_hip_avgpool_fc_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]
+    lib.bnn_hip_avgpool_fc_workspace_bytes.argtypes = [_i, _i]
+    lib.bnn_hip_avgpool_fc_workspace_bytes.restype = ctypes.c_size_t
+    lib.bnn_hip_avgpool_fc_ws_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp]
     lib.bnn_hip_sign_thresholds_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]
     lib.bnn_hip_grad_weight_pack_bytes.restype = ctypes.c_size_t
     lib.bnn_hip_grad_weight_pack_bytes.argtypes = [_i, _i, _i]

@@ -100,7 +100,9 @@ class ShardedInference(nn.Module):
         its own stream behind the kernels that produced the logits, and the calling stream goes straight on to its next
         batch instead of idling through a latency-bound 1 MB-per-rank collective.  The returned tensor is valid after
         ``wait()`` (or a device synchronisation); the NEXT ``forward_even`` of this object waits for the collective
-        before the model may overwrite the buffers it reads."""
+        before the model may overwrite the buffers it reads.  It is this object's ONE gather buffer: the next
+        ``forward_even(overlap=True)`` overwrites it — copy it out in stream order (``wait()``, then ``.clone()``) to
+        keep a step's logits across steps or to read them on another stream."""
         if overlap and self._pending is not None:
             self._pending.wait()
             self._pending = None

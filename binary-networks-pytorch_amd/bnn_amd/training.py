@@ -118,10 +118,14 @@ FUSED_BN = os.environ.get("BNN_AMD_TRAIN_FUSED_BN", "1") == "1"
 class BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, bn, relu):
+        # the kernels address NCHW: what is SAVED must be the contiguous tensor they ran on (a channels_last / strided
+        # input would otherwise reach the backward kernels with its own strides: wrong dx, dgamma, dbeta)
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
         y, mean, invstd = hipops.bn_train_forward(x, weight, bias, bn.running_mean, bn.running_var,
                                                   _momentum(bn), bn.eps, relu, residual)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        _stats_written(bn)
         ctx.relu, ctx.has_res = relu, residual is not None
         ctx.save_for_backward(x, y if relu else None, mean, invstd, weight)
         return y
@@ -135,6 +139,17 @@ class BNActFn(torch.autograd.Function):
             dres = gy            # no ReLU in between: the residual's gradient IS the incoming one
         return (dx if ctx.needs_input_grad[0] else None, dgamma if ctx.needs_input_grad[1] else None,
                 dbeta if ctx.needs_input_grad[2] else None, dres, None, None)
+
+
+def _stats_written(bn: nn.BatchNorm2d) -> None:
+    """The kernel has updated ``running_mean`` / ``running_var`` through raw pointers: bump their version counters (what an
+    in-place torch op would have done — caches keyed on ``_version``, e.g. ``inference.cached_fold``, must see the
+    change) and count the batch."""
+    for t in (bn.running_mean, bn.running_var):
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
 
 
 def _momentum(bn: nn.BatchNorm2d) -> float:
@@ -171,10 +186,10 @@ class StemTailFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, bn):
+        x = x.contiguous()   # (see BNActFn.forward)
         p, code, mean, invstd = hipops.bn_relu_maxpool_train_forward(x, weight, bias, bn.running_mean, bn.running_var,
                                                                     _momentum(bn), bn.eps)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        _stats_written(bn)
         ctx.save_for_backward(x, p, code, mean, invstd, weight)
         ctx.mark_non_differentiable(code)
         return p, code

@@ -72,6 +72,14 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       nz = count_nonzero<NW, NN>(pr, mr, 0);
     }
   }
+  // EP_MIDT on a single chunk: the popcount chains start from kMidtBias - nz / 2 (bconv_core.h: midt2_shift_in)
+  constexpr bool MIDT2 = EP == EP_MIDT && !MULTI && !WZ;
+  [[maybe_unused]] int midt_seed = 0;
+  [[maybe_unused]] unsigned long long midt_odd = 0ull;
+  if constexpr (MIDT2) {
+    midt_seed = kMidtBias - (nz >> 1);
+    midt_odd = __builtin_amdgcn_ballot_w64((nz & 1) != 0);
+  }
 #pragma unroll 1
   for (int obi = 0; obi < OBW; ++obi) {
   const int ob = ob0 + obi;
@@ -115,6 +123,16 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       // the scalar registers (8 values wait in VGPRs); multi-chunk kernels (16 or 32 values, a register file at its
       // occupancy step): after it
       if constexpr (DS && !MULTI) shortcut_values<NACC>(g, ob * kOCB + ps * NACC, sc, dsr, ds_nz, resv);
+      // two-instruction sign test: the pass's comparands as wave-uniform buffer loads (bconv_core.h: midt2_shift_in)
+      [[maybe_unused]] int midt_a[NACC];
+      if constexpr (MIDT2) {
+        // (unconditional: under `if (fullb)` the compiler zero-initialises the eight registers first — eight v_mov and a
+        // wait for every earlier load; channels past O lie beyond the descriptor's range and read as 0, unused)
+        const BufRsrc rt = make_rsrc_sized(epi.thr, (unsigned)g.O * (unsigned)(kThrStride * 4));
+#pragma unroll
+        for (int j = 0; j < NACC; ++j)
+          midt_a[j] = (int)buf_ld_u32s(rt, (unsigned)(kThrStride * (ob * kOCB + ps * NACC + j) + (NN ? 2 : 3)) * 4u);
+      }
       // compile-time profiles with a float epilogue: the counts are kept as the bit pattern of 2^23 + count (epilogue())
       constexpr bool SEEDED = !WZ && NACC % 2 == 0 && EP != EP_RUNTIME && EP != EP_MIDT;
 #pragma unroll
@@ -133,6 +151,7 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       } else {
         const size_t woff = (size_t)ps * (NACC * NW);
         if constexpr (WZ) stream_weights_wz<NW, NACC>(wblk + woff, zblk + woff, pr, mr, acc, nzacc);
+        else if constexpr (MIDT2) stream_weights<NW, NACC, NN, true, true, BNN_STREAM_ILP, true>(wblk + woff, pr, mr, acc, midt_seed);
         else stream_weights<NW, NACC, NN, true, EP == EP_MIDT>(wblk + woff, pr, mr, acc, SEEDED ? (int)kCountSeed : 0);
       }
       // ONE branch on `fullb` around everything that differs: with the late shortcut fetch and the epilogue under two
@@ -161,6 +180,16 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
         to_dot();
         if (fullb) epilogue<NACC, EP, true>(g, px, o0, acc, resv, epi, pbits, mbits, negnz);
         else epilogue<NACC, EP>(g, px, o0, acc, resv, epi, pbits, mbits, negnz);
+      } else if constexpr (MIDT2) {
+        if (fullb) {  // two vector instructions per channel (midt2_shift_in)
+#pragma unroll
+          for (int j = 0; j < NACC; ++j)
+            pbits = midt2_shift_in<NN>(pbits, acc[j], midt_a[j], epi.thr[kThrStride * (o0 + j)], midt_odd);
+        } else {      // a block past O: the guarded form on the plain counts
+#pragma unroll
+          for (int j = 0; j < NACC; ++j) acc[j] -= midt_seed;
+          epilogue<NACC, EP>(g, px, o0, acc, resv, epi, pbits, mbits, negnz, NN ? 2.0f : -2.0f);
+        }
       } else if (fullb) {
         if constexpr (RES_LATE_FETCH) prefetch_residual<NACC, EP, true>(g, px, o0, epi, resv);
         if constexpr (SEEDED) {
@@ -200,7 +229,8 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
   const bool rev = (ob + 1) * kOCB <= g.O;  // == fullb of every pass of this block
   uint32_t xorw = 0u;  // EP_MIDT: flip bits of this block's channels (blocks past O — zero tail words — have none)
   if constexpr (EP == EP_MIDT) {
-    if (ob * kOCB < g.O) xorw = (uint32_t)epi.thr[2 * (ob * kOCB) + 1];
+    if (ob * kOCB < g.O) xorw = (uint32_t)epi.thr[kThrStride * (ob * kOCB) + 1];
+    if (MIDT2 && NN && rev) xorw = ~xorw;  // the agreement form shifts in the COMPLEMENT of every bit of a full block
   }
   if constexpr (GSPLIT) store_packed_part<PASSES>(g, px, ob, part, pbits, mbits, epi, rev, xorw);
   else store_packed(g, px, ob, pbits, mbits, epi, rev, xorw);

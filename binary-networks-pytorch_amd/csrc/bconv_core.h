@@ -61,7 +61,7 @@ struct EpiArgs {
   uint32_t* outM;
   const float* pack_a;
   const float* pack_b;
-  const int32_t* thr;  // EP_MIDT: per channel {T, flip word of its 32-channel block}: bit = (dot >= T) ^ flip (bnn_hip.h)
+  const int32_t* thr;  // EP_MIDT: per channel {T, flip word of its 32-channel block, A_nn, A_tp}: bit = (dot >= T) ^ flip (bnn_hip.h)
 };
 
 #ifndef BNN_TILED_MIN_WAVES  // waves per SIMD the tiled kernels are register-allocated for
@@ -150,6 +150,10 @@ __device__ __forceinline__ BufRsrc make_rsrc_sized(const void* p, unsigned bytes
 __device__ __forceinline__ uint32_t buf_ld_u32(BufRsrc r, unsigned boff) {
   return __builtin_amdgcn_raw_buffer_load_b32(r, (int)boff, 0, 0);
 }
+// wave-uniform address (scalar offset only): every lane receives the same dword
+__device__ __forceinline__ uint32_t buf_ld_u32s(BufRsrc r, unsigned sboff) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, 0, (int)sboff, 0);
+}
 __device__ __forceinline__ float buf_ld(BufRsrc r, unsigned lane_boff, unsigned chan_boff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_boff, (int)chan_boff, 0));
 }
@@ -161,6 +165,7 @@ struct BufRsrc {};
 __device__ __forceinline__ BufRsrc make_rsrc(const void*) { return {}; }
 __device__ __forceinline__ BufRsrc make_rsrc_sized(const void*, unsigned) { return {}; }
 __device__ __forceinline__ uint32_t buf_ld_u32(BufRsrc, unsigned) { return 0u; }
+__device__ __forceinline__ uint32_t buf_ld_u32s(BufRsrc, unsigned) { return 0u; }
 __device__ __forceinline__ float buf_ld(BufRsrc, unsigned, unsigned) { return 0.0f; }
 __device__ __forceinline__ void buf_st(BufRsrc, unsigned, unsigned, float) {}
 #endif
@@ -432,7 +437,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
     for (int j = 0; j < NACC; ++j) {
       const int o = o0 + j;
       if (full || o < g.O) {
-        const bool bit = dot[j] * km + negnz >= e.thr[2 * o];
+        const bool bit = dot[j] * km + negnz >= e.thr[4 * o];
         if constexpr (FULL) pbits = shift_in(pbits, bit);
         else pbits |= (bit ? 1u : 0u) << (bit0 + j);
       }
@@ -533,6 +538,54 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
       }
     }
   }
+}
+
+// EP_MIDT, single-chunk kernels, full blocks: the sign test of a channel in TWO vector instructions (instead of
+// v_lshl_add + v_cmp + v_addc).  With nz = 2q + p the lane's non-zero inputs, T = 2a + t and `cnt` the channel's popcount:
+//   agreements   (NN):  2 cnt - nz >= T  <=>  cnt - q >= ceil(T / 2) + (p & T even)
+//   disagreements    :  nz - 2 cnt >= T  <=>  cnt - q <  floor(-T / 2) + 1 + (p & T odd)
+// Both are "cnt' < A + carry" with cnt' = cnt - q + kMidtBias (the popcount chain STARTS from kMidtBias - q: the VGPR addend
+// of its first v_bcnt, free), A per channel from the thresholds table (thr[4o + 2] / thr[4o + 3], csrc/thresholds.hip)
+// and the carry mask chosen from T's parity on the scalar unit:
+//   v_subbrev_co_u32 tmp, vcc, A, cnt', vcc     vcc <- borrow = (cnt' < A + carry), unsigned: hence the bias
+//   v_addc_co_u32    word, vcc, word, word, vcc  shifts the borrow in
+// A gfx9 vector instruction reads ONE scalar operand and the carry-in is one, so A has to be a vector register: it is
+// fetched as a wave-uniform BUFFER load (every lane the same address: one cache line, no vector-ALU work — a v_mov from
+// the scalar value would be the third instruction again), eight per pass, issued before the pass's popcount loop.
+// (The parity coupling cannot be removed: 2 cnt - nz has the parity of the LANE's nz, so the integer bound on cnt
+// differs by one between lanes of even and odd nz exactly when T has the other parity.)
+// The borrow is the bit itself for the disagreement form and its complement for the agreement form (the complement
+// joins the block's flip word, which is XORed into the finished word anyway).  "never" (T = 2^30) and "always"
+// (T = -kmax) need no special case: A saturates at 0 from below (cnt' >= 1) and nothing reaches 2^29.
+// Checked against the plain integer test by enumeration on the host (tests/test_midt_cpu.py) and on the device bit for
+// bit (tests/test_gpu_fused.py: the threshold planes equal the float epilogue's).
+constexpr int kMidtBias = 1 << 20;  // > K / 2 for every K the thresholds kernel accepts (K < 2^20)
+constexpr int kThrStride = 4;       // int32 per channel of the thresholds table: {T, flip word of the block, A_nn, A_tp}
+template <bool NN>
+__device__ __forceinline__ uint32_t midt2_shift_in(uint32_t word, int cnt, int A, int T, unsigned long long oddmask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int tmp;
+  if constexpr (NN) {
+    asm("s_bitcmp0_b32 %[T], 0\n\t"              // SCC = T even
+        "s_cselect_b64 vcc, %[odd], 0\n\t"
+        "v_subbrev_co_u32 %[tmp], vcc, %[a], %[cnt], vcc\n\t"
+        "v_addc_co_u32 %[w], vcc, %[w], %[w], vcc"
+        : [w] "+v"(word), [tmp] "=&v"(tmp)
+        : [T] "s"(T), [odd] "s"(oddmask), [cnt] "v"(cnt), [a] "v"(A)
+        : "vcc", "scc");
+  } else {
+    asm("s_bitcmp1_b32 %[T], 0\n\t"              // SCC = T odd
+        "s_cselect_b64 vcc, %[odd], 0\n\t"
+        "v_subbrev_co_u32 %[tmp], vcc, %[a], %[cnt], vcc\n\t"
+        "v_addc_co_u32 %[w], vcc, %[w], %[w], vcc"
+        : [w] "+v"(word), [tmp] "=&v"(tmp)
+        : [T] "s"(T), [odd] "s"(oddmask), [cnt] "v"(cnt), [a] "v"(A)
+        : "vcc", "scc");
+  }
+  return word;
+#else
+  return word;
+#endif
 }
 
 // Residual (shortcut) values of NACC channels for this lane's pixel.  Called at the START of a
@@ -768,10 +821,13 @@ constexpr int pick_wblock(int total) {
 #ifndef BNN_STREAM_ILP  // 2: config-2 kernel 208 -> 201 us (0.905 -> 0.936 of the int-ALU roofline), round 3
 #define BNN_STREAM_ILP 2
 #endif
-template <int NW, int NACC, bool NN = false, bool USEED = false, bool ONECHAIN = false, int ILP = BNN_STREAM_ILP>
+// VSEED (with USEED and ONECHAIN): the seed is a per-lane value (a VGPR addend of the chain's first v_bcnt: as free as the scalar one).
+template <int NW, int NACC, bool NN = false, bool USEED = false, bool ONECHAIN = false, int ILP = BNN_STREAM_ILP,
+          bool VSEED = false>
 __device__ __forceinline__ void stream_weights(const uint32_t* __restrict__ wrun,
                                                const uint32_t (&pr)[NW], const uint32_t (&mr)[NW],
                                                int (&acc)[NACC], [[maybe_unused]] int useed = 0) {
+  static_assert(!VSEED || (USEED && ONECHAIN), "a per-lane seed: single-chunk, one chain per channel");
   constexpr int WB = pick_wblock(NACC * NW);
   constexpr int NB = NACC * NW / WB;
   static_assert((NACC * NW) % WB == 0, "weight run must be a whole number of blocks");
@@ -807,7 +863,7 @@ __device__ __forceinline__ void stream_weights(const uint32_t* __restrict__ wrun
         constexpr int f = b * WB + e0 + k;
         constexpr int j = f / NW, i = f % NW;
         if constexpr (ONECHAIN) {
-          acc[j] = (USEED && i == 0) ? popc_acc_s(d[k], useed) : popc_acc(d[k], acc[j]);
+          acc[j] = (USEED && i == 0) ? (VSEED ? popc_acc(d[k], useed) : popc_acc_s(d[k], useed)) : popc_acc(d[k], acc[j]);
           (void)t0; (void)t1;
         } else {
           // the even chain continues from the running count (acc[j]: 0, the count seed, or the previous chunks' sum);

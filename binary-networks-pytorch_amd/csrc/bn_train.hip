@@ -258,8 +258,11 @@ __global__ __launch_bounds__(bnt::NT) void bn_relu_pool_fwd_kernel(const float* 
     for (int dx = 0; dx < 3; ++dx) {
       const int q = 2 * px - 1 + dx;
       if ((unsigned)r < (unsigned)H && (unsigned)q < (unsigned)W) {
-        const float v = fmaxf(fmaf(xb[(size_t)r * W + q], scale, shift), 0.0f);
-        if (v > best) { best = v; bc = 3 * dy + dx; }
+        // NaN survives the ReLU and wins the maximum, as in torch's relu + max_pool2d (a diverged run must not turn
+        // into all-zero activations with a finite loss)
+        const float t = fmaf(xb[(size_t)r * W + q], scale, shift);
+        const float v = t < 0.0f ? 0.0f : t;
+        if (v > best || v != v) { best = v; bc = 3 * dy + dx; }
       }
     }
   }

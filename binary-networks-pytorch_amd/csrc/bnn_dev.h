@@ -135,6 +135,10 @@ int launch_stem_rows(const float* x, const float* w, const float* bn_a, const fl
                       int W, int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_avgpool_fc(const float* x, const float* wt, const float* bias, float* out, int N, int C, int HW,
                       int O, hipStream_t stream);
+size_t avgpool_fc_workspace_bytes(int N, int C);
+bool avgpool_fc_ws_supported(int C, int HW);
+int launch_avgpool_fc_ws(const float* x, const float* wt, const float* bias, float* out, float* ws, int N, int C, int HW,
+                         int O, hipStream_t stream);
 size_t grad_weight_pack_bytes(int O, int C, int ks);
 int launch_grad_pack_weight(const float* what, int O, int C, int ks, void* packed, float* alpha, hipStream_t s);
 int launch_dgrad(const float* g, const float* alpha, const void* packed, const void* xin, int x_planes, float* gx, int N,

@@ -305,6 +305,29 @@ int bnn_hip_avgpool_fc_f32(const float* x, int N, int C, int HW, const float* w_
   return bnn::launch_avgpool_fc(x, w_t, bias, out, N, C, HW, O, static_cast<hipStream_t>(stream));
 }
 
+size_t bnn_hip_avgpool_fc_workspace_bytes(int N, int C) {
+  if (N <= 0 || C <= 0) return 0;
+  return bnn::avgpool_fc_workspace_bytes(N, C);
+}
+
+int bnn_hip_avgpool_fc_ws_f32(const float* x, int N, int C, int HW, const float* w_t, const float* bias, int O,
+                              float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !w_t || !out || N <= 0 || C <= 0 || HW <= 0 || O <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (!aligned(x, 4) || !aligned(w_t, 4) || !aligned(out, 4)) return BNN_HIP_ERR_INVALID_ARG;
+  if (mulc(N, C, HW) > 4 * kMaxElems || mulc(N, O) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (!bnn::avgpool_fc_ws_supported(C, HW)) {  // the one-kernel form needs no workspace
+    g_launches.fetch_add(1, std::memory_order_relaxed);
+    BNN_RANGE();
+    return bnn::launch_avgpool_fc(x, w_t, bias, out, N, C, HW, O, static_cast<hipStream_t>(stream));
+  }
+  if (!workspace || !aligned(workspace, 16) || workspace_bytes < bnn::avgpool_fc_workspace_bytes(N, C))
+    return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(2, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_avgpool_fc_ws(x, w_t, bias, out, static_cast<float*>(workspace), N, C, HW, O,
+                                   static_cast<hipStream_t>(stream));
+}
+
 static bool grad_ks_ok(int ksize) { return ksize == 1 || ksize == 3; }
 
 size_t bnn_hip_grad_weight_pack_bytes(int O, int C, int ksize) {
@@ -463,7 +486,8 @@ int bnn_hip_shortcut_fold_supported(const bnn_hip_conv_desc* d, int sc_C) {
 
 int bnn_hip_sign_thresholds_f32(const float* alpha, const float* bias, const float* post_scale, const float* bn_scale,
                                 const float* bn_shift, int O, int kmax, int32_t* thresholds, void* stream) {
-  if (!alpha || !thresholds || O <= 0 || kmax <= 0 || kmax >= (1 << 24)) return BNN_HIP_ERR_INVALID_ARG;
+  // (kmax < 2^20: the two-instruction form of the test biases its counts by 2^20 > kmax / 2, bconv_core.h kMidtBias)
+  if (!alpha || !thresholds || O <= 0 || kmax <= 0 || kmax >= (1 << 20)) return BNN_HIP_ERR_INVALID_ARG;
   if ((bn_scale == nullptr) != (bn_shift == nullptr)) return BNN_HIP_ERR_INVALID_ARG;
   if (!aligned(thresholds, 4)) return BNN_HIP_ERR_INVALID_ARG;
   g_launches.fetch_add(1, std::memory_order_relaxed);

@@ -34,6 +34,9 @@
 
 #include "bnn_dev.h"
 
+#ifndef BNN_ROWS_K16TAIL  // 1: the last k-step (k-row 20 and three zero rows) as v_mfma_f32_16x16x16_f16 (k-rows 20, 21)
+#define BNN_ROWS_K16TAIL 0
+#endif
 #ifndef BNN_ROWS_ABL  // timing ablations only (wrong results): 1 matrix, 2 epilogue, 4 fragment reads, 8 fetch + commit,
 #define BNN_ROWS_ABL 0  // 16 fp32 stores, 32 sign words
 #endif
@@ -67,6 +70,7 @@ constexpr int NSTEP = KSTEPS * PTH;                  // (pooled row, k-step) ste
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half4 = __attribute__((ext_vector_type(4))) _Float16;
 using half2v = __attribute__((ext_vector_type(2))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
 
   // ---- once: A fragments (hi, lo) of this wave's 2 channel tiles x 6 k-steps.
   // MFMA 16x16x32 A operand: lane holds A[i = li][k = 8*lg + e]  ->  channel 16*tt + li, k-row 4*ks + lg, kx = e - 1.
+  constexpr bool K16 = BNN_ROWS_K16TAIL != 0 && !HALF;
   half8 wh[KSTEPS][2], wl[KSTEPS][2];
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -160,7 +165,12 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
       const int o = 32 * nh + 16 * tt + li;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float v = (krow < CIN * KS && e >= 1) ? w[((size_t)(o * CIN + c) * KS + ky) * KS + e - 1] : 0.0f;
+        float v = (krow < CIN * KS && e >= 1) ? w[((size_t)(o * CIN + c) * KS + ky) * KS + e - 1] : 0.0f;
+        if (K16 && ks == KSTEPS - 1) {
+          // 16x16x16 A operand: lane holds A[i = li][k = 4*lg + e], e < 4: k-row 20 + (lg >> 1), kx slot 4*(lg & 1) + e
+          const int slot = 4 * (lg & 1) + e;
+          v = (lg < 2 && e < 4 && slot >= 1) ? w[((size_t)(o * CIN + CIN - 1) * KS + KS - 1) * KS + slot - 1] : 0.0f;
+        }
         const _Float16 h = (_Float16)v;
         wh[ks][tt][e] = h;
         wl[ks][tt][e] = (_Float16)(v - (float)h);
@@ -169,13 +179,20 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
   }
   // B operand: lane holds B[k = 8*lg + e][j = li] = patch[c][2*t + ky][2*(14*mg + lcol) + e] of conv pixel (t, 14*mg + lcol).
   // kb[ks]: byte offset of (k-row 4*ks + lg, conv row 0, column pair 14*mg + lcol); zero-weight k-rows read k-row 20.
+  // (LDS ADDRESSES, the base of the dynamic-LDS symbol included: added per read it is a `v_add_u32 v, 0, v` in front of
+  // every fragment request — the symbol's offset is only known to the assembler)
+  using lds_byte = __attribute__((address_space(3))) unsigned char;
+  using lds_word = __attribute__((address_space(3))) const uint32_t;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte*)lds_rows;
   uint32_t kb[KSTEPS];
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
     int krow = 4 * ks + lg;
     if (krow >= CIN * KS) krow = CIN * KS - 1;
     const int c = krow / KS, ky = krow - c * KS;
-    kb[ks] = (uint32_t)((c * ITH + ky) * ROWD + 2 * WPW * mg + lcol) * 4u;
+    kb[ks] = lds0 + (uint32_t)((c * ITH + ky) * ROWD + 2 * WPW * mg + lcol) * 4u;
+    if (K16 && ks == KSTEPS - 1)  // k-row 20 for every lane group, its kx slots 4*(lg & 1) .. + 3 (two column pairs)
+      kb[ks] = lds0 + (uint32_t)(((CIN - 1) * ITH + KS - 1) * ROWD + 2 * WPW * mg + lcol + 2 * (lg & 1)) * 4u;
   }
   // BN constants of the accumulator layout (register r of tile tt -> channel 32*nh + 16*tt + 4*lg + r)
   float ba[2][4], bb[2][4];
@@ -351,7 +368,7 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
     half8 fh[RING][2], fl[RING][2];
     // fragments of `rows` conv rows at the walking base of k-step ks into ring slot `slot`
     auto request = [&](int slot, int ks, int rows) {  // constants after unrolling
-      const uint32_t* p = reinterpret_cast<const uint32_t*>(lds_rows + kq[ks]);
+      lds_word* p = (lds_word*)(uintptr_t)kq[ks];
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
         if (d >= rows) continue;
@@ -360,13 +377,15 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
           fl[slot][d] = wl[ks][d];
           continue;
         }
-        u32x4 v;
-        v[0] = p[d * CONV_ROW_D + 0]; v[1] = p[d * CONV_ROW_D + 1]; v[2] = p[d * CONV_ROW_D + 2]; v[3] = p[d * CONV_ROW_D + 3];
+        const bool k16 = K16 && ks == KSTEPS - 1;  // two column pairs per lane
+        u32x4 v{0u, 0u, 0u, 0u};
+        v[0] = p[d * CONV_ROW_D + 0]; v[1] = p[d * CONV_ROW_D + 1];
+        if (!k16) { v[2] = p[d * CONV_ROW_D + 2]; v[3] = p[d * CONV_ROW_D + 3]; }
         fh[slot][d] = __builtin_bit_cast(half8, v);
         if constexpr (!HALF) {
-          u32x4 l;
+          u32x4 l{0u, 0u, 0u, 0u};
           l[0] = p[d * CONV_ROW_D + LO_D + 0]; l[1] = p[d * CONV_ROW_D + LO_D + 1];
-          l[2] = p[d * CONV_ROW_D + LO_D + 2]; l[3] = p[d * CONV_ROW_D + LO_D + 3];
+          if (!k16) { l[2] = p[d * CONV_ROW_D + LO_D + 2]; l[3] = p[d * CONV_ROW_D + LO_D + 3]; }
           fl[slot][d] = __builtin_bit_cast(half8, l);
         }
       }
@@ -376,7 +395,26 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
     f32x4 acc[2][2];
     // the MFMAs of one k-step on `rows` conv rows: product-type major, so that the accumulator chains of a step are
     // independent between two MFMAs on the same one
+    auto lo4 = [](half8 v) { return half4{v[0], v[1], v[2], v[3]}; };
     auto multiply = [&](int slot, int ks, int rows) {
+      if (K16 && ks == KSTEPS - 1) {  // (constant after unrolling) the same three products, 16 k per instruction
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+            if (d < rows) acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x16f16(lo4(wh[ks][tt]), lo4(fl[slot][d]), acc[d][tt], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+            if (d < rows) acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x16f16(lo4(wl[ks][tt]), lo4(fh[slot][d]), acc[d][tt], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+            if (d < rows) acc[d][tt] = __builtin_amdgcn_mfma_f32_16x16x16f16(lo4(wh[ks][tt]), lo4(fh[slot][d]), acc[d][tt], 0, 0, 0);
+        return;
+      }
       if constexpr (!HALF && !(BNN_ROWS_ABL & 1)) {
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -405,10 +443,16 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
     // BN of accumulator row d = conv row t of the tile (the ReLU is applied after the max-pool: max and relu commute
     // exactly); positions outside the conv output are MaxPool padding: 0 never beats a ReLU output
     auto bn_row = [&](float (&y)[2][4], int d, int t) {
+      using f32x2 = __attribute__((ext_vector_type(2))) float;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[tt][r] = fmaf(acc[d][tt][r], ba[tt][r], bb[tt][r]);
+        for (int r = 0; r < 4; r += 2) {  // two channels per v_pk_fma_f32: the same fma per element
+          const f32x2 v = __builtin_elementwise_fma(f32x2{acc[d][tt][r], acc[d][tt][r + 1]}, f32x2{ba[tt][r], ba[tt][r + 1]},
+                                                    f32x2{bb[tt][r], bb[tt][r + 1]});
+          y[tt][r] = v.x;
+          y[tt][r + 1] = v.y;
+        }
       if (!interior) {
         const bool in = col_in && (unsigned)(cy0 + t) < (unsigned)Hc;
 #pragma unroll
@@ -476,7 +520,12 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
       bn_row(carry, 0, 0);
     }
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) kq[ks] += (uint32_t)(CONV_ROW_D * 4);  // the stream starts at conv row 1
+    for (int ks = 0; ks < KSTEPS; ++ks) {  // the stream starts at conv row 1
+      kq[ks] += (uint32_t)(CONV_ROW_D * 4);
+      // opaque: folded into the reads' offsets instead, this row moves every fragment of the SECOND conv row of a step
+      // beyond ds_read2_b32's 8-bit offsets (four v_add_u32 per k-step and pooled row for their addresses)
+      asm volatile("" : "+v"(kq[ks]));
+    }
     ROWS_T(1)
     // The tile is a stream of 24 steps (pooled row, k-step) of 12 MFMAs on two conv rows.  The B fragments of step
     // s + AHEAD are requested BEFORE the MFMAs of step s are issued (ring of AHEAD + 1 fragment sets): with two waves

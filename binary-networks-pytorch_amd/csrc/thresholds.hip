@@ -8,8 +8,8 @@
 // (csrc/bconv.hip: epilogue()); the conv kernel then needs one integer compare per channel and pixel instead of
 // int->float, two fmas and a float compare — same bits by construction (tests/test_gpu_fused.py).
 // A monotone function crosses zero once, so the interval always touches an end of [-K, K] and ONE one-sided compare
-// is enough:   thr[2o] = T,   P  <=>  (dot >= T) XOR flip_o ,
-// with the flip bits of a 32-channel block gathered into one word that every thr[2o+1] of the block repeats
+// is enough:   thr[4o] = T,   P  <=>  (dot >= T) XOR flip_o ,
+// with the flip bits of a 32-channel block gathered into one word that every thr[4o+1] of the block repeats
 // (bit k = flip of channel 32*(o/32) + k): increasing channels have flip 0 and T = first dot whose bit is 1,
 // decreasing ones flip 1 and T = last such dot + 1; "always" is T = -K, "never" (a NaN constant too) T = 2^30.
 #include "bnn_dev.h"
@@ -60,8 +60,15 @@ __global__ __launch_bounds__(256) void sign_threshold_kernel(const float* __rest
   const unsigned long long fm = __ballot(in && flip);
   const uint32_t word = (threadIdx.x & 32) ? (uint32_t)(fm >> 32) : (uint32_t)fm;
   if (in) {
-    thr[2 * o] = T;
-    thr[2 * o + 1] = (int32_t)word;
+    // words 2, 3: the comparand of the two-instruction form of the test (bconv_core.h: midt2_shift_in), for the
+    // agreement count (non-negative activations) and for the disagreement count, both with the bias of the chains
+    constexpr int kBias = 1 << 20;
+    const int a_nn = (int)(((long long)T + 1 + 2 * kBias) >> 1);                    // ceil(T / 2) + bias
+    const long long tp = ((long long)2 + 2 * kBias - T) >> 1;                       // floor(-T / 2) + 1 + bias
+    thr[4 * o] = T;
+    thr[4 * o + 1] = (int32_t)word;
+    thr[4 * o + 2] = a_nn;
+    thr[4 * o + 3] = (int)(tp < 0 ? 0 : tp);
   }
 }
 

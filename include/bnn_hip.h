@@ -61,14 +61,16 @@
 extern "C" {
 #endif
 
-/* ABI 13 (round 4): + bnn_hip_bn_act_f32 (eval-mode BatchNorm + residual + ReLU tail of the per-layer path);
+/* ABI 14 (round 5): + bnn_hip_avgpool_fc_ws_f32 / bnn_hip_avgpool_fc_workspace_bytes (the head as two streaming launches
+ * through a workspace); the table of bnn_hip_sign_thresholds_f32 holds FOUR words per channel (was two) and kmax < 2^20.
+ * ABI 13 (round 4): + bnn_hip_bn_act_f32 (eval-mode BatchNorm + residual + ReLU tail of the per-layer path);
  * bnn_hip_xnor_weight_backward_f32 takes `splits` partial slabs.
  * ABI 12 (round 4): + bnn_hip_probe_clock; + the training-side entry points bnn_hip_pack_act_ste_f32,
  * bnn_hip_bconv_grad_{input,weight}_packed_f32 (3-bit saved state), bnn_hip_bn_train_{workspace_bytes,forward,backward}_f32,
  * bnn_hip_bn_relu_maxpool_train_{forward,backward}_f32, bnn_hip_xnor_weight_{forward,backward}_f32;
  * - BNN_HIP_STEM_STAGED and BNN_HIP_FLAG_WEIGHTS_LDS (those kernels are test-only now: csrc/legacy/);
  * stem tensors capped at the 32-bit buffer-descriptor range; size arithmetic of all validators saturating.          */
-#define BNN_HIP_ABI_VERSION 13
+#define BNN_HIP_ABI_VERSION 14
 #define BNN_HIP_OCB 32 /* output channels per weight block (padding granularity of O) */
 
 typedef enum bnn_hip_status {
@@ -149,7 +151,7 @@ typedef struct bnn_hip_epilogue {
   const float* pack_shift;
   int32_t out_c_offset;    /* see above; 0/0 = plain [N,O,Ho,Wo]        */
   int32_t out_c_total;
-  const int32_t* sign_thresholds; /* NULL, or [O][2] from bnn_hip_sign_thresholds_f32 for THIS alpha / bn_scale /
+  const int32_t* sign_thresholds; /* NULL, or [O][4] from bnn_hip_sign_thresholds_f32 for THIS alpha / bn_scale /
                                      bn_shift: used when the epilogue is exactly BN + ReLU -> planes only (no bias,
                                      scale, residual, fp32 output): the sign bit then comes from an integer compare
                                      of the dot — same bits as the float path, fewer instructions.  Ignored
@@ -179,9 +181,12 @@ typedef struct bnn_hip_epilogue {
 /* Per channel the integer dots (|dot| <= kmax = C*KH*KW) whose epilogue value
  *   fmaf(fmaf(alpha, dot, bias) [* post_scale], bn_scale, bn_shift)   is > 0.
  * Every step is monotone in dot, so that set is one-sided:  bit = (dot >= T) XOR flip.
- * thresholds[2o] = T; thresholds[2o+1] = the flip bits of o's 32-channel block as one word (bit k = channel
- * 32*(o/32)+k; every entry of a block repeats it).  Found by bisection with the conv epilogue's own float
- * operations.  Re-derive when any input changes.  (ABI 9; up to ABI 8 the table held {lo, span} of an interval.)   */
+ * thresholds[4o] = T; thresholds[4o+1] = the flip bits of o's 32-channel block as one word (bit k = channel
+ * 32*(o/32)+k; every entry of a block repeats it); thresholds[4o+2], [4o+3] = the comparands of the kernels'
+ * two-instruction form of the same test on the agreement / disagreement count (ceil(T/2) + 2^20 and
+ * max(floor(-T/2) + 1 + 2^20, 0): csrc/bconv_core.h midt2_shift_in).  Found by bisection with the conv epilogue's
+ * own float operations.  Re-derive when any input changes.  kmax < 2^20.
+ * (ABI 14: four words per channel; ABI 9-13: {T, flip}; up to ABI 8 the table held {lo, span} of an interval.)     */
 int bnn_hip_sign_thresholds_f32(const float* alpha, const float* bias, const float* post_scale,
                                 const float* bn_scale, const float* bn_shift, int O, int kmax,
                                 int32_t* thresholds, void* stream);
@@ -294,6 +299,16 @@ int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w,
  * out: float32 [N,O].  fp32 fmaf accumulation in index order; C*16 bytes of LDS (C <= 10240).       */
 int bnn_hip_avgpool_fc_f32(const float* x, int N, int C, int HW, const float* w_t, const float* bias,
                            int O, float* out, void* stream);
+/* ABI 14 — the same head as two launches through a caller-provided workspace (the library allocates nothing):
+ * a streaming average-pool kernel (coalesced loads, the same index-order fp32 sums) into the workspace, then the
+ * product as 16-image x 64-output tiles with the k range split over eight waves whose partial sums are added in
+ * segment order.  workspace: bnn_hip_avgpool_fc_workspace_bytes(N, C) bytes, 16-byte aligned, contents undefined
+ * before and after.  Shapes the two-launch form does not cover (C * 64 bytes of LDS above the CU's 160 KB) run the
+ * one-kernel form.  Per-image results do not depend on N or on the image's position in the batch.
+ * ResNet-18, batch 256: see profiles/ (round 5) — the one-kernel form is 28 us, latency-bound.                     */
+size_t bnn_hip_avgpool_fc_workspace_bytes(int N, int C);
+int bnn_hip_avgpool_fc_ws_f32(const float* x, int N, int C, int HW, const float* w_t, const float* bias,
+                              int O, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* XNOR-Net weight binarisation.  w: float32 [O,C,KH,KW] contiguous.
  *   center        != 0: subtract the mean over C per (o,ky,kx) first  (ops.py:130-132)

@@ -323,6 +323,76 @@ def make_stacks():
     np.savez_compressed(os.path.join(HERE, "stacks.npz"), **blob)
 
 
+class RefHBlockNet(nn.Module):
+    """BASELINE config 5's network, which the reference cannot construct itself (HBlock has no
+    `expansion` and rejects stride > 1), assembled here from the REFERENCE's own modules in the layout the build
+    defines (bnn_amd/models/resnet.py: ResNet(HBlock, [3, 4, 6, 3])): the reference's stem (resnet.py:93-96,150-153),
+    per stage an AvgPool2d(2, ceil, no pad count) in front of stride-2 stages, the reference's HBlock
+    (hierarchical_block.py:8-60) with a BN -> conv1x1 shortcut where the width changes, the reference's head
+    (resnet.py:160-164).  Same attribute names and Sequential indices as the build's model, so that the seeded state of
+    tests/golden/gen.py maps key by key."""
+
+    def __init__(self, depths=(3, 4, 6, 3)):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        inplanes = 64
+        for i, (planes, blocks) in enumerate(zip((64, 128, 256, 512), depths)):
+            stride = 1 if i == 0 else 2
+            stage = []
+            if stride != 1:
+                stage.append(nn.AvgPool2d(kernel_size=stride, stride=stride, ceil_mode=True, count_include_pad=False))
+            shortcut = None
+            if stride != 1 or inplanes != planes:
+                shortcut = nn.Sequential(nn.BatchNorm2d(inplanes), nn.Conv2d(inplanes, planes, 1, bias=False))
+            stage.append(RefHBlock(inplanes, planes, 1, shortcut, norm_layer=nn.BatchNorm2d))
+            inplanes = planes
+            for _ in range(1, blocks):
+                stage.append(RefHBlock(inplanes, planes, norm_layer=nn.BatchNorm2d))
+            setattr(self, f"layer{i + 1}", nn.Sequential(*stage))
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512, 1000)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+def make_hblock_net():
+    """G10: config 5 at its real size pinned to the reference's modules (task 6): 8 images 224x224
+    through RefHBlockNet([3, 4, 6, 3]) — logits + the sign checksums in front of all 51 binary convolutions, the same
+    scheme as resnet18_b256.npz — and the reference against itself (other conv backend, fp64)."""
+    net = bnn.prepare_binary_model(RefHBlockNet(), xnor_cfg(), custom_config_layers_name={"conv1": bnn.BConfig(),
+                                                                                         "fc": bnn.BConfig()})
+    load_state(net, seed=1)
+    net.eval()
+    x = gen.normal(gen.seed_of("c5", "b128"), (128, 3, 224, 224))[:8].copy()     # the first 8 images of the c5 test batch
+    y, names, h = _binary_inputs(net, x, batch=4)
+    with torch.backends.mkldnn.flags(enabled=False):
+        y2, _, h2 = _binary_inputs(net, x, batch=4)
+    y64, _, h64 = _binary_inputs(net.double(), x.astype(np.float64), batch=4)
+    net.float()
+    y64 = y64.astype(np.float32)
+
+    def compare(ya, ha, yb, hb):
+        flipped = np.any(ha != hb, 1)
+        ok = np.all(np.abs(ya - yb) <= 1e-3 * np.abs(yb).max() + 1e-3 * np.abs(yb), 1)
+        return {"images": int(ya.shape[0]), "within_tol": int(ok.sum()), "images_with_a_sign_flip": int(flipped.sum()),
+                "max_abs_logit_dev": float(np.abs(ya - yb).max()),
+                "max_dev_without_flip": float(np.abs(ya - yb)[~flipped].max()) if (~flipped).any() else 0.0}
+    self_check = {"max_abs_logit": float(np.abs(y).max()), "torch": torch.__version__,
+                  "ref_onednn_vs_ref_native_conv": compare(y2, h2, y, h), "ref_fp32_vs_ref_fp64": compare(y, h, y64, h64)}
+    print(json.dumps(self_check, indent=1))
+    assert len(names) == 3 * 16 + 3, names
+    np.savez_compressed(os.path.join(HERE, "hblock_net_b8.npz"), logits=y, sign_hash=h, logits_f64=y64, sign_hash_f64=h64,
+                        layers=np.array(names), state_keys=np.array(list(net.state_dict().keys())),
+                        self_check=np.array(json.dumps(self_check)))
+    print("hblock_net_b8", y.shape, h.shape)
+
+
 GRAD_CASES = ("c2_relu", "l2_0_c1_s2", "l3_ds_1x1")
 
 
@@ -356,7 +426,7 @@ def make_grads():
 
 ALL = {"ref_test_layers": make_ref_test_layers, "layers": make_layers, "resnet18": make_resnet18,
        "resnet18_b256": make_resnet18_b256, "blocks": make_blocks, "convert": make_convert,
-       "prenet": make_prenet, "stacks": make_stacks, "grads": make_grads}
+       "prenet": make_prenet, "stacks": make_stacks, "grads": make_grads, "hblock_net": make_hblock_net}
 
 if __name__ == "__main__":
     for which in (sys.argv[1:] or list(ALL)):   # no argument: every fixture

@@ -46,13 +46,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 # images (of 256) allowed to differ in at least one sign() from (the reference's fp32 forward, the reference evaluated
-# in fp64): the values measured on MI355X in rounds 2 and 3 (profiles/r03_c3_b256_parity_*.json: 2/3, 6/3, 3/2 — the
-# kernels are deterministic) + 1 for a driver / compiler change of the real-valued stem.  A regression from 2 flipped
-# images to 9 must not pass.
+# in fp64): exactly the values measured on MI355X in rounds 2, 3 and 4 (profiles/r0N_c3_b256_parity_*.json: 2/3, 6/3,
+# 6/3, 3/2 — the kernels are deterministic and the stem has been bit-stable for three rounds: no allowance on top).
+# A regression from 2 flipped images to 3 must not pass.
 # "layerwise" (round 4: the stem kernel and the one-launch BatchNorm tails of the per-layer path) computes the fused
 # executor's integers; "layerwise_library" (torch's own stem / BatchNorm / ReLU / add around the binary layers) is the
 # independent composition the 2/3 were measured on.
-MAX_FLIPPED = {"layerwise_library": (3, 4), "layerwise": (7, 4), "fused": (7, 4), "fused_exact_stem": (4, 3)}
+MAX_FLIPPED = {"layerwise_library": (2, 3), "layerwise": (6, 3), "fused": (6, 3), "fused_exact_stem": (3, 2)}
 # every flip starts where the reference's own fp32 rounding decides: behind the real-valued stem / first residual sums
 EARLY_LAYERS = ("layer1.", "layer2.0.conv1", "layer2.0.downsample")
 
@@ -180,9 +180,11 @@ def _binary_conv_names(net):
 
 def test_c5_hblock_3463_at_its_stated_size():
     """BASELINE config 5 at full size on one GPU's share: the build-defined ResNet(HBlock,[3,4,6,3]) (the
-    reference cannot construct it; its blocks are pinned by module fixtures), 224x224, 128 images,
-    fp16 MFMA stem.  Properties at full size + parity of the fused executor against the per-layer drop-in path
-    (torch BN/act/cat between HIP convs) on a sub-batch, judged on equal discrete state like config 3."""
+    reference cannot construct it), 224x224, 128 images, fp16 MFMA stem: properties at full size.
+    Parity (round 5): the first 8 images against the REFERENCE — tests/golden/hblock_net_b8.npz, the same [3,4,6,3]
+    stack assembled from the reference's own HBlock / BatchNorm / shortcut modules by tests/golden/make_golden.py
+    (`hblock_net`): fused executor and per-layer path both against its fp32 logits and the sign checksums in front of
+    all 51 binary convolutions, with the strict / counted split of config 3."""
     net = _r18(lambda: ResNet(HBlock, [3, 4, 6, 3]))
     x = torch.from_numpy(gen.normal(gen.seed_of("c5", "b128"), (128, 3, 224, 224))).to(DEV)
     fused16 = FusedResNet(net, stem_fp16=True)
@@ -192,15 +194,28 @@ def test_c5_hblock_3463_at_its_stated_size():
         assert torch.equal(fused16(x[lo:hi].contiguous()), y[lo:hi])
     fused16.capture(x)
     assert torch.equal(fused16(x), y)
-    names = _binary_conv_names(net)
+    g = np.load(os.path.join(HERE, "golden", "hblock_net_b8.npz"))
+    names = [str(n) for n in g["layers"]]
+    assert names == _binary_conv_names(net) or sorted(names) == sorted(_binary_conv_names(net))
     assert len(names) == 3 * 16 + 3                     # 16 HBlocks x 3 convs + 3 binary 1x1 shortcuts
+    assert [str(k) for k in g["state_keys"]] == list(net.state_dict().keys())      # the same model, key by key
+    ref, href = g["logits"], g["sign_hash"]
     xs = x[:8].contiguous()
-    yl, hl = _run_layerwise(net, xs, names)
-    yf, hf = _run_fused(net, xs, names)                 # default (fp32-class) stem
-    yl, hl, yf, hf = yl.cpu().numpy(), hl.cpu().numpy(), yf.cpu().numpy(), hf.cpu().numpy()
-    flipped = np.any(hl != hf, 1)
-    ok = np.all(np.abs(yf - yl) <= 1e-3 * np.abs(yl).max() + 1e-3 * np.abs(yl), 1)
-    assert ok[~flipped].all() and flipped.sum() <= 2, (flipped, np.abs(yf - yl).max(1))
+    report = {"reference_self_check": json.loads(str(g["self_check"]))}
+    for path, (yy, hh) in (("layerwise", _run_layerwise(net, xs, names)), ("fused", _run_fused(net, xs, names))):
+        rep, ok, flipped = _compare(yy.cpu().numpy(), hh.cpu().numpy(), ref, href, names)
+        report[path] = rep
+        # (1) strict: same integers everywhere => logits within 1e-3 (measured: 1e-5 of the largest logit)
+        assert ok[~flipped].all(), rep
+        assert rep["max_dev_without_flip"] <= 1e-4 * np.abs(ref).max(), rep
+        # (2) counted: 8 images x 51 layers; the reference against its own other conv backend flips some too (see the
+        # fixture's self check).  At most 2 of the 8 images may differ in a sign.
+        assert rep["images_with_a_sign_flip"] <= 2, rep
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "c5_b8_parity.json"), "w") as fh:
+            json.dump(report, fh, indent=1)
+    print(json.dumps({k: report[k] for k in ("layerwise", "fused")}))
     # the fp16 stem is a precision trade (5e-4 relative in the stem): same classes for almost every image
-    agree = (y[:8].argmax(1).cpu().numpy() == yl.argmax(1)).sum()
+    agree = (y[:8].argmax(1).cpu().numpy() == ref.argmax(1)).sum()
     assert agree >= 6

@@ -149,11 +149,11 @@ def test_bench_with_two_ranks_sharing_the_gpu(engine):
     assert rec["value"] > 0 and rec["scaling"] == "weak"
 
 
-def _run_worker(what):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+def _run_worker(what, nproc=2):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "helpers", "dist_worker.py"), what]
-    out = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="4"), capture_output=True, text=True,
-                         timeout=900)
+    out = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="4" if nproc <= 2 else "1"),
+                         capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0 and "DIST_WORKER_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
 
 
@@ -166,6 +166,78 @@ def test_two_ranks_even_and_ragged_shards_through_the_hip_executors():
 
 def test_two_ranks_ddp_gradients_with_hip_kernels_equal_one_process():
     _run_worker("ddp")
+
+
+# ---- round 5: world size 8 rehearsed on the one GPU ------------------------------------------------------------------
+
+@pytest.mark.parametrize("engine", ["graph", "net_call"])
+def test_bench_with_eight_ranks_sharing_the_gpu(engine):
+    """`bench.py --gpus 8 --backend gloo --batch 8`: what the driver's 8-GPU run executes, minus xGMI — the self-launch
+    of 8 ranks, `validate_gather` over 8 rank blocks on every rank, 8 per-rank step times, the rank -> device map and
+    the scaling-efficiency record against a stored N = 1 line."""
+    rec = _run_bench([sys.executable, "bench.py", "--gpus", "8", "--backend", "gloo", "--engine", engine, "--steps", "3",
+                      "--warmup", "1", "--spinup", "2", "--batch", "8", "--sustain", "0", "--no-cpu-baseline",
+                      "--no-roofline", "--no-extras"])
+    assert rec["n_gpus"] == 8 and rec["config"]["global_batch"] == 64 and rec["config"]["engine"] == engine
+    assert rec["dist"]["world_size"] == 8 and rec["dist"]["backend"] == "gloo" and rec["dist"]["launcher"] == "self"
+    assert rec["gather_check"]["ranks_checked"] == 8 and rec["gather_check"]["bit_equal"] is True
+    assert rec["gather_check"]["images_per_rank"] == 8
+    pr = rec["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 8 and 0 < pr["min"] <= pr["max"]
+    # LOCAL_RANK -> cuda:(LOCAL_RANK % visible GPUs): on this box every rank lands on the one GPU
+    n_dev = torch.cuda.device_count()
+    assert rec["dist"]["rank_devices"] == [r % n_dev for r in range(8)]
+    assert rec["value"] > 0 and rec["scaling"] == "weak"
+
+
+def test_rank_to_device_mapping(tmp_path):
+    """The launcher form of the driver (`torch.distributed.run`, RCCL): rank r of a node runs on cuda:LOCAL_RANK — set
+    from LOCAL_RANK alone, HIP_VISIBLE_DEVICES untouched — and an N > 1 line carries `scaling_efficiency` against a
+    stored N = 1 line of the same engine and per-GPU batch.  (One GPU here: world 1 through RCCL for the mapping, world
+    2 through gloo for the efficiency record.)"""
+    common = ["--steps", "3", "--warmup", "1", "--spinup", "2", "--batch", "16", "--sustain", "0", "--no-cpu-baseline",
+              "--no-roofline", "--no-extras"]
+    one = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                      "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "1"] + common,
+                     env_extra={"HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES", "0")})
+    assert one["dist"]["backend"] == "nccl" and one["dist"]["rank_devices"] == [0] and "scaling_efficiency" not in one
+    n1 = tmp_path / "n1.json"
+    n1.write_text(json.dumps(one))
+    two = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo"] + common,
+                     env_extra={"BNN_BENCH_N1_JSON": str(n1)})
+    eff = two["scaling_efficiency"]
+    assert eff["n1_value"] == one["value"] and eff["n1_source"].endswith("n1.json")
+    assert abs(eff["efficiency"] - two["value"] / 2 / one["value"]) < 1e-9 and 0.1 < eff["efficiency"] < 1.5
+
+
+def test_eight_ranks_even_and_ragged_shards_through_the_hip_executors():
+    """tests/helpers/dist_worker.py `inference` with 8 ranks on the one GPU: 16 images (even), 61 (five shards of 8 and
+    three of 7) and 13 (shards of 2 and 1) through `net(x)` + the gather == one process's logits bit for bit, and two
+    batches in flight with each batch's gather on its own stream."""
+    _run_worker("inference", nproc=8)
+
+
+def test_overlapped_gather_over_rccl_fifty_steps_with_changing_inputs(rccl_world1):
+    """`forward_even(overlap=True)` as bench.py's graph engines use it — the asynchronous RCCL all-gather behind the
+    slot's graph replay, the slot's NEXT replay waiting for it — for 50 steps on two slots with a different input every
+    step, EVERY step's gathered logits checked (round 4 checked the last launch of three repetitions)."""
+    net = _r18()
+    xs = [torch.from_numpy(gen.normal(300 + i, (8, 3, 64, 64))).to(DEV) for i in range(10)]
+    single = FusedResNet(net)
+    want = [single(x).clone() for x in xs]
+    pipe = PipelinedInference(net, xs[0], n_streams=2)
+    models = [ShardedInference(e, force_collective=True) for e in pipe.engines]
+    kept = []
+    for step in range(50):
+        k, j = step % 2, (7 * step) % 10
+        with torch.cuda.stream(pipe.stream(step)):
+            pipe.input(step).copy_(xs[j])
+            out = models[k].forward_even(pipe.engines[k].static_input, overlap=True)
+            models[k].wait()                       # this stream waits for the collective; the host does not
+            kept.append((j, out.clone()))          # copied out in stream order: the slot's next gather overwrites `out`
+    pipe.synchronize()
+    for step, (j, o) in enumerate(kept):
+        assert torch.equal(o, want[j]), step
 
 
 def test_ddp_training_step_over_rccl_world1(rccl_world1):

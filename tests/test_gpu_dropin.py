@@ -3,7 +3,7 @@
     net = prepare_binary_model(resnet18(), bconfig, custom_config_layers_name={'conv1': BConfig(), 'fc': BConfig()})
     net.eval();  with torch.no_grad(): outputs = net(inputs)           # examples/cifar10.py:61-71,140-149
 
-takes the fused executor — first batch of a shape as eager launches (18 for ResNet-18), from the second one on as
+takes the fused executor — first batch of a shape as eager launches (19 for ResNet-18), from the second one on as
 "stem launch on the caller's tensor + HIP graph of the rest" (bnn_amd/inference.py: AutoFusion, forward_fresh) — and
 is bit-identical to FusedResNet(net)(x).  Everything that has to keep the per-layer path (training, autograd, hooks on
 inner modules, uncovered models, foreign classes whose fused result does not check out) is covered too."""
@@ -59,9 +59,9 @@ def test_net_call_runs_the_fused_executor_and_equals_it_bit_for_bit():
         assert st.calls == {"graph": 0, "eager": 1, "declined": 0} and st.engine is not None
         launches0 = native.launch_count()
         y0 = net(xs[0])
-        # first batch of this shape: the 18 eager launches of the fused executor (stem, 16 convs with the shortcut
+        # first batch of this shape: the 19 eager launches of the fused executor (stem, 16 convs with the shortcut
         # convs and their OR-pools folded in, head) — and nothing through the per-layer path
-        assert native.launch_count() - launches0 == 18 and fastpath.stats()["conv2d"] == per_layer0
+        assert native.launch_count() - launches0 == 19 and fastpath.stats()["conv2d"] == per_layer0
         assert st.calls == {"graph": 0, "eager": 2, "declined": 0}
         ys = [y0]
         for x in xs[1:]:

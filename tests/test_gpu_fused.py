@@ -519,7 +519,8 @@ def test_fused_resnet_with_and_without_mfma_stem_agree():
 
 
 @pytest.mark.parametrize("shape,O", [((256, 512, 7, 7), 1000), ((3, 512, 7, 7), 1000), ((9, 70, 3, 5), 13),
-                                     ((1, 2048, 7, 7), 1000), ((17, 64, 1, 1), 300)])
+                                     ((1, 2048, 7, 7), 1000), ((17, 64, 1, 1), 300), ((33, 6, 7, 7), 65),
+                                     ((2, 3000, 2, 2), 10)])
 def test_head_kernel_matches_fp64_avgpool_fc(shape, O):
     """bnn_hip_avgpool_fc_f32 (avgpool -> flatten -> fc of bnn/models/resnet.py:160-164 in one kernel) against the
     same computation in fp64: fp32 accumulation over C terms -> 2e-6 of the largest logit."""
@@ -535,6 +536,18 @@ def test_head_kernel_matches_fp64_avgpool_fc(shape, O):
     assert torch.allclose(y2.double(), ref - b.double(), rtol=0, atol=2e-6 * float(ref.abs().max()))
     lib_y = F.linear(torch.flatten(F.adaptive_avg_pool2d(x, 1), 1), w, b)          # what the reference runs
     assert torch.allclose(y, lib_y, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    # round 5: `y` came from the two-launch head (bnn_hip_avgpool_fc_ws_f32); the one-kernel form computes the same
+    # means and sums the product in another order
+    y1 = hipops.avgpool_fc(x, w.t().contiguous(), b, one_kernel=True)
+    assert float((y1.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    assert torch.allclose(y, y1, rtol=0, atol=2e-6 * float(ref.abs().max()))
+    # an image's logits depend neither on the batch size nor on its position in the batch (16-image groups inside)
+    for lo, hi in ((0, 1), (N // 2, N), (max(N - 3, 0), N)):
+        if hi > lo:
+            assert torch.equal(hipops.avgpool_fc(x[lo:hi].contiguous(), w.t().contiguous(), b), y[lo:hi])
+    if N > 1:
+        perm = torch.arange(N - 1, -1, -1, device=x.device)
+        assert torch.equal(hipops.avgpool_fc(x[perm].contiguous(), w.t().contiguous(), b), y[perm])
 
 
 @pytest.mark.parametrize("shape", [(3, 64, 14, 14, 64, 1), (2, 64, 12, 10, 128, 2), (2, 128, 9, 9, 96, 1),
@@ -604,11 +617,11 @@ def test_fused_executor_uses_the_head_kernel_and_no_library_gemm():
     y = fused(x)
     # stem + 16 convs (the 3 shortcut convs AND, since ABI 12, the OR-pools of their inputs folded into the last conv of
     # their block) + head
-    assert native.launch_count() - before == 1 + 16 + 1
+    assert native.launch_count() - before == 1 + 16 + 2      # stem, convs, head (average pool + product)
     unfolded = FusedResNet(net, fold_shortcut=False)    # (building an executor packs the weights: launches too)
     before = native.launch_count()
     y2 = unfolded(x)
-    assert native.launch_count() - before == 1 + 16 + 3 + 3 + 1    # + 3 shortcut convs as launches of their own
+    assert native.launch_count() - before == 1 + 16 + 3 + 3 + 2    # + 3 shortcut convs as launches of their own
     assert torch.equal(y, y2)
     with torch.no_grad():
         assert torch.allclose(y, net(x), rtol=1e-3, atol=1e-3 * float(y.abs().max()))

@@ -487,6 +487,65 @@ def test_residual_blocks_train_with_the_fused_batchnorm_and_match_the_unfused_st
             assert close(a, b, 5e-2 if what == "r18" else 2e-3), what
 
 
+@pytest.mark.parametrize("op", ["bn_add_relu", "stem_tail"])
+def test_fused_batchnorm_ops_on_channels_last_inputs(op):
+    """A channels_last (or otherwise strided) input of the fused BatchNorm ops — `model.to(memory_format=channels_last)`
+    makes the library stem conv emit one: the kernels address NCHW, so the forward runs on a contiguous copy and the
+    BACKWARD must run on that same copy (round-4 advisor finding: the original strided tensor was saved, dx / dgamma /
+    dbeta were silently wrong).  Gradients against torch's own modules on the same strided tensors; the statistics'
+    version counters move (caches keyed on `_version` see the update)."""
+    shape = (4, 32, 18, 22)
+    N, C, H, W = shape
+    x0 = dev((gen.normal(gen.seed_of("clx", shape), shape) * 1.4 + 0.2).astype(np.float32)).contiguous(
+        memory_format=torch.channels_last)
+    r0 = dev(gen.normal(gen.seed_of("clr", shape), shape)).contiguous(memory_format=torch.channels_last)
+    assert not x0.is_contiguous()
+
+    def run(fused):
+        bn = nn.BatchNorm2d(C).to(DEV).train()
+        with torch.no_grad():
+            bn.weight.copy_(dev((0.5 + gen.uniform(1, (C,))).astype(np.float32)))
+            bn.bias.copy_(dev((0.3 * gen.normal(2, (C,))).astype(np.float32)))
+        versions = (bn.running_mean._version, bn.running_var._version)
+        x = x0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+        r = r0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+        assert not x.is_contiguous()
+        training.FUSED_BN = fused
+        try:
+            if op == "stem_tail":
+                y = training.stem_tail(x, bn, nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1))
+            else:
+                y = training.bn_act(x, bn, nn.ReLU(inplace=True), r)
+        finally:
+            training.FUSED_BN = True
+        assert bn.running_mean._version > versions[0] and bn.running_var._version > versions[1]
+        gy = dev(gen.normal(gen.seed_of("clg", tuple(y.shape)), tuple(y.shape)))
+        y.backward(gy)
+        return (y.detach(), x.grad, bn.weight.grad, bn.bias.grad, r.grad if op != "stem_tail" else None,
+                bn.running_mean.clone(), bn.running_var.clone())
+    got, want = run(True), run(False)
+    for name, a, b, tol in (("y", got[0], want[0], 2e-5), ("dx", got[1], want[1], 3e-4), ("dgamma", got[2], want[2], 3e-4),
+                            ("dbeta", got[3], want[3], 3e-4), ("running_mean", got[5], want[5], 1e-5),
+                            ("running_var", got[6], want[6], 1e-5)):
+        assert a.shape == b.shape
+        assert torch.allclose(a, b, rtol=tol, atol=tol * float(b.abs().max()) + 1e-7), (name, float((a - b).abs().max()))
+    if op != "stem_tail":
+        assert torch.allclose(got[4], want[4], rtol=1e-6, atol=0)
+
+
+def test_fused_stem_tail_keeps_nan_like_relu_and_maxpool():
+    """A NaN in the stem's conv output (a diverged run): torch's relu + max_pool2d propagate it, and so does the fused
+    stem tail — it used to clamp NaN to 0 (`fmaxf`), which hides the divergence behind all-zero activations."""
+    x = dev(gen.normal(5, (2, 4, 9, 9))).requires_grad_(True)
+    with torch.no_grad():
+        x[1, 2, 4, 4] = float("nan")
+    bn = nn.BatchNorm2d(4).to(DEV).train()
+    y = training.stem_tail(x, bn, nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1))
+    ref = nn.MaxPool2d(3, 2, 1)(torch.relu(nn.BatchNorm2d(4).to(DEV).train()(x.detach())))
+    assert torch.equal(torch.isnan(y), torch.isnan(ref)) and bool(torch.isnan(y).any())
+    assert bool(torch.isnan(y[1, 2]).all()) and not bool(torch.isnan(y[0]).any())
+
+
 @pytest.mark.parametrize("shape", [(4, 64, 112, 112), (3, 16, 17, 23), (2, 8, 7, 7), (5, 64, 32, 32), (2, 3, 1, 1)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_fused_stem_tail_matches_batchnorm_relu_maxpool_of_the_library(shape):

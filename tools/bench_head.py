@@ -17,6 +17,12 @@ def t(fn, n=200):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
+nbytes = int(lib.bnn_hip_avgpool_fc_workspace_bytes(N, C))
+ws = torch.empty(nbytes // 4, device=dev)
+out2 = torch.empty(N, O, device=dev)
 for _ in range(3):
     a = t(lambda: lib.bnn_hip_avgpool_fc_f32(x.data_ptr(), N, C, HW, wt.data_ptr(), b.data_ptr(), O, out.data_ptr(), s))
-    print("batch %d: avgpool + fc %.1f us" % (N, a))
+    a2 = t(lambda: lib.bnn_hip_avgpool_fc_ws_f32(x.data_ptr(), N, C, HW, wt.data_ptr(), b.data_ptr(), O, out2.data_ptr(),
+                                                 ws.data_ptr(), nbytes, s))
+    print("batch %d: avgpool + fc, one kernel %.1f us   two launches through a workspace %.1f us   (max |diff| %.2e)"
+          % (N, a, a2, float((out - out2).abs().max())))

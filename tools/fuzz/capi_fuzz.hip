@@ -116,6 +116,17 @@ int launch_stem(const float* x, const float* w, const float* a, const float* b, 
 int launch_avgpool_fc(const float* x, const float* wt, const float*, float* out, int N, int C, int HW, int O, hipStream_t) {
   ++g_reached; REQUIRE(x && wt && out && N > 0 && C > 0 && HW > 0 && O > 0); return BNN_HIP_OK;
 }
+size_t avgpool_fc_workspace_bytes(int N, int C) {
+  REQUIRE(N > 0 && C > 0);
+  const unsigned long long e = (((unsigned long long)N + 15) / 16) * (unsigned long long)C;
+  return e > (1ull << 56) ? ~(size_t)0 : (size_t)(e * 64);
+}
+bool avgpool_fc_ws_supported(int C, int HW) { REQUIRE(C > 0 && HW > 0); return (size_t)C * 64 <= 160 * 1024 - 1024; }
+int launch_avgpool_fc_ws(const float* x, const float* wt, const float*, float* out, float* ws, int N, int C, int HW, int O,
+                         hipStream_t) {
+  ++g_reached; REQUIRE(x && wt && out && ws && al(ws, 16) && N > 0 && C > 0 && HW > 0 && O > 0 && (size_t)C * 64 <= 160 * 1024 - 1024);
+  return BNN_HIP_OK;
+}
 size_t grad_weight_pack_bytes(int O, int C, int ks) { REQUIRE(O > 0 && C > 0 && (ks == 1 || ks == 3)); return 16; }
 int launch_grad_pack_weight(const float* w, int O, int C, int ks, void* packed, float* alpha, hipStream_t) {
   ++g_reached; REQUIRE(w && packed && alpha && O > 0 && C > 0 && (ks == 1 || ks == 3) && al(packed, 16)); return BNN_HIP_OK;
@@ -148,7 +159,7 @@ int launch_pack_weight(const float* w, int O, int C, int KH, int KW, int, int, c
 }
 int launch_sign_thresholds(const float* alpha, const float*, const float*, const float* a, const float* b, int O, int kmax,
                            int32_t* thr, hipStream_t) {
-  ++g_reached; REQUIRE(alpha && thr && O > 0 && kmax > 0 && kmax < (1 << 24) && (a == nullptr) == (b == nullptr) && al(thr, 4));
+  ++g_reached; REQUIRE(alpha && thr && O > 0 && kmax > 0 && kmax < (1 << 20) && (a == nullptr) == (b == nullptr) && al(thr, 4));
   return BNN_HIP_OK;
 }
 int launch_xnor_what(const float* w, int O, int C, int taps, int, int, float* what, float*, hipStream_t) {
@@ -241,7 +252,7 @@ int main(int argc, char** argv) {
   for (long it = 0; it < iters; ++it) {
     ++g_calls;
     int st = 0;
-    switch (rnd() % 30) {
+    switch (rnd() % 31) {
       case 0: { bnn_hip_conv_desc d = pick_desc();
         st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
                              pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
@@ -339,6 +350,11 @@ int main(int argc, char** argv) {
                                                      pick_int(), pick_int(), pick_int(), pick_ptr<float>(), stream); break;
       case 28: st = bnn_hip_bn_act_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_ptr<float>(), pick_ptr<float>(),
                                        pick_ptr<float>(), pick_int(), pick_ptr<float>(), stream); break;
+      case 29: { const int n = pick_int(), c = pick_int();
+        const size_t need = bnn_hip_avgpool_fc_workspace_bytes(n, c);
+        st = bnn_hip_avgpool_fc_ws_f32(pick_ptr<float>(), n, c, pick_int(), pick_ptr<float>(), pick_ptr<float>(), pick_int(),
+                                       pick_ptr<float>(), pick_ptr<float>(), rnd() % 4 ? need : (size_t)(rnd() % 4096), stream);
+        break; }
       default: { bnn_hip_conv_desc d = pick_desc();
         (void)bnn_hip_shortcut_fold_supported(rnd() % 16 ? &d : nullptr, pick_int());
         st = bnn_hip_blinear(pick_int(), pick_int(), pick_int(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
