@@ -37,6 +37,17 @@
 #ifndef BNN_ROWS_K16TAIL  // 1: the last k-step (k-row 20 and three zero rows) as v_mfma_f32_16x16x16_f16 (k-rows 20, 21)
 #define BNN_ROWS_K16TAIL 0
 #endif
+#ifndef BNN_ROWS_LEAN  // 1: fewer live registers (BatchNorm constants read from LDS where a pooled row is finished, one
+#define BNN_ROWS_LEAN 0  // walking fragment base per k-step kept across tiles) — so that two stem waves leave room on a SIMD
+#endif                   // for waves of ANOTHER kernel (the other stream's binary convolutions: VALU work beside the MFMAs)
+#ifndef BNN_ROWS_PRIO   // s_setprio of the stem's waves (0 = default priority)
+#define BNN_ROWS_PRIO 0
+#endif
+#ifdef BNN_ROWS_VGPRS   // register budget of the kernel (allocation granule 8; two waves per SIMD leave 512 - 2 * budget)
+#define BNN_ROWS_VGPR_ATTR __attribute__((amdgpu_num_vgpr(BNN_ROWS_VGPRS)))
+#else
+#define BNN_ROWS_VGPR_ATTR
+#endif
 #ifndef BNN_ROWS_ABL  // timing ablations only (wrong results): 1 matrix, 2 epilogue, 4 fragment reads, 8 fetch + commit,
 #define BNN_ROWS_ABL 0  // 16 fp32 stores, 32 sign words
 #endif
@@ -61,7 +72,8 @@ constexpr int OFF_BITS = 2 * PATCH_D * 4;            // sign words of the tile: 
 constexpr int OFF_TIME = OFF_BITS + 2 * PTH * PTW * 8;
 constexpr int LDS_BYTES = OFF_TIME + NW * 16 * 64 * 4;
 #else
-constexpr int LDS_BYTES = OFF_BITS + 2 * PTH * PTW * 8;
+constexpr int OFF_BN = OFF_BITS + 2 * PTH * PTW * 8;  // BNN_ROWS_LEAN: BatchNorm constants [a|b][64 channels] fp32
+constexpr int LDS_BYTES = OFF_BN + 2 * COUT * 4;
 #endif
 constexpr int CONV_ROW_D = 2 * ROWD;                 // one conv row further = two input rows further
 static_assert(CONV_ROW_D + LO_D + 3 < 256, "two conv rows must stay inside ds_read2_b32's offsets");
@@ -131,7 +143,7 @@ constexpr unsigned kRowsOOB = 0xFFFFFFF0u;  // beyond every descriptor's num_rec
 
 // HALF: plain fp16 operands, one MFMA per product (BNN_HIP_STEM_FP16).
 template <bool HALF>
-__global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
+__global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bn_a,
     const float* __restrict__ bn_b, int N, int H, int W, int Hc, int Wc, int Hp, int Wp, int tiles_y,
     int tiles_x, int seg_len, int nseg, unsigned x_bytes, float* __restrict__ out, uint64_t* __restrict__ P,
@@ -195,21 +207,35 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
       kb[ks] = lds0 + (uint32_t)(((CIN - 1) * ITH + KS - 1) * ROWD + 2 * WPW * mg + lcol + 2 * (lg & 1)) * 4u;
   }
   // BN constants of the accumulator layout (register r of tile tt -> channel 32*nh + 16*tt + 4*lg + r)
-  float ba[2][4], bb[2][4];
-#pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      ba[tt][r] = bn_a[32 * nh + 16 * tt + 4 * lg + r];
-      bb[tt][r] = bn_b[32 * nh + 16 * tt + 4 * lg + r];
+  constexpr bool LEAN = BNN_ROWS_LEAN != 0;
+  [[maybe_unused]] float ba[2][4], bb[2][4];
+  using lds_f4 = __attribute__((address_space(3))) const f32x4;
+  [[maybe_unused]] const uint32_t bn_lane = lds0 + (uint32_t)(OFF_BN + (32 * nh + 4 * lg) * 4);  // + 64 * tt, + 256 for b
+  if constexpr (LEAN) {
+    if (tid < COUT) {  // visible after the barrier below ("the zero fill is complete")
+      float* bnl = reinterpret_cast<float*>(lds_rows + OFF_BN);
+      bnl[tid] = bn_a[tid];
+      bnl[COUT + tid] = bn_b[tid];
     }
+  } else {
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
+    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {  // waited for HERE: inside the loop the wait would also cover the next patch's loads
-      asm volatile("" : "+v"(ba[tt][r]));
-      asm volatile("" : "+v"(bb[tt][r]));
-    }
+      for (int r = 0; r < 4; ++r) {
+        ba[tt][r] = bn_a[32 * nh + 16 * tt + 4 * lg + r];
+        bb[tt][r] = bn_b[32 * nh + 16 * tt + 4 * lg + r];
+      }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // waited for HERE: inside the loop the wait would also cover the next patch's loads
+        asm volatile("" : "+v"(ba[tt][r]));
+        asm volatile("" : "+v"(bb[tt][r]));
+      }
+  }
+#if BNN_ROWS_PRIO
+  __builtin_amdgcn_s_setprio(BNN_ROWS_PRIO);
+#endif
   // fetch role: column pair `fpc` of patch rows frow0 + 8*u.  Buffer loads: zero padding = an offset beyond the
   // descriptor, one tile-invariant per-lane offset per load + a wave-uniform offset per tile (no address arithmetic
   // and no exec-mask regions in the tile loop)
@@ -335,6 +361,9 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) carry[tt][r] = 0.0f;
+  [[maybe_unused]] uint32_t kq_run[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) kq_run[ks] = kb[ks];
   for (int it = 0; it < niter && valid; ++it) {
     ROWS_T(13)
     __syncthreads();                   // this tile's patch (buffer pb) is in LDS; nobody reads buffer pb ^ 1 any more
@@ -361,9 +390,14 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
     const unsigned out_tile = (unsigned)(((n * COUT + 32 * nh) * Hp + py0) * Wp + px0 + WPW * mg) * 4u;  // wave-uniform
     const unsigned chw4 = (unsigned)(Hp * Wp) * 4u;
 
-    uint32_t kq[KSTEPS];  // walks down the strip: advanced by the rows a step has read
+    // walks down the strip: advanced by the rows a step has read.  LEAN: ONE register per k-step for the whole kernel
+    // (the tile's start = the previous tile's end minus its nine conv rows, in the other patch buffer)
+    uint32_t kq_tile[KSTEPS];
+    uint32_t (&kq)[KSTEPS] = LEAN ? kq_run : kq_tile;
+    if constexpr (!LEAN) {
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) kq[ks] = kb[ks] + (uint32_t)(pb * PATCH_D * 4);
+      for (int ks = 0; ks < KSTEPS; ++ks) kq[ks] = kb[ks] + (uint32_t)(pb * PATCH_D * 4);
+    }
 
     half8 fh[RING][2], fl[RING][2];
     // fragments of `rows` conv rows at the walking base of k-step ks into ring slot `slot`
@@ -444,6 +478,17 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
     // exactly); positions outside the conv output are MaxPool padding: 0 never beats a ReLU output
     auto bn_row = [&](float (&y)[2][4], int d, int t) {
       using f32x2 = __attribute__((ext_vector_type(2))) float;
+      if constexpr (LEAN) {  // (two ds_read_b128 per channel tile: 16 registers that are not alive across the MFMA stream)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const f32x4 a4 = *(lds_f4*)(uintptr_t)(bn_lane + 64u * tt), b4 = *(lds_f4*)(uintptr_t)(bn_lane + 64u * tt + 256u);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            ba[tt][r] = a4[r];
+            bb[tt][r] = b4[r];
+          }
+        }
+      }
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -546,6 +591,11 @@ __global__ __launch_bounds__(stemr::NT, 2) void stem_rows_kernel(
       if (s == 2 * KSTEPS - 1 && more && !(BNN_ROWS_ABL & 8)) commit(pb ^ 1);  // next patch: registers -> the other LDS buffer
       if (s == 2 * KSTEPS - 1) ROWS_T(12)
     }
+    if constexpr (LEAN) {
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+        kq_run[ks] += (uint32_t)((pb ? -1 : 1) * PATCH_D * 4 - CTH * CONV_ROW_D * 4);
+    }
     prev_n = n;
     prev_py0 = py0;
     prev_px0 = px0;
@@ -575,7 +625,10 @@ static int launch_stem_rows_t(const float* x, const float* w, const float* bn_a,
   const int tiles_y = (Hp + PTH - 1) / PTH, tiles_x = (Wp + PTW - 1) / PTW;
   const long long ntiles = (long long)N * tiles_y * tiles_x;
   const int cus = current_device_cus();
-  const long long want = (long long)cus * (8 / NW);  // 8 waves (two workgroups) per CU
+#ifndef BNN_ROWS_WG_PER_CU  // workgroups per CU (2: two waves per SIMD cover each other's LDS latency)
+#define BNN_ROWS_WG_PER_CU (8 / NW)
+#endif
+  const long long want = (long long)cus * BNN_ROWS_WG_PER_CU;  // 8 waves (two workgroups) per CU
   const unsigned grid = (unsigned)(ntiles < want ? ((ntiles + 7) / 8 * 8) : want);
   // segments (see the kernel): whole strips round-robin when every workgroup gets at least one, else one chunk each
   const long long strips = (long long)N * tiles_x;

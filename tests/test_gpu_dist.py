@@ -116,7 +116,7 @@ def test_bench_line_plain_vs_one_rank_under_the_launcher():
     for rec in (plain, launched):
         assert rec["n_gpus"] == 1 and rec["unit"] == "images/s" and rec["value"] > 0
         assert rec["config"]["global_batch"] == 32 and rec["scaling"] == "weak"
-    assert plain["dist"] == {"world_size": 1, "initialized": False, "launcher": "none"}
+    assert plain["dist"] == {"world_size": 1, "initialized": False, "launcher": "none", "rank_devices": [0]}
     assert launched["dist"]["initialized"] and launched["dist"]["backend"] == "nccl"
     assert launched["dist"]["world_size"] == 1 and launched["dist"]["launcher"] == "torchrun"
     # the N > 1 run validates itself: every rank recomputes the first images of every rank and compares them with its
