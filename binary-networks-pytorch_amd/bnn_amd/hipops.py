@@ -239,7 +239,7 @@ def sign_thresholds(w: PackedWeight, bn_scale: torch.Tensor, bn_shift: torch.Ten
     bias = _per_channel(bias, O, "bias")
     post_scale = _per_channel(post_scale, O, "post_scale")
     with torch.cuda.device(dev):
-        thr = torch.empty((O, 4), dtype=torch.int32, device=dev)
+        thr = torch.empty(((O + 31) // 32 * 32, 4), dtype=torch.int32, device=dev)   # whole 32-channel blocks
         native.check(lib.bnn_hip_sign_thresholds_f32(w.alpha.data_ptr(), _ptr(bias), _ptr(post_scale), bn_scale.data_ptr(),
                                                      bn_shift.data_ptr(), O, C * KH * KW, thr.data_ptr(), _stream(dev)),
                      "bnn_hip_sign_thresholds_f32")

@@ -87,6 +87,9 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
   if (ob * kOCB < g.O) {
     const uint32_t* wblk = W + (size_t)ob * g.nchunk * (kOCB * NW);
     const uint32_t* zblk = WZ ? Z + (size_t)ob * g.nchunk * (kOCB * NW) : nullptr;
+    // the parities of the block's thresholds (word 1 of its first ODD channel: thresholds.hip)
+    [[maybe_unused]] uint32_t midt_par = 0u;
+    if constexpr (MIDT2) midt_par = (uint32_t)epi.thr[kThrStride * (ob * kOCB + 1) + 1];
     // conv2-type single-chunk kernels (BN + residual + ReLU -> fp32 [+ packed]): ALL shortcut values of the block
     // are requested up front.  gfx950 counts loads and stores in one vmcnt, and once both kinds are pending the
     // compiler has to wait for vmcnt(0): a residual load issued after the previous pass's stores would make the
@@ -128,13 +131,20 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       if constexpr (MIDT2) {
         // (unconditional: under `if (fullb)` the compiler zero-initialises the eight registers first — eight v_mov and a
         // wait for every earlier load; channels past O lie beyond the descriptor's range and read as 0, unused)
-        const BufRsrc rt = make_rsrc_sized(epi.thr, (unsigned)g.O * (unsigned)(kThrStride * 4));
+        const BufRsrc rt = make_rsrc_sized(epi.thr, (unsigned)((g.O + kOCB - 1) / kOCB * kOCB) * (unsigned)(kThrStride * 4));
 #pragma unroll
         for (int j = 0; j < NACC; ++j)
           midt_a[j] = (int)buf_ld_u32s(rt, (unsigned)(kThrStride * (ob * kOCB + ps * NACC + j) + (NN ? 2 : 3)) * 4u);
       }
       // compile-time profiles with a float epilogue: the counts are kept as the bit pattern of 2^23 + count (epilogue())
       constexpr bool SEEDED = !WZ && NACC % 2 == 0 && EP != EP_RUNTIME && EP != EP_MIDT;
+      // their BatchNorm shifts as vector registers (epilogue(): bnb) — requested in front of the popcount loop where the
+      // pass is short on registers to spare (single-chunk: 8 values), behind it in the multi-chunk kernels
+      // (not in the kernels that queue all residual loads in front of their stores, RES_ALL: a load behind a pass's fp32
+      // stores would wait for their acknowledgements — those kernels are the HBM-bound ones)
+      constexpr bool BNB = SEEDED && (ep_flags(EP, 0) & EF_BN) != 0 && !RES_ALL;
+      [[maybe_unused]] float bnbv[BNB ? NACC : 1];
+      if constexpr (BNB && !MULTI) prefetch_bn_shift<NACC>(g, ob * kOCB + ps * NACC, epi, bnbv);
 #pragma unroll
       for (int j = 0; j < NACC; ++j) {
         acc[j] = SEEDED ? (int)kCountSeed : 0;
@@ -181,20 +191,21 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
         if (fullb) epilogue<NACC, EP, true>(g, px, o0, acc, resv, epi, pbits, mbits, negnz);
         else epilogue<NACC, EP>(g, px, o0, acc, resv, epi, pbits, mbits, negnz);
       } else if constexpr (MIDT2) {
-        if (fullb) {  // two vector instructions per channel (midt2_shift_in)
-#pragma unroll
-          for (int j = 0; j < NACC; ++j)
-            pbits = midt2_shift_in<NN>(pbits, acc[j], midt_a[j], epi.thr[kThrStride * (o0 + j)], midt_odd);
-        } else {      // a block past O: the guarded form on the plain counts
-#pragma unroll
-          for (int j = 0; j < NACC; ++j) acc[j] -= midt_seed;
-          epilogue<NACC, EP>(g, px, o0, acc, resv, epi, pbits, mbits, negnz, NN ? 2.0f : -2.0f);
-        }
+        // two vector instructions per channel (midt2_shift_in), for EVERY block — no branch on `fullb`: the pass stays one
+        // basic block, so the comparands' loads stay in front of the popcount loop (behind a branch the compiler sinks
+        // them to their use, and every pass would wait out a memory round trip).  The table covers whole blocks (pad
+        // channels: "never"); their bits are cleared at the store (`keep`).
+        const uint32_t par = midt_par >> (ps * NACC);
+        static_for<NACC>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          pbits = midt2_shift_in<NN, j>(pbits, acc[j], midt_a[j], par, midt_odd);
+        });
       } else if (fullb) {
         if constexpr (RES_LATE_FETCH) prefetch_residual<NACC, EP, true>(g, px, o0, epi, resv);
         if constexpr (SEEDED) {
+          if constexpr (BNB && MULTI) prefetch_bn_shift<NACC>(g, o0, epi, bnbv);
           epilogue<NACC, EP, true, true>(g, px, o0, acc, resv, epi, pbits, mbits, 0, NN ? 2.0f : -2.0f,
-                                         NN ? -(float)nz : (float)nz);
+                                         NN ? -(float)nz : (float)nz, BNB ? bnbv : nullptr);
         } else {
           to_dot();
           epilogue<NACC, EP, true>(g, px, o0, acc, resv, epi, pbits, mbits, negnz, NN ? 2.0f : -2.0f);
@@ -226,14 +237,19 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
         one_pass(ps, std::integral_constant<int, 0>{});
     }
   }
-  const bool rev = (ob + 1) * kOCB <= g.O;  // == fullb of every pass of this block
+  const bool rev = MIDT2 || (ob + 1) * kOCB <= g.O;  // == fullb of every pass of this block (MIDT2: always shift-in)
   uint32_t xorw = 0u;  // EP_MIDT: flip bits of this block's channels (blocks past O — zero tail words — have none)
+  uint32_t keep = ~0u;  // MIDT2: the channels of the block that exist
   if constexpr (EP == EP_MIDT) {
     if (ob * kOCB < g.O) xorw = (uint32_t)epi.thr[kThrStride * (ob * kOCB) + 1];
-    if (MIDT2 && NN && rev) xorw = ~xorw;  // the agreement form shifts in the COMPLEMENT of every bit of a full block
+    if (MIDT2 && NN) xorw = ~xorw;  // the agreement form shifts in the COMPLEMENT of every bit
+    if constexpr (MIDT2) {
+      const int left = g.O - ob * kOCB;
+      keep = left >= kOCB ? ~0u : left <= 0 ? 0u : ((1u << left) - 1u);
+    }
   }
-  if constexpr (GSPLIT) store_packed_part<PASSES>(g, px, ob, part, pbits, mbits, epi, rev, xorw);
-  else store_packed(g, px, ob, pbits, mbits, epi, rev, xorw);
+  if constexpr (GSPLIT) store_packed_part<PASSES>(g, px, ob, part, pbits, mbits, epi, rev, xorw, keep);
+  else store_packed(g, px, ob, pbits, mbits, epi, rev, xorw, keep);
   }
 }
 

@@ -369,7 +369,11 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
                                          const int (&dot)[NACC], const float (&resv)[NACC],
                                          const EpiArgs& e, uint32_t& pbits, uint32_t& mbits,
                                          [[maybe_unused]] int negnz = 0, [[maybe_unused]] float dscale = 0.0f,
-                                         [[maybe_unused]] float doff = 0.0f) {
+                                         [[maybe_unused]] float doff = 0.0f,
+                                         [[maybe_unused]] const float* bnb = nullptr) {
+  // bnb (straight-line packed path): bn_b[o0 .. o0 + NACC) already in VECTOR registers (prefetch_bn_shift: wave-uniform
+  // buffer loads).  v_pk_fma_f32 reads ONE scalar operand pair; with bn_a and bn_b both wave-uniform the second pair
+  // costs two v_mov per channel pair — fetched through the vector memory path it costs no vector-ALU instruction.
   static_assert(!RAWF || (FULL && NACC % 2 == 0 && EP != EP_RUNTIME && EP != EP_MIDT), "see above");
   // EP_MIDT: `dot` holds the raw popcount, `dscale` +-2 and `negnz` the lane's -+(non-zero inputs); other profiles: the dot product
   constexpr bool FUSED = EP != EP_PLAIN;
@@ -459,7 +463,9 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
       f2 y = __builtin_elementwise_fma(f2{e.alpha[o], e.alpha[o + 1]}, dot_pair(j),
                                        (f & EF_BIAS) ? f2{e.bias[o], e.bias[o + 1]} : zero2);
       if (f & EF_SCALE) y *= f2{e.scale[o], e.scale[o + 1]};
-      if (f & EF_BN) y = __builtin_elementwise_fma(y, f2{e.bn_a[o], e.bn_a[o + 1]}, f2{e.bn_b[o], e.bn_b[o + 1]});
+      if (f & EF_BN)
+        y = __builtin_elementwise_fma(y, f2{e.bn_a[o], e.bn_a[o + 1]},
+                                      bnb ? f2{bnb[j], bnb[j + 1]} : f2{e.bn_b[o], e.bn_b[o + 1]});
       if ((f & EF_RES) && !(f & EF_RES_LATE)) y += f2{resv[j], resv[j + 1]};
       if ((f & EF_RELU) && !no_clamp) {
         const float yx = y.x, yy = y.y;  // (bit_cast straight on a vector element reads element 0 with hipcc 7.2)
@@ -546,7 +552,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
 //   disagreements    :  nz - 2 cnt >= T  <=>  cnt - q <  floor(-T / 2) + 1 + (p & T odd)
 // Both are "cnt' < A + carry" with cnt' = cnt - q + kMidtBias (the popcount chain STARTS from kMidtBias - q: the VGPR addend
 // of its first v_bcnt, free), A per channel from the thresholds table (thr[4o + 2] / thr[4o + 3], csrc/thresholds.hip)
-// and the carry mask chosen from T's parity on the scalar unit:
+// and the carry mask chosen from T's parity on the scalar unit (one bit test on the block's parity word):
 //   v_subbrev_co_u32 tmp, vcc, A, cnt', vcc     vcc <- borrow = (cnt' < A + carry), unsigned: hence the bias
 //   v_addc_co_u32    word, vcc, word, word, vcc  shifts the borrow in
 // A gfx9 vector instruction reads ONE scalar operand and the carry-in is one, so A has to be a vector register: it is
@@ -560,26 +566,28 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
 // Checked against the plain integer test by enumeration on the host (tests/test_midt_cpu.py) and on the device bit for
 // bit (tests/test_gpu_fused.py: the threshold planes equal the float epilogue's).
 constexpr int kMidtBias = 1 << 20;  // > K / 2 for every K the thresholds kernel accepts (K < 2^20)
-constexpr int kThrStride = 4;       // int32 per channel of the thresholds table: {T, flip word of the block, A_nn, A_tp}
-template <bool NN>
-__device__ __forceinline__ uint32_t midt2_shift_in(uint32_t word, int cnt, int A, int T, unsigned long long oddmask) {
+constexpr int kThrStride = 4;       // int32 per channel of the thresholds table: {T, flip | parity word of the block, A_nn, A_tp}
+// J: the channel's bit in `parity` (the pass's slice of the block's parity word, thresholds.hip).
+template <bool NN, int J>
+__device__ __forceinline__ uint32_t midt2_shift_in(uint32_t word, int cnt, int A, uint32_t parity,
+                                                   unsigned long long oddmask) {
 #if defined(__HIP_DEVICE_COMPILE__)
   int tmp;
   if constexpr (NN) {
-    asm("s_bitcmp0_b32 %[T], 0\n\t"              // SCC = T even
+    asm("s_bitcmp0_b32 %[par], %[j]\n\t"          // SCC = T even
         "s_cselect_b64 vcc, %[odd], 0\n\t"
         "v_subbrev_co_u32 %[tmp], vcc, %[a], %[cnt], vcc\n\t"
         "v_addc_co_u32 %[w], vcc, %[w], %[w], vcc"
         : [w] "+v"(word), [tmp] "=&v"(tmp)
-        : [T] "s"(T), [odd] "s"(oddmask), [cnt] "v"(cnt), [a] "v"(A)
+        : [par] "s"(parity), [j] "i"(J), [odd] "s"(oddmask), [cnt] "v"(cnt), [a] "v"(A)
         : "vcc", "scc");
   } else {
-    asm("s_bitcmp1_b32 %[T], 0\n\t"              // SCC = T odd
+    asm("s_bitcmp1_b32 %[par], %[j]\n\t"          // SCC = T odd
         "s_cselect_b64 vcc, %[odd], 0\n\t"
         "v_subbrev_co_u32 %[tmp], vcc, %[a], %[cnt], vcc\n\t"
         "v_addc_co_u32 %[w], vcc, %[w], %[w], vcc"
         : [w] "+v"(word), [tmp] "=&v"(tmp)
-        : [T] "s"(T), [odd] "s"(oddmask), [cnt] "v"(cnt), [a] "v"(A)
+        : [par] "s"(parity), [j] "i"(J), [odd] "s"(oddmask), [cnt] "v"(cnt), [a] "v"(A)
         : "vcc", "scc");
   }
   return word;
@@ -610,18 +618,29 @@ __device__ __forceinline__ void prefetch_residual(const Geo& g, const Pix& px, i
     else resv[j] = (o0 + j < g.O) ? ld_off(e.res + (size_t)(o0 + j + g.c_off) * hw, lane_off) : 0.0f;
 }
 
+// bn_b[o0 .. o0 + NACC) into vector registers as wave-uniform buffer loads (see epilogue(): bnb).  Channels past O lie
+// beyond the descriptor's range and read as 0 (such blocks take the guarded epilogue, which does not use them).
+template <int NACC>
+__device__ __forceinline__ void prefetch_bn_shift(const Geo& g, int o0, const EpiArgs& e, float (&bnb)[NACC]) {
+  const BufRsrc r = make_rsrc_sized(e.bn_b, (unsigned)g.O * 4u);
+#pragma unroll
+  for (int j = 0; j < NACC; ++j) bnb[j] = __builtin_bit_cast(float, buf_ld_u32s(r, (unsigned)(o0 + j) * 4u));
+}
+
 // sign(y) of one 32-channel block: one half of a uint64 word of the [n][group][y][x] output planes.
 // `rev`: the words were built by shift-in (straight-line epilogue, all 32 channels of the block): bit-reversed.
 // `xorw` (EP_MIDT): the flip bits of the block's channels, applied to the finished P word.
+// `keep` (two-instruction threshold form): the bits of channels that exist, applied last.
 __device__ __forceinline__ void store_packed(const Geo& g, const Pix& px, int ob, uint32_t pbits,
-                                             uint32_t mbits, const EpiArgs& e, bool rev = false, uint32_t xorw = 0u) {
+                                             uint32_t mbits, const EpiArgs& e, bool rev = false, uint32_t xorw = 0u,
+                                             uint32_t keep = ~0u) {
   // lanes past the last pixel hold a copy of it (decode_pixel): they store the same word to the same place
   if (!(g.flags & EF_PACK) || (g.flags & EF_RAW)) return;
   if (rev) {
     pbits = __builtin_bitreverse32(pbits);
     mbits = __builtin_bitreverse32(mbits);
   }
-  pbits ^= xorw;
+  pbits = (pbits ^ xorw) & keep;
   const int hw = g.Ho * g.Wo;
   const unsigned w = (((px.pk_base + (unsigned)((ob >> 1) * hw)) << 1) + (unsigned)(ob & 1)) * 4u;  // bytes
   st_off(e.outP, w, pbits);
@@ -634,14 +653,14 @@ __device__ __forceinline__ void store_packed(const Geo& g, const Pix& px, int ob
 template <int PARTS>
 __device__ __forceinline__ void store_packed_part(const Geo& g, const Pix& px, int ob, int part,
                                                   uint32_t pbits, uint32_t mbits, const EpiArgs& e, bool rev = false,
-                                                  uint32_t xorw = 0u) {
+                                                  uint32_t xorw = 0u, uint32_t keep = ~0u) {
   static_assert(PARTS == 2 || PARTS == 4, "16- or 8-bit pieces");
   if (!(g.flags & EF_PACK) || (g.flags & EF_RAW)) return;
   if (rev) {  // bits 0 .. 32/PARTS-1 reversed -> the top of bitreverse32; move them to the part's position
     pbits = (__builtin_bitreverse32(pbits) >> (32 - 32 / PARTS)) << ((32 / PARTS) * part);
     mbits = (__builtin_bitreverse32(mbits) >> (32 - 32 / PARTS)) << ((32 / PARTS) * part);
   }
-  pbits ^= xorw & (((1u << (32 / PARTS)) - 1u) << ((32 / PARTS) * part));
+  pbits = (pbits ^ (xorw & (((1u << (32 / PARTS)) - 1u) << ((32 / PARTS) * part)))) & keep;
   const int hw = g.Ho * g.Wo;
   const size_t w = (((size_t)px.pk_base + (size_t)(ob >> 1) * hw) << 1) + (ob & 1);
   constexpr int BITS = 32 / PARTS;

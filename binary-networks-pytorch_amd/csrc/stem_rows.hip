@@ -35,7 +35,7 @@
 #include "bnn_dev.h"
 
 #ifndef BNN_ROWS_K16TAIL  // 1: the last k-step (k-row 20 and three zero rows) as v_mfma_f32_16x16x16_f16 (k-rows 20, 21)
-#define BNN_ROWS_K16TAIL 0
+#define BNN_ROWS_K16TAIL 1
 #endif
 #ifndef BNN_ROWS_LEAN  // 1: fewer live registers (BatchNorm constants read from LDS where a pooled row is finished, one
 #define BNN_ROWS_LEAN 0  // walking fragment base per k-step kept across tiles) — so that two stem waves leave room on a SIMD

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(tail::NT) void avgpool_fc_kernel(const float* __res
 namespace tail2 {
 constexpr int ROWS = 256;        // rows (= threads) per avgpool workgroup
 constexpr int IMG = 16, OT = 64, KSEG = 8, NT = KSEG * 64;
-constexpr int KU = 16;           // weight loads in flight per wave
+constexpr int KU = 64;           // weight loads in flight per wave (ResNet-18: a wave's whole k-segment)
 }  // namespace tail2
 
 template <int HWC>
@@ -143,23 +143,29 @@ __global__ __launch_bounds__(tail2::NT) void fc_ws_kernel(const float* __restric
   extern __shared__ __attribute__((aligned(16))) float lds[];  // means [C][IMG]; afterwards partial sums [KSEG][IMG][OT]
   const int g = blockIdx.x, o0 = blockIdx.y * OT;
   const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
+  const int o = o0 + lane;
+  const float* wp = wt + (o < O ? o : O - 1);  // lanes past the last output recompute it and store nothing
+  const int klen = (C + KSEG - 1) / KSEG;
+  const int k0 = seg * klen, k1 = min(C, k0 + klen);
+  // the first KU weights of the segment are requested BEFORE the means are staged: they depend on nothing in LDS, and
+  // at ResNet-18 size (C = 512: 64 values per segment) they are the whole segment — one memory round trip
+  float w[KU];
+#pragma unroll
+  for (int u = 0; u < KU; ++u) w[u] = k0 < k1 ? wp[(size_t)min(k0 + u, k1 - 1) * O] : 0.0f;
   {  // the group's means: one contiguous block of C * IMG floats
     const float4* src = reinterpret_cast<const float4*>(mt + (size_t)g * C * IMG);
     float4* dst = reinterpret_cast<float4*>(lds);
     for (int i = tid; i < C * IMG / 4; i += NT) dst[i] = src[i];
   }
   __syncthreads();
-  const int o = o0 + lane;
-  const float* wp = wt + (o < O ? o : O - 1);  // lanes past the last output recompute it and store nothing
-  const int klen = (C + KSEG - 1) / KSEG;
-  const int k0 = seg * klen, k1 = min(C, k0 + klen);
   f2 acc[IMG / 2];
 #pragma unroll
   for (int i = 0; i < IMG / 2; ++i) acc[i] = f2{0.0f, 0.0f};
   for (int kb = k0; kb < k1; kb += KU) {
-    float w[KU];
+    if (kb > k0) {
 #pragma unroll
-    for (int u = 0; u < KU; ++u) w[u] = wp[(size_t)min(kb + u, k1 - 1) * O];
+      for (int u = 0; u < KU; ++u) w[u] = wp[(size_t)min(kb + u, k1 - 1) * O];
+    }
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
       if (kb + u < k1) {  // wave-uniform

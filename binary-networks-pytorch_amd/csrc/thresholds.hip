@@ -9,8 +9,8 @@
 // int->float, two fmas and a float compare — same bits by construction (tests/test_gpu_fused.py).
 // A monotone function crosses zero once, so the interval always touches an end of [-K, K] and ONE one-sided compare
 // is enough:   thr[4o] = T,   P  <=>  (dot >= T) XOR flip_o ,
-// with the flip bits of a 32-channel block gathered into one word that every thr[4o+1] of the block repeats
-// (bit k = flip of channel 32*(o/32) + k): increasing channels have flip 0 and T = first dot whose bit is 1,
+// with the flip bits of a 32-channel block gathered into one word that thr[4o+1] of the block's EVEN channels repeats
+// (bit k = flip of channel 32*(o/32) + k; the odd channels' word 1 holds the parities of the block's T instead): increasing channels have flip 0 and T = first dot whose bit is 1,
 // decreasing ones flip 1 and T = last such dot + 1; "always" is T = -K, "never" (a NaN constant too) T = 2^30.
 #include "bnn_dev.h"
 
@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void sign_threshold_kernel(const float* __rest
                                                              int32_t* __restrict__ thr) {
   const int o = blockIdx.x * 256 + threadIdx.x;
   const bool in = o < O;
-  const int oc = in ? o : O - 1;  // lanes past the last channel recompute it (they take part in the ballot below)
+  const int o_pad = (O + 31) / 32 * 32;  // the table covers whole 32-channel blocks: pad channels are "never"
+  const int oc = in ? o : O - 1;  // lanes past the last channel recompute it (they take part in the ballots below)
   const float al = alpha[oc], bi = bias ? bias[oc] : 0.0f, sc = scale ? scale[oc] : 1.0f;
   const float a = bn_a ? bn_a[oc] : 1.0f, b = bn_b ? bn_b[oc] : 0.0f;
   auto pos = [&](int d) {
@@ -56,10 +57,19 @@ __global__ __launch_bounds__(256) void sign_threshold_kernel(const float* __rest
     T = h;
     flip = true;
   }
-  // flip word of the 32-channel block: a wave holds two consecutive blocks (256 threads = consecutive channels)
-  const unsigned long long fm = __ballot(in && flip);
-  const uint32_t word = (threadIdx.x & 32) ? (uint32_t)(fm >> 32) : (uint32_t)fm;
-  if (in) {
+  if (!in) {  // pad channel of the last block
+    T = 0x40000000;
+    flip = false;
+  }
+  // flip word and PARITY word (bit k = T of channel k is odd) of the 32-channel block: a wave holds two consecutive
+  // blocks (256 threads = consecutive channels).  Word 1 of an even channel is the block's flip word, of an odd channel
+  // its parity word (the two-instruction form of the test picks its carry mask by T's parity: one scalar bit test on
+  // this word instead of a scalar load of T per channel)
+  const unsigned long long fm = __ballot(in && flip), pm = __ballot((T & 1) != 0);
+  const uint32_t fword = (threadIdx.x & 32) ? (uint32_t)(fm >> 32) : (uint32_t)fm;
+  const uint32_t pword = (threadIdx.x & 32) ? (uint32_t)(pm >> 32) : (uint32_t)pm;
+  const uint32_t word = (o & 1) ? pword : fword;
+  if (o < o_pad) {
     // words 2, 3: the comparand of the two-instruction form of the test (bconv_core.h: midt2_shift_in), for the
     // agreement count (non-negative activations) and for the disagreement count, both with the bias of the chains
     constexpr int kBias = 1 << 20;
@@ -74,7 +84,7 @@ __global__ __launch_bounds__(256) void sign_threshold_kernel(const float* __rest
 
 int launch_sign_thresholds(const float* alpha, const float* bias, const float* scale, const float* bn_a,
                            const float* bn_b, int O, int kmax, int32_t* thr, hipStream_t stream) {
-  hipLaunchKernelGGL(sign_threshold_kernel, dim3((O + 255) / 256), dim3(256), 0, stream, alpha, bias, scale, bn_a, bn_b,
+  hipLaunchKernelGGL(sign_threshold_kernel, dim3(((O + 31) / 32 * 32 + 255) / 256), dim3(256), 0, stream, alpha, bias, scale, bn_a, bn_b,
                      O, kmax, thr);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }

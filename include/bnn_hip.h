@@ -151,7 +151,7 @@ typedef struct bnn_hip_epilogue {
   const float* pack_shift;
   int32_t out_c_offset;    /* see above; 0/0 = plain [N,O,Ho,Wo]        */
   int32_t out_c_total;
-  const int32_t* sign_thresholds; /* NULL, or [O][4] from bnn_hip_sign_thresholds_f32 for THIS alpha / bn_scale /
+  const int32_t* sign_thresholds; /* NULL, or [32*ceil(O/32)][4] from bnn_hip_sign_thresholds_f32 for THIS alpha / bn_scale /
                                      bn_shift: used when the epilogue is exactly BN + ReLU -> planes only (no bias,
                                      scale, residual, fp32 output): the sign bit then comes from an integer compare
                                      of the dot — same bits as the float path, fewer instructions.  Ignored
@@ -181,8 +181,10 @@ typedef struct bnn_hip_epilogue {
 /* Per channel the integer dots (|dot| <= kmax = C*KH*KW) whose epilogue value
  *   fmaf(fmaf(alpha, dot, bias) [* post_scale], bn_scale, bn_shift)   is > 0.
  * Every step is monotone in dot, so that set is one-sided:  bit = (dot >= T) XOR flip.
- * thresholds[4o] = T; thresholds[4o+1] = the flip bits of o's 32-channel block as one word (bit k = channel
- * 32*(o/32)+k; every entry of a block repeats it); thresholds[4o+2], [4o+3] = the comparands of the kernels'
+ * `thresholds` holds 4 * 32 * ceil(O / 32) int32 (whole 32-channel blocks; pad channels are written as "never").
+ * thresholds[4o] = T; thresholds[4o+1] = for EVEN o the flip bits of o's 32-channel block as one word (bit k = channel
+ * 32*(o/32)+k), for ODD o the parities of the block's T (bit k = T of channel k is odd); thresholds[4o+2], [4o+3] = the
+ * comparands of the kernels'
  * two-instruction form of the same test on the agreement / disagreement count (ceil(T/2) + 2^20 and
  * max(floor(-T/2) + 1 + 2^20, 0): csrc/bconv_core.h midt2_shift_in).  Found by bisection with the conv epilogue's
  * own float operations.  Re-derive when any input changes.  kmax < 2^20.

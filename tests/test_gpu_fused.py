@@ -581,13 +581,32 @@ def test_integer_sign_thresholds_give_the_float_epilogue_bits(shape):
     assert torch.equal(got.P, ref.P) and torch.equal(got.M, ref.M) and not bool(got.M.any())
     # the table against the float predicate on the dots themselves
     dot = hipops.bconv2d(act, pw, stride=stride, padding=1, raw_dot=True)                      # int32 [N,O,Ho,Wo]
-    T = thr[:, 0].view(1, -1, 1, 1).long()                      # bit = (dot >= T) XOR flip (include/bnn_hip.h)
+    o_pad = (O + 31) // 32 * 32
+    assert thr.shape == (o_pad, 4)                              # whole 32-channel blocks (include/bnn_hip.h)
+    T = thr[:O, 0].view(1, -1, 1, 1).long()                     # bit = (dot >= T) XOR flip
     ch = torch.arange(O, device=thr.device)
-    flip = ((thr[:, 1].long() & 0xFFFFFFFF) >> (ch % 32)) & 1
-    assert all(int(thr[o, 1]) == int(thr[o - o % 32, 1]) for o in range(O))   # one word per 32-channel block
+    fword = thr[ch - ch % 32, 1].long() & 0xFFFFFFFF            # word 1 of the block's first (even) channel: the flips
+    flip = (fword >> (ch % 32)) & 1
+    # word 1: even channels repeat the block's flip word, odd channels its parity word (bit k = T of channel k is odd)
+    allc = torch.arange(o_pad, device=thr.device)
+    pword = thr[allc - allc % 32 + 1, 1].long() & 0xFFFFFFFF
+    assert torch.equal((pword >> (allc % 32)) & 1, thr[:, 0].long() & 1)
+    assert all(int(thr[o, 1]) == int(thr[o - o % 32 + (o & 1), 1]) for o in range(o_pad))
+    assert bool((thr[O:, 0] == 0x40000000).all())               # pad channels: "never"
+    # words 2, 3: the comparands of the two-instruction form (csrc/bconv_core.h midt2_shift_in)
+    Tl = thr[:, 0].long()
+    assert torch.equal(thr[:, 2].long(), (Tl + 1 + (2 << 20)) >> 1)
+    assert torch.equal(thr[:, 3].long(), torch.clamp((2 + (2 << 20) - Tl) >> 1, min=0))
     bit = (dot.long() >= T) ^ flip.view(1, -1, 1, 1).bool()
     P, _ = oracle.pack_act(np.where(bit.cpu().numpy(), 1.0, 0.0).astype(np.float32))
     assert np.array_equal(u64(ref.P), P)
+    # the disagreement form of the test: the same layer on TWO planes (an input with negative values)
+    x2 = dev(gen.normal(gen.seed_of("thrx2", shape), (N, C, H, W)) * (gen.uniform(9, (N, C, H, W)) > 0.2))
+    act2 = hipops.pack_act(x2)
+    assert bool(act2.M.any()) and not getattr(act2, "nonneg", False)
+    _, ref2 = hipops.bconv2d_fused(act2, pw, **kw)
+    _, got2 = hipops.bconv2d_fused(act2, pw, sign_thresholds=thr, **kw)
+    assert torch.equal(got2.P, ref2.P) and torch.equal(got2.M, ref2.M)
 
 
 def test_fused_resnet_with_integer_thresholds_is_bit_identical():
