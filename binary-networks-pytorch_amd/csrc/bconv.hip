@@ -138,13 +138,6 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       }
       // compile-time profiles with a float epilogue: the counts are kept as the bit pattern of 2^23 + count (epilogue())
       constexpr bool SEEDED = !WZ && NACC % 2 == 0 && EP != EP_RUNTIME && EP != EP_MIDT;
-      // their BatchNorm shifts as vector registers (epilogue(): bnb) — requested in front of the popcount loop where the
-      // pass is short on registers to spare (single-chunk: 8 values), behind it in the multi-chunk kernels
-      // (not in the kernels that queue all residual loads in front of their stores, RES_ALL: a load behind a pass's fp32
-      // stores would wait for their acknowledgements — those kernels are the HBM-bound ones)
-      constexpr bool BNB = SEEDED && (ep_flags(EP, 0) & EF_BN) != 0 && !RES_ALL;
-      [[maybe_unused]] float bnbv[BNB ? NACC : 1];
-      if constexpr (BNB && !MULTI) prefetch_bn_shift<NACC>(g, ob * kOCB + ps * NACC, epi, bnbv);
 #pragma unroll
       for (int j = 0; j < NACC; ++j) {
         acc[j] = SEEDED ? (int)kCountSeed : 0;
@@ -203,9 +196,8 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       } else if (fullb) {
         if constexpr (RES_LATE_FETCH) prefetch_residual<NACC, EP, true>(g, px, o0, epi, resv);
         if constexpr (SEEDED) {
-          if constexpr (BNB && MULTI) prefetch_bn_shift<NACC>(g, o0, epi, bnbv);
           epilogue<NACC, EP, true, true>(g, px, o0, acc, resv, epi, pbits, mbits, 0, NN ? 2.0f : -2.0f,
-                                         NN ? -(float)nz : (float)nz, BNB ? bnbv : nullptr);
+                                         NN ? -(float)nz : (float)nz);
         } else {
           to_dot();
           epilogue<NACC, EP, true>(g, px, o0, acc, resv, epi, pbits, mbits, negnz, NN ? 2.0f : -2.0f);
@@ -345,6 +337,9 @@ __global__ __launch_bounds__(64) void bconv_generic_kernel(
 #ifndef BNN_GSPLIT_MAX_WAVES  // ...when the unsplit launch has at most this many waves
 #define BNN_GSPLIT_MAX_WAVES 16384
 #endif
+#ifndef BNN_GSPLIT4_MAX_WAVES  // four pieces instead, when two pieces give at most this many waves (0 = never)
+#define BNN_GSPLIT4_MAX_WAVES 8192
+#endif
 
 #ifndef BNN_SGPR_OBW  // 32-channel blocks per wave of the single-chunk 3x3 EP_PLAIN kernels (1 = one block per wave)
 #define BNN_SGPR_OBW 2
@@ -411,6 +406,23 @@ static void launch_sgpr_t(const ConvP& p, const Geo& g, bool split_ok, hipStream
     // throughput mode keeps the split for launches of fewer than 2048 waves (two per SIMD): those need it even
     // beside another batch (config-5 net at batch 128: 127 k images/s with the split, 119 k without)
     if ((split_ok || grid.x < 2048u) && (long long)grid.x <= BNN_GSPLIT_MAX_WAVES) {
+      // one batch at a time and still fewer than BNN_GSPLIT4_MAX_WAVES waves when split in two (layer 4 at batch 256:
+      // 6272 equal waves over 1024 SIMDs = a seventh round for an eighth of them): four pieces — 12.25 waves per SIMD,
+      // the extra field loads cost less than the tail (round 5; with every multi-chunk layer split in four the net
+      // LOST, tools/experiments/README.md 20: layer 3 has enough waves as it is)
+      if (split_ok && (long long)grid.x * BNN_MULTI_GSPLIT <= BNN_GSPLIT4_MAX_WAVES) {
+        const dim3 grid4(grid.x * 4);
+        if constexpr (EP == EP_OUT && NN) {
+          if (p.ds_P) {
+            hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MW, 4, true, true, NN, false, 1, true>), grid4,
+                               dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
+            return;
+          }
+        }
+        hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MW, 4, true, true, NN>), grid4, dim3(kWave), 0, s, p.P,
+                           p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
+        return;
+      }
       const dim3 grid2(grid.x * BNN_MULTI_GSPLIT);
       if constexpr (EP == EP_OUT && NN) {
         if (p.ds_P) {

@@ -369,11 +369,7 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
                                          const int (&dot)[NACC], const float (&resv)[NACC],
                                          const EpiArgs& e, uint32_t& pbits, uint32_t& mbits,
                                          [[maybe_unused]] int negnz = 0, [[maybe_unused]] float dscale = 0.0f,
-                                         [[maybe_unused]] float doff = 0.0f,
-                                         [[maybe_unused]] const float* bnb = nullptr) {
-  // bnb (straight-line packed path): bn_b[o0 .. o0 + NACC) already in VECTOR registers (prefetch_bn_shift: wave-uniform
-  // buffer loads).  v_pk_fma_f32 reads ONE scalar operand pair; with bn_a and bn_b both wave-uniform the second pair
-  // costs two v_mov per channel pair — fetched through the vector memory path it costs no vector-ALU instruction.
+                                         [[maybe_unused]] float doff = 0.0f) {
   static_assert(!RAWF || (FULL && NACC % 2 == 0 && EP != EP_RUNTIME && EP != EP_MIDT), "see above");
   // EP_MIDT: `dot` holds the raw popcount, `dscale` +-2 and `negnz` the lane's -+(non-zero inputs); other profiles: the dot product
   constexpr bool FUSED = EP != EP_PLAIN;
@@ -463,9 +459,11 @@ __device__ __forceinline__ void epilogue(const Geo& g, const Pix& px, int o0,
       f2 y = __builtin_elementwise_fma(f2{e.alpha[o], e.alpha[o + 1]}, dot_pair(j),
                                        (f & EF_BIAS) ? f2{e.bias[o], e.bias[o + 1]} : zero2);
       if (f & EF_SCALE) y *= f2{e.scale[o], e.scale[o + 1]};
-      if (f & EF_BN)
-        y = __builtin_elementwise_fma(y, f2{e.bn_a[o], e.bn_a[o + 1]},
-                                      bnb ? f2{bnb[j], bnb[j + 1]} : f2{e.bn_b[o], e.bn_b[o + 1]});
+      // (v_pk_fma_f32 reads ONE scalar operand pair: bn_b costs two v_mov per channel pair.  Fetching it as a wave-
+      // uniform buffer load instead — no vector-ALU work — was measured in round 5 and is SLOWER in the single-chunk
+      // kernels, 72.5 -> 76.6 us on layer2.0.conv2: the compiler sinks the loads behind the `fullb` branch to their use,
+      // and every pass then waits out a memory round trip; neutral in the multi-chunk kernels.  CHANGELOG.md.)
+      if (f & EF_BN) y = __builtin_elementwise_fma(y, f2{e.bn_a[o], e.bn_a[o + 1]}, f2{e.bn_b[o], e.bn_b[o + 1]});
       if ((f & EF_RES) && !(f & EF_RES_LATE)) y += f2{resv[j], resv[j + 1]};
       if ((f & EF_RELU) && !no_clamp) {
         const float yx = y.x, yy = y.y;  // (bit_cast straight on a vector element reads element 0 with hipcc 7.2)
@@ -616,15 +614,6 @@ __device__ __forceinline__ void prefetch_residual(const Geo& g, const Pix& px, i
     // live copy, because store_packed() lets them store
     if constexpr (FULL) resv[j] = buf_ld(make_rsrc(e.res), lane_off, (unsigned)(o0 + j + g.c_off) * (unsigned)hw * 4u);
     else resv[j] = (o0 + j < g.O) ? ld_off(e.res + (size_t)(o0 + j + g.c_off) * hw, lane_off) : 0.0f;
-}
-
-// bn_b[o0 .. o0 + NACC) into vector registers as wave-uniform buffer loads (see epilogue(): bnb).  Channels past O lie
-// beyond the descriptor's range and read as 0 (such blocks take the guarded epilogue, which does not use them).
-template <int NACC>
-__device__ __forceinline__ void prefetch_bn_shift(const Geo& g, int o0, const EpiArgs& e, float (&bnb)[NACC]) {
-  const BufRsrc r = make_rsrc_sized(e.bn_b, (unsigned)g.O * 4u);
-#pragma unroll
-  for (int j = 0; j < NACC; ++j) bnb[j] = __builtin_bit_cast(float, buf_ld_u32s(r, (unsigned)(o0 + j) * 4u));
 }
 
 // sign(y) of one 32-channel block: one half of a uint64 word of the [n][group][y][x] output planes.

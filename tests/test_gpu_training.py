@@ -543,8 +543,9 @@ def test_fused_stem_tail_keeps_nan_like_relu_and_maxpool():
     bn = nn.BatchNorm2d(4).to(DEV).train()
     y = training.stem_tail(x, bn, nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1))
     ref = nn.MaxPool2d(3, 2, 1)(torch.relu(nn.BatchNorm2d(4).to(DEV).train()(x.detach())))
+    # (the NaN poisons the batch statistics of ITS channel: that channel is NaN in every image, the others are clean)
     assert torch.equal(torch.isnan(y), torch.isnan(ref)) and bool(torch.isnan(y).any())
-    assert bool(torch.isnan(y[1, 2]).all()) and not bool(torch.isnan(y[0]).any())
+    assert bool(torch.isnan(y[:, 2]).all()) and not bool(torch.isnan(y[:, [0, 1, 3]]).any())
 
 
 @pytest.mark.parametrize("shape", [(4, 64, 112, 112), (3, 16, 17, 23), (2, 8, 7, 7), (5, 64, 32, 32), (2, 3, 1, 1)],
