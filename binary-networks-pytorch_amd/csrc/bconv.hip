@@ -406,22 +406,18 @@ static void launch_sgpr_t(const ConvP& p, const Geo& g, bool split_ok, hipStream
     // throughput mode keeps the split for launches of fewer than 2048 waves (two per SIMD): those need it even
     // beside another batch (config-5 net at batch 128: 127 k images/s with the split, 119 k without)
     if ((split_ok || grid.x < 2048u) && (long long)grid.x <= BNN_GSPLIT_MAX_WAVES) {
-      // one batch at a time and still fewer than BNN_GSPLIT4_MAX_WAVES waves when split in two (layer 4 at batch 256:
-      // 6272 equal waves over 1024 SIMDs = a seventh round for an eighth of them): four pieces — 12.25 waves per SIMD,
-      // the extra field loads cost less than the tail (round 5; with every multi-chunk layer split in four the net
-      // LOST, tools/experiments/README.md 20: layer 3 has enough waves as it is)
-      if (split_ok && (long long)grid.x * BNN_MULTI_GSPLIT <= BNN_GSPLIT4_MAX_WAVES) {
-        const dim3 grid4(grid.x * 4);
-        if constexpr (EP == EP_OUT && NN) {
-          if (p.ds_P) {
-            hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MW, 4, true, true, NN, false, 1, true>), grid4,
-                               dim3(kWave), 0, s, p.P, p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
-            return;
-          }
+      // conv1-type layers, one batch at a time, still fewer than BNN_GSPLIT4_MAX_WAVES waves when split in two (layer 4
+      // at batch 256: 6272 equal waves over 1024 SIMDs = a seventh round for an eighth of them): four pieces, 12.25
+      // waves per SIMD.  Measured (round 5): layer4.0.conv1 + layer4.1.conv1 99.4 -> 94.6 us; the conv2-type layers do
+      // not gain (64.0 -> 63.6 us) or lose (folded shortcut: 73.3 -> 76.3 us: every piece recomputes the shortcut
+      // field) and keep two pieces; with EVERY multi-chunk layer in four the net lost (tools/experiments/README.md 20).
+      if constexpr (EP == EP_MID || EP == EP_MIDT) {
+        if (split_ok && (long long)grid.x * BNN_MULTI_GSPLIT <= BNN_GSPLIT4_MAX_WAVES) {
+          const dim3 grid4(grid.x * 4);
+          hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MW, 4, true, true, NN>), grid4, dim3(kWave), 0, s, p.P,
+                             p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
+          return;
         }
-        hipLaunchKernelGGL((bconv_sgpr_kernel<KH, KW, CWC, EP, MW, 4, true, true, NN>), grid4, dim3(kWave), 0, s, p.P,
-                           p.M, p.W, p.Z, BNN_EPI_ACTUALS, BNN_DS_ACTUALS, g);
-        return;
       }
       const dim3 grid2(grid.x * BNN_MULTI_GSPLIT);
       if constexpr (EP == EP_OUT && NN) {

@@ -89,7 +89,10 @@ __global__ __launch_bounds__(tail::NT) void avgpool_fc_kernel(const float* __res
 //       group-major, mt[n / 16][c][n % 16], so that an fc workgroup's operand is one contiguous block.
 //   fc_ws_kernel: workgroup = 16 images x 64 outputs, 8 waves = 8 k-segments; a lane owns one output and 16
 //       accumulators (images), per k one coalesced weight load (the weight is read once per workgroup, 32 MB of L2
-//       traffic per call instead of 128), the 16 means as ONE scalar load into SGPRs, eight v_pk_fma_f32.  The
+//       traffic per call instead of 128), four broadcast ds_read_b128 of the 16 means, eight v_pk_fma_f32 (measured:
+//       12 us inside a forward — the broadcast reads are 16 k cycles of LDS pipe per workgroup; the means through the
+//       scalar cache instead, one s_load_dwordx16 per k feeding v_pk_fma_f32 as its scalar pair: 36 us, the loads
+//       serialise on lgkmcnt(0) — not kept).  The
 //       partial sums of the segments meet in LDS and are added in segment order, then the bias: the summation tree of
 //       an output depends on C only — not on the batch size nor on the image's position in the batch.
 namespace tail2 {
@@ -135,6 +138,10 @@ __global__ __launch_bounds__(tail2::ROWS) void avgpool_rows_kernel(const float* 
   }
 }
 
+#ifdef BNN_FC_READLANE
+// Variant: the means of a wave's k-segment live in VECTOR registers, lane l holding the 16 means of k = kb + l (one
+// coalesced 4 KB read per 64 k), and step u broadcasts lane u's values with v_readlane_b32 into the scalar operand pair
+// of v_pk_fma_f32 — no LDS traffic in the product at all (LDS only for the eight partial sums).
 __global__ __launch_bounds__(tail2::NT) void fc_ws_kernel(const float* __restrict__ mt, const float* __restrict__ wt,
                                                            const float* __restrict__ bias, float* __restrict__ out,
                                                            int N, int C, int O) {
@@ -143,33 +150,104 @@ __global__ __launch_bounds__(tail2::NT) void fc_ws_kernel(const float* __restric
   extern __shared__ __attribute__((aligned(16))) float lds[];  // partial sums [KSEG][IMG][OT]
   const int g = blockIdx.x, o0 = blockIdx.y * OT;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int seg = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: what depends on it is wave-uniform
+  const int seg = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int o = o0 + lane;
-  const float* wp = wt + (o < O ? o : O - 1);  // lanes past the last output recompute it and store nothing
+  const float* wp = wt + (o < O ? o : O - 1);
   const int klen = (C + KSEG - 1) / KSEG;
   const int k0 = seg * klen, k1 = min(C, k0 + klen);
-  // The 16 means of a k are WAVE-UNIFORM: they come through the scalar cache into SGPRs (one s_load_dwordx16 per k) and
-  // feed v_pk_fma_f32 as its scalar operand pair.  (First version: means staged in LDS, four broadcast ds_read_b128 per
-  // k — a broadcast read still moves 1 KB through the LDS pipe: 2048 reads per workgroup = 16 k cycles, the kernel
-  // took 12 us for 3 us of arithmetic.)
   const float* mg = mt + (size_t)g * C * IMG;
   f2 acc[IMG / 2];
 #pragma unroll
   for (int i = 0; i < IMG / 2; ++i) acc[i] = f2{0.0f, 0.0f};
-  for (int kb = k0; kb < k1; kb += KU) {
-    float w[KU];
+  for (int kb = k0; kb < k1; kb += 64) {
+    float w[64];
 #pragma unroll
-    for (int u = 0; u < KU; ++u) w[u] = wp[(size_t)min(kb + u, k1 - 1) * O];
-#pragma unroll 8
-    for (int u = 0; u < KU; ++u) {
-      if (kb + u < k1) {  // wave-uniform
-        const float* m = mg + (size_t)(kb + u) * IMG;   // uniform address: scalar loads
+    for (int u = 0; u < 64; ++u) w[u] = wp[(size_t)min(kb + u, k1 - 1) * O];
+    float mv[IMG];
+    {
+      const float4* src = reinterpret_cast<const float4*>(mg + (size_t)min(kb + lane, k1 - 1) * IMG);
+#pragma unroll
+      for (int i = 0; i < IMG / 4; ++i) {
+        const float4 v = src[i];
+        mv[4 * i] = v.x; mv[4 * i + 1] = v.y; mv[4 * i + 2] = v.z; mv[4 * i + 3] = v.w;
+      }
+    }
+    const int nk = min(64, k1 - kb);  // wave-uniform
+#pragma unroll
+    for (int u = 0; u < 64; ++u) {
+      if (u < nk) {
         const f2 ww = f2{w[u], w[u]};
 #pragma unroll
-        for (int i = 0; i < IMG / 2; ++i) acc[i] = __builtin_elementwise_fma(f2{m[2 * i], m[2 * i + 1]}, ww, acc[i]);
+        for (int i = 0; i < IMG / 2; ++i) {
+          const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mv[2 * i]), u));
+          const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mv[2 * i + 1]), u));
+          acc[i] = __builtin_elementwise_fma(f2{a, b}, ww, acc[i]);
+        }
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < IMG / 2; ++i) {
+    lds[(seg * IMG + 2 * i) * OT + lane] = acc[i].x;
+    lds[(seg * IMG + 2 * i + 1) * OT + lane] = acc[i].y;
+  }
+  __syncthreads();
+  const float bv = (bias && o < O) ? bias[o] : 0.0f;
+  for (int i = seg; i < IMG; i += KSEG) {
+    float y = lds[i * OT + lane];
+#pragma unroll
+    for (int sg = 1; sg < KSEG; ++sg) y += lds[(sg * IMG + i) * OT + lane];
+    const int n = g * IMG + i;
+    if (n < N && o < O) out[(size_t)n * O + o] = y + bv;
+  }
+}
+#else
+__global__ __launch_bounds__(tail2::NT) void fc_ws_kernel(const float* __restrict__ mt, const float* __restrict__ wt,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int N, int C, int O) {
+  using namespace tail2;
+  using f2 = __attribute__((ext_vector_type(2))) float;
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // means [C][IMG]; afterwards partial sums [KSEG][IMG][OT]
+  const int g = blockIdx.x, o0 = blockIdx.y * OT;
+  const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
+  const int o = o0 + lane;
+  const float* wp = wt + (o < O ? o : O - 1);  // lanes past the last output recompute it and store nothing
+  const int klen = (C + KSEG - 1) / KSEG;
+  const int k0 = seg * klen, k1 = min(C, k0 + klen);
+  // the first KU weights of the segment are requested BEFORE the means are staged: they depend on nothing in LDS, and
+  // at ResNet-18 size (C = 512: 64 values per segment) they are the whole segment — one memory round trip
+  float w[KU];
+#pragma unroll
+  for (int u = 0; u < KU; ++u) w[u] = k0 < k1 ? wp[(size_t)min(k0 + u, k1 - 1) * O] : 0.0f;
+  {  // the group's means: one contiguous block of C * IMG floats
+    const float4* src = reinterpret_cast<const float4*>(mt + (size_t)g * C * IMG);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = tid; i < C * IMG / 4; i += NT) dst[i] = src[i];
+  }
+  __syncthreads();
+  f2 acc[IMG / 2];
+#pragma unroll
+  for (int i = 0; i < IMG / 2; ++i) acc[i] = f2{0.0f, 0.0f};
+  for (int kb = k0; kb < k1; kb += KU) {
+    if (kb > k0) {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) w[u] = wp[(size_t)min(kb + u, k1 - 1) * O];
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      if (kb + u < k1) {  // wave-uniform
+        const float4* m4 = reinterpret_cast<const float4*>(&lds[(kb + u) * IMG]);
+        const f2 ww = f2{w[u], w[u]};
+#pragma unroll
+        for (int i = 0; i < IMG / 4; ++i) {
+          const float4 a = m4[i];
+          acc[2 * i] = __builtin_elementwise_fma(f2{a.x, a.y}, ww, acc[2 * i]);
+          acc[2 * i + 1] = __builtin_elementwise_fma(f2{a.z, a.w}, ww, acc[2 * i + 1]);
+        }
+      }
+    }
+  }
+  __syncthreads();  // everybody is done with the means
 #pragma unroll
   for (int i = 0; i < IMG / 2; ++i) {
     lds[(seg * IMG + 2 * i) * OT + lane] = acc[i].x;
@@ -186,14 +264,19 @@ __global__ __launch_bounds__(tail2::NT) void fc_ws_kernel(const float* __restric
   }
 }
 
+#endif
+
 size_t avgpool_fc_workspace_bytes(int N, int C) {  // (64-bit, saturating: N and C are unchecked caller values here)
   const unsigned long long groups = ((unsigned long long)N + tail2::IMG - 1) / tail2::IMG;
   const unsigned long long elems = groups * (unsigned long long)C;  // < 2^58
   return elems > (1ull << 56) ? ~(size_t)0 : (size_t)(elems * tail2::IMG * sizeof(float));
 }
 
-// Whether the two-launch head covers the shape (else the caller runs the one-kernel form): any.
-bool avgpool_fc_ws_supported(int C, int HW) { return C >= 1 && HW >= 1; }
+// Whether the two-launch head covers the shape (else the caller runs the one-kernel form).
+bool avgpool_fc_ws_supported(int C, int HW) {
+  const size_t fc_lds = (size_t)C * tail2::IMG * sizeof(float);
+  return HW >= 1 && fc_lds <= (size_t)kMaxDynamicLds - 1024;
+}
 
 int launch_avgpool_fc_ws(const float* x, const float* wt, const float* bias, float* out, float* ws, int N, int C,
                          int HW, int O, hipStream_t stream) {
@@ -207,7 +290,13 @@ int launch_avgpool_fc_ws(const float* x, const float* wt, const float* bias, flo
     hipLaunchKernelGGL(avgpool_rows_kernel<0>, dim3(gridA), dim3(ROWS), 0, stream, x, ws, N, C, HW);
   }
   if (hipGetLastError() != hipSuccess) return BNN_HIP_ERR_LAUNCH;
-  const size_t lds = (size_t)KSEG * IMG * OT * sizeof(float);  // 32 KB
+  const size_t part = (size_t)KSEG * IMG * OT * sizeof(float);
+  size_t lds = (size_t)C * IMG * sizeof(float);
+  if (lds < part) lds = part;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(fc_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          kMaxDynamicLds) != hipSuccess)
+    return BNN_HIP_ERR_UNSUPPORTED;
   const dim3 gridB((N + IMG - 1) / IMG, (O + OT - 1) / OT);
   hipLaunchKernelGGL(fc_ws_kernel, gridB, dim3(NT), lds, stream, ws, wt, bias, out, N, C, O);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;

@@ -305,7 +305,8 @@ int bnn_hip_avgpool_fc_f32(const float* x, int N, int C, int HW, const float* w_
  * a streaming average-pool kernel (coalesced loads, the same index-order fp32 sums) into the workspace, then the
  * product as 16-image x 64-output tiles with the k range split over eight waves whose partial sums are added in
  * segment order.  workspace: bnn_hip_avgpool_fc_workspace_bytes(N, C) bytes, 16-byte aligned, contents undefined
- * before and after.  Per-image results do not depend on N or on the image's position in the batch.
+ * before and after.  Shapes the two-launch form does not cover (C * 64 bytes of LDS above the CU's 160 KB) run the
+ * one-kernel form.  Per-image results do not depend on N or on the image's position in the batch.
  * ResNet-18, batch 256: see profiles/ (round 5) — the one-kernel form is 28 us, latency-bound.                     */
 size_t bnn_hip_avgpool_fc_workspace_bytes(int N, int C);
 int bnn_hip_avgpool_fc_ws_f32(const float* x, int N, int C, int HW, const float* w_t, const float* bias,

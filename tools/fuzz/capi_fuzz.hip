@@ -121,10 +121,10 @@ size_t avgpool_fc_workspace_bytes(int N, int C) {
   const unsigned long long e = (((unsigned long long)N + 15) / 16) * (unsigned long long)C;
   return e > (1ull << 56) ? ~(size_t)0 : (size_t)(e * 64);
 }
-bool avgpool_fc_ws_supported(int C, int HW) { REQUIRE(C > 0 && HW > 0); return true; }
+bool avgpool_fc_ws_supported(int C, int HW) { REQUIRE(C > 0 && HW > 0); return (size_t)C * 64 <= 160 * 1024 - 1024; }
 int launch_avgpool_fc_ws(const float* x, const float* wt, const float*, float* out, float* ws, int N, int C, int HW, int O,
                          hipStream_t) {
-  ++g_reached; REQUIRE(x && wt && out && ws && al(ws, 16) && N > 0 && C > 0 && HW > 0 && O > 0);
+  ++g_reached; REQUIRE(x && wt && out && ws && al(ws, 16) && N > 0 && C > 0 && HW > 0 && O > 0 && (size_t)C * 64 <= 160 * 1024 - 1024);
   return BNN_HIP_OK;
 }
 size_t grad_weight_pack_bytes(int O, int C, int ks) { REQUIRE(O > 0 && C > 0 && (ks == 1 || ks == 3)); return 16; }

@@ -55,6 +55,8 @@ cd /tmp
 timeout 300 python "$R/tools/stem_ab.py" 2>&1 | tail -12 > "$OUT/stem_ab.txt"
 # VALU instructions per wave of every launch of one forward, from the SAME build (tools/kernel_roofline.py)
 bash "$R/tools/pmc_net.sh" > "$OUT/pmc_net.log" 2>&1
+# clocks / power under load and the two-stream timeline (round 5)
+( cd "$R" && bash tools/power_and_overlap.sh > "$OUT/power.log" 2>&1 )
 cd /tmp
 find "$OUT" -name "*kernel_trace.csv" -size +8M -delete
 cut -c1-400 "$OUT/bench.json"; echo; head -8 "$OUT"/stats1/*kernel_stats.csv 2>/dev/null | cut -c1-140
