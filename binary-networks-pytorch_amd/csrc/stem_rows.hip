@@ -149,7 +149,10 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
     int tiles_x, int seg_len, int nseg, unsigned x_bytes, float* __restrict__ out, uint64_t* __restrict__ P,
     uint64_t* __restrict__ M, unsigned out_bytes, unsigned plane_bytes) {
   using namespace stemr;
-  constexpr int AHEAD = HALF ? 3 : 1, RING = AHEAD + 1;  // fragment sets requested ahead (a HALF step is 4 MFMAs long)
+#ifndef BNN_ROWS_AHEAD  // fragment sets requested ahead in the split mode (each set: 32 VGPRs of the ring)
+#define BNN_ROWS_AHEAD 1
+#endif
+  constexpr int AHEAD = HALF ? 3 : BNN_ROWS_AHEAD, RING = AHEAD + 1;  // (a HALF step is 4 MFMAs long)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_rows[];
   uint32_t* patch = reinterpret_cast<uint32_t*>(lds_rows);
   uint32_t* bits = reinterpret_cast<uint32_t*>(lds_rows + OFF_BITS);  // double-buffered: tile t's words leave during t + 1

@@ -92,7 +92,8 @@ __global__ __launch_bounds__(tail::NT) void avgpool_fc_kernel(const float* __res
 //       traffic per call instead of 128), four broadcast ds_read_b128 of the 16 means, eight v_pk_fma_f32 (measured:
 //       12 us inside a forward — the broadcast reads are 16 k cycles of LDS pipe per workgroup; the means through the
 //       scalar cache instead, one s_load_dwordx16 per k feeding v_pk_fma_f32 as its scalar pair: 36 us, the loads
-//       serialise on lgkmcnt(0) — not kept).  The
+//       serialise on lgkmcnt(0); the means in vector registers, lane l holding those of k = kb + l, broadcast per step
+//       with v_readlane_b32 into the scalar pair: 12 us again — the reads are not what binds; neither kept).  The
 //       partial sums of the segments meet in LDS and are added in segment order, then the bias: the summation tree of
 //       an output depends on C only — not on the batch size nor on the image's position in the batch.
 namespace tail2 {
@@ -138,70 +139,6 @@ __global__ __launch_bounds__(tail2::ROWS) void avgpool_rows_kernel(const float* 
   }
 }
 
-#ifdef BNN_FC_READLANE
-// Variant: the means of a wave's k-segment live in VECTOR registers, lane l holding the 16 means of k = kb + l (one
-// coalesced 4 KB read per 64 k), and step u broadcasts lane u's values with v_readlane_b32 into the scalar operand pair
-// of v_pk_fma_f32 — no LDS traffic in the product at all (LDS only for the eight partial sums).
-__global__ __launch_bounds__(tail2::NT) void fc_ws_kernel(const float* __restrict__ mt, const float* __restrict__ wt,
-                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                           int N, int C, int O) {
-  using namespace tail2;
-  using f2 = __attribute__((ext_vector_type(2))) float;
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // partial sums [KSEG][IMG][OT]
-  const int g = blockIdx.x, o0 = blockIdx.y * OT;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int seg = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int o = o0 + lane;
-  const float* wp = wt + (o < O ? o : O - 1);
-  const int klen = (C + KSEG - 1) / KSEG;
-  const int k0 = seg * klen, k1 = min(C, k0 + klen);
-  const float* mg = mt + (size_t)g * C * IMG;
-  f2 acc[IMG / 2];
-#pragma unroll
-  for (int i = 0; i < IMG / 2; ++i) acc[i] = f2{0.0f, 0.0f};
-  for (int kb = k0; kb < k1; kb += 64) {
-    float w[64];
-#pragma unroll
-    for (int u = 0; u < 64; ++u) w[u] = wp[(size_t)min(kb + u, k1 - 1) * O];
-    float mv[IMG];
-    {
-      const float4* src = reinterpret_cast<const float4*>(mg + (size_t)min(kb + lane, k1 - 1) * IMG);
-#pragma unroll
-      for (int i = 0; i < IMG / 4; ++i) {
-        const float4 v = src[i];
-        mv[4 * i] = v.x; mv[4 * i + 1] = v.y; mv[4 * i + 2] = v.z; mv[4 * i + 3] = v.w;
-      }
-    }
-    const int nk = min(64, k1 - kb);  // wave-uniform
-#pragma unroll
-    for (int u = 0; u < 64; ++u) {
-      if (u < nk) {
-        const f2 ww = f2{w[u], w[u]};
-#pragma unroll
-        for (int i = 0; i < IMG / 2; ++i) {
-          const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mv[2 * i]), u));
-          const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mv[2 * i + 1]), u));
-          acc[i] = __builtin_elementwise_fma(f2{a, b}, ww, acc[i]);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < IMG / 2; ++i) {
-    lds[(seg * IMG + 2 * i) * OT + lane] = acc[i].x;
-    lds[(seg * IMG + 2 * i + 1) * OT + lane] = acc[i].y;
-  }
-  __syncthreads();
-  const float bv = (bias && o < O) ? bias[o] : 0.0f;
-  for (int i = seg; i < IMG; i += KSEG) {
-    float y = lds[i * OT + lane];
-#pragma unroll
-    for (int sg = 1; sg < KSEG; ++sg) y += lds[(sg * IMG + i) * OT + lane];
-    const int n = g * IMG + i;
-    if (n < N && o < O) out[(size_t)n * O + o] = y + bv;
-  }
-}
-#else
 __global__ __launch_bounds__(tail2::NT) void fc_ws_kernel(const float* __restrict__ mt, const float* __restrict__ wt,
                                                            const float* __restrict__ bias, float* __restrict__ out,
                                                            int N, int C, int O) {
@@ -264,7 +201,6 @@ __global__ __launch_bounds__(tail2::NT) void fc_ws_kernel(const float* __restric
   }
 }
 
-#endif
 
 size_t avgpool_fc_workspace_bytes(int N, int C) {  // (64-bit, saturating: N and C are unchecked caller values here)
   const unsigned long long groups = ((unsigned long long)N + tail2::IMG - 1) / tail2::IMG;
