@@ -121,7 +121,7 @@ class AutoFusion:
     model the executor does not cover (``FusionError``, remembered until the parameters change), or
     ``BNN_AMD_AUTOFUSE=0``.
 
-    Policy: the first batch of a given shape runs the fused launches eagerly (18 for ResNet-18); from the second one
+    Policy: the first batch of a given shape runs the fused launches eagerly (19 for ResNet-18); from the second one
     on the stem reads the caller's tensor and a HIP graph replays the rest (``FusedResNet.forward_fresh``) — the last,
     ragged batch of an epoch never pays for a capture.  A model built from classes of another package (same names
     and layout: the reference's ``bnn.models``) is fused only after its first fused result has been checked against

@@ -35,7 +35,7 @@ def _fused(block, x):
 def _bn_act(x, bn, act=None, residual=None):
     """``act(bn(x) (+ residual))``: on a HIP device in training mode one fused op (bnn_amd/training.py: bn_act — batch
     statistics, normalisation, residual add and ReLU in three launches instead of four library passes), in eval mode
-    without autograd one launch (bnn_amd/inference.py: eval_tail), else the modules themselves in the reference's
+    without autograd one launch (bnn_amd/tails.py: eval_tail), else the modules themselves in the reference's
     order."""
     if x.is_cuda and bn.training:
         from .. import training
@@ -54,7 +54,7 @@ def _bn_act(x, bn, act=None, residual=None):
 class _Residual(nn.Module):
     """Base of the residual blocks.  ``forward`` is the reference's op sequence (``_forward``), except that a block
     evaluated for inference on a HIP device first offers itself to the fused block executor
-    (``bnn_amd/inference.py: BlockFusion``) — the blocks of a ``ResNet`` are normally fused as part of the whole model
+    (``bnn_amd/dispatch.py: BlockFusion``) — the blocks of a ``ResNet`` are normally fused as part of the whole model
     (``AutoFusion``) and never get here."""
     expansion = 1
 

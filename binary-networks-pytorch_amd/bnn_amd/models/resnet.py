@@ -158,7 +158,7 @@ class ResNet(nn.Module):
         return self.maxpool(self.relu(self.bn1(x)))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        # eval + no_grad on a HIP device: the fused executor (bnn_amd/inference.py: AutoFusion) — what makes the
+        # eval + no_grad on a HIP device: the fused executor (bnn_amd/dispatch.py: AutoFusion) — what makes the
         # reference's own call `outputs = net(inputs)` (examples/cifar10.py:140-149) the fast path.  None -> per layer.
         inference = not self.training and x.is_cuda and not torch.is_grad_enabled()
         if inference:

@@ -143,7 +143,7 @@ class BNActFn(torch.autograd.Function):
 
 def _stats_written(bn: nn.BatchNorm2d) -> None:
     """The kernel has updated ``running_mean`` / ``running_var`` through raw pointers: bump their version counters (what an
-    in-place torch op would have done — caches keyed on ``_version``, e.g. ``inference.cached_fold``, must see the
+    in-place torch op would have done — caches keyed on ``_version``, e.g. ``tails.cached_fold``, must see the
     change) and count the batch."""
     for t in (bn.running_mean, bn.running_var):
         if t is not None:
