@@ -370,6 +370,11 @@ __device__ unsigned long long bnn_fly_dbg[8 * 16 * 4096];
 #define FLY_NOW() 0ull
 #endif
 
+#ifndef BNN_FLY_WAIT_AHEAD  // measured on config 2 (round 5, two alternating runs each): no limit 230.0 / 228.5 us,
+#define BNN_FLY_WAIT_AHEAD 0  // 8: 228.6 / 230.3, 2: 227.3 / 228.1, 0: 225.3 / 224.2 — the mean wave starts its first
+#endif                        // convolution 26 us after entry instead of 36 (per-wave stamps, -DBNN_FLY_TIMING)
+constexpr int kWaitAhead = BNN_FLY_WAIT_AHEAD;
+
 // The dataflow skeleton: zero fill, producers, then units until the tickets run out.
 // `conv(g, f, B, c, pg, p0, np, lane, nonneg)` computes one unit: passes p0 .. p0+np-1 of pixel group pg; `nonneg`:
 // no negative value under the unit's receptive fields (M planes all zero).
@@ -449,7 +454,15 @@ __device__ __forceinline__ void fly_run(const void* __restrict__ x, unsigned cha
       if (__hip_atomic_load(&c.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want &&
           range_ready(f, c, lo, hi, anyneg))
         break;
-      if (pack_item(x, g, f, B, c)) {  // whoever waits works
+      // whoever waits works — but (with producer waves, which hand out every item sooner or later) only on items near
+      // what this unit needs: at the start of a band all 16 waves wait, and if each of them takes the next item the
+      // first three rows arrive together with the first sixteen items (a third of the band: ~25 us of HBM time in
+      // which no convolution runs).  BNN_FLY_WAIT_AHEAD: pixel groups beyond the unit's own inputs a waiting consumer
+      // may still pack (< 0: no limit)
+      const bool near = f.nprod == 0 || kWaitAhead < 0 ||
+                        __hip_atomic_load(&c.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
+                            (uint32_t)((hi + 1 + kWaitAhead) * f.gpi);
+      if (near && pack_item(x, g, f, B, c)) {
 #ifdef BNN_FLY_TIMING
         ++n_items;
 #endif
