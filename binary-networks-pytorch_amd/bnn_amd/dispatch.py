@@ -375,6 +375,13 @@ def _auto_class(base: type) -> type:
                     return y
             return base.forward(self, x, *args, **kwargs)
 
+        def train(self, mode=True):             # train() <-> eval() drops the executor (models/resnet.py: ResNet.train)
+            if bool(mode) != self.training:
+                st = self.__dict__.get("_bnn_auto")
+                if st is not None:
+                    st.reset()
+            return base.train(self, mode)
+
         def __reduce_ex__(self, protocol):      # pickle / deepcopy: rebuilt from the importable base class
             return (_rebuild_auto, (base,), self.__dict__)
 
@@ -382,7 +389,8 @@ def _auto_class(base: type) -> type:
             auto_fusion(self)
             return base._replicate_for_data_parallel(self)
 
-        dyn = type(base.__name__, (base,), {"forward": forward, "__reduce_ex__": __reduce_ex__, "_bnn_base": base,
+        dyn = type(base.__name__, (base,), {"forward": forward, "train": train, "__reduce_ex__": __reduce_ex__,
+                                            "_bnn_base": base,
                                             "_replicate_for_data_parallel": _replicate_for_data_parallel,
                                             "__module__": base.__module__, "__qualname__": base.__qualname__,
                                             "__doc__": base.__doc__})

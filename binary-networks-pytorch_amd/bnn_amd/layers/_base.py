@@ -29,6 +29,18 @@ class BinaryLayerMixin:
         self.activation_post_process = bconfig.activation_post_process(self)
         self.weight_pre_process = bconfig.weight_pre_process()
 
+    def train(self, mode: bool = True):
+        """Switching between training and evaluation drops the derived data (packed weights): the packed-weight cache is
+        keyed on the weight's storage pointer + autograd version counter, which writes through ``.data`` —
+        ``p.data.clamp_(-1, 1)`` after the optimizer step, EMA swaps — do not move.  Whatever was written while training
+        is therefore seen by the first forward after ``model.eval()`` (and the other way round); the reference has no such
+        state to go stale (it re-binarises on every forward, bnn/layers/conv.py:92).  A ``.data`` write BETWEEN two
+        forwards of the same mode still needs ``fastpath.invalidate(model)``."""
+        if bool(mode) != self.training:
+            self.__dict__.pop("_bnn_packed", None)
+            self.__dict__.pop("_bnn_packed_replicas", None)
+        return super().train(mode)
+
     def _replicate_for_data_parallel(self):
         """``nn.DataParallel`` (examples/cifar10.py:74-77) makes its per-device replicas with this on EVERY forward:
         ``__dict__`` is copied shallowly and the parameters are replaced by freshly broadcast copies.  The replica

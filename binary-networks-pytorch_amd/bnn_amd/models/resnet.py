@@ -135,6 +135,16 @@ class ResNet(nn.Module):
         self.outplanes = out_ch
         return nn.Sequential(*stage)
 
+    def train(self, mode: bool = True):
+        # train() <-> eval(): the fused executor's packed weights and folded BatchNorm constants are derived data of
+        # the parameters; drop them with the mode (layers/_base.py: BinaryLayerMixin.train — `.data` writes made while
+        # training are then seen by the first evaluation forward)
+        if bool(mode) != self.training:
+            st = self.__dict__.get("_bnn_auto")
+            if st is not None:
+                st.reset()
+        return super().train(mode)
+
     def _replicate_for_data_parallel(self):
         # nn.DataParallel replicas share the master's AutoFusion state (`replicate` copies __dict__): it must exist
         # before the copy is made, or every replica of every forward would start from scratch

@@ -174,3 +174,33 @@ def test_the_one_launch_tails_keep_out_of_everything_they_do_not_cover():
     assert not inference.TwoHalves.wanted(torch.empty(127, 3, 224, 224, device="meta"))
     assert inference.TwoHalves.wanted(torch.empty(512, 3, 112, 112, device="meta"))
     assert not inference.TwoHalves.wanted(torch.empty(1, 3, 4096, 4096, device="meta"))
+
+
+def test_switching_between_training_and_evaluation_drops_derived_data():
+    """`model.train()` / `model.eval()` drop the packed-weight caches of the binary layers (and the fused executor of a
+    ResNet): writes through `.data` made while training — weight clipping after the optimizer step, which autograd's
+    version counter does not see — reach the first evaluation forward without `fastpath.invalidate`."""
+    import torch.nn as nn
+    from bnn_amd.models import resnet18
+    from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer
+    cfg = bnn.BConfig(activation_pre_process=BasicInputBinarizer, activation_post_process=bnn.Identity,
+                      weight_pre_process=XNORWeightBinarizer)
+    layer = bnn.prepare_binary_model(nn.Conv2d(8, 8, 3), cfg)
+    assert layer.training
+    layer.__dict__["_bnn_packed"] = ("key", "pack")
+    layer.__dict__["_bnn_packed_replicas"] = {"cuda:1": ("key", "pack")}
+    layer.train()                                   # no switch: nothing dropped
+    assert "_bnn_packed" in layer.__dict__
+    layer.eval()
+    assert "_bnn_packed" not in layer.__dict__ and "_bnn_packed_replicas" not in layer.__dict__ and not layer.training
+    layer.__dict__["_bnn_packed"] = ("key", "pack")
+    layer.eval()
+    assert "_bnn_packed" in layer.__dict__
+    layer.train()
+    assert "_bnn_packed" not in layer.__dict__ and layer.training
+    net = bnn.prepare_binary_model(resnet18(), cfg, custom_config_layers_name={"conv1": bnn.BConfig(), "fc": bnn.BConfig()})
+    st = auto_fusion(net)
+    st.engine, st.verified = object(), True
+    net.layer1[0].conv1.__dict__["_bnn_packed"] = ("key", "pack")
+    net.eval()
+    assert st.engine is None and not st.verified and "_bnn_packed" not in net.layer1[0].conv1.__dict__

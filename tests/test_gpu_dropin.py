@@ -136,6 +136,30 @@ def test_parameter_updates_are_seen_by_the_next_call():
     assert torch.allclose(y1, y_layer, rtol=1e-3, atol=1e-3 * float(y_layer.abs().max()))
 
 
+def test_weights_written_through_dot_data_while_training_reach_the_next_evaluation():
+    """`p.data.clamp_()` after the optimizer step does not move autograd's version counter — the one thing the fused
+    executor's packed weights are keyed on.  `net.train()` / `net.eval()` drop the executor and the layers' packs
+    (round 5), so the usual loop — train with clipping, then evaluate — sees the clipped weights without
+    `fastpath.invalidate`."""
+    net = _r18()
+    x = dev(gen.normal(16, (4, 3, 64, 64)))
+    with torch.no_grad():
+        y0 = net(x)
+        assert auto_fusion(net).engine is not None
+        net.train()
+        assert auto_fusion(net).engine is None
+        w = net.layer2[1].conv1.weight
+        v = w._version
+        w.data.mul_(-1.0)                             # through .data: invisible to the version counter
+        assert w._version == v
+        net.eval()
+        y1 = net(x)
+        assert not torch.equal(y1, y0) and torch.equal(y1, FusedResNet(net)(x))
+        with per_layer_forward():
+            y_layer = net(x)
+        assert torch.allclose(y1, y_layer, rtol=1e-3, atol=1e-3 * float(y_layer.abs().max()))
+
+
 def test_data_parallel_wrapper_and_deepcopy_and_state_dict():
     net = _r18()
     keys = list(net.state_dict().keys())

@@ -529,6 +529,19 @@ def test_writes_through_dot_data_need_invalidate_and_training_never_trusts_the_c
         layer.weight.data.mul_(-1.0)
     y_tr = layer(xd.clone().requires_grad_(True))     # training forward: always from the current values
     assert torch.equal(y_tr.detach(), y0)
+    # round 5: train() <-> eval() drops the derived data, so what was written through .data while training (weight
+    # clipping after the optimizer step) is seen by the first evaluation forward without invalidate()
+    layer.eval()
+    with torch.no_grad():
+        assert torch.equal(layer(xd), y0)
+        layer.train()
+        layer.weight.data.mul_(-1.0)                  # "p.data.clamp_()" of a training loop
+        layer.eval()
+        assert torch.equal(layer(xd), -y0)
+        layer.weight.data.mul_(-1.0)                  # between two forwards of the SAME mode: still the documented case
+        assert torch.equal(layer(xd), -y0)
+        fastpath.invalidate(layer)
+        assert torch.equal(layer(xd), y0)
 
 
 def test_zero_weights_first_seen_by_a_grad_mode_forward_are_honoured_by_inference():
