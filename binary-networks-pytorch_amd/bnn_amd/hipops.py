@@ -225,6 +225,28 @@ def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: 
     return y, pk
 
 
+def stem7x7_conv(x: torch.Tensor, w: torch.Tensor, fp16: bool = False) -> torch.Tensor:
+    """The stem's convolution alone — conv 7x7/2/3, 3 -> 64, no bias (bnn/models/resnet.py:93,150) — on the matrix cores
+    (``bnn_hip_stem7x7_conv_f32``: the MFMA stream of ``stem7x7``, fp32-class accuracy): what a TRAINING step needs in
+    front of its batch-statistics BatchNorm.  Returns fp32 ``[N, 64, Hc, Wc]``."""
+    x = _require_cuda_f32(x, "stem input")
+    w = _require_cuda_f32(w.detach(), "stem weight")
+    if x.dim() != 4 or x.shape[1] != 3 or tuple(w.shape) != (64, 3, 7, 7):
+        raise native.NativeError("bnn_amd: stem7x7_conv expects x [N,3,H,W] and w [64,3,7,7]")
+    lib = native.require()
+    N, _, H, W = x.shape
+    hc, wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    with torch.cuda.device(x.device):
+        y = torch.empty((N, 64, hc, wc), dtype=torch.float32, device=x.device)
+        step = max(1, min(N, _MAX_DESC_BYTES // max(12 * H * W, 256 * hc * wc)))   # 32-bit descriptors (see stem7x7)
+        for n0 in range(0, N, step):
+            n1 = min(N, n0 + step)
+            native.check(lib.bnn_hip_stem7x7_conv_f32(x[n0:n1].data_ptr(), w.data_ptr(), n1 - n0, H, W,
+                                                      native.STEM_FP16 if fp16 else 0, y[n0:n1].data_ptr(),
+                                                      _stream(x.device)), "bnn_hip_stem7x7_conv_f32")
+    return y
+
+
 def sign_thresholds(w: PackedWeight, bn_scale: torch.Tensor, bn_shift: torch.Tensor, bias=None, post_scale=None):
     """Integer form of ``sign(relu(bn(alpha * dot + bias)))`` for ``bconv2d_fused(..., sign_thresholds=...)``:
     int32 ``[O, 4]`` = (bound T, flip word of the channel's 32-channel block, the two comparands of the kernels'

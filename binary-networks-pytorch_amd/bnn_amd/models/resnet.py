@@ -159,10 +159,14 @@ class ResNet(nn.Module):
             y = eval_stem(self, x)
             if y is not None:
                 return y
+        if self.stem_type == "basic" and x.is_cuda and self.training:
+            # training on a HIP device: the 7x7 convolution on the matrix cores, bn1 -> relu -> maxpool as one fused op
+            from .. import training
+            return training.stem_tail(training.stem_conv(x, self.conv1), self.bn1, self.relu, self.maxpool)
         x = self.conv1(x)
         if self.stem_type != "basic":
             return x
-        if x.is_cuda and self.bn1.training:          # training on a HIP device: bn1 -> relu -> maxpool as one fused op
+        if x.is_cuda and self.bn1.training:          # (bn1 alone in training mode)
             from .. import training
             return training.stem_tail(x, self.bn1, self.relu, self.maxpool)
         return self.maxpool(self.relu(self.bn1(x)))

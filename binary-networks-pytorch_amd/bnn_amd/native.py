@@ -43,6 +43,7 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_bn_train_backward_f32", "bnn_hip_bn_relu_maxpool_train_forward_f32",
     "bnn_hip_bn_relu_maxpool_train_backward_f32", "bnn_hip_xnor_weight_forward_f32", "bnn_hip_xnor_weight_backward_f32",
     "bnn_hip_bn_act_f32", "bnn_hip_avgpool_fc_workspace_bytes", "bnn_hip_avgpool_fc_ws_f32",
+    "bnn_hip_stem7x7_conv_f32",
 )
 
 
@@ -144,6 +145,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_bconv2d_direct_plan.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(FlyPlan)]
     lib.bnn_hip_bconv2d_direct.argtypes = [ctypes.POINTER(ConvDesc), _vp, _i] + [_vp] * 6 + \
         [ctypes.POINTER(FlyPlan), _vp]
+    lib.bnn_hip_stem7x7_conv_f32.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp, _vp]
     lib.bnn_hip_avgpool_fc_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]
     lib.bnn_hip_avgpool_fc_workspace_bytes.argtypes = [_i, _i]
     lib.bnn_hip_avgpool_fc_workspace_bytes.restype = ctypes.c_size_t

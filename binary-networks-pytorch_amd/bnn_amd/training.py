@@ -202,6 +202,48 @@ class StemTailFn(torch.autograd.Function):
                 dbeta if ctx.needs_input_grad[2] else None, None)
 
 
+# The stem's convolution in a training step (bnn/models/resnet.py:150): the library's 7x7 forward is 1.2 ms of a 19.6 ms
+# step at batch 256; the inference stem's MFMA core with a raw-conv epilogue (csrc/stem_rows.hip, RAW) is ~0.4 ms.  The
+# weight gradient stays the library's (the input is data: no input gradient).
+FUSED_STEM_CONV = os.environ.get("BNN_AMD_TRAIN_STEM_CONV", "1") == "1"
+
+
+class StemConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return hipops.stem7x7_conv(x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx, gw, _ = torch.ops.aten.convolution_backward(
+            g.contiguous(), x, w, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+            [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
+        return (gx if ctx.needs_input_grad[0] else None, gw if ctx.needs_input_grad[1] else None)
+
+
+def stem_conv_applies(conv: nn.Module, x: torch.Tensor) -> bool:
+    """``conv(x)`` is the canonical real-valued stem convolution in a training step on a HIP device: a stock
+    ``nn.Conv2d`` (or a binary-class layer whose recipe is all-Identity, examples/cifar10.py:71) 3 -> 64, 7x7, stride 2,
+    padding 3, no bias, fp32 NCHW, no hooks."""
+    from .executor import _is_float_layer
+    return (FUSED_STEM_CONV and ENABLED and isinstance(conv, nn.Conv2d) and _is_float_layer(conv)
+            and conv.in_channels == 3 and conv.out_channels == 64 and tuple(conv.kernel_size) == (7, 7)
+            and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (3, 3) and tuple(conv.dilation) == (1, 1)
+            and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros"
+            and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and conv.weight.dtype == torch.float32 and torch.is_grad_enabled()
+            and not conv._forward_hooks and not conv._forward_pre_hooks and not conv._backward_hooks)
+
+
+def stem_conv(x: torch.Tensor, conv: nn.Module) -> torch.Tensor:
+    """``conv(x)`` — the MFMA kernel when ``stem_conv_applies``, else the module itself."""
+    if stem_conv_applies(conv, x):
+        return StemConvFn.apply(x, conv.weight)
+    return conv(x)
+
+
 def stem_tail(x: torch.Tensor, bn: nn.Module, act: nn.Module, pool: nn.Module) -> torch.Tensor:
     """``pool(act(bn(x)))`` — one fused op when it is BatchNorm2d (training) -> ReLU -> MaxPool2d(3, 2, 1) on a HIP
     device, else the modules themselves."""

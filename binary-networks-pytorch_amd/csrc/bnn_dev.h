@@ -133,6 +133,7 @@ int launch_stem_split(const float* x, const float* w, const float* bn_a, const f
 int launch_bconv_lds(const ConvP& p, hipStream_t s);
 int launch_stem_rows(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                       int W, int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
+int launch_stem_conv(const float* x, const float* w, int N, int H, int W, int half, float* out, hipStream_t stream);
 int launch_avgpool_fc(const float* x, const float* wt, const float* bias, float* out, int N, int C, int HW,
                       int O, hipStream_t stream);
 size_t avgpool_fc_workspace_bytes(int N, int C);

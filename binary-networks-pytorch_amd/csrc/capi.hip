@@ -295,6 +295,20 @@ int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w, const 
                           static_cast<hipStream_t>(stream));
 }
 
+int bnn_hip_stem7x7_conv_f32(const float* x, const float* w, int N, int H, int W, int flags, float* out,
+                             void* stream) {
+  if (!x || !w || !out || N <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (flags & ~BNN_HIP_STEM_FP16) return BNN_HIP_ERR_INVALID_ARG;
+  if (!aligned(x, 4) || !aligned(w, 4) || !aligned(out, 4)) return BNN_HIP_ERR_INVALID_ARG;
+  {  // 32-bit buffer descriptors, as in the fused stem: input and the [N, 64, Hc, Wc] output below 2^32 - 512 bytes
+    const long long hc = (H - 1) / 2 + 1, wc = (W - 1) / 2 + 1;
+    if (mulc(N, 12, H, W) > kMaxDescBytes || mulc(N, 256, hc, wc) > kMaxDescBytes) return BNN_HIP_ERR_TOO_LARGE;
+  }
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_stem_conv(x, w, N, H, W, (flags & BNN_HIP_STEM_FP16) != 0, out, static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_avgpool_fc_f32(const float* x, int N, int C, int HW, const float* w_t, const float* bias, int O,
                            float* out, void* stream) {
   if (!x || !w_t || !out || N <= 0 || C <= 0 || HW <= 0 || O <= 0) return BNN_HIP_ERR_INVALID_ARG;

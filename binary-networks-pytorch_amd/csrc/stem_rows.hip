@@ -142,7 +142,10 @@ __device__ __forceinline__ uint32_t or_rows(uint32_t w) { return w; }
 constexpr unsigned kRowsOOB = 0xFFFFFFF0u;  // beyond every descriptor's num_records
 
 // HALF: plain fp16 operands, one MFMA per product (BNN_HIP_STEM_FP16).
-template <bool HALF>
+// RAW (round 5, the training forward: bnn_hip_stem7x7_conv_f32): the convolution alone — every conv row leaves as it is
+// finished, fp32 [N, 64, Hc, Wc]; no BatchNorm, no pooling, no sign planes (bn_a / bn_b / P / M unused).  The same
+// MFMA stream, so the values are the ones the fused kernel normalises and pools.
+template <bool HALF, bool RAW = false>
 __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bn_a,
     const float* __restrict__ bn_b, int N, int H, int W, int Hc, int Wc, int Hp, int Wp, int tiles_y,
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
       kb[ks] = lds0 + (uint32_t)(((CIN - 1) * ITH + KS - 1) * ROWD + 2 * WPW * mg + lcol + 2 * (lg & 1)) * 4u;
   }
   // BN constants of the accumulator layout (register r of tile tt -> channel 32*nh + 16*tt + 4*lg + r)
-  constexpr bool LEAN = BNN_ROWS_LEAN != 0;
+  constexpr bool LEAN = BNN_ROWS_LEAN != 0 && !RAW;
   [[maybe_unused]] float ba[2][4], bb[2][4];
   using lds_f4 = __attribute__((address_space(3))) const f32x4;
   [[maybe_unused]] const uint32_t bn_lane = lds0 + (uint32_t)(OFF_BN + (32 * nh + 4 * lg) * 4);  // + 64 * tt, + 256 for b
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
       bnl[tid] = bn_a[tid];
       bnl[COUT + tid] = bn_b[tid];
     }
-  } else {
+  } else if constexpr (!RAW) {
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -257,6 +260,10 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
   const bool pool_lane = li >= 8 && li < 8 + WPW;
   const unsigned out_lane = (unsigned)((4 * lg * Hp) * Wp + plx) * 4u;      // channel 4*lg (+ r), pooled column plx
   const unsigned flush_lane = (unsigned)((tid / PTW) * Wp + tid % PTW) * 8u;  // pixel (tid / PTW, tid % PTW) of a tile
+  // RAW: a wave stores conv columns 1 .. 14 of its strip (column 0 is its left neighbour's column 14, column 15 idles):
+  // channel 4*lg (+ r), conv column 14*mg + lcol - 1 of the tile's 28
+  [[maybe_unused]] const unsigned raw_lane = (unsigned)((4 * lg * Hc) * Wc + 2 * WPW * mg + lcol - 1) * 4u;
+  [[maybe_unused]] const bool raw_col = lcol >= 1 && lcol <= 2 * WPW;
 
   // Tile list: strip-major (image, column strip, row).  A workgroup works through `nseg` segments of `seg_len`
   // consecutive tiles; segment j of logical workgroup wg starts at tile (wg + j * grid) * seg_len.  With at least
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
   // whole 64-bit words
   int prev_n = -1, prev_py0 = 0, prev_px0 = 0, buf = 0, pb = 0;
   auto flush_bits = [&](int b) {
-    if (prev_n >= 0 && tid < PTH * PTW) {  // wave 0 only
+    if (!RAW && prev_n >= 0 && tid < PTH * PTW) {  // wave 0 only
       const int ply = tid / PTW, px = tid - ply * PTW;
       const bool ok = prev_py0 + ply < Hp && prev_px0 + px < Wp;
       const unsigned soff = (unsigned)((prev_n * Hp + prev_py0) * Wp + prev_px0) * 8u;
@@ -435,6 +442,15 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
     auto lo4 = [](half8 v) { return half4{v[0], v[1], v[2], v[3]}; };
     auto multiply = [&](int slot, int ks, int rows) {
       if (K16 && ks == KSTEPS - 1) {  // (constant after unrolling) the same three products, 16 k per instruction
+#if defined(__HIP_DEVICE_COMPILE__)
+        // hipcc 7.2 schedules an 8-pass v_mfma_f32_16x16x32_f16 and, in the very next slot, a 4-pass
+        // v_mfma_f32_16x16x16_f16 whose SrcC is that result and whose vDst is another register quad, with no wait states
+        // between them; gfx950 then delivers two of the four result registers wrong (seen in the RAW kernel's last
+        // pooled row: conv rows 6 mod 8, channels 4*lg + {0, 1}; tools/experiments/README.md 54).  The packed kernels'
+        // schedules never place the pair back to back (tools/isa_extract.py; their bit-exactness tests would show it);
+        // RAW closes the window explicitly: every 32-k product is issued before the first 16-k one, 16 slots apart.
+        if constexpr (RAW) asm volatile("s_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+#endif
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -511,6 +527,27 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
     };
     // pooled row q of the tile from the kept row and the two rows in the accumulators: pooling, stores, sign bits
     auto finish = [&](int q) {
+      if constexpr (RAW) {
+        // conv rows 2q + 1, 2q + 2 of the tile = rows 8*ty + 2q, + 1 of the image (row 0 of a tile is the previous
+        // tile's row 8: stored there), columns 28*tx + 14*mg .. + 13
+        const bool col_ok = raw_col && 2 * px0 + 2 * WPW * mg + lcol - 1 < Wc;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int row = 2 * py0 + 2 * q + d;
+          if (col_ok && row < Hc) {
+            unsigned soff = (unsigned)(((n * COUT + 32 * nh) * Hc + row) * Wc + 2 * px0) * 4u;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                rows_st(r_out, raw_lane, soff, acc[d][tt][r]);
+                soff += (r == 3 ? 13u : 1u) * (unsigned)(Hc * Wc) * 4u;
+                asm volatile("" : "+s"(soff));
+              }
+          }
+        }
+        return;
+      }
       float y0[2][4], y1[2][4];
       bn_row(y0, 0, 2 * q + 1);
       bn_row(y1, 1, 2 * q + 2);
@@ -551,7 +588,9 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
 
     // The conv row above the tile: kept in registers from the tile above (same strip, previous iteration); MaxPool
     // padding above the image; computed here (2 accumulator chains only) at the start of a chunk inside a strip.
-    if (cy0 < 0) {
+    if (RAW) {
+      // (no pooling: the row above the tile is not needed)
+    } else if (cy0 < 0) {
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -619,7 +658,7 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
 #endif
 }
 
-template <bool HALF>
+template <bool HALF, bool RAW = false>
 static int launch_stem_rows_t(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                               int W, float* out, uint64_t* P, uint64_t* M, hipStream_t stream) {
   using namespace stemr;
@@ -638,15 +677,15 @@ static int launch_stem_rows_t(const float* x, const float* w, const float* bn_a,
   const int seg_len = strips >= grid ? tiles_y : (int)((ntiles + grid - 1) / grid);
   const int nseg = strips >= grid ? (int)((strips + grid - 1) / grid) : 1;
   // per device and per kernel, so it is set on every launch (no mutable global state in a re-entrant API)
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_rows_kernel<HALF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          LDS_BYTES) != hipSuccess)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_rows_kernel<HALF, RAW>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
     return BNN_HIP_ERR_LAUNCH;
   // byte sizes of the streams (the C-ABI caps every tensor below 2^32 bytes)
-  const unsigned out_bytes = (unsigned)((long long)N * COUT * Hp * Wp * 4);
+  const unsigned out_bytes = (unsigned)((long long)N * COUT * (RAW ? (long long)Hc * Wc : (long long)Hp * Wp) * 4);
   const unsigned plane_bytes = (unsigned)((long long)N * Hp * Wp * 8);
   const unsigned x_bytes = (unsigned)((long long)N * CIN * H * W * 4);
-  hipLaunchKernelGGL(stem_rows_kernel<HALF>, dim3(grid), dim3(NT), LDS_BYTES, stream, x, w, bn_a, bn_b, N, H, W, Hc,
-                     Wc, Hp, Wp, tiles_y, tiles_x, seg_len, nseg, x_bytes, out, P, M, out_bytes, plane_bytes);
+  hipLaunchKernelGGL((stem_rows_kernel<HALF, RAW>), dim3(grid), dim3(NT), LDS_BYTES, stream, x, w, bn_a, bn_b, N, H, W,
+                     Hc, Wc, Hp, Wp, tiles_y, tiles_x, seg_len, nseg, x_bytes, out, P, M, out_bytes, plane_bytes);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
@@ -654,6 +693,12 @@ int launch_stem_rows(const float* x, const float* w, const float* bn_a, const fl
                      int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream) {
   return half ? launch_stem_rows_t<true>(x, w, bn_a, bn_b, N, H, W, out, P, M, stream)
               : launch_stem_rows_t<false>(x, w, bn_a, bn_b, N, H, W, out, P, M, stream);
+}
+
+// The convolution alone (training forward): fp32 [N, 64, Hc, Wc].
+int launch_stem_conv(const float* x, const float* w, int N, int H, int W, int half, float* out, hipStream_t stream) {
+  return half ? launch_stem_rows_t<true, true>(x, w, nullptr, nullptr, N, H, W, out, nullptr, nullptr, stream)
+              : launch_stem_rows_t<false, true>(x, w, nullptr, nullptr, N, H, W, out, nullptr, nullptr, stream);
 }
 
 }  // namespace bnn

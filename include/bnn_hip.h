@@ -62,7 +62,7 @@ extern "C" {
 #endif
 
 /* ABI 14 (round 5): + bnn_hip_avgpool_fc_ws_f32 / bnn_hip_avgpool_fc_workspace_bytes (the head as two streaming launches
- * through a workspace); the table of bnn_hip_sign_thresholds_f32 holds FOUR words per channel (was two) and kmax < 2^20.
+ * through a workspace); + bnn_hip_stem7x7_conv_f32 (the stem's convolution alone: the training forward); the table of bnn_hip_sign_thresholds_f32 holds FOUR words per channel (was two) and kmax < 2^20.
  * ABI 13 (round 4): + bnn_hip_bn_act_f32 (eval-mode BatchNorm + residual + ReLU tail of the per-layer path);
  * bnn_hip_xnor_weight_backward_f32 takes `splits` partial slabs.
  * ABI 12 (round 4): + bnn_hip_probe_clock; + the training-side entry points bnn_hip_pack_act_ste_f32,
@@ -293,6 +293,14 @@ int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w,
                                           const float* bn_scale, const float* bn_shift,
                                           int N, int H, int W, int flags,
                                           float* out_f32, uint64_t* P, uint64_t* M, void* stream);
+
+/* ABI 14 — the stem's convolution ALONE, for the training forward (bnn/models/resnet.py:150: `x = self.conv1(x)`; the
+ * BatchNorm of a training step needs the raw conv output for its batch statistics): conv 7x7 / stride 2 / pad 3,
+ * 3 -> 64 channels, no bias.  x: float32 [N,3,H,W], w: float32 [64,3,7,7], out: float32 [N,64,Hc,Wc] with
+ * Hc = (H - 1) / 2 + 1.  The same MFMA stream as the fused stem (fp32 operands as fp16 hi + lo, three products, fp32
+ * accumulation; flags = BNN_HIP_STEM_FP16: plain fp16 operands): the values the fused kernel normalises and pools, bit
+ * for bit.  Same size limits as the fused stem.                                                                     */
+int bnn_hip_stem7x7_conv_f32(const float* x, const float* w, int N, int H, int W, int flags, float* out, void* stream);
 
 /* The real-valued head of the reference's ResNets in one kernel (bnn/models/resnet.py:160-164:
  * avgpool -> flatten -> fc):  out[n,o] = bias[o] + sum_c w_t[c,o] * mean_hw x[n,c,hw].

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 import bnn_amd as bnn
-from bnn_amd import fastpath, training
+from bnn_amd import fastpath, hipops, training
 from bnn_amd.models import resnet18
 from bnn_amd.ops import BasicInputBinarizer, BasicScaleBinarizer, XNORWeightBinarizer
 from tests.golden import gen
@@ -621,3 +621,52 @@ def test_training_step_with_and_without_the_fused_weight_hook():
     assert l1 == l0                                         # the forward does not depend on the hook's form
     for a, b in zip(g1, g0):
         assert float((a - b).norm()) <= 1e-3 * float(b.norm()) + 1e-12
+
+
+@pytest.mark.parametrize("shape", [(4, 3, 224, 224), (3, 3, 64, 64), (2, 3, 50, 38), (1, 3, 97, 131), (5, 3, 33, 65), (1, 3, 7, 9)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_stem_convolution_alone_matches_fp64_and_feeds_the_fused_stem_its_values(shape):
+    """bnn_hip_stem7x7_conv_f32 (round 5: conv1 of a TRAINING step on the matrix cores, bnn/models/resnet.py:150): the raw
+    convolution against fp64, and — BatchNorm, ReLU and MaxPool applied to it by torch — the fused inference stem's
+    output: the same MFMA stream, so the same values."""
+    import torch.nn.functional as F
+    x = dev(gen.normal(gen.seed_of("stemraw", shape), shape))
+    w = dev(gen.conv_weight("kaiming", 3, (64, 3, 7, 7)))
+    y = hipops.stem7x7_conv(x, w)
+    ref = F.conv2d(x.double(), w.double(), None, 2, 3)
+    assert y.shape == ref.shape
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    a = dev((0.5 + gen.uniform(1, (64,))).astype(np.float32) * np.where(np.arange(64) % 7 == 0, -1, 1).astype(np.float32))
+    b = dev((0.3 * gen.normal(2, (64,))).astype(np.float32))
+    fused, _ = hipops.stem7x7(x, w, a, b, out_packed=False)
+    # fma(y, a, b) in fp64 and rounded once (the product of two fp32 values is exact in fp64)
+    z = (y.double() * a.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1)).float()
+    mine = F.max_pool2d(torch.relu(z), 3, 2, 1)
+    assert mine.shape == fused.shape
+    assert float((mine != fused).float().mean()) <= 1e-6          # (double rounding of the fp64 emulation of fma: ~never)
+    assert torch.allclose(mine, fused, rtol=1e-6, atol=1e-6 * float(fused.abs().max()))
+    y16 = hipops.stem7x7_conv(x, w, fp16=True)
+    assert float((y16.double() - ref).abs().max()) <= 3e-3 * float(ref.abs().max())
+
+
+def test_training_step_with_the_stem_convolution_on_the_matrix_cores():
+    """One ResNet-18 training step with conv1 as the MFMA kernel (default) against the same step with the library's
+    convolution: loss, the weight gradient of conv1 (the library's backward either way) and the input gradient."""
+    def step(on):
+        training.FUSED_STEM_CONV = on
+        try:
+            net = _r18_train()
+            assert training.stem_conv_applies(net.conv1, dev(gen.normal(1, (2, 3, 32, 32)))) == on
+            x = dev(gen.normal(91, (8, 3, 64, 64))).requires_grad_(True)
+            loss = torch.nn.functional.cross_entropy(net(x), torch.arange(8, device=DEV) * 7)
+            loss.backward()
+            return float(loss.detach()), net.conv1.weight.grad.clone(), x.grad.clone()
+        finally:
+            training.FUSED_STEM_CONV = True
+    l1, gw1, gx1 = step(True)
+    l0, gw0, gx0 = step(False)
+    assert abs(l1 - l0) <= 1e-4 * abs(l0)
+
+    def close(a, b, tol):      # (binarised nets are discontinuous: compare in norm, as the fused-BatchNorm test does)
+        return float((a - b).norm()) <= tol * float(b.norm()) + 1e-12
+    assert close(gw1, gw0, 5e-2) and close(gx1, gx0, 2e-2)

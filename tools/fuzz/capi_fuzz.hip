@@ -113,6 +113,13 @@ int launch_stem(const float* x, const float* w, const float* a, const float* b, 
   REQUIRE(!P || (al(P, 8) && al(M, 8)));
   return BNN_HIP_OK;
 }
+int launch_stem_conv(const float* x, const float* w, int N, int H, int W, int, float* out, hipStream_t) {
+  ++g_reached;
+  REQUIRE(x && w && out && N > 0 && H > 0 && W > 0);
+  const long long hc = (H - 1) / 2 + 1, wc = (W - 1) / 2 + 1;
+  REQUIRE((long long)N * 3 * H * W * 4 <= kDesc && (long long)N * 64 * hc * wc * 4 <= kDesc);
+  return BNN_HIP_OK;
+}
 int launch_avgpool_fc(const float* x, const float* wt, const float*, float* out, int N, int C, int HW, int O, hipStream_t) {
   ++g_reached; REQUIRE(x && wt && out && N > 0 && C > 0 && HW > 0 && O > 0); return BNN_HIP_OK;
 }
@@ -252,7 +259,7 @@ int main(int argc, char** argv) {
   for (long it = 0; it < iters; ++it) {
     ++g_calls;
     int st = 0;
-    switch (rnd() % 31) {
+    switch (rnd() % 32) {
       case 0: { bnn_hip_conv_desc d = pick_desc();
         st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
                              pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
@@ -355,6 +362,8 @@ int main(int argc, char** argv) {
         st = bnn_hip_avgpool_fc_ws_f32(pick_ptr<float>(), n, c, pick_int(), pick_ptr<float>(), pick_ptr<float>(), pick_int(),
                                        pick_ptr<float>(), pick_ptr<float>(), rnd() % 4 ? need : (size_t)(rnd() % 4096), stream);
         break; }
+      case 30: st = bnn_hip_stem7x7_conv_f32(pick_ptr<float>(), pick_ptr<float>(), pick_int(), pick_int(), pick_int(),
+                                             (int)(rnd() % 8), pick_ptr<float>(), stream); break;
       default: { bnn_hip_conv_desc d = pick_desc();
         (void)bnn_hip_shortcut_fold_supported(rnd() % 16 ? &d : nullptr, pick_int());
         st = bnn_hip_blinear(pick_int(), pick_int(), pick_int(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
