@@ -68,11 +68,11 @@ constexpr int RSTEP = NT / NPC;                      // 8 rows per sweep
 constexpr int PER_T = (NROW + RSTEP - 1) / RSTEP;    // 9 column pairs per thread
 constexpr int PATCH_D = NROW * ROWD;                 // dwords per patch buffer
 constexpr int OFF_BITS = 2 * PATCH_D * 4;            // sign words of the tile: [2][56 pixels][2 halves] u32
+constexpr int OFF_BN = OFF_BITS + 2 * PTH * PTW * 8;  // BNN_ROWS_LEAN: BatchNorm constants [a|b][64 channels] fp32
 #ifdef BNN_ROWS_TIMING  // per-phase shader-clock sums of every wave (debug builds): [wave][16 phases][64 lanes] u32 in LDS
-constexpr int OFF_TIME = OFF_BITS + 2 * PTH * PTW * 8;
+constexpr int OFF_TIME = OFF_BN + 2 * COUT * 4;
 constexpr int LDS_BYTES = OFF_TIME + NW * 16 * 64 * 4;
 #else
-constexpr int OFF_BN = OFF_BITS + 2 * PTH * PTW * 8;  // BNN_ROWS_LEAN: BatchNorm constants [a|b][64 channels] fp32
 constexpr int LDS_BYTES = OFF_BN + 2 * COUT * 4;
 #endif
 constexpr int CONV_ROW_D = 2 * ROWD;                 // one conv row further = two input rows further
@@ -95,6 +95,14 @@ __device__ __forceinline__ RowsRsrc rows_rsrc(const void* p, unsigned bytes) {
 __device__ __forceinline__ float rows_ld(RowsRsrc r, unsigned voff, unsigned soff) {  // out of range reads as 0
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
+// Two floats per lane.  NOT __builtin_amdgcn_raw_buffer_load_b64: hipcc 7.2 narrows that load to ONE dword when its two
+// elements are extracted (both read the first; tools/experiments/README.md 55) — the float-vector form of the same
+// intrinsic is selected as buffer_load_dwordx2.
+using f32x2v = __attribute__((ext_vector_type(2))) float;
+__device__ f32x2v rows_ld2_intrinsic(RowsRsrc r, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.ptr.buffer.load.v2f32");
+__device__ __forceinline__ f32x2v rows_ld2(RowsRsrc r, unsigned voff, unsigned soff) {  // out of range reads as 0
+  return rows_ld2_intrinsic(r, (int)voff, (int)soff, 0);
+}
 __device__ __forceinline__ void rows_st(RowsRsrc r, unsigned voff, unsigned soff, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
@@ -107,20 +115,61 @@ __device__ __forceinline__ void rows_st2(RowsRsrc r, unsigned voff, unsigned sof
 // 8..15 the odd ones 1, 3, .. 15: pooled column j (centre column 2j + 1) ends up on lane 8 + j, its neighbours sit 8
 // and 7 lanes below (row_shr:8, row_shr:7; a missing source reads as 0) — the seven pooled values of a row leave from
 // seven ADJACENT lanes.  Hand-written: from the builtins hipcc emits v_mov_dpp + a canonicalising v_max + the v_max
-// per neighbour and canonicalises a, b, c; the s_nop covers the two wait states between a VALU write and a DPP read.
-__device__ __forceinline__ float pool3x3(float a, float b, float c) {
-  float t, v;
-  asm("v_max3_f32 %0, %2, %3, %4\n\t"
-      "v_max_f32_e32 %0, 0, %0\n\t"
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %1, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-      "v_max_f32_dpp %1, %0, %1 row_shr:7 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-      : "=&v"(t), "=&v"(v) : "v"(a), "v"(b), "v"(c));
-  return v;
+// per neighbour and canonicalises a, b, c.  The eight values of a pooled row (2 channel tiles x 4 registers) go through
+// each step TOGETHER, one asm block per step: neighbours in the stream are independent (no dependent-issue stalls) and
+// the two wait states between a VALU write and a DPP read of the same register are covered by the other values'
+// instructions instead of an s_nop (round 5; one value at a time: +90 cycles per pooled row).
+__device__ __forceinline__ void pool_rows4(float (&t)[4], const float (&a)[4], const float (&b)[4], const float (&c)[4]) {
+  asm("v_max3_f32 %0, %4, %8, %12\n\tv_max3_f32 %1, %5, %9, %13\n\tv_max3_f32 %2, %6, %10, %14\n\tv_max3_f32 %3, %7, %11, %15"
+      : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+        "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
 }
-// word = 2 * word + (v is a positive number): v_cmp_class + v_addc (the carry-in IS the bit)
-__device__ __forceinline__ void shift_in_pos(uint32_t& word, float v) {
-  asm("v_cmp_class_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(word) : "v"(v), "s"(kClassPos) : "vcc");
+__device__ __forceinline__ void pool_cols8(float (&v)[8], float (&t)[8]) {
+  asm("v_max_f32_e32 %8, 0, %8\n\tv_max_f32_e32 %9, 0, %9\n\tv_max_f32_e32 %10, 0, %10\n\tv_max_f32_e32 %11, 0, %11\n\t"
+      "v_max_f32_e32 %12, 0, %12\n\tv_max_f32_e32 %13, 0, %13\n\tv_max_f32_e32 %14, 0, %14\n\tv_max_f32_e32 %15, 0, %15\n\t"
+      "v_max_f32_dpp %0, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %1, %9, %9 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %2, %10, %10 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %3, %11, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %4, %12, %12 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %5, %13, %13 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %6, %14, %14 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %7, %15, %15 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %0, %8, %0 row_shr:7 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %1, %9, %1 row_shr:7 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %2, %10, %2 row_shr:7 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %3, %11, %3 row_shr:7 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %4, %12, %4 row_shr:7 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %5, %13, %5 row_shr:7 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %6, %14, %6 row_shr:7 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "v_max_f32_dpp %7, %15, %7 row_shr:7 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+        "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+}
+// bit r of z0 = (v[r] is a positive number), bit r of z1 = (v[4 + r] is): word = 2 * word + bit as v_cmp_class + v_addc
+// (the carry-in IS the bit), two independent carry chains (vcc and a scalar pair), the first bit of each placed by a select
+__device__ __forceinline__ void sign_bits8(uint32_t& z0, uint32_t& z1, const float (&v)[8]) {
+  uint64_t c1;
+  asm("v_cmp_class_f32 vcc, %6, %11\n\t"
+      "v_cmp_class_f32 %2, %10, %11\n\t"
+      "v_cndmask_b32_e64 %0, 0, 1, vcc\n\t"
+      "v_cndmask_b32_e64 %1, 0, 1, %2\n\t"
+      "v_cmp_class_f32 vcc, %5, %11\n\t"
+      "v_cmp_class_f32 %2, %9, %11\n\t"
+      "v_addc_co_u32_e64 %0, vcc, %0, %0, vcc\n\t"
+      "v_addc_co_u32_e64 %1, %2, %1, %1, %2\n\t"
+      "v_cmp_class_f32 vcc, %4, %11\n\t"
+      "v_cmp_class_f32 %2, %8, %11\n\t"
+      "v_addc_co_u32_e64 %0, vcc, %0, %0, vcc\n\t"
+      "v_addc_co_u32_e64 %1, %2, %1, %1, %2\n\t"
+      "v_cmp_class_f32 vcc, %3, %11\n\t"
+      "v_cmp_class_f32 %2, %7, %11\n\t"
+      "v_addc_co_u32_e64 %0, vcc, %0, %0, vcc\n\t"
+      "v_addc_co_u32_e64 %1, %2, %1, %1, %2"
+      : "=&v"(z0), "=&v"(z1), "=&s"(c1)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "s"(kClassPos)
+      : "vcc");
 }
 // OR of the four 16-lane rows of a wave, in every lane: two lane-swap instructions (no LDS round trip)
 __device__ __forceinline__ uint32_t or_rows(uint32_t w) {
@@ -133,10 +182,13 @@ __device__ __forceinline__ uint32_t or_rows(uint32_t w) {
 struct RowsRsrc {};
 __device__ __forceinline__ RowsRsrc rows_rsrc(const void*, unsigned) { return {}; }
 __device__ __forceinline__ float rows_ld(RowsRsrc, unsigned, unsigned) { return 0.0f; }
+using f32x2v = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2v rows_ld2(RowsRsrc, unsigned, unsigned) { return f32x2v{0.0f, 0.0f}; }
 __device__ __forceinline__ void rows_st(RowsRsrc, unsigned, unsigned, float) {}
 __device__ __forceinline__ void rows_st2(RowsRsrc, unsigned, unsigned, u32x2) {}
-__device__ __forceinline__ float pool3x3(float a, float, float) { return a; }
-__device__ __forceinline__ void shift_in_pos(uint32_t&, float) {}
+__device__ __forceinline__ void pool_rows4(float (&t)[4], const float (&a)[4], const float (&)[4], const float (&)[4]) { for (int i = 0; i < 4; ++i) t[i] = a[i]; }
+__device__ __forceinline__ void pool_cols8(float (&v)[8], float (&t)[8]) { for (int i = 0; i < 8; ++i) v[i] = t[i]; }
+__device__ __forceinline__ void sign_bits8(uint32_t& z0, uint32_t& z1, const float (&)[8]) { z0 = z1 = 0; }
 __device__ __forceinline__ uint32_t or_rows(uint32_t w) { return w; }
 #endif
 constexpr unsigned kRowsOOB = 0xFFFFFFF0u;  // beyond every descriptor's num_records
@@ -163,7 +215,7 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: what depends on it is uniform
   const int li = lane & 15, lg = lane >> 4;
-  const int lcol = li < 8 ? 2 * li : 2 * li - 15;  // conv column of the strip held by this lane (see pool3x3)
+  const int lcol = li < 8 ? 2 * li : 2 * li - 15;  // conv column of the strip held by this lane (see pool_cols8)
   const int mg = wave & 1, nh = wave >> 1;  // pooled columns 7*mg .. 7*mg + 6, channels 32*nh .. 32*nh + 31
 
   // ---- once: zero both patch buffers (columns 64, 65 and the row padding are read by the idle pixel column and
@@ -275,18 +327,22 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
   const int seg_stride = (int)gridDim.x * seg_len;
   const int niter = nseg * seg_len;
   float nx0[PER_T], nx1[PER_T];
+  // even width and an 8-byte aligned tensor: every column pair of the patch (it starts at an even column) is one aligned
+  // 8-byte word that lies inside or outside the image as a whole
+  const bool pair_loads = !(W & 1) && !((uintptr_t)x & 7u);
   auto fetch = [&](int n, int tx, int ty) {
     const int iy0 = 4 * ty * PTH - 5, ixe = 4 * tx * PTW - 6;  // first input row; first (even) input column
     const unsigned img = (unsigned)(n * CIN * H * W) * 4u;
     const int toff = (iy0 * W + ixe) * 4;
     const bool rows_in = iy0 >= 0 && iy0 + ITH <= H;
-    if (rows_in && ixe >= 0 && ixe + 2 * NPC <= W) {  // the patch lies inside the image
+    if (rows_in && pair_loads && ixe >= 0 && ixe + 2 * NPC <= W) {  // the patch lies inside the image
 #pragma unroll
-      for (int u = 0; u < PER_T; ++u) {
-        nx0[u] = rows_ld(r_x, rowoff[u], img + (unsigned)toff);
-        nx1[u] = rows_ld(r_x, rowoff[u] + 4u, img + (unsigned)toff);
+      for (int u = 0; u < PER_T; ++u) {  // a column pair per 8-byte load (half the requests of the texture addresser)
+        const f32x2v v = rows_ld2(r_x, rowoff[u], img + (unsigned)toff);
+        nx0[u] = v.x;
+        nx1[u] = v.y;
       }
-    } else if (rows_in && !(W & 1)) {
+    } else if (rows_in && pair_loads) {
       // left / right edge of an even-width image: a column pair is inside or outside as a whole (the patch starts at
       // an even column) — one select per load
       const bool okc = (unsigned)(ixe + 2 * fpc) < (unsigned)W;
@@ -294,8 +350,9 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
 #pragma unroll
       for (int u = 0; u < PER_T; ++u) {
         const unsigned off = (okc && frow0 + RSTEP * u < NROW) ? rowoff[u] + (unsigned)(ixe * 4) : kRowsOOB;
-        nx0[u] = rows_ld(r_x, off, rowpart);
-        nx1[u] = rows_ld(r_x, off + 4u, rowpart);
+        const f32x2v v = rows_ld2(r_x, off, rowpart);
+        nx0[u] = v.x;
+        nx1[u] = v.y;
       }
     } else {
       const int ix = ixe + 2 * fpc;
@@ -379,6 +436,7 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
     __syncthreads();                   // this tile's patch (buffer pb) is in LDS; nobody reads buffer pb ^ 1 any more
     ROWS_T(0)
     flush_bits(buf ^ 1);
+    ROWS_T(14)
     // the next tile: one step down the list, or the first tile of the next segment
     const bool seg_first = it % seg_len == 0, seg_last = (it + 1) % seg_len == 0;
     int ng = g + 1, nn = n, ntx = tx, nty = ty + 1;
@@ -391,6 +449,7 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
     }
     const bool more = it + 1 < niter && ng < ntiles;
     if (more && !(BNN_ROWS_ABL & 8)) fetch(nn, ntx, nty);  // global loads fly during the first half of the tile
+    ROWS_T(15)
     const int py0 = ty * PTH, px0 = tx * PTW;        // pooled origin
     const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;  // conv origin (pool pad 1): conv row t of the tile is row cy0 + t
     // most tiles lie entirely inside the conv output: no range tests there
@@ -443,13 +502,14 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
     auto multiply = [&](int slot, int ks, int rows) {
       if (K16 && ks == KSTEPS - 1) {  // (constant after unrolling) the same three products, 16 k per instruction
 #if defined(__HIP_DEVICE_COMPILE__)
-        // hipcc 7.2 schedules an 8-pass v_mfma_f32_16x16x32_f16 and, in the very next slot, a 4-pass
+        // hipcc 7.2 may schedule an 8-pass v_mfma_f32_16x16x32_f16 and, in the very next slot, a 4-pass
         // v_mfma_f32_16x16x16_f16 whose SrcC is that result and whose vDst is another register quad, with no wait states
-        // between them; gfx950 then delivers two of the four result registers wrong (seen in the RAW kernel's last
-        // pooled row: conv rows 6 mod 8, channels 4*lg + {0, 1}; tools/experiments/README.md 54).  The packed kernels'
-        // schedules never place the pair back to back (tools/isa_extract.py; their bit-exactness tests would show it);
-        // RAW closes the window explicitly: every 32-k product is issued before the first 16-k one, 16 slots apart.
-        if constexpr (RAW) asm volatile("s_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        // between them; gfx950 then delivers two of the four result registers wrong (seen in the last pooled row of a
+        // tile: conv rows 6 mod 8 / pooled rows 3 mod 4, channels 4*lg + {0, 1}; tools/experiments/README.md 54).
+        // Whether the pair ends up back to back depends on the schedule of the surrounding code, so the window is closed
+        // explicitly: every 32-k product is issued before the first 16-k one, 16 slots apart (4 x 16 cycles per tile).
+        // tools/mfma_pairs.py + tests/test_isa_cpu.py scan the assembly for the pair.
+        asm volatile("s_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
 #endif
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -551,14 +611,20 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
       float y0[2][4], y1[2][4];
       bn_row(y0, 0, 2 * q + 1);
       bn_row(y1, 1, 2 * q + 2);
-      float v[2][4];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
+      float t[8], v8[8];
+      {
+        float t0[4], t1[4];
+        pool_rows4(t0, carry[0], y0[0], y1[0]);
+        pool_rows4(t1, carry[1], y0[1], y1[1]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[tt][r] = pool3x3(carry[tt][r], y0[tt][r], y1[tt][r]);  // the pooled value on lanes 8 .. 14
-          carry[tt][r] = y1[tt][r];
+          t[r] = t0[r];
+          t[4 + r] = t1[r];
+          carry[0][r] = y1[0][r];
+          carry[1][r] = y1[1][r];
         }
+      }
+      pool_cols8(v8, t);  // v8[4*tt + r]: the pooled value of channel 16*tt + r (+ 4*lg) on lanes 8 .. 14
       // fp32 stores under an EXEC mask of the 28 lanes that hold a pooled value (rows below / columns right of the
       // image dropped): the texture addresser walks the active lanes of a store, not all 64
       if (out_live && py0 + q < Hp && !(BNN_ROWS_ABL & 16)) {
@@ -566,22 +632,17 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
         // invariants they are spilled to lanes and read back in front of every store)
         unsigned soff = out_tile + (unsigned)(q * Wp) * 4u;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            rows_st(r_out, out_lane, soff, v[tt][r]);
-            soff += (r == 3 ? 13u : 1u) * chw4;
-            asm volatile("" : "+s"(soff));
-          }
+        for (int j = 0; j < 8; ++j) {
+          rows_st(r_out, out_lane, soff, v8[j]);
+          soff += ((j & 3) == 3 ? 13u : 1u) * chw4;
+          asm volatile("" : "+s"(soff));
+        }
       }
-      uint32_t z = 0;
-#pragma unroll
-      for (int tt = 1; tt >= 0; --tt)
-#pragma unroll
-        for (int r = 3; r >= 0; --r) shift_in_pos(z, v[tt][r]);  // bit 4*tt + r
+      uint32_t z0, z1;
+      sign_bits8(z0, z1, v8);
       if (P != nullptr && !(BNN_ROWS_ABL & 32)) {
         // channel 16*tt + 4*lg + r is bit 16*tt + 4*lg + r of this wave's half of the pixel's word
-        const uint32_t wd = or_rows(((z & 0xFu) | ((z & 0xF0u) << 12)) << (4 * lg));
+        const uint32_t wd = or_rows((z0 | (z1 << 16)) << (4 * lg));
         if (lg == 0 && pool_lane) bits[((buf * PTH + q) * PTW + WPW * mg + plx) * 2 + nh] = wd;
       }
     };
@@ -628,9 +689,11 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
       multiply(s % RING, ks, 2);
       __builtin_amdgcn_sched_barrier(0);
       if (ks == KSTEPS - 1) ROWS_T(2 + s / KSTEPS)
+      // next patch: registers -> the other LDS buffer.  BEFORE this row's stores: the loads' counted wait then has the
+      // eight stores of the first pooled row behind them, not sixteen (the compiler counts as if none were issued)
+      if (s == 2 * KSTEPS - 1 && more && !(BNN_ROWS_ABL & 8)) commit(pb ^ 1);
       if (ks == KSTEPS - 1 && !(BNN_ROWS_ABL & 2)) finish(s / KSTEPS);
       if (ks == KSTEPS - 1) ROWS_T(7 + s / KSTEPS)
-      if (s == 2 * KSTEPS - 1 && more && !(BNN_ROWS_ABL & 8)) commit(pb ^ 1);  // next patch: registers -> the other LDS buffer
       if (s == 2 * KSTEPS - 1) ROWS_T(12)
     }
     if constexpr (LEAN) {

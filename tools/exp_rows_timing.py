@@ -24,9 +24,9 @@ for name, kw in (("split", {}), ("fp16", {"fp16": True})):
     t = pk.M.cpu().numpy().reshape(-1)[:512 * 4 * 16].astype(np.float64).reshape(512, 4, 16)
     tiles = 28
     names = ["barrier wait", "flush+fetch+row0", "mfma row 0", "mfma row 1", "mfma row 2", "mfma row 3", "-",
-             "finish 0", "finish 1", "finish 2", "finish 3", "-", "commit", "loop tail"]
+             "finish 0", "finish 1", "finish 2", "finish 3", "-", "commit", "loop tail", "flush bits", "next tile + fetch"]
     print("%s: %.1f us per launch (instrumented); cycles per tile, mean over workgroups, by wave (mg,nh)=(0,0),(1,0),(0,1),(1,1)" % (name, us))
     for k, nm in enumerate(names):
         print("  %-18s" % nm, " ".join("%7.0f" % (t[:, wv, k].mean() / tiles) for wv in range(4)))
-    print("  %-18s" % "total", " ".join("%7.0f" % (t[:, wv, :14].sum(axis=1).mean() / tiles) for wv in range(4)),
-          "  -> %.2f GHz" % (t[:, 0, :14].sum(axis=1).mean() / us / 1e3))
+    print("  %-18s" % "total", " ".join("%7.0f" % (t[:, wv, :16].sum(axis=1).mean() / tiles) for wv in range(4)),
+          "  -> %.2f GHz" % (t[:, 0, :16].sum(axis=1).mean() / us / 1e3))
