@@ -247,6 +247,35 @@ def stem7x7_conv(x: torch.Tensor, w: torch.Tensor, fp16: bool = False) -> torch.
     return y
 
 
+def stem7x7_wgrad_supported(x: torch.Tensor) -> bool:
+    """``stem7x7_wgrad`` implements this input size (image rows up to ~950 pixels: the kernel's LDS patch)."""
+    lib = native.require()
+    return x.dim() == 4 and x.shape[1] == 3 and lib.bnn_hip_stem7x7_wgrad_workspace_bytes(
+        int(x.shape[0]), int(x.shape[2]), int(x.shape[3])) > 0
+
+
+def stem7x7_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """Weight gradient of the stem's convolution (``bnn_hip_stem7x7_wgrad_f32``; what
+    ``aten::convolution_backward(dy, x, w, ...)[1]`` returns for conv 7x7/2/3, 3 -> 64): fp32 ``[64, 3, 7, 7]``.
+    fp32 products on the matrix cores, partial sums added in index order — the same bits on every run."""
+    x = _require_cuda_f32(x, "stem input")
+    dy = _require_cuda_f32(dy, "stem output gradient")
+    N, _, H, W = x.shape
+    hc, wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if x.dim() != 4 or x.shape[1] != 3 or tuple(dy.shape) != (N, 64, hc, wc):
+        raise native.NativeError("bnn_amd: stem7x7_wgrad expects x [N,3,H,W] and dy [N,64,Hc,Wc]")
+    lib = native.require()
+    with torch.cuda.device(x.device):
+        need = lib.bnn_hip_stem7x7_wgrad_workspace_bytes(N, H, W)
+        if need == 0:
+            raise native.NativeError(f"bnn_amd: stem7x7_wgrad does not implement input size {tuple(x.shape)}")
+        work = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+        dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=x.device)
+        native.check(lib.bnn_hip_stem7x7_wgrad_f32(x.data_ptr(), dy.data_ptr(), N, H, W, work.data_ptr(), need,
+                                                   dw.data_ptr(), _stream(x.device)), "bnn_hip_stem7x7_wgrad_f32")
+    return dw
+
+
 def sign_thresholds(w: PackedWeight, bn_scale: torch.Tensor, bn_shift: torch.Tensor, bias=None, post_scale=None):
     """Integer form of ``sign(relu(bn(alpha * dot + bias)))`` for ``bconv2d_fused(..., sign_thresholds=...)``:
     int32 ``[O, 4]`` = (bound T, flip word of the channel's 32-channel block, the two comparands of the kernels'

@@ -206,6 +206,7 @@ class StemTailFn(torch.autograd.Function):
 # step at batch 256; the inference stem's MFMA core with a raw-conv epilogue (csrc/stem_rows.hip, RAW) is ~0.4 ms.  The
 # weight gradient stays the library's (the input is data: no input gradient).
 FUSED_STEM_CONV = os.environ.get("BNN_AMD_TRAIN_STEM_CONV", "1") == "1"
+FUSED_STEM_WGRAD = os.environ.get("BNN_AMD_TRAIN_STEM_WGRAD", "1") == "1"
 
 
 class StemConvFn(torch.autograd.Function):
@@ -217,6 +218,10 @@ class StemConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
+        if not ctx.needs_input_grad[0] and FUSED_STEM_WGRAD and hipops.stem7x7_wgrad_supported(x):
+            # the input is data: the weight gradient is the whole backward (csrc/stem_wgrad.hip: fp32 MFMA, 0.6 ms
+            # where the library's implicit GEMM with its two NHWC transposes of the 822 MB gradient takes 1.46)
+            return None, (hipops.stem7x7_wgrad(x, g.contiguous()) if ctx.needs_input_grad[1] else None)
         gx, gw, _ = torch.ops.aten.convolution_backward(
             g.contiguous(), x, w, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
             [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])

@@ -309,6 +309,28 @@ int bnn_hip_stem7x7_conv_f32(const float* x, const float* w, int N, int H, int W
   return bnn::launch_stem_conv(x, w, N, H, W, (flags & BNN_HIP_STEM_FP16) != 0, out, static_cast<hipStream_t>(stream));
 }
 
+size_t bnn_hip_stem7x7_wgrad_workspace_bytes(int N, int H, int W) {
+  if (N <= 0 || H <= 0 || W <= 0) return 0;
+  const long long hc = (H - 1) / 2 + 1, wc = (W - 1) / 2 + 1;
+  if (mulc(N, 3, H, W) > kMaxElems || mulc(N, 64, hc, wc) > kMaxElems) return 0;
+  return bnn::stem_wgrad_workspace_bytes(N, H, W);
+}
+
+int bnn_hip_stem7x7_wgrad_f32(const float* x, const float* dy, int N, int H, int W, float* workspace,
+                              size_t workspace_bytes, float* dw, void* stream) {
+  if (!x || !dy || !dw || !workspace || N <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (!aligned(x, 4) || !aligned(dy, 4) || !aligned(dw, 4) || !aligned(workspace, 4)) return BNN_HIP_ERR_INVALID_ARG;
+  {
+    const long long hc = (H - 1) / 2 + 1, wc = (W - 1) / 2 + 1;
+    if (mulc(N, 3, H, W) > kMaxElems || mulc(N, 64, hc, wc) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  }
+  if (!bnn::stem_wgrad_supported(H, W)) return BNN_HIP_ERR_UNSUPPORTED;
+  if (workspace_bytes < bnn::stem_wgrad_workspace_bytes(N, H, W)) return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(2, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_stem_wgrad(x, dy, N, H, W, workspace, dw, static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_avgpool_fc_f32(const float* x, int N, int C, int HW, const float* w_t, const float* bias, int O,
                            float* out, void* stream) {
   if (!x || !w_t || !out || N <= 0 || C <= 0 || HW <= 0 || O <= 0) return BNN_HIP_ERR_INVALID_ARG;

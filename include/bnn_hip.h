@@ -61,7 +61,8 @@
 extern "C" {
 #endif
 
-/* ABI 14 (round 5): + bnn_hip_avgpool_fc_ws_f32 / bnn_hip_avgpool_fc_workspace_bytes (the head as two streaming launches
+/* ABI 14 (round 5): + bnn_hip_stem7x7_wgrad_f32 / bnn_hip_stem7x7_wgrad_workspace_bytes (weight gradient of the stem
+ * convolution: the training backward of that layer); + bnn_hip_avgpool_fc_ws_f32 / bnn_hip_avgpool_fc_workspace_bytes (the head as two streaming launches
  * through a workspace); + bnn_hip_stem7x7_conv_f32 (the stem's convolution alone: the training forward); the table of bnn_hip_sign_thresholds_f32 holds FOUR words per channel (was two) and kmax < 2^20.
  * ABI 13 (round 4): + bnn_hip_bn_act_f32 (eval-mode BatchNorm + residual + ReLU tail of the per-layer path);
  * bnn_hip_xnor_weight_backward_f32 takes `splits` partial slabs.
@@ -301,6 +302,18 @@ int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w,
  * accumulation; flags = BNN_HIP_STEM_FP16: plain fp16 operands): the values the fused kernel normalises and pools, bit
  * for bit.  Same size limits as the fused stem.                                                                     */
 int bnn_hip_stem7x7_conv_f32(const float* x, const float* w, int N, int H, int W, int flags, float* out, void* stream);
+
+/* ABI 14 — the weight gradient of that convolution: the training backward of bnn/models/resnet.py:150 (the input is data,
+ * so this is the layer's whole backward; torch: aten::convolution_backward with output_mask = {0, 1, 0}).
+ *   dw[o][c][ky][kx] = sum over n, y, x of dy[n][o][y][x] * x[n][c][2y + ky - 3][2x + kx - 3]        (zero padding)
+ * x: float32 [N,3,H,W], dy: float32 [N,64,Hc,Wc] (Hc = (H - 1) / 2 + 1), dw: float32 [64,3,7,7] (overwritten).
+ * fp32 products and fp32 accumulation on the matrix cores (v_mfma_f32_16x16x4_f32), per-workgroup partial sums in
+ * `workspace` added in index order in fp64: deterministic, no atomics.  Two launches.  workspace: at least
+ * bnn_hip_stem7x7_wgrad_workspace_bytes(N, H, W) bytes (0 = this shape is not supported: image rows wider than ~950
+ * pixels do not fit the kernel's LDS patch, BNN_HIP_ERR_UNSUPPORTED — the caller keeps its own backward).          */
+size_t bnn_hip_stem7x7_wgrad_workspace_bytes(int N, int H, int W);
+int bnn_hip_stem7x7_wgrad_f32(const float* x, const float* dy, int N, int H, int W, float* workspace,
+                              size_t workspace_bytes, float* dw, void* stream);
 
 /* The real-valued head of the reference's ResNets in one kernel (bnn/models/resnet.py:160-164:
  * avgpool -> flatten -> fc):  out[n,o] = bias[o] + sum_c w_t[c,o] * mean_hw x[n,c,hw].

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 import bnn_amd as bnn
-from bnn_amd import fastpath, hipops, training
+from bnn_amd import fastpath, hipops, native, training
 from bnn_amd.models import resnet18
 from bnn_amd.ops import BasicInputBinarizer, BasicScaleBinarizer, XNORWeightBinarizer
 from tests.golden import gen
@@ -670,3 +670,54 @@ def test_training_step_with_the_stem_convolution_on_the_matrix_cores():
     def close(a, b, tol):      # (binarised nets are discontinuous: compare in norm, as the fused-BatchNorm test does)
         return float((a - b).norm()) <= tol * float(b.norm()) + 1e-12
     assert close(gw1, gw0, 5e-2) and close(gx1, gx0, 2e-2)
+
+
+@pytest.mark.parametrize("shape", [(4, 3, 224, 224), (3, 3, 64, 64), (2, 3, 50, 38), (1, 3, 97, 131), (5, 3, 33, 65), (1, 3, 7, 9),
+                                   (2, 3, 8, 256)], ids=lambda s: "x".join(map(str, s)))
+def test_stem_weight_gradient_kernel_matches_fp64_autograd(shape):
+    """bnn_hip_stem7x7_wgrad_f32 (round 5: the backward of conv1 in a training step, bnn/models/resnet.py:150 — the input is
+    data, so the weight gradient is all of it) against fp64 autograd of the same convolution; the same bits on every
+    run (partials are added in index order); the library's backward for comparison of the error."""
+    import torch.nn.functional as F
+    n, _, h, w_ = shape
+    x = dev(gen.normal(gen.seed_of("stemwg", shape), shape))
+    dy = dev(gen.normal(gen.seed_of("stemwg_dy", shape), (n, 64, (h - 1) // 2 + 1, (w_ - 1) // 2 + 1)))
+    assert hipops.stem7x7_wgrad_supported(x)
+    dw = hipops.stem7x7_wgrad(x, dy)
+    wd = torch.zeros(64, 3, 7, 7, device=DEV, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wd, None, 2, 3).backward(dy.double())
+    ref = wd.grad
+    scale = float(ref.abs().max())
+    err = float((dw.double() - ref).abs().max())
+    lib = torch.ops.aten.convolution_backward(dy, x, wd.detach().float(), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                              [False, True, False])[1]
+    lib_err = float((lib.double() - ref).abs().max())
+    assert err <= 2e-5 * scale, (err, lib_err, scale)
+    assert err <= 4 * lib_err + 1e-6 * scale, (err, lib_err)         # fp32 accumulation: the library's error class
+    assert torch.equal(dw, hipops.stem7x7_wgrad(x, dy))
+
+
+def test_stem_weight_gradient_kernel_declines_rows_beyond_its_patch():
+    x = torch.zeros(1, 3, 8, 4096, device=DEV)
+    assert not hipops.stem7x7_wgrad_supported(x)
+    with pytest.raises(native.NativeError):
+        hipops.stem7x7_wgrad(x, torch.zeros(1, 64, 4, 2048, device=DEV))
+
+
+def test_training_step_with_the_stem_weight_gradient_kernel():
+    """One ResNet-18 training step with conv1's backward as the fp32 MFMA kernel (default) against the same step with the
+    library's convolution backward: the same loss, conv1's weight gradient to fp32 accumulation accuracy."""
+    def step(on):
+        training.FUSED_STEM_WGRAD = on
+        try:
+            net = _r18_train()
+            x = dev(gen.normal(92, (8, 3, 64, 64)))
+            loss = torch.nn.functional.cross_entropy(net(x), torch.arange(8, device=DEV) * 7)
+            loss.backward()
+            return float(loss.detach()), net.conv1.weight.grad.clone(), net.layer1[0].conv1.weight.grad.clone()
+        finally:
+            training.FUSED_STEM_WGRAD = True
+    l1, gw1, gl1 = step(True)
+    l0, gw0, gl0 = step(False)
+    assert l1 == l0 and torch.equal(gl1, gl0)                    # nothing in front of conv1's backward changed
+    assert float((gw1 - gw0).norm()) <= 1e-5 * float(gw0.norm())

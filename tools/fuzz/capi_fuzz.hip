@@ -120,6 +120,26 @@ int launch_stem_conv(const float* x, const float* w, int N, int H, int W, int, f
   REQUIRE((long long)N * 3 * H * W * 4 <= kDesc && (long long)N * 64 * hc * wc * 4 <= kDesc);
   return BNN_HIP_OK;
 }
+// the stub mirrors the product's support rule and slab arithmetic (csrc/stem_wgrad.hip) with a fixed workgroup count
+static size_t stub_wgrad_lds(int W) {
+  const int wc = (W - 1) / 2 + 1, need = 2 * ((wc + 15) / 16 * 16) + 8;
+  int s = (need + 63) / 64 * 64 + 32;
+  if (s - 64 >= need) s -= 64;
+  return (size_t)3 * 13 * s * 4;
+}
+bool stem_wgrad_supported(int H, int W) { return H > 0 && W > 0 && stub_wgrad_lds(W) <= 64 * 1024; }
+size_t stem_wgrad_workspace_bytes(int N, int H, int W) {
+  if (N <= 0 || !stem_wgrad_supported(H, W)) return 0;
+  const long long bands = (long long)N * (((H - 1) / 2 + 1 + 3) / 4);
+  return (size_t)std::min<long long>(bands, 768) * 64 * 176 * 4;
+}
+int launch_stem_wgrad(const float* x, const float* dy, int N, int H, int W, float* work, float* dw, hipStream_t) {
+  ++g_reached;
+  REQUIRE(x && dy && work && dw && N > 0 && stem_wgrad_supported(H, W));
+  const long long hc = (H - 1) / 2 + 1, wc = (W - 1) / 2 + 1;
+  REQUIRE((long long)N * 3 * H * W <= 0x7fffffffLL && (long long)N * 64 * hc * wc <= 0x7fffffffLL);
+  return BNN_HIP_OK;
+}
 int launch_avgpool_fc(const float* x, const float* wt, const float*, float* out, int N, int C, int HW, int O, hipStream_t) {
   ++g_reached; REQUIRE(x && wt && out && N > 0 && C > 0 && HW > 0 && O > 0); return BNN_HIP_OK;
 }
@@ -259,7 +279,7 @@ int main(int argc, char** argv) {
   for (long it = 0; it < iters; ++it) {
     ++g_calls;
     int st = 0;
-    switch (rnd() % 32) {
+    switch (rnd() % 33) {
       case 0: { bnn_hip_conv_desc d = pick_desc();
         st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
                              pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
@@ -364,6 +384,11 @@ int main(int argc, char** argv) {
         break; }
       case 30: st = bnn_hip_stem7x7_conv_f32(pick_ptr<float>(), pick_ptr<float>(), pick_int(), pick_int(), pick_int(),
                                              (int)(rnd() % 8), pick_ptr<float>(), stream); break;
+      case 31: { const int n = pick_int(), h = pick_int(), w = pick_int();
+        const size_t need = bnn_hip_stem7x7_wgrad_workspace_bytes(n, h, w);
+        st = bnn_hip_stem7x7_wgrad_f32(pick_ptr<float>(), pick_ptr<float>(), n, h, w, pick_ptr<float>(),
+                                       rnd() % 4 ? need : (size_t)(rnd() % 4096), pick_ptr<float>(), stream);
+        break; }
       default: { bnn_hip_conv_desc d = pick_desc();
         (void)bnn_hip_shortcut_fold_supported(rnd() % 16 ? &d : nullptr, pick_int());
         st = bnn_hip_blinear(pick_int(), pick_int(), pick_int(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
