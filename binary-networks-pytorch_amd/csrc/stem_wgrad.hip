@@ -84,14 +84,33 @@ __global__ __launch_bounds__(swg::NT) void stem_wgrad_kernel(const float* __rest
     const int n = b / bands_y, y0 = (b - n * bands_y) * RB;
     __syncthreads();  // the previous band's reads are done
     // ---- the band's patch: input rows 2 y0 - 3 .. 2 y0 + 2 RB + 1, columns -3 .. row_stride - 4 (zeros outside)
-    for (int r = wave; r < CIN * PR; r += NW) {
-      const int c = r / PR, pr = r - c * PR;
-      const int iy = 2 * y0 - 3 + pr;
-      const bool row_in = (unsigned)iy < (unsigned)H;
-      const float* src = x + ((size_t)(n * CIN + c) * H + (row_in ? iy : 0)) * W;
-      for (int col = lane; col < row_stride; col += 64) {
-        const int ix = col - 3;
-        patch[r * row_stride + col] = (row_in && (unsigned)ix < (unsigned)W) ? src[ix] : 0.0f;
+    // (a wave takes rows wave, wave + 4, ..; the loads of TWO rows are issued before the first LDS write: one element
+    // at a time the staging is ~50 dependent global-memory latencies per band, several times the band's matrix work)
+    for (int r0 = wave; r0 < CIN * PR; r0 += 2 * NW) {
+      float v[2][8];
+      for (int cb = 0; cb < row_stride; cb += 8 * 64) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = r0 + h * NW;
+          const int c = r / PR, pr = r - c * PR;
+          const int iy = 2 * y0 - 3 + pr;
+          const bool row_in = r < CIN * PR && (unsigned)iy < (unsigned)H;
+          const float* src = x + ((size_t)(n * CIN + (row_in ? c : 0)) * H + (row_in ? iy : 0)) * W;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int ix = cb + lane + 64 * j - 3;
+            v[h][j] = (row_in && (unsigned)ix < (unsigned)W) ? src[ix] : 0.0f;
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = r0 + h * NW;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int col = cb + lane + 64 * j;
+            if (r < CIN * PR && col < row_stride) patch[r * row_stride + col] = v[h][j];
+          }
+        }
       }
     }
     __syncthreads();
@@ -153,17 +172,24 @@ __global__ __launch_bounds__(swg::NT) void stem_wgrad_kernel(const float* __rest
     for (int r = 0; r < 4; ++r) out[(size_t)r * KPAD + 16 * k] = acc[k][r];
 }
 
-// dW[o][c][ky][kx] = sum over the workgroups' partials, in index order, in fp64
-__global__ __launch_bounds__(192) void stem_wgrad_reduce_kernel(const float* __restrict__ work, int G, float* __restrict__ dw) {
+// dW[o][c][ky][kx] = sum over the workgroups' partials in fp64: four slices of the list in parallel (each in index order),
+// the four slice sums added in slice order — a fixed order, so the same bits on every run
+__global__ __launch_bounds__(4 * 192) void stem_wgrad_reduce_kernel(const float* __restrict__ work, int G, float* __restrict__ dw) {
   using namespace swg;
-  const int o = blockIdx.x, j = threadIdx.x;
-  if (j >= CIN * KS * 8) return;
-  const int R = j >> 3, kx = j & 7;
-  if (kx >= KS) return;
+  __shared__ double part[4][192];
+  const int o = blockIdx.x, j = threadIdx.x % 192, sl = threadIdx.x / 192;
+  const int per = (G + 3) / 4, g0 = sl * per, g1 = min(G, g0 + per);
   double s = 0.0;
-  const float* p = work + (size_t)o * KPAD + j;
-  for (int g = 0; g < G; ++g) s += (double)p[(size_t)g * COUT * KPAD];
-  dw[(size_t)o * CIN * KS * KS + R * KS + kx] = (float)s;
+  if (j < KPAD) {
+    const float* p = work + (size_t)o * KPAD + j;
+#pragma unroll 8
+    for (int g = g0; g < g1; ++g) s += (double)p[(size_t)g * COUT * KPAD];
+  }
+  part[sl][j] = s;
+  __syncthreads();
+  const int R = j >> 3, kx = j & 7;
+  if (sl == 0 && R < CIN * KS && kx < KS)
+    dw[(size_t)o * CIN * KS * KS + R * KS + kx] = (float)(((part[0][j] + part[1][j]) + part[2][j]) + part[3][j]);
 }
 
 size_t stem_wgrad_lds_bytes(int H, int W);
@@ -205,7 +231,7 @@ int launch_stem_wgrad(const float* x, const float* dy, int N, int H, int W, floa
       hipSuccess)
     return BNN_HIP_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(G), dim3(NT), lds, stream, x, dy, N, H, W, Hc, Wc, bands_y, rs, work);
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(COUT), dim3(192), 0, stream, work, G, dw);
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(COUT), dim3(4 * 192), 0, stream, work, G, dw);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
