@@ -459,6 +459,67 @@ int launch_bn_bwd_dx(const float* gy, const float* y, const float* x, const floa
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
+// The same dx with the routing done in LDS (round 5; planes of at most 64 KB: 112 x 112 at ImageNet size).  One workgroup
+// per (image, channel) plane: every pooled output is read ONCE, coalesced (the gather form above reads each of them from
+// the lanes of three conv rows: 18 small loads per float4 of dx), its gy is added to the plane's LDS copy at the pixel
+// its code names, and the plane leaves as float4s.  Windows of equal row and column parity never share a pixel (their
+// 3 x 3 fields are two pixels apart), so the four parity classes are added one after the other without atomics: a fixed
+// order, the same bits on every run.
+__global__ __launch_bounds__(bnt::NT) void bn_pool_bwd_dx_lds_kernel(const float* __restrict__ gy, const float* __restrict__ p,
+                                                                     const unsigned char* __restrict__ code,
+                                                                     const float* __restrict__ x,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ coef, float* __restrict__ dx,
+                                                                     int C, int H, int W, int Hp, int Wp) {
+  extern __shared__ __attribute__((aligned(16))) float gpl[];
+  constexpr int PER = 16;  // pooled outputs per thread: Hp * Wp <= 16 * 256 (H * W <= 16384)
+  const int tid = threadIdx.x;
+  const size_t plane = blockIdx.x;
+  const int c = (int)(plane % C);
+  const int hw = H * W, hwp = Hp * Wp;
+  const size_t pb = plane * hwp;
+  // this thread's pooled outputs: value (0 if the ReLU closed the window: p == 0) and target pixel, parity class
+  float val[PER];
+  int tgt[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int idx = tid + u * bnt::NT;
+    val[u] = 0.0f;
+    tgt[u] = -1;
+    if (idx < hwp) {
+      const int py = idx / Wp, px = idx - py * Wp;
+      const int cd = code[pb + idx];
+      const float g = gy[pb + idx];
+      const bool open = p[pb + idx] > 0.0f;
+      const int wy = cd / 3, wx = cd - 3 * wy;
+      val[u] = open ? g : 0.0f;
+      tgt[u] = open ? (((2 * py - 1 + wy) * W + 2 * px - 1 + wx) << 2) | ((py & 1) << 1) | (px & 1) : -1;
+    }
+  }
+  for (int i = tid * 4; i < hw; i += bnt::NT * 4) *reinterpret_cast<float4*>(gpl + i) = float4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+      if (tgt[u] >= 0 && (tgt[u] & 3) == ph) gpl[tgt[u] >> 2] += val[u];
+    __syncthreads();
+  }
+  const float mu = mean[c], k = coef[3 * c], mb = coef[3 * c + 1], kg = coef[3 * c + 2];
+  const float* xp = x + plane * hw;
+  float* dp = dx + plane * hw;
+  for (int i = tid * 4; i < hw; i += bnt::NT * 4) {
+    const float4 xv = *reinterpret_cast<const float4*>(xp + i);
+    const float4 g = *reinterpret_cast<const float4*>(gpl + i);
+    float4 d;
+    d.x = k * (g.x - mb - (xv.x - mu) * kg);
+    d.y = k * (g.y - mb - (xv.y - mu) * kg);
+    d.z = k * (g.z - mb - (xv.z - mu) * kg);
+    d.w = k * (g.w - mb - (xv.w - mu) * kg);
+    *reinterpret_cast<float4*>(dp + i) = d;
+  }
+}
+
 // stem tail forward: statistics + finalize as launch_bn_apply, then the pooling pass instead of the apply pass
 int launch_bn_relu_pool_fwd(const float* x, const double* partial, int splits, const float* gamma, const float* beta,
                             float* p, unsigned char* code, int N, int C, int H, int W, float eps, float momentum, float* rm,
@@ -487,7 +548,13 @@ int launch_bn_relu_pool_bwd(const float* gy, const float* p, const unsigned char
   while ((1 << lpr_shift) < (v4 ? W / 4 : W) && lpr_shift < 6) ++lpr_shift;
   const long long rows_per_block = (long long)(bnt::NT / 64) * (64 >> lpr_shift);
   const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
-  if (v4)
+  const long long hw = (long long)H * W;
+  if (hw % 4 == 0 && hw <= 16384 && vec4(x, dx, nullptr, nullptr, 4) && (long long)Hp * Wp <= 16 * bnt::NT &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(bn_pool_bwd_dx_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)(hw * 4)) == hipSuccess)
+    hipLaunchKernelGGL(bn_pool_bwd_dx_lds_kernel, dim3((unsigned)((long long)N * C)), dim3(bnt::NT), (size_t)hw * 4, s, gy, p, code,
+                       x, mean, work, dx, C, H, W, Hp, Wp);
+  else if (v4)
     hipLaunchKernelGGL(bn_pool_bwd_dx_kernel<4>, grid, dim3(bnt::NT), 0, s, gy, p, code, x, mean, work, dx, rows, C, H, W, Hp,
                        Wp, lpr_shift);
   else
