@@ -270,6 +270,51 @@ __global__ __launch_bounds__(bnt::NT) void bn_relu_pool_fwd_kernel(const float* 
   code[o] = (unsigned char)bc;
 }
 
+// The same forward with the plane staged in LDS (round 5; planes of at most 64 KB): one workgroup per (image, channel)
+// plane reads it once as float4s, keeps relu(fma(x, scale, shift)) in LDS and takes every window from there — the same
+// nine comparisons in the same order as above, so the same pooled values and codes.
+__global__ __launch_bounds__(bnt::NT) void bn_relu_pool_fwd_lds_kernel(const float* __restrict__ x,
+                                                                       const float* __restrict__ scale_c,
+                                                                       const float* __restrict__ shift_c,
+                                                                       float* __restrict__ p, unsigned char* __restrict__ code,
+                                                                       int C, int H, int W, int Hp, int Wp) {
+  extern __shared__ __attribute__((aligned(16))) float vpl[];
+  const int tid = threadIdx.x;
+  const size_t plane = blockIdx.x;
+  const int c = (int)(plane % C);
+  const float scale = scale_c[c], shift = shift_c[c];
+  const int hw = H * W, hwp = Hp * Wp;
+  const float* xp = x + plane * hw;
+  auto act = [&](float xv) {
+    const float t = fmaf(xv, scale, shift);
+    return t < 0.0f ? 0.0f : t;  // NaN stays NaN
+  };
+  for (int i = tid * 4; i < hw; i += bnt::NT * 4) {
+    const float4 xv = *reinterpret_cast<const float4*>(xp + i);
+    *reinterpret_cast<float4*>(vpl + i) = float4{act(xv.x), act(xv.y), act(xv.z), act(xv.w)};
+  }
+  __syncthreads();
+  for (int idx = tid; idx < hwp; idx += bnt::NT) {
+    const int py = idx / Wp, px = idx - py * Wp;
+    float best = -1.0f;
+    int bc = 0;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int r = 2 * py - 1 + dy;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int q = 2 * px - 1 + dx;
+        if ((unsigned)r < (unsigned)H && (unsigned)q < (unsigned)W) {
+          const float v = vpl[r * W + q];
+          if (v > best || v != v) { best = v; bc = 3 * dy + dx; }
+        }
+      }
+    }
+    p[plane * hwp + idx] = best;
+    code[plane * hwp + idx] = (unsigned char)bc;
+  }
+}
+
 // partial[c][s] = (sum g, sum g * xhat) over the images of split s, from the pooled outputs: g is non-zero only at winners
 __global__ __launch_bounds__(bnt::NT) void bn_pool_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ p,
                                                                      const unsigned char* __restrict__ code,
@@ -528,6 +573,14 @@ int launch_bn_relu_pool_fwd(const float* x, const double* partial, int splits, c
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, partial, splits, C,
                      (double)N * H * W, gamma, beta, eps, momentum, rm, rv, mean_out, invstd_out, work, work + C);
   const long long total = (long long)N * C * Hp * Wp;
+  const long long hw = (long long)H * W;
+  if (hw % 4 == 0 && hw <= 16384 && vec4(x, nullptr, nullptr, nullptr, 4) &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(bn_relu_pool_fwd_lds_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(hw * 4)) == hipSuccess) {
+    hipLaunchKernelGGL(bn_relu_pool_fwd_lds_kernel, dim3((unsigned)((long long)N * C)), dim3(bnt::NT), (size_t)hw * 4, s, x, work,
+                       work + C, p, code, C, H, W, Hp, Wp);
+    return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3((unsigned)((total + bnt::NT - 1) / bnt::NT)), dim3(bnt::NT), 0, s, x,
                      work, work + C, p, code, total, C, H, W, Hp, Wp);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
@@ -538,6 +591,10 @@ int launch_bn_relu_pool_bwd(const float* gy, const float* p, const unsigned char
                             double* partial, float* work, float* dx, float* dgamma, float* dbeta, hipStream_t s) {
   const int Hp = (H - 1) / 2 + 1, Wp = (W - 1) / 2 + 1;
   const int per = (N + splits - 1) / splits;
+  const long long hw = (long long)H * W;
+  const bool lds_plane = hw % 4 == 0 && hw <= 16384 && vec4(x, dx, nullptr, nullptr, 4);
+  // (the reduction keeps its gather form: with the plane staged in LDS — one block per channel and split walking its
+  // images — it measured 0.77 ms against 0.43)
   hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3((unsigned)C, (unsigned)splits), dim3(bnt::NT), 0, s, gy, p, code, x, mean,
                      invstd, N, C, H, W, Hp, Wp, per, partial);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, partial, splits, C,
@@ -548,8 +605,7 @@ int launch_bn_relu_pool_bwd(const float* gy, const float* p, const unsigned char
   while ((1 << lpr_shift) < (v4 ? W / 4 : W) && lpr_shift < 6) ++lpr_shift;
   const long long rows_per_block = (long long)(bnt::NT / 64) * (64 >> lpr_shift);
   const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
-  const long long hw = (long long)H * W;
-  if (hw % 4 == 0 && hw <= 16384 && vec4(x, dx, nullptr, nullptr, 4) && (long long)Hp * Wp <= 16 * bnt::NT &&
+  if (lds_plane && (long long)Hp * Wp <= 16 * bnt::NT &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(bn_pool_bwd_dx_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)(hw * 4)) == hipSuccess)
     hipLaunchKernelGGL(bn_pool_bwd_dx_lds_kernel, dim3((unsigned)((long long)N * C)), dim3(bnt::NT), (size_t)hw * 4, s, gy, p, code,
