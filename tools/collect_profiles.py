@@ -74,7 +74,7 @@ if sagg:
     stem = {c: int(round(sum(v) / len(v))) for c, v in sorted(sagg.items())}
     if sdur:
         stem["avg_duration_us_profiled"] = round(sum(sdur) / len(sdur), 1)
-    stem["kernel"] = "bnn::stem_rows_kernel<false>, batch 256, 224x224, fp32 + sign planes out (tools/bench_stem.py)"
+    stem["kernel"] = "bnn::stem_rows_kernel<false, false>, batch 256, 224x224, fp32 + sign planes out (tools/bench_stem.py)"
     stem["provenance"] = STAMP
     json.dump(stem, open(os.path.join(dst, f"{tag}_stem_pmc.json"), "w"), indent=1, sort_keys=True)
 
