@@ -9,7 +9,7 @@ sel = [r for r in rows if end - win <= int(r["Start_Timestamp"]) and int(r["End_
 agg = collections.defaultdict(lambda: [0, 0])
 for r in sel:
     n = r["Kernel_Name"]
-    n = n.replace("void ", "").replace("bnn::", "").split("(")[0].replace("at::native::", "")[:110]
+    n = n.replace("void ", "").replace("bnn::", "").replace("(anonymous namespace)::", "").split("(")[0].replace("at::native::", "")[:110]
     agg[n][0] += 1
     agg[n][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 tot = sum(v[1] for v in agg.values())
