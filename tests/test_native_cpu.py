@@ -161,6 +161,17 @@ def test_argument_validation_without_touching_the_gpu():
     assert lib.bnn_hip_bconv_grad_input_f32(16, 16, 16, 16, 16, 2, 64, 64, 8, 8, 3, 3, None) == -2   # stride 3
     assert lib.bnn_hip_bconv_grad_input_f32(16, 16, 16, 16, 16, 2, 64, 64, 8, 8, 1, 2, None) == -2   # strided 1x1
     assert lib.bnn_hip_bconv_grad_weight_f32(None, 16, 16, 1, 2, 64, 64, 8, 8, 3, 1, None) == -1
+    # stem convolution of a training step: forward argument checks; backward workspace arithmetic and support rule
+    assert lib.bnn_hip_stem7x7_conv_f32(None, 16, 1, 8, 8, 0, 16, None) == -1
+    assert lib.bnn_hip_stem7x7_conv_f32(16, 16, 1, 8, 8, 2, 16, None) == -1                 # unknown flag
+    ws = lib.bnn_hip_stem7x7_wgrad_workspace_bytes(256, 224, 224)
+    assert ws > 0 and ws % (64 * 176 * 4) == 0 and ws // (64 * 176 * 4) <= 256 * 28      # one slab per workgroup, <= bands
+    assert lib.bnn_hip_stem7x7_wgrad_workspace_bytes(1, 7, 9) == 64 * 176 * 4                # one band
+    assert lib.bnn_hip_stem7x7_wgrad_workspace_bytes(1, 8, 4096) == 0                         # rows beyond the LDS patch
+    assert lib.bnn_hip_stem7x7_wgrad_workspace_bytes(0, 224, 224) == 0
+    assert lib.bnn_hip_stem7x7_wgrad_f32(None, 16, 1, 8, 8, 16, 1 << 20, 16, None) == -1
+    assert lib.bnn_hip_stem7x7_wgrad_f32(16, 16, 1, 8, 4096, 16, 1 << 20, 16, None) == -2    # unsupported width
+    assert lib.bnn_hip_stem7x7_wgrad_f32(16, 16, 1, 8, 8, 16, 16, 16, None) == -1             # workspace too small
     assert lib.bnn_hip_conv_workspace_bytes(ctypes.byref(d)) == 0       # the layer is one launch: no workspace
     assert lib.bnn_hip_bconv2d_direct(ctypes.byref(d), None, 0, None, None, None, None, None, None, None, None) == -1
     assert lib.bnn_hip_bconv2d_direct(ctypes.byref(d), 16, 7, 16, 16, 16, None, None, 16, None, None) == -1   # dtype
