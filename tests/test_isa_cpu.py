@@ -1,4 +1,4 @@
-"""Compiler-output check that needs no GPU: the stem kernels' assembly holds no back-to-back pair of different matrix-core
+"""Compiler-output check that needs no GPU: the assembly of every source with matrix-core instructions holds no back-to-back pair of different matrix-core
 opcodes chained through SrcC (tools/mfma_pairs.py; tools/experiments/README.md 54 — gfx950 returned two of four result
 registers wrong for it and hipcc 7.2 schedules no wait states there)."""
 import os
@@ -28,11 +28,13 @@ def test_scanner_sees_the_pair_and_nothing_else():
     assert mfma_pairs.dependent_pairs(apart) == []
     independent = bad.replace("v[106:107], v[98:101]", "v[106:107], v[82:85]")
     assert mfma_pairs.dependent_pairs(independent) == []
+    accvgpr = bad.replace("v[98:101]", "a[8:11]")       # accumulators in AccVGPRs: the same pair
+    assert len(mfma_pairs.dependent_pairs(accvgpr)) == 1
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("src", ["stem_rows.hip", "stem.hip"])
-def test_stem_kernels_hold_no_back_to_back_mixed_mfma_chain(tmp_path, src):
+@pytest.mark.parametrize("src", ["stem_rows.hip", "stem.hip", "stem_wgrad.hip", "grad.hip"])
+def test_mfma_kernels_hold_no_back_to_back_mixed_mfma_chain(tmp_path, src):
     out = tmp_path / "k.s"
     subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
                     os.path.join(ROOT, "binary-networks-pytorch_amd", "csrc", src), "-o", str(out)],

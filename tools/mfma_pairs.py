@@ -11,7 +11,17 @@ tests/test_isa_cpu.py compiles csrc/stem_rows.hip and calls :func:`dependent_pai
 import re
 import sys
 
-_REG = re.compile(r"v\[(\d+):(\d+)\]")
+_REG = re.compile(r"^([av])(?:\[(\d+):(\d+)\]|(\d+))$")
+
+
+def _reg(tok):
+    """(file, lo, hi) of a VGPR / AccVGPR operand, None for anything else (constants, modifiers)."""
+    m = _REG.match(tok.strip())
+    if not m:
+        return None
+    if m.group(4) is not None:
+        return m.group(1), int(m.group(4)), int(m.group(4))
+    return m.group(1), int(m.group(2)), int(m.group(3))
 
 
 def dependent_pairs(asm_text):
@@ -28,10 +38,11 @@ def dependent_pairs(asm_text):
             prev = None
             continue
         op = t.split()[0]
-        regs = _REG.findall(t)
-        dst = tuple(map(int, regs[0]))
-        srcc = tuple(map(int, regs[-1])) if len(regs) == 4 else None
-        if prev and prev[0] != op and srcc is not None and srcc[0] <= prev[1][1] and prev[1][0] <= srcc[1]:
+        ops = [_reg(x) for x in t[len(op):].split(",")[:4]]
+        dst = ops[0]
+        srcc = ops[3] if len(ops) == 4 else None
+        if (prev and prev[0] != op and dst is not None and srcc is not None and prev[1] is not None
+                and srcc[0] == prev[1][0] and srcc[1] <= prev[1][2] and prev[1][1] <= srcc[2]):
             out.append((kernel, no, prev[2], t))
         prev = (op, dst, t)
     return out
