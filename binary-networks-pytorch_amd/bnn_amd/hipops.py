@@ -276,6 +276,21 @@ def stem7x7_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     return dw
 
 
+def avgpool2x2_backward(gy: torch.Tensor) -> torch.Tensor:
+    """Backward of ``AvgPool2d(2, 2)`` on an even-sized map: ``gx[..., 2y + a, 2x + b] = gy[..., y, x] / 4``
+    (``bnn_hip_avgpool2x2_backward_f32``)."""
+    gy = _require_cuda_f32(gy, "pooled gradient")
+    if gy.dim() != 4:
+        raise native.NativeError("bnn_amd: avgpool2x2_backward expects [N,C,Ho,Wo]")
+    lib = native.require()
+    N, C, Ho, Wo = gy.shape
+    with torch.cuda.device(gy.device):
+        gx = torch.empty((N, C, 2 * Ho, 2 * Wo), dtype=torch.float32, device=gy.device)
+        native.check(lib.bnn_hip_avgpool2x2_backward_f32(gy.data_ptr(), N, C, Ho, Wo, gx.data_ptr(), _stream(gy.device)),
+                     "bnn_hip_avgpool2x2_backward_f32")
+    return gx
+
+
 def sign_thresholds(w: PackedWeight, bn_scale: torch.Tensor, bn_shift: torch.Tensor, bias=None, post_scale=None):
     """Integer form of ``sign(relu(bn(alpha * dot + bias)))`` for ``bconv2d_fused(..., sign_thresholds=...)``:
     int32 ``[O, 4]`` = (bound T, flip word of the channel's 32-channel block, the two comparands of the kernels'

@@ -64,7 +64,12 @@ class _Residual(nn.Module):
             return x
         if (isinstance(ds, nn.Sequential) and len(ds) == 3 and isinstance(ds[2], nn.BatchNorm2d)
                 and not ds._forward_hooks and not ds._forward_pre_hooks):
-            return _bn_act(ds[1](ds[0](x)), ds[2])       # AvgPool -> conv1x1 -> BN (bnn/models/resnet.py:128-133)
+            if x.is_cuda and self.training and torch.is_grad_enabled():
+                from .. import training
+                pooled = training.shortcut_pool(x, ds[0])   # (the same forward; a streaming kernel for its backward)
+            else:
+                pooled = ds[0](x)
+            return _bn_act(ds[1](pooled), ds[2])         # AvgPool -> conv1x1 -> BN (bnn/models/resnet.py:128-133)
         return ds(x)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -419,6 +419,50 @@ int bn_train_splits(int N, int C, int HW) {
   return (N + per - 1) / per;
 }
 
+// ------------------------------------------------------------------------------------------------- shortcut pooling
+// Backward of AvgPool2d(2, 2) on an even-sized map (the shortcut branch of a down-sampling block, bnn/models/resnet.py:
+// 128-133, in a training step): gx[n, c, 2y + a, 2x + b] = gy[n, c, y, x] / 4.  A streaming kernel (the library's generic
+// avg_pool2d backward: 0.53 ms for the three shortcuts of a ResNet-18 step at batch 256 — this: 0.09).  VEC: two pooled
+// values per thread in, two float4 rows out.
+template <bool VEC>
+__global__ __launch_bounds__(bnt::NT) void avgpool2_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                               long long units, int Ho, int Wo) {
+  const long long u = (long long)blockIdx.x * bnt::NT + threadIdx.x;
+  if (u >= units) return;
+  if constexpr (VEC) {
+    const int wp = Wo / 2;
+    const long long row = u / wp;              // n * C * Ho + y
+    const int xp = (int)(u - row * wp);
+    const float2 g = *reinterpret_cast<const float2*>(gy + row * Wo + 2 * xp);
+    const float a = 0.25f * g.x, b = 0.25f * g.y;
+    const long long plane_row = row / Ho;      // n * C
+    const int y = (int)(row - plane_row * Ho);
+    float* o = gx + ((plane_row * 2 * Ho + 2 * y) * (2LL * Wo)) + 4 * xp;
+    const float4 v{a, a, b, b};
+    *reinterpret_cast<float4*>(o) = v;
+    *reinterpret_cast<float4*>(o + 2 * Wo) = v;
+  } else {
+    const long long row = u / Wo;
+    const int x = (int)(u - row * Wo);
+    const float a = 0.25f * gy[u];
+    const long long plane_row = row / Ho;
+    const int y = (int)(row - plane_row * Ho);
+    float* o = gx + ((plane_row * 2 * Ho + 2 * y) * (2LL * Wo)) + 2 * x;
+    o[0] = a; o[1] = a; o[2 * Wo] = a; o[2 * Wo + 1] = a;
+  }
+}
+
+int launch_avgpool2x2_bwd(const float* gy, int N, int C, int Ho, int Wo, float* gx, hipStream_t s) {
+  const bool vec = Wo % 2 == 0 && (reinterpret_cast<uintptr_t>(gy) & 7) == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0;
+  const long long units = (long long)N * C * Ho * (vec ? Wo / 2 : Wo);
+  const dim3 grid((unsigned)((units + bnt::NT - 1) / bnt::NT));
+  if (vec)
+    hipLaunchKernelGGL(avgpool2_bwd_kernel<true>, grid, dim3(bnt::NT), 0, s, gy, gx, units, Ho, Wo);
+  else
+    hipLaunchKernelGGL(avgpool2_bwd_kernel<false>, grid, dim3(bnt::NT), 0, s, gy, gx, units, Ho, Wo);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
 static bool vec4(const void* a, const void* b, const void* c, const void* d, int HW) {
   auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   return HW % 4 == 0 && al(a) && al(b) && al(c) && al(d);

@@ -138,6 +138,7 @@ int launch_stem_conv(const float* x, const float* w, int N, int H, int W, int ha
 bool stem_wgrad_supported(int H, int W);
 size_t stem_wgrad_workspace_bytes(int N, int H, int W);
 int launch_stem_wgrad(const float* x, const float* dy, int N, int H, int W, float* work, float* dw, hipStream_t stream);
+int launch_avgpool2x2_bwd(const float* gy, int N, int C, int Ho, int Wo, float* gx, hipStream_t s);
 int launch_avgpool_fc(const float* x, const float* wt, const float* bias, float* out, int N, int C, int HW,
                       int O, hipStream_t stream);
 size_t avgpool_fc_workspace_bytes(int N, int C);

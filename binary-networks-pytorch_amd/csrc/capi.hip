@@ -309,6 +309,15 @@ int bnn_hip_stem7x7_conv_f32(const float* x, const float* w, int N, int H, int W
   return bnn::launch_stem_conv(x, w, N, H, W, (flags & BNN_HIP_STEM_FP16) != 0, out, static_cast<hipStream_t>(stream));
 }
 
+int bnn_hip_avgpool2x2_backward_f32(const float* gy, int N, int C, int Ho, int Wo, float* gx, void* stream) {
+  if (!gy || !gx || N <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (!aligned(gy, 4) || !aligned(gx, 4)) return BNN_HIP_ERR_INVALID_ARG;
+  if (mulc(N, C, Ho, Wo) > kMaxElems / 4) return BNN_HIP_ERR_TOO_LARGE;   // gx holds four times as many elements
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_avgpool2x2_bwd(gy, N, C, Ho, Wo, gx, static_cast<hipStream_t>(stream));
+}
+
 size_t bnn_hip_stem7x7_wgrad_workspace_bytes(int N, int H, int W) {
   if (N <= 0 || H <= 0 || W <= 0) return 0;
   const long long hc = (H - 1) / 2 + 1, wc = (W - 1) / 2 + 1;

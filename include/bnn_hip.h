@@ -62,7 +62,7 @@ extern "C" {
 #endif
 
 /* ABI 14 (round 5): + bnn_hip_stem7x7_wgrad_f32 / bnn_hip_stem7x7_wgrad_workspace_bytes (weight gradient of the stem
- * convolution: the training backward of that layer); + bnn_hip_avgpool_fc_ws_f32 / bnn_hip_avgpool_fc_workspace_bytes (the head as two streaming launches
+ * convolution: the training backward of that layer); + bnn_hip_avgpool2x2_backward_f32; + bnn_hip_avgpool_fc_ws_f32 / bnn_hip_avgpool_fc_workspace_bytes (the head as two streaming launches
  * through a workspace); + bnn_hip_stem7x7_conv_f32 (the stem's convolution alone: the training forward); the table of bnn_hip_sign_thresholds_f32 holds FOUR words per channel (was two) and kmax < 2^20.
  * ABI 13 (round 4): + bnn_hip_bn_act_f32 (eval-mode BatchNorm + residual + ReLU tail of the per-layer path);
  * bnn_hip_xnor_weight_backward_f32 takes `splits` partial slabs.
@@ -314,6 +314,11 @@ int bnn_hip_stem7x7_conv_f32(const float* x, const float* w, int N, int H, int W
 size_t bnn_hip_stem7x7_wgrad_workspace_bytes(int N, int H, int W);
 int bnn_hip_stem7x7_wgrad_f32(const float* x, const float* dy, int N, int H, int W, float* workspace,
                               size_t workspace_bytes, float* dw, void* stream);
+
+/* ABI 14 — backward of the shortcut's AvgPool2d(2, 2) on an even-sized map (bnn/models/resnet.py:128-133 in a training
+ * step): gx[n, c, 2y + a, 2x + b] = gy[n, c, y, x] / 4.  gy: float32 [N,C,Ho,Wo], gx: float32 [N,C,2 Ho,2 Wo]
+ * (overwritten).  One streaming launch.                                                                              */
+int bnn_hip_avgpool2x2_backward_f32(const float* gy, int N, int C, int Ho, int Wo, float* gx, void* stream);
 
 /* The real-valued head of the reference's ResNets in one kernel (bnn/models/resnet.py:160-164:
  * avgpool -> flatten -> fc):  out[n,o] = bias[o] + sum_c w_t[c,o] * mean_hw x[n,c,hw].

@@ -721,3 +721,25 @@ def test_training_step_with_the_stem_weight_gradient_kernel():
     l0, gw0, gl0 = step(False)
     assert l1 == l0 and torch.equal(gl1, gl0)                    # nothing in front of conv1's backward changed
     assert float((gw1 - gw0).norm()) <= 1e-5 * float(gw0.norm())
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 56, 56), (3, 16, 6, 10), (2, 5, 2, 2), (1, 7, 4, 6), (2, 128, 28, 28)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_shortcut_pool_backward_kernel_is_the_avgpool_backward(shape):
+    """bnn_hip_avgpool2x2_backward_f32 (the shortcut's AvgPool2d of bnn/models/resnet.py:128-133 in a training step): the
+    same forward, and gx = gy / 4 at the four pixels of every window — the bits of torch's own backward."""
+    pool = nn.AvgPool2d(kernel_size=2, stride=2, ceil_mode=True, count_include_pad=False)
+    x0 = dev(gen.normal(gen.seed_of("sp", shape), shape))
+    gy = dev(gen.normal(gen.seed_of("spg", shape), (shape[0], shape[1], shape[2] // 2, shape[3] // 2)))
+    x1 = x0.clone().requires_grad_(True)
+    y1 = training.shortcut_pool(x1, pool)
+    assert y1.grad_fn is not None and "AvgPool2x2Fn" in type(y1.grad_fn).__name__
+    y1.backward(gy)
+    x2 = x0.clone().requires_grad_(True)
+    y2 = pool(x2)
+    y2.backward(gy)
+    assert torch.equal(y1, y2) and torch.equal(x1.grad, x2.grad)
+    # odd sizes, padding, other windows: the module itself
+    xo = dev(gen.normal(3, (1, 2, 5, 7))).requires_grad_(True)
+    assert "AvgPool2x2Fn" not in type(training.shortcut_pool(xo, pool).grad_fn).__name__
+    assert "AvgPool2x2Fn" not in type(training.shortcut_pool(x1, nn.AvgPool2d(3, 2, 1)).grad_fn).__name__

@@ -172,6 +172,9 @@ def test_argument_validation_without_touching_the_gpu():
     assert lib.bnn_hip_stem7x7_wgrad_f32(None, 16, 1, 8, 8, 16, 1 << 20, 16, None) == -1
     assert lib.bnn_hip_stem7x7_wgrad_f32(16, 16, 1, 8, 4096, 16, 1 << 20, 16, None) == -2    # unsupported width
     assert lib.bnn_hip_stem7x7_wgrad_f32(16, 16, 1, 8, 8, 16, 16, 16, None) == -1             # workspace too small
+    assert lib.bnn_hip_avgpool2x2_backward_f32(None, 1, 1, 1, 1, 16, None) == -1
+    assert lib.bnn_hip_avgpool2x2_backward_f32(16, 1, 1, 0, 1, 16, None) == -1
+    assert lib.bnn_hip_avgpool2x2_backward_f32(16, 1 << 15, 1 << 10, 1 << 5, 1 << 5, 16, None) == -4
     assert lib.bnn_hip_conv_workspace_bytes(ctypes.byref(d)) == 0       # the layer is one launch: no workspace
     assert lib.bnn_hip_bconv2d_direct(ctypes.byref(d), None, 0, None, None, None, None, None, None, None, None) == -1
     assert lib.bnn_hip_bconv2d_direct(ctypes.byref(d), 16, 7, 16, 16, 16, None, None, 16, None, None) == -1   # dtype

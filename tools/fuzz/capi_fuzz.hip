@@ -140,6 +140,11 @@ int launch_stem_wgrad(const float* x, const float* dy, int N, int H, int W, floa
   REQUIRE((long long)N * 3 * H * W <= 0x7fffffffLL && (long long)N * 64 * hc * wc <= 0x7fffffffLL);
   return BNN_HIP_OK;
 }
+int launch_avgpool2x2_bwd(const float* gy, int N, int C, int Ho, int Wo, float* gx, hipStream_t) {
+  ++g_reached;
+  REQUIRE(gy && gx && N > 0 && C > 0 && Ho > 0 && Wo > 0 && (long long)N * C * Ho * Wo * 4 <= 0x7fffffffLL);
+  return BNN_HIP_OK;
+}
 int launch_avgpool_fc(const float* x, const float* wt, const float*, float* out, int N, int C, int HW, int O, hipStream_t) {
   ++g_reached; REQUIRE(x && wt && out && N > 0 && C > 0 && HW > 0 && O > 0); return BNN_HIP_OK;
 }
@@ -279,7 +284,7 @@ int main(int argc, char** argv) {
   for (long it = 0; it < iters; ++it) {
     ++g_calls;
     int st = 0;
-    switch (rnd() % 33) {
+    switch (rnd() % 34) {
       case 0: { bnn_hip_conv_desc d = pick_desc();
         st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
                              pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
@@ -389,6 +394,8 @@ int main(int argc, char** argv) {
         st = bnn_hip_stem7x7_wgrad_f32(pick_ptr<float>(), pick_ptr<float>(), n, h, w, pick_ptr<float>(),
                                        rnd() % 4 ? need : (size_t)(rnd() % 4096), pick_ptr<float>(), stream);
         break; }
+      case 32: st = bnn_hip_avgpool2x2_backward_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(),
+                                                    pick_ptr<float>(), stream); break;
       default: { bnn_hip_conv_desc d = pick_desc();
         (void)bnn_hip_shortcut_fold_supported(rnd() % 16 ? &d : nullptr, pick_int());
         st = bnn_hip_blinear(pick_int(), pick_int(), pick_int(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
