@@ -683,6 +683,21 @@ def grad_pack_weight(w_hat: torch.Tensor):
     return packed, alpha
 
 
+def xnor_grad_pack_weight(w: torch.Tensor, center: bool, compute_alpha: bool):
+    """``grad_pack_weight(xnor_what(w, center, compute_alpha))`` in one launch (``bnn_hip_xnor_grad_pack_weight_f32``): the
+    sign fragments and ``alpha[O]`` the input-gradient kernel reads, straight from the raw weight — the same bytes."""
+    w = _require_cuda_f32(w.detach(), "weight")
+    lib = native.require()
+    O, C, k = w.shape[0], w.shape[1], w.shape[2]
+    with torch.cuda.device(w.device):
+        packed = torch.empty(int(lib.bnn_hip_grad_weight_pack_bytes(O, C, k)), dtype=torch.uint8, device=w.device)
+        alpha = torch.empty(O, dtype=torch.float32, device=w.device)
+        native.check(lib.bnn_hip_xnor_grad_pack_weight_f32(w.data_ptr(), O, C, k, int(center), int(compute_alpha),
+                                                           packed.data_ptr(), alpha.data_ptr(), _stream(w.device)),
+                     "bnn_hip_xnor_grad_pack_weight_f32")
+    return packed, alpha
+
+
 @dataclass
 class SavedAct:
     """What the backward of a binary convolution needs from its fp32 input, in 3 bits per element: the sign planes

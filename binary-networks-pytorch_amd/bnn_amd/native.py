@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_bn_relu_maxpool_train_backward_f32", "bnn_hip_xnor_weight_forward_f32", "bnn_hip_xnor_weight_backward_f32",
     "bnn_hip_bn_act_f32", "bnn_hip_avgpool_fc_workspace_bytes", "bnn_hip_avgpool_fc_ws_f32",
     "bnn_hip_stem7x7_conv_f32", "bnn_hip_stem7x7_wgrad_workspace_bytes", "bnn_hip_stem7x7_wgrad_f32",
-    "bnn_hip_avgpool2x2_backward_f32",
+    "bnn_hip_avgpool2x2_backward_f32", "bnn_hip_xnor_grad_pack_weight_f32",
 )
 
 
@@ -152,6 +152,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_stem7x7_wgrad_workspace_bytes.restype = ctypes.c_size_t
     lib.bnn_hip_stem7x7_wgrad_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, _vp, _vp]
     lib.bnn_hip_avgpool2x2_backward_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp]
+    lib.bnn_hip_xnor_grad_pack_weight_f32.argtypes = [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]
     lib.bnn_hip_avgpool_fc_workspace_bytes.argtypes = [_i, _i]
     lib.bnn_hip_avgpool_fc_workspace_bytes.restype = ctypes.c_size_t
     lib.bnn_hip_avgpool_fc_ws_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp]

@@ -329,7 +329,7 @@ class BinaryConv2dTrainFusedFn(torch.autograd.Function):
         if ctx.x_shape is not None or (
                 BINARY_GRADS and hipops.grad_supported(x.shape, w.shape, stride, padding, dilation)):
             if need_x:
-                packed, alpha = hipops.grad_pack_weight(hipops.xnor_what(w, center, compute_alpha))
+                packed, alpha = hipops.xnor_grad_pack_weight(w, center, compute_alpha)   # (one launch, the same bytes)
                 gx = hipops.bconv_grad_input(g, x, packed, alpha, w.shape[2], stride[0])       # STE mask fused
             if need_w:
                 # the split-K slabs: up to 16 are added inside the hook's kernel (one workgroup per output channel walks them),

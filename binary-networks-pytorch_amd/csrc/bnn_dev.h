@@ -165,6 +165,8 @@ bool fly_supported(const ConvP& p);
 int fly_default_plan(const ConvP& p, int flags, bnn_hip_fly_plan* plan);
 int launch_bconv_fly(const ConvP& p, const void* x, int x_half, int flags, const bnn_hip_fly_plan* plan, hipStream_t s);
 // xnor_train.hip: XNORWeightBinarizer under autograd, value and backward
+int launch_xnor_grad_pack(const float* w, int O, int C, int ks, int center, int compute_alpha, void* packed, float* alpha,
+                          hipStream_t s);
 int launch_xnor_what(const float* w, int O, int C, int taps, int center, int compute_alpha, float* what, float* alpha,
                      hipStream_t s);
 int launch_xnor_weight_bwd(const float* w, const float* dwhat, int splits, int O, int C, int taps, int center,

@@ -659,6 +659,18 @@ int bnn_hip_xnor_weight_forward_f32(const float* w, int O, int C, int KH, int KW
   return bnn::launch_xnor_what(w, O, C, KH * KW, center != 0, compute_alpha != 0, what, alpha, static_cast<hipStream_t>(stream));
 }
 
+int bnn_hip_xnor_grad_pack_weight_f32(const float* w, int O, int C, int ksize, int center, int compute_alpha, void* packed,
+                                      float* alpha, void* stream) {
+  if (!w || !packed || !alpha || O <= 0 || C <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (!grad_ks_ok(ksize)) return BNN_HIP_ERR_UNSUPPORTED;
+  if (mulc(O, C, ksize, ksize) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (!aligned(w, 4) || !aligned(packed, 16) || !aligned(alpha, 4)) return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_xnor_grad_pack(w, O, C, ksize, center != 0, compute_alpha != 0, packed, alpha,
+                                    static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_xnor_weight_backward_f32(const float* w, const float* dwhat, int splits, int O, int C, int KH, int KW,
                                      int center, int compute_alpha, float* dw, void* stream) {
   if (!w || !dwhat || !dw || O <= 0 || C <= 0 || KH <= 0 || KW <= 0 || splits <= 0) return BNN_HIP_ERR_INVALID_ARG;

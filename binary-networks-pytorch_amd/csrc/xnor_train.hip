@@ -111,6 +111,56 @@ __global__ __launch_bounds__(xt::NT) void xnor_weight_bwd_kernel(const float* __
     dwo[k] = dvc(k, t) - (center ? dmean[t] : 0.0f);
 }
 
+// What the input-gradient kernel needs of the weights, straight from W (round 5; was xnor_what_kernel -> grad_alpha_kernel
+// -> grad_pack_weight_kernel: three launches per layer and backward pass, 57 per ResNet-18 step): alpha[o] and
+// sign(Wc) in the MFMA B-fragment order of csrc/grad.hip,
+//     Bp[ob][tap][cs][lane][e] = sign(Wc[o = 32 ob + 8 (lane >> 4) + e][c = 16 cs + (lane & 15)][tap])     (bf16)
+// One workgroup per output channel of the PADDED range (32 * ceil(O / 32)): channels past O and input channels past C
+// are written as zeros, so the buffer needs no clearing.  The same centring / alpha code as xnor_what_kernel: the same
+// bits as the three-launch form for finite weights (alpha there: max |What| = alpha, or 0 when every sign is 0 — see
+// below; a NaN weight made that form's What NaN throughout, i.e. all signs 0 and alpha 0 — here the channel keeps the
+// signs of its finite weights and alpha = NaN reaches the input gradient).
+__global__ __launch_bounds__(xt::NT) void xnor_grad_pack_kernel(const float* __restrict__ w, int O, int C, int taps, int center,
+                                                                int compute_alpha, int CS, unsigned short* __restrict__ Bp,
+                                                                float* __restrict__ alpha_out) {
+  __shared__ float mean[xt::kMaxTaps];
+  __shared__ double red[4];
+  __shared__ int any_nz;
+  const int o = blockIdx.x, tid = threadIdx.x, K = C * taps;
+  const int ob = o >> 5, lg = (o & 31) >> 3, e = o & 7;
+  const bool live = o < O;
+  float alpha = 0.0f;
+  if (tid == 0) any_nz = 0;
+  const float* wo = w + (size_t)(live ? o : 0) * K;
+  if (live) alpha = xt::centre_and_alpha(wo, C, taps, center, compute_alpha, mean, red);   // (block-uniform branch)
+  else __syncthreads();
+  int nz = 0;
+  const int KP = CS * 16 * taps;                  // the channel range padded to whole 16-channel fragments
+  for (int k = tid; k < KP; k += xt::NT) {
+    const int c = k / taps, t = k - c * taps;
+    unsigned short b = 0;
+    if (live && c < C) {
+      const float v = wo[(size_t)c * taps + t] - mean[t];
+      b = is_pos(v) ? (unsigned short)0x3F80 : is_neg(v) ? (unsigned short)0xBF80 : (unsigned short)0;
+      nz |= b != 0;
+    }
+    const size_t blk = ((size_t)ob * taps + t) * CS + (c >> 4);
+    Bp[(blk * 64 + (c & 15) + 16 * lg) * 8 + e] = b;
+  }
+  if (nz) any_nz = 1;                             // (benign race: every writer stores 1)
+  __syncthreads();
+  // the three-launch form derived alpha as max |What|: 0 for a channel whose signs are all 0
+  if (live && tid == 0) alpha_out[o] = any_nz ? alpha : 0.0f;
+}
+
+int launch_xnor_grad_pack(const float* w, int O, int C, int ks, int center, int compute_alpha, void* packed, float* alpha,
+                          hipStream_t s) {
+  const int taps = ks * ks, CS = (C + 15) / 16, OB = (O + 31) / 32;
+  hipLaunchKernelGGL(xnor_grad_pack_kernel, dim3((unsigned)(OB * 32)), dim3(xt::NT), 0, s, w, O, C, taps, center, compute_alpha,
+                     CS, static_cast<unsigned short*>(packed), alpha);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
 int launch_xnor_what(const float* w, int O, int C, int taps, int center, int compute_alpha, float* what, float* alpha,
                      hipStream_t s) {
   if (taps > xt::kMaxTaps) return BNN_HIP_ERR_UNSUPPORTED;

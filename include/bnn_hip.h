@@ -62,7 +62,7 @@ extern "C" {
 #endif
 
 /* ABI 14 (round 5): + bnn_hip_stem7x7_wgrad_f32 / bnn_hip_stem7x7_wgrad_workspace_bytes (weight gradient of the stem
- * convolution: the training backward of that layer); + bnn_hip_avgpool2x2_backward_f32; + bnn_hip_avgpool_fc_ws_f32 / bnn_hip_avgpool_fc_workspace_bytes (the head as two streaming launches
+ * convolution: the training backward of that layer); + bnn_hip_avgpool2x2_backward_f32, bnn_hip_xnor_grad_pack_weight_f32; + bnn_hip_avgpool_fc_ws_f32 / bnn_hip_avgpool_fc_workspace_bytes (the head as two streaming launches
  * through a workspace); + bnn_hip_stem7x7_conv_f32 (the stem's convolution alone: the training forward); the table of bnn_hip_sign_thresholds_f32 holds FOUR words per channel (was two) and kmax < 2^20.
  * ABI 13 (round 4): + bnn_hip_bn_act_f32 (eval-mode BatchNorm + residual + ReLU tail of the per-layer path);
  * bnn_hip_xnor_weight_backward_f32 takes `splits` partial slabs.
@@ -486,6 +486,14 @@ int bnn_hip_xnor_weight_forward_f32(const float* w, int O, int C, int KH, int KW
                                     float* what, float* alpha, void* stream);
 int bnn_hip_xnor_weight_backward_f32(const float* w, const float* dwhat, int splits, int O, int C, int KH, int KW,
                                      int center, int compute_alpha, float* dw, void* stream);
+
+/* ABI 14 — what bnn_hip_bconv_grad_input_f32 needs of the weights, straight from W in ONE launch: the fragments and alpha of
+ * bnn_hip_grad_pack_weight_f32(What) for What = XNORWeightBinarizer(W) (bnn/ops.py:129-140) — the same bytes as
+ * bnn_hip_xnor_weight_forward_f32 followed by bnn_hip_grad_pack_weight_f32 (three launches), without the fp32 What.
+ * w: float32 [O,C,k,k], k = 3 or 1; packed: bnn_hip_grad_weight_pack_bytes(O, C, k) bytes, 16-byte aligned (written
+ * completely: no clearing needed); alpha: float32 [O].                                                                  */
+int bnn_hip_xnor_grad_pack_weight_f32(const float* w, int O, int C, int ksize, int center, int compute_alpha, void* packed,
+                                      float* alpha, void* stream);
 
 /* Training-mode BatchNorm2d fused with what follows it in the reference's residual blocks:
  *     y = relu?( batch_norm_train(x) (+ residual) )          bnn/models/layers/res_block.py:40-56, resnet.py:150-153

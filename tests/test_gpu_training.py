@@ -293,7 +293,8 @@ def test_binary_gradient_kernels_are_used_and_can_be_switched_off():
         launches_library = native.launch_count() - n0
     finally:
         training.BINARY_GRADS = True
-    assert launches_binary == launches_library + 4      # alpha + sign fragments + dgrad + wgrad
+    # the binary path: weight prep (one launch from W, round 5) + dgrad + wgrad; the library path: the fp32 What (one launch)
+    assert launches_binary == launches_library + 2
     assert torch.equal(y1, y0)
     assert torch.allclose(gx1, gx0, rtol=1e-4, atol=2e-5 * float(gx0.abs().max()))
     for n in gp0:
@@ -743,3 +744,24 @@ def test_shortcut_pool_backward_kernel_is_the_avgpool_backward(shape):
     xo = dev(gen.normal(3, (1, 2, 5, 7))).requires_grad_(True)
     assert "AvgPool2x2Fn" not in type(training.shortcut_pool(xo, pool).grad_fn).__name__
     assert "AvgPool2x2Fn" not in type(training.shortcut_pool(x1, nn.AvgPool2d(3, 2, 1)).grad_fn).__name__
+
+
+@pytest.mark.parametrize("center,compute_alpha", [(False, True), (True, True), (False, False), (True, False)],
+                         ids=["xnor", "xnor_centered", "sign_only", "sign_centered"])
+@pytest.mark.parametrize("shape", [(64, 64, 3, 3), (40, 70, 3, 3), (128, 96, 1, 1), (33, 17, 3, 3), (512, 512, 3, 3)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_one_launch_weight_prep_of_the_input_gradient_equals_the_three_launch_form(shape, center, compute_alpha):
+    """bnn_hip_xnor_grad_pack_weight_f32 (round 5): the fragments and alpha the input-gradient kernel reads, straight from
+    W — byte for byte what xnor_what -> grad_pack_weight produce (padding channels included: the buffer starts as garbage),
+    with exact zeros, weights outside (-1, 1) and an all-zero output channel."""
+    wn = gen.normal(gen.seed_of("wp", shape), shape).astype(np.float32) * 0.8
+    wn.reshape(-1)[::9] = 0.0
+    wn[1] = 0.0                              # a channel whose signs are all 0 (after centring too: its mean is 0)
+    w = dev(wn)
+    want_p, want_a = hipops.grad_pack_weight(hipops.xnor_what(w, center, compute_alpha))
+    torch.empty(want_p.numel() * 4, dtype=torch.uint8, device=DEV).fill_(0xAB)     # (dirty the allocator's next block)
+    got_p, got_a = hipops.xnor_grad_pack_weight(w, center, compute_alpha)
+    assert torch.equal(got_p, want_p)
+    assert torch.equal(got_a, want_a)
+    if not center:
+        assert float(got_a[1]) == 0.0

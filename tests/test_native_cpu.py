@@ -172,6 +172,9 @@ def test_argument_validation_without_touching_the_gpu():
     assert lib.bnn_hip_stem7x7_wgrad_f32(None, 16, 1, 8, 8, 16, 1 << 20, 16, None) == -1
     assert lib.bnn_hip_stem7x7_wgrad_f32(16, 16, 1, 8, 4096, 16, 1 << 20, 16, None) == -2    # unsupported width
     assert lib.bnn_hip_stem7x7_wgrad_f32(16, 16, 1, 8, 8, 16, 16, 16, None) == -1             # workspace too small
+    assert lib.bnn_hip_xnor_grad_pack_weight_f32(None, 64, 64, 3, 0, 1, 16, 16, None) == -1
+    assert lib.bnn_hip_xnor_grad_pack_weight_f32(16, 64, 64, 5, 0, 1, 16, 16, None) == -2      # 5x5: unsupported
+    assert lib.bnn_hip_xnor_grad_pack_weight_f32(16, 64, 64, 3, 0, 1, 8, 16, None) == -1       # packed: 16-byte aligned
     assert lib.bnn_hip_avgpool2x2_backward_f32(None, 1, 1, 1, 1, 16, None) == -1
     assert lib.bnn_hip_avgpool2x2_backward_f32(16, 1, 1, 0, 1, 16, None) == -1
     assert lib.bnn_hip_avgpool2x2_backward_f32(16, 1 << 15, 1 << 10, 1 << 5, 1 << 5, 16, None) == -4

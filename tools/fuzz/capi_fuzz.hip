@@ -194,6 +194,9 @@ int launch_sign_thresholds(const float* alpha, const float*, const float*, const
   ++g_reached; REQUIRE(alpha && thr && O > 0 && kmax > 0 && kmax < (1 << 20) && (a == nullptr) == (b == nullptr) && al(thr, 4));
   return BNN_HIP_OK;
 }
+int launch_xnor_grad_pack(const float* w, int O, int C, int ks, int, int, void* packed, float* alpha, hipStream_t) {
+  ++g_reached; REQUIRE(w && packed && alpha && O > 0 && C > 0 && (ks == 1 || ks == 3)); return BNN_HIP_OK;
+}
 int launch_xnor_what(const float* w, int O, int C, int taps, int, int, float* what, float*, hipStream_t) {
   ++g_reached; REQUIRE(w && what && O > 0 && C > 0 && taps > 0 && taps <= 1024 && (long long)O * C * taps <= (1LL << 31) - 1);
   return BNN_HIP_OK;
@@ -284,7 +287,7 @@ int main(int argc, char** argv) {
   for (long it = 0; it < iters; ++it) {
     ++g_calls;
     int st = 0;
-    switch (rnd() % 34) {
+    switch (rnd() % 35) {
       case 0: { bnn_hip_conv_desc d = pick_desc();
         st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
                              pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
@@ -396,6 +399,8 @@ int main(int argc, char** argv) {
         break; }
       case 32: st = bnn_hip_avgpool2x2_backward_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(),
                                                     pick_ptr<float>(), stream); break;
+      case 33: st = bnn_hip_xnor_grad_pack_weight_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(),
+                                                      pick_ptr<float>(), pick_ptr<float>(), stream); break;
       default: { bnn_hip_conv_desc d = pick_desc();
         (void)bnn_hip_shortcut_fold_supported(rnd() % 16 ? &d : nullptr, pick_int());
         st = bnn_hip_blinear(pick_int(), pick_int(), pick_int(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
