@@ -268,3 +268,13 @@ def test_batch_step_respects_both_launch_limits():
     assert 4095 * 2048 < (1 << 23) <= 4096 * 2048
     assert hipops._batch_step(4096, 64 * 112 * 112, 64) == ((1 << 30) - 1) // (64 * 112 * 112)   # addressing
     assert hipops._batch_step(5, 1 << 40, 1) == 1 and hipops._batch_step(3, 0, 0) == 3           # degenerate inputs
+
+
+def test_integration_doc_names_every_exported_entry_point():
+    """INTEGRATION.md's binding table covers the whole C-ABI (a few rows use the `_backward_f32` / `_workspace_bytes`
+    shorthand next to their forward entry point)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = [s for s in native.EXPORTED_SYMBOLS
+               if s not in text and s.replace("_backward_f32", "") not in text and s.replace("_workspace_bytes", "") not in text]
+    assert not missing, missing
