@@ -42,3 +42,18 @@ def test_mfma_kernels_hold_no_back_to_back_mixed_mfma_chain(tmp_path, src):
     text = out.read_text()
     assert "v_mfma" in text
     assert mfma_pairs.dependent_pairs(text) == []
+
+
+def test_no_source_uses_the_wide_buffer_load_builtins_hipcc_7_2_miscompiles():
+    """`__builtin_amdgcn_raw_buffer_load_b64 / _b96 / _b128`: hipcc 7.2 narrows them to one dword when the elements of the
+    result are extracted (tools/experiments/README.md 55) — `csrc/stem_rows.hip: rows_ld2` shows the form that works."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "binary-networks-pytorch_amd", "csrc")
+    bad = []
+    for path in glob.glob(os.path.join(csrc, "**", "*.h*"), recursive=True):
+        for no, line in enumerate(open(path), 1):
+            code = line.split("//")[0]
+            if re.search(r"__builtin_amdgcn_raw_buffer_load_b(64|96|128)\b", code):
+                bad.append(f"{os.path.relpath(path, ROOT)}:{no}")
+    assert not bad, bad
