@@ -77,3 +77,23 @@ def test_straight_through_estimator_is_the_hard_tanh_mask():
     assert torch.equal(y.detach(), torch.tensor([-1.0, -1.0, -1.0, 0.0, 0.0, 1.0, 1.0, 1.0]))
     y.backward(torch.arange(1.0, 9.0))
     assert torch.equal(x.grad, torch.tensor([0.0, 0.0, 3.0, 4.0, 5.0, 6.0, 0.0, 0.0]))   # |x| >= 1 -> 0
+
+
+def test_training_fast_paths_decline_cpu_tensors_and_other_modules():
+    """Dispatch rules of the training-side fused ops (bnn_amd/training.py) on a box without a GPU: CPU tensors, other
+    window sizes and modules with hooks take the modules themselves — same values, torch's autograd graph."""
+    x = torch.from_numpy(gen.normal(71, (2, 3, 16, 16))).requires_grad_(True)
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+    assert not training.stem_conv_applies(conv, x)                      # CPU tensor
+    y = training.stem_conv(x, conv)
+    assert torch.equal(y, conv(x)) and "Convolution" in type(y.grad_fn).__name__
+    pool = nn.AvgPool2d(kernel_size=2, stride=2, ceil_mode=True, count_include_pad=False)
+    p = training.shortcut_pool(x, pool)
+    assert torch.equal(p, pool(x)) and "AvgPool2x2Fn" not in type(p.grad_fn).__name__
+    bn, act, mp_ = nn.BatchNorm2d(64).train(), nn.ReLU(), nn.MaxPool2d(3, 2, 1)
+    assert not training.bn_act_applies(bn, act, y)
+    z = training.stem_tail(y, bn, act, mp_)
+    bn2 = nn.BatchNorm2d(64).train()
+    assert torch.allclose(z, mp_(act(bn2(conv(x)))))
+    z.sum().backward()
+    assert x.grad is not None and conv.weight.grad is not None
