@@ -638,6 +638,103 @@ def bconv2d_fused(a: PackedAct, w: PackedWeight, *, bias=None, post_scale=None, 
     return y, pk
 
 
+@dataclass
+class HBlockPack:
+    """Derived data of one hierarchical block for ``hblock_forward`` (include/bnn_hip.h: bnn_hip_hblock_forward): the
+    three weight packs in the kernel's dense layout and ONE constants buffer (alphas, folded bn2 / bn3, the next
+    block's folded bn1)."""
+    weights: torch.Tensor     # int32 [weight_words]
+    consts: torch.Tensor      # float32 [const_floats]
+    c_in: int
+    planes: int
+    has_next: bool
+
+
+def hblock_pack(w1: PackedWeight, w2: PackedWeight, w3: PackedWeight, bn2, bn3, next_bn=None) -> HBlockPack:
+    """``w1..w3``: standard packs of the block's three 3x3 convolutions (no zero weights); ``bn2`` / ``bn3`` /
+    ``next_bn``: (scale, shift) of the folded BatchNorms in front of conv2 / conv3 / the NEXT block's conv1."""
+    lib = native.require()
+    planes, c_in = 2 * w1.shape[0], w1.shape[1]
+    if (w1.has_zero or w2.has_zero or w3.has_zero or tuple(w1.shape[2:]) != (3, 3)
+            or tuple(w2.shape) != (planes // 4, planes // 2, 3, 3) or tuple(w3.shape) != (planes // 4, planes // 4, 3, 3)):
+        raise native.NativeError("bnn_amd: hblock_pack expects the three 3x3 packs of an HBlock without zero weights")
+    L = native.HBlockLayout()
+    native.check(lib.bnn_hip_hblock_layout_of(c_in, planes, ctypes.byref(L)), "bnn_hip_hblock_layout_of")
+    dev = w1.wbits.device
+    with torch.cuda.device(dev):
+        wbuf = torch.empty(int(L.weight_words), dtype=torch.int32, device=dev)
+        native.check(lib.bnn_hip_hblock_pack_weights(c_in, planes, w1.wbits.data_ptr(), w2.wbits.data_ptr(),
+                                                     w3.wbits.data_ptr(), wbuf.data_ptr(), _stream(dev)),
+                     "bnn_hip_hblock_pack_weights")
+        consts = torch.zeros(int(L.const_floats), dtype=torch.float32, device=dev)
+        for k, w in enumerate((w1, w2, w3)):
+            consts[L.alpha_off[k]:L.alpha_off[k] + w.shape[0]] = w.alpha[:w.shape[0]]
+        for k, bn in enumerate((bn2, bn3)):
+            n = (planes // 2, planes // 4)[k]
+            consts[L.pack_a_off[k]:L.pack_a_off[k] + n] = _per_channel(bn[0], n, "bn scale")
+            consts[L.pack_b_off[k]:L.pack_b_off[k] + n] = _per_channel(bn[1], n, "bn shift")
+        if next_bn is not None:
+            consts[L.next_a_off:L.next_a_off + planes] = _per_channel(next_bn[0], planes, "next bn scale")
+            consts[L.next_b_off:L.next_b_off + planes] = _per_channel(next_bn[1], planes, "next bn shift")
+    return HBlockPack(wbuf, consts, c_in, planes, next_bn is not None)
+
+
+def _hblock_desc(N, c_in, H, W, planes, throughput=False, rows_per_band=0, images_per_band=0, waves=0):
+    return native.HBlockDesc(N, c_in, H, W, planes, native.FLAG_THROUGHPUT if throughput else 0, rows_per_band,
+                             images_per_band, waves, 0)
+
+
+def hblock_supported(N: int, c_in: int, H: int, W: int, planes: int, throughput: bool = False, rows_per_band: int = 0,
+                     images_per_band: int = 0, waves: int = 0) -> bool:
+    """Whether ``hblock_forward`` covers this geometry (with this plan) on the current device."""
+    lib = native.require()
+    d = _hblock_desc(N, c_in, H, W, planes, throughput, rows_per_band, images_per_band, waves)
+    return bool(lib.bnn_hip_hblock_supported(ctypes.byref(d)))
+
+
+def hblock_forward(a: PackedAct, pack: HBlockPack, residual: torch.Tensor, out_packed: bool = True,
+                   throughput: bool = False, rows_per_band: int = 0, images_per_band: int = 0, waves: int = 0):
+    """``HBlock.forward`` behind its first BatchNorm + ReLU (bnn/models/layers/hierarchical_block.py:38-60) in ONE
+    launch: ``a`` = planes of ``sign(relu(bn1(x)))`` (non-negative), ``residual`` = the shortcut (fp32 NCHW).
+    Returns ``(y, PackedAct(sign(relu(next_bn(y)))) | None)``."""
+    lib = native.require()
+    N, c_in, H, W = a.shape
+    if not a.nonneg or c_in != pack.c_in:
+        raise native.NativeError("bnn_amd: hblock_forward needs non-negative input planes of the block's width")
+    residual = _require_cuda_f32(residual, "residual")
+    if tuple(residual.shape) != (N, pack.planes, H, W):
+        raise native.NativeError(f"bnn_amd: residual shape {tuple(residual.shape)} != block output")
+    if out_packed and not pack.has_next:
+        raise native.NativeError("bnn_amd: this HBlockPack holds no next-block BatchNorm")
+    dev = a.P.device
+    with torch.cuda.device(dev):
+        y = torch.empty_like(residual)
+        pk = None
+        if out_packed:
+            pk = PackedAct(torch.empty((N, pack.planes // 64, H, W), dtype=torch.int64, device=dev),
+                           _zero_plane((N, pack.planes // 64, H, W), dev), (N, pack.planes, H, W), nonneg=True)
+        if N == 0:
+            return y, pk
+        d = _hblock_desc(N, c_in, H, W, pack.planes, throughput, rows_per_band, images_per_band, waves)
+        native.check(lib.bnn_hip_hblock_forward(ctypes.byref(d), a.P.data_ptr(), pack.weights.data_ptr(),
+                                                pack.consts.data_ptr(), residual.data_ptr(), y.data_ptr(),
+                                                None if pk is None else pk.P.data_ptr(), _stream(dev)),
+                     "bnn_hip_hblock_forward")
+    return y, pk
+
+
+_ZERO_PLANES = {}
+
+
+def _zero_plane(shape, dev) -> torch.Tensor:
+    """An all-zero M plane (read-only by convention: planes of non-negative activations), shared per shape and device."""
+    key = (tuple(shape), dev.index)
+    z = _ZERO_PLANES.get(key)
+    if z is None:
+        z = _ZERO_PLANES[key] = torch.zeros(shape, dtype=torch.int64, device=dev)
+    return z
+
+
 def fused_launch_images(N: int, C: int, H: int, W: int, O: int, kernel_size, stride=1, padding=0, dilation=1,
                         c_total: Optional[int] = None) -> int:
     """Images ONE launch of ``bconv2d_fused`` covers for this geometry (a batch whose tensors exceed the kernels'

@@ -23,7 +23,7 @@ FLAG_ACT_NONNEG = 32
 FLAG_THROUGHPUT = 64
 STEM_EXACT_FP32 = 1
 STEM_FP16 = 4
-ABI_VERSION = 14
+ABI_VERSION = 15
 DTYPE_F32 = 0
 DTYPE_F16 = 1
 
@@ -45,6 +45,7 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_bn_act_f32", "bnn_hip_avgpool_fc_workspace_bytes", "bnn_hip_avgpool_fc_ws_f32",
     "bnn_hip_stem7x7_conv_f32", "bnn_hip_stem7x7_wgrad_workspace_bytes", "bnn_hip_stem7x7_wgrad_f32",
     "bnn_hip_avgpool2x2_backward_f32", "bnn_hip_xnor_grad_pack_weight_f32",
+    "bnn_hip_hblock_supported", "bnn_hip_hblock_layout_of", "bnn_hip_hblock_pack_weights", "bnn_hip_hblock_forward",
 )
 
 
@@ -67,6 +68,19 @@ class FlyPlan(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "images_per_band", "rows_per_band", "waves", "blocks_per_unit", "pack_ahead", "fine_head", "fine_tail", "producers",
         "lds_bytes", "n_bands")]
+
+
+class HBlockDesc(ctypes.Structure):
+    """``bnn_hip_hblock_desc``"""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "N", "C_in", "H", "W", "planes", "flags", "rows_per_band", "images_per_band", "waves", "reserved")]
+
+
+class HBlockLayout(ctypes.Structure):
+    """``bnn_hip_hblock_layout``"""
+    _fields_ = [("weight_words", ctypes.c_int64), ("w_off", ctypes.c_int64 * 3), ("const_floats", ctypes.c_int64),
+                ("alpha_off", ctypes.c_int64 * 3), ("pack_a_off", ctypes.c_int64 * 2), ("pack_b_off", ctypes.c_int64 * 2),
+                ("next_a_off", ctypes.c_int64), ("next_b_off", ctypes.c_int64)]
 
 
 class DevInfo(ctypes.Structure):
@@ -180,6 +194,10 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_probe_int_alu.argtypes = [_i, _i, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), _vp]
     lib.bnn_hip_probe_clock.argtypes = [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _vp]
+    lib.bnn_hip_hblock_supported.argtypes = [ctypes.POINTER(HBlockDesc)]
+    lib.bnn_hip_hblock_layout_of.argtypes = [_i, _i, ctypes.POINTER(HBlockLayout)]
+    lib.bnn_hip_hblock_pack_weights.argtypes = [_i, _i, _vp, _vp, _vp, _vp, _vp]
+    lib.bnn_hip_hblock_forward.argtypes = [ctypes.POINTER(HBlockDesc)] + [_vp] * 7
 
 
 def load() -> Optional[ctypes.CDLL]:

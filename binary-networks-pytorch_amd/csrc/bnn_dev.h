@@ -164,6 +164,12 @@ int launch_bconv(const ConvP& p, int flags, hipStream_t s);
 bool fly_supported(const ConvP& p);
 int fly_default_plan(const ConvP& p, int flags, bnn_hip_fly_plan* plan);
 int launch_bconv_fly(const ConvP& p, const void* x, int x_half, int flags, const bnn_hip_fly_plan* plan, hipStream_t s);
+// hblock.hip: the hierarchical block in one launch
+bool hblock_supported(const bnn_hip_hblock_desc* d);
+int hblock_layout(int C_in, int planes, bnn_hip_hblock_layout* L);
+int launch_hblock_pack_weights(int C_in, int planes, const uint32_t* const w[3], uint32_t* dst, hipStream_t s);
+int launch_hblock(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc, const float* res,
+                  float* out, uint64_t* outP, hipStream_t stream);
 // xnor_train.hip: XNORWeightBinarizer under autograd, value and backward
 int launch_xnor_grad_pack(const float* w, int O, int C, int ks, int center, int compute_alpha, void* packed, float* alpha,
                           hipStream_t s);

@@ -1,0 +1,531 @@
+// hblock.hip — the hierarchical block (bnn/models/layers/hierarchical_block.py:38-60) in ONE launch.
+//
+//     o1 = conv1(sign(act1(bn1(x))))     3x3, C_in -> C/2
+//     o2 = conv2(sign(act2(bn2(o1))))    3x3, C/2  -> C/4
+//     o3 = conv3(sign(act3(bn3(o2))))    3x3, C/4  -> C/4
+//     y  = cat(o1, o2, o3) + shortcut(x)
+//
+// Launch by launch (bconv_sgpr_kernel x 3 + a packing pass in front) this block is 4 launches of 13-27 us for 16 us of
+// integer-ALU work at batch 128 (profiles/r06_c5_kernel_roofline_before.md): the widths are small (O = 16 .. 256), the
+// intermediate sign planes travel through HBM, C/2 and C/4 input channels below 64 are padded to 64-channel groups and
+// every launch pays its own ramp and tail.  Here a workgroup owns a REGION — whole images, or a band of rows of one
+// image with its halo — and runs the three convolutions back to back with every sign plane in LDS:
+//
+//   phase 0   the block's input planes (sign(act1(bn1(x))), P plane: activations out of a ReLU) HBM -> LDS, band + 3 halo rows
+//   phase 1   conv1 on band + 2 halo rows: fp32 y[:, 0:C/2] = o1 + shortcut (band rows only);  sign(act2(bn2(o1))) -> LDS
+//   phase 2   conv2 on band + 1 halo row:  fp32 y[:, C/2:3C/4];                                sign(act3(bn3(o2))) -> LDS
+//   phase 3   conv3 on the band:           fp32 y[:, 3C/4:C]
+//   every phase also leaves sign(act1'(bn1'(y))) of its channels — the NEXT block's input planes — in LDS;
+//   phase 4   copies them out (coalesced 8-byte stores).
+//
+// The inner loop is the one of bconv_sgpr_kernel: lane = output pixel, the pixel's receptive field for one chunk of
+// input channels in VGPRs (read from LDS), weights wave-uniform through the scalar cache into SGPRs, v_and_b32 +
+// v_bcnt_u32_b32 (bconv_core.h: stream_weights).  Planes are dense: a cell holds ceil(C_in / 32) words (C_in = 16 / 32:
+// ONE word per tap, not two), and a convolution of 16 output channels runs 16 channels, not a padded block of 32.
+// Same integers and the same float operations, in the same order, as the launch-by-launch form: bit-identical y and planes.
+#include <algorithm>
+#include <cstring>
+
+#include "bconv_core.h"
+
+namespace bnn {
+
+struct HbPhase {
+  int O;              // output channels
+  int nchunk;         // chunks of CWC words of its input cell
+  int halo;           // rows of its output domain beyond the band on each side (2, 1, 0)
+  int c_off;          // first channel of its slice of the block's output
+  int ppu;            // passes per unit (one load of the field)
+  int npass, upg;     // passes (O / NACC), units per pixel group
+  unsigned w_off;     // words: its weights in W, [pass][chunk][j][tap][CWC]
+  unsigned a_off, pa_off, pb_off;  // floats: alpha / the next phase's BatchNorm in the constants
+  unsigned lds_in;    // byte offset of its input plane, [chunk][cell][CWC]
+  int rows_in;        // rows of that plane's slab per image: band rows + 2 * (halo + 1)
+  int ncell_in;       // cells of the slab: G * rows_in * WP
+  uint32_t m_upg;
+  int s_upg;
+};
+
+struct HbGeo {
+  int N, H, W, C;     // images, image size, block width
+  int G, BR, nbi;     // images per region | rows per band, bands per image
+  int WP;             // row pitch of the slabs in cells: W + 2
+  int ng_in, cw_in;   // 64-channel groups / 32-bit words per pixel of the block's input planes
+  HbPhase ph[3];
+  unsigned lds_out;   // next block's planes: [group][cell][2 words], cell = (image, band row, column)
+  int ncell_out;
+  unsigned lds16;     // LDS bytes / 16
+  unsigned na_off, nb_off;  // floats: the next block's bn1
+  uint32_t m_hw, m_w;
+  int s_hw, s_w;
+  unsigned f32_bytes;  // bytes of the fp32 tensors (residual, out): the range of their descriptors
+};
+
+namespace {
+
+extern __shared__ __attribute__((aligned(16))) unsigned char hb_smem[];
+
+__device__ __forceinline__ uint32_t hb_uniform(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_readfirstlane(v);
+#else
+  return v;
+#endif
+}
+
+__device__ __forceinline__ uint32_t hb_ticket(uint32_t* ctr, int lane) {
+  uint32_t t = 0;
+  if (lane == 0) t = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return hb_uniform(t);
+}
+
+template <int N>
+__device__ __forceinline__ void hb_lds_words(const uint32_t* base, unsigned word_off, uint32_t* dst) {
+  if constexpr (N == 4) {
+    const uint4 v = *reinterpret_cast<const uint4*>(base + word_off);
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+  } else if constexpr (N == 2) {
+    const uint2 v = *reinterpret_cast<const uint2*>(base + word_off);
+    dst[0] = v.x; dst[1] = v.y;
+  } else {
+    dst[0] = base[word_off];
+  }
+}
+
+constexpr unsigned kOob = 0xFFFFFFF0u;  // a byte offset beyond every descriptor: loads return 0, stores are dropped
+
+// One convolution of the block on the region's planes.
+//   CWC / MULTI: words per (chunk, cell) of its input plane; several chunks
+//   K: 0, 1, 2;  CWCN: CWC of the next phase (layout of the plane this one writes; unused for K == 2)
+//   NEXT: the next block's input planes are wanted (sign(act(bn1'(y)))
+template <int CWC, bool MULTI, int K, int CWCN, bool NEXT>
+__device__ __forceinline__ void hb_phase(const uint32_t* __restrict__ Wt, const float* __restrict__ Kc,
+                                         const float* __restrict__ res, float* __restrict__ out, const HbGeo& g,
+                                         unsigned char* smem, int n0, int kk, int y0, int rows, int lane) {
+  constexpr int NW = 9 * CWC;
+  constexpr int NACC = CWC == 1 ? 16 : 8;  // channels per pass: weight runs of NACC * NW words are whole 64-byte lines
+  constexpr int PPU = 32 / NACC;           // passes per unit at most
+  constexpr bool LAST = K == 2;
+  using f2 = __attribute__((ext_vector_type(2))) float;
+  const HbPhase& ph = g.ph[K];
+  const int ra = max(0, y0 - ph.halo), rb = min(g.H, y0 + rows + ph.halo);
+  const int nrows = rb - ra;  // (kk > 1: whole images, nrows == H)
+  const int npix = kk * nrows * g.W;
+  const int npg = (npix + 63) >> 6;
+  const int nunits = npg * ph.upg;
+  const int hw = g.H * g.W;
+  uint32_t* ctl = reinterpret_cast<uint32_t*>(smem);
+  const uint32_t* pin = reinterpret_cast<const uint32_t*>(smem + ph.lds_in);
+  const BufRsrc rres = make_rsrc_sized(res, g.f32_bytes), rout = make_rsrc_sized(out, g.f32_bytes);
+  for (;;) {
+    const uint32_t u = hb_ticket(&ctl[K], lane);
+    if (u >= (uint32_t)nunits) break;
+    const int pg = (int)fast_div(u, ph.m_upg, ph.s_upg);
+    const int p0 = ((int)u - pg * ph.upg) * ph.ppu;
+    const int np = min(ph.ppu, ph.npass - p0);
+    // the lane's pixel (lanes past the domain's last pixel copy it: same values to the same places)
+    const int j = min((pg << 6) + lane, npix - 1);
+    int img = 0, rem = j;
+    if (kk > 1) {
+      img = (int)fast_div((uint32_t)j, g.m_hw, g.s_hw);
+      rem = j - imul<true>(img, hw);
+    }
+    const int rowl = (int)fast_div((uint32_t)rem, g.m_w, g.s_w);
+    const int col = rem - imul<true>(rowl, g.W);
+    const int row = ra + rowl;
+    const bool interior = row >= y0 && row < y0 + rows;  // a band row: its fp32 values and next-block bits are this region's
+    const unsigned lane_off =
+        interior ? (unsigned)(imul<true>(imul<true>(n0 + img, g.C), hw) + imul<true>(row, g.W) + col) * 4u : kOob;
+    // top-left tap of the receptive field in the phase's input slab (slab row 0 = image row y0 - halo - 1, column 0 = -1)
+    const unsigned cell0 = (unsigned)(imul<true>(imul<true>(img, ph.rows_in) + (row - y0 + ph.halo), g.WP) + col);
+    uint32_t pr[NW], mr[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) mr[i] = 0u;
+    int nz = 0;
+    if constexpr (!MULTI) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        hb_lds_words<CWC>(pin, (cell0 + (unsigned)((t / 3) * g.WP + (t % 3))) * CWC, &pr[t * CWC]);
+      nz = count_nonzero<NW, true>(pr, mr, 0);
+    }
+    // the unit's shortcut values, all requested up front (loads before stores in the wave's vmcnt order: bconv.hip, RES_ALL)
+    float resq[PPU * NACC];
+#pragma unroll
+    for (int i = 0; i < PPU * NACC; ++i) {
+      const int c = ph.c_off + p0 * NACC + i;
+      resq[i] = buf_ld(rres, (i / NACC) < np ? lane_off : kOob, (unsigned)c * (unsigned)hw * 4u);
+    }
+#pragma unroll 1
+    for (int ps = 0; ps < np; ++ps) {
+      const int o0 = (p0 + ps) * NACC;
+      int acc[NACC];
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = (int)kCountSeed;
+      const uint32_t* wrun = Wt + ph.w_off + (size_t)(p0 + ps) * ph.nchunk * (NACC * NW);
+      if constexpr (MULTI) {
+        for (int ch = 0; ch < ph.nchunk; ++ch) {
+          const unsigned cbase = (unsigned)(ch * ph.ncell_in) + cell0;
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+            hb_lds_words<CWC>(pin, (cbase + (unsigned)((t / 3) * g.WP + (t % 3))) * CWC, &pr[t * CWC]);
+          if (ps == 0) nz = count_nonzero<NW, true>(pr, mr, nz);
+          stream_weights<NW, NACC, true, false, false>(wrun + (size_t)ch * (NACC * NW), pr, mr, acc);
+        }
+      } else {
+        stream_weights<NW, NACC, true, true, false>(wrun, pr, mr, acc, (int)kCountSeed);
+      }
+      // epilogue: the float operations of bconv_core.h epilogue<EP_HB> (alpha, late residual, next BatchNorm in front of
+      // the sign) and of pack_act.hip's bn_act_pack (the next block's bn1 on y), two channels per packed instruction
+      const f2 dscale = {2.0f, 2.0f}, doff = {-(float)nz, -(float)nz};
+      [[maybe_unused]] float pvi[NACC];
+      [[maybe_unused]] float pvn[NACC];
+#pragma unroll
+      for (int i = 0; i < NACC; i += 2) {
+        const int o = o0 + i, co = ph.c_off + o;
+        const f2 cnt = f2{__int_as_float(acc[i]), __int_as_float(acc[i + 1])} - f2{8388608.0f, 8388608.0f};
+        const f2 dot = __builtin_elementwise_fma(cnt, dscale, doff);
+        const f2 ov = __builtin_elementwise_fma(f2{Kc[ph.a_off + o], Kc[ph.a_off + o + 1]}, dot, f2{0.0f, 0.0f});
+        if constexpr (!LAST) {
+          const f2 v = __builtin_elementwise_fma(ov, f2{Kc[ph.pa_off + o], Kc[ph.pa_off + o + 1]},
+                                                 f2{Kc[ph.pb_off + o], Kc[ph.pb_off + o + 1]});
+          pvi[i] = v.x;
+          pvi[i + 1] = v.y;
+        }
+        const f2 y = ov + f2{resq[i], resq[i + 1]};
+        buf_st(rout, lane_off, (unsigned)co * (unsigned)hw * 4u, y.x);
+        buf_st(rout, lane_off, (unsigned)(co + 1) * (unsigned)hw * 4u, y.y);
+        if constexpr (NEXT) {
+          const f2 v = __builtin_elementwise_fma(y, f2{Kc[g.na_off + co], Kc[g.na_off + co + 1]},
+                                                 f2{Kc[g.nb_off + co], Kc[g.nb_off + co + 1]});
+          pvn[i] = v.x;
+          pvn[i + 1] = v.y;
+        }
+      }
+      // the rest of the shortcut queue moves up (registers cannot be indexed by the pass number)
+#pragma unroll
+      for (int i = 0; i + NACC < PPU * NACC; ++i) resq[i] = resq[i + NACC];
+      if constexpr (!LAST) {
+        uint32_t bits = 0u;
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) bits = shift_in(bits, is_pos(pvi[i]));
+        bits = __builtin_bitreverse32(bits) >> (32 - NACC);  // channel o0 + i in bit i
+        const HbPhase& pn = g.ph[K < 2 ? K + 1 : 2];
+        const unsigned celln = (unsigned)(imul<true>(imul<true>(img, pn.rows_in) + (row - y0 + pn.halo + 1), g.WP) + col + 1);
+        const int wq = o0 >> 5;
+        const unsigned widx = ((unsigned)((wq / CWCN) * pn.ncell_in) + celln) * CWCN + (unsigned)(wq % CWCN);
+        unsigned char* dst = smem + pn.lds_in + widx * 4u + (unsigned)((o0 & 31) >> 3);
+        if constexpr (NACC == 16) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)bits;
+        else *dst = (uint8_t)bits;
+      }
+      if constexpr (NEXT) {
+        uint32_t bits = 0u;
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) bits = shift_in(bits, is_pos(pvn[i]));
+        bits = __builtin_bitreverse32(bits) >> (32 - NACC);
+        if (interior) {
+          const int co0 = ph.c_off + o0;
+          const unsigned cello = (unsigned)(imul<true>(imul<true>(img, g.BR) + (row - y0), g.W) + col);
+          const unsigned widx = ((unsigned)((co0 >> 6) * g.ncell_out) + cello) * 2u + (unsigned)((co0 & 63) >> 5);
+          unsigned char* dst = smem + g.lds_out + widx * 4u + (unsigned)((co0 & 31) >> 3);
+          if constexpr (NACC == 16) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)bits;
+          else *dst = (uint8_t)bits;
+        }
+      }
+    }
+  }
+}
+
+template <int CWC1, bool M1, int CWC2, bool M2, int CWC3, bool M3, bool NEXT>
+__global__ __launch_bounds__(1024) void hblock_kernel(const uint64_t* __restrict__ inP, const uint32_t* __restrict__ Wt,
+                                                      const float* __restrict__ Kc, const float* __restrict__ res,
+                                                      float* __restrict__ out, uint64_t* __restrict__ outP,
+                                                      const HbGeo g) {
+  unsigned char* smem = hb_smem;
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  const int bi = g.nbi > 1 ? (int)blockIdx.x / g.nbi : (int)blockIdx.x;
+  const int bj = (int)blockIdx.x - bi * g.nbi;
+  const int n0 = bi * g.G, kk = min(g.G, g.N - n0);
+  const int y0 = bj * g.BR, rows = min(g.BR, g.H - y0);
+  const int hw = g.H * g.W;
+  {  // zero: tickets, padding cells, halo rows outside the image
+    uint4* z = reinterpret_cast<uint4*>(smem);
+    const uint4 zero = {0u, 0u, 0u, 0u};
+    for (unsigned i = tid; i < g.lds16; i += nthr) z[i] = zero;
+  }
+  __syncthreads();
+  {  // phase 0: the block's input planes, band + 3 halo rows (rows of the image only)
+    const HbPhase& p1 = g.ph[0];
+    const int ra = max(0, y0 - 3), rb = min(g.H, y0 + rows + 3);
+    const int per_img = (rb - ra) * g.W, per_grp = kk * per_img, total = g.ng_in * per_grp;
+    uint32_t* pl = reinterpret_cast<uint32_t*>(smem + p1.lds_in);
+    for (int i = tid; i < total; i += nthr) {
+      const int gq = i / per_grp, r1 = i - gq * per_grp;
+      const int img = r1 / per_img, r2 = r1 - img * per_img;
+      const int rowl = r2 / g.W, col = r2 - rowl * g.W;
+      const int row = ra + rowl;
+      const uint64_t v = inP[((size_t)(n0 + img) * g.ng_in + gq) * hw + (size_t)row * g.W + col];
+      const unsigned cell = (unsigned)((img * p1.rows_in + (row - y0 + 3)) * g.WP + col + 1);
+      const int w0 = 2 * gq;
+      if constexpr (CWC1 == 1) {
+        pl[cell] = (uint32_t)v;
+      } else {
+        const unsigned widx = ((unsigned)((w0 / CWC1) * p1.ncell_in) + cell) * CWC1 + (unsigned)(w0 % CWC1);
+        *reinterpret_cast<uint2*>(pl + widx) = uint2{(uint32_t)v, (uint32_t)(v >> 32)};
+      }
+    }
+  }
+  __syncthreads();
+  hb_phase<CWC1, M1, 0, CWC2, NEXT>(Wt, Kc, res, out, g, smem, n0, kk, y0, rows, lane);
+  __syncthreads();
+  hb_phase<CWC2, M2, 1, CWC3, NEXT>(Wt, Kc, res, out, g, smem, n0, kk, y0, rows, lane);
+  __syncthreads();
+  hb_phase<CWC3, M3, 2, 1, NEXT>(Wt, Kc, res, out, g, smem, n0, kk, y0, rows, lane);
+  if constexpr (NEXT) {
+    __syncthreads();
+    const int ngo = g.C >> 6;
+    const int per_img = rows * g.W, per_grp = kk * per_img, total = ngo * per_grp;
+    const uint2* po = reinterpret_cast<const uint2*>(smem + g.lds_out);
+    for (int i = tid; i < total; i += nthr) {
+      const int gq = i / per_grp, r1 = i - gq * per_grp;
+      const int img = r1 / per_img, r2 = r1 - img * per_img;
+      const uint2 v = po[(unsigned)(gq * g.ncell_out + img * (g.BR * g.W) + r2)];
+      outP[((size_t)(n0 + img) * ngo + gq) * hw + (size_t)y0 * g.W + r2] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    }
+  }
+}
+
+// standard packed weights (bnn_hip_pack_weight_f32: wbits[ob][chunk][j][tap][cwc], 64-channel granularity) -> the dense
+// layout of one phase, [pass][chunk][j < NACC][tap][CWC]
+__global__ __launch_bounds__(256) void hblock_pack_weight_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                                 int O, int cw, int cwc, int nacc, int cw_s, int cwc_s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= O * 9 * cw) return;
+  const int cwi = i % cw, tap = (i / cw) % 9, o = i / (9 * cw);
+  const int ob = o >> 5, j = o & 31, nchunk_s = cw_s / cwc_s;
+  const uint32_t v = src[((size_t)(ob * nchunk_s + cwi / cwc_s) * 32 + j) * 9 * cwc_s + tap * cwc_s + cwi % cwc_s];
+  const int nchunk = cw / cwc;
+  dst[((size_t)((o / nacc) * nchunk + cwi / cwc) * nacc + o % nacc) * 9 * cwc + tap * cwc + cwi % cwc] = v;
+}
+
+constexpr int kHbLdsBudget = 160 * 1024;
+
+struct HbShape {
+  int cin[3], O[3], cw[3], cwc[3], nchunk[3], nacc[3];
+};
+
+bool hb_shape(int C_in, int planes, HbShape& s) {
+  if (C_in <= 0 || planes < 64 || planes % 64 != 0 || planes > 4096) return false;
+  s.cin[0] = C_in; s.cin[1] = planes / 2; s.cin[2] = planes / 4;
+  s.O[0] = planes / 2; s.O[1] = planes / 4; s.O[2] = planes / 4;
+  for (int k = 0; k < 3; ++k) {
+    s.cw[k] = (s.cin[k] + 31) / 32;
+    if (s.cw[k] <= 4) {
+      if (s.cw[k] == 3) return false;
+      s.cwc[k] = s.cw[k];
+    } else {
+      if (s.cw[k] % 4) return false;
+      s.cwc[k] = 4;
+    }
+    s.nchunk[k] = s.cw[k] / s.cwc[k];
+    s.nacc[k] = s.cwc[k] == 1 ? 16 : 8;
+    if (s.O[k] % s.nacc[k]) return false;
+  }
+  // the block's input planes arrive as whole 64-channel groups; a one-word cell takes the low half of group 0
+  if (s.cw[0] == 1 ? C_in > 32 : (s.cw[0] % 2 != 0)) return false;
+  return true;
+}
+
+}  // namespace
+
+int hblock_layout(int C_in, int planes, bnn_hip_hblock_layout* L) {
+  HbShape s;
+  if (!hb_shape(C_in, planes, s)) return BNN_HIP_ERR_UNSUPPORTED;
+  long long w = 0;
+  for (int k = 0; k < 3; ++k) {
+    L->w_off[k] = w;
+    w += (long long)s.O[k] * 9 * s.cw[k];
+  }
+  L->weight_words = w;
+  long long f = 0;
+  for (int k = 0; k < 3; ++k) { L->alpha_off[k] = f; f += s.O[k]; }
+  for (int k = 0; k < 2; ++k) { L->pack_a_off[k] = f; f += s.O[k]; L->pack_b_off[k] = f; f += s.O[k]; }
+  L->next_a_off = f; f += planes;
+  L->next_b_off = f; f += planes;
+  L->const_floats = f;
+  return BNN_HIP_OK;
+}
+
+int launch_hblock_pack_weights(int C_in, int planes, const uint32_t* const w[3], uint32_t* dst, hipStream_t s) {
+  HbShape sh;
+  bnn_hip_hblock_layout L;
+  if (!hb_shape(C_in, planes, sh) || hblock_layout(C_in, planes, &L) != BNN_HIP_OK) return BNN_HIP_ERR_UNSUPPORTED;
+  for (int k = 0; k < 3; ++k) {
+    const int cw_s = 2 * ((sh.cin[k] + 63) / 64), cwc_s = choose_cwc(cw_s, 3, 3);
+    const int n = sh.O[k] * 9 * sh.cw[k];
+    hipLaunchKernelGGL(hblock_pack_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w[k], dst + L.w_off[k],
+                       sh.O[k], sh.cw[k], sh.cwc[k], sh.nacc[k], cw_s, cwc_s);
+  }
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+namespace {
+
+// LDS bytes of a region of G images x BR band rows, and the offsets of its pieces.
+long long hb_lds(const HbShape& s, int W, int planes, int G, int BR, bool next, HbGeo* g) {
+  long long off = 16;  // tickets
+  for (int k = 0; k < 3; ++k) {
+    const int rows_in = BR + 2 * (3 - k);
+    const long long ncell = (long long)G * rows_in * (W + 2);
+    if (g) {
+      g->ph[k].lds_in = (unsigned)off;
+      g->ph[k].rows_in = rows_in;
+      g->ph[k].ncell_in = (int)ncell;
+    }
+    off += (ncell * s.cw[k] * 4 + 15) / 16 * 16;
+  }
+  const long long ncell_out = (long long)G * BR * W;
+  if (g) {
+    g->lds_out = (unsigned)off;
+    g->ncell_out = (int)ncell_out;
+  }
+  if (next) off += ((long long)(planes / 64) * ncell_out * 8 + 15) / 16 * 16;
+  return off;
+}
+
+template <class K>
+int hb_launch(K kernel, const HbGeo& g, int nblocks, int waves, const uint64_t* inP, const uint32_t* W, const float* Kc,
+              const float* res, float* out, uint64_t* outP, hipStream_t s) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          kMaxDynamicLds) != hipSuccess)
+    return BNN_HIP_ERR_LAUNCH;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3((unsigned)waves * kWave), (size_t)g.lds16 * 16, s, inP, W, Kc,
+                     res, out, outP, g);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
+}  // namespace
+
+// The region plan: rows per band / images per region / waves.  Whole images when there are enough of them to fill the
+// chip (or other work shares it: BNN_HIP_FLAG_THROUGHPUT); else bands of rows — each band recomputes 2 halo rows of
+// conv1 and 1 of conv2 on each side, so the split is taken only where the idle compute units cost more.
+int hblock_plan(const bnn_hip_hblock_desc* d, int* G_out, int* BR_out, int* waves_out) {
+  HbShape s;
+  if (!hb_shape(d->C_in, d->planes, s)) return BNN_HIP_ERR_UNSUPPORTED;
+  const int ncu = current_device_cus();
+  const bool shared = (d->flags & BNN_HIP_FLAG_THROUGHPUT) != 0;
+  int G = 1, BR = d->H;
+  if (d->rows_per_band > 0 || d->images_per_band > 0) {
+    G = d->images_per_band > 0 ? std::min(d->images_per_band, d->N) : 1;
+    BR = d->rows_per_band > 0 ? std::min(d->rows_per_band, d->H) : d->H;
+    if (G > 1 && BR != d->H) return BNN_HIP_ERR_INVALID_ARG;
+  } else {
+    const double w1 = (double)s.cin[0] * s.O[0], w2 = (double)s.cin[1] * s.O[1], w3 = (double)s.cin[2] * s.O[2];
+    const int slots = shared ? std::max(1, ncu / 2) : ncu;
+    double best = 0;
+    int best_nbi = 0;
+    for (int nbi = 1; nbi <= 4 && nbi <= d->H; ++nbi) {
+      const int br = (d->H + nbi - 1) / nbi;
+      if (nbi > 1 && br < 4) break;
+      if (hb_lds(s, d->W, d->planes, 1, br, true, nullptr) > kHbLdsBudget) continue;
+      const long long rounds = ((long long)d->N * nbi + slots - 1) / slots;
+      const double work = w1 * std::min(d->H, br + 4) + w2 * std::min(d->H, br + 2) + w3 * br;
+      const double cost = rounds * work;
+      if (best_nbi == 0 || cost < best * 0.97) { best = cost; best_nbi = nbi; }
+    }
+    if (best_nbi == 0) return BNN_HIP_ERR_UNSUPPORTED;
+    BR = (d->H + best_nbi - 1) / best_nbi;
+    if (best_nbi == 1) {  // small images, many of them: several per region (fewer idle lanes in the last pixel group)
+      while (G * 2 <= d->N && (long long)d->H * d->W * G * 2 <= 64 * 64 && d->N / (G * 2) >= 2 * ncu &&
+             hb_lds(s, d->W, d->planes, G * 2, BR, true, nullptr) <= kHbLdsBudget / 2)
+        G *= 2;
+    }
+  }
+  if (hb_lds(s, d->W, d->planes, G, BR, true, nullptr) > kHbLdsBudget) return BNN_HIP_ERR_UNSUPPORTED;
+  int waves = d->waves > 0 ? d->waves : 16;
+  if (waves > 16) return BNN_HIP_ERR_INVALID_ARG;
+  *G_out = G;
+  *BR_out = BR;
+  *waves_out = waves;
+  return BNN_HIP_OK;
+}
+
+int launch_hblock(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc,
+                  const float* res, float* out, uint64_t* outP, hipStream_t stream) {
+  HbShape s;
+  bnn_hip_hblock_layout L;
+  if (!hb_shape(d->C_in, d->planes, s) || hblock_layout(d->C_in, d->planes, &L) != BNN_HIP_OK) return BNN_HIP_ERR_UNSUPPORTED;
+  int G, BR, waves;
+  const int st = hblock_plan(d, &G, &BR, &waves);
+  if (st != BNN_HIP_OK) return st;
+  HbGeo g;
+  std::memset(&g, 0, sizeof(g));
+  g.N = d->N; g.H = d->H; g.W = d->W; g.C = d->planes;
+  g.G = G; g.BR = BR; g.nbi = (d->H + BR - 1) / BR;
+  g.WP = d->W + 2;
+  g.ng_in = (d->C_in + 63) / 64;
+  g.cw_in = s.cw[0];
+  const bool next = outP != nullptr;
+  g.lds16 = (unsigned)((hb_lds(s, d->W, d->planes, G, BR, next, &g) + 15) / 16);
+  int c_off = 0;
+  for (int k = 0; k < 3; ++k) {
+    HbPhase& p = g.ph[k];
+    p.O = s.O[k];
+    p.nchunk = s.nchunk[k];
+    p.halo = 2 - k;
+    p.c_off = c_off;
+    c_off += s.O[k];
+    p.npass = s.O[k] / s.nacc[k];
+    // passes per unit: as many as keep every wave of the workgroup busy at least twice per phase
+    const int rows_dom = std::min(d->H, BR + 2 * p.halo);
+    const int npg = (G * rows_dom * d->W + 63) / 64;
+    int ppu = 32 / s.nacc[k];
+    while (ppu > 1 && (ppu > p.npass || npg * ((p.npass + ppu - 1) / ppu) < 2 * waves)) ppu >>= 1;
+    p.ppu = ppu;
+    p.upg = (p.npass + ppu - 1) / ppu;
+    div_magic((uint32_t)p.upg, p.m_upg, p.s_upg);
+    p.w_off = (unsigned)L.w_off[k];
+    p.a_off = (unsigned)L.alpha_off[k];
+    p.pa_off = k < 2 ? (unsigned)L.pack_a_off[k] : 0u;
+    p.pb_off = k < 2 ? (unsigned)L.pack_b_off[k] : 0u;
+  }
+  g.na_off = (unsigned)L.next_a_off;
+  g.nb_off = (unsigned)L.next_b_off;
+  div_magic((uint32_t)(d->H * d->W), g.m_hw, g.s_hw);
+  div_magic((uint32_t)d->W, g.m_w, g.s_w);
+  g.f32_bytes = (unsigned)((long long)d->N * d->planes * d->H * d->W * 4);
+  const int nblocks = ((d->N + G - 1) / G) * g.nbi;
+
+#define HB_PICK(C1, M1_, C2, M2_, C3, M3_)                                                                              \
+  if (s.cwc[0] == C1 && (s.nchunk[0] > 1) == M1_ && s.cwc[1] == C2 && (s.nchunk[1] > 1) == M2_ && s.cwc[2] == C3 &&    \
+      (s.nchunk[2] > 1) == M3_) {                                                                                       \
+    if (next)                                                                                                           \
+      return hb_launch(hblock_kernel<C1, M1_, C2, M2_, C3, M3_, true>, g, nblocks, waves, inP, W, Kc, res, out, outP,   \
+                       stream);                                                                                         \
+    return hb_launch(hblock_kernel<C1, M1_, C2, M2_, C3, M3_, false>, g, nblocks, waves, inP, W, Kc, res, out, outP,    \
+                     stream);                                                                                           \
+  }
+  HB_PICK(2, false, 1, false, 1, false)   // 64 -> 64:   64 -> 32 -> 16 -> 16
+  HB_PICK(2, false, 2, false, 1, false)   // 64 -> 128:  64 -> 64 -> 32 -> 32
+  HB_PICK(4, false, 2, false, 1, false)   // 128 -> 128
+  HB_PICK(4, false, 4, false, 2, false)   // 128 -> 256
+  HB_PICK(4, true, 4, false, 2, false)    // 256 -> 256
+  HB_PICK(4, true, 4, true, 4, false)     // 256 -> 512 and 512 -> 512
+#undef HB_PICK
+  return BNN_HIP_ERR_UNSUPPORTED;
+}
+
+bool hblock_supported(const bnn_hip_hblock_desc* d) {
+  HbShape s;
+  if (!hb_shape(d->C_in, d->planes, s)) return false;
+  int G, BR, waves;
+  if (hblock_plan(d, &G, &BR, &waves) != BNN_HIP_OK) return false;
+  const bool m[3] = {s.nchunk[0] > 1, s.nchunk[1] > 1, s.nchunk[2] > 1};
+  const int c[3] = {s.cwc[0], s.cwc[1], s.cwc[2]};
+  auto is = [&](int c1, bool m1, int c2, bool m2, int c3, bool m3) {
+    return c[0] == c1 && m[0] == m1 && c[1] == c2 && m[1] == m2 && c[2] == c3 && m[2] == m3;
+  };
+  return is(2, false, 1, false, 1, false) || is(2, false, 2, false, 1, false) || is(4, false, 2, false, 1, false) ||
+         is(4, false, 4, false, 2, false) || is(4, true, 4, false, 2, false) || is(4, true, 4, true, 4, false);
+}
+
+}  // namespace bnn

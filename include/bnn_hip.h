@@ -61,7 +61,8 @@
 extern "C" {
 #endif
 
-/* ABI 14 (round 5): + bnn_hip_stem7x7_wgrad_f32 / bnn_hip_stem7x7_wgrad_workspace_bytes (weight gradient of the stem
+/* ABI 15 (round 6): + bnn_hip_hblock_{supported,layout_of,pack_weights,forward} (the hierarchical block in one launch).
+ * ABI 14 (round 5): + bnn_hip_stem7x7_wgrad_f32 / bnn_hip_stem7x7_wgrad_workspace_bytes (weight gradient of the stem
  * convolution: the training backward of that layer); + bnn_hip_avgpool2x2_backward_f32, bnn_hip_xnor_grad_pack_weight_f32; + bnn_hip_avgpool_fc_ws_f32 / bnn_hip_avgpool_fc_workspace_bytes (the head as two streaming launches
  * through a workspace); + bnn_hip_stem7x7_conv_f32 (the stem's convolution alone: the training forward); the table of bnn_hip_sign_thresholds_f32 holds FOUR words per channel (was two) and kmax < 2^20.
  * ABI 13 (round 4): + bnn_hip_bn_act_f32 (eval-mode BatchNorm + residual + ReLU tail of the per-layer path);
@@ -71,7 +72,7 @@ extern "C" {
  * bnn_hip_bn_relu_maxpool_train_{forward,backward}_f32, bnn_hip_xnor_weight_{forward,backward}_f32;
  * - BNN_HIP_STEM_STAGED and BNN_HIP_FLAG_WEIGHTS_LDS (those kernels are test-only now: csrc/legacy/);
  * stem tensors capped at the 32-bit buffer-descriptor range; size arithmetic of all validators saturating.          */
-#define BNN_HIP_ABI_VERSION 14
+#define BNN_HIP_ABI_VERSION 15
 #define BNN_HIP_OCB 32 /* output channels per weight block (padding granularity of O) */
 
 typedef enum bnn_hip_status {
@@ -463,6 +464,49 @@ int bnn_hip_bconv2d_direct(const bnn_hip_conv_desc* d, const void* x, int x_dtyp
                            const uint32_t* wbits, const uint32_t* wnz,
                            const float* alpha, const float* bias, const float* post_scale,
                            float* out, const bnn_hip_fly_plan* plan, void* stream);
+
+/* ---- The hierarchical block in one launch (ABI 15): bnn.models.layers.HBlock.forward
+ * (bnn/models/layers/hierarchical_block.py:38-60) behind its first BatchNorm + activation:
+ *     o1 = conv1(sign(act1(bn1(x))));  o2 = conv2(sign(act2(bn2(o1))));  o3 = conv3(sign(act3(bn3(o2))))
+ *     y  = cat(o1, o2, o3) + residual
+ * three 3x3 / stride 1 / padding 1 binary convolutions (C_in -> C/2 -> C/4 -> C/4, C = `planes`) with ReLU
+ * activations: every sign plane between them is non-negative (P plane only) and stays in LDS; a workgroup owns whole
+ * images or a band of rows of one image with its halo (csrc/hblock.hip).  Bit-identical to three bnn_hip_bconv2d_fused
+ * launches with BNN_HIP_EPI_RES_AFTER_ACT | PACK_BEFORE_RES | PACK_RELU.
+ *   in_P:     the block's input planes, sign(act1(bn1(x))): [N, ceil(C_in/64), H, W] uint64, P plane (bnn_hip_bn_act_pack_f32
+ *             with relu = 1, or the out_P of the previous block's launch)
+ *   weights:  bnn_hip_hblock_pack_weights() of the three standard weight packs (no zero weights; bias-free convolutions)
+ *   consts:   fp32, offsets from bnn_hip_hblock_layout_of(): alpha of conv1 / conv2 / conv3 | folded bn2 scale, shift |
+ *             folded bn3 scale, shift | the NEXT block's folded bn1 scale, shift over all C channels (read only when out_P != NULL)
+ *   residual: fp32 [N, C, H, W] (the block input, or its shortcut branch);  out: fp32 [N, C, H, W], must not alias residual
+ *   out_P:    NULL, or [N, C/64, H, W] uint64: sign(relu(fmaf(y, next_a, next_b))) — the next block's in_P
+ * planes % 64 == 0; C_in <= 32 or C_in % 64 == 0; N * planes < 2^23; N * planes * H * W < 2^30.                     */
+typedef struct bnn_hip_hblock_desc {
+  int32_t N, C_in, H, W;
+  int32_t planes;
+  int32_t flags;            /* BNN_HIP_FLAG_THROUGHPUT: other work shares the GPU — whole-image regions preferred     */
+  int32_t rows_per_band;    /* 0 = the planner's choice; else rows of one image per workgroup                         */
+  int32_t images_per_band;  /* 0 = the planner's choice; > 1 only with rows_per_band == 0 or H                         */
+  int32_t waves;            /* 0 = 16; wavefronts per workgroup, 1..16                                                */
+  int32_t reserved;
+} bnn_hip_hblock_desc;
+typedef struct bnn_hip_hblock_layout {
+  int64_t weight_words;     /* uint32 words of the weight buffer (64-byte aligned)                                    */
+  int64_t w_off[3];         /* word offset of conv1 / conv2 / conv3 in it                                             */
+  int64_t const_floats;     /* floats of the constants buffer                                                         */
+  int64_t alpha_off[3];     /* float offsets: alpha[O_k] of conv k                                                    */
+  int64_t pack_a_off[2], pack_b_off[2];  /* folded bn2 (C/2 values each) and bn3 (C/4)                                */
+  int64_t next_a_off, next_b_off;        /* the next block's folded bn1 (C values each)                               */
+} bnn_hip_hblock_layout;
+/* HOST: 1 when bnn_hip_hblock_forward covers this geometry on the current device, else 0. */
+int bnn_hip_hblock_supported(const bnn_hip_hblock_desc* d);
+/* HOST: buffer sizes and offsets for a block of this shape. */
+int bnn_hip_hblock_layout_of(int C_in, int planes, bnn_hip_hblock_layout* out);
+/* wbits1..3: bnn_hip_pack_weight_f32 packs of [C/2, C_in, 3, 3], [C/4, C/2, 3, 3], [C/4, C/4, 3, 3]. */
+int bnn_hip_hblock_pack_weights(int C_in, int planes, const uint32_t* wbits1, const uint32_t* wbits2,
+                                const uint32_t* wbits3, uint32_t* weights, void* stream);
+int bnn_hip_hblock_forward(const bnn_hip_hblock_desc* d, const uint64_t* in_P, const uint32_t* weights,
+                           const float* consts, const float* residual, float* out, uint64_t* out_P, void* stream);
 
 /* fp32 NCHW in -> fp32 NCHW out.  ONE launch (bnn_hip_bconv2d_direct) wherever that path applies:
  * bnn_hip_conv_workspace_bytes(d) is then 0 and `workspace` may be NULL.  For the remaining geometries (see above)

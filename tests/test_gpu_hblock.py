@@ -1,0 +1,121 @@
+"""The hierarchical block in one launch (csrc/hblock.hip, bnn_hip_hblock_forward): bit for bit the three
+bnn_hip_bconv2d_fused launches it replaces (fp32 output AND the next block's sign planes), on every plan (whole images,
+several images per workgroup, bands of rows with their halos), and within tolerance of the reference's formulation
+(bnn/models/layers/hierarchical_block.py:38-60) out of torch float ops."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bnn_amd import hipops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _block(seed, c_in, planes, N, H, W):
+    g = torch.Generator().manual_seed(seed)
+    half, quarter = planes // 2, planes // 4
+
+    def rnd(*s, scale=1.0):
+        return (torch.randn(*s, generator=g) * scale).to(DEV)
+
+    def bn(c):
+        return (torch.rand(c, generator=g) + 0.5).to(DEV), rnd(c, scale=0.3)
+
+    ws = [rnd(half, c_in, 3, 3, scale=0.05), rnd(quarter, half, 3, 3, scale=0.05), rnd(quarter, quarter, 3, 3, scale=0.05)]
+    x = rnd(N, c_in, H, W)
+    res = rnd(N, planes, H, W)
+    return x, res, ws, bn(c_in), bn(half), bn(quarter), bn(planes)
+
+
+def _launch_by_launch(p_in, pws, bn2, bn3, nbn, res):
+    """bnn_amd/executor.py: the three slice-writing launches + the packing pass of the next block."""
+    N, _, H, W = res.shape
+    planes = res.shape[1]
+    half, quarter = planes // 2, planes // 4
+    y = torch.empty_like(res)
+    late = dict(residual=res, residual_after_act=True, pack_before_residual=True, out=y, out_f32=True, padding=1)
+    _, p = hipops.bconv2d_fused(p_in, pws[0], out_packed=True, out_c_offset=0, pack_scale=bn2[0], pack_shift=bn2[1],
+                                pack_relu=True, **late)
+    _, p = hipops.bconv2d_fused(p, pws[1], out_packed=True, out_c_offset=half, pack_scale=bn3[0], pack_shift=bn3[1],
+                                pack_relu=True, **late)
+    hipops.bconv2d_fused(p, pws[2], out_packed=False, out_c_offset=half + quarter, **late)
+    return y, hipops.bn_act_pack(y, nbn[0], nbn[1], relu=True)
+
+
+SHAPES = [  # c_in, planes, N, H, W
+    (64, 64, 3, 56, 56), (64, 128, 3, 28, 28), (128, 128, 3, 28, 28), (128, 256, 5, 14, 14), (256, 256, 5, 14, 14),
+    (256, 512, 9, 7, 7), (512, 512, 9, 7, 7),
+    (64, 64, 2, 13, 9), (128, 128, 2, 5, 7), (256, 256, 3, 3, 3), (512, 512, 2, 1, 1),
+]
+PLANS = [dict(), dict(rows_per_band=4), dict(rows_per_band=5), dict(images_per_band=2), dict(images_per_band=4),
+         dict(throughput=True), dict(waves=4), dict(rows_per_band=1)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_one_launch_equals_three_launches(shape):
+    c_in, planes, N, H, W = shape
+    x, res, ws, bn1, bn2, bn3, nbn = _block(hash(shape) % 1000, c_in, planes, N, H, W)
+    p_in = hipops.bn_act_pack(x, bn1[0], bn1[1], relu=True)
+    pws = [hipops.pack_weight(w) for w in ws]
+    want_y, want_p = _launch_by_launch(p_in, pws, bn2, bn3, nbn, res)
+    pack = hipops.hblock_pack(*pws, bn2, bn3, nbn)
+    pack_last = hipops.hblock_pack(*pws, bn2, bn3, None)
+    for plan in PLANS:
+        if plan.get("rows_per_band", 0) > H or plan.get("images_per_band", 0) > N:
+            continue
+        if not hipops.hblock_supported(N, c_in, H, W, planes, **plan):     # (several large images exceed the LDS)
+            assert plan.get("images_per_band", 0) > 1 and H * W > 1000
+            continue
+        y, p = hipops.hblock_forward(p_in, pack, res, **plan)
+        assert torch.equal(y, want_y), plan
+        assert torch.equal(p.P, want_p.P), plan
+        assert p.nonneg and not bool(p.M.any())
+        y2, p2 = hipops.hblock_forward(p_in, pack_last, res, out_packed=False, **plan)
+        assert p2 is None and torch.equal(y2, want_y), plan
+
+
+def test_against_the_float_formulation():
+    """The reference's op sequence in torch float ops (sign -> conv2d with sign(W) * alpha -> cat -> + residual)."""
+    c_in, planes, N, H, W = 128, 128, 4, 28, 28
+    x, res, ws, bn1, bn2, bn3, nbn = _block(7, c_in, planes, N, H, W)
+
+    def binconv(t, w):
+        alpha = w.abs().mean(dim=(1, 2, 3), keepdim=True)
+        return F.conv2d(torch.sign(t), torch.sign(w) * alpha, padding=1)
+
+    def bnrelu(t, bn):
+        return torch.relu(t * bn[0][None, :, None, None] + bn[1][None, :, None, None])
+
+    o1 = binconv(bnrelu(x, bn1), ws[0])
+    o2 = binconv(bnrelu(o1, bn2), ws[1])
+    o3 = binconv(bnrelu(o2, bn3), ws[2])
+    want = torch.cat((o1, o2, o3), 1) + res
+    p_in = hipops.bn_act_pack(x, bn1[0], bn1[1], relu=True)
+    pack = hipops.hblock_pack(*[hipops.pack_weight(w) for w in ws], bn2, bn3, nbn)
+    y, _ = hipops.hblock_forward(p_in, pack, res)
+    # a sign() in front of conv2 / conv3 flips where the float conv's rounding crosses zero: compare where it did not
+    close = torch.isclose(y, want, rtol=1e-3, atol=1e-4)
+    assert close.float().mean().item() > 0.999
+    assert torch.allclose(y[:, :planes // 2], want[:, :planes // 2], rtol=1e-3, atol=1e-4)   # conv1: no sign() between
+
+
+def test_argument_checks():
+    c_in, planes, N, H, W = 64, 64, 2, 8, 8
+    x, res, ws, bn1, bn2, bn3, nbn = _block(3, c_in, planes, N, H, W)
+    p_in = hipops.bn_act_pack(x, bn1[0], bn1[1], relu=True)
+    pws = [hipops.pack_weight(w) for w in ws]
+    pack = hipops.hblock_pack(*pws, bn2, bn3, None)
+    from bnn_amd import native
+    with pytest.raises(native.NativeError):
+        hipops.hblock_forward(p_in, pack, res, out_packed=True)          # no next-block constants in this pack
+    with pytest.raises(native.NativeError):
+        hipops.hblock_forward(p_in, pack, res[:, :32], out_packed=False)  # residual of the wrong width
+    assert hipops.hblock_supported(128, 64, 56, 56, 64)
+    assert not hipops.hblock_supported(128, 64, 56, 56, 96)              # planes % 64
+    assert not hipops.hblock_supported(2, 96, 8, 8, 64)                  # three-word input cells
+    wz = ws[0].clone()
+    wz[0, 0, 0, 0] = 0.0
+    with pytest.raises(native.NativeError):
+        hipops.hblock_pack(hipops.pack_weight(wz), pws[1], pws[2], bn2, bn3, None)
