@@ -178,8 +178,11 @@ class FusedResNet(nn.Module):
 
     def __init__(self, model: ResNet, use_mfma_stem: bool = True, overlap_shortcut: bool = True,
                  stem_fp16: bool = False, stem_exact_fp32: bool = False, throughput_mode: bool = False,
-                 int_thresholds: bool = True, skip_dead_f32: bool = True, fold_shortcut: bool = True) -> None:
+                 int_thresholds: bool = True, skip_dead_f32: bool = True, fold_shortcut: bool = True,
+                 fuse_hblock: bool = True) -> None:
         super().__init__()
+        # a hierarchical block as ONE launch (bnn_hip_hblock_forward) instead of a packing pass + three convolutions
+        self.fuse_hblock = fuse_hblock
         # the last conv of a block writes no fp32 tensor when the next block consumes sign planes only
         self.skip_dead_f32 = skip_dead_f32
         # BN + ReLU + sign of the conv1-type layers as an integer compare of the dot (same bits, fewer instructions)
@@ -264,8 +267,37 @@ class FusedResNet(nn.Module):
         for stage in (m.layer1, m.layer2, m.layer3, m.layer4):
             for blk in stage:
                 self._add_block(blk)
+        self._link_hblocks()
         self._graph = None
         self._sig = self._signature()
+
+    def _link_hblocks(self) -> None:
+        """One-launch form of every hierarchical block that qualifies (csrc/hblock.hip): ReLU activations (all sign
+        planes non-negative), bias-free 3x3 / stride 1 / padding 1 convolutions without post scale or zero weights.  The
+        launch also writes the NEXT block's input planes when that block is a hierarchical block behind a ReLU."""
+        if not getattr(self, "fuse_hblock", True):
+            return
+        for i, b in enumerate(self._blocks):
+            if b["kind"] != "h":
+                continue
+            convs = b["convs"]
+            ok = all(b["relu"]) and all(
+                c.layer.bias is None and c.plan.scale is None and not c.weight.has_zero and c.prelu is None and not c.relu
+                and tuple(c.layer.kernel_size) == (3, 3) and tuple(c.layer.stride) == (1, 1)
+                and tuple(c.layer.padding) == (1, 1) and tuple(c.layer.dilation) == (1, 1) for c in convs)
+            planes = b["planes"]
+            ok = ok and convs[0].layer.out_channels * 2 == planes and convs[1].layer.out_channels * 4 == planes \
+                and convs[2].layer.out_channels * 4 == planes and planes % 64 == 0
+            if not ok:
+                continue
+            nxt = self._blocks[i + 1] if i + 1 < len(self._blocks) else None
+            nbn = nxt["bn"][0] if (nxt is not None and nxt["kind"] == "h" and nxt["relu"][0]
+                                   and nxt["convs"][0].layer.in_channels == planes) else None
+            try:
+                b["hpack"] = hipops.hblock_pack(convs[0].weight, convs[1].weight, convs[2].weight, b["bn"][1], b["bn"][2], nbn)
+            except native.NativeError:      # a width the one-launch kernel has no instance for
+                b["hpack"] = None
+            b["hgeo"] = {}
 
     def _add_block(self, blk) -> None:
         """Derive the fused form of one residual block (appends to ``self._blocks``)."""
@@ -356,13 +388,17 @@ class FusedResNet(nn.Module):
         for i, b in enumerate(self._blocks):
             nxt = self._blocks[i + 1] if i < last else None
             if b["kind"] == "pool":
+                fused = self._pool_into_hblock(b["mod"], nxt, t)
+                if fused is not None:       # the pool + both sign planes the next stage's first block reads, one pass
+                    t, packed = fused
+                    continue
                 t, packed = b["mod"](t), None
                 continue
             if b["kind"] == "pre":
                 t, packed = self._run_pre(b, nxt, t, packed)
                 continue
             if b["kind"] == "h":
-                t, packed = self._run_h(b, t), None
+                t, packed = self._run_h(b, t, packed, nxt)
                 continue
             if packed is None:
                 packed = hipops.pack_act(t)
@@ -481,15 +517,55 @@ class FusedResNet(nn.Module):
         t, _ = c2.run(p1, residual=idn, out_f32=True, out_packed=False, residual_after_act=True)
         return t, None
 
-    def _run_h(self, b, t):
+    def _pool_into_hblock(self, pool, nxt, t):
+        """``AvgPool2d(2, 2)`` in front of a hierarchical block that runs as one launch: the pooled tensor is only ever
+        binarised — by the block's bn1 -> ReLU and by its shortcut's BatchNorm — so one pass writes both sets of planes
+        and (when the block has a shortcut convolution) no fp32 tensor at all.  None: not that case."""
+        if (_TAP is not None or nxt is None or nxt["kind"] != "h" or nxt.get("hpack") is None or t is None
+                or not isinstance(pool, nn.AvgPool2d) or pool.kernel_size not in (2, (2, 2))
+                or pool.stride not in (2, (2, 2)) or pool.padding not in (0, (0, 0))
+                or t.shape[2] % 2 or t.shape[3] % 2 or not nxt["relu"][0]):
+            return None
+        N, C, H, W = t.shape
+        hp = nxt["hpack"]
+        if C != hp.c_in or not self._hblock_ok(nxt, N, H // 2, W // 2):
+            return None
+        ds_bn = nxt["ds"][0] if nxt["ds"] is not None else None
+        p1, p2, tp = hipops.avgpool2_bn_pack2(t, nxt["bn"][0], True, ds_bn, False, out_f32=ds_bn is None)
+        p1._h_for = nxt
+        p1._ds_planes = p2
+        return tp, p1
+
+    def _hblock_ok(self, b, N, H, W) -> bool:
+        ok = b["hgeo"].get((N, H, W))
+        if ok is None:
+            hp = b["hpack"]
+            ok = b["hgeo"][(N, H, W)] = hipops.hblock_supported(N, hp.c_in, H, W, hp.planes, self.throughput_mode)
+        return ok
+
+    def _run_h(self, b, t, packed=None, nxt=None):
         """HBlock: three BN-act-conv stages write their slice of the concatenated output in place, each
-        adds its slice of the shortcut and hands ``sign(act(bn_next(o_k)))`` to the next stage."""
+        adds its slice of the shortcut and hands ``sign(act(bn_next(o_k)))`` to the next stage.  Returns
+        ``(y, planes of the next block's input | None)``; ``packed``: what the previous block's launch left for this one."""
+        mine = packed is not None and getattr(packed, "_h_for", None) is b    # planes the previous launch left for this block
         if b["ds"] is not None:
             (sa, sb), conv = b["ds"]
-            idn, _ = conv.run(hipops.bn_act_pack(t, sa, sb, relu=False), out_f32=True, out_packed=False)
+            sp = getattr(packed, "_ds_planes", None) if mine else None
+            idn, _ = conv.run(sp if sp is not None else hipops.bn_act_pack(t, sa, sb, relu=False), out_f32=True,
+                              out_packed=False)
         else:
             idn = t
         c1, c2, c3 = b["convs"]
+        hp = b.get("hpack")
+        if hp is not None and _TAP is None:     # (a tap wants the planes in front of every convolution: launch by launch)
+            N, _, H, W = idn.shape
+            if self._hblock_ok(b, N, H, W):
+                if not mine:
+                    packed = hipops.bn_act_pack(t, *b["bn"][0], relu=True)
+                y, pk = hipops.hblock_forward(packed, hp, idn, out_packed=hp.has_next, throughput=self.throughput_mode)
+                if pk is not None:
+                    pk._h_for = nxt
+                return y, pk
         half = b["planes"] // 2
         quarter = c2.layer.out_channels
         p = hipops.bn_act_pack(t, *b["bn"][0], relu=b["relu"][0])
@@ -500,7 +576,7 @@ class FusedResNet(nn.Module):
         _, p = c2.run(p, out_packed=True, out_c_offset=half, pack_scale=b["bn"][2][0], pack_shift=b["bn"][2][1],
                       pack_relu=b["relu"][2], **late)
         c3.run(p, out_packed=False, out_c_offset=half + quarter, **late)
-        return y
+        return y, None
 
     def _signature(self):
         """Changes whenever a parameter or buffer of the wrapped model is replaced or written in place
@@ -676,6 +752,7 @@ class FusedBlocks(FusedResNet):
         self.throughput_mode = throughput_mode
         self.overlap_shortcut = True
         self.fold_shortcut = True
+        self.fuse_hblock = True
         self._side = {}
         self.model = blocks
         self._blocks = []
@@ -693,6 +770,7 @@ class FusedBlocks(FusedResNet):
         self._names = {id(mod): name for name, mod in self.model.named_modules()}
         for blk in self.model:
             self._add_block(blk)
+        self._link_hblocks()
         self._graph = None
         self._sig = self._signature()
 

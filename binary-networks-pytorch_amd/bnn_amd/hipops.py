@@ -291,6 +291,34 @@ def avgpool2x2_backward(gy: torch.Tensor) -> torch.Tensor:
     return gx
 
 
+def avgpool2_bn_pack2(x: torch.Tensor, bn1, relu1: bool, bn2=None, relu2: bool = False, out_f32: bool = False):
+    """``AvgPool2d(2, 2)`` of an fp32 NCHW tensor (even H, W) + ``sign(act(bn(.)))`` of the pooled tensor for up to two
+    BatchNorm branches in one pass (``bnn_hip_avgpool2_bn_pack2_f32``).  ``bn1`` / ``bn2``: (scale, shift).
+    Returns ``(PackedAct 1, PackedAct 2 | None, pooled fp32 | None)``."""
+    x = _require_cuda_f32(x, "activation")
+    lib = native.require()
+    N, C, H, W = x.shape
+    if H % 2 or W % 2:
+        raise native.NativeError("bnn_amd: avgpool2_bn_pack2 needs even H and W")
+    a1, b1 = _per_channel(bn1[0], C, "bn scale"), _per_channel(bn1[1], C, "bn shift")
+    a2 = b2 = None
+    if bn2 is not None:
+        a2, b2 = _per_channel(bn2[0], C, "bn scale"), _per_channel(bn2[1], C, "bn shift")
+    with torch.cuda.device(x.device):
+        p1 = empty_packed(N, C, H // 2, W // 2, x.device)
+        p2 = empty_packed(N, C, H // 2, W // 2, x.device) if bn2 is not None else None
+        t = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device) if out_f32 else None
+        if N:
+            native.check(lib.bnn_hip_avgpool2_bn_pack2_f32(
+                x.data_ptr(), N, C, H, W, a1.data_ptr(), b1.data_ptr(), int(bool(relu1)), p1.P.data_ptr(), p1.M.data_ptr(),
+                _ptr(a2), _ptr(b2), int(bool(relu2)), None if p2 is None else p2.P.data_ptr(),
+                None if p2 is None else p2.M.data_ptr(), _ptr(t), _stream(x.device)), "bnn_hip_avgpool2_bn_pack2_f32")
+    p1.nonneg = bool(relu1)
+    if p2 is not None:
+        p2.nonneg = bool(relu2)
+    return p1, p2, t
+
+
 def sign_thresholds(w: PackedWeight, bn_scale: torch.Tensor, bn_shift: torch.Tensor, bias=None, post_scale=None):
     """Integer form of ``sign(relu(bn(alpha * dot + bias)))`` for ``bconv2d_fused(..., sign_thresholds=...)``:
     int32 ``[O, 4]`` = (bound T, flip word of the channel's 32-channel block, the two comparands of the kernels'

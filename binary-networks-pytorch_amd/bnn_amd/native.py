@@ -46,6 +46,7 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_stem7x7_conv_f32", "bnn_hip_stem7x7_wgrad_workspace_bytes", "bnn_hip_stem7x7_wgrad_f32",
     "bnn_hip_avgpool2x2_backward_f32", "bnn_hip_xnor_grad_pack_weight_f32",
     "bnn_hip_hblock_supported", "bnn_hip_hblock_layout_of", "bnn_hip_hblock_pack_weights", "bnn_hip_hblock_forward",
+    "bnn_hip_avgpool2_bn_pack2_f32",
 )
 
 
@@ -194,6 +195,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_probe_int_alu.argtypes = [_i, _i, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_double), _vp]
     lib.bnn_hip_probe_clock.argtypes = [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _vp]
+    lib.bnn_hip_avgpool2_bn_pack2_f32.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]
     lib.bnn_hip_hblock_supported.argtypes = [ctypes.POINTER(HBlockDesc)]
     lib.bnn_hip_hblock_layout_of.argtypes = [_i, _i, ctypes.POINTER(HBlockLayout)]
     lib.bnn_hip_hblock_pack_weights.argtypes = [_i, _i, _vp, _vp, _vp, _vp, _vp]

@@ -120,6 +120,9 @@ int launch_bn_act_pack(const float* x, int N, int C, int H, int W, const float* 
                        int relu, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_avgpool_pack(const float* x, int N, int C, int H, int W, int k, uint64_t* P, uint64_t* M,
                         hipStream_t stream);
+int launch_avgpool2_bn_pack2(const float* x, int N, int C, int H, int W, const float* a1, const float* b1, int relu1,
+                             uint64_t* P1, uint64_t* M1, const float* a2, const float* b2, int relu2, uint64_t* P2,
+                             uint64_t* M2, float* out, hipStream_t stream);
 int launch_orpool_packed(const uint64_t* P, int N, int C, int H, int W, int k, uint64_t* outP, uint64_t* outM,
                          hipStream_t stream);
 int launch_bn_relu_maxpool_pack(const float* x, int N, int C, int H, int W, const float* bn_a,

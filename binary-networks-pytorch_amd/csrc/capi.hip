@@ -244,6 +244,23 @@ int bnn_hip_avgpool_pack_f32(const float* x, int N, int C, int H, int W, int k, 
   return bnn::launch_avgpool_pack(x, N, C, H, W, k, P, M, static_cast<hipStream_t>(stream));
 }
 
+int bnn_hip_avgpool2_bn_pack2_f32(const float* x, int N, int C, int H, int W, const float* a1, const float* b1, int relu1,
+                                  uint64_t* P1, uint64_t* M1, const float* a2, const float* b2, int relu2, uint64_t* P2,
+                                  uint64_t* M2, float* out_f32, void* stream) {
+  if (!x || !a1 || !b1 || !P1 || !M1 || N <= 0 || C <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (H % 2 || W % 2) return BNN_HIP_ERR_UNSUPPORTED;
+  if ((a2 == nullptr) != (b2 == nullptr) || (a2 && (!P2 || !M2))) return BNN_HIP_ERR_INVALID_ARG;
+  if (mulc(N, C, H, W) > kMaxElems) return BNN_HIP_ERR_TOO_LARGE;
+  if (2 * (((long long)C + 63) / 64) > 65535) return BNN_HIP_ERR_UNSUPPORTED;
+  if (!aligned(x, 8) || !aligned(P1, 8) || !aligned(M1, 8) || (a2 && (!aligned(P2, 8) || !aligned(M2, 8))) ||
+      (out_f32 && !aligned(out_f32, 4)))
+    return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_avgpool2_bn_pack2(x, N, C, H, W, a1, b1, relu1, P1, M1, a2, b2, relu2, P2, M2, out_f32,
+                                       static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_orpool_packed(const uint64_t* P, int N, int C, int H, int W, int k, uint64_t* out_P,
                           uint64_t* out_M, void* stream) {
   if (!P || !out_P || !out_M || N <= 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0) return BNN_HIP_ERR_INVALID_ARG;

@@ -54,6 +54,7 @@ struct HbGeo {
   HbPhase ph[3];
   unsigned lds_out;   // next block's planes: [group][cell][2 words], cell = (image, band row, column)
   int ncell_out;
+  unsigned lds_done;  // completion counters: one per pixel group of conv1's, then of conv2's domain
   unsigned lds16;     // LDS bytes / 16
   unsigned na_off, nb_off;  // floats: the next block's bn1
   uint32_t m_hw, m_w;
@@ -94,144 +95,207 @@ __device__ __forceinline__ void hb_lds_words(const uint32_t* base, unsigned word
 
 constexpr unsigned kOob = 0xFFFFFFF0u;  // a byte offset beyond every descriptor: loads return 0, stores are dropped
 
-// One convolution of the block on the region's planes.
+// The output domain of phase K in this region (wave-uniform): rows [ra, rb) of kk images, 64-pixel groups.
+struct HbDom {
+  int ra, nrows, npix, npg;
+};
+__device__ __forceinline__ HbDom hb_domain(const HbGeo& g, int K, int kk, int y0, int rows) {
+  HbDom d;
+  d.ra = max(0, y0 - g.ph[K].halo);
+  d.nrows = min(g.H, y0 + rows + g.ph[K].halo) - d.ra;  // (kk > 1: whole images, nrows == H)
+  d.npix = kk * d.nrows * g.W;
+  d.npg = (d.npix + 63) >> 6;
+  return d;
+}
+
+// Wait until the planes under the receptive fields of pixel group `pg` of phase K (>= 1) are complete: every pass of
+// every pixel group of phase K - 1 that holds a row of the hull [first pixel's row - 1, last pixel's row + 1].
+// The phases are not separated by barriers: a unit only ever waits for units with smaller tickets, which running
+// waves hold (csrc/bconv_fly.hip uses the same argument).
+__device__ __forceinline__ void hb_wait_inputs(const HbGeo& g, int K, const HbDom& d, const HbDom& dp, int pg, int kk,
+                                               const uint32_t* done_prev, int lane) {
+  const int j0 = pg << 6, j1 = min(j0 + 63, d.npix - 1);
+  int i0 = 0, i1 = 0, r0 = j0, r1 = j1;
+  const int hw = g.H * g.W;
+  if (kk > 1) {
+    i0 = (int)fast_div((uint32_t)j0, g.m_hw, g.s_hw);
+    i1 = (int)fast_div((uint32_t)j1, g.m_hw, g.s_hw);
+    r0 = j0 - i0 * hw;
+    r1 = j1 - i1 * hw;
+  }
+  const int row0 = d.ra + (int)fast_div((uint32_t)r0, g.m_w, g.s_w), row1 = d.ra + (int)fast_div((uint32_t)r1, g.m_w, g.s_w);
+  const int per_img = dp.nrows * g.W;
+  const int lo = (i0 * per_img + (max(row0 - 1, dp.ra) - dp.ra) * g.W) >> 6;
+  const int hi = (i1 * per_img + (min(row1 + 1, dp.ra + dp.nrows - 1) - dp.ra) * g.W + g.W - 1) >> 6;
+  const uint32_t want = (uint32_t)g.ph[K - 1].npass;
+  for ([[maybe_unused]] unsigned idle = 0;; ++idle) {
+    [[maybe_unused]] bool missing = false;
+    for (int i = lo + lane; i <= hi; i += 64)
+      missing |= __hip_atomic_load(&done_prev[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_ballot_w64(missing) == 0ull) break;
+    __builtin_amdgcn_s_sleep(4);
+    if (idle > (1u << 24)) __builtin_trap();  // seconds of idling: a lost update — abort loudly rather than hang
+#else
+    break;
+#endif
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+}
+
+// One unit of one convolution of the block: passes p0 .. p0 + np - 1 of pixel group `pg`.
 //   CWC / MULTI: words per (chunk, cell) of its input plane; several chunks
 //   K: 0, 1, 2;  CWCN: CWC of the next phase (layout of the plane this one writes; unused for K == 2)
 //   NEXT: the next block's input planes are wanted (sign(act(bn1'(y)))
 template <int CWC, bool MULTI, int K, int CWCN, bool NEXT>
-__device__ __forceinline__ void hb_phase(const uint32_t* __restrict__ Wt, const float* __restrict__ Kc,
-                                         const float* __restrict__ res, float* __restrict__ out, const HbGeo& g,
-                                         unsigned char* smem, int n0, int kk, int y0, int rows, int lane) {
+__device__ __forceinline__ void hb_unit(const uint32_t* __restrict__ Wt, const float* __restrict__ Kc,
+                                        const float* __restrict__ res, float* __restrict__ out, const HbGeo& g,
+                                        unsigned char* smem, const HbDom& d, uint32_t* done, int pg, int p0, int np, int n0,
+                                        int kk, int y0, int rows, int lane) {
   constexpr int NW = 9 * CWC;
   constexpr int NACC = CWC == 1 ? 16 : 8;  // channels per pass: weight runs of NACC * NW words are whole 64-byte lines
-  constexpr int PPU = 32 / NACC;           // passes per unit at most
   constexpr bool LAST = K == 2;
   using f2 = __attribute__((ext_vector_type(2))) float;
   const HbPhase& ph = g.ph[K];
-  const int ra = max(0, y0 - ph.halo), rb = min(g.H, y0 + rows + ph.halo);
-  const int nrows = rb - ra;  // (kk > 1: whole images, nrows == H)
-  const int npix = kk * nrows * g.W;
-  const int npg = (npix + 63) >> 6;
-  const int nunits = npg * ph.upg;
   const int hw = g.H * g.W;
-  uint32_t* ctl = reinterpret_cast<uint32_t*>(smem);
   const uint32_t* pin = reinterpret_cast<const uint32_t*>(smem + ph.lds_in);
   const BufRsrc rres = make_rsrc_sized(res, g.f32_bytes), rout = make_rsrc_sized(out, g.f32_bytes);
-  for (;;) {
-    const uint32_t u = hb_ticket(&ctl[K], lane);
-    if (u >= (uint32_t)nunits) break;
-    const int pg = (int)fast_div(u, ph.m_upg, ph.s_upg);
-    const int p0 = ((int)u - pg * ph.upg) * ph.ppu;
-    const int np = min(ph.ppu, ph.npass - p0);
-    // the lane's pixel (lanes past the domain's last pixel copy it: same values to the same places)
-    const int j = min((pg << 6) + lane, npix - 1);
-    int img = 0, rem = j;
-    if (kk > 1) {
-      img = (int)fast_div((uint32_t)j, g.m_hw, g.s_hw);
-      rem = j - imul<true>(img, hw);
-    }
-    const int rowl = (int)fast_div((uint32_t)rem, g.m_w, g.s_w);
-    const int col = rem - imul<true>(rowl, g.W);
-    const int row = ra + rowl;
-    const bool interior = row >= y0 && row < y0 + rows;  // a band row: its fp32 values and next-block bits are this region's
-    const unsigned lane_off =
-        interior ? (unsigned)(imul<true>(imul<true>(n0 + img, g.C), hw) + imul<true>(row, g.W) + col) * 4u : kOob;
-    // top-left tap of the receptive field in the phase's input slab (slab row 0 = image row y0 - halo - 1, column 0 = -1)
-    const unsigned cell0 = (unsigned)(imul<true>(imul<true>(img, ph.rows_in) + (row - y0 + ph.halo), g.WP) + col);
-    uint32_t pr[NW], mr[NW];
+  // the lane's pixel (lanes past the domain's last pixel copy it: same values to the same places)
+  const int j = min((pg << 6) + lane, d.npix - 1);
+  int img = 0, rem = j;
+  if (kk > 1) {
+    img = (int)fast_div((uint32_t)j, g.m_hw, g.s_hw);
+    rem = j - imul<true>(img, hw);
+  }
+  const int rowl = (int)fast_div((uint32_t)rem, g.m_w, g.s_w);
+  const int col = rem - imul<true>(rowl, g.W);
+  const int row = d.ra + rowl;
+  const bool interior = row >= y0 && row < y0 + rows;  // a band row: its fp32 values and next-block bits are this region's
+  const unsigned lane_off =
+      interior ? (unsigned)(imul<true>(imul<true>(n0 + img, g.C), hw) + imul<true>(row, g.W) + col) * 4u : kOob;
+  // top-left tap of the receptive field in the phase's input slab (slab row 0 = image row y0 - halo - 1, column 0 = -1)
+  const unsigned cell0 = (unsigned)(imul<true>(imul<true>(img, ph.rows_in) + (row - y0 + ph.halo), g.WP) + col);
+  uint32_t pr[NW], mr[NW];
 #pragma unroll
-    for (int i = 0; i < NW; ++i) mr[i] = 0u;
-    int nz = 0;
-    if constexpr (!MULTI) {
+  for (int i = 0; i < NW; ++i) mr[i] = 0u;
+  int nz = 0;
+  if constexpr (!MULTI) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
-        hb_lds_words<CWC>(pin, (cell0 + (unsigned)((t / 3) * g.WP + (t % 3))) * CWC, &pr[t * CWC]);
-      nz = count_nonzero<NW, true>(pr, mr, 0);
-    }
-    // the unit's shortcut values, all requested up front (loads before stores in the wave's vmcnt order: bconv.hip, RES_ALL)
-    float resq[PPU * NACC];
-#pragma unroll
-    for (int i = 0; i < PPU * NACC; ++i) {
-      const int c = ph.c_off + p0 * NACC + i;
-      resq[i] = buf_ld(rres, (i / NACC) < np ? lane_off : kOob, (unsigned)c * (unsigned)hw * 4u);
-    }
+    for (int t = 0; t < 9; ++t)
+      hb_lds_words<CWC>(pin, (cell0 + (unsigned)((t / 3) * g.WP + (t % 3))) * CWC, &pr[t * CWC]);
+    nz = count_nonzero<NW, true>(pr, mr, 0);
+  }
+  // where this lane's bits go: the next phase's input plane / the next block's planes
+  [[maybe_unused]] unsigned celln = 0u, cello = 0u;
+  if constexpr (!LAST) {
+    const HbPhase& pn = g.ph[K < 2 ? K + 1 : 2];
+    celln = (unsigned)(imul<true>(imul<true>(img, pn.rows_in) + (row - y0 + pn.halo + 1), g.WP) + col + 1);
+  }
+  if constexpr (NEXT) cello = (unsigned)(imul<true>(imul<true>(img, g.BR) + (row - y0), g.W) + col);
 #pragma unroll 1
-    for (int ps = 0; ps < np; ++ps) {
-      const int o0 = (p0 + ps) * NACC;
-      int acc[NACC];
+  for (int ps = 0; ps < np; ++ps) {
+    const int o0 = (p0 + ps) * NACC;
+    // the pass's shortcut values: requested before the popcount loop, they land under it
+    float resv[NACC];
 #pragma unroll
-      for (int i = 0; i < NACC; ++i) acc[i] = (int)kCountSeed;
-      const uint32_t* wrun = Wt + ph.w_off + (size_t)(p0 + ps) * ph.nchunk * (NACC * NW);
-      if constexpr (MULTI) {
-        for (int ch = 0; ch < ph.nchunk; ++ch) {
-          const unsigned cbase = (unsigned)(ch * ph.ncell_in) + cell0;
+    for (int i = 0; i < NACC; ++i) resv[i] = buf_ld(rres, lane_off, (unsigned)(ph.c_off + o0 + i) * (unsigned)hw * 4u);
+    int acc[NACC];
 #pragma unroll
-          for (int t = 0; t < 9; ++t)
-            hb_lds_words<CWC>(pin, (cbase + (unsigned)((t / 3) * g.WP + (t % 3))) * CWC, &pr[t * CWC]);
-          if (ps == 0) nz = count_nonzero<NW, true>(pr, mr, nz);
-          stream_weights<NW, NACC, true, false, false>(wrun + (size_t)ch * (NACC * NW), pr, mr, acc);
-        }
-      } else {
-        stream_weights<NW, NACC, true, true, false>(wrun, pr, mr, acc, (int)kCountSeed);
+    for (int i = 0; i < NACC; ++i) acc[i] = (int)kCountSeed;
+    const uint32_t* wrun = Wt + ph.w_off + (size_t)(p0 + ps) * ph.nchunk * (NACC * NW);
+    if constexpr (MULTI) {
+      for (int ch = 0; ch < ph.nchunk; ++ch) {
+        const unsigned cbase = (unsigned)(ch * ph.ncell_in) + cell0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          hb_lds_words<CWC>(pin, (cbase + (unsigned)((t / 3) * g.WP + (t % 3))) * CWC, &pr[t * CWC]);
+        if (ps == 0) nz = count_nonzero<NW, true>(pr, mr, nz);
+        stream_weights<NW, NACC, true, false, false>(wrun + (size_t)ch * (NACC * NW), pr, mr, acc);
       }
-      // epilogue: the float operations of bconv_core.h epilogue<EP_HB> (alpha, late residual, next BatchNorm in front of
-      // the sign) and of pack_act.hip's bn_act_pack (the next block's bn1 on y), two channels per packed instruction
-      const f2 dscale = {2.0f, 2.0f}, doff = {-(float)nz, -(float)nz};
-      [[maybe_unused]] float pvi[NACC];
-      [[maybe_unused]] float pvn[NACC];
+    } else {
+      stream_weights<NW, NACC, true, true, false>(wrun, pr, mr, acc, (int)kCountSeed);
+    }
+    // epilogue: the float operations of bconv_core.h epilogue<EP_HB> (alpha, late residual, next BatchNorm in front of
+    // the sign) and of pack_act.hip's bn_act_pack (the next block's bn1 on y), two channels per packed instruction
+    const f2 dscale = {2.0f, 2.0f}, doff = {-(float)nz, -(float)nz};
+    [[maybe_unused]] float pvi[NACC];
+    [[maybe_unused]] float pvn[NACC];
 #pragma unroll
-      for (int i = 0; i < NACC; i += 2) {
-        const int o = o0 + i, co = ph.c_off + o;
-        const f2 cnt = f2{__int_as_float(acc[i]), __int_as_float(acc[i + 1])} - f2{8388608.0f, 8388608.0f};
-        const f2 dot = __builtin_elementwise_fma(cnt, dscale, doff);
-        const f2 ov = __builtin_elementwise_fma(f2{Kc[ph.a_off + o], Kc[ph.a_off + o + 1]}, dot, f2{0.0f, 0.0f});
-        if constexpr (!LAST) {
-          const f2 v = __builtin_elementwise_fma(ov, f2{Kc[ph.pa_off + o], Kc[ph.pa_off + o + 1]},
-                                                 f2{Kc[ph.pb_off + o], Kc[ph.pb_off + o + 1]});
-          pvi[i] = v.x;
-          pvi[i + 1] = v.y;
-        }
-        const f2 y = ov + f2{resq[i], resq[i + 1]};
-        buf_st(rout, lane_off, (unsigned)co * (unsigned)hw * 4u, y.x);
-        buf_st(rout, lane_off, (unsigned)(co + 1) * (unsigned)hw * 4u, y.y);
-        if constexpr (NEXT) {
-          const f2 v = __builtin_elementwise_fma(y, f2{Kc[g.na_off + co], Kc[g.na_off + co + 1]},
-                                                 f2{Kc[g.nb_off + co], Kc[g.nb_off + co + 1]});
-          pvn[i] = v.x;
-          pvn[i + 1] = v.y;
-        }
-      }
-      // the rest of the shortcut queue moves up (registers cannot be indexed by the pass number)
-#pragma unroll
-      for (int i = 0; i + NACC < PPU * NACC; ++i) resq[i] = resq[i + NACC];
+    for (int i = 0; i < NACC; i += 2) {
+      const int o = o0 + i, co = ph.c_off + o;
+      const f2 cnt = f2{__int_as_float(acc[i]), __int_as_float(acc[i + 1])} - f2{8388608.0f, 8388608.0f};
+      const f2 dot = __builtin_elementwise_fma(cnt, dscale, doff);
+      const f2 ov = __builtin_elementwise_fma(f2{Kc[ph.a_off + o], Kc[ph.a_off + o + 1]}, dot, f2{0.0f, 0.0f});
       if constexpr (!LAST) {
-        uint32_t bits = 0u;
+        const f2 v = __builtin_elementwise_fma(ov, f2{Kc[ph.pa_off + o], Kc[ph.pa_off + o + 1]},
+                                               f2{Kc[ph.pb_off + o], Kc[ph.pb_off + o + 1]});
+        pvi[i] = v.x;
+        pvi[i + 1] = v.y;
+      }
+      const f2 y = ov + f2{resv[i], resv[i + 1]};
+      buf_st(rout, lane_off, (unsigned)co * (unsigned)hw * 4u, y.x);
+      buf_st(rout, lane_off, (unsigned)(co + 1) * (unsigned)hw * 4u, y.y);
+      if constexpr (NEXT) {
+        const f2 v = __builtin_elementwise_fma(y, f2{Kc[g.na_off + co], Kc[g.na_off + co + 1]},
+                                               f2{Kc[g.nb_off + co], Kc[g.nb_off + co + 1]});
+        pvn[i] = v.x;
+        pvn[i + 1] = v.y;
+      }
+    }
+    if constexpr (NEXT) {
+      uint32_t bits = 0u;
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) bits = shift_in(bits, is_pos(pvi[i]));
-        bits = __builtin_bitreverse32(bits) >> (32 - NACC);  // channel o0 + i in bit i
-        const HbPhase& pn = g.ph[K < 2 ? K + 1 : 2];
-        const unsigned celln = (unsigned)(imul<true>(imul<true>(img, pn.rows_in) + (row - y0 + pn.halo + 1), g.WP) + col + 1);
-        const int wq = o0 >> 5;
-        const unsigned widx = ((unsigned)((wq / CWCN) * pn.ncell_in) + celln) * CWCN + (unsigned)(wq % CWCN);
-        unsigned char* dst = smem + pn.lds_in + widx * 4u + (unsigned)((o0 & 31) >> 3);
+      for (int i = 0; i < NACC; ++i) bits = shift_in(bits, is_pos(pvn[i]));
+      bits = __builtin_bitreverse32(bits) >> (32 - NACC);
+      if (interior) {
+        const int co0 = ph.c_off + o0;
+        const unsigned widx = ((unsigned)((co0 >> 6) * g.ncell_out) + cello) * 2u + (unsigned)((co0 & 63) >> 5);
+        unsigned char* dst = smem + g.lds_out + widx * 4u + (unsigned)((co0 & 31) >> 3);
         if constexpr (NACC == 16) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)bits;
         else *dst = (uint8_t)bits;
       }
-      if constexpr (NEXT) {
-        uint32_t bits = 0u;
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) bits = shift_in(bits, is_pos(pvn[i]));
-        bits = __builtin_bitreverse32(bits) >> (32 - NACC);
-        if (interior) {
-          const int co0 = ph.c_off + o0;
-          const unsigned cello = (unsigned)(imul<true>(imul<true>(img, g.BR) + (row - y0), g.W) + col);
-          const unsigned widx = ((unsigned)((co0 >> 6) * g.ncell_out) + cello) * 2u + (unsigned)((co0 & 63) >> 5);
-          unsigned char* dst = smem + g.lds_out + widx * 4u + (unsigned)((co0 & 31) >> 3);
-          if constexpr (NACC == 16) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)bits;
-          else *dst = (uint8_t)bits;
-        }
-      }
     }
+    if constexpr (!LAST) {
+      uint32_t bits = 0u;
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) bits = shift_in(bits, is_pos(pvi[i]));
+      bits = __builtin_bitreverse32(bits) >> (32 - NACC);  // channel o0 + i in bit i
+      const HbPhase& pn = g.ph[K < 2 ? K + 1 : 2];
+      const int wq = o0 >> 5;
+      const unsigned widx = ((unsigned)((wq / CWCN) * pn.ncell_in) + celln) * CWCN + (unsigned)(wq % CWCN);
+      unsigned char* dst = smem + pn.lds_in + widx * 4u + (unsigned)((o0 & 31) >> 3);
+      if constexpr (NACC == 16) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)bits;
+      else *dst = (uint8_t)bits;
+      // the pass is complete for this pixel group: the byte stores above precede the counter update in this wave's
+      // LDS instruction stream (release)
+      if (lane == 0) __hip_atomic_fetch_add(&done[pg], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
+
+template <int CWC, bool MULTI, int K, int CWCN, bool NEXT>
+__device__ __forceinline__ void hb_phase(const uint32_t* __restrict__ Wt, const float* __restrict__ Kc,
+                                         const float* __restrict__ res, float* __restrict__ out, const HbGeo& g,
+                                         unsigned char* smem, int n0, int kk, int y0, int rows, int lane) {
+  const HbPhase& ph = g.ph[K];
+  const HbDom d = hb_domain(g, K, kk, y0, rows);
+  uint32_t* ctl = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* done0 = reinterpret_cast<uint32_t*>(smem + g.lds_done);
+  // completion counters: conv1's pixel groups, then conv2's
+  uint32_t* done = K == 0 ? done0 : done0 + hb_domain(g, 0, kk, y0, rows).npg;
+  const uint32_t nunits = (uint32_t)(d.npg * ph.upg);
+  for (;;) {
+    const uint32_t u = hb_ticket(&ctl[K], lane);
+    if (u >= nunits) break;
+    const int pg = (int)fast_div(u, ph.m_upg, ph.s_upg), p0 = ((int)u - pg * ph.upg) * ph.ppu;
+    if constexpr (K > 0) {
+      const HbDom dp = hb_domain(g, K - 1, kk, y0, rows);
+      hb_wait_inputs(g, K, d, dp, pg, kk, K == 1 ? done0 : done, lane);
+    }
+    hb_unit<CWC, MULTI, K, CWCN, NEXT>(Wt, Kc, res, out, g, smem, d, done, pg, p0, min(ph.ppu, ph.npass - p0), n0, kk, y0,
+                                       rows, lane);
   }
 }
 
@@ -247,7 +311,7 @@ __global__ __launch_bounds__(1024) void hblock_kernel(const uint64_t* __restrict
   const int n0 = bi * g.G, kk = min(g.G, g.N - n0);
   const int y0 = bj * g.BR, rows = min(g.BR, g.H - y0);
   const int hw = g.H * g.W;
-  {  // zero: tickets, padding cells, halo rows outside the image
+  {  // zero: tickets, completion counters, padding cells, halo rows outside the image
     uint4* z = reinterpret_cast<uint4*>(smem);
     const uint4 zero = {0u, 0u, 0u, 0u};
     for (unsigned i = tid; i < g.lds16; i += nthr) z[i] = zero;
@@ -275,10 +339,12 @@ __global__ __launch_bounds__(1024) void hblock_kernel(const uint64_t* __restrict
     }
   }
   __syncthreads();
+  // The three convolutions, each with its own ticket counter, NOT separated by barriers: a wave that finds conv1's
+  // tickets handed out goes on to conv2's units, whose inputs — pixel groups of conv1's plane — are tracked by completion
+  // counters (hb_wait_inputs).  A unit only waits for units of the previous convolution, all of which are in the hands
+  // of running waves by then.
   hb_phase<CWC1, M1, 0, CWC2, NEXT>(Wt, Kc, res, out, g, smem, n0, kk, y0, rows, lane);
-  __syncthreads();
   hb_phase<CWC2, M2, 1, CWC3, NEXT>(Wt, Kc, res, out, g, smem, n0, kk, y0, rows, lane);
-  __syncthreads();
   hb_phase<CWC3, M3, 2, 1, NEXT>(Wt, Kc, res, out, g, smem, n0, kk, y0, rows, lane);
   if constexpr (NEXT) {
     __syncthreads();
@@ -373,6 +439,12 @@ namespace {
 // LDS bytes of a region of G images x BR band rows, and the offsets of its pieces.
 long long hb_lds(const HbShape& s, int W, int planes, int G, int BR, bool next, HbGeo* g) {
   long long off = 16;  // tickets
+  {  // completion counters of conv1 / conv2 (64-pixel groups of their domains, at most band + halo rows)
+    long long n = 0;
+    for (int k = 0; k < 2; ++k) n += ((long long)G * (BR + 2 * (2 - k)) * W + 63) / 64;
+    if (g) g->lds_done = (unsigned)off;
+    off += (n * 4 + 15) / 16 * 16;
+  }
   for (int k = 0; k < 3; ++k) {
     const int rows_in = BR + 2 * (3 - k);
     const long long ncell = (long long)G * rows_in * (W + 2);
@@ -428,7 +500,9 @@ int hblock_plan(const bnn_hip_hblock_desc* d, int* G_out, int* BR_out, int* wave
       if (nbi > 1 && br < 4) break;
       if (hb_lds(s, d->W, d->planes, 1, br, true, nullptr) > kHbLdsBudget) continue;
       const long long rounds = ((long long)d->N * nbi + slots - 1) / slots;
-      const double work = w1 * std::min(d->H, br + 4) + w2 * std::min(d->H, br + 2) + w3 * br;
+      // work in whole 64-pixel groups: what the lanes of a wave execute, used or not
+      auto groups = [&](int r) { return (double)(((long long)std::min(d->H, r) * d->W + 63) / 64); };
+      const double work = w1 * groups(br + 4) + w2 * groups(br + 2) + w3 * groups(br);
       const double cost = rounds * work;
       if (best_nbi == 0 || cost < best * 0.97) { best = cost; best_nbi = nbi; }
     }

@@ -331,6 +331,84 @@ int launch_avgpool_pack(const float* x, int N, int C, int H, int W, int k, uint6
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
+// AvgPool2d(2, 2) in front of a pre-activation stage + the sign planes of up to TWO BatchNorm branches of its result in one
+// pass (a hierarchical-block stage behind a pool, bnn_amd/models/resnet.py: the block's bn1 -> act -> conv1 and its
+// shortcut's bn -> conv1x1 both binarise the pooled tensor):
+//     t  = (((x00 + x01) + x10) + x11) / 4        ATen's avg_pool2d: window summed row by row, then divided
+//     u1 = fmaf(t, a1[c], b1[c]) -> P1 / M1 (relu1: M1 = 0);   u2 = fmaf(t, a2[c], b2[c]) -> P2 / M2
+// The fp32 tensor t is written only when `out` is given (nobody reads it when both consumers take planes).
+// A workgroup = 64 consecutive output pixels x one 32-channel word; wave w of it = channels 8w .. 8w+7 of the word (lane =
+// pixel: coalesced float2 loads, 16 in flight per lane); the four 8-bit pieces meet in LDS.  Even H and W.
+__global__ __launch_bounds__(256) void avgpool2_bn_pack2_kernel(
+    const float* __restrict__ x, int C, int H, int W, int Ho, int Wo, long long npix_out, int cw32,
+    const float* __restrict__ a1, const float* __restrict__ b1, int relu1, uint32_t* __restrict__ P1,
+    uint32_t* __restrict__ M1, const float* __restrict__ a2, const float* __restrict__ b2, int relu2,
+    uint32_t* __restrict__ P2, uint32_t* __restrict__ M2, float* __restrict__ out) {
+  __shared__ uint32_t pieces[4][64];  // [plane][pixel]: byte w = the piece of wave w
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long q0 = (long long)blockIdx.x * 64 + lane;
+  const long long q = q0 < npix_out ? q0 : npix_out - 1;  // lanes past the end copy the last pixel (nothing stored)
+  const int word = blockIdx.y;
+  const int hw = Ho * Wo;
+  const int n = (int)(q / hw);
+  const int r = (int)(q - (long long)n * hw);
+  const int oy = r / Wo, ox = r - oy * Wo;
+  if (wv == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pieces[k][lane] = 0u;
+  }
+  __syncthreads();
+  uint32_t p1 = 0u, m1 = 0u, p2 = 0u, m2 = 0u;
+  const int c0 = word * 32 + wv * 8;
+  const float* base = x + (((size_t)n * C + (size_t)c0) * H + 2 * oy) * W + 2 * ox;
+  const size_t cstride = (size_t)H * W;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const int c = c0 + b;
+    if (c >= C) break;
+    const float2 u = *reinterpret_cast<const float2*>(base + b * cstride);
+    const float2 v = *reinterpret_cast<const float2*>(base + b * cstride + W);
+    const float t = (((u.x + u.y) + v.x) + v.y) * 0.25f;   // (x / 4 and x * 0.25 are the same float for every x)
+    if (out && q0 < npix_out) out[((size_t)n * C + c) * hw + r] = t;
+    const float u1 = fmaf(t, a1[c], b1[c]);
+    p1 |= (is_pos(u1) ? 1u : 0u) << b;
+    m1 |= ((!relu1 && is_neg(u1)) ? 1u : 0u) << b;
+    if (a2) {
+      const float u2 = fmaf(t, a2[c], b2[c]);
+      p2 |= (is_pos(u2) ? 1u : 0u) << b;
+      m2 |= ((!relu2 && is_neg(u2)) ? 1u : 0u) << b;
+    }
+  }
+  unsigned char* pb = reinterpret_cast<unsigned char*>(&pieces[0][0]);
+  pb[(0 * 64 + lane) * 4 + wv] = (unsigned char)p1;
+  pb[(1 * 64 + lane) * 4 + wv] = (unsigned char)m1;
+  pb[(2 * 64 + lane) * 4 + wv] = (unsigned char)p2;
+  pb[(3 * 64 + lane) * 4 + wv] = (unsigned char)m2;
+  __syncthreads();
+  if (wv == 0 && q0 < npix_out) {
+    const size_t o = ((((size_t)n * (cw32 >> 1) + (word >> 1)) * hw + r) << 1) + (word & 1);
+    P1[o] = pieces[0][lane];
+    M1[o] = pieces[1][lane];
+    if (a2) {
+      P2[o] = pieces[2][lane];
+      M2[o] = pieces[3][lane];
+    }
+  }
+}
+
+int launch_avgpool2_bn_pack2(const float* x, int N, int C, int H, int W, const float* a1, const float* b1, int relu1,
+                             uint64_t* P1, uint64_t* M1, const float* a2, const float* b2, int relu2, uint64_t* P2,
+                             uint64_t* M2, float* out, hipStream_t stream) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long long npix = (long long)N * Ho * Wo;
+  const int cw32 = 2 * ((C + 63) / 64);
+  hipLaunchKernelGGL(avgpool2_bn_pack2_kernel, dim3((unsigned)((npix + 63) / 64), (unsigned)cw32), dim3(256), 0, stream,
+                     x, C, H, W, Ho, Wo, npix, cw32, a1, b1, relu1, reinterpret_cast<uint32_t*>(P1),
+                     reinterpret_cast<uint32_t*>(M1), a2, b2, relu2, reinterpret_cast<uint32_t*>(P2),
+                     reinterpret_cast<uint32_t*>(M2), out);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+}
+
 // Tail of the real-valued stem in ONE pass over the stem conv's output
 // (bnn/models/resnet.py:150-153: bn1 -> relu -> maxpool, then the first binary conv's sign()):
 //     v = fma(x, bn_a[c], bn_b[c])   eval-mode BatchNorm (optional)

@@ -61,7 +61,8 @@
 extern "C" {
 #endif
 
-/* ABI 15 (round 6): + bnn_hip_hblock_{supported,layout_of,pack_weights,forward} (the hierarchical block in one launch).
+/* ABI 15 (round 6): + bnn_hip_hblock_{supported,layout_of,pack_weights,forward} (the hierarchical block in one launch);
+ * + bnn_hip_avgpool2_bn_pack2_f32 (the pool in front of a pre-activation stage + both sign planes it feeds).
  * ABI 14 (round 5): + bnn_hip_stem7x7_wgrad_f32 / bnn_hip_stem7x7_wgrad_workspace_bytes (weight gradient of the stem
  * convolution: the training backward of that layer); + bnn_hip_avgpool2x2_backward_f32, bnn_hip_xnor_grad_pack_weight_f32; + bnn_hip_avgpool_fc_ws_f32 / bnn_hip_avgpool_fc_workspace_bytes (the head as two streaming launches
  * through a workspace); + bnn_hip_stem7x7_conv_f32 (the stem's convolution alone: the training forward); the table of bnn_hip_sign_thresholds_f32 holds FOUR words per channel (was two) and kmax < 2^20.
@@ -249,6 +250,14 @@ int bnn_hip_pack_act_f16(const void* x, int N, int C, int H, int W,
  * ceil(H/k) x ceil(W/k) pixels.                                                    */
 int bnn_hip_avgpool_pack_f32(const float* x, int N, int C, int H, int W, int k,
                              uint64_t* P, uint64_t* M, void* stream);
+
+/* AvgPool2d(2, 2) (even H, W; bnn_amd/models/resnet.py: the pool in front of a hierarchical-block stage) + the sign planes
+ * of up to two BatchNorm branches of the pooled tensor in one pass:  t = window sum (row by row) / 4 as ATen computes it,
+ * P1/M1 = sign(act1(fmaf(t, a1, b1))), P2/M2 = sign(act2(fmaf(t, a2, b2))) (relu: M = 0).  a2 == NULL: one branch.
+ * out_f32: NULL, or the pooled tensor [N, C, H/2, W/2] when somebody needs it.                                     */
+int bnn_hip_avgpool2_bn_pack2_f32(const float* x, int N, int C, int H, int W, const float* a1, const float* b1, int relu1,
+                                  uint64_t* P1, uint64_t* M1, const float* a2, const float* b2, int relu2, uint64_t* P2,
+                                  uint64_t* M2, float* out_f32, void* stream);
 
 /* The same shortcut input from the SIGN PLANES of a NON-NEGATIVE tensor (a ReLU output: M == 0): the average of
  * non-negative values is positive iff one of them is, so sign(AvgPool_k(x)) is the OR of the P plane over each

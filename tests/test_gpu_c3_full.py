@@ -211,6 +211,10 @@ def test_c5_hblock_3463_at_its_stated_size():
         # (2) counted: 8 images x 51 layers; the reference against its own other conv backend flips some too (see the
         # fixture's self check).  At most 2 of the 8 images may differ in a sign.
         assert rep["images_with_a_sign_flip"] <= 2, rep
+    # the tapped run above is launch by launch (the taps want the planes in front of every convolution); what runs without
+    # a tap is one launch per hierarchical block (csrc/hblock.hip): the same logits bit for bit
+    assert torch.equal(FusedResNet(net)(xs), yy)
+    assert torch.equal(FusedResNet(net, fuse_hblock=False)(xs), yy)
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "c5_b8_parity.json"), "w") as fh:

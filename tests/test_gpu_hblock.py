@@ -119,3 +119,25 @@ def test_argument_checks():
     wz[0, 0, 0, 0] = 0.0
     with pytest.raises(native.NativeError):
         hipops.hblock_pack(hipops.pack_weight(wz), pws[1], pws[2], bn2, bn3, None)
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 56, 56), (2, 128, 28, 28), (5, 256, 14, 14), (2, 96, 6, 10)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_pool_and_both_packs_in_one_pass(shape):
+    """bnn_hip_avgpool2_bn_pack2_f32 == ATen's avg_pool2d followed by the two packing passes, bit for bit."""
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, C, H, W, generator=g).to(DEV)
+    x[0, 0, :2, :2] = 0.0                                # an exactly-zero window: neither plane
+    x[0, 1, 0, 0] = float("nan")
+    bn1 = ((torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV))
+    bn2 = ((torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV))
+    t = F.avg_pool2d(x, 2, 2, ceil_mode=True, count_include_pad=False)
+    w1 = hipops.bn_act_pack(t, *bn1, relu=True)
+    w2 = hipops.bn_act_pack(t, *bn2, relu=False)
+    p1, p2, tp = hipops.avgpool2_bn_pack2(x, bn1, True, bn2, False, out_f32=True)
+    assert torch.equal(tp[0, 2:], t[0, 2:]) and torch.equal(tp[1:], t[1:])     # (NaN != NaN in channel 1 of image 0)
+    assert torch.equal(p1.P, w1.P) and torch.equal(p1.M, w1.M) and p1.nonneg
+    assert torch.equal(p2.P, w2.P) and torch.equal(p2.M, w2.M) and not p2.nonneg
+    q1, q2, tq = hipops.avgpool2_bn_pack2(x, bn1, True)
+    assert q2 is None and tq is None and torch.equal(q1.P, w1.P)
