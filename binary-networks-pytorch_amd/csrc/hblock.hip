@@ -24,6 +24,7 @@
 // ONE word per tap, not two), and a convolution of 16 output channels runs 16 channels, not a padded block of 32.
 // Same integers and the same float operations, in the same order, as the launch-by-launch form: bit-identical y and planes.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "bconv_core.h"
@@ -93,7 +94,30 @@ __device__ __forceinline__ void hb_lds_words(const uint32_t* base, unsigned word
   }
 }
 
+#ifdef HB_TIMING  // variant builds only (tools/exp_hblock_timing.py): per-wave cycle stamps of the phases
+__device__ unsigned long long bnn_hb_dbg[8 * 16 * 4096];
+#define HB_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define HB_NOW() 0ull
+#endif
+
+// N consecutive wave-uniform floats (32-byte aligned) as s_load_dwordx8 pieces.
+template <int N>
+__device__ __forceinline__ void hb_consts(const float* __restrict__ src, float (&dst)[N]) {
+  static_assert(N % 8 == 0, "whole dwordx8 pieces");
+  struct alignas(32) F8 { float v[8]; };
+#pragma unroll
+  for (int i = 0; i < N / 8; ++i) {
+    const F8 t = *reinterpret_cast<const F8*>(__builtin_assume_aligned(src + 8 * i, 32));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[8 * i + e] = t.v[e];
+  }
+}
+
 constexpr unsigned kOob = 0xFFFFFFF0u;  // a byte offset beyond every descriptor: loads return 0, stores are dropped
+#ifndef HB_MINW  // waves per SIMD the kernel is register-allocated for (8: two 16-wave workgroups per CU)
+#define HB_MINW 4
+#endif
 
 // The output domain of phase K in this region (wave-uniform): rows [ra, rb) of kk images, 64-pixel groups.
 struct HbDom {
@@ -220,17 +244,28 @@ __device__ __forceinline__ void hb_unit(const uint32_t* __restrict__ Wt, const f
     // epilogue: the float operations of bconv_core.h epilogue<EP_HB> (alpha, late residual, next BatchNorm in front of
     // the sign) and of pack_act.hip's bn_act_pack (the next block's bn1 on y), two channels per packed instruction
     const f2 dscale = {2.0f, 2.0f}, doff = {-(float)nz, -(float)nz};
+    // the pass's per-channel constants: NACC consecutive floats each, fetched as whole 32-byte scalar loads (the layout
+    // keeps every run 32-byte aligned: hblock_layout)
+    float ka[NACC], kpa[NACC], kpb[NACC], kna[NACC], knb[NACC];
+    hb_consts<NACC>(Kc + ph.a_off + o0, ka);
+    if constexpr (!LAST) {
+      hb_consts<NACC>(Kc + ph.pa_off + o0, kpa);
+      hb_consts<NACC>(Kc + ph.pb_off + o0, kpb);
+    }
+    if constexpr (NEXT) {
+      hb_consts<NACC>(Kc + g.na_off + ph.c_off + o0, kna);
+      hb_consts<NACC>(Kc + g.nb_off + ph.c_off + o0, knb);
+    }
     [[maybe_unused]] float pvi[NACC];
     [[maybe_unused]] float pvn[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; i += 2) {
-      const int o = o0 + i, co = ph.c_off + o;
+      const int co = ph.c_off + o0 + i;
       const f2 cnt = f2{__int_as_float(acc[i]), __int_as_float(acc[i + 1])} - f2{8388608.0f, 8388608.0f};
       const f2 dot = __builtin_elementwise_fma(cnt, dscale, doff);
-      const f2 ov = __builtin_elementwise_fma(f2{Kc[ph.a_off + o], Kc[ph.a_off + o + 1]}, dot, f2{0.0f, 0.0f});
+      const f2 ov = __builtin_elementwise_fma(f2{ka[i], ka[i + 1]}, dot, f2{0.0f, 0.0f});
       if constexpr (!LAST) {
-        const f2 v = __builtin_elementwise_fma(ov, f2{Kc[ph.pa_off + o], Kc[ph.pa_off + o + 1]},
-                                               f2{Kc[ph.pb_off + o], Kc[ph.pb_off + o + 1]});
+        const f2 v = __builtin_elementwise_fma(ov, f2{kpa[i], kpa[i + 1]}, f2{kpb[i], kpb[i + 1]});
         pvi[i] = v.x;
         pvi[i + 1] = v.y;
       }
@@ -238,8 +273,7 @@ __device__ __forceinline__ void hb_unit(const uint32_t* __restrict__ Wt, const f
       buf_st(rout, lane_off, (unsigned)co * (unsigned)hw * 4u, y.x);
       buf_st(rout, lane_off, (unsigned)(co + 1) * (unsigned)hw * 4u, y.y);
       if constexpr (NEXT) {
-        const f2 v = __builtin_elementwise_fma(y, f2{Kc[g.na_off + co], Kc[g.na_off + co + 1]},
-                                               f2{Kc[g.nb_off + co], Kc[g.nb_off + co + 1]});
+        const f2 v = __builtin_elementwise_fma(y, f2{kna[i], kna[i + 1]}, f2{knb[i], knb[i + 1]});
         pvn[i] = v.x;
         pvn[i + 1] = v.y;
       }
@@ -300,12 +334,13 @@ __device__ __forceinline__ void hb_phase(const uint32_t* __restrict__ Wt, const 
 }
 
 template <int CWC1, bool M1, int CWC2, bool M2, int CWC3, bool M3, bool NEXT>
-__global__ __launch_bounds__(1024) void hblock_kernel(const uint64_t* __restrict__ inP, const uint32_t* __restrict__ Wt,
+__global__ __launch_bounds__(1024, HB_MINW) void hblock_kernel(const uint64_t* __restrict__ inP, const uint32_t* __restrict__ Wt,
                                                       const float* __restrict__ Kc, const float* __restrict__ res,
                                                       float* __restrict__ out, uint64_t* __restrict__ outP,
                                                       const HbGeo g) {
   unsigned char* smem = hb_smem;
   const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  [[maybe_unused]] const unsigned long long t_entry = HB_NOW();
   const int bi = g.nbi > 1 ? (int)blockIdx.x / g.nbi : (int)blockIdx.x;
   const int bj = (int)blockIdx.x - bi * g.nbi;
   const int n0 = bi * g.G, kk = min(g.G, g.N - n0);
@@ -317,6 +352,7 @@ __global__ __launch_bounds__(1024) void hblock_kernel(const uint64_t* __restrict
     for (unsigned i = tid; i < g.lds16; i += nthr) z[i] = zero;
   }
   __syncthreads();
+  [[maybe_unused]] const unsigned long long t_zero = HB_NOW();
   {  // phase 0: the block's input planes, band + 3 halo rows (rows of the image only)
     const HbPhase& p1 = g.ph[0];
     const int ra = max(0, y0 - 3), rb = min(g.H, y0 + rows + 3);
@@ -343,9 +379,13 @@ __global__ __launch_bounds__(1024) void hblock_kernel(const uint64_t* __restrict
   // tickets handed out goes on to conv2's units, whose inputs — pixel groups of conv1's plane — are tracked by completion
   // counters (hb_wait_inputs).  A unit only waits for units of the previous convolution, all of which are in the hands
   // of running waves by then.
+  [[maybe_unused]] const unsigned long long t_p0 = HB_NOW();
   hb_phase<CWC1, M1, 0, CWC2, NEXT>(Wt, Kc, res, out, g, smem, n0, kk, y0, rows, lane);
+  [[maybe_unused]] const unsigned long long t_c1 = HB_NOW();
   hb_phase<CWC2, M2, 1, CWC3, NEXT>(Wt, Kc, res, out, g, smem, n0, kk, y0, rows, lane);
+  [[maybe_unused]] const unsigned long long t_c2 = HB_NOW();
   hb_phase<CWC3, M3, 2, 1, NEXT>(Wt, Kc, res, out, g, smem, n0, kk, y0, rows, lane);
+  [[maybe_unused]] const unsigned long long t_c3 = HB_NOW();
   if constexpr (NEXT) {
     __syncthreads();
     const int ngo = g.C >> 6;
@@ -358,6 +398,12 @@ __global__ __launch_bounds__(1024) void hblock_kernel(const uint64_t* __restrict
       outP[((size_t)(n0 + img) * ngo + gq) * hw + (size_t)y0 * g.W + r2] = (uint64_t)v.x | ((uint64_t)v.y << 32);
     }
   }
+#ifdef HB_TIMING
+  if (lane == 0 && blockIdx.x < 4096) {
+    unsigned long long* d = bnn_hb_dbg + ((size_t)blockIdx.x * 16 + (tid >> 6)) * 8;
+    d[0] = t_entry; d[1] = t_zero; d[2] = t_p0; d[3] = t_c1; d[4] = t_c2; d[5] = t_c3; d[6] = HB_NOW(); d[7] = 0;
+  }
+#endif
 }
 
 // standard packed weights (bnn_hip_pack_weight_f32: wbits[ob][chunk][j][tap][cwc], 64-channel granularity) -> the dense
@@ -484,7 +530,8 @@ int hblock_plan(const bnn_hip_hblock_desc* d, int* G_out, int* BR_out, int* wave
   HbShape s;
   if (!hb_shape(d->C_in, d->planes, s)) return BNN_HIP_ERR_UNSUPPORTED;
   const int ncu = current_device_cus();
-  const bool shared = (d->flags & BNN_HIP_FLAG_THROUGHPUT) != 0;
+  static const bool split_when_shared = [] { const char* e = std::getenv("BNN_HBLOCK_SHARED_SPLIT"); return e && e[0] == '1'; }();
+  const bool shared = (d->flags & BNN_HIP_FLAG_THROUGHPUT) != 0 && !split_when_shared;
   int G = 1, BR = d->H;
   if (d->rows_per_band > 0 || d->images_per_band > 0) {
     G = d->images_per_band > 0 ? std::min(d->images_per_band, d->N) : 1;
@@ -603,3 +650,9 @@ bool hblock_supported(const bnn_hip_hblock_desc* d) {
 }
 
 }  // namespace bnn
+
+#ifdef HB_TIMING
+extern "C" int bnn_hip_debug_hblock_timing(unsigned long long* host_dst, size_t n_words) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(bnn::bnn_hb_dbg), n_words * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -339,6 +339,8 @@ int launch_avgpool_pack(const float* x, int N, int C, int H, int W, int k, uint6
 // The fp32 tensor t is written only when `out` is given (nobody reads it when both consumers take planes).
 // A workgroup = 64 consecutive output pixels x one 32-channel word; wave w of it = channels 8w .. 8w+7 of the word (lane =
 // pixel: coalesced float2 loads, 16 in flight per lane); the four 8-bit pieces meet in LDS.  Even H and W.
+// (large tensors — the 56x56 -> 28x28 transition at batch 128 — stream at 4.9 TB/s in the one-thread-per-word form below;
+// this one is for the smaller transitions, where that form has too few threads: 19.4 -> 14.3 us and 18.4 -> 11.0 us)
 __global__ __launch_bounds__(256) void avgpool2_bn_pack2_kernel(
     const float* __restrict__ x, int C, int H, int W, int Ho, int Wo, long long npix_out, int cw32,
     const float* __restrict__ a1, const float* __restrict__ b1, int relu1, uint32_t* __restrict__ P1,
@@ -396,12 +398,61 @@ __global__ __launch_bounds__(256) void avgpool2_bn_pack2_kernel(
   }
 }
 
+// One thread = one output pixel x one 32-channel word.
+__global__ __launch_bounds__(256) void avgpool2_bn_pack2_wide_kernel(
+    const float* __restrict__ x, int C, int H, int W, int Ho, int Wo, long long npix_out, int cw32,
+    const float* __restrict__ a1, const float* __restrict__ b1, int relu1, uint32_t* __restrict__ P1,
+    uint32_t* __restrict__ M1, const float* __restrict__ a2, const float* __restrict__ b2, int relu2,
+    uint32_t* __restrict__ P2, uint32_t* __restrict__ M2, float* __restrict__ out) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= npix_out) return;
+  const int word = blockIdx.y;
+  const int hw = Ho * Wo;
+  const int n = (int)(q / hw);
+  const int r = (int)(q - (long long)n * hw);
+  const int oy = r / Wo, ox = r - oy * Wo;
+  uint32_t p1 = 0u, m1 = 0u, p2 = 0u, m2 = 0u;
+  const float* base = x + (((size_t)n * C + (size_t)word * 32) * H + 2 * oy) * W + 2 * ox;
+  const size_t cstride = (size_t)H * W;
+#pragma unroll 8
+  for (int b = 0; b < 32; ++b) {
+    const int c = word * 32 + b;
+    if (c >= C) break;
+    const float2 u = *reinterpret_cast<const float2*>(base + b * cstride);
+    const float2 v = *reinterpret_cast<const float2*>(base + b * cstride + W);
+    const float t = (((u.x + u.y) + v.x) + v.y) * 0.25f;
+    if (out) out[((size_t)n * C + c) * hw + r] = t;
+    const float u1 = fmaf(t, a1[c], b1[c]);
+    p1 |= (is_pos(u1) ? 1u : 0u) << b;
+    m1 |= ((!relu1 && is_neg(u1)) ? 1u : 0u) << b;
+    if (a2) {
+      const float u2 = fmaf(t, a2[c], b2[c]);
+      p2 |= (is_pos(u2) ? 1u : 0u) << b;
+      m2 |= ((!relu2 && is_neg(u2)) ? 1u : 0u) << b;
+    }
+  }
+  const size_t o = ((((size_t)n * (cw32 >> 1) + (word >> 1)) * hw + r) << 1) + (word & 1);
+  P1[o] = p1;
+  M1[o] = m1;
+  if (a2) {
+    P2[o] = p2;
+    M2[o] = m2;
+  }
+}
+
 int launch_avgpool2_bn_pack2(const float* x, int N, int C, int H, int W, const float* a1, const float* b1, int relu1,
                              uint64_t* P1, uint64_t* M1, const float* a2, const float* b2, int relu2, uint64_t* P2,
                              uint64_t* M2, float* out, hipStream_t stream) {
   const int Ho = H / 2, Wo = W / 2;
   const long long npix = (long long)N * Ho * Wo;
   const int cw32 = 2 * ((C + 63) / 64);
+  if (npix * cw32 >= 256LL * 2048) {  // enough threads to fill the chip with one per (pixel, word)
+    hipLaunchKernelGGL(avgpool2_bn_pack2_wide_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)cw32), dim3(256), 0,
+                       stream, x, C, H, W, Ho, Wo, npix, cw32, a1, b1, relu1, reinterpret_cast<uint32_t*>(P1),
+                       reinterpret_cast<uint32_t*>(M1), a2, b2, relu2, reinterpret_cast<uint32_t*>(P2),
+                       reinterpret_cast<uint32_t*>(M2), out);
+    return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(avgpool2_bn_pack2_kernel, dim3((unsigned)((npix + 63) / 64), (unsigned)cw32), dim3(256), 0, stream,
                      x, C, H, W, Ho, Wo, npix, cw32, a1, b1, relu1, reinterpret_cast<uint32_t*>(P1),
                      reinterpret_cast<uint32_t*>(M1), a2, b2, relu2, reinterpret_cast<uint32_t*>(P2),
