@@ -446,7 +446,7 @@ int launch_avgpool2_bn_pack2(const float* x, int N, int C, int H, int W, const f
   const int Ho = H / 2, Wo = W / 2;
   const long long npix = (long long)N * Ho * Wo;
   const int cw32 = 2 * ((C + 63) / 64);
-  if (npix * cw32 >= 256LL * 2048) {  // enough threads to fill the chip with one per (pixel, word)
+  if (npix * cw32 >= 150000LL) {  // enough threads to fill the chip with one per (pixel, word)
     hipLaunchKernelGGL(avgpool2_bn_pack2_wide_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)cw32), dim3(256), 0,
                        stream, x, C, H, W, Ho, Wo, npix, cw32, a1, b1, relu1, reinterpret_cast<uint32_t*>(P1),
                        reinterpret_cast<uint32_t*>(M1), a2, b2, relu2, reinterpret_cast<uint32_t*>(P2),
