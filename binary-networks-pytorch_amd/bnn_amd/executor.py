@@ -25,6 +25,7 @@ from __future__ import annotations
 import collections
 import contextlib
 import itertools
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -182,7 +183,7 @@ class FusedResNet(nn.Module):
                  fuse_hblock: bool = True) -> None:
         super().__init__()
         # a hierarchical block as ONE launch (bnn_hip_hblock_forward) instead of a packing pass + three convolutions
-        self.fuse_hblock = fuse_hblock
+        self.fuse_hblock = fuse_hblock and os.environ.get("BNN_AMD_FUSE_HBLOCK", "1") != "0"   # ("0": launch by launch, for A/B profiles)
         # the last conv of a block writes no fp32 tensor when the next block consumes sign planes only
         self.skip_dead_f32 = skip_dead_f32
         # BN + ReLU + sign of the conv1-type layers as an integer compare of the dot (same bits, fewer instructions)
