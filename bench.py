@@ -118,6 +118,7 @@ from tests.golden import gen  # noqa: E402  (portable synthetic-data generator, 
 
 # ResNet-18 @224: algorithmic int lane-ops per image over all binary convs (SURVEY §A.2 / BASELINE.md §4)
 R18_LANE_OPS_PER_IMG = 105.97e6
+C5_LANE_OPS_PER_IMG = 75.41e6     # ResNet(HBlock,[3,4,6,3]) at 224 x 224: 48 3x3 + 3 1x1 binary convolutions
 
 DTYPE = ("int1 xnor-popcount on the integer ALU (19 binary convs: two bit planes, v_bitop3_b32 + v_bcnt_u32_b32, "
          "int32 accumulation) + fp32 epilogues (alpha, BN, residual) + stem conv with fp32 operands split into "
@@ -201,7 +202,9 @@ def conv_c2_roofline(device, info, batch=256, iters=50, act_kind="relu", nonneg=
     out_bytes = N * O * H * W * 4
     traffic, traffic_note = pmc_traffic()
     return {
-        "bound": "int_alu", "kernel": "bconv_sgpr_kernel<3,3,4>", "workload": "conv3x3 128->128 56x56 b256",
+        "bound": "int_alu", "kernel": "bconv_sgpr_kernel<3,3,4>",
+        "workload": "conv3x3 128->128 56x56 b256, PACKED input (sign planes from bnn_hip_pack_act_f32) -> fp32: row a4 without "
+                    "row a1; config 2 as worded is `roofline_config2_as_worded`",
         "achieved": lane_ops / t_conv / 1e12, "peak": peak / 1e12, "unit": "Tlane-op/s",
         "frac": lane_ops / t_conv / peak, "traffic": traffic, "traffic_note": traffic_note,
         # the same launches against the peak at the engine clock they were MEASURED to run at (the fraction above divides by
@@ -231,12 +234,25 @@ def conv_c2_roofline(device, info, batch=256, iters=50, act_kind="relu", nonneg=
     }
 
 
+def as_worded(roof):
+    """`roofline_config2_as_worded`: BASELINE config 2 literally — fp32 NCHW in -> fp32 NCHW out, ONE launch — as a record
+    of its own with SURVEY 8(d)'s algorithmic bytes (411 MB in + 411 MB out + weights = 822.7 MB)."""
+    f = roof["fp32_in_fp32_out"]
+    return {"bound": "int_alu", "kernel": f["kernel"], "workload": "conv3x3 128->128 56x56 b256, fp32 NCHW in -> fp32 NCHW out, "
+            "one bnn_hip_bconv2d_direct launch (sign(x) on the fly into LDS)",
+            "achieved": f["frac"] * roof["peak"], "peak": roof["peak"], "unit": roof["unit"], "frac": f["frac"],
+            "frac_at_measured_clock": f["frac_at_measured_clock"], "avg_kernel_us": f["us"],
+            "algorithmic_bytes": f["algorithmic_bytes"], "GBps": f["GBps"], "hbm_floor_us": f["algorithmic_bytes"] / 8e12 * 1e6,
+            "traffic": f["traffic"], "traffic_note": f["traffic_note"], "timed_launches": roof["timed_launches"],
+            "engine_clock_mhz": roof["engine_clock_mhz"], "two_launch_form": f["two_launch_form"]}
+
+
 def pmc_traffic():
     """HBM bytes per launch of the graded kernel from the committed rocprofv3 PMC passes
     (profiles/rNN_c2_pmc_counters.json, collected by tools/gpu_profile.sh with separate --pmc runs).
     FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
     (checked on this box: pack_act's 411 MB float4 stream reads as 205 MB)."""
-    for name in ("r05_c2_pmc_counters.json", "r04_c2_pmc_counters.json", "r03_c2_pmc_counters.json", "r02_c2_pmc_counters.json",
+    for name in ("r06_c2_pmc_counters.json", "r05_c2_pmc_counters.json", "r04_c2_pmc_counters.json", "r03_c2_pmc_counters.json", "r02_c2_pmc_counters.json",
                  "r01_c2_pmc_counters.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
@@ -252,7 +268,7 @@ def pmc_traffic():
 def fly_traffic():
     """HBM bytes per launch of the one-launch layer kernel from its committed PMC passes
     (profiles/rNN_c2_fused_pmc.json: 2*FETCH_SIZE + WRITE_SIZE, KiB, same correction as above)."""
-    for name in ("r05_c2_fused_pmc.json", "r04_c2_fused_pmc.json", "r03_c2_fused_pmc.json"):
+    for name in ("r06_c2_fused_pmc.json", "r05_c2_fused_pmc.json", "r04_c2_fused_pmc.json", "r03_c2_fused_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 k = json.load(fh)
@@ -459,7 +475,19 @@ def gpu_c1(device):
             torch.cuda.synchronize(device)
             dtl = (time.perf_counter() - t0) / 20
     assert y.shape == (32, 1000)
-    return {"value": 32 / dt, "unit": "images/s", "ms_per_batch": dt * 1e3, "engine": "net_call (stem launch + HIP graph)",
+    # the logits of the last timed call against the reference's own forward of the same batch (tests/golden/resnet18.npz:
+    # c1_logits_j, generated by importing the reference: tests/golden/make_golden.py `resnet18`)
+    check = None
+    fx_path = os.path.join(ROOT, "tests", "golden", "resnet18.npz")
+    if os.path.exists(fx_path):
+        ref = np.load(fx_path)["c1_logits_%d" % ((n - 1) % 4)]
+        dev_ = np.abs(y.float().cpu().numpy() - ref)
+        ok = np.all(dev_ <= 1e-3 * np.abs(ref).max() + 1e-3 * np.abs(ref), 1)
+        check = {"images": 32, "within_1e-3_of_reference": int(ok.sum()), "max_abs_dev": float(dev_.max()),
+                 "max_abs_logit": float(np.abs(ref).max()),
+                 "note": "images outside the tolerance had a sign() decided by fp32 rounding (DESIGN.md section 2)"}
+        assert ok.sum() >= 24, check
+    return {"value": 32 / dt, "logits_vs_reference": check, "unit": "images/s", "ms_per_batch": dt * 1e3, "engine": "net_call (stem launch + HIP graph)",
             "calls": dict(st), "layerwise": {"value": 32 / dtl, "ms_per_batch": dtl * 1e3}}
 
 
@@ -507,6 +535,7 @@ def bench_c2(args, world, rank, device, info, timed):
         rec["sustained"] = sustained
     if roof is not None:
         rec["roofline"] = roof
+        rec["roofline_config2_as_worded"] = as_worded(roof)
         rec["packed_input_only"] = {"images_per_s": roof["images_per_s_kernel"], "us": roof["avg_kernel_us"],
                                     "frac": roof["frac"]}
     return rec
@@ -728,8 +757,17 @@ def bench_net(args, world, rank, device, info, timed):
         rec["gather_check"] = gather_check
     if not c5:
         rec["net_int_alu_frac"] = value / world * R18_LANE_OPS_PER_IMG / int_alu_peak(info)
+    else:
+        # the 51 binary convolutions of ResNet(HBlock,[3,4,6,3]): 2 * ceil(9 C_in / 32) lane-ops per output, dense words
+        # (tools/c5_roofline.py recomputes the figure layer by layer)
+        rec["c5_int_alu_frac"] = value / world * C5_LANE_OPS_PER_IMG / int_alu_peak(info)
+        rec["c5_lane_ops_per_image"] = C5_LANE_OPS_PER_IMG
+        if "one_batch_at_a_time" in rec:
+            rec["one_batch_at_a_time"]["c5_int_alu_frac"] = \
+                rec["one_batch_at_a_time"]["value"] / world * C5_LANE_OPS_PER_IMG / int_alu_peak(info)
     if not args.no_roofline:
         rec["roofline"] = conv_c2_roofline(device, info, act_kind="relu")
+        rec["roofline_config2_as_worded"] = as_worded(rec["roofline"])
         rec["roofline_normal_input"] = {k: v for k, v in conv_c2_roofline(device, info, act_kind="normal").items()
                                         if k in ("achieved", "frac", "avg_kernel_us")}
         rec["roofline_relu_input_nonneg_kernel"] = {

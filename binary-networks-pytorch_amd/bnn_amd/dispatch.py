@@ -16,7 +16,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from . import native
+from . import fastpath, native
 from . import tails as _tails
 from .executor import FusedBlocks, FusedResNet, FusionError, is_native_model, resnet_shaped, tap_binary_inputs
 from .pipeline import TwoHalves
@@ -64,7 +64,7 @@ class BlockFusion:
     def run(self, block: nn.Module, x: torch.Tensor) -> Optional[torch.Tensor]:
         if (block.training or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4
                 or x.shape[0] == 0 or getattr(block, "_is_replica", False) or _tails._PER_LAYER
-                or os.environ.get("BNN_AMD_AUTOFUSE", "1") == "0" or not native.available()):
+                or os.environ.get("BNN_AMD_AUTOFUSE", "1") == "0" or fastpath.strict_weights() or not native.available()):
             self.calls["declined"] += 1
             return None
         with self.lock:
@@ -166,6 +166,12 @@ class AutoFusion:
 
     def reset(self) -> None:
         with self.lock:
+            # replays of the executors' HIP graphs may still be in flight on their side streams (two halves of a batch,
+            # the shortcut stream): wait for them before the graphs and their static buffers are released
+            for e in [self.engine] + [v[1] for v in self.replica_engines.values()]:
+                p = next(e.parameters(), None) if isinstance(e, nn.Module) else None
+                if p is not None and p.is_cuda:
+                    torch.cuda.synchronize(p.device)
             self.engine, self.failed_sig, self.reason, self.verified = None, None, None, False
             self.seen.clear()
             self.replica_engines.clear()
@@ -173,7 +179,8 @@ class AutoFusion:
 
     @staticmethod
     def enabled() -> bool:
-        return _tails._PER_LAYER == 0 and _NO_MODEL_FUSION == 0 and os.environ.get("BNN_AMD_AUTOFUSE", "1") != "0"
+        return (_tails._PER_LAYER == 0 and _NO_MODEL_FUSION == 0 and os.environ.get("BNN_AMD_AUTOFUSE", "1") != "0"
+                and not fastpath.strict_weights())       # (strict: nothing derived from the weights outlives a call)
 
     @staticmethod
     def _hooked(model: nn.Module) -> bool:

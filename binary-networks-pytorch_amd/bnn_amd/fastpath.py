@@ -24,6 +24,7 @@ of truth (reference: ``bnn/layers/conv.py:111-112`` shares it with the float mod
 """
 from __future__ import annotations
 
+import os
 import threading
 import warnings
 from dataclasses import dataclass
@@ -47,6 +48,17 @@ def stats() -> dict:
 def _bump(key: str) -> None:
     with _stats_lock:
         _stats[key] += 1
+
+
+def strict_weights() -> bool:
+    """``BNN_AMD_STRICT_WEIGHTS=1``: derived weight data is never cached — every forward of every binary layer re-derives
+    sign bits, zero mask and alpha from the CURRENT values of ``weight`` and reads the zero-weight flag before it
+    launches, exactly as the reference re-binarises on every forward (bnn/layers/conv.py:92, bnn/ops.py:129-140).
+    Writes through ``.data`` need no ``invalidate()`` then, and a training step never runs on an unverified "no exact
+    zero" assumption.  The price is one packing launch and one host round trip per layer and call, and ``model(x)``
+    stays on the per-layer tier (the fused executors and their HIP graphs hold derived data by construction):
+    README.md has the measured cost.  Read at every call, so tests can flip it."""
+    return os.environ.get("BNN_AMD_STRICT_WEIGHTS", "0") == "1"
 
 
 @dataclass
@@ -159,6 +171,8 @@ def packed_weight(layer, plan: Plan, sync: bool = True, fresh: bool = False) -> 
     travels to pinned host memory asynchronously.  It is resolved by the NEXT call for this layer — a training
     call checks the previous step's flag (long since on the host), an inference call (``sync=True``) waits for
     it — and a layer that ever showed a zero is packed synchronously (mask-aware kernel) from then on."""
+    if strict_weights():
+        sync, fresh = True, True
     master = layer.__dict__.get("_bnn_master")
     if master is not None:          # a DataParallel replica: cached on the layer it was replicated from
         return _replica_packed_weight(layer, master, plan, fresh)
@@ -219,6 +233,9 @@ def invalidate(module: nn.Module) -> int:
         if m.__dict__.pop("_bnn_packed", None) is not None:
             n += 1
         m.__dict__.pop("_bnn_packed_replicas", None)
+        m.__dict__.pop("_bnn_auto_block", None)      # a residual block's own fused executor (dispatch.BlockFusion)
+    from .tails import drop_derived                 # folded BatchNorms / transposed head weights of the per-layer tails
+    drop_derived(module)
     return n
 
 

@@ -260,9 +260,11 @@ def stem7x7_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     fp32 products on the matrix cores, partial sums added in index order — the same bits on every run."""
     x = _require_cuda_f32(x, "stem input")
     dy = _require_cuda_f32(dy, "stem output gradient")
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise native.NativeError(f"bnn_amd: stem7x7_wgrad expects x [N,3,H,W], got {tuple(x.shape)}")
     N, _, H, W = x.shape
     hc, wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    if x.dim() != 4 or x.shape[1] != 3 or tuple(dy.shape) != (N, 64, hc, wc):
+    if tuple(dy.shape) != (N, 64, hc, wc):
         raise native.NativeError("bnn_amd: stem7x7_wgrad expects x [N,3,H,W] and dy [N,64,Hc,Wc]")
     lib = native.require()
     with torch.cuda.device(x.device):

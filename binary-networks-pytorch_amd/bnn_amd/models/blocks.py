@@ -72,6 +72,17 @@ class _Residual(nn.Module):
             return _bn_act(ds[1](pooled), ds[2])         # AvgPool -> conv1x1 -> BN (bnn/models/resnet.py:128-133)
         return ds(x)
 
+    def train(self, mode: bool = True):
+        # train() <-> eval(): what was derived from the block's parameters and buffers goes with the mode — the block
+        # tier's executor (packed weights, folded BatchNorm constants, thresholds) and the per-layer tails' folded
+        # BatchNorms: `.data` writes made while training (clamps, EMA swaps) reach the first evaluation forward
+        # (layers/_base.py: BinaryLayerMixin.train gives the same guarantee for the packed weights)
+        if bool(mode) != self.training:
+            self.__dict__.pop("_bnn_auto_block", None)
+            from ..tails import drop_derived
+            drop_derived(self)
+        return super().train(mode)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.training and x.is_cuda and not torch.is_grad_enabled():
             y = _fused(self, x)

@@ -129,18 +129,23 @@ class StochasticInputBinarizer(BinarizerBase):
 
 
 class AdvancedInputBinarizer(BinarizerBase):
-    """``sign(f(t*x))`` with the gradient of ``f`` (``bnn/ops.py:167-177``)."""
+    """``sign(f(t*x))`` (``bnn/ops.py:167-177``).  As upstream, the sign is taken under ``torch.no_grad()``: the result
+    carries NO gradient path (the reference returns a tensor that does not require grad, so a layer using this hook
+    trains its weights but passes nothing back through its input).  ``soft_gradient=True`` (an extension, off by
+    default) gives the value of ``sign(f(t*x))`` with the gradient of ``f(t*x)`` — what the class name suggests."""
 
-    def __init__(self, derivative_funct=torch.tanh, t: int = 5) -> None:
+    def __init__(self, derivative_funct=torch.tanh, t: int = 5, soft_gradient: bool = False) -> None:
         super().__init__()
         self.derivative_funct = derivative_funct
         self.t = t
+        self.soft_gradient = soft_gradient
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         soft = self.derivative_funct(x * self.t)
-        # value: exactly sign(soft); gradient: that of `soft` (the reference computes the sign
-        # under no_grad and therefore returns a tensor without any gradient path).
-        return torch.sign(soft).detach() + (soft - soft.detach())
+        if self.soft_gradient:
+            return torch.sign(soft).detach() + (soft - soft.detach())
+        with torch.no_grad():
+            return torch.sign(soft)
 
 
 class BasicScaleBinarizer(BinarizerBase):

@@ -10,7 +10,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from . import hipops
+from . import fastpath, hipops
 from .executor import _is_float_layer, _is_float_layer_linear, fold_bn
 
 
@@ -67,12 +67,20 @@ _FOLDS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 _HEAD_WEIGHTS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
 
+def drop_derived(module: nn.Module) -> None:
+    """Forget the folded BatchNorm constants and transposed head weights of every module under ``module`` (mode switches,
+    ``fastpath.invalidate``): they are keyed on version counters, which writes through ``.data`` do not move."""
+    for m in module.modules():
+        _FOLDS.pop(m, None)
+        _HEAD_WEIGHTS.pop(m, None)
+
+
 def cached_fold(bn: nn.BatchNorm2d):
     """``fold_bn(bn)`` on ``bn``'s device, kept until one of the module's four tensors is written or replaced."""
     ts = (bn.running_mean, bn.running_var, bn.weight, bn.bias)
     key = tuple((id(t), t._version, t.data_ptr()) if t is not None else None for t in ts) + (bn.eps,)
     c = _FOLDS.get(bn)
-    if c is None or c[0] != key:
+    if c is None or c[0] != key or fastpath.strict_weights():
         c = _FOLDS[bn] = (key, fold_bn(bn))
     return c[1]
 
@@ -132,7 +140,7 @@ def eval_head(model: nn.Module, x: torch.Tensor) -> Optional[torch.Tensor]:
     w = fc.weight
     key = (id(w), w._version, w.data_ptr())
     c = _HEAD_WEIGHTS.get(fc)
-    if c is None or c[0] != key:
+    if c is None or c[0] != key or fastpath.strict_weights():
         c = _HEAD_WEIGHTS[fc] = (key, w.detach().t().contiguous())
     return hipops.avgpool_fc(x, c[1], None if fc.bias is None else fc.bias.detach())
 

@@ -20,6 +20,7 @@ stand in a training graph.
 from __future__ import annotations
 
 import collections
+import threading
 import weakref
 from typing import List, Optional, Tuple
 
@@ -32,6 +33,10 @@ _NS = "bnn_amd"
 
 _PACK_CACHE: "collections.OrderedDict" = collections.OrderedDict()
 _PACK_CACHE_MAX = 256
+# nn.DataParallel calls the ops from one thread per GPU (examples/cifar10.py:76) and the weak-reference callbacks run on
+# whichever thread drops a tensor: every access to the dictionary is under this lock (re-entrant: a callback may fire
+# while the owner of the lock is inside the dictionary)
+_PACK_LOCK = threading.RLock()
 
 
 def _packed(weight: torch.Tensor, center: bool, compute_alpha: bool) -> hipops.PackedWeight:
@@ -44,24 +49,39 @@ def _packed(weight: torch.Tensor, center: bool, compute_alpha: bool) -> hipops.P
     alive: the caching allocator hands the address of a freed weight to the next tensor of the same shape, whose
     version counter is 0 again — pointer + version alone would return the previous tensor's signs and alpha."""
     key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), center, compute_alpha)
-    hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0]() is weight:
-        _PACK_CACHE.move_to_end(key)
-        return hit[1]
-    pw = hipops.pack_weight(weight, center, compute_alpha)
+    strict = fastpath_strict()
+    with _PACK_LOCK:
+        hit = None if strict else _PACK_CACHE.get(key)
+        if hit is not None and hit[0]() is weight:
+            _PACK_CACHE.move_to_end(key)
+            return hit[1]
+    pw = hipops.pack_weight(weight, center, compute_alpha)      # (outside the lock: it synchronises with the device)
+    if strict:
+        return pw
+
+    def _drop(_r, k=key):
+        with _PACK_LOCK:
+            _PACK_CACHE.pop(k, None)
     try:
-        ref = weakref.ref(weight, lambda _r, k=key: _PACK_CACHE.pop(k, None))   # dropped with its tensor
+        ref = weakref.ref(weight, _drop)   # dropped with its tensor
     except TypeError:       # (fake / functional tensor wrappers): not cacheable
         return pw
-    _PACK_CACHE[key] = (ref, pw)
-    _PACK_CACHE.move_to_end(key)
-    while len(_PACK_CACHE) > _PACK_CACHE_MAX:
-        _PACK_CACHE.popitem(last=False)
+    with _PACK_LOCK:
+        _PACK_CACHE[key] = (ref, pw)
+        _PACK_CACHE.move_to_end(key)
+        while len(_PACK_CACHE) > _PACK_CACHE_MAX:
+            _PACK_CACHE.popitem(last=False)
     return pw
 
 
+def fastpath_strict() -> bool:
+    from . import fastpath
+    return fastpath.strict_weights()
+
+
 def clear_cache() -> None:
-    _PACK_CACHE.clear()
+    with _PACK_LOCK:
+        _PACK_CACHE.clear()
 
 
 def _need_gpu(*ts: Optional[torch.Tensor]) -> None:

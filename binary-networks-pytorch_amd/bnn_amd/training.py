@@ -239,7 +239,9 @@ def stem_conv_applies(conv: nn.Module, x: torch.Tensor) -> bool:
             and conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros"
             and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
             and conv.weight.dtype == torch.float32 and torch.is_grad_enabled()
-            and not conv._forward_hooks and not conv._forward_pre_hooks and not conv._backward_hooks)
+            and not conv._forward_hooks and not conv._forward_pre_hooks and not conv._backward_hooks
+            and not conv._backward_pre_hooks          # (they would not fire on the fused path)
+            and not torch.is_autocast_enabled())      # (under AMP the reference's conv returns fp16: the module itself)
 
 
 def stem_conv(x: torch.Tensor, conv: nn.Module) -> torch.Tensor:

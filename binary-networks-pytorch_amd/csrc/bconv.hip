@@ -130,7 +130,10 @@ __global__ __launch_bounds__(64, MINW) void bconv_sgpr_kernel(
       [[maybe_unused]] int midt_a[NACC];
       if constexpr (MIDT2) {
         // (unconditional: under `if (fullb)` the compiler zero-initialises the eight registers first — eight v_mov and a
-        // wait for every earlier load; channels past O lie beyond the descriptor's range and read as 0, unused)
+        // wait for every earlier load.  The loads of channels past O are safe because the TABLE is padded to whole
+        // 32-channel blocks (bnn_hip_sign_thresholds_f32 writes o_pad rows; capi.hip documents the size) and the block
+        // is guarded by ob * kOCB < O — not because of the descriptor: the offset travels in `soffset`, which raw
+        // buffers do not range-check)
         const BufRsrc rt = make_rsrc_sized(epi.thr, (unsigned)((g.O + kOCB - 1) / kOCB * kOCB) * (unsigned)(kThrStride * 4));
 #pragma unroll
         for (int j = 0; j < NACC; ++j)

@@ -426,7 +426,7 @@ struct HbShape {
 };
 
 bool hb_shape(int C_in, int planes, HbShape& s) {
-  if (C_in <= 0 || planes < 64 || planes % 64 != 0 || planes > 4096) return false;
+  if (C_in <= 0 || C_in > (1 << 20) || planes < 64 || planes % 64 != 0 || planes > 4096) return false;
   s.cin[0] = C_in; s.cin[1] = planes / 2; s.cin[2] = planes / 4;
   s.O[0] = planes / 2; s.O[1] = planes / 4; s.O[2] = planes / 4;
   for (int k = 0; k < 3; ++k) {

@@ -132,10 +132,12 @@ __global__ __launch_bounds__(tail2::ROWS) void avgpool_rows_kernel(const float* 
       for (int q = 0; q < HW; ++q) s += p[q];
     }
   }
+  // rows of the images that pad the last group of IMG (the grid covers them): zeros — fc_ws_kernel stages whole groups
   const long long r = r0 + tid;
-  if (r < rows) {
+  const long long rows_pad = (((long long)N + IMG - 1) / IMG) * IMG * C;
+  if (r < rows_pad) {
     const int n = (int)(r / C), c = (int)(r - (long long)n * C);
-    mt[((size_t)(n / IMG) * C + c) * IMG + (n % IMG)] = s / (float)HW;
+    mt[((size_t)(n / IMG) * C + c) * IMG + (n % IMG)] = r < rows ? s / (float)HW : 0.0f;
   }
 }
 
@@ -217,7 +219,7 @@ bool avgpool_fc_ws_supported(int C, int HW) {
 int launch_avgpool_fc_ws(const float* x, const float* wt, const float* bias, float* out, float* ws, int N, int C,
                          int HW, int O, hipStream_t stream) {
   using namespace tail2;
-  const long long rows = (long long)N * C;
+  const long long rows = (((long long)N + IMG - 1) / IMG) * IMG * C;  // incl. the pad images of the last group (zeros)
   const unsigned gridA = (unsigned)((rows + ROWS - 1) / ROWS);
   if (HW == 49) {
     hipLaunchKernelGGL(avgpool_rows_kernel<49>, dim3(gridA), dim3(ROWS), ROWS * 49 * sizeof(float), stream, x, ws, N, C,

@@ -151,6 +151,14 @@ def make_resnet18():
             y = net(t(x)).numpy()
         blob["logits_" + tag] = y
         print("resnet18", tag, y.shape, float(np.abs(y).max()))
+    # BASELINE config 1 at its stated size (examples/cifar10.py model, 32 x 32 inputs, batch 32): the four batches
+    # bench.py's gpu_c1 leg feeds (gen.normal(40 + j, ...)), logits + sign checksums in front of the 19 binary convolutions
+    for j in range(4):
+        y, names, h = _binary_inputs(net, gen.normal(40 + j, (32, 3, 32, 32)), batch=32)
+        blob["c1_logits_%d" % j] = y
+        blob["c1_sign_hash_%d" % j] = h
+        blob["c1_layers"] = np.array(names)
+        print("resnet18 c1 batch", j, y.shape, h.shape)
     blob["state_keys"] = np.array(list(net.state_dict().keys()))
     blob["module_types"] = np.array([f"{n}:{type(m).__name__}" for n, m in net.named_modules()])
     np.savez_compressed(os.path.join(HERE, "resnet18.npz"), **blob)
@@ -362,14 +370,14 @@ class RefHBlockNet(nn.Module):
 
 
 def make_hblock_net():
-    """G10: config 5 at its real size pinned to the reference's modules (task 6): 8 images 224x224
+    """G10: config 5 at its real size pinned to the reference's modules (task 6; round 5: 32 images): 32 images 224x224
     through RefHBlockNet([3, 4, 6, 3]) — logits + the sign checksums in front of all 51 binary convolutions, the same
     scheme as resnet18_b256.npz — and the reference against itself (other conv backend, fp64)."""
     net = bnn.prepare_binary_model(RefHBlockNet(), xnor_cfg(), custom_config_layers_name={"conv1": bnn.BConfig(),
                                                                                          "fc": bnn.BConfig()})
     load_state(net, seed=1)
     net.eval()
-    x = gen.normal(gen.seed_of("c5", "b128"), (128, 3, 224, 224))[:8].copy()     # the first 8 images of the c5 test batch
+    x = gen.normal(gen.seed_of("c5", "b128"), (128, 3, 224, 224))[:32].copy()     # the first 32 images of the c5 test batch
     y, names, h = _binary_inputs(net, x, batch=4)
     with torch.backends.mkldnn.flags(enabled=False):
         y2, _, h2 = _binary_inputs(net, x, batch=4)
@@ -387,10 +395,10 @@ def make_hblock_net():
                   "ref_onednn_vs_ref_native_conv": compare(y2, h2, y, h), "ref_fp32_vs_ref_fp64": compare(y, h, y64, h64)}
     print(json.dumps(self_check, indent=1))
     assert len(names) == 3 * 16 + 3, names
-    np.savez_compressed(os.path.join(HERE, "hblock_net_b8.npz"), logits=y, sign_hash=h, logits_f64=y64, sign_hash_f64=h64,
+    np.savez_compressed(os.path.join(HERE, "hblock_net_b32.npz"), logits=y, sign_hash=h, logits_f64=y64, sign_hash_f64=h64,
                         layers=np.array(names), state_keys=np.array(list(net.state_dict().keys())),
                         self_check=np.array(json.dumps(self_check)))
-    print("hblock_net_b8", y.shape, h.shape)
+    print("hblock_net_b32", y.shape, h.shape)
 
 
 GRAD_CASES = ("c2_relu", "l2_0_c1_s2", "l3_ds_1x1")

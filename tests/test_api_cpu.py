@@ -270,7 +270,12 @@ def test_ste_backward_and_other_binarizers():
     SignActivation.apply(x).sum().backward()
     assert x.grad.tolist() == [0, 1, 1, 1, 0]
     y = AdvancedInputBinarizer()(torch.tensor([-0.3, 0.2], requires_grad=True))
-    assert y.tolist() == [-1.0, 1.0] and y.requires_grad
+    assert y.tolist() == [-1.0, 1.0] and not y.requires_grad      # as upstream (bnn/ops.py:174-176): sign under no_grad
+    xs = torch.tensor([-0.3, 0.2], requires_grad=True)
+    ys = AdvancedInputBinarizer(soft_gradient=True)(xs)
+    assert ys.tolist() == [-1.0, 1.0] and ys.requires_grad
+    ys.sum().backward()
+    assert torch.allclose(xs.grad, 5 * (1 - torch.tanh(5 * xs.detach()) ** 2))
     z = StochasticInputBinarizer()(torch.randn(100))
     assert set(z.unique().tolist()) <= {-1.0, 1.0}
 

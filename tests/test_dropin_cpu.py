@@ -204,3 +204,51 @@ def test_switching_between_training_and_evaluation_drops_derived_data():
     net.layer1[0].conv1.__dict__["_bnn_packed"] = ("key", "pack")
     net.eval()
     assert st.engine is None and not st.verified and "_bnn_packed" not in net.layer1[0].conv1.__dict__
+
+
+def test_mode_switch_and_invalidate_also_drop_the_block_tier_and_the_tails_constants():
+    """the block tier's executor (`_bnn_auto_block`) and the per-layer tails' folded BatchNorms / transposed
+    head weight are derived data as well — a mode switch of a block (or of the whole model) and `fastpath.invalidate` drop
+    them, so that `.data` writes made while training reach the first evaluation forward on EVERY tier."""
+    from bnn_amd import fastpath, tails
+    net = _prepare(resnet18())
+    blk = net.layer1[0]
+    blk.__dict__["_bnn_auto_block"] = object()
+    tails._FOLDS[blk.bn1] = ("key", "fold")
+    tails._HEAD_WEIGHTS[net.fc] = ("key", "wt")
+    blk.eval()                                      # no switch: nothing dropped
+    assert "_bnn_auto_block" in blk.__dict__ and blk.bn1 in tails._FOLDS
+    net.train()
+    assert "_bnn_auto_block" not in blk.__dict__ and blk.bn1 not in tails._FOLDS
+    assert net.fc in tails._HEAD_WEIGHTS            # (the head belongs to the model, not to a block ...)
+    blk.__dict__["_bnn_auto_block"] = object()
+    tails._FOLDS[blk.bn2] = ("key", "fold")
+    assert fastpath.invalidate(net) == 0
+    assert "_bnn_auto_block" not in blk.__dict__ and blk.bn2 not in tails._FOLDS and net.fc not in tails._HEAD_WEIGHTS
+
+
+def test_strict_weights_mode_keeps_nothing_derived(monkeypatch):
+    """`BNN_AMD_STRICT_WEIGHTS=1`: the reference's behaviour (re-binarise on every forward, bnn/layers/conv.py:92) — the
+    fused tiers decline, and the packed-weight lookups ask for a fresh, synchronous pack every time."""
+    from bnn_amd import dispatch, fastpath
+    assert not fastpath.strict_weights() and AutoFusion.enabled()
+    monkeypatch.setenv("BNN_AMD_STRICT_WEIGHTS", "1")
+    assert fastpath.strict_weights() and not AutoFusion.enabled()
+    calls = []
+    monkeypatch.setattr(fastpath.hipops, "pack_weight", lambda w, c, a, sync=True: calls.append(sync) or
+                        type("PW", (), {"has_zero": False, "zero_probe": None})())
+    import torch.nn as nn
+    layer = bnn.prepare_binary_model(nn.Conv2d(8, 8, 3), _cfg()).eval()
+    plan = fastpath._recognise(layer, 8)
+    fastpath.packed_weight(layer, plan, sync=False)
+    fastpath.packed_weight(layer, plan, sync=False)
+    assert calls == [True, True]                    # never cached, never on an unverified "no exact zero" assumption
+    monkeypatch.delenv("BNN_AMD_STRICT_WEIGHTS")
+    calls.clear()
+    fastpath.invalidate(layer)
+    fastpath.packed_weight(layer, plan)
+    fastpath.packed_weight(layer, plan)
+    assert calls == [True]                          # the default: packed once per weight version
+    blk = dispatch.BlockFusion()
+    monkeypatch.setenv("BNN_AMD_STRICT_WEIGHTS", "1")
+    assert blk.run(_prepare(resnet18()).layer1[0], torch.zeros(1, 64, 8, 8)) is None

@@ -557,3 +557,43 @@ def test_net_call_inside_a_callers_own_graph_capture(tier):
         assert torch.equal(y, w)
     if tier == "model":
         assert auto_fusion(net).calls["eager"] >= 2         # the first call + the captured one
+
+
+def test_config1_batch32_against_the_reference_fixture():
+    """BASELINE config 1 at its stated size on the GPU (examples/cifar10.py model, 32 x 32 inputs, batch 32): the four
+    batches bench.py's `gpu_c1` leg times, through the reference's own call `net(x)`, against the reference's logits and
+    the sign checksums in front of its 19 binary convolutions (tests/golden/resnet18.npz: c1_*, from
+    tests/golden/make_golden.py `resnet18`).  Same strict / counted split as config 3: an image whose checksums all equal
+    the reference's is within 1e-3 (measured 1e-6); images with a flipped sign are counted."""
+    import os
+    import numpy as np
+    from tests.golden import gen, sighash
+    from bnn_amd import inference
+    from bnn_amd.inference import FusedResNet
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resnet18.npz"))
+    names = [str(n) for n in fx["c1_layers"]]
+    net = _r18()
+    flipped_total = 0
+    for j in range(4):
+        x = torch.from_numpy(gen.normal(40 + j, (32, 3, 32, 32))).to(DEV)
+        with torch.no_grad():
+            y = net(x)                                   # the drop-in call: fused executor (eager, then stem + graph)
+            y2 = net(x)
+        assert torch.equal(y, y2)
+        hashes = {}
+        with inference.tap_binary_inputs(lambda n, a: hashes.__setitem__(n, sighash.sign_hash_planes(a.P, a.M, a.shape[1]))):
+            yt = FusedResNet(net)(x)
+        assert torch.equal(yt, y)
+        h = torch.stack([hashes[n] for n in names], 1).cpu().numpy()
+        ref, href = fx["c1_logits_%d" % j], fx["c1_sign_hash_%d" % j]
+        flipped = np.any(h != href, 1)
+        dev_ = np.abs(y.cpu().numpy() - ref)
+        ok = np.all(dev_ <= 1e-3 * np.abs(ref).max() + 1e-3 * np.abs(ref), 1)
+        assert ok[~flipped].all()
+        assert dev_[~flipped].max() <= 1e-4 * np.abs(ref).max()
+        flipped_total += int(flipped.sum())
+    print({"c1_images_with_a_sign_flip_of_128": flipped_total})
+    assert flipped_total <= C1_FLIPPED
+
+
+C1_FLIPPED = 6          # placeholder until measured

@@ -66,7 +66,7 @@ def test_capi_validators_survive_an_argument_fuzz_under_asan_and_ubsan():
 
 def test_require_loads_and_reports_abi():
     lib = native.require()
-    assert lib.bnn_hip_abi_version() == native.ABI_VERSION == 14
+    assert lib.bnn_hip_abi_version() == native.ABI_VERSION == 15
     assert lib.bnn_hip_status_string(0) == b"ok"
     assert b"invalid" in lib.bnn_hip_status_string(-1)
     assert isinstance(native.launch_count(), int)

@@ -143,11 +143,11 @@ for n in ("layerwise_library", "layerwise", "fused", "fused_exact_stem"):     # 
         rec = json.load(open(fn))
         rec["provenance"] = STAMP
         json.dump(rec, open(os.path.join(dst, f"{tag}_c3_b256_parity_{n}.json"), "w"), indent=1)
-fn = os.path.join(ROOT, "gpurun_out", "c5_b8_parity.json")      # tests/test_gpu_c3_full.py::test_c5_hblock_3463_at_its_stated_size
+fn = os.path.join(ROOT, "gpurun_out", "c5_b32_parity.json")      # tests/test_gpu_c3_full.py::test_c5_hblock_3463_at_its_stated_size
 if os.path.exists(fn) and fresh([fn]):
     rec = json.load(open(fn))
     rec["provenance"] = STAMP
-    json.dump(rec, open(os.path.join(dst, f"{tag}_c5_b8_parity.json"), "w"), indent=1)
+    json.dump(rec, open(os.path.join(dst, f"{tag}_c5_b32_parity.json"), "w"), indent=1)
 # clocks / power under load, two-stream timeline (tools/power_and_overlap.sh)
 for name, out_name in (("overlap.txt", "two_stream_overlap.txt"), ("summary.txt", "clock_power_under_load.txt")):
     fn = os.path.join(ROOT, "gpurun_out", "power", name)

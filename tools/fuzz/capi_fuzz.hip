@@ -92,6 +92,51 @@ int launch_bn_act_pack(const float* x, int N, int C, int H, int W, const float* 
 int launch_avgpool_pack(const float* x, int N, int C, int H, int W, int k, uint64_t* P, uint64_t* M, hipStream_t) {
   ++g_reached; REQUIRE(x && P && M && N > 0 && C > 0 && H > 0 && W > 0 && k > 0 && al(P, 8) && al(M, 8)); return BNN_HIP_OK;
 }
+int launch_avgpool2_bn_pack2(const float* x, int N, int C, int H, int W, const float* a1, const float* b1, int, uint64_t* P1,
+                             uint64_t* M1, const float* a2, const float* b2, int, uint64_t* P2, uint64_t* M2, float* out,
+                             hipStream_t) {
+  ++g_reached;
+  REQUIRE(x && a1 && b1 && P1 && M1 && N > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && al(x, 8));
+  REQUIRE((a2 == nullptr) == (b2 == nullptr) && (!a2 || (P2 && M2 && al(P2, 8) && al(M2, 8))) && al(P1, 8) && al(M1, 8));
+  REQUIRE((long long)N * C * H * W <= (1LL << 31) - 1 && (!out || al(out, 4)));
+  return BNN_HIP_OK;
+}
+// csrc/hblock.hip: the shape rule and the launch contract of the one-launch hierarchical block
+static bool stub_hb_shape(int C_in, int planes) {
+  if (C_in <= 0 || C_in > (1 << 20) || planes < 64 || planes % 64 || planes > 4096) return false;
+  const int cin[3] = {C_in, planes / 2, planes / 4};
+  for (int k = 0; k < 3; ++k) {
+    const int cw = (cin[k] + 31) / 32;
+    if (cw == 3 || (cw > 4 && cw % 4)) return false;
+  }
+  const int cw0 = (C_in + 31) / 32;
+  return cw0 == 1 ? C_in <= 32 : cw0 % 2 == 0;
+}
+bool hblock_supported(const bnn_hip_hblock_desc* d) {
+  REQUIRE(d && d->N > 0 && d->C_in > 0 && d->H > 0 && d->W > 0 && d->planes > 0 && d->waves >= 0 && d->waves <= 16);
+  REQUIRE((long long)d->N * d->planes < (1LL << 23) && (long long)d->H * d->W < (1LL << 23));
+  return stub_hb_shape(d->C_in, d->planes) && (long long)(d->H + 6) * (d->W + 2) * ((d->C_in + 31) / 32) * 4 < 160 * 1024;
+}
+int hblock_layout(int C_in, int planes, bnn_hip_hblock_layout* L) {
+  REQUIRE(L && C_in > 0 && planes > 0);
+  if (!stub_hb_shape(C_in, planes)) return BNN_HIP_ERR_UNSUPPORTED;
+  L->weight_words = 9LL * ((C_in + 31) / 32) * (planes / 2) + 9LL * ((planes / 2 + 31) / 32) * (planes / 4) +
+                    9LL * ((planes / 4 + 31) / 32) * (planes / 4);
+  L->const_floats = 4LL * planes;
+  return BNN_HIP_OK;
+}
+int launch_hblock_pack_weights(int C_in, int planes, const uint32_t* const w[3], uint32_t* dst, hipStream_t) {
+  ++g_reached; REQUIRE(C_in > 0 && planes > 0 && w[0] && w[1] && w[2] && dst && al(dst, 64));
+  return stub_hb_shape(C_in, planes) ? BNN_HIP_OK : BNN_HIP_ERR_UNSUPPORTED;
+}
+int launch_hblock(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc, const float* res,
+                  float* out, uint64_t* outP, hipStream_t) {
+  ++g_reached;
+  REQUIRE(d && inP && W && Kc && res && out && res != out && al(inP, 8) && al(W, 64) && (!outP || al(outP, 8)));
+  REQUIRE(stub_hb_shape(d->C_in, d->planes) && (long long)d->N * d->planes * d->H * d->W <= kConvElems);
+  REQUIRE((long long)d->N * ((d->C_in + 63) / 64) * d->H * d->W <= kPlaneWords);
+  return BNN_HIP_OK;
+}
 int launch_orpool_packed(const uint64_t* P, int N, int C, int H, int W, int k, uint64_t* oP, uint64_t* oM, hipStream_t) {
   ++g_reached; REQUIRE(P && oP && oM && N > 0 && C > 0 && H > 0 && W > 0 && k > 0 && al(P, 8) && al(oP, 8) && al(oM, 8));
   return BNN_HIP_OK;
@@ -287,7 +332,7 @@ int main(int argc, char** argv) {
   for (long it = 0; it < iters; ++it) {
     ++g_calls;
     int st = 0;
-    switch (rnd() % 35) {
+    switch (rnd() % 39) {
       case 0: { bnn_hip_conv_desc d = pick_desc();
         st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
                              pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
@@ -399,6 +444,24 @@ int main(int argc, char** argv) {
         break; }
       case 32: st = bnn_hip_avgpool2x2_backward_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(),
                                                     pick_ptr<float>(), stream); break;
+      case 34: st = bnn_hip_avgpool2_bn_pack2_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_ptr<float>(),
+                                                  pick_ptr<float>(), pick_int(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(),
+                                                  pick_ptr<float>(), pick_ptr<float>(), pick_int(), pick_ptr<uint64_t>(),
+                                                  pick_ptr<uint64_t>(), pick_ptr<float>(), stream); break;
+      case 35: { bnn_hip_hblock_desc d; int* f = reinterpret_cast<int*>(&d);
+        for (size_t i = 0; i < sizeof(d) / sizeof(int); ++i) f[i] = pick_int();
+        if (rnd() % 2) { d.planes = 64 << (rnd() % 4); d.C_in = rnd() % 2 ? d.planes : d.planes / 2; d.flags = (int)(rnd() % 2) * 64;
+                         d.rows_per_band = d.images_per_band = d.waves = 0; }
+        (void)bnn_hip_hblock_supported(rnd() % 16 ? &d : nullptr);
+        st = bnn_hip_hblock_forward(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint32_t>(), pick_ptr<float>(),
+                                    pick_ptr<float>(), pick_ptr<float>(), pick_ptr<uint64_t>(), stream);
+        break; }
+      case 36: { bnn_hip_hblock_layout L;
+        st = bnn_hip_hblock_layout_of(pick_int(), pick_int(), rnd() % 16 ? &L : nullptr);
+        if (st == BNN_HIP_OK && (L.weight_words <= 0 || L.const_floats <= 0)) broken("hblock layout");
+        break; }
+      case 37: st = bnn_hip_hblock_pack_weights(pick_int(), pick_int(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(),
+                                                pick_ptr<uint32_t>(), stream); break;
       case 33: st = bnn_hip_xnor_grad_pack_weight_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(),
                                                       pick_ptr<float>(), pick_ptr<float>(), stream); break;
       default: { bnn_hip_conv_desc d = pick_desc();
