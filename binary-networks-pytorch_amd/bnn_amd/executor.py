@@ -234,7 +234,7 @@ class FusedResNet(nn.Module):
         through ``.data`` (they bypass the counters), then ``capture`` again if a graph was captured."""
         native.require()
         m = self.model
-        fastpath.invalidate(m)
+        fastpath.invalidate(m, executors=False)
         if m.training:
             raise FusionError("FusedResNet is inference-only: call model.eval() first")
         dev = m.fc.weight.device
@@ -764,7 +764,7 @@ class FusedBlocks(FusedResNet):
 
     def refresh(self) -> None:
         native.require()
-        fastpath.invalidate(self.model)
+        fastpath.invalidate(self.model, executors=False)
         if self.model.training:
             raise FusionError("FusedBlocks is inference-only: call .eval() first")
         self._blocks = []

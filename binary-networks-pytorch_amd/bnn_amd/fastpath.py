@@ -223,7 +223,7 @@ def _replica_packed_weight(layer, master, plan: Plan, fresh: bool = False) -> hi
     return pw
 
 
-def invalidate(module: nn.Module) -> int:
+def invalidate(module: nn.Module, executors: bool = True) -> int:
     """Drop every cached packed weight under ``module`` (returns how many).  Needed after writing weights
     through ``.data`` (weight clipping ``p.data.clamp_(-1, 1)``, EMA swaps ``p.data.copy_(ema)``, hand-written
     SGD on ``.data``): those writes do not bump the Parameter's version counter, so nothing else can notice
@@ -233,7 +233,8 @@ def invalidate(module: nn.Module) -> int:
         if m.__dict__.pop("_bnn_packed", None) is not None:
             n += 1
         m.__dict__.pop("_bnn_packed_replicas", None)
-        m.__dict__.pop("_bnn_auto_block", None)      # a residual block's own fused executor (dispatch.BlockFusion)
+        if executors:       # a residual block's own fused executor (dispatch.BlockFusion); an executor that re-derives
+            m.__dict__.pop("_bnn_auto_block", None)     # ITSELF (refresh) passes False: it may be that very object
     from .tails import drop_derived                 # folded BatchNorms / transposed head weights of the per-layer tails
     drop_derived(module)
     return n

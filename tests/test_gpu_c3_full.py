@@ -178,8 +178,8 @@ def _binary_conv_names(net):
             if isinstance(m, bnn.layers.Conv2d) and isinstance(m.activation_pre_process, BasicInputBinarizer)]
 
 
-C5_FLIPPED = 1          # placeholder until measured (see the test)
-C5_FP16_ARGMAX = 24
+C5_FLIPPED = 0          # measured (round 6, MI355X): no image of the 32 differs from the reference in any sign()
+C5_FP16_ARGMAX = 32     # measured: the plain-fp16 stem keeps the class of all 32 images
 
 
 def test_c5_hblock_3463_at_its_stated_size():

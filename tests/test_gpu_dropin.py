@@ -365,9 +365,17 @@ def test_other_block_families_fuse_themselves_too(kind):
         with no_model_fusion():                 # (switches whole-model fusion off, not the blocks)
             assert torch.equal(blk(x), y)
         blk.train()
+        assert "_bnn_auto_block" not in blk.__dict__    # the mode switch drops the block's executor (derived data) ...
         blk(x)
         blk.eval()
-        assert blk.__dict__["_bnn_auto_block"].calls["fused"] == 2
+        # ... and a `.data` write made while training reaches the first evaluation forward of the block tier
+        w = blk.conv1.weight
+        w.data.neg_()
+        y_neg = blk(x)
+        assert blk.__dict__["_bnn_auto_block"].calls["fused"] == 1 and not torch.equal(y_neg, y)
+        with per_layer_forward():               # (the training-mode call above moved the BatchNorm statistics: a new reference)
+            want_neg = blk(x)
+        assert torch.allclose(y_neg, want_neg, rtol=1e-3, atol=1e-3 * float(want_neg.abs().max()))
     assert torch.allclose(y, want, rtol=1e-3, atol=1e-3 * float(want.abs().max()))
 
 
@@ -596,4 +604,4 @@ def test_config1_batch32_against_the_reference_fixture():
     assert flipped_total <= C1_FLIPPED
 
 
-C1_FLIPPED = 6          # placeholder until measured
+C1_FLIPPED = 0          # measured (round 6, MI355X): all 128 images carry the reference's integers at every layer
