@@ -89,6 +89,14 @@ def parse_args():
                          "engines, SLOW_SPIN — and 4000 for c2; 0 = none)")
     ap.add_argument("--roofline-spinup", type=int, default=1000,
                     help="untimed launches of the graded kernel in front of its event-timed launches")
+    ap.add_argument("--preflight", action="store_true",
+                    help="check what an N-GPU run needs and stop: one visible GPU per rank, the RCCL version, the "
+                         "hipDeviceCanAccessPeer matrix, the IPC mode, a two-collective smoke test with known values; "
+                         "prints one JSON line, exit code 3 when something is wrong (the same checks run in front of every "
+                         "N > 1 bench and land in `dist.preflight`)")
+    ap.add_argument("--no-rccl-log", action="store_true",
+                    help="do not turn on NCCL_DEBUG=INFO (N > 1 over RCCL: the transport / topology lines of the "
+                         "communicator setup are recorded into `dist.rccl_log`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-fp32-stem and one-batch-at-a-time lines")
@@ -113,7 +121,7 @@ from bnn_amd.inference import (FusedResNet, PipelinedInference, auto_fusion, lib
                                no_model_fusion, per_layer_forward)
 from bnn_amd.models import HBlock, ResNet, resnet18  # noqa: E402
 from bnn_amd.ops import BasicInputBinarizer, XNORWeightBinarizer  # noqa: E402
-from bnn_amd.parallel import ShardedInference, all_gather_scalar  # noqa: E402
+from bnn_amd.parallel import ShardedInference, all_gather_rows, all_gather_scalar  # noqa: E402
 from tests.golden import gen  # noqa: E402  (portable synthetic-data generator, no reference code)
 
 # ResNet-18 @224: algorithmic int lane-ops per image over all binary convs (SURVEY §A.2 / BASELINE.md §4)
@@ -310,6 +318,144 @@ def cpu_baseline():
             "c2_conv3x3_128_56x56_b256": {"value": 256 / t2, "unit": "images/s", "s_per_batch": t2}}
 
 
+def rccl_log_path(rank):
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "bnn_bench_rccl_%s_rank%d.log" % (os.environ.get("MASTER_PORT", "0"), rank))
+
+
+def enable_rccl_log(rank):
+    """NCCL_DEBUG=INFO into a per-rank file (unless the caller configured RCCL's logging already): which transport every
+    channel uses (P2P/IPC over xGMI, SHM, NET), the rings / trees RCCL built, the topology it detected."""
+    if "NCCL_DEBUG" in os.environ:
+        return None
+    path = rccl_log_path(rank)
+    try:
+        os.remove(path)
+    except OSError:
+        pass
+    os.environ["NCCL_DEBUG"] = "INFO"
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,ENV")
+    os.environ["NCCL_DEBUG_FILE"] = path
+    return path
+
+
+def read_rccl_log(path, limit=60):
+    import re
+    if not path or not os.path.exists(path):
+        return None
+    pat = re.compile(r"(via |Channel |Ring |Tree |Trees|P2P|XGMI|xGMI|SHM|NET/|Using |topology|nNodes|nRanks|comm 0x|Connected|"
+                     r"RCCL version|NCCL version|hipDev|busId)")
+    seen, out = set(), []
+    with open(path, errors="replace") as fh:
+        for ln in fh:
+            ln = ln.strip()
+            msg = ln.split("NCCL INFO", 1)[-1].strip()
+            if pat.search(msg) and msg not in seen:
+                seen.add(msg)
+                out.append(msg[:200])
+    return {"lines": out[:limit], "total_matching": len(out), "file": path}
+
+
+def preflight(args, world, rank, local_rank):
+    """What an N-GPU run needs, checked without a process group: returns (record, problems)."""
+    problems = []
+    n_dev = torch.cuda.device_count()
+    rec = {"gpus_visible": n_dev, "world_size": world, "backend": args.backend,
+           "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+           "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"), "ROCR_VISIBLE_DEVICES": os.environ.get("ROCR_VISIBLE_DEVICES"),
+           "rccl_env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_")) and k != "NCCL_DEBUG_FILE"}}
+    if args.backend == "nccl":
+        if world > n_dev:
+            problems.append(f"{world} ranks but {n_dev} visible GPU(s): RCCL needs one GPU per rank")
+        try:
+            rec["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as exc:  # noqa: BLE001
+            rec["rccl_version"] = None
+            problems.append(f"no RCCL in this torch build ({exc})")
+        if world > 1 and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+            problems.append("HSA_ENABLE_IPC_MODE_LEGACY != 0: this driver only supports dmabuf IPC (hipIpcGetMemHandle fails)")
+    # hipDeviceCanAccessPeer for every pair of visible devices: xGMI peers must all see each other
+    peers = [[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(n_dev)] for i in range(n_dev)]
+    rec["peer_access"] = peers
+    if args.backend == "nccl" and world > 1:
+        missing = [(i, j) for i in range(min(world, n_dev)) for j in range(min(world, n_dev)) if not peers[i][j]]
+        if missing:
+            problems.append(f"no peer access between device pairs {missing[:8]}: RCCL would fall back to host staging")
+    try:
+        rec["devices"] = [torch.cuda.get_device_name(i) for i in range(n_dev)]
+        if len(set(rec["devices"])) > 1:
+            problems.append("the visible GPUs are not all the same model")
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        native.require()
+        rec["libbnn_hip_abi"] = native.ABI_VERSION
+    except Exception as exc:  # noqa: BLE001
+        problems.append(f"libbnn_hip.so: {exc}")
+    return rec, problems
+
+
+def collective_smoke(device, world, rank):
+    """Two collectives with known values through the initialised group (all ranks): an all-reduce of rank + 1 and the
+    bench's own all-gather of a [8, 1000] block filled with the rank number."""
+    t = torch.full((4,), float(rank + 1), device=device)
+    if dist.get_backend() == "gloo":
+        th = t.cpu()
+        dist.all_reduce(th)
+        t = th.to(device)
+    else:
+        dist.all_reduce(t)
+    ok = bool((t == world * (world + 1) / 2).all())
+    g = all_gather_rows(torch.full((8, 1000), float(rank), device=device))
+    ok = ok and all(bool((g[8 * r:8 * r + 8] == r).all()) for r in range(world))
+    return ok
+
+
+def collective_probe(device, world, B, load=None, iters=50):
+    """The step's only collective — all_gather_into_tensor of the [B, 1000] fp32 logits — timed alone: with nothing else
+    in flight, and (``load``: a function that enqueues one step of graph replays without a collective) behind the
+    kernels of a step.  The same number of collectives on every rank.  Microseconds per gather as THIS rank sees them."""
+    y = torch.randn(B, 1000, device=device)
+    for _ in range(5):
+        all_gather_rows(y)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = all_gather_rows(y)
+    torch.cuda.synchronize(device)
+    idle_us = (time.perf_counter() - t0) / iters * 1e6
+    rec = {"bytes_per_rank": B * 4000, "iters": iters, "idle_us": idle_us,
+           "what": "all_gather_into_tensor of the [B, 1000] fp32 logits, back to back, nothing else in flight"}
+    assert out.shape == (world * B, 1000)
+    if load is not None:
+        n = max(10, iters // 2)
+        for i in range(4):
+            load(i)
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(n):
+            load(i)
+        torch.cuda.synchronize(device)
+        t_load = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(n):
+            load(i)
+            all_gather_rows(y)
+        torch.cuda.synchronize(device)
+        t_both = time.perf_counter() - t0
+        rec["under_graph_replay"] = {"steps": n, "ms_per_step_without_gather": t_load / n * 1e3,
+                                     "ms_per_step_with_gather": t_both / n * 1e3,
+                                     "added_us_per_gather": (t_both - t_load) / n * 1e6,
+                                     "what": "one gather per step of graph replays (no overlap tricks): what the collective "
+                                             "costs when it shares the GPU with the forward"}
+    return rec
+
+
 def dist_info(world):
     rec = {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
            "initialized": bool(dist.is_initialized()),
@@ -365,6 +511,12 @@ def main():
                          "rank (--backend gloo lets ranks share a GPU)")
     device = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(device)
+    pre, problems = preflight(args, world, rank, local_rank)
+    if problems and (args.preflight or (world > 1 and args.backend == "nccl")):
+        if rank == 0:
+            print(json.dumps({"preflight": pre, "ok": False, "problems": problems}), flush=True)
+        raise SystemExit(3)
+    rccl_log = enable_rccl_log(rank) if (world > 1 and args.backend == "nccl" and not args.no_rccl_log) else None
     if "WORLD_SIZE" in os.environ:     # under a launcher — also at world size 1, so that N = 1 runs the same code
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -373,6 +525,25 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if dist.is_initialized():
+        # two collectives with known values before anything is timed: a group that cannot move 32 KB correctly must not
+        # get as far as a throughput number
+        t0 = time.perf_counter()
+        pre["collective_smoke"] = {"ok": collective_smoke(device, world, rank), "seconds": None}
+        torch.cuda.synchronize(device)
+        pre["collective_smoke"]["seconds"] = time.perf_counter() - t0
+        if not pre["collective_smoke"]["ok"]:
+            print(json.dumps({"preflight": pre, "ok": False, "problems": ["collective smoke test returned wrong values"]}),
+                  flush=True)
+            raise SystemExit(3)
+    if args.preflight:
+        if rank == 0:
+            pre["rccl_log"] = read_rccl_log(rccl_log)
+            print(json.dumps({"preflight": pre, "ok": True, "problems": []}), flush=True)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     native.require()
     info = native.device_info(device.index)
@@ -434,6 +605,9 @@ def main():
     if rank == 0:
         rec["dist"] = dist_info(world)
         rec["dist"]["rank_devices"] = rank_devices
+        if world > 1 or args.backend != "nccl" or dist.is_initialized():
+            rec["dist"]["preflight"] = pre
+            rec["dist"]["rccl_log"] = read_rccl_log(rccl_log)
         if world > 1 and args.config != "c2":
             eff = scaling_efficiency(rec, args)
             if eff is not None:
@@ -624,14 +798,26 @@ def bench_net(args, world, rank, device, info, timed):
             fresh = [x] + [rank_input(rank, j=j) for j in range(1, N_FRESH)]
         return fresh
 
-    def make_step(engine, n_streams, **kw):
-        """One step of `engine` -> all ranks' logits (ShardedInference: the all-gather is part of the step)."""
+    class _Local(torch.nn.Module):
+        """ShardedInference without its collective: this rank's own logits (the compute-only leg of an N > 1 line)."""
+
+        def __init__(self, model):
+            super().__init__()
+            self.model = model
+
+        def forward_even(self, xl, overlap=False):
+            return self.model(xl)
+
+    def make_step(engine, n_streams, collective=True, **kw):
+        """One step of `engine` -> all ranks' logits (ShardedInference: the all-gather is part of the step;
+        ``collective=False``: this rank's logits only)."""
+        Sharded = ShardedInference if collective else _Local
         if engine == "graph":
             # every stream owns a graph-captured executor whose static input buffer holds its batch (filled by
             # capture): no per-step device-to-device copy of the 154 MB input, and `n_streams` batches in flight
             # (with more than one the executors run in throughput mode: BNN_HIP_FLAG_THROUGHPUT)
             pipe = PipelinedInference(net, x, n_streams=n_streams, **kw)
-            models = [ShardedInference(e) for e in pipe.engines]
+            models = [Sharded(e) for e in pipe.engines]
 
             def step(i):
                 k = i % n_streams
@@ -642,7 +828,7 @@ def bench_net(args, world, rank, device, info, timed):
         xs = fresh_inputs()
         if engine == "graph_fresh":
             pipe = PipelinedInference(net, x, n_streams=n_streams, fresh_input=True, **kw)
-            models = [ShardedInference(_Fresh(e)) for e in pipe.engines]
+            models = [Sharded(_Fresh(e)) for e in pipe.engines]
 
             def step(i):
                 k = i % n_streams
@@ -650,9 +836,9 @@ def bench_net(args, world, rank, device, info, timed):
                     return models[k].forward_even(xs[i % N_FRESH], overlap=True)
             return step
         if engine == "fused":
-            model = ShardedInference(FusedResNet(net, **kw))
+            model = Sharded(FusedResNet(net, **kw))
             return lambda i: model.forward_even(xs[i % N_FRESH])
-        model = ShardedInference(net)               # net_call / layerwise: the reference's own call
+        model = Sharded(net)               # net_call / layerwise: the reference's own call
         if engine in ("layerwise", "layerwise_library", "blockwise"):
             def step(i):
                 with no_model_fusion() if engine == "blockwise" else per_layer_forward(), \
@@ -718,6 +904,21 @@ def bench_net(args, world, rank, device, info, timed):
                 extras["exact_fp32_stem"] = dict(
                     ex, max_abs_logit_diff_vs_default=float((lx - logits).abs().max()),
                     note="stem as a k-ordered fp32 fmaf chain on v_mfma_f32_16x16x4_f32 (bit-for-bit IEEE fp32)")
+        # N > 1: what the step costs WITHOUT its collective (this rank's forward alone, same engine, same protocol) and
+        # what the collective costs alone — a slow first 8-GPU run then says where the time went
+        split = None
+        if dist.is_initialized() and (world > 1 or os.environ.get("BNN_BENCH_SPLIT") == "1"):
+            d_c, _ = timed(make_step(args.engine, n_streams, collective=False, **head_kw), args.steps, args.warmup,
+                           spinup=min(head_spin, 200))
+            compute_ms = [float(t) for t in all_gather_scalar(timed.local / args.steps * 1e3, device)]
+            load_pipe = PipelinedInference(net, x, n_streams=n_streams, **fused_kw)
+            probe = collective_probe(device, world, B, load=lambda i: load_pipe.launch(i))
+            probe_all = {k: [float(t) for t in all_gather_scalar(v, device)] for k, v in
+                         (("idle_us", probe["idle_us"]),
+                          ("added_us_per_gather", probe["under_graph_replay"]["added_us_per_gather"]))}
+            del load_pipe
+            split = {"compute_only_ms_per_step": {"per_rank": compute_ms, "max": max(compute_ms)},
+                     "collective": dict(probe, per_rank=probe_all)}
         gather_check = validate_gather(net, logits, lambda r, n: rank_input(r, n, last_j), B, world, rank, device,
                                        head_kw, layerwise=args.engine if args.engine in SLOW_SPIN else False) \
             if dist.is_initialized() else None
@@ -753,6 +954,14 @@ def bench_net(args, world, rank, device, info, timed):
         rec["engines"] = engines
     rec.update(extras)
     rec["per_rank_ms_per_step"] = {"min": min(per_rank_ms), "max": max(per_rank_ms), "all": per_rank_ms}
+    if split is not None:
+        comp = split["compute_only_ms_per_step"]["per_rank"]
+        rec["per_rank_ms_per_step"]["compute_only"] = comp
+        rec["per_rank_ms_per_step"]["collective_share"] = [a - b for a, b in zip(per_rank_ms, comp)]
+        rec["per_rank_ms_per_step"]["note"] = ("compute_only: the same engine without the all-gather, timed the same way; "
+                                               "collective_share = step - compute_only (what waiting for / issuing the "
+                                               "gather adds on that rank; ~0 when it hides behind the next batch)")
+        rec["collective"] = split["collective"]
     if gather_check is not None:
         rec["gather_check"] = gather_check
     if not c5:

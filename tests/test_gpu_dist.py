@@ -188,6 +188,13 @@ def test_bench_with_eight_ranks_sharing_the_gpu(engine):
     n_dev = torch.cuda.device_count()
     assert rec["dist"]["rank_devices"] == [r % n_dev for r in range(8)]
     assert rec["value"] > 0 and rec["scaling"] == "weak"
+    # round 6: the line says where an N-rank step's time goes — per rank, the step without its collective; the collective
+    # alone, idle and behind graph replays; the preflight record (peer-access matrix, collective smoke test)
+    assert len(pr["compute_only"]) == 8 and len(pr["collective_share"]) == 8
+    assert rec["collective"]["bytes_per_rank"] == 8 * 4000 and len(rec["collective"]["per_rank"]["idle_us"]) == 8
+    assert rec["collective"]["under_graph_replay"]["added_us_per_gather"] == rec["collective"]["under_graph_replay"]["added_us_per_gather"]
+    pre = rec["dist"]["preflight"]
+    assert pre["world_size"] == 8 and pre["collective_smoke"]["ok"] is True and len(pre["peer_access"]) == n_dev
 
 
 def test_rank_to_device_mapping(tmp_path):
@@ -337,3 +344,61 @@ def test_data_parallel_replicas_share_packed_weights_per_device_and_version():
         assert fastpath.stats()["weight_packs"] == packs and torch.equal(y_lw, y_lw2)
         assert torch.allclose(y_lw, y_new, rtol=1e-3, atol=1e-3 * float(y_new.abs().max()))
         assert torch.equal(nn.DataParallel(net, device_ids=[0])(xs), y_new)
+
+
+# ---- round 6: the first N-GPU run describes itself ------------------------------------------------------------------
+
+def test_two_entries_in_the_per_device_executor_table():
+    """`nn.DataParallel` over more than one device (examples/cifar10.py:76) keeps ONE executor per device in
+    `AutoFusion.replica_engines`.  With one GPU in the box the second device is a key of its own (`cuda:1`) holding a
+    stand-in: calls on cuda:0 must find THEIR entry, leave the other one alone, and a changed master parameter must
+    re-derive only the entry of the device that is asked next (each entry carries the signature it was derived for)."""
+    import torch.nn as nn
+    from bnn_amd.inference import auto_fusion
+    net = _r18()
+    xs = torch.from_numpy(gen.normal(5, (4, 3, 64, 64))).to(DEV)
+    other = torch.device("cuda", 1)
+    with torch.no_grad():
+        want = FusedResNet(net)(xs)
+        st = auto_fusion(net)
+        assert torch.equal(nn.parallel.replicate(net, [0])[0](xs), want)
+        sig0, eng0 = st.replica_engines[xs.device]
+        stand_in = object()
+        st.replica_engines[other] = (sig0, stand_in)                     # "the replica on the second GPU"
+        assert torch.equal(nn.parallel.replicate(net, [0])[0](xs), want)
+        assert set(st.replica_engines) == {xs.device, other}
+        assert st.replica_engines[xs.device][1] is eng0 and st.replica_engines[other] == (sig0, stand_in)
+        net.layer2[0].conv1.weight.neg_()                                # optimiser step on the master
+        y_new = nn.parallel.replicate(net, [0])[0](xs)
+        assert not torch.equal(y_new, want) and torch.equal(y_new, FusedResNet(net)(xs))
+        sig1, eng1 = st.replica_engines[xs.device]
+        assert eng1 is not eng0 and sig1 != sig0
+        assert st.replica_engines[other] == (sig0, stand_in)             # stale by ITS signature: re-derived when asked
+        st.reset()
+        assert not st.replica_engines
+
+
+def test_bench_preflight_and_the_self_describing_fields_of_an_n_rank_line():
+    """`bench.py --preflight` (one JSON line, exit code 0, the peer-access matrix and a collective smoke test) and the
+    fields an N > 1 line carries so that a slow first multi-GPU run says where the time went: the same checks under
+    `dist.preflight`, the step without its collective per rank, the collective alone (idle / behind graph replays)."""
+    pre = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--preflight"])
+    assert pre["ok"] is True and pre["problems"] == []
+    p = pre["preflight"]
+    assert p["world_size"] == 2 and p["gpus_visible"] >= 1 and p["collective_smoke"]["ok"] is True
+    assert len(p["peer_access"]) == p["gpus_visible"] and all(p["peer_access"][i][i] for i in range(p["gpus_visible"]))
+    # RCCL with more ranks than GPUs is refused by the preflight itself, with a reason, before any process group exists
+    env = dict(os.environ)
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", str(torch.cuda.device_count() + 1), "--preflight"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert line and json.loads(line[-1])["ok"] is False and "one GPU per rank" in json.loads(line[-1])["problems"][0]
+    rec = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                      "--spinup", "2", "--batch", "16", "--sustain", "0", "--no-cpu-baseline", "--no-roofline", "--no-extras"])
+    assert rec["dist"]["preflight"]["collective_smoke"]["ok"] is True and "peer_access" in rec["dist"]["preflight"]
+    pr = rec["per_rank_ms_per_step"]
+    assert len(pr["compute_only"]) == 2 and len(pr["collective_share"]) == 2 and all(v > 0 for v in pr["compute_only"])
+    c = rec["collective"]
+    assert c["bytes_per_rank"] == 16 * 4000 and c["idle_us"] > 0 and c["under_graph_replay"]["steps"] >= 10
+    assert len(c["per_rank"]["idle_us"]) == 2 and len(c["per_rank"]["added_us_per_gather"]) == 2
