@@ -325,8 +325,8 @@ def rccl_log_path(rank):
 def enable_rccl_log(rank):
     """NCCL_DEBUG=INFO into a per-rank file (unless the caller configured RCCL's logging already): which transport every
     channel uses (P2P/IPC over xGMI, SHM, NET), the rings / trees RCCL built, the topology it detected."""
-    if "NCCL_DEBUG" in os.environ:
-        return None
+    if os.environ.get("NCCL_DEBUG", "VERSION").upper() not in ("VERSION", "WARN", ""):
+        return os.environ.get("NCCL_DEBUG_FILE")      # the caller's own INFO / TRACE logging: read its file if it names one
     path = rccl_log_path(rank)
     try:
         os.remove(path)
