@@ -338,21 +338,35 @@ def enable_rccl_log(rank):
     return path
 
 
-def read_rccl_log(path, limit=60):
+def read_rccl_log(path, limit=40):
+    """What RCCL said while it built the communicator: the transport of every channel (counted per kind: P2P/IPC over
+    xGMI, SHM, NET), how many rings / trees / channels it made (first two of each kept), and every other setup line that
+    names a topology, a network or a version."""
     import re
     if not path or not os.path.exists(path):
         return None
-    pat = re.compile(r"(via |Channel |Ring |Tree |Trees|P2P|XGMI|xGMI|SHM|NET/|Using |topology|nNodes|nRanks|comm 0x|Connected|"
-                     r"RCCL version|NCCL version|hipDev|busId)")
-    seen, out = set(), []
+    pat = re.compile(r"(via |P2P|XGMI|xGMI|SHM|NET/|Using |topology|nNodes|nRanks|comm 0x|Connected|RCCL version|NCCL version|"
+                     r"hipDev|busId|nChannels|Setting affinity|MSCCL|IB |Socket)")
+    seen, other, transports = set(), [], {}
+    kinds = {"Tree": [0, []], "Ring": [0, []], "Channel": [0, []]}
     with open(path, errors="replace") as fh:
         for ln in fh:
-            ln = ln.strip()
-            msg = ln.split("NCCL INFO", 1)[-1].strip()
-            if pat.search(msg) and msg not in seen:
-                seen.add(msg)
-                out.append(msg[:200])
-    return {"lines": out[:limit], "total_matching": len(out), "file": path}
+            msg = ln.strip().split("NCCL INFO", 1)[-1].strip()
+            if not msg or msg in seen:
+                continue
+            seen.add(msg)
+            m = re.search(r" via (\S+)", msg)
+            if m:
+                transports[m.group(1)] = transports.get(m.group(1), 0) + 1
+            kind = next((k for k in kinds if msg.startswith(k + " ")), None)
+            if kind:
+                kinds[kind][0] += 1
+                if len(kinds[kind][1]) < 2:
+                    kinds[kind][1].append(msg[:200])
+            elif pat.search(msg):
+                other.append(msg[:200])
+    return {"transports": transports, "lines": other[:limit], "lines_total": len(other),
+            "rings_trees_channels": {k: {"count": v[0], "first": v[1]} for k, v in kinds.items()}, "file": path}
 
 
 def preflight(args, world, rank, local_rank):
@@ -516,7 +530,8 @@ def main():
         if rank == 0:
             print(json.dumps({"preflight": pre, "ok": False, "problems": problems}), flush=True)
         raise SystemExit(3)
-    rccl_log = enable_rccl_log(rank) if (world > 1 and args.backend == "nccl" and not args.no_rccl_log) else None
+    rccl_log = enable_rccl_log(rank) if (args.backend == "nccl" and not args.no_rccl_log and "WORLD_SIZE" in os.environ
+                                         and (world > 1 or os.environ.get("BNN_BENCH_RCCL_LOG") == "1")) else None
     if "WORLD_SIZE" in os.environ:     # under a launcher — also at world size 1, so that N = 1 runs the same code
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
