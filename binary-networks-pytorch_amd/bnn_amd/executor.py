@@ -538,10 +538,19 @@ class FusedResNet(nn.Module):
         return tp, p1
 
     def _hblock_ok(self, b, N, H, W) -> bool:
+        """Whether the one-launch kernel covers this geometry; also decides which form of it runs (``b["hcl"]``): the
+        small-image form (lanes = output channels, csrc/hblock_cl.hip) on 7 x 7 images, and on 14 x 14 images when other
+        work shares the GPU — there whole images per workgroup win; alone, the pixel-lane kernel splits a 14 x 14 image over
+        two workgroups and fills the chip (measured at batch 128, us per block: 7 x 7 53.6 vs 67.1; 14 x 14 shared 60.4 vs
+        72.0, alone 60.4 vs 44.8)."""
         ok = b["hgeo"].get((N, H, W))
         if ok is None:
             hp = b["hpack"]
-            ok = b["hgeo"][(N, H, W)] = hipops.hblock_supported(N, hp.c_in, H, W, hp.planes, self.throughput_mode)
+            cl = (os.environ.get("BNN_AMD_HBLOCK_CL", "1") != "0" and (H == 7 or self.throughput_mode)
+                  and hipops.hblock_supported(N, hp.c_in, H, W, hp.planes, self.throughput_mode, channel_lanes=True))
+            ok = cl or hipops.hblock_supported(N, hp.c_in, H, W, hp.planes, self.throughput_mode)
+            b["hgeo"][(N, H, W)] = ok
+            b.setdefault("hcl", {})[(N, H, W)] = cl
         return ok
 
     def _run_h(self, b, t, packed=None, nxt=None):
@@ -563,7 +572,8 @@ class FusedResNet(nn.Module):
             if self._hblock_ok(b, N, H, W):
                 if not mine:
                     packed = hipops.bn_act_pack(t, *b["bn"][0], relu=True)
-                y, pk = hipops.hblock_forward(packed, hp, idn, out_packed=hp.has_next, throughput=self.throughput_mode)
+                y, pk = hipops.hblock_forward(packed, hp, idn, out_packed=hp.has_next, throughput=self.throughput_mode,
+                                              channel_lanes=b["hcl"][(N, H, W)])
                 if pk is not None:
                     pk._h_for = nxt
                 return y, pk

@@ -678,6 +678,21 @@ class HBlockPack:
     c_in: int
     planes: int
     has_next: bool
+    packs: tuple = ()                              # the three standard packs (kept for the other weight order)
+    weights_cl: Optional[torch.Tensor] = None      # the same weights in the channel-lane kernel's order (made on first use)
+
+    def channel_lane_weights(self) -> torch.Tensor:
+        if self.weights_cl is None:
+            lib = native.require()
+            w1, w2, w3 = self.packs
+            dev = self.weights.device
+            with torch.cuda.device(dev):
+                buf = torch.empty_like(self.weights)
+                native.check(lib.bnn_hip_hblock_pack_weights_cl(self.c_in, self.planes, w1.wbits.data_ptr(), w2.wbits.data_ptr(),
+                                                                w3.wbits.data_ptr(), buf.data_ptr(), _stream(dev)),
+                             "bnn_hip_hblock_pack_weights_cl")
+            self.weights_cl = buf
+        return self.weights_cl
 
 
 def hblock_pack(w1: PackedWeight, w2: PackedWeight, w3: PackedWeight, bn2, bn3, next_bn=None) -> HBlockPack:
@@ -706,24 +721,26 @@ def hblock_pack(w1: PackedWeight, w2: PackedWeight, w3: PackedWeight, bn2, bn3, 
         if next_bn is not None:
             consts[L.next_a_off:L.next_a_off + planes] = _per_channel(next_bn[0], planes, "next bn scale")
             consts[L.next_b_off:L.next_b_off + planes] = _per_channel(next_bn[1], planes, "next bn shift")
-    return HBlockPack(wbuf, consts, c_in, planes, next_bn is not None)
+    return HBlockPack(wbuf, consts, c_in, planes, next_bn is not None, (w1, w2, w3))
 
 
-def _hblock_desc(N, c_in, H, W, planes, throughput=False, rows_per_band=0, images_per_band=0, waves=0):
-    return native.HBlockDesc(N, c_in, H, W, planes, native.FLAG_THROUGHPUT if throughput else 0, rows_per_band,
-                             images_per_band, waves, 0)
+def _hblock_desc(N, c_in, H, W, planes, throughput=False, rows_per_band=0, images_per_band=0, waves=0, channel_lanes=False):
+    flags = (native.FLAG_THROUGHPUT if throughput else 0) | (native.HBLOCK_CHANNEL_LANES if channel_lanes else 0)
+    return native.HBlockDesc(N, c_in, H, W, planes, flags, rows_per_band, images_per_band, waves, 0)
 
 
 def hblock_supported(N: int, c_in: int, H: int, W: int, planes: int, throughput: bool = False, rows_per_band: int = 0,
-                     images_per_band: int = 0, waves: int = 0) -> bool:
-    """Whether ``hblock_forward`` covers this geometry (with this plan) on the current device."""
+                     images_per_band: int = 0, waves: int = 0, channel_lanes: bool = False) -> bool:
+    """Whether ``hblock_forward`` covers this geometry (with this plan) on the current device.  ``channel_lanes``: the
+    small-image form of the kernel (csrc/hblock_cl.hip: 14 x 14 / 7 x 7, lanes = output channels)."""
     lib = native.require()
-    d = _hblock_desc(N, c_in, H, W, planes, throughput, rows_per_band, images_per_band, waves)
+    d = _hblock_desc(N, c_in, H, W, planes, throughput, rows_per_band, images_per_band, waves, channel_lanes)
     return bool(lib.bnn_hip_hblock_supported(ctypes.byref(d)))
 
 
 def hblock_forward(a: PackedAct, pack: HBlockPack, residual: torch.Tensor, out_packed: bool = True,
-                   throughput: bool = False, rows_per_band: int = 0, images_per_band: int = 0, waves: int = 0):
+                   throughput: bool = False, rows_per_band: int = 0, images_per_band: int = 0, waves: int = 0,
+                   channel_lanes: bool = False):
     """``HBlock.forward`` behind its first BatchNorm + ReLU (bnn/models/layers/hierarchical_block.py:38-60) in ONE
     launch: ``a`` = planes of ``sign(relu(bn1(x)))`` (non-negative), ``residual`` = the shortcut (fp32 NCHW).
     Returns ``(y, PackedAct(sign(relu(next_bn(y)))) | None)``."""
@@ -745,8 +762,9 @@ def hblock_forward(a: PackedAct, pack: HBlockPack, residual: torch.Tensor, out_p
                            _zero_plane((N, pack.planes // 64, H, W), dev), (N, pack.planes, H, W), nonneg=True)
         if N == 0:
             return y, pk
-        d = _hblock_desc(N, c_in, H, W, pack.planes, throughput, rows_per_band, images_per_band, waves)
-        native.check(lib.bnn_hip_hblock_forward(ctypes.byref(d), a.P.data_ptr(), pack.weights.data_ptr(),
+        d = _hblock_desc(N, c_in, H, W, pack.planes, throughput, rows_per_band, images_per_band, waves, channel_lanes)
+        wbuf = pack.channel_lane_weights() if channel_lanes else pack.weights
+        native.check(lib.bnn_hip_hblock_forward(ctypes.byref(d), a.P.data_ptr(), wbuf.data_ptr(),
                                                 pack.consts.data_ptr(), residual.data_ptr(), y.data_ptr(),
                                                 None if pk is None else pk.P.data_ptr(), _stream(dev)),
                      "bnn_hip_hblock_forward")

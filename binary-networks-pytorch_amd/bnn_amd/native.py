@@ -21,6 +21,7 @@ FLAG_WEIGHT_ZEROS = 2
 FLAG_WEIGHTS_SGPR = 4
 FLAG_ACT_NONNEG = 32
 FLAG_THROUGHPUT = 64
+HBLOCK_CHANNEL_LANES = 128
 STEM_EXACT_FP32 = 1
 STEM_FP16 = 4
 ABI_VERSION = 15
@@ -46,7 +47,7 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_stem7x7_conv_f32", "bnn_hip_stem7x7_wgrad_workspace_bytes", "bnn_hip_stem7x7_wgrad_f32",
     "bnn_hip_avgpool2x2_backward_f32", "bnn_hip_xnor_grad_pack_weight_f32",
     "bnn_hip_hblock_supported", "bnn_hip_hblock_layout_of", "bnn_hip_hblock_pack_weights", "bnn_hip_hblock_forward",
-    "bnn_hip_avgpool2_bn_pack2_f32",
+    "bnn_hip_avgpool2_bn_pack2_f32", "bnn_hip_hblock_pack_weights_cl",
 )
 
 
@@ -199,6 +200,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_hblock_supported.argtypes = [ctypes.POINTER(HBlockDesc)]
     lib.bnn_hip_hblock_layout_of.argtypes = [_i, _i, ctypes.POINTER(HBlockLayout)]
     lib.bnn_hip_hblock_pack_weights.argtypes = [_i, _i, _vp, _vp, _vp, _vp, _vp]
+    lib.bnn_hip_hblock_pack_weights_cl.argtypes = [_i, _i, _vp, _vp, _vp, _vp, _vp]
     lib.bnn_hip_hblock_forward.argtypes = [ctypes.POINTER(HBlockDesc)] + [_vp] * 7
 
 

@@ -811,7 +811,7 @@ static int check_hblock(const bnn_hip_hblock_desc* d) {
   if (!d) return BNN_HIP_ERR_INVALID_ARG;
   if (d->N <= 0 || d->C_in <= 0 || d->H <= 0 || d->W <= 0 || d->planes <= 0) return BNN_HIP_ERR_INVALID_ARG;
   if (d->rows_per_band < 0 || d->images_per_band < 0 || d->waves < 0 || d->waves > 16) return BNN_HIP_ERR_INVALID_ARG;
-  if (d->flags & ~BNN_HIP_FLAG_THROUGHPUT) return BNN_HIP_ERR_INVALID_ARG;
+  if (d->flags & ~(BNN_HIP_FLAG_THROUGHPUT | BNN_HIP_HBLOCK_CHANNEL_LANES)) return BNN_HIP_ERR_INVALID_ARG;
   // the kernel's index arithmetic: 24-bit multiplies, 32-bit byte offsets into the fp32 tensors
   const long long lim = 1ll << 23;
   if (mulc(d->N, d->planes) >= lim || mulc(d->H, d->W) >= lim || mulc(d->H + 8, d->W + 2) >= lim) return BNN_HIP_ERR_TOO_LARGE;
@@ -822,6 +822,7 @@ static int check_hblock(const bnn_hip_hblock_desc* d) {
 
 int bnn_hip_hblock_supported(const bnn_hip_hblock_desc* d) {
   if (check_hblock(d) != BNN_HIP_OK) return 0;
+  if (d->flags & BNN_HIP_HBLOCK_CHANNEL_LANES) return bnn::hblock_cl_supported(d) ? 1 : 0;
   return bnn::hblock_supported(d) ? 1 : 0;
 }
 
@@ -841,6 +842,16 @@ int bnn_hip_hblock_pack_weights(int C_in, int planes, const uint32_t* wbits1, co
   return bnn::launch_hblock_pack_weights(C_in, planes, w, weights, static_cast<hipStream_t>(stream));
 }
 
+int bnn_hip_hblock_pack_weights_cl(int C_in, int planes, const uint32_t* wbits1, const uint32_t* wbits2,
+                                   const uint32_t* wbits3, uint32_t* weights, void* stream) {
+  if (!wbits1 || !wbits2 || !wbits3 || !weights || C_in <= 0 || planes <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (!aligned(wbits1, 4) || !aligned(wbits2, 4) || !aligned(wbits3, 4) || !aligned(weights, 64)) return BNN_HIP_ERR_INVALID_ARG;
+  const uint32_t* const w[3] = {wbits1, wbits2, wbits3};
+  g_launches.fetch_add(3, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_hblock_cl_pack_weights(C_in, planes, w, weights, static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_hblock_forward(const bnn_hip_hblock_desc* d, const uint64_t* in_P, const uint32_t* weights,
                            const float* consts, const float* residual, float* out, uint64_t* out_P, void* stream) {
   const int st = check_hblock(d);
@@ -849,6 +860,12 @@ int bnn_hip_hblock_forward(const bnn_hip_hblock_desc* d, const uint64_t* in_P, c
   if (!aligned(in_P, 8) || !aligned(weights, 64) || !aligned(consts, 8) || !aligned(residual, 4) || !aligned(out, 4) ||
       (out_P && !aligned(out_P, 8)))
     return BNN_HIP_ERR_INVALID_ARG;
+  if (d->flags & BNN_HIP_HBLOCK_CHANNEL_LANES) {
+    if (!bnn::hblock_cl_supported(d)) return BNN_HIP_ERR_UNSUPPORTED;
+    g_launches.fetch_add(1, std::memory_order_relaxed);
+    Range range("bnn_hip_hblock_forward(channel lanes)");
+    return bnn::launch_hblock_cl(d, in_P, weights, consts, residual, out, out_P, static_cast<hipStream_t>(stream));
+  }
   if (!bnn::hblock_supported(d)) return BNN_HIP_ERR_UNSUPPORTED;
   g_launches.fetch_add(1, std::memory_order_relaxed);
   BNN_RANGE();

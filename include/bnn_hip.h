@@ -490,10 +490,16 @@ int bnn_hip_bconv2d_direct(const bnn_hip_conv_desc* d, const void* x, int x_dtyp
  *   residual: fp32 [N, C, H, W] (the block input, or its shortcut branch);  out: fp32 [N, C, H, W], must not alias residual
  *   out_P:    NULL, or [N, C/64, H, W] uint64: sign(relu(fmaf(y, next_a, next_b))) — the next block's in_P
  * planes % 64 == 0; C_in <= 32 or C_in % 64 == 0; N * planes < 2^23; N * planes * H * W < 2^30.                     */
+/* flags bit of bnn_hip_hblock_desc: the SMALL-image form of the kernel (csrc/hblock_cl.hip: 14 x 14 and 7 x 7 images, planes a
+ * multiple of 256, C_in a multiple of 64): a wave's lanes are 64 output channels instead of 64 pixels — no idle lanes on 196- or
+ * 49-pixel images, taps in the left / right padding not computed.  `weights` must then come from
+ * bnn_hip_hblock_pack_weights_cl (same size, another order); consts and results are the same, bit for bit.        */
+#define BNN_HIP_HBLOCK_CHANNEL_LANES 128
 typedef struct bnn_hip_hblock_desc {
   int32_t N, C_in, H, W;
   int32_t planes;
-  int32_t flags;            /* BNN_HIP_FLAG_THROUGHPUT: other work shares the GPU — whole-image regions preferred     */
+  int32_t flags;            /* BNN_HIP_FLAG_THROUGHPUT: other work shares the GPU — whole-image regions preferred;
+                               BNN_HIP_HBLOCK_CHANNEL_LANES (below)                                                   */
   int32_t rows_per_band;    /* 0 = the planner's choice; else rows of one image per workgroup                         */
   int32_t images_per_band;  /* 0 = the planner's choice; > 1 only with rows_per_band == 0 or H                         */
   int32_t waves;            /* 0 = 16; wavefronts per workgroup, 1..16                                                */
@@ -514,6 +520,8 @@ int bnn_hip_hblock_layout_of(int C_in, int planes, bnn_hip_hblock_layout* out);
 /* wbits1..3: bnn_hip_pack_weight_f32 packs of [C/2, C_in, 3, 3], [C/4, C/2, 3, 3], [C/4, C/4, 3, 3]. */
 int bnn_hip_hblock_pack_weights(int C_in, int planes, const uint32_t* wbits1, const uint32_t* wbits2,
                                 const uint32_t* wbits3, uint32_t* weights, void* stream);
+int bnn_hip_hblock_pack_weights_cl(int C_in, int planes, const uint32_t* wbits1, const uint32_t* wbits2,
+                                   const uint32_t* wbits3, uint32_t* weights, void* stream);
 int bnn_hip_hblock_forward(const bnn_hip_hblock_desc* d, const uint64_t* in_P, const uint32_t* weights,
                            const float* consts, const float* residual, float* out, uint64_t* out_P, void* stream);
 

@@ -74,6 +74,15 @@ def test_one_launch_equals_three_launches(shape):
         assert p.nonneg and not bool(p.M.any())
         y2, p2 = hipops.hblock_forward(p_in, pack_last, res, out_packed=False, **plan)
         assert p2 is None and torch.equal(y2, want_y), plan
+    # the small-image form (lanes = output channels): 14 x 14 / 7 x 7, widths from 256 on
+    cl = hipops.hblock_supported(N, c_in, H, W, planes, channel_lanes=True)
+    assert cl == ((H, W) in ((14, 14), (7, 7)) and planes % 256 == 0)
+    if cl:
+        for waves in (0, 4, 3):
+            y, p = hipops.hblock_forward(p_in, pack, res, channel_lanes=True, waves=waves)
+            assert torch.equal(y, want_y) and torch.equal(p.P, want_p.P), waves
+        y2, p2 = hipops.hblock_forward(p_in, pack_last, res, out_packed=False, channel_lanes=True)
+        assert p2 is None and torch.equal(y2, want_y)
 
 
 def test_against_the_float_formulation():

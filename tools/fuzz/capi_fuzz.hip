@@ -137,6 +137,21 @@ int launch_hblock(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint3
   REQUIRE((long long)d->N * ((d->C_in + 63) / 64) * d->H * d->W <= kPlaneWords);
   return BNN_HIP_OK;
 }
+bool hblock_cl_supported(const bnn_hip_hblock_desc* d) {
+  REQUIRE(d && d->N > 0 && d->C_in > 0 && d->planes > 0);
+  return stub_hb_shape(d->C_in, d->planes) && d->planes % 256 == 0 && d->C_in % 64 == 0 && d->H == d->W && (d->H == 7 || d->H == 14);
+}
+int launch_hblock_cl_pack_weights(int C_in, int planes, const uint32_t* const w[3], uint32_t* dst, hipStream_t) {
+  ++g_reached; REQUIRE(C_in > 0 && planes > 0 && w[0] && w[1] && w[2] && dst && al(dst, 64));
+  return stub_hb_shape(C_in, planes) && planes % 256 == 0 ? BNN_HIP_OK : BNN_HIP_ERR_UNSUPPORTED;
+}
+int launch_hblock_cl(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc, const float* res,
+                     float* out, uint64_t* outP, hipStream_t) {
+  ++g_reached;
+  REQUIRE(d && inP && W && Kc && res && out && res != out && al(inP, 8) && al(W, 64) && (!outP || al(outP, 8)));
+  REQUIRE(d->planes % 256 == 0 && d->H == d->W && (d->H == 7 || d->H == 14));
+  return BNN_HIP_OK;
+}
 int launch_orpool_packed(const uint64_t* P, int N, int C, int H, int W, int k, uint64_t* oP, uint64_t* oM, hipStream_t) {
   ++g_reached; REQUIRE(P && oP && oM && N > 0 && C > 0 && H > 0 && W > 0 && k > 0 && al(P, 8) && al(oP, 8) && al(oM, 8));
   return BNN_HIP_OK;
@@ -332,7 +347,7 @@ int main(int argc, char** argv) {
   for (long it = 0; it < iters; ++it) {
     ++g_calls;
     int st = 0;
-    switch (rnd() % 39) {
+    switch (rnd() % 40) {
       case 0: { bnn_hip_conv_desc d = pick_desc();
         st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
                              pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
@@ -450,7 +465,7 @@ int main(int argc, char** argv) {
                                                   pick_ptr<uint64_t>(), pick_ptr<float>(), stream); break;
       case 35: { bnn_hip_hblock_desc d; int* f = reinterpret_cast<int*>(&d);
         for (size_t i = 0; i < sizeof(d) / sizeof(int); ++i) f[i] = pick_int();
-        if (rnd() % 2) { d.planes = 64 << (rnd() % 4); d.C_in = rnd() % 2 ? d.planes : d.planes / 2; d.flags = (int)(rnd() % 2) * 64;
+        if (rnd() % 2) { d.planes = 64 << (rnd() % 4); d.C_in = rnd() % 2 ? d.planes : d.planes / 2; d.flags = (int)(rnd() % 2) * 64 + (int)(rnd() % 2) * 128; if (rnd() % 2) d.H = d.W = (rnd() % 2) ? 7 : 14;
                          d.rows_per_band = d.images_per_band = d.waves = 0; }
         (void)bnn_hip_hblock_supported(rnd() % 16 ? &d : nullptr);
         st = bnn_hip_hblock_forward(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint32_t>(), pick_ptr<float>(),
@@ -460,6 +475,8 @@ int main(int argc, char** argv) {
         st = bnn_hip_hblock_layout_of(pick_int(), pick_int(), rnd() % 16 ? &L : nullptr);
         if (st == BNN_HIP_OK && (L.weight_words <= 0 || L.const_floats <= 0)) broken("hblock layout");
         break; }
+      case 38: st = bnn_hip_hblock_pack_weights_cl(pick_int(), pick_int(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(),
+                                                   pick_ptr<uint32_t>(), stream); break;
       case 37: st = bnn_hip_hblock_pack_weights(pick_int(), pick_int(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(),
                                                 pick_ptr<uint32_t>(), stream); break;
       case 33: st = bnn_hip_xnor_grad_pack_weight_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(),
