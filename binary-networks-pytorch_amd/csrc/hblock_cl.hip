@@ -43,6 +43,10 @@ struct ClGeo {
 
 namespace {
 
+#ifndef CL_MAX_WAVES  // waves per workgroup the kernel is register-allocated for (12: three per SIMD, 168 registers; 16 spills)
+#define CL_MAX_WAVES 12
+#endif
+
 extern __shared__ __attribute__((aligned(16))) unsigned char cl_smem[];
 
 __device__ __forceinline__ uint32_t cl_uniform(uint32_t v) {
@@ -152,16 +156,15 @@ __device__ __forceinline__ void cl_unit(const uint32_t* __restrict__ Wt, const f
   // the tile's shortcut values: lane = channel, one load per pixel, all requested before the popcount loop
   const BufRsrc rres = make_rsrc_sized(res, g.f32_bytes), rout = make_rsrc_sized(out, g.f32_bytes);
   const unsigned voff = (unsigned)(((n * g.C + co) * HW + r0 * W) * 4);
-  // (W = 14: the 28 pixels of a lane's channel are 112 contiguous, 16-byte aligned bytes: seven 16-byte loads / stores —
-  // a quarter of the instructions and of the partial-line writes L2 has to merge; 7 x 7 images: 196-byte rows, dwords)
-  constexpr bool VEC4 = W == 14;
+  // (W = 14: the 14 pixels of a lane's channel in this row are 56 contiguous, 8-byte aligned bytes: seven 8-byte loads /
+  // stores — half the instructions and of the partial-line writes L2 has to merge; 7 x 7 images: 196-byte planes, dwords)
+  constexpr bool VEC2 = W == 14;
   float resv[T];
-  if constexpr (VEC4) {
+  if constexpr (VEC2) {
 #pragma unroll
-    for (int p = 0; p < T; p += 4) {
-      // (plain 16-byte global loads: hipcc 7.2 mis-lowers the wide buffer-load builtins, tests/test_isa_cpu.py)
-      const float4 v4 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(res) + voff + (unsigned)(p * 4));
-      resv[p] = v4.x; resv[p + 1] = v4.y; resv[p + 2] = v4.z; resv[p + 3] = v4.w;
+    for (int p = 0; p < T; p += 2) {
+      const float2 v2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(res) + voff + (unsigned)(p * 4));
+      resv[p] = v2.x; resv[p + 1] = v2.y;
     }
   } else {
 #pragma unroll
@@ -197,31 +200,42 @@ __device__ __forceinline__ void cl_unit(const uint32_t* __restrict__ Wt, const f
     }
     // plane row r0 + cy holds image row r0 + cy - 1 (row 0 / row H + 1: zeros)
     const uint32_t* prow = plane + (size_t)(r0 * W) * ph.cw + s * KW;
-    static_for<R + 2>([&](auto cyc) {
-      static_for<W>([&](auto cxc) {
-        constexpr int cy = decltype(cyc)::value, cx = decltype(cxc)::value;
-        const V av = *reinterpret_cast<const V*>(prow + (size_t)(cy * W + cx) * ph.cw);   // the same address in every lane
-        uint32_t a[KW];
-        {
-          const uint32_t* e = reinterpret_cast<const uint32_t*>(&av);
+    // the cells of the window, in order, read AHEAD of their use: the broadcast read of cell i + kAhead is issued before
+    // cell i is consumed (left to itself hipcc issues every ds_read right in front of its use and waits out the whole LDS
+    // latency per cell: one register quad, `s_waitcnt lgkmcnt(0)` behind each of the 84 reads of a K-step)
+    constexpr int NCELL = (R + 2) * W, kAhead = 2;
+    V ring[kAhead + 1];
+    static_for<kAhead>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      ring[i] = *reinterpret_cast<const V*>(prow + (size_t)i * ph.cw);
+    });
+    static_for<NCELL>([&](auto cc) {
+      constexpr int ci = decltype(cc)::value, cy = ci / W, cx = ci % W;
+      if constexpr (ci + kAhead < NCELL)
+        ring[(ci + kAhead) % (kAhead + 1)] = *reinterpret_cast<const V*>(prow + (size_t)(ci + kAhead) * ph.cw);
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      uint32_t a[KW];
+      {
+        const uint32_t* e = reinterpret_cast<const uint32_t*>(&ring[ci % (kAhead + 1)]);
 #pragma unroll
-          for (int j = 0; j < KW; ++j) a[j] = e[j];
-        }
-        // (cy, cx are constants of the unrolled loops: the valid taps of the cell are known at compile time)
-        static_for<5>([&](auto qc) {
-          constexpr int q = decltype(qc)::value;
-          constexpr int tA = cl_valid_tap(cy, cx, R, W, 2 * q), tB = cl_valid_tap(cy, cx, R, W, 2 * q + 1);
-          if constexpr (tA >= 0 && tB >= 0) {
-            if constexpr (KW == 4) {
-              cl_tap2(acc[(cy - tA / 3) * W + cx - tA % 3 + 1], acc[(cy - tB / 3) * W + cx - tB % 3 + 1], w[tA], w[tB], a);
-            } else {
-              cl_tap<KW>(acc[(cy - tA / 3) * W + cx - tA % 3 + 1], w[tA], a);
-              cl_tap<KW>(acc[(cy - tB / 3) * W + cx - tB % 3 + 1], w[tB], a);
-            }
-          } else if constexpr (tA >= 0) {
+        for (int j = 0; j < KW; ++j) a[j] = e[j];
+      }
+      // (cy, cx are constants: the valid taps of the cell are known at compile time)
+      static_for<5>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int tA = cl_valid_tap(cy, cx, R, W, 2 * q), tB = cl_valid_tap(cy, cx, R, W, 2 * q + 1);
+        if constexpr (tA >= 0 && tB >= 0) {
+          if constexpr (KW == 4) {
+            cl_tap2(acc[(cy - tA / 3) * W + cx - tA % 3 + 1], acc[(cy - tB / 3) * W + cx - tB % 3 + 1], w[tA], w[tB], a);
+          } else {
             cl_tap<KW>(acc[(cy - tA / 3) * W + cx - tA % 3 + 1], w[tA], a);
+            cl_tap<KW>(acc[(cy - tB / 3) * W + cx - tB % 3 + 1], w[tB], a);
           }
-        });
+        } else if constexpr (tA >= 0) {
+          cl_tap<KW>(acc[(cy - tA / 3) * W + cx - tA % 3 + 1], w[tA], a);
+        }
       });
     });
   }
@@ -245,12 +259,10 @@ __device__ __forceinline__ void cl_unit(const uint32_t* __restrict__ Wt, const f
 #endif
     }
     const float y = ov + resv[p];
-    if constexpr (VEC4) {
-      resv[p] = y;   // (kept: stored four pixels at a time below)
-      if constexpr (p % 4 == 3) {
-        *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + ovoff + (unsigned)((p - 3) * 4)) =
-            float4{resv[p - 3], resv[p - 2], resv[p - 1], resv[p]};
-      }
+    if constexpr (VEC2) {
+      resv[p] = y;   // (kept: stored two pixels at a time)
+      if constexpr (p % 2 == 1)
+        *reinterpret_cast<float2*>(reinterpret_cast<char*>(out) + ovoff + (unsigned)((p - 1) * 4)) = float2{resv[p - 1], resv[p]};
     } else {
       buf_st(rout, ovoff + (unsigned)(p * 4), 0u, y);
     }
@@ -282,16 +294,18 @@ __device__ __forceinline__ void cl_unit(const uint32_t* __restrict__ Wt, const f
   }
 }
 
-// tiles of a W x W image: rows per tile, first row
+// tiles of a W x W image: 14 x 14 -> fourteen single rows; 7 x 7 -> rows {0,1} {2,3} {4,5} {6}.  Small tiles: 14 (or 7)
+// accumulators per lane keep the kernel under 128 registers — sixteen waves per workgroup, four per SIMD — and give a
+// convolution of 64 output channels fourteen (four) units instead of seven (two).
 template <int W>
 struct ClTiles;
 template <>
 struct ClTiles<14> {
-  static constexpr int N = 7;
+  static constexpr int N = 14;
 };
 template <>
 struct ClTiles<7> {
-  static constexpr int N = 2;
+  static constexpr int N = 4;
 };
 
 template <int W, int KW, int K, bool NEXT>
@@ -300,10 +314,10 @@ __device__ __forceinline__ void cl_unit_of_tile(const uint32_t* __restrict__ Wt,
                                                 unsigned char* smem, int n, int cg, int tile, int lane,
                                                 typename ClVec<KW>::type (&wnext)[9], int cg_following) {
   if constexpr (W == 14) {
-    cl_unit<14, 2, KW, K, NEXT>(Wt, Kc, res, out, g, smem, n, cg, 2 * tile, lane, wnext, cg_following);
+    cl_unit<14, 1, KW, K, NEXT>(Wt, Kc, res, out, g, smem, n, cg, tile, lane, wnext, cg_following);
   } else {
-    if (tile == 0) cl_unit<7, 4, KW, K, NEXT>(Wt, Kc, res, out, g, smem, n, cg, 0, lane, wnext, cg_following);
-    else cl_unit<7, 3, KW, K, NEXT>(Wt, Kc, res, out, g, smem, n, cg, 4, lane, wnext, cg_following);
+    if (tile < 3) cl_unit<7, 2, KW, K, NEXT>(Wt, Kc, res, out, g, smem, n, cg, 2 * tile, lane, wnext, cg_following);
+    else cl_unit<7, 1, KW, K, NEXT>(Wt, Kc, res, out, g, smem, n, cg, 6, lane, wnext, cg_following);
   }
 }
 
@@ -368,7 +382,7 @@ __device__ __forceinline__ void cl_phase(const uint32_t* __restrict__ Wt, const 
 
 // One workgroup = one image.  KW3: words per K-step of conv3 (2 when its input has 64 channels).
 template <int W, int KW3, bool NEXT>
-__global__ __launch_bounds__(512) void hblock_cl_kernel(const uint64_t* __restrict__ inP, const uint32_t* __restrict__ Wt,
+__global__ __launch_bounds__(CL_MAX_WAVES * 64) void hblock_cl_kernel(const uint64_t* __restrict__ inP, const uint32_t* __restrict__ Wt,
                                                         const float* __restrict__ Kc, const float* __restrict__ res,
                                                         float* __restrict__ out, uint64_t* __restrict__ outP,
                                                         const ClGeo g) {
@@ -455,7 +469,7 @@ bool cl_shape(int C_in, int planes, ClShape& s) {
 long long cl_lds(const ClShape& s, int W, int planes, bool next, ClGeo* g) {
   const int H = W;
   long long off = 16;
-  const int nt = W == 14 ? 7 : 2;
+  const int nt = W == 14 ? 14 : 4;
   if (g) g->lds_done = (unsigned)off;
   off += (2 * nt * 4 + 15) / 16 * 16;
   for (int k = 0; k < 3; ++k) {
@@ -536,7 +550,7 @@ int launch_hblock_cl(const bnn_hip_hblock_desc* d, const uint64_t* inP, const ui
   g.na_off = (unsigned)L.next_a_off;
   g.nb_off = (unsigned)L.next_b_off;
   g.f32_bytes = (unsigned)((long long)d->N * d->planes * d->H * d->W * 4);
-  const int waves = d->waves > 0 ? std::min(d->waves, 8) : 8;
+  const int waves = d->waves > 0 ? std::min(d->waves, CL_MAX_WAVES) : CL_MAX_WAVES;
   const size_t lds = (size_t)g.lds16 * 16;
 #define CL_LAUNCH(W_, KW3_, NEXT_)                                                                                      \
   hipLaunchKernelGGL((hblock_cl_kernel<W_, KW3_, NEXT_>), dim3((unsigned)d->N), dim3((unsigned)waves * kWave), lds, stream, \

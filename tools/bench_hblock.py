@@ -10,7 +10,7 @@ from bnn_amd import hipops
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 DEV = "cuda:0"
 SHAPES = [(64, 64, 56), (64, 128, 28), (128, 128, 28), (128, 256, 14), (256, 256, 14), (256, 512, 7), (512, 512, 7)]
-PLANS = [("default", {}), ("whole", dict(throughput=True)), ("cl8", dict(channel_lanes=True)), ("cl4", dict(channel_lanes=True, waves=4))]
+PLANS = [("default", {}), ("whole", dict(throughput=True)), ("cl12", dict(channel_lanes=True)), ("cl8", dict(channel_lanes=True, waves=8))]
 if os.environ.get("PLANS"):
     PLANS = [(p, eval("dict(%s)" % p)) for p in os.environ["PLANS"].split(";")]
 
