@@ -175,8 +175,18 @@ class TwoHalves:
     def _streams(self, device):
         return torch.cuda.current_stream(device), self.side
 
+    # Share of the batch that runs on the CALLER's stream.  The side half is enqueued first, and the two stems cannot run
+    # side by side (a stem fills the register files): the half that starts second finishes ~one stem later, and nothing
+    # of the NEXT call may start before both are done (the caller's tensors are ordered on the caller's stream).  The
+    # side half therefore gets fewer images: 136 + 120 of 256 measured best (k images/s, 20 steps / sustained: 128 + 128
+    # 224.6 / 240.2, 136 + 120 239.3 / 248.2, 144 + 112 221.9 / 232.3; BNN_AMD_SPLIT_SHARE overrides).
+    SHARE_CUR = float(os.environ.get("BNN_AMD_SPLIT_SHARE", "0.53"))
+
+    def _split(self, n: int) -> int:
+        return min(n - 1, max(1, int(round(n * self.SHARE_CUR / 8.0)) * 8 if n >= 64 else (n + 1) // 2))
+
     def captured(self, x: torch.Tensor) -> bool:
-        h = (x.shape[0] + 1) // 2
+        h = self._split(x.shape[0])
         keys = [((n,) + tuple(x.shape[1:]), st.cuda_stream) for n, st in zip((h, x.shape[0] - h), self._streams(x.device))]
         return all(k in e._split for k, e in zip(keys, self.engines))
 
@@ -184,7 +194,7 @@ class TwoHalves:
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         dev = x.device
         cur, side = self._streams(dev)
-        h = (x.shape[0] + 1) // 2
+        h = self._split(x.shape[0])
         with self._lock:
             if self._done is not None:           # a caller on ANOTHER stream may still be reading the halves' static
                 cur.wait_event(self._done)       # output buffers (its torch.cat): overwrite them only behind it
