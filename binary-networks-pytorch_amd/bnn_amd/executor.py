@@ -362,8 +362,18 @@ class FusedResNet(nn.Module):
         -> (fp32 NCHW, sign planes).  ``out``: the results of an earlier call to overwrite (one-kernel stem only)."""
         m = self.model
         if self._stem_mfma:
-            return hipops.stem7x7(x, m.conv1.weight, self._stem[0], self._stem[1],
-                                  exact_fp32=self.stem_exact_fp32, fp16=self.stem_fp16, out=out)
+            # a hierarchical block behind the stem reads sign(relu(bn1(t))): the stem kernel writes THOSE planes (its own
+            # packing pass over the fp32 tensor disappears); the tag tells _run_h whose planes they are
+            b0 = self._blocks[0] if self._blocks else None
+            aff = None
+            if (b0 is not None and b0["kind"] == "h" and b0.get("hpack") is not None and b0["relu"][0] and b0["ds"] is None
+                    and not self.stem_exact_fp32 and _TAP is None and b0["hpack"].c_in == 64):
+                aff = b0["bn"][0]
+            t, pk = hipops.stem7x7(x, m.conv1.weight, self._stem[0], self._stem[1], exact_fp32=self.stem_exact_fp32,
+                                   fp16=self.stem_fp16, out=out, pack_affine=aff)
+            if aff is not None:
+                pk._h_for = b0
+            return t, pk
         if out is not None:
             raise FusionError("only the one-kernel stem writes into preallocated buffers")
         if self._stem is not None:   # the conv runs in the vendor library, its BN -> ReLU -> MaxPool -> sign tail in one pass

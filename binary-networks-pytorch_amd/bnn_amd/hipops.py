@@ -184,11 +184,13 @@ def orpool_packed(a: PackedAct, k: int) -> PackedAct:
 
 def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: torch.Tensor,
             out_f32: bool = True, out_packed: bool = True, exact_fp32: bool = False, fp16: bool = False,
-            out: Optional[tuple] = None):
+            out: Optional[tuple] = None, pack_affine: Optional[tuple] = None):
     """conv 7x7/2/3 (3->64, no bias) -> folded BN -> ReLU -> MaxPool 3/2/1 in one MFMA kernel
     (bnn/models/resnet.py:93-96,150-153).  Returns (fp32 NCHW | None, PackedAct | None).
     ``out = (y, PackedAct)``: write into these preallocated results of an earlier call with the same input shape
-    (the static buffers a captured HIP graph of the rest of the network reads: ``FusedResNet.forward_fresh``)."""
+    (the static buffers a captured HIP graph of the rest of the network reads: ``FusedResNet.forward_fresh``).
+    ``pack_affine = (scale, shift)``: the planes are those of ``fmaf(y, scale[c], shift[c]) > 0`` — the input of a
+    pre-activation block's first binary layer (its bn1 + ReLU) — instead of ``y > 0``; the fp32 output is unchanged."""
     x = _require_cuda_f32(x, "stem input")
     w = _require_cuda_f32(w.detach(), "stem weight")
     if x.dim() != 4 or x.shape[1] != 3 or tuple(w.shape) != (64, 3, 7, 7):
@@ -213,8 +215,18 @@ def stem7x7(x: torch.Tensor, w: torch.Tensor, bn_scale: torch.Tensor, bn_shift: 
         # tensor (include/bnn_hip.h) — larger batches go in several launches
         step = max(1, min(N, _MAX_DESC_BYTES // max(12 * H * W, 256 * hp * wp)))
         flags = native.STEM_EXACT_FP32 if exact_fp32 else (native.STEM_FP16 if fp16 else 0)
+        if pack_affine is not None:
+            if exact_fp32 or pk is None:
+                raise native.NativeError("bnn_amd: stem7x7(pack_affine=...) needs packed output and is not built for the exact-fp32 stem")
+            pa, pb = _per_channel(pack_affine[0], 64, "pack scale"), _per_channel(pack_affine[1], 64, "pack shift")
         for n0 in range(0, N, step):
             n1 = min(N, n0 + step)
+            if pack_affine is not None:
+                native.check(lib.bnn_hip_stem7x7_bn_relu_pool_pack_affine_f32(
+                    x[n0:n1].data_ptr(), w.data_ptr(), bn_scale.data_ptr(), bn_shift.data_ptr(), pa.data_ptr(), pb.data_ptr(),
+                    n1 - n0, H, W, flags, None if y is None else y[n0:n1].data_ptr(), pk.P[n0:n1].data_ptr(),
+                    pk.M[n0:n1].data_ptr(), _stream(x.device)), "bnn_hip_stem7x7_bn_relu_pool_pack_affine_f32")
+                continue
             native.check(lib.bnn_hip_stem7x7_bn_relu_pool_pack_f32(
                 x[n0:n1].data_ptr(), w.data_ptr(), bn_scale.data_ptr(), bn_shift.data_ptr(), n1 - n0, H, W, flags,
                 None if y is None else y[n0:n1].data_ptr(),

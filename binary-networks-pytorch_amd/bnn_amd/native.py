@@ -47,7 +47,7 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_stem7x7_conv_f32", "bnn_hip_stem7x7_wgrad_workspace_bytes", "bnn_hip_stem7x7_wgrad_f32",
     "bnn_hip_avgpool2x2_backward_f32", "bnn_hip_xnor_grad_pack_weight_f32",
     "bnn_hip_hblock_supported", "bnn_hip_hblock_layout_of", "bnn_hip_hblock_pack_weights", "bnn_hip_hblock_forward",
-    "bnn_hip_avgpool2_bn_pack2_f32", "bnn_hip_hblock_pack_weights_cl",
+    "bnn_hip_avgpool2_bn_pack2_f32", "bnn_hip_hblock_pack_weights_cl", "bnn_hip_stem7x7_bn_relu_pool_pack_affine_f32",
 )
 
 
@@ -162,6 +162,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_bconv2d_direct_plan.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(FlyPlan)]
     lib.bnn_hip_bconv2d_direct.argtypes = [ctypes.POINTER(ConvDesc), _vp, _i] + [_vp] * 6 + \
         [ctypes.POINTER(FlyPlan), _vp]
+    lib.bnn_hip_stem7x7_bn_relu_pool_pack_affine_f32.argtypes = [_vp] * 6 + [_i, _i, _i, _i, _vp, _vp, _vp, _vp]
     lib.bnn_hip_stem7x7_conv_f32.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp, _vp]
     lib.bnn_hip_avgpool_fc_f32.argtypes = [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]
     lib.bnn_hip_stem7x7_wgrad_workspace_bytes.argtypes = [_i, _i, _i]

@@ -137,6 +137,9 @@ int launch_bconv_lds(const ConvP& p, hipStream_t s);
 int launch_stem_rows(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
                       int W, int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream);
 int launch_stem_conv(const float* x, const float* w, int N, int H, int W, int half, float* out, hipStream_t stream);
+int launch_stem_rows_aff(const float* x, const float* w, const float* bn_a, const float* bn_b, const float* pk_a,
+                         const float* pk_b, int N, int H, int W, int half, float* out, uint64_t* P, uint64_t* M,
+                         hipStream_t stream);
 // stem_wgrad.hip: weight gradient of the stem convolution (fp32 MFMA; partial slabs in `work`, reduced in index order)
 bool stem_wgrad_supported(int H, int W);
 size_t stem_wgrad_workspace_bytes(int N, int H, int W);

@@ -312,6 +312,24 @@ int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w, const 
                           static_cast<hipStream_t>(stream));
 }
 
+int bnn_hip_stem7x7_bn_relu_pool_pack_affine_f32(const float* x, const float* w, const float* bn_scale,
+                                                 const float* bn_shift, const float* pack_scale, const float* pack_shift,
+                                                 int N, int H, int W, int flags, float* out_f32, uint64_t* P, uint64_t* M,
+                                                 void* stream) {
+  if (!x || !w || !bn_scale || !bn_shift || !pack_scale || !pack_shift || !P || !M || N <= 0 || H <= 0 || W <= 0)
+    return BNN_HIP_ERR_INVALID_ARG;
+  if (flags & ~BNN_HIP_STEM_FP16) return BNN_HIP_ERR_INVALID_ARG;   // (the exact-fp32 stem has no such variant)
+  if (!aligned(P, 8) || !aligned(M, 8)) return BNN_HIP_ERR_INVALID_ARG;
+  {
+    const long long hc = (H - 1) / 2 + 1, wc = (W - 1) / 2 + 1, hp = (hc - 1) / 2 + 1, wp = (wc - 1) / 2 + 1;
+    if (mulc(N, 12, H, W) > kMaxDescBytes || mulc(N, 256, hp, wp) > kMaxDescBytes) return BNN_HIP_ERR_TOO_LARGE;
+  }
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_stem_rows_aff(x, w, bn_scale, bn_shift, pack_scale, pack_shift, N, H, W, (flags & BNN_HIP_STEM_FP16) != 0,
+                                   out_f32, P, M, static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_stem7x7_conv_f32(const float* x, const float* w, int N, int H, int W, int flags, float* out,
                              void* stream) {
   if (!x || !w || !out || N <= 0 || H <= 0 || W <= 0) return BNN_HIP_ERR_INVALID_ARG;

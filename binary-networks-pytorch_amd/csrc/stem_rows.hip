@@ -197,12 +197,17 @@ constexpr unsigned kRowsOOB = 0xFFFFFFF0u;  // beyond every descriptor's num_rec
 // RAW (round 5, the training forward: bnn_hip_stem7x7_conv_f32): the convolution alone — every conv row leaves as it is
 // finished, fp32 [N, 64, Hc, Wc]; no BatchNorm, no pooling, no sign planes (bn_a / bn_b / P / M unused).  The same
 // MFMA stream, so the values are the ones the fused kernel normalises and pools.
-template <bool HALF, bool RAW = false>
+// AFF (round 6): the sign planes are those of fmaf(y, pk_a[c], pk_b[c]) instead of y — the first binary layer of a
+// pre-activation network (a hierarchical block: bn1 -> relu -> conv1, hierarchical_block.py:39) binarises the stem's output
+// behind its own BatchNorm; with it the separate packing pass over the fp32 tensor disappears.  The fp32 output is unchanged.
+template <bool HALF, bool RAW = false, bool AFF = false>
 __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bn_a,
     const float* __restrict__ bn_b, int N, int H, int W, int Hc, int Wc, int Hp, int Wp, int tiles_y,
     int tiles_x, int seg_len, int nseg, unsigned x_bytes, float* __restrict__ out, uint64_t* __restrict__ P,
-    uint64_t* __restrict__ M, unsigned out_bytes, unsigned plane_bytes) {
+    uint64_t* __restrict__ M, unsigned out_bytes, unsigned plane_bytes, const float* __restrict__ pk_a = nullptr,
+    const float* __restrict__ pk_b = nullptr) {
+  static_assert(!(AFF && RAW), "the raw convolution writes no planes");
   using namespace stemr;
 #ifndef BNN_ROWS_AHEAD  // fragment sets requested ahead in the split mode (each set: 32 VGPRs of the ring)
 #define BNN_ROWS_AHEAD 1
@@ -289,6 +294,23 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
       for (int r = 0; r < 4; ++r) {  // waited for HERE: inside the loop the wait would also cover the next patch's loads
         asm volatile("" : "+v"(ba[tt][r]));
         asm volatile("" : "+v"(bb[tt][r]));
+      }
+  }
+  [[maybe_unused]] float pka[2][4], pkb[2][4];
+  if constexpr (AFF) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pka[tt][r] = pk_a[32 * nh + 16 * tt + 4 * lg + r];
+        pkb[tt][r] = pk_b[32 * nh + 16 * tt + 4 * lg + r];
+      }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        asm volatile("" : "+v"(pka[tt][r]));
+        asm volatile("" : "+v"(pkb[tt][r]));
       }
   }
 #if BNN_ROWS_PRIO
@@ -639,7 +661,14 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
         }
       }
       uint32_t z0, z1;
-      sign_bits8(z0, z1, v8);
+      if constexpr (AFF) {   // (v8[4 * tt + r]: channel 32 * nh + 16 * tt + 4 * lg + r)
+        float u8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u8[j] = fmaf(v8[j], pka[j >> 2][j & 3], pkb[j >> 2][j & 3]);
+        sign_bits8(z0, z1, u8);
+      } else {
+        sign_bits8(z0, z1, v8);
+      }
       if (P != nullptr && !(BNN_ROWS_ABL & 32)) {
         // channel 16*tt + 4*lg + r is bit 16*tt + 4*lg + r of this wave's half of the pixel's word
         const uint32_t wd = or_rows((z0 | (z1 << 16)) << (4 * lg));
@@ -721,9 +750,10 @@ __global__ __launch_bounds__(stemr::NT, 2) BNN_ROWS_VGPR_ATTR void stem_rows_ker
 #endif
 }
 
-template <bool HALF, bool RAW = false>
+template <bool HALF, bool RAW = false, bool AFF = false>
 static int launch_stem_rows_t(const float* x, const float* w, const float* bn_a, const float* bn_b, int N, int H,
-                              int W, float* out, uint64_t* P, uint64_t* M, hipStream_t stream) {
+                              int W, float* out, uint64_t* P, uint64_t* M, hipStream_t stream,
+                              const float* pk_a = nullptr, const float* pk_b = nullptr) {
   using namespace stemr;
   const int Hc = (H + 6 - KS) / 2 + 1, Wc = (W + 6 - KS) / 2 + 1;
   const int Hp = (Hc + 2 - 3) / 2 + 1, Wp = (Wc + 2 - 3) / 2 + 1;
@@ -740,15 +770,15 @@ static int launch_stem_rows_t(const float* x, const float* w, const float* bn_a,
   const int seg_len = strips >= grid ? tiles_y : (int)((ntiles + grid - 1) / grid);
   const int nseg = strips >= grid ? (int)((strips + grid - 1) / grid) : 1;
   // per device and per kernel, so it is set on every launch (no mutable global state in a re-entrant API)
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_rows_kernel<HALF, RAW>),
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_rows_kernel<HALF, RAW, AFF>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
     return BNN_HIP_ERR_LAUNCH;
   // byte sizes of the streams (the C-ABI caps every tensor below 2^32 bytes)
   const unsigned out_bytes = (unsigned)((long long)N * COUT * (RAW ? (long long)Hc * Wc : (long long)Hp * Wp) * 4);
   const unsigned plane_bytes = (unsigned)((long long)N * Hp * Wp * 8);
   const unsigned x_bytes = (unsigned)((long long)N * CIN * H * W * 4);
-  hipLaunchKernelGGL((stem_rows_kernel<HALF, RAW>), dim3(grid), dim3(NT), LDS_BYTES, stream, x, w, bn_a, bn_b, N, H, W,
-                     Hc, Wc, Hp, Wp, tiles_y, tiles_x, seg_len, nseg, x_bytes, out, P, M, out_bytes, plane_bytes);
+  hipLaunchKernelGGL((stem_rows_kernel<HALF, RAW, AFF>), dim3(grid), dim3(NT), LDS_BYTES, stream, x, w, bn_a, bn_b, N, H, W,
+                     Hc, Wc, Hp, Wp, tiles_y, tiles_x, seg_len, nseg, x_bytes, out, P, M, out_bytes, plane_bytes, pk_a, pk_b);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
@@ -756,6 +786,14 @@ int launch_stem_rows(const float* x, const float* w, const float* bn_a, const fl
                      int half, float* out, uint64_t* P, uint64_t* M, hipStream_t stream) {
   return half ? launch_stem_rows_t<true>(x, w, bn_a, bn_b, N, H, W, out, P, M, stream)
               : launch_stem_rows_t<false>(x, w, bn_a, bn_b, N, H, W, out, P, M, stream);
+}
+
+// The sign planes behind a per-channel affine of the output (see AFF above).
+int launch_stem_rows_aff(const float* x, const float* w, const float* bn_a, const float* bn_b, const float* pk_a,
+                         const float* pk_b, int N, int H, int W, int half, float* out, uint64_t* P, uint64_t* M,
+                         hipStream_t stream) {
+  return half ? launch_stem_rows_t<true, false, true>(x, w, bn_a, bn_b, N, H, W, out, P, M, stream, pk_a, pk_b)
+              : launch_stem_rows_t<false, false, true>(x, w, bn_a, bn_b, N, H, W, out, P, M, stream, pk_a, pk_b);
 }
 
 // The convolution alone (training forward): fp32 [N, 64, Hc, Wc].

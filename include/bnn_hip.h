@@ -311,6 +311,15 @@ int bnn_hip_stem7x7_bn_relu_pool_pack_f32(const float* x, const float* w,
  * Hc = (H - 1) / 2 + 1.  The same MFMA stream as the fused stem (fp32 operands as fp16 hi + lo, three products, fp32
  * accumulation; flags = BNN_HIP_STEM_FP16: plain fp16 operands): the values the fused kernel normalises and pools, bit
  * for bit.  Same size limits as the fused stem.                                                                     */
+/* The same kernel with the sign planes taken behind a per-channel affine of its output (ABI 15):
+ *     P = fmaf(y, pack_scale[c], pack_shift[c]) > 0,  M = 0          (y: the pooled ReLU output, written to out_f32 unchanged)
+ * — what the first binary layer of a pre-activation network reads (HBlock: bn1 -> relu -> conv1, hierarchical_block.py:39):
+ * the packing pass over the fp32 tensor (bnn_hip_bn_act_pack_f32, relu = 1) disappears, same bits.  flags: 0 or
+ * BNN_HIP_STEM_FP16.                                                                                              */
+int bnn_hip_stem7x7_bn_relu_pool_pack_affine_f32(const float* x, const float* w, const float* bn_scale,
+                                                 const float* bn_shift, const float* pack_scale, const float* pack_shift,
+                                                 int N, int H, int W, int flags, float* out_f32, uint64_t* P, uint64_t* M,
+                                                 void* stream);
 int bnn_hip_stem7x7_conv_f32(const float* x, const float* w, int N, int H, int W, int flags, float* out, void* stream);
 
 /* ABI 14 — the weight gradient of that convolution: the training backward of bnn/models/resnet.py:150 (the input is data,

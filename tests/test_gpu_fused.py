@@ -741,3 +741,35 @@ def test_images_beyond_the_24_bit_index_range_take_the_generic_kernel():
         assert torch.equal(big.P[n:n + 1, :, r0 + lo:r0 + hi], small.P[:, :, lo:hi])
         assert torch.equal(big.M[n:n + 1, :, r0 + lo:r0 + hi], small.M[:, :, lo:hi])
     assert bool(big.P.any()) and not bool(big.M.any())
+
+
+@pytest.mark.parametrize("fp16", [False, True], ids=["f16x3", "f16"])
+@pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 64, 64), (1, 3, 32, 32), (2, 3, 50, 38), (1, 3, 97, 131),
+                                   (1, 3, 7, 9), (129, 3, 224, 224)])
+def test_stem_planes_behind_the_first_blocks_batchnorm(shape, fp16):
+    """bnn_hip_stem7x7_bn_relu_pool_pack_affine_f32 (ABI 15): the stem's planes taken behind a per-channel affine of its
+    output — what a pre-activation block's first binary layer reads (hierarchical_block.py:39) — are the planes the
+    packing pass computes from the stem's fp32 output (bnn_hip_bn_act_pack_f32, relu = 1), bit for bit; the fp32 output is
+    the plain stem's."""
+    x = dev(gen.normal(gen.seed_of("stemaff", shape), (min(shape[0], 6),) + shape[1:]))
+    x = x.repeat((shape[0] + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:shape[0]].contiguous()
+    w = dev(gen.conv_weight("kaiming", 3, (64, 3, 7, 7)))
+    a = dev((0.5 + gen.uniform(1, (64,))).astype(np.float32) * np.where(np.arange(64) % 7 == 0, -1, 1).astype(np.float32))
+    b = dev((0.3 * gen.normal(2, (64,))).astype(np.float32))
+    pa = dev((0.4 + gen.uniform(3, (64,))).astype(np.float32) * np.where(np.arange(64) % 5 == 0, -1, 1).astype(np.float32))
+    pb = dev((-0.6 + 0.5 * gen.normal(4, (64,))).astype(np.float32))
+    y0, _ = hipops.stem7x7(x, w, a, b, fp16=fp16)
+    ref = hipops.bn_act_pack(y0, pa, pb, relu=True)
+    y1, p1 = hipops.stem7x7(x, w, a, b, fp16=fp16, pack_affine=(pa, pb))
+    assert torch.equal(y0, y1) and torch.equal(p1.P, ref.P) and torch.equal(p1.M, ref.M)
+    frac = float((p1.P != hipops.stem7x7(x, w, a, b, fp16=fp16)[1].P).float().mean())
+    assert frac > 0.5                        # (the affine really moves signs: not the plain planes again)
+    _, p2 = hipops.stem7x7(x, w, a, b, fp16=fp16, pack_affine=(pa, pb), out_f32=False)
+    assert torch.equal(p2.P, ref.P)
+    with pytest.raises(native.NativeError):
+        hipops.stem7x7(x[:1], w, a, b, exact_fp32=True, pack_affine=(pa, pb))
+    lib = native.require()
+    args = (x.data_ptr(), w.data_ptr(), a.data_ptr(), b.data_ptr(), pa.data_ptr(), pb.data_ptr(), 1, shape[2], shape[3])
+    assert lib.bnn_hip_stem7x7_bn_relu_pool_pack_affine_f32(*args, native.STEM_EXACT_FP32, None, p1.P.data_ptr(),
+                                                            p1.M.data_ptr(), None) == -1
+    assert lib.bnn_hip_stem7x7_bn_relu_pool_pack_affine_f32(*args, 0, None, None, None, None) == -1

@@ -173,6 +173,14 @@ int launch_stem(const float* x, const float* w, const float* a, const float* b, 
   REQUIRE(!P || (al(P, 8) && al(M, 8)));
   return BNN_HIP_OK;
 }
+int launch_stem_rows_aff(const float* x, const float* w, const float* a, const float* b, const float* pa, const float* pb,
+                         int N, int H, int W, int, float*, uint64_t* P, uint64_t* M, hipStream_t) {
+  ++g_reached;
+  REQUIRE(x && w && a && b && pa && pb && P && M && N > 0 && H > 0 && W > 0 && al(P, 8) && al(M, 8));
+  const long long hc = (H - 1) / 2 + 1, wc = (W - 1) / 2 + 1, hp = (hc - 1) / 2 + 1, wp = (wc - 1) / 2 + 1;
+  REQUIRE((long long)N * 3 * H * W * 4 <= kDesc && (long long)N * 64 * hp * wp * 4 <= kDesc);
+  return BNN_HIP_OK;
+}
 int launch_stem_conv(const float* x, const float* w, int N, int H, int W, int, float* out, hipStream_t) {
   ++g_reached;
   REQUIRE(x && w && out && N > 0 && H > 0 && W > 0);
@@ -347,7 +355,7 @@ int main(int argc, char** argv) {
   for (long it = 0; it < iters; ++it) {
     ++g_calls;
     int st = 0;
-    switch (rnd() % 40) {
+    switch (rnd() % 41) {
       case 0: { bnn_hip_conv_desc d = pick_desc();
         st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
                              pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
@@ -477,6 +485,10 @@ int main(int argc, char** argv) {
         break; }
       case 38: st = bnn_hip_hblock_pack_weights_cl(pick_int(), pick_int(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(),
                                                    pick_ptr<uint32_t>(), stream); break;
+      case 39: st = bnn_hip_stem7x7_bn_relu_pool_pack_affine_f32(pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(),
+                                                                pick_ptr<float>(), pick_ptr<float>(), pick_int(), pick_int(), pick_int(),
+                                                                pick_int() & 3, pick_ptr<float>(), pick_ptr<uint64_t>(),
+                                                                pick_ptr<uint64_t>(), stream); break;
       case 37: st = bnn_hip_hblock_pack_weights(pick_int(), pick_int(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(),
                                                 pick_ptr<uint32_t>(), stream); break;
       case 33: st = bnn_hip_xnor_grad_pack_weight_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(),
