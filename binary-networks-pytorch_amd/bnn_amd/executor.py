@@ -399,6 +399,8 @@ class FusedResNet(nn.Module):
         for i, b in enumerate(self._blocks):
             nxt = self._blocks[i + 1] if i < last else None
             if b["kind"] == "pool":
+                if t is None and packed is not None and getattr(packed, "_h_for", None) is nxt:
+                    continue                # the previous block's launch pooled and binarised its own output (_run_h)
                 fused = self._pool_into_hblock(b["mod"], nxt, t)
                 if fused is not None:       # the pool + both sign planes the next stage's first block reads, one pass
                     t, packed = fused
@@ -409,7 +411,7 @@ class FusedResNet(nn.Module):
                 t, packed = self._run_pre(b, nxt, t, packed)
                 continue
             if b["kind"] == "h":
-                t, packed = self._run_h(b, t, packed, nxt)
+                t, packed = self._run_h(b, t, packed, nxt, self._blocks[i + 2] if i + 2 <= last else None)
                 continue
             if packed is None:
                 packed = hipops.pack_act(t)
@@ -563,10 +565,36 @@ class FusedResNet(nn.Module):
             b.setdefault("hcl", {})[(N, H, W)] = cl
         return ok
 
-    def _run_h(self, b, t, packed=None, nxt=None):
+    def _pooled_form(self, b, nxt, nxt2, N, H, W):
+        """The constants of ``hipops.hblock_pool_forward`` when block ``b`` ends a stage — ``nxt`` is ``AvgPool2d(2, 2)`` and
+        ``nxt2`` a one-launch hierarchical block with a shortcut convolution, so that nobody reads ``b``'s fp32 output —
+        and the kernel covers the geometry; else None."""
+        key = ("pool", N, H, W)
+        hit = b["hgeo"].get(key)
+        if hit is None:
+            hit = False
+            pool = nxt["mod"] if nxt is not None and nxt["kind"] == "pool" else None
+            hp = b["hpack"]
+            if (os.environ.get("BNN_AMD_HBLOCK_POOL", "1") != "0" and _TAP is None and pool is not None and nxt2 is not None
+                    and nxt2["kind"] == "h" and nxt2.get("hpack") is not None and nxt2["ds"] is not None and nxt2["relu"][0]
+                    and isinstance(pool, nn.AvgPool2d) and pool.kernel_size in (2, (2, 2)) and pool.stride in (2, (2, 2))
+                    and pool.padding in (0, (0, 0)) and H % 2 == 0 and W % 2 == 0 and hp.c_in == hp.planes
+                    and H * W >= int(os.environ.get("BNN_AMD_HBLOCK_POOL_MIN", "784"))
+                    and nxt2["hpack"].c_in == hp.planes and self._hblock_ok(nxt2, N, H // 2, W // 2)
+                    and hipops.hblock_pool_supported(N, hp.c_in, H, W, hp.planes, self.throughput_mode)):
+                try:
+                    hit = hipops.hblock_pool_consts(nxt2["bn"][0], nxt2["ds"][0], hp.planes)
+                except native.NativeError:      # (a scale that cannot take the average's 1 / 4 exactly)
+                    hit = False
+            b["hgeo"][key] = hit
+        return None if hit is False else hit
+
+    def _run_h(self, b, t, packed=None, nxt=None, nxt2=None):
         """HBlock: three BN-act-conv stages write their slice of the concatenated output in place, each
         adds its slice of the shortcut and hands ``sign(act(bn_next(o_k)))`` to the next stage.  Returns
-        ``(y, planes of the next block's input | None)``; ``packed``: what the previous block's launch left for this one."""
+        ``(y, planes of the next block's input | None)``; ``packed``: what the previous block's launch left for this one.
+        The last block of a stage returns ``(None, planes of the next stage's first block)``: pooled and binarised in the
+        same launch (``_pooled_form``)."""
         mine = packed is not None and getattr(packed, "_h_for", None) is b    # planes the previous launch left for this block
         if b["ds"] is not None:
             (sa, sb), conv = b["ds"]
@@ -582,6 +610,12 @@ class FusedResNet(nn.Module):
             if self._hblock_ok(b, N, H, W):
                 if not mine:
                     packed = hipops.bn_act_pack(t, *b["bn"][0], relu=True)
+                kp = self._pooled_form(b, nxt, nxt2, N, H, W)
+                if kp is not None:
+                    p1, p2 = hipops.hblock_pool_forward(packed, hp, idn, kp, throughput=self.throughput_mode)
+                    p1._h_for = nxt2
+                    p1._ds_planes = p2
+                    return None, p1
                 y, pk = hipops.hblock_forward(packed, hp, idn, out_packed=hp.has_next, throughput=self.throughput_mode,
                                               channel_lanes=b["hcl"][(N, H, W)])
                 if pk is not None:

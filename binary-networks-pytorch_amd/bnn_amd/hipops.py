@@ -783,6 +783,59 @@ def hblock_forward(a: PackedAct, pack: HBlockPack, residual: torch.Tensor, out_p
     return y, pk
 
 
+def hblock_pool_supported(N: int, c_in: int, H: int, W: int, planes: int, throughput: bool = False, rows_per_band: int = 0,
+                          images_per_band: int = 0, waves: int = 0) -> bool:
+    """Whether ``hblock_pool_forward`` covers this geometry (with this plan) on the current device."""
+    lib = native.require()
+    d = _hblock_desc(N, c_in, H, W, planes, throughput, rows_per_band, images_per_band, waves)
+    return bool(lib.bnn_hip_hblock_pool_supported(ctypes.byref(d)))
+
+
+def hblock_pool_consts(bn1, bn_ds, planes: int) -> torch.Tensor:
+    """The constants of ``hblock_pool_forward`` (include/bnn_hip.h: ``[a1/4 | b1 | a2/4 | b2 | -a2/4 | -b2 | 0 | 0]``) from
+    the folded bn1 of the next stage's first block and the folded BatchNorm of its shortcut (hierarchical_block.py:30-39).
+    The average's division by 4 moves into the scales; raises when that is not exact (a scale next to the smallest normal)."""
+    a1, b1, a2, b2 = (_per_channel(t, planes, "pool bn") for t in (bn1[0], bn1[1], bn_ds[0], bn_ds[1]))
+    q1, q2 = a1 * 0.25, a2 * 0.25
+    if not (bool((q1 * 4.0 == a1).all()) and bool((q2 * 4.0 == a2).all())):
+        raise native.NativeError("bnn_amd: hblock_pool_consts: a BatchNorm scale too small to be divided by 4 exactly")
+    z = torch.zeros_like(a1)
+    return torch.cat((q1, b1, q2, b2, -q2, -b2, z, z)).contiguous()
+
+
+def hblock_pool_forward(a: PackedAct, pack: HBlockPack, residual: torch.Tensor, pool_consts: torch.Tensor,
+                        throughput: bool = False, rows_per_band: int = 0, images_per_band: int = 0, waves: int = 0):
+    """The LAST hierarchical block of a stage + ``AvgPool2d(2, 2)`` + the two binarisations of the pooled tensor that the
+    next stage's first block performs (its bn1 -> ReLU -> sign; its shortcut's BatchNorm -> sign), ONE launch, no fp32
+    output (bnn/models/resnet.py: ``nn.Sequential(AvgPool2d(2, 2), HBlock(...))`` stages).  Returns
+    ``(PackedAct of sign(relu(bn1(t))), PackedAct of sign(bn_ds(t)))`` with ``t = AvgPool2d(2, 2)(HBlock(x))``."""
+    lib = native.require()
+    N, c_in, H, W = a.shape
+    if not a.nonneg or c_in != pack.c_in or c_in != pack.planes:
+        raise native.NativeError("bnn_amd: hblock_pool_forward needs non-negative input planes of a width-preserving block")
+    residual = _require_cuda_f32(residual, "residual")
+    if tuple(residual.shape) != (N, pack.planes, H, W) or H % 2 or W % 2:
+        raise native.NativeError(f"bnn_amd: residual shape {tuple(residual.shape)} != block output (even height and width)")
+    if (pool_consts.dtype != torch.float32 or pool_consts.numel() != 8 * pack.planes or not pool_consts.is_contiguous()
+            or pool_consts.device != a.P.device):
+        raise native.NativeError("bnn_amd: pool_consts must be the buffer of hblock_pool_consts")
+    dev = a.P.device
+    with torch.cuda.device(dev):
+        shp = (N, pack.planes // 64, H // 2, W // 2)
+        p1 = PackedAct(torch.empty(shp, dtype=torch.int64, device=dev), _zero_plane(shp, dev),
+                       (N, pack.planes, H // 2, W // 2), nonneg=True)
+        p2 = PackedAct(torch.empty(shp, dtype=torch.int64, device=dev), torch.empty(shp, dtype=torch.int64, device=dev),
+                       (N, pack.planes, H // 2, W // 2))
+        if N == 0:
+            return p1, p2
+        d = _hblock_desc(N, c_in, H, W, pack.planes, throughput, rows_per_band, images_per_band, waves)
+        native.check(lib.bnn_hip_hblock_pool_forward(ctypes.byref(d), a.P.data_ptr(), pack.weights.data_ptr(),
+                                                     pack.consts.data_ptr(), pool_consts.data_ptr(), residual.data_ptr(),
+                                                     p1.P.data_ptr(), p2.P.data_ptr(), p2.M.data_ptr(), _stream(dev)),
+                     "bnn_hip_hblock_pool_forward")
+    return p1, p2
+
+
 _ZERO_PLANES = {}
 
 

@@ -890,6 +890,28 @@ int bnn_hip_hblock_forward(const bnn_hip_hblock_desc* d, const uint64_t* in_P, c
   return bnn::launch_hblock(d, in_P, weights, consts, residual, out, out_P, static_cast<hipStream_t>(stream));
 }
 
+int bnn_hip_hblock_pool_supported(const bnn_hip_hblock_desc* d) {
+  if (check_hblock(d) != BNN_HIP_OK || (d->flags & BNN_HIP_HBLOCK_CHANNEL_LANES)) return 0;
+  return bnn::hblock_pool_supported(d) ? 1 : 0;
+}
+
+int bnn_hip_hblock_pool_forward(const bnn_hip_hblock_desc* d, const uint64_t* in_P, const uint32_t* weights,
+                                const float* consts, const float* pool_consts, const float* residual, uint64_t* out_P1,
+                                uint64_t* out_P2, uint64_t* out_M2, void* stream) {
+  const int st = check_hblock(d);
+  if (st != BNN_HIP_OK) return st;
+  if (d->flags & BNN_HIP_HBLOCK_CHANNEL_LANES) return BNN_HIP_ERR_INVALID_ARG;
+  if (!in_P || !weights || !consts || !pool_consts || !residual || !out_P1 || !out_P2 || !out_M2) return BNN_HIP_ERR_INVALID_ARG;
+  if (!aligned(in_P, 8) || !aligned(weights, 64) || !aligned(consts, 8) || !aligned(pool_consts, 32) || !aligned(residual, 4) ||
+      !aligned(out_P1, 8) || !aligned(out_P2, 8) || !aligned(out_M2, 8))
+    return BNN_HIP_ERR_INVALID_ARG;
+  if (!bnn::hblock_pool_supported(d)) return BNN_HIP_ERR_UNSUPPORTED;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_hblock_pool(d, in_P, weights, consts, pool_consts, residual, out_P1, out_P2, out_M2,
+                                 static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_probe_clock(int spin_iters, double* shader_mhz, double* elapsed_us, void* stream) {
   if (spin_iters <= 0 || spin_iters > (1 << 24) || !shader_mhz) return BNN_HIP_ERR_INVALID_ARG;
   return bnn::launch_probe_clock(spin_iters, shader_mhz, elapsed_us, static_cast<hipStream_t>(stream));

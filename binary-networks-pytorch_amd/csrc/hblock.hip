@@ -23,6 +23,12 @@
 // v_bcnt_u32_b32 (bconv_core.h: stream_weights).  Planes are dense: a cell holds ceil(C_in / 32) words (C_in = 16 / 32:
 // ONE word per tap, not two), and a convolution of 16 output channels runs 16 channels, not a padded block of 32.
 // Same integers and the same float operations, in the same order, as the launch-by-launch form: bit-identical y and planes.
+//
+// MODE 2 (the last block of a stage in front of `AvgPool2d(2, 2)` + a block with a shortcut convolution): y is only ever
+// pooled and binarised — by the next block's bn1 -> ReLU and by its shortcut's BatchNorm (hierarchical_block.py:39, 30-36) —
+// so the launch writes THOSE planes at half resolution and no fp32 tensor at all.  Lanes then walk the pixels window by
+// window (4 lanes = one 2 x 2 window: the pool is three adds across a quad), in every convolution alike, so that the
+// completion counters keep meaning "pixel group g of the previous convolution".
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -61,6 +67,7 @@ struct HbGeo {
   uint32_t m_hw, m_w;
   int s_hw, s_w;
   unsigned f32_bytes;  // bytes of the fp32 tensors (residual, out): the range of their descriptors
+  int ncell_pool;      // MODE 2: cells of one pooled plane set of the region, G * (BR / 2) * (W / 2)
 };
 
 namespace {
@@ -114,6 +121,24 @@ __device__ __forceinline__ void hb_consts(const float* __restrict__ src, float (
   }
 }
 
+// ((v of lane 0 + v of lane 1) + v of lane 2) + v of lane 3 of the lane's quad, in every lane: one DPP move and three adds
+// with a DPP operand
+template <int CTRL>
+__device__ __forceinline__ float hb_quad(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+#else
+  return v;
+#endif
+}
+__device__ __forceinline__ float hb_quad_sum(float v) {
+  float s = hb_quad<0x00>(v);
+  s = hb_quad<0x55>(v) + s;
+  s = hb_quad<0xAA>(v) + s;
+  return hb_quad<0xFF>(v) + s;
+}
+
+constexpr int HB_NONE = 0, HB_NEXT = 1, HB_POOL = 2;  // what a launch leaves for the next block
 constexpr unsigned kOob = 0xFFFFFFF0u;  // a byte offset beyond every descriptor: loads return 0, stores are dropped
 #ifndef HB_MINW  // waves per SIMD the kernel is register-allocated for (8: two 16-wave workgroups per CU)
 #define HB_MINW 4
@@ -122,35 +147,63 @@ constexpr unsigned kOob = 0xFFFFFFF0u;  // a byte offset beyond every descriptor
 // The output domain of phase K in this region (wave-uniform): rows [ra, rb) of kk images, 64-pixel groups.
 struct HbDom {
   int ra, nrows, npix, npg;
+  int rlo, rhi;   // the rows that exist: [rlo, rhi) (POOL: [ra, ra + nrows) is that range widened to whole windows)
 };
+template <bool POOL>
 __device__ __forceinline__ HbDom hb_domain(const HbGeo& g, int K, int kk, int y0, int rows) {
   HbDom d;
-  d.ra = max(0, y0 - g.ph[K].halo);
-  d.nrows = min(g.H, y0 + rows + g.ph[K].halo) - d.ra;  // (kk > 1: whole images, nrows == H)
+  d.rlo = max(0, y0 - g.ph[K].halo);
+  d.rhi = min(g.H, y0 + rows + g.ph[K].halo);
+  d.ra = POOL ? (d.rlo & ~1) : d.rlo;
+  d.nrows = (POOL ? ((d.rhi + 1) & ~1) : d.rhi) - d.ra;  // (kk > 1: whole images, nrows == H)
   d.npix = kk * d.nrows * g.W;
   d.npg = (d.npix + 63) >> 6;
   return d;
+}
+// pixel j of a domain -> (image, row, column).  Linear: row-major.  POOL: window-major, 4 consecutive pixels = one
+// 2 x 2 window (g.m_hw / g.m_w then divide by the WINDOWS of an image / of a row).
+template <bool POOL>
+__device__ __forceinline__ void hb_pixel(const HbGeo& g, const HbDom& d, int kk, int j, int& img, int& row, int& col) {
+  if constexpr (POOL) {
+    const int q = j >> 2, sub = j & 3, wpr = g.W >> 1;
+    int wrem = q;
+    img = 0;
+    if (kk > 1) {
+      img = (int)fast_div((uint32_t)q, g.m_hw, g.s_hw);
+      wrem = q - imul<true>(img, (g.H >> 1) * wpr);
+    }
+    const int wy = (int)fast_div((uint32_t)wrem, g.m_w, g.s_w);
+    row = d.ra + 2 * wy + (sub >> 1);
+    col = 2 * (wrem - imul<true>(wy, wpr)) + (sub & 1);
+  } else {
+    int rem = j;
+    img = 0;
+    if (kk > 1) {
+      img = (int)fast_div((uint32_t)j, g.m_hw, g.s_hw);
+      rem = j - imul<true>(img, g.H * g.W);
+    }
+    const int rowl = (int)fast_div((uint32_t)rem, g.m_w, g.s_w);
+    col = rem - imul<true>(rowl, g.W);
+    row = d.ra + rowl;
+  }
 }
 
 // Wait until the planes under the receptive fields of pixel group `pg` of phase K (>= 1) are complete: every pass of
 // every pixel group of phase K - 1 that holds a row of the hull [first pixel's row - 1, last pixel's row + 1].
 // The phases are not separated by barriers: a unit only ever waits for units with smaller tickets, which running
 // waves hold (csrc/bconv_fly.hip uses the same argument).
+template <bool POOL>
 __device__ __forceinline__ void hb_wait_inputs(const HbGeo& g, int K, const HbDom& d, const HbDom& dp, int pg, int kk,
                                                const uint32_t* done_prev, int lane) {
   const int j0 = pg << 6, j1 = min(j0 + 63, d.npix - 1);
-  int i0 = 0, i1 = 0, r0 = j0, r1 = j1;
-  const int hw = g.H * g.W;
-  if (kk > 1) {
-    i0 = (int)fast_div((uint32_t)j0, g.m_hw, g.s_hw);
-    i1 = (int)fast_div((uint32_t)j1, g.m_hw, g.s_hw);
-    r0 = j0 - i0 * hw;
-    r1 = j1 - i1 * hw;
-  }
-  const int row0 = d.ra + (int)fast_div((uint32_t)r0, g.m_w, g.s_w), row1 = d.ra + (int)fast_div((uint32_t)r1, g.m_w, g.s_w);
+  int i0, i1, row0, row1, c0, c1;
+  hb_pixel<POOL>(g, d, kk, j0, i0, row0, c0);
+  hb_pixel<POOL>(g, d, kk, j1, i1, row1, c1);
   const int per_img = dp.nrows * g.W;
-  const int lo = (i0 * per_img + (max(row0 - 1, dp.ra) - dp.ra) * g.W) >> 6;
-  const int hi = (i1 * per_img + (min(row1 + 1, dp.ra + dp.nrows - 1) - dp.ra) * g.W + g.W - 1) >> 6;
+  // (POOL: a window row = 2 * W consecutive pixels of the previous domain, whose first row is even like this one's)
+  const int above = max(row0 - 1, dp.rlo) - dp.ra, below = min(row1 + 1, dp.rhi - 1) - dp.ra;
+  const int lo = (i0 * per_img + (POOL ? (above >> 1) * 2 : above) * g.W) >> 6;
+  const int hi = (i1 * per_img + (POOL ? (below >> 1) * 2 + 1 : below) * g.W + g.W - 1) >> 6;
   const uint32_t want = (uint32_t)g.ph[K - 1].npass;
   for ([[maybe_unused]] unsigned idle = 0;; ++idle) {
     [[maybe_unused]] bool missing = false;
@@ -172,15 +225,21 @@ __device__ __forceinline__ void hb_wait_inputs(const HbGeo& g, int K, const HbDo
 // One unit of one convolution of the block: passes p0 .. p0 + np - 1 of pixel group `pg`.
 //   CWC / MULTI: words per (chunk, cell) of its input plane; several chunks
 //   K: 0, 1, 2;  CWCN: CWC of the next phase (layout of the plane this one writes; unused for K == 2)
-//   NEXT: the next block's input planes are wanted (sign(act(bn1'(y)))
-template <int CWC, bool MULTI, int K, int CWCN, bool NEXT>
+//   MODE: HB_NEXT — the next block's input planes are wanted (sign(act(bn1'(y)));  HB_POOL — those of AvgPool2d(2)(y) for
+//         its bn1 (P) and its shortcut's BatchNorm (P and M), and no fp32 output.  Kp = [lane of the quad][a | b][C]: lane 0
+//         (a1 / 4, b1), lane 1 (a2 / 4, b2), lane 2 (-a2 / 4, -b2) — each lane of a window tests ONE plane's bit,
+//         fmaf(window sum, a, b) > 0: the division by 4 is exact in the scale, the negative plane is the positive one of
+//         the negated affine
+template <int CWC, bool MULTI, int K, int CWCN, int MODE>
 __device__ __forceinline__ void hb_unit(const uint32_t* __restrict__ Wt, const float* __restrict__ Kc,
-                                        const float* __restrict__ res, float* __restrict__ out, const HbGeo& g,
+                                        const float* __restrict__ Kp, const float* __restrict__ res, float* __restrict__ out,
+                                        const HbGeo& g,
                                         unsigned char* smem, const HbDom& d, uint32_t* done, int pg, int p0, int np, int n0,
                                         int kk, int y0, int rows, int lane) {
   constexpr int NW = 9 * CWC;
   constexpr int NACC = CWC == 1 ? 16 : 8;  // channels per pass: weight runs of NACC * NW words are whole 64-byte lines
   constexpr bool LAST = K == 2;
+  constexpr bool NEXT = MODE == HB_NEXT, POOL = MODE == HB_POOL;
   using f2 = __attribute__((ext_vector_type(2))) float;
   const HbPhase& ph = g.ph[K];
   const int hw = g.H * g.W;
@@ -188,14 +247,12 @@ __device__ __forceinline__ void hb_unit(const uint32_t* __restrict__ Wt, const f
   const BufRsrc rres = make_rsrc_sized(res, g.f32_bytes), rout = make_rsrc_sized(out, g.f32_bytes);
   // the lane's pixel (lanes past the domain's last pixel copy it: same values to the same places)
   const int j = min((pg << 6) + lane, d.npix - 1);
-  int img = 0, rem = j;
-  if (kk > 1) {
-    img = (int)fast_div((uint32_t)j, g.m_hw, g.s_hw);
-    rem = j - imul<true>(img, hw);
-  }
-  const int rowl = (int)fast_div((uint32_t)rem, g.m_w, g.s_w);
-  const int col = rem - imul<true>(rowl, g.W);
-  const int row = d.ra + rowl;
+  int img, row, col;
+  hb_pixel<POOL>(g, d, kk, j, img, row, col);
+  // POOL: a domain widened to whole windows has a row that does not exist (its lanes compute on a copy of the nearest
+  // one and store nothing); lanes past the domain's end would pool four copies of one pixel: they store nothing either
+  [[maybe_unused]] const bool exists = !POOL || (row >= d.rlo && row < d.rhi && (pg << 6) + lane < d.npix);
+  if constexpr (POOL) row = min(max(row, d.rlo), d.rhi - 1);
   const bool interior = row >= y0 && row < y0 + rows;  // a band row: its fp32 values and next-block bits are this region's
   const unsigned lane_off =
       interior ? (unsigned)(imul<true>(imul<true>(n0 + img, g.C), hw) + imul<true>(row, g.W) + col) * 4u : kOob;
@@ -218,6 +275,8 @@ __device__ __forceinline__ void hb_unit(const uint32_t* __restrict__ Wt, const f
     celln = (unsigned)(imul<true>(imul<true>(img, pn.rows_in) + (row - y0 + pn.halo + 1), g.WP) + col + 1);
   }
   if constexpr (NEXT) cello = (unsigned)(imul<true>(imul<true>(img, g.BR) + (row - y0), g.W) + col);
+  if constexpr (POOL)   // the window's cell in a pooled plane set
+    cello = (unsigned)(imul<true>(imul<true>(img, g.BR >> 1) + ((row - y0) >> 1), g.W >> 1) + (col >> 1));
 #pragma unroll 1
   for (int ps = 0; ps < np; ++ps) {
     const int o0 = (p0 + ps) * NACC;
@@ -225,6 +284,16 @@ __device__ __forceinline__ void hb_unit(const uint32_t* __restrict__ Wt, const f
     float resv[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) resv[i] = buf_ld(rres, lane_off, (unsigned)(ph.c_off + o0 + i) * (unsigned)hw * 4u);
+    [[maybe_unused]] float qa[NACC], qb[NACC];
+    if constexpr (POOL) {  // this lane's affine of the pass's channels (4 distinct addresses per wave)
+      const float* kq = Kp + (size_t)((lane & 3) * 2 * g.C + ph.c_off + o0);
+#pragma unroll
+      for (int i = 0; i < NACC; i += 4) {
+        const float4 a4 = *reinterpret_cast<const float4*>(kq + i), b4 = *reinterpret_cast<const float4*>(kq + g.C + i);
+        qa[i] = a4.x; qa[i + 1] = a4.y; qa[i + 2] = a4.z; qa[i + 3] = a4.w;
+        qb[i] = b4.x; qb[i + 1] = b4.y; qb[i + 2] = b4.z; qb[i + 3] = b4.w;
+      }
+    }
     int acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = (int)kCountSeed;
@@ -270,8 +339,16 @@ __device__ __forceinline__ void hb_unit(const uint32_t* __restrict__ Wt, const f
         pvi[i + 1] = v.y;
       }
       const f2 y = ov + f2{resv[i], resv[i + 1]};
-      buf_st(rout, lane_off, (unsigned)co * (unsigned)hw * 4u, y.x);
-      buf_st(rout, lane_off, (unsigned)(co + 1) * (unsigned)hw * 4u, y.y);
+      if constexpr (!POOL) {
+        buf_st(rout, lane_off, (unsigned)co * (unsigned)hw * 4u, y.x);
+        buf_st(rout, lane_off, (unsigned)(co + 1) * (unsigned)hw * 4u, y.y);
+      } else {
+        // AvgPool2d(2, 2) as ATen sums a window (pack_act.hip: avgpool2_bn_pack2): ((y00 + y01) + y10) + y11, every lane
+        // of the quad with the whole sum; then this lane's BatchNorm branch of the next block
+        const f2 v = __builtin_elementwise_fma(f2{hb_quad_sum(y.x), hb_quad_sum(y.y)}, f2{qa[i], qa[i + 1]}, f2{qb[i], qb[i + 1]});
+        pvn[i] = v.x;
+        pvn[i + 1] = v.y;
+      }
       if constexpr (NEXT) {
         const f2 v = __builtin_elementwise_fma(y, f2{kna[i], kna[i + 1]}, f2{knb[i], knb[i + 1]});
         pvn[i] = v.x;
@@ -291,6 +368,22 @@ __device__ __forceinline__ void hb_unit(const uint32_t* __restrict__ Wt, const f
         else *dst = (uint8_t)bits;
       }
     }
+    if constexpr (POOL) {
+      // three pieces per window — bn1: positive (its ReLU: no minus plane); shortcut: positive, negative — stored by
+      // three lanes of the quad, one each
+      uint32_t bits = 0u;
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) bits = shift_in(bits, is_pos(pvn[i]));
+      bits = __builtin_bitreverse32(bits) >> (32 - NACC);
+      const int sub = lane & 3;
+      if (interior && exists && sub < 3) {
+        const int co0 = ph.c_off + o0;
+        const unsigned widx = ((unsigned)((sub * (g.C >> 6) + (co0 >> 6)) * g.ncell_pool) + cello) * 2u + (unsigned)((co0 & 63) >> 5);
+        unsigned char* dst = smem + g.lds_out + widx * 4u + (unsigned)((co0 & 31) >> 3);
+        if constexpr (NACC == 16) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)bits;
+        else *dst = (uint8_t)bits;
+      }
+    }
     if constexpr (!LAST) {
       uint32_t bits = 0u;
 #pragma unroll
@@ -300,8 +393,10 @@ __device__ __forceinline__ void hb_unit(const uint32_t* __restrict__ Wt, const f
       const int wq = o0 >> 5;
       const unsigned widx = ((unsigned)((wq / CWCN) * pn.ncell_in) + celln) * CWCN + (unsigned)(wq % CWCN);
       unsigned char* dst = smem + pn.lds_in + widx * 4u + (unsigned)((o0 & 31) >> 3);
-      if constexpr (NACC == 16) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)bits;
-      else *dst = (uint8_t)bits;
+      if (exists) {
+        if constexpr (NACC == 16) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)bits;
+        else *dst = (uint8_t)bits;
+      }
       // the pass is complete for this pixel group: the byte stores above precede the counter update in this wave's
       // LDS instruction stream (release)
       if (lane == 0) __hip_atomic_fetch_add(&done[pg], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -309,35 +404,39 @@ __device__ __forceinline__ void hb_unit(const uint32_t* __restrict__ Wt, const f
   }
 }
 
-template <int CWC, bool MULTI, int K, int CWCN, bool NEXT>
+template <int CWC, bool MULTI, int K, int CWCN, int MODE>
 __device__ __forceinline__ void hb_phase(const uint32_t* __restrict__ Wt, const float* __restrict__ Kc,
-                                         const float* __restrict__ res, float* __restrict__ out, const HbGeo& g,
-                                         unsigned char* smem, int n0, int kk, int y0, int rows, int lane) {
+                                         const float* __restrict__ Kp, const float* __restrict__ res,
+                                         float* __restrict__ out, const HbGeo& g, unsigned char* smem, int n0, int kk,
+                                         int y0, int rows, int lane) {
+  constexpr bool POOL = MODE == HB_POOL;
   const HbPhase& ph = g.ph[K];
-  const HbDom d = hb_domain(g, K, kk, y0, rows);
+  const HbDom d = hb_domain<POOL>(g, K, kk, y0, rows);
   uint32_t* ctl = reinterpret_cast<uint32_t*>(smem);
   uint32_t* done0 = reinterpret_cast<uint32_t*>(smem + g.lds_done);
   // completion counters: conv1's pixel groups, then conv2's
-  uint32_t* done = K == 0 ? done0 : done0 + hb_domain(g, 0, kk, y0, rows).npg;
+  uint32_t* done = K == 0 ? done0 : done0 + hb_domain<POOL>(g, 0, kk, y0, rows).npg;
   const uint32_t nunits = (uint32_t)(d.npg * ph.upg);
   for (;;) {
     const uint32_t u = hb_ticket(&ctl[K], lane);
     if (u >= nunits) break;
     const int pg = (int)fast_div(u, ph.m_upg, ph.s_upg), p0 = ((int)u - pg * ph.upg) * ph.ppu;
     if constexpr (K > 0) {
-      const HbDom dp = hb_domain(g, K - 1, kk, y0, rows);
-      hb_wait_inputs(g, K, d, dp, pg, kk, K == 1 ? done0 : done, lane);
+      const HbDom dp = hb_domain<POOL>(g, K - 1, kk, y0, rows);
+      hb_wait_inputs<POOL>(g, K, d, dp, pg, kk, K == 1 ? done0 : done, lane);
     }
-    hb_unit<CWC, MULTI, K, CWCN, NEXT>(Wt, Kc, res, out, g, smem, d, done, pg, p0, min(ph.ppu, ph.npass - p0), n0, kk, y0,
-                                       rows, lane);
+    hb_unit<CWC, MULTI, K, CWCN, MODE>(Wt, Kc, Kp, res, out, g, smem, d, done, pg, p0, min(ph.ppu, ph.npass - p0), n0, kk,
+                                       y0, rows, lane);
   }
 }
 
-template <int CWC1, bool M1, int CWC2, bool M2, int CWC3, bool M3, bool NEXT>
+template <int CWC1, bool M1, int CWC2, bool M2, int CWC3, bool M3, int MODE>
 __global__ __launch_bounds__(1024, HB_MINW) void hblock_kernel(const uint64_t* __restrict__ inP, const uint32_t* __restrict__ Wt,
                                                       const float* __restrict__ Kc, const float* __restrict__ res,
                                                       float* __restrict__ out, uint64_t* __restrict__ outP,
-                                                      const HbGeo g) {
+                                                      const HbGeo g, const float* __restrict__ Kp,
+                                                      uint64_t* __restrict__ outP2, uint64_t* __restrict__ outM2) {
+  constexpr bool NEXT = MODE == HB_NEXT;
   unsigned char* smem = hb_smem;
   const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
   [[maybe_unused]] const unsigned long long t_entry = HB_NOW();
@@ -380,11 +479,11 @@ __global__ __launch_bounds__(1024, HB_MINW) void hblock_kernel(const uint64_t* _
   // counters (hb_wait_inputs).  A unit only waits for units of the previous convolution, all of which are in the hands
   // of running waves by then.
   [[maybe_unused]] const unsigned long long t_p0 = HB_NOW();
-  hb_phase<CWC1, M1, 0, CWC2, NEXT>(Wt, Kc, res, out, g, smem, n0, kk, y0, rows, lane);
+  hb_phase<CWC1, M1, 0, CWC2, MODE>(Wt, Kc, Kp, res, out, g, smem, n0, kk, y0, rows, lane);
   [[maybe_unused]] const unsigned long long t_c1 = HB_NOW();
-  hb_phase<CWC2, M2, 1, CWC3, NEXT>(Wt, Kc, res, out, g, smem, n0, kk, y0, rows, lane);
+  hb_phase<CWC2, M2, 1, CWC3, MODE>(Wt, Kc, Kp, res, out, g, smem, n0, kk, y0, rows, lane);
   [[maybe_unused]] const unsigned long long t_c2 = HB_NOW();
-  hb_phase<CWC3, M3, 2, 1, NEXT>(Wt, Kc, res, out, g, smem, n0, kk, y0, rows, lane);
+  hb_phase<CWC3, M3, 2, 1, MODE>(Wt, Kc, Kp, res, out, g, smem, n0, kk, y0, rows, lane);
   [[maybe_unused]] const unsigned long long t_c3 = HB_NOW();
   if constexpr (NEXT) {
     __syncthreads();
@@ -396,6 +495,20 @@ __global__ __launch_bounds__(1024, HB_MINW) void hblock_kernel(const uint64_t* _
       const int img = r1 / per_img, r2 = r1 - img * per_img;
       const uint2 v = po[(unsigned)(gq * g.ncell_out + img * (g.BR * g.W) + r2)];
       outP[((size_t)(n0 + img) * ngo + gq) * hw + (size_t)y0 * g.W + r2] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    }
+  }
+  if constexpr (MODE == HB_POOL) {   // the three pooled plane sets of the band's windows
+    __syncthreads();
+    const int ngo = g.C >> 6, wpr = g.W >> 1;
+    const int per_img = (rows >> 1) * wpr, per_grp = kk * per_img, per_set = ngo * per_grp, total = 3 * per_set;
+    const uint2* po = reinterpret_cast<const uint2*>(smem + g.lds_out);
+    for (int i = tid; i < total; i += nthr) {
+      const int st = i / per_set, r0 = i - st * per_set;
+      const int gq = r0 / per_grp, r1 = r0 - gq * per_grp;
+      const int img = r1 / per_img, r2 = r1 - img * per_img;
+      const uint2 v = po[(unsigned)((st * ngo + gq) * g.ncell_pool + img * ((g.BR >> 1) * wpr) + r2)];
+      uint64_t* dst = st == 0 ? outP : (st == 1 ? outP2 : outM2);
+      dst[((size_t)(n0 + img) * ngo + gq) * (hw >> 2) + (size_t)(y0 >> 1) * wpr + r2] = (uint64_t)v.x | ((uint64_t)v.y << 32);
     }
   }
 #ifdef HB_TIMING
@@ -483,11 +596,12 @@ int launch_hblock_pack_weights(int C_in, int planes, const uint32_t* const w[3],
 namespace {
 
 // LDS bytes of a region of G images x BR band rows, and the offsets of its pieces.
-long long hb_lds(const HbShape& s, int W, int planes, int G, int BR, bool next, HbGeo* g) {
+long long hb_lds(const HbShape& s, int W, int planes, int G, int BR, int mode, HbGeo* g) {
   long long off = 16;  // tickets
-  {  // completion counters of conv1 / conv2 (64-pixel groups of their domains, at most band + halo rows)
+  {  // completion counters of conv1 / conv2 (64-pixel groups of their domains, at most band + halo rows; HB_POOL: + 2 rows
+     // of a domain widened to whole windows)
     long long n = 0;
-    for (int k = 0; k < 2; ++k) n += ((long long)G * (BR + 2 * (2 - k)) * W + 63) / 64;
+    for (int k = 0; k < 2; ++k) n += ((long long)G * (BR + 2 * (2 - k) + (mode == HB_POOL ? 2 : 0)) * W + 63) / 64;
     if (g) g->lds_done = (unsigned)off;
     off += (n * 4 + 15) / 16 * 16;
   }
@@ -506,18 +620,24 @@ long long hb_lds(const HbShape& s, int W, int planes, int G, int BR, bool next, 
     g->lds_out = (unsigned)off;
     g->ncell_out = (int)ncell_out;
   }
-  if (next) off += ((long long)(planes / 64) * ncell_out * 8 + 15) / 16 * 16;
+  if (mode == HB_NEXT) off += ((long long)(planes / 64) * ncell_out * 8 + 15) / 16 * 16;
+  if (mode == HB_POOL) {
+    const long long ncell_pool = (long long)G * (BR / 2) * (W / 2);
+    if (g) g->ncell_pool = (int)ncell_pool;
+    off += (3LL * (planes / 64) * ncell_pool * 8 + 15) / 16 * 16;
+  }
   return off;
 }
 
 template <class K>
 int hb_launch(K kernel, const HbGeo& g, int nblocks, int waves, const uint64_t* inP, const uint32_t* W, const float* Kc,
-              const float* res, float* out, uint64_t* outP, hipStream_t s) {
+              const float* res, float* out, uint64_t* outP, hipStream_t s, const float* Kp = nullptr,
+              uint64_t* outP2 = nullptr, uint64_t* outM2 = nullptr) {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           kMaxDynamicLds) != hipSuccess)
     return BNN_HIP_ERR_LAUNCH;
   hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3((unsigned)waves * kWave), (size_t)g.lds16 * 16, s, inP, W, Kc,
-                     res, out, outP, g);
+                     res, out, outP, g, Kp, outP2, outM2);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
@@ -526,9 +646,11 @@ int hb_launch(K kernel, const HbGeo& g, int nblocks, int waves, const uint64_t* 
 // The region plan: rows per band / images per region / waves.  Whole images when there are enough of them to fill the
 // chip (or other work shares it: BNN_HIP_FLAG_THROUGHPUT); else bands of rows — each band recomputes 2 halo rows of
 // conv1 and 1 of conv2 on each side, so the split is taken only where the idle compute units cost more.
-int hblock_plan(const bnn_hip_hblock_desc* d, int* G_out, int* BR_out, int* waves_out) {
+int hblock_plan(const bnn_hip_hblock_desc* d, int* G_out, int* BR_out, int* waves_out, int mode = HB_NEXT) {
   HbShape s;
   if (!hb_shape(d->C_in, d->planes, s)) return BNN_HIP_ERR_UNSUPPORTED;
+  const bool pool = mode == HB_POOL;   // bands of whole windows: an even number of rows
+  if (pool && (d->H % 2 || d->W % 2)) return BNN_HIP_ERR_UNSUPPORTED;
   const int ncu = current_device_cus();
   static const bool split_when_shared = [] { const char* e = std::getenv("BNN_HBLOCK_SHARED_SPLIT"); return e && e[0] == '1'; }();
   const bool shared = (d->flags & BNN_HIP_FLAG_THROUGHPUT) != 0 && !split_when_shared;
@@ -537,16 +659,19 @@ int hblock_plan(const bnn_hip_hblock_desc* d, int* G_out, int* BR_out, int* wave
     G = d->images_per_band > 0 ? std::min(d->images_per_band, d->N) : 1;
     BR = d->rows_per_band > 0 ? std::min(d->rows_per_band, d->H) : d->H;
     if (G > 1 && BR != d->H) return BNN_HIP_ERR_INVALID_ARG;
+    if (pool && BR % 2) return BNN_HIP_ERR_INVALID_ARG;
   } else {
     const double w1 = (double)s.cin[0] * s.O[0], w2 = (double)s.cin[1] * s.O[1], w3 = (double)s.cin[2] * s.O[2];
     const int slots = shared ? std::max(1, ncu / 2) : ncu;
     double best = 0;
     int best_nbi = 0;
     for (int nbi = 1; nbi <= 4 && nbi <= d->H; ++nbi) {
-      const int br = (d->H + nbi - 1) / nbi;
+      int br = (d->H + nbi - 1) / nbi;
       if (nbi > 1 && br < 4) break;
-      if (hb_lds(s, d->W, d->planes, 1, br, true, nullptr) > kHbLdsBudget) continue;
-      const long long rounds = ((long long)d->N * nbi + slots - 1) / slots;
+      if (pool) br += br & 1;
+      const int nb = (d->H + br - 1) / br;   // (what nbi bands of br rows really are: 14 rows as 8 + 6)
+      if (hb_lds(s, d->W, d->planes, 1, br, mode, nullptr) > kHbLdsBudget) continue;
+      const long long rounds = ((long long)d->N * nb + slots - 1) / slots;
       // work in whole 64-pixel groups: what the lanes of a wave execute, used or not
       auto groups = [&](int r) { return (double)(((long long)std::min(d->H, r) * d->W + 63) / 64); };
       const double work = w1 * groups(br + 4) + w2 * groups(br + 2) + w3 * groups(br);
@@ -555,13 +680,14 @@ int hblock_plan(const bnn_hip_hblock_desc* d, int* G_out, int* BR_out, int* wave
     }
     if (best_nbi == 0) return BNN_HIP_ERR_UNSUPPORTED;
     BR = (d->H + best_nbi - 1) / best_nbi;
+    if (pool) BR += BR & 1;
     if (best_nbi == 1) {  // small images, many of them: several per region (fewer idle lanes in the last pixel group)
       while (G * 2 <= d->N && (long long)d->H * d->W * G * 2 <= 64 * 64 && d->N / (G * 2) >= 2 * ncu &&
-             hb_lds(s, d->W, d->planes, G * 2, BR, true, nullptr) <= kHbLdsBudget / 2)
+             hb_lds(s, d->W, d->planes, G * 2, BR, mode, nullptr) <= kHbLdsBudget / 2)
         G *= 2;
     }
   }
-  if (hb_lds(s, d->W, d->planes, G, BR, true, nullptr) > kHbLdsBudget) return BNN_HIP_ERR_UNSUPPORTED;
+  if (hb_lds(s, d->W, d->planes, G, BR, mode, nullptr) > kHbLdsBudget) return BNN_HIP_ERR_UNSUPPORTED;
   int waves = d->waves > 0 ? d->waves : 16;
   if (waves > 16) return BNN_HIP_ERR_INVALID_ARG;
   *G_out = G;
@@ -570,13 +696,30 @@ int hblock_plan(const bnn_hip_hblock_desc* d, int* G_out, int* BR_out, int* wave
   return BNN_HIP_OK;
 }
 
-int launch_hblock(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc,
-                  const float* res, float* out, uint64_t* outP, hipStream_t stream) {
+namespace {
+template <int C1, bool M1, int C2, bool M2, int C3, bool M3, bool POOLED>
+int hb_dispatch(int mode, const HbGeo& g, int nblocks, int waves, const uint64_t* inP, const uint32_t* W, const float* Kc,
+                const float* Kp, const float* res, float* out, uint64_t* outP, uint64_t* outP2, uint64_t* outM2,
+                hipStream_t stream) {
+  if constexpr (POOLED) {
+    if (mode == HB_POOL)
+      return hb_launch(hblock_kernel<C1, M1, C2, M2, C3, M3, HB_POOL>, g, nblocks, waves, inP, W, Kc, res, out, outP, stream,
+                       Kp, outP2, outM2);
+  }
+  if (mode == HB_NEXT)
+    return hb_launch(hblock_kernel<C1, M1, C2, M2, C3, M3, HB_NEXT>, g, nblocks, waves, inP, W, Kc, res, out, outP, stream);
+  if (mode == HB_NONE)
+    return hb_launch(hblock_kernel<C1, M1, C2, M2, C3, M3, HB_NONE>, g, nblocks, waves, inP, W, Kc, res, out, outP, stream);
+  return BNN_HIP_ERR_UNSUPPORTED;
+}
+
+int hb_run(const bnn_hip_hblock_desc* d, int mode, const uint64_t* inP, const uint32_t* W, const float* Kc, const float* Kp,
+           const float* res, float* out, uint64_t* outP, uint64_t* outP2, uint64_t* outM2, hipStream_t stream) {
   HbShape s;
   bnn_hip_hblock_layout L;
   if (!hb_shape(d->C_in, d->planes, s) || hblock_layout(d->C_in, d->planes, &L) != BNN_HIP_OK) return BNN_HIP_ERR_UNSUPPORTED;
   int G, BR, waves;
-  const int st = hblock_plan(d, &G, &BR, &waves);
+  const int st = hblock_plan(d, &G, &BR, &waves, mode);
   if (st != BNN_HIP_OK) return st;
   HbGeo g;
   std::memset(&g, 0, sizeof(g));
@@ -585,8 +728,7 @@ int launch_hblock(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint3
   g.WP = d->W + 2;
   g.ng_in = (d->C_in + 63) / 64;
   g.cw_in = s.cw[0];
-  const bool next = outP != nullptr;
-  g.lds16 = (unsigned)((hb_lds(s, d->W, d->planes, G, BR, next, &g) + 15) / 16);
+  g.lds16 = (unsigned)((hb_lds(s, d->W, d->planes, G, BR, mode, &g) + 15) / 16);
   int c_off = 0;
   for (int k = 0; k < 3; ++k) {
     HbPhase& p = g.ph[k];
@@ -611,28 +753,53 @@ int launch_hblock(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint3
   }
   g.na_off = (unsigned)L.next_a_off;
   g.nb_off = (unsigned)L.next_b_off;
-  div_magic((uint32_t)(d->H * d->W), g.m_hw, g.s_hw);
-  div_magic((uint32_t)d->W, g.m_w, g.s_w);
+  if (mode == HB_POOL) {   // (hb_pixel: windows of an image / of a row)
+    div_magic((uint32_t)(d->H * d->W / 4), g.m_hw, g.s_hw);
+    div_magic((uint32_t)(d->W / 2), g.m_w, g.s_w);
+  } else {
+    div_magic((uint32_t)(d->H * d->W), g.m_hw, g.s_hw);
+    div_magic((uint32_t)d->W, g.m_w, g.s_w);
+  }
   g.f32_bytes = (unsigned)((long long)d->N * d->planes * d->H * d->W * 4);
   const int nblocks = ((d->N + G - 1) / G) * g.nbi;
 
-#define HB_PICK(C1, M1_, C2, M2_, C3, M3_)                                                                              \
+#define HB_PICK(C1, M1_, C2, M2_, C3, M3_, POOLED)                                                                       \
   if (s.cwc[0] == C1 && (s.nchunk[0] > 1) == M1_ && s.cwc[1] == C2 && (s.nchunk[1] > 1) == M2_ && s.cwc[2] == C3 &&    \
-      (s.nchunk[2] > 1) == M3_) {                                                                                       \
-    if (next)                                                                                                           \
-      return hb_launch(hblock_kernel<C1, M1_, C2, M2_, C3, M3_, true>, g, nblocks, waves, inP, W, Kc, res, out, outP,   \
-                       stream);                                                                                         \
-    return hb_launch(hblock_kernel<C1, M1_, C2, M2_, C3, M3_, false>, g, nblocks, waves, inP, W, Kc, res, out, outP,    \
-                     stream);                                                                                           \
-  }
-  HB_PICK(2, false, 1, false, 1, false)   // 64 -> 64:   64 -> 32 -> 16 -> 16
-  HB_PICK(2, false, 2, false, 1, false)   // 64 -> 128:  64 -> 64 -> 32 -> 32
-  HB_PICK(4, false, 2, false, 1, false)   // 128 -> 128
-  HB_PICK(4, false, 4, false, 2, false)   // 128 -> 256
-  HB_PICK(4, true, 4, false, 2, false)    // 256 -> 256
-  HB_PICK(4, true, 4, true, 4, false)     // 256 -> 512 and 512 -> 512
+      (s.nchunk[2] > 1) == M3_)                                                                                         \
+    return hb_dispatch<C1, M1_, C2, M2_, C3, M3_, POOLED>(mode, g, nblocks, waves, inP, W, Kc, Kp, res, out, outP,      \
+                                                          outP2, outM2, stream);
+  // (the pooled form: the widths that END a stage of the [64, 128, 256, 512] networks)
+  HB_PICK(2, false, 1, false, 1, false, true)    // 64 -> 64:   64 -> 32 -> 16 -> 16
+  HB_PICK(2, false, 2, false, 1, false, false)   // 64 -> 128:  64 -> 64 -> 32 -> 32
+  HB_PICK(4, false, 2, false, 1, false, true)    // 128 -> 128
+  HB_PICK(4, false, 4, false, 2, false, false)   // 128 -> 256
+  HB_PICK(4, true, 4, false, 2, false, true)     // 256 -> 256
+  HB_PICK(4, true, 4, true, 4, false, false)     // 256 -> 512 and 512 -> 512
 #undef HB_PICK
   return BNN_HIP_ERR_UNSUPPORTED;
+}
+}  // namespace
+
+int launch_hblock(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc,
+                  const float* res, float* out, uint64_t* outP, hipStream_t stream) {
+  return hb_run(d, outP != nullptr ? HB_NEXT : HB_NONE, inP, W, Kc, nullptr, res, out, outP, nullptr, nullptr, stream);
+}
+
+// The block + AvgPool2d(2, 2) + the two binarisations of the next stage's first block (MODE 2 at the top of the file).
+int launch_hblock_pool(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc,
+                       const float* Kp, const float* res, uint64_t* outP1, uint64_t* outP2, uint64_t* outM2,
+                       hipStream_t stream) {
+  return hb_run(d, HB_POOL, inP, W, Kc, Kp, res, nullptr, outP1, outP2, outM2, stream);
+}
+
+bool hblock_pool_supported(const bnn_hip_hblock_desc* d) {
+  HbShape s;
+  if (!hb_shape(d->C_in, d->planes, s) || d->C_in != d->planes) return false;
+  int G, BR, waves;
+  if (hblock_plan(d, &G, &BR, &waves, HB_POOL) != BNN_HIP_OK) return false;
+  const bool m0 = s.nchunk[0] > 1;
+  return (s.cwc[0] == 2 && !m0 && s.cwc[1] == 1 && s.cwc[2] == 1) || (s.cwc[0] == 4 && !m0 && s.cwc[1] == 2 && s.cwc[2] == 1) ||
+         (s.cwc[0] == 4 && m0 && s.cwc[1] == 4 && s.nchunk[1] == 1 && s.cwc[2] == 2);
 }
 
 bool hblock_supported(const bnn_hip_hblock_desc* d) {

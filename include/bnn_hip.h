@@ -534,6 +534,23 @@ int bnn_hip_hblock_pack_weights_cl(int C_in, int planes, const uint32_t* wbits1,
 int bnn_hip_hblock_forward(const bnn_hip_hblock_desc* d, const uint64_t* in_P, const uint32_t* weights,
                            const float* consts, const float* residual, float* out, uint64_t* out_P, void* stream);
 
+/* The last block of a stage in front of `AvgPool2d(2, 2)` and a block with a shortcut convolution (ABI 15;
+ * bnn/models/resnet.py: the stages of the hierarchical-block network, hierarchical_block.py:30-39): the block's output is
+ * only ever pooled and binarised — by the next block's bn1 -> ReLU and by its shortcut's BatchNorm — so this launch writes
+ * those planes at half resolution and NO fp32 tensor:
+ *     t      = AvgPool2d(2, 2)(y)                     (((y00 + y01) + y10) + y11) / 4, as ATen sums a window
+ *     out_P1 = fmaf(t, a1[c], b1[c]) > 0              (the minus plane of a ReLU'd tensor is zero: not written)
+ *     out_P2 = fmaf(t, a2[c], b2[c]) > 0,  out_M2 = ... < 0
+ * pool_consts = [a1/4 | b1 | a2/4 | b2 | -a2/4 | -b2 | 0 | 0], `planes` floats each, 32-byte aligned (the four lanes of a
+ * window each test one plane's bit as fmaf(window sum, a, b) > 0: the caller checks that a/4 is exact, i.e. that a is not
+ * within two binades of the smallest normal).  C_in == planes, even H and W, the widths of
+ * bnn_hip_hblock_pool_supported; the planes are [N, planes / 64, H / 2, W / 2].  Same bits as bnn_hip_hblock_forward +
+ * bnn_hip_avgpool2_bn_pack2_f32.  */
+int bnn_hip_hblock_pool_supported(const bnn_hip_hblock_desc* d);
+int bnn_hip_hblock_pool_forward(const bnn_hip_hblock_desc* d, const uint64_t* in_P, const uint32_t* weights,
+                                const float* consts, const float* pool_consts, const float* residual, uint64_t* out_P1,
+                                uint64_t* out_P2, uint64_t* out_M2, void* stream);
+
 /* fp32 NCHW in -> fp32 NCHW out.  ONE launch (bnn_hip_bconv2d_direct) wherever that path applies:
  * bnn_hip_conv_workspace_bytes(d) is then 0 and `workspace` may be NULL.  For the remaining geometries (see above)
  * it is pack_act + conv through `workspace` (bnn_hip_conv_workspace_bytes(d) bytes, 16-byte aligned).          */

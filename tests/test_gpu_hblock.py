@@ -150,3 +150,61 @@ def test_pool_and_both_packs_in_one_pass(shape):
     assert torch.equal(p2.P, w2.P) and torch.equal(p2.M, w2.M) and not p2.nonneg
     q1, q2, tq = hipops.avgpool2_bn_pack2(x, bn1, True)
     assert q2 is None and tq is None and torch.equal(q1.P, w1.P)
+
+
+POOL_SHAPES = [  # planes, N, H, W
+    (64, 3, 56, 56), (128, 3, 28, 28), (256, 5, 14, 14), (64, 2, 12, 10), (128, 2, 6, 6), (256, 3, 2, 2), (64, 5, 8, 24),
+    (128, 130, 28, 28),
+]
+POOL_PLANS = [dict(), dict(rows_per_band=4), dict(rows_per_band=6), dict(rows_per_band=2), dict(images_per_band=2),
+              dict(images_per_band=4), dict(throughput=True), dict(waves=4), dict(waves=3, rows_per_band=8)]
+
+
+@pytest.mark.parametrize("shape", POOL_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_last_block_of_a_stage_with_the_pool_and_both_binarisations(shape):
+    """bnn_hip_hblock_pool_forward: block + AvgPool2d(2, 2) + sign(relu(bn1(.))) + sign(bn_ds(.)) in one launch, no fp32
+    output — the planes of bnn_hip_hblock_forward's y through bnn_hip_avgpool2_bn_pack2_f32, bit for bit, on every plan
+    (whole images, several per workgroup, bands of whole windows with their halos)."""
+    planes, N, H, W = shape
+    x, res, ws, bn1, bn2, bn3, nbn = _block(hash(shape) % 1000, planes, planes, N, H, W)
+    g = torch.Generator().manual_seed(7)
+    ds = ((torch.rand(planes, generator=g) + 0.5).to(DEV) * torch.where(torch.arange(planes) % 5 == 0, -1.0, 1.0).to(DEV),
+          (torch.randn(planes, generator=g) * 0.3).to(DEV))
+    p_in = hipops.bn_act_pack(x, bn1[0], bn1[1], relu=True)
+    pws = [hipops.pack_weight(w) for w in ws]
+    pack = hipops.hblock_pack(*pws, bn2, bn3, None)
+    y, _ = hipops.hblock_forward(p_in, pack, res, out_packed=False)
+    w1, w2, _ = hipops.avgpool2_bn_pack2(y, nbn, True, ds, False, out_f32=False)
+    assert bool(w2.M.any()) and bool(w2.P.any())
+    kp = hipops.hblock_pool_consts(nbn, ds, planes)
+    ran = 0
+    for plan in POOL_PLANS:
+        if plan.get("rows_per_band", 0) > H or plan.get("images_per_band", 0) > N:
+            continue
+        if not hipops.hblock_pool_supported(N, planes, H, W, planes, **plan):
+            assert plan.get("images_per_band", 0) > 1 and H * W > 1000
+            continue
+        p1, p2 = hipops.hblock_pool_forward(p_in, pack, res, kp, **plan)
+        assert torch.equal(p1.P, w1.P), plan
+        assert torch.equal(p2.P, w2.P) and torch.equal(p2.M, w2.M), plan
+        assert p1.nonneg and not bool(p1.M.any()) and not p2.nonneg
+        ran += 1
+    assert ran >= 4
+
+
+def test_pool_form_argument_checks():
+    from bnn_amd import native
+    assert not hipops.hblock_pool_supported(2, 64, 13, 9, 64)              # odd image
+    assert not hipops.hblock_pool_supported(2, 64, 28, 28, 128)            # the first block of a stage: other widths
+    assert not hipops.hblock_pool_supported(2, 512, 14, 14, 512)           # no instance
+    assert not hipops.hblock_pool_supported(2, 64, 28, 28, 64, rows_per_band=5)   # bands of whole windows
+    x, res, ws, bn1, bn2, bn3, nbn = _block(3, 64, 64, 2, 8, 8)
+    p_in = hipops.bn_act_pack(x, bn1[0], bn1[1], relu=True)
+    pack = hipops.hblock_pack(*[hipops.pack_weight(w) for w in ws], bn2, bn3, None)
+    kp = hipops.hblock_pool_consts(nbn, nbn, 64)
+    with pytest.raises(native.NativeError):
+        hipops.hblock_pool_forward(p_in, pack, res, kp[:-1])
+    with pytest.raises(native.NativeError):
+        hipops.hblock_pool_forward(p_in, pack, res[:, :, :7], kp)
+    with pytest.raises(native.NativeError):
+        hipops.hblock_pool_forward(p_in, pack, res, kp, rows_per_band=3)
