@@ -80,9 +80,11 @@ def parse_args():
     ap.add_argument("--sustain", type=float, default=3.0,
                     help="seconds of the same step run (and timed) after the K timed steps: the `sustained` record, "
                          "with the engine clock sampled right behind it (0 = skip)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=0,
                     help="graph engine: batches in flight per GPU (graph-captured executors on their own HIP "
-                         "streams, replayed round-robin; 1 = strictly one batch at a time)")
+                         "streams, replayed round-robin; 1 = strictly one batch at a time).  Default: 2 for ResNet-18, 4 "
+                         "for c5 — its 26 launches of 10-80 us leave more of the chip idle between them (measured round 6, "
+                         "sustained k images/s: 2: 213, 3: 231, 4: 233, 5: 204; ResNet-18: 2: 274, 3: 271)")
     ap.add_argument("--spinup", type=int, default=-1,
                     help="untimed steps in front of the warm-up steps that bring the GPU clocks up from idle "
                          "(default: about 1 s of work: 1000 for the nets — 150 ... 400 for the layerwise / blockwise "
@@ -794,6 +796,8 @@ ENGINE_NOTES = {
 
 def bench_net(args, world, rank, device, info, timed):
     c5 = args.config == "c5"
+    if args.streams <= 0:
+        args.streams = 4 if c5 else 2
     B = args.batch or (128 if c5 else 256)
     net = build_model(device, (lambda: ResNet(HBlock, [3, 4, 6, 3])) if c5 else resnet18)
     fused_kw = {"stem_fp16": True} if c5 else {}
@@ -986,6 +990,9 @@ def bench_net(args, world, rank, device, info, timed):
         # (tools/c5_roofline.py recomputes the figure layer by layer)
         rec["c5_int_alu_frac"] = value / world * C5_LANE_OPS_PER_IMG / int_alu_peak(info)
         rec["c5_lane_ops_per_image"] = C5_LANE_OPS_PER_IMG
+        if isinstance(rec.get("sustained"), dict) and "value" in rec["sustained"]:   # (K timed steps include the pipeline's
+            rec["sustained"]["c5_int_alu_frac"] = \
+                rec["sustained"]["value"] / world * C5_LANE_OPS_PER_IMG / int_alu_peak(info)   # fill and drain: ~one forward)
         if "one_batch_at_a_time" in rec:
             rec["one_batch_at_a_time"]["c5_int_alu_frac"] = \
                 rec["one_batch_at_a_time"]["value"] / world * C5_LANE_OPS_PER_IMG / int_alu_peak(info)

@@ -741,8 +741,9 @@ int hb_run(const bnn_hip_hblock_desc* d, int mode, const uint64_t* inP, const ui
     // passes per unit: as many as keep every wave of the workgroup busy at least twice per phase
     const int rows_dom = std::min(d->H, BR + 2 * p.halo);
     const int npg = (G * rows_dom * d->W + 63) / 64;
+    static const int upw = [] { const char* e = std::getenv("BNN_HBLOCK_UNITS_PER_WAVE"); return e ? std::atoi(e) : 2; }();
     int ppu = 32 / s.nacc[k];
-    while (ppu > 1 && (ppu > p.npass || npg * ((p.npass + ppu - 1) / ppu) < 2 * waves)) ppu >>= 1;
+    while (ppu > 1 && (ppu > p.npass || npg * ((p.npass + ppu - 1) / ppu) < upw * waves)) ppu >>= 1;
     p.ppu = ppu;
     p.upg = (p.npass + ppu - 1) / ppu;
     div_magic((uint32_t)p.upg, p.m_upg, p.s_upg);
