@@ -125,6 +125,17 @@ int hblock_layout(int C_in, int planes, bnn_hip_hblock_layout* L) {
   L->const_floats = 4LL * planes;
   return BNN_HIP_OK;
 }
+bool hblock_pool_supported(const bnn_hip_hblock_desc* d) {
+  return d->C_in == d->planes && (d->planes == 64 || d->planes == 128 || d->planes == 256) && d->H % 2 == 0 && d->W % 2 == 0 &&
+         d->rows_per_band % 2 == 0 && (long long)d->H * d->W <= 4096;
+}
+int launch_hblock_pool(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc, const float* Kp,
+                       const float* res, uint64_t* o1, uint64_t* o2, uint64_t* o3, hipStream_t) {
+  ++g_reached;
+  REQUIRE(d && inP && W && Kc && Kp && res && o1 && o2 && o3 && al(Kp, 32) && al(o1, 8) && al(o2, 8) && al(o3, 8));
+  REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->H % 2 == 0 && d->W % 2 == 0 && d->C_in == d->planes);
+  return BNN_HIP_OK;
+}
 int launch_hblock_pack_weights(int C_in, int planes, const uint32_t* const w[3], uint32_t* dst, hipStream_t) {
   ++g_reached; REQUIRE(C_in > 0 && planes > 0 && w[0] && w[1] && w[2] && dst && al(dst, 64));
   return stub_hb_shape(C_in, planes) ? BNN_HIP_OK : BNN_HIP_ERR_UNSUPPORTED;
@@ -355,7 +366,7 @@ int main(int argc, char** argv) {
   for (long it = 0; it < iters; ++it) {
     ++g_calls;
     int st = 0;
-    switch (rnd() % 41) {
+    switch (rnd() % 42) {
       case 0: { bnn_hip_conv_desc d = pick_desc();
         st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
                              pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
@@ -489,6 +500,15 @@ int main(int argc, char** argv) {
                                                                 pick_ptr<float>(), pick_ptr<float>(), pick_int(), pick_int(), pick_int(),
                                                                 pick_int() & 3, pick_ptr<float>(), pick_ptr<uint64_t>(),
                                                                 pick_ptr<uint64_t>(), stream); break;
+      case 40: { bnn_hip_hblock_desc d; int* f = reinterpret_cast<int*>(&d);
+        for (size_t i = 0; i < sizeof(d) / sizeof(int); ++i) f[i] = pick_int();
+        if (rnd() % 2) { d.planes = d.C_in = 64 << (rnd() % 3); d.flags = (int)(rnd() % 2) * 64; d.H = d.W = 2 * (1 + (int)(rnd() % 28));
+                         d.rows_per_band = d.images_per_band = d.waves = 0; }
+        (void)bnn_hip_hblock_pool_supported(rnd() % 16 ? &d : nullptr);
+        st = bnn_hip_hblock_pool_forward(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint32_t>(), pick_ptr<float>(),
+                                         pick_ptr<float>(), pick_ptr<float>(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(),
+                                         pick_ptr<uint64_t>(), stream);
+        break; }
       case 37: st = bnn_hip_hblock_pack_weights(pick_int(), pick_int(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(),
                                                 pick_ptr<uint32_t>(), stream); break;
       case 33: st = bnn_hip_xnor_grad_pack_weight_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(),
