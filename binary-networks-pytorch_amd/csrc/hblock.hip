@@ -68,6 +68,8 @@ struct HbGeo {
   int s_hw, s_w;
   unsigned f32_bytes;  // bytes of the fp32 tensors (residual, out): the range of their descriptors
   int ncell_pool;      // MODE 2: cells of one pooled plane set of the region, G * (BR / 2) * (W / 2)
+  uint32_t m_wc;       // phase 0: division by W (m_w divides by W / 2 in MODE 2)
+  int s_wc;
 };
 
 namespace {
@@ -455,23 +457,27 @@ __global__ __launch_bounds__(1024, HB_MINW) void hblock_kernel(const uint64_t* _
   {  // phase 0: the block's input planes, band + 3 halo rows (rows of the image only)
     const HbPhase& p1 = g.ph[0];
     const int ra = max(0, y0 - 3), rb = min(g.H, y0 + rows + 3);
-    const int per_img = (rb - ra) * g.W, per_grp = kk * per_img, total = g.ng_in * per_grp;
+    const int per_img = (rb - ra) * g.W;
     uint32_t* pl = reinterpret_cast<uint32_t*>(smem + p1.lds_in);
-    for (int i = tid; i < total; i += nthr) {
-      const int gq = i / per_grp, r1 = i - gq * per_grp;
-      const int img = r1 / per_img, r2 = r1 - img * per_img;
-      const int rowl = r2 / g.W, col = r2 - rowl * g.W;
-      const int row = ra + rowl;
-      const uint64_t v = inP[((size_t)(n0 + img) * g.ng_in + gq) * hw + (size_t)row * g.W + col];
-      const unsigned cell = (unsigned)((img * p1.rows_in + (row - y0 + 3)) * g.WP + col + 1);
-      const int w0 = 2 * gq;
-      if constexpr (CWC1 == 1) {
-        pl[cell] = (uint32_t)v;
-      } else {
-        const unsigned widx = ((unsigned)((w0 / CWC1) * p1.ncell_in) + cell) * CWC1 + (unsigned)(w0 % CWC1);
-        *reinterpret_cast<uint2*>(pl + widx) = uint2{(uint32_t)v, (uint32_t)(v >> 32)};
+    // (image, 64-channel group) pairs in the outer loops, wave-uniform; one division per element, by W, as a multiply —
+    // the flat form's three divisions by run-time values were ~80 VALU instructions per element)
+    for (int img = 0; img < kk; ++img)
+      for (int gq = 0; gq < g.ng_in; ++gq) {
+        const uint64_t* src = inP + ((size_t)(n0 + img) * g.ng_in + gq) * hw + (size_t)ra * g.W;
+        const int w0 = 2 * gq;
+        const unsigned cbase = (unsigned)((img * p1.rows_in + (ra - y0 + 3)) * g.WP + 1);
+        for (int r2 = tid; r2 < per_img; r2 += nthr) {
+          const int rowl = (int)fast_div((uint32_t)r2, g.m_wc, g.s_wc), col = r2 - rowl * g.W;
+          const uint64_t v = src[r2];
+          const unsigned cell = cbase + (unsigned)(rowl * g.WP + col);
+          if constexpr (CWC1 == 1) {
+            pl[cell] = (uint32_t)v;
+          } else {
+            const unsigned widx = ((unsigned)((w0 / CWC1) * p1.ncell_in) + cell) * CWC1 + (unsigned)(w0 % CWC1);
+            *reinterpret_cast<uint2*>(pl + widx) = uint2{(uint32_t)v, (uint32_t)(v >> 32)};
+          }
+        }
       }
-    }
   }
   __syncthreads();
   // The three convolutions, each with its own ticket counter, NOT separated by barriers: a wave that finds conv1's
@@ -488,28 +494,34 @@ __global__ __launch_bounds__(1024, HB_MINW) void hblock_kernel(const uint64_t* _
   if constexpr (NEXT) {
     __syncthreads();
     const int ngo = g.C >> 6;
-    const int per_img = rows * g.W, per_grp = kk * per_img, total = ngo * per_grp;
+    const int per_img = rows * g.W;
     const uint2* po = reinterpret_cast<const uint2*>(smem + g.lds_out);
-    for (int i = tid; i < total; i += nthr) {
-      const int gq = i / per_grp, r1 = i - gq * per_grp;
-      const int img = r1 / per_img, r2 = r1 - img * per_img;
-      const uint2 v = po[(unsigned)(gq * g.ncell_out + img * (g.BR * g.W) + r2)];
-      outP[((size_t)(n0 + img) * ngo + gq) * hw + (size_t)y0 * g.W + r2] = (uint64_t)v.x | ((uint64_t)v.y << 32);
-    }
+    for (int img = 0; img < kk; ++img)
+      for (int gq = 0; gq < ngo; ++gq) {
+        const uint2* src = po + (unsigned)(gq * g.ncell_out + img * (g.BR * g.W));
+        uint64_t* dst = outP + ((size_t)(n0 + img) * ngo + gq) * hw + (size_t)y0 * g.W;
+        for (int r2 = tid; r2 < per_img; r2 += nthr) {
+          const uint2 v = src[r2];
+          dst[r2] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        }
+      }
   }
   if constexpr (MODE == HB_POOL) {   // the three pooled plane sets of the band's windows
     __syncthreads();
     const int ngo = g.C >> 6, wpr = g.W >> 1;
-    const int per_img = (rows >> 1) * wpr, per_grp = kk * per_img, per_set = ngo * per_grp, total = 3 * per_set;
+    const int per_img = (rows >> 1) * wpr;
     const uint2* po = reinterpret_cast<const uint2*>(smem + g.lds_out);
-    for (int i = tid; i < total; i += nthr) {
-      const int st = i / per_set, r0 = i - st * per_set;
-      const int gq = r0 / per_grp, r1 = r0 - gq * per_grp;
-      const int img = r1 / per_img, r2 = r1 - img * per_img;
-      const uint2 v = po[(unsigned)((st * ngo + gq) * g.ncell_pool + img * ((g.BR >> 1) * wpr) + r2)];
-      uint64_t* dst = st == 0 ? outP : (st == 1 ? outP2 : outM2);
-      dst[((size_t)(n0 + img) * ngo + gq) * (hw >> 2) + (size_t)(y0 >> 1) * wpr + r2] = (uint64_t)v.x | ((uint64_t)v.y << 32);
-    }
+    for (int st = 0; st < 3; ++st)
+      for (int img = 0; img < kk; ++img)
+        for (int gq = 0; gq < ngo; ++gq) {
+          const uint2* src = po + (unsigned)((st * ngo + gq) * g.ncell_pool + img * ((g.BR >> 1) * wpr));
+          uint64_t* dst = (st == 0 ? outP : (st == 1 ? outP2 : outM2)) + ((size_t)(n0 + img) * ngo + gq) * (hw >> 2) +
+                          (size_t)(y0 >> 1) * wpr;
+          for (int r2 = tid; r2 < per_img; r2 += nthr) {
+            const uint2 v = src[r2];
+            dst[r2] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+          }
+        }
   }
 #ifdef HB_TIMING
   if (lane == 0 && blockIdx.x < 4096) {
@@ -754,6 +766,7 @@ int hb_run(const bnn_hip_hblock_desc* d, int mode, const uint64_t* inP, const ui
   }
   g.na_off = (unsigned)L.next_a_off;
   g.nb_off = (unsigned)L.next_b_off;
+  div_magic((uint32_t)d->W, g.m_wc, g.s_wc);
   if (mode == HB_POOL) {   // (hb_pixel: windows of an image / of a row)
     div_magic((uint32_t)(d->H * d->W / 4), g.m_hw, g.s_hw);
     div_magic((uint32_t)(d->W / 2), g.m_w, g.s_w);
