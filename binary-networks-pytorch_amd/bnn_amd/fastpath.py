@@ -170,7 +170,10 @@ def packed_weight(layer, plan: Plan, sync: bool = True, fresh: bool = False) -> 
     reads the zero-weight flag: the pack is made under the assumption "no weight is exactly 0" and the flag
     travels to pinned host memory asynchronously.  It is resolved by the NEXT call for this layer — a training
     call checks the previous step's flag (long since on the host), an inference call (``sync=True``) waits for
-    it — and a layer that ever showed a zero is packed synchronously (mask-aware kernel) from then on."""
+    it — and a layer that ever showed a zero is packed synchronously (mask-aware kernel) from then on.  The FIRST
+    pack of a layer is always synchronous: zeros that are there from the start (pruned or zero-initialised weights, a
+    loaded sparse checkpoint) take the zero-aware kernels from the first step on; what the optimistic path can still
+    meet is a weight that an update lands on exactly 0.0 — one forward treats it as -1, the next call warns."""
     if strict_weights():
         sync, fresh = True, True
     master = layer.__dict__.get("_bnn_master")
@@ -179,6 +182,7 @@ def packed_weight(layer, plan: Plan, sync: bool = True, fresh: bool = False) -> 
     w = layer.weight
     key = (w.data_ptr(), w._version, str(w.device), tuple(w.shape), plan.center, plan.compute_alpha)
     cached = layer.__dict__.get("_bnn_packed")
+    sync = sync or cached is None
     if cached is not None and cached[1].zero_probe is not None and (sync or fresh or cached[0] != key):
         # a pack made without reading its zero flag: resolve it before it is trusted / replaced
         pw = cached[1]

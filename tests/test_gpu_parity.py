@@ -544,16 +544,20 @@ def test_writes_through_dot_data_need_invalidate_and_training_never_trusts_the_c
         assert torch.equal(layer(xd), y0)
 
 
-def test_zero_weights_first_seen_by_a_grad_mode_forward_are_honoured_by_inference():
-    """A pack made by the training path skips reading the zero-weight flag; an inference forward that finds it in
-    the cache must resolve the flag first (sign(0) == 0, never -1)."""
+def test_zero_weights_first_seen_by_a_grad_mode_forward_are_honoured_at_once():
+    """Weights that are exactly 0 from the start (pruned, zero-initialised): the first pack of a layer reads its zero
+    flag even in grad mode, so the training forward and the inference forward behind it are both exact (sign(0) == 0,
+    never -1) and nothing has to be warned about afterwards."""
+    import warnings
     case = LAYER_CASES_BY_NAME["zero_weights"]
     layer, x = make_layer(case)
     xd = dev(x)
-    with pytest.warns(RuntimeWarning, match="exactly 0"):
-        layer(xd.clone().requires_grad_(True))        # grad mode: optimistic pack, cached
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        yt = layer(xd.clone().requires_grad_(True))   # grad mode, cold cache: synchronous, zero-aware pack
         with torch.no_grad():
-            y = layer(xd)                             # same key: must not reuse the unmasked pack
+            y = layer(xd)
+    assert layer.__dict__["_bnn_packed"][1].has_zero and torch.equal(yt.detach(), y)
     ref, _ = oracle.binary_conv2d_int(x, case.tensors()[1], None, None, case.stride, case.pad, case.dilation,
                                       case.center, case.compute_alpha)
     assert np.array_equal(y.cpu().numpy(), ref)

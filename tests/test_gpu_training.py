@@ -105,9 +105,14 @@ def test_training_pack_is_asynchronous_and_a_zero_weight_is_caught_one_step_late
     x = dev(gen.normal(4, (2, 64, 6, 6)))
     y = layer(x.clone().requires_grad_(True))
     pw = layer.__dict__["_bnn_packed"][1]
-    assert pw.zero_probe is not None and not pw.has_zero and not pw.zero_found_later()
+    assert pw.zero_probe is None and not pw.has_zero   # the first pack of a layer reads its zero flag (zeros from the start)
     with torch.no_grad():
-        layer.weight[3, 5] = 0.0                       # exact zeros appear (e.g. a pruning step)
+        layer.weight.mul_(1.0)                         # an optimizer step: new version
+    y = layer(x.clone().requires_grad_(True))
+    pw = layer.__dict__["_bnn_packed"][1]
+    assert pw.zero_probe is not None and not pw.has_zero and not pw.zero_found_later()     # from then on: optimistic
+    with torch.no_grad():
+        layer.weight[3, 5] = 0.0                       # an exact zero appears between two steps
     layer(x.clone().requires_grad_(True))              # packed optimistically: the zeros are only flagged
     assert layer.__dict__["_bnn_packed"][1].zero_found_later()
     with torch.no_grad():
