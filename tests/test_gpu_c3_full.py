@@ -218,8 +218,17 @@ def test_c5_hblock_3463_at_its_stated_size():
         assert rep["images_with_a_sign_flip"] <= C5_FLIPPED, rep
     # the tapped run above is launch by launch (the taps want the planes in front of every convolution); what runs without
     # a tap is one launch per hierarchical block (csrc/hblock.hip): the same logits bit for bit
-    assert torch.equal(FusedResNet(net)(xs), yy)
+    from bnn_amd import native
+    eng = FusedResNet(net)
+    assert torch.equal(eng(xs), yy)
+    n0 = native.launch_count()
+    eng(xs)
+    # stem (writes block 1's planes) + 16 blocks + 3 shortcut 1x1 + the 14x14 -> 7x7 pool + 2 head launches: the stage
+    # ends at 56x56 and 28x28 pool and binarise their own output (bnn_hip_hblock_pool_forward)
+    assert native.launch_count() - n0 == 23
     assert torch.equal(FusedResNet(net, fuse_hblock=False)(xs), yy)
+    # the plan of several batches in flight (whole images per workgroup, lanes = channels on 14x14 too): the same bits
+    assert torch.equal(FusedResNet(net, throughput_mode=True)(xs), yy)
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "c5_b32_parity.json"), "w") as fh:
