@@ -299,6 +299,20 @@ class FusedResNet(nn.Module):
             except native.NativeError:      # a width the one-launch kernel has no instance for
                 b["hpack"] = None
             b["hgeo"] = {}
+            # the shortcut convolution of a stage's first block inside the block's launch (bnn_hip_hblock_shortcut_forward):
+            # a plain binary 1x1 (no bias, no scale, no zero weights) behind its own BatchNorm, and a next block in the stage
+            b["hsc"] = None
+            if b["hpack"] is not None and b["ds"] is not None and nbn is not None:
+                sc = b["ds"][1]
+                lay = sc.layer
+                if (lay.bias is None and sc.plan.scale is None and not sc.weight.has_zero and sc.prelu is None and not sc.relu
+                        and sc.bn_scale is None and tuple(lay.kernel_size) == (1, 1) and tuple(lay.stride) == (1, 1)
+                        and tuple(lay.padding) == (0, 0) and lay.in_channels * 2 == planes
+                        and os.environ.get("BNN_AMD_HBLOCK_SHORTCUT", "1") != "0"):
+                    try:
+                        b["hsc"] = hipops.hblock_shortcut_pack(sc.weight)
+                    except native.NativeError:
+                        b["hsc"] = None
 
     def _add_block(self, blk) -> None:
         """Derive the fused form of one residual block (appends to ``self._blocks``)."""
@@ -599,8 +613,24 @@ class FusedResNet(nn.Module):
         if b["ds"] is not None:
             (sa, sb), conv = b["ds"]
             sp = getattr(packed, "_ds_planes", None) if mine else None
-            idn, _ = conv.run(sp if sp is not None else hipops.bn_act_pack(t, sa, sb, relu=False), out_f32=True,
-                              out_packed=False)
+            if sp is None:
+                sp = hipops.bn_act_pack(t, sa, sb, relu=False)
+            hp = b.get("hpack")
+            if b.get("hsc") is not None and _TAP is None:
+                N, _, H, W = sp.shape
+                key = ("sc", N, H, W)
+                ok = b["hgeo"].get(key)
+                if ok is None:     # (the small-image form has no such variant: where it is the faster block, the 1x1 launch stays)
+                    ok = b["hgeo"][key] = (self._hblock_ok(b, N, H, W) and
+                                           (not b["hcl"][(N, H, W)] or os.environ.get("BNN_AMD_HBLOCK_SHORTCUT_OVER_CL") == "1") and
+                                           hipops.hblock_shortcut_supported(N, hp.c_in, H, W, hp.planes, self.throughput_mode))
+                if ok:
+                    if not mine:
+                        packed = hipops.bn_act_pack(t, *b["bn"][0], relu=True)
+                    y, pk = hipops.hblock_shortcut_forward(packed, hp, sp, b["hsc"], throughput=self.throughput_mode)
+                    pk._h_for = nxt
+                    return y, pk
+            idn, _ = conv.run(sp, out_f32=True, out_packed=False)
         else:
             idn = t
         c1, c2, c3 = b["convs"]

@@ -783,6 +783,59 @@ def hblock_forward(a: PackedAct, pack: HBlockPack, residual: torch.Tensor, out_p
     return y, pk
 
 
+def hblock_shortcut_supported(N: int, c_in: int, H: int, W: int, planes: int, throughput: bool = False, rows_per_band: int = 0,
+                              images_per_band: int = 0, waves: int = 0) -> bool:
+    """Whether ``hblock_shortcut_forward`` covers this geometry (with this plan) on the current device."""
+    lib = native.require()
+    d = _hblock_desc(N, c_in, H, W, planes, throughput, rows_per_band, images_per_band, waves)
+    return bool(lib.bnn_hip_hblock_shortcut_supported(ctypes.byref(d)))
+
+
+def hblock_shortcut_pack(w: PackedWeight):
+    """``(weights [planes][C_in / 32] int32, alpha [planes])`` of a block's 1x1 shortcut convolution for
+    ``hblock_shortcut_forward`` (no zero weights)."""
+    lib = native.require()
+    planes, c_in = w.shape[0], w.shape[1]
+    if w.has_zero or tuple(w.shape[2:]) != (1, 1) or c_in % 64:
+        raise native.NativeError("bnn_amd: hblock_shortcut_pack expects the pack of a 1x1 convolution without zero weights")
+    dev = w.wbits.device
+    with torch.cuda.device(dev):
+        buf = torch.empty(planes * (c_in // 32), dtype=torch.int32, device=dev)
+        native.check(lib.bnn_hip_hblock_pack_shortcut_weights(c_in, planes, w.wbits.data_ptr(), buf.data_ptr(), _stream(dev)),
+                     "bnn_hip_hblock_pack_shortcut_weights")
+        alpha = w.alpha[:planes].contiguous().clone()
+    return buf, alpha
+
+
+def hblock_shortcut_forward(a: PackedAct, pack: HBlockPack, sc: PackedAct, sc_pack, throughput: bool = False,
+                            rows_per_band: int = 0, images_per_band: int = 0, waves: int = 0):
+    """The first hierarchical block of a stage with its shortcut (``BatchNorm -> sign -> conv1x1``,
+    hierarchical_block.py:30-36) computed inside the launch from the sign planes ``sc`` of that binarisation:
+    no shortcut launch, no fp32 shortcut tensor.  Returns ``(y, PackedAct of the next block's input)``."""
+    lib = native.require()
+    N, c_in, H, W = a.shape
+    if not a.nonneg or c_in != pack.c_in or tuple(sc.shape) != tuple(a.shape) or not pack.has_next:
+        raise native.NativeError("bnn_amd: hblock_shortcut_forward needs the block's input planes, the shortcut's planes of "
+                                 "the same shape, and a pack with the next block's BatchNorm")
+    wsc, asc = sc_pack
+    if wsc.numel() != pack.planes * (c_in // 32) or asc.numel() != pack.planes:
+        raise native.NativeError("bnn_amd: shortcut pack of another width")
+    dev = a.P.device
+    with torch.cuda.device(dev):
+        y = torch.empty((N, pack.planes, H, W), dtype=torch.float32, device=dev)
+        shp = (N, pack.planes // 64, H, W)
+        pk = PackedAct(torch.empty(shp, dtype=torch.int64, device=dev), _zero_plane(shp, dev), (N, pack.planes, H, W),
+                       nonneg=True)
+        if N == 0:
+            return y, pk
+        d = _hblock_desc(N, c_in, H, W, pack.planes, throughput, rows_per_band, images_per_band, waves)
+        native.check(lib.bnn_hip_hblock_shortcut_forward(ctypes.byref(d), a.P.data_ptr(), pack.weights.data_ptr(),
+                                                         pack.consts.data_ptr(), sc.P.data_ptr(), sc.M.data_ptr(),
+                                                         wsc.data_ptr(), asc.data_ptr(), y.data_ptr(), pk.P.data_ptr(),
+                                                         _stream(dev)), "bnn_hip_hblock_shortcut_forward")
+    return y, pk
+
+
 def hblock_pool_supported(N: int, c_in: int, H: int, W: int, planes: int, throughput: bool = False, rows_per_band: int = 0,
                           images_per_band: int = 0, waves: int = 0) -> bool:
     """Whether ``hblock_pool_forward`` covers this geometry (with this plan) on the current device."""

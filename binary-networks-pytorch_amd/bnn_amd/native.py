@@ -49,6 +49,7 @@ EXPORTED_SYMBOLS = (
     "bnn_hip_hblock_supported", "bnn_hip_hblock_layout_of", "bnn_hip_hblock_pack_weights", "bnn_hip_hblock_forward",
     "bnn_hip_avgpool2_bn_pack2_f32", "bnn_hip_hblock_pack_weights_cl", "bnn_hip_stem7x7_bn_relu_pool_pack_affine_f32",
     "bnn_hip_hblock_pool_supported", "bnn_hip_hblock_pool_forward",
+    "bnn_hip_hblock_shortcut_supported", "bnn_hip_hblock_pack_shortcut_weights", "bnn_hip_hblock_shortcut_forward",
 )
 
 
@@ -206,6 +207,9 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.bnn_hip_hblock_forward.argtypes = [ctypes.POINTER(HBlockDesc)] + [_vp] * 7
     lib.bnn_hip_hblock_pool_supported.argtypes = [ctypes.POINTER(HBlockDesc)]
     lib.bnn_hip_hblock_pool_forward.argtypes = [ctypes.POINTER(HBlockDesc)] + [_vp] * 9
+    lib.bnn_hip_hblock_shortcut_supported.argtypes = [ctypes.POINTER(HBlockDesc)]
+    lib.bnn_hip_hblock_pack_shortcut_weights.argtypes = [_i, _i, _vp, _vp, _vp]
+    lib.bnn_hip_hblock_shortcut_forward.argtypes = [ctypes.POINTER(HBlockDesc)] + [_vp] * 10
 
 
 def load() -> Optional[ctypes.CDLL]:

@@ -179,6 +179,11 @@ int launch_hblock(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint3
 int launch_hblock_pool(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc, const float* Kp,
                        const float* res, uint64_t* outP1, uint64_t* outP2, uint64_t* outM2, hipStream_t stream);
 bool hblock_pool_supported(const bnn_hip_hblock_desc* d);
+int launch_hblock_ds(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc,
+                     const uint64_t* dsP, const uint64_t* dsM, const uint32_t* dsW, const float* dsA, float* out,
+                     uint64_t* outP, hipStream_t stream);
+bool hblock_ds_supported(const bnn_hip_hblock_desc* d);
+int launch_hblock_ds_pack_weights(int C_in, int planes, const uint32_t* w, uint32_t* dst, hipStream_t s);
 // hblock_cl.hip: the same block for 14 x 14 / 7 x 7 images, lanes = output channels
 bool hblock_cl_supported(const bnn_hip_hblock_desc* d);
 int launch_hblock_cl_pack_weights(int C_in, int planes, const uint32_t* const w[3], uint32_t* dst, hipStream_t s);

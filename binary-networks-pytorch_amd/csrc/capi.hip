@@ -912,6 +912,37 @@ int bnn_hip_hblock_pool_forward(const bnn_hip_hblock_desc* d, const uint64_t* in
                                  static_cast<hipStream_t>(stream));
 }
 
+int bnn_hip_hblock_shortcut_supported(const bnn_hip_hblock_desc* d) {
+  if (check_hblock(d) != BNN_HIP_OK || (d->flags & BNN_HIP_HBLOCK_CHANNEL_LANES)) return 0;
+  return bnn::hblock_ds_supported(d) ? 1 : 0;
+}
+
+int bnn_hip_hblock_pack_shortcut_weights(int C_in, int planes, const uint32_t* wbits, uint32_t* weights, void* stream) {
+  if (!wbits || !weights || C_in <= 0 || planes <= 0) return BNN_HIP_ERR_INVALID_ARG;
+  if (!aligned(wbits, 4) || !aligned(weights, 32)) return BNN_HIP_ERR_INVALID_ARG;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_hblock_ds_pack_weights(C_in, planes, wbits, weights, static_cast<hipStream_t>(stream));
+}
+
+int bnn_hip_hblock_shortcut_forward(const bnn_hip_hblock_desc* d, const uint64_t* in_P, const uint32_t* weights,
+                                    const float* consts, const uint64_t* sc_P, const uint64_t* sc_M,
+                                    const uint32_t* sc_weights, const float* sc_alpha, float* out, uint64_t* out_P,
+                                    void* stream) {
+  const int st = check_hblock(d);
+  if (st != BNN_HIP_OK) return st;
+  if (d->flags & BNN_HIP_HBLOCK_CHANNEL_LANES) return BNN_HIP_ERR_INVALID_ARG;
+  if (!in_P || !weights || !consts || !sc_P || !sc_M || !sc_weights || !sc_alpha || !out || !out_P) return BNN_HIP_ERR_INVALID_ARG;
+  if (!aligned(in_P, 8) || !aligned(weights, 64) || !aligned(consts, 8) || !aligned(sc_P, 8) || !aligned(sc_M, 8) ||
+      !aligned(sc_weights, 32) || !aligned(sc_alpha, 32) || !aligned(out, 4) || !aligned(out_P, 8))
+    return BNN_HIP_ERR_INVALID_ARG;
+  if (!bnn::hblock_ds_supported(d)) return BNN_HIP_ERR_UNSUPPORTED;
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+  BNN_RANGE();
+  return bnn::launch_hblock_ds(d, in_P, weights, consts, sc_P, sc_M, sc_weights, sc_alpha, out, out_P,
+                               static_cast<hipStream_t>(stream));
+}
+
 int bnn_hip_probe_clock(int spin_iters, double* shader_mhz, double* elapsed_us, void* stream) {
   if (spin_iters <= 0 || spin_iters > (1 << 24) || !shader_mhz) return BNN_HIP_ERR_INVALID_ARG;
   return bnn::launch_probe_clock(spin_iters, shader_mhz, elapsed_us, static_cast<hipStream_t>(stream));

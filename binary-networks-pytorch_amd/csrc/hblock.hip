@@ -72,6 +72,16 @@ struct HbGeo {
   int s_wc;
 };
 
+// DS: the block's shortcut is a binary 1 x 1 convolution of ANOTHER binarisation of its input (the first block of a stage:
+// hierarchical_block.py:30-36, BatchNorm -> sign -> conv1x1) and is computed here, per pass, from that tensor's two sign
+// planes — no shortcut launch, no fp32 shortcut tensor written and read back.
+struct HbDs {
+  const uint64_t* P;   // [N, ceil(C_in / 64), H, W]: the shortcut input is positive / negative
+  const uint64_t* M;
+  const uint32_t* W;   // [C][cw_in] words, bit = the weight is +1 (hblock_ds_pack_weight_kernel)
+  const float* A;      // [C]: alpha of the 1 x 1 convolution
+};
+
 namespace {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char hb_smem[];
@@ -138,6 +148,19 @@ __device__ __forceinline__ float hb_quad_sum(float v) {
   s = hb_quad<0x55>(v) + s;
   s = hb_quad<0xAA>(v) + s;
   return hb_quad<0xFF>(v) + s;
+}
+
+// N consecutive wave-uniform 32-bit words (32-byte aligned), the same way.
+template <int N>
+__device__ __forceinline__ void hb_words(const uint32_t* __restrict__ src, uint32_t (&dst)[N]) {
+  static_assert(N % 8 == 0, "whole dwordx8 pieces");
+  struct alignas(32) U8 { uint32_t v[8]; };
+#pragma unroll
+  for (int i = 0; i < N / 8; ++i) {
+    const U8 t = *reinterpret_cast<const U8*>(__builtin_assume_aligned(src + 8 * i, 32));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[8 * i + e] = t.v[e];
+  }
 }
 
 constexpr int HB_NONE = 0, HB_NEXT = 1, HB_POOL = 2;  // what a launch leaves for the next block
@@ -232,10 +255,10 @@ __device__ __forceinline__ void hb_wait_inputs(const HbGeo& g, int K, const HbDo
 //         (a1 / 4, b1), lane 1 (a2 / 4, b2), lane 2 (-a2 / 4, -b2) — each lane of a window tests ONE plane's bit,
 //         fmaf(window sum, a, b) > 0: the division by 4 is exact in the scale, the negative plane is the positive one of
 //         the negated affine
-template <int CWC, bool MULTI, int K, int CWCN, int MODE>
+template <int CWC, bool MULTI, int K, int CWCN, int MODE, int DSW = 0>
 __device__ __forceinline__ void hb_unit(const uint32_t* __restrict__ Wt, const float* __restrict__ Kc,
                                         const float* __restrict__ Kp, const float* __restrict__ res, float* __restrict__ out,
-                                        const HbGeo& g,
+                                        const HbDs& ds, const HbGeo& g,
                                         unsigned char* smem, const HbDom& d, uint32_t* done, int pg, int p0, int np, int n0,
                                         int kk, int y0, int rows, int lane) {
   constexpr int NW = 9 * CWC;
@@ -279,13 +302,47 @@ __device__ __forceinline__ void hb_unit(const uint32_t* __restrict__ Wt, const f
   if constexpr (NEXT) cello = (unsigned)(imul<true>(imul<true>(img, g.BR) + (row - y0), g.W) + col);
   if constexpr (POOL)   // the window's cell in a pooled plane set
     cello = (unsigned)(imul<true>(imul<true>(img, g.BR >> 1) + ((row - y0) >> 1), g.W >> 1) + (col >> 1));
+  // DSW > 0: the two sign planes of the shortcut's input at this lane's pixel (DSW words each) and how many are non-zero
+  [[maybe_unused]] uint32_t dsp[DSW > 0 ? DSW : 1], dsm[DSW > 0 ? DSW : 1];
+  [[maybe_unused]] int dsnz = 0;
+  if constexpr (DSW > 0) {
+    const size_t pix = (size_t)imul<true>(row, g.W) + (size_t)col;
+#pragma unroll
+    for (int q = 0; q < DSW / 2; ++q) {
+      const size_t at = ((size_t)(n0 + img) * (DSW / 2) + q) * hw + pix;
+      const uint64_t pv = interior ? ds.P[at] : 0ull, mv = interior ? ds.M[at] : 0ull;
+      dsp[2 * q] = (uint32_t)pv; dsp[2 * q + 1] = (uint32_t)(pv >> 32);
+      dsm[2 * q] = (uint32_t)mv; dsm[2 * q + 1] = (uint32_t)(mv >> 32);
+    }
+#pragma unroll
+    for (int w = 0; w < DSW; ++w) dsnz += __builtin_popcount(dsp[w] | dsm[w]);
+  }
 #pragma unroll 1
   for (int ps = 0; ps < np; ++ps) {
     const int o0 = (p0 + ps) * NACC;
     // the pass's shortcut values: requested before the popcount loop, they land under it
     float resv[NACC];
+    if constexpr (DSW > 0) {
+      // ... or computed: dot = 2 * (agreeing non-zero inputs) - (non-zero inputs), value = fmaf(alpha, dot, 0) — the
+      // integer and the one rounding of bnn_hip_bconv2d's plain epilogue (bconv_core.h)
+      uint32_t wd[NACC * DSW];
+      hb_words<NACC * DSW>(ds.W + (size_t)(ph.c_off + o0) * DSW, wd);
+      float da[NACC];
+      hb_consts<NACC>(ds.A + ph.c_off + o0, da);
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) resv[i] = buf_ld(rres, lane_off, (unsigned)(ph.c_off + o0 + i) * (unsigned)hw * 4u);
+      for (int i = 0; i < NACC; ++i) {
+        int agree = 0;
+#pragma unroll
+        for (int w = 0; w < DSW; ++w) {
+          const uint32_t wv = wd[i * DSW + w];
+          agree += __builtin_popcount((dsp[w] & wv) | (dsm[w] & ~wv));
+        }
+        resv[i] = __builtin_fmaf(da[i], (float)(2 * agree - dsnz), 0.0f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) resv[i] = buf_ld(rres, lane_off, (unsigned)(ph.c_off + o0 + i) * (unsigned)hw * 4u);
+    }
     [[maybe_unused]] float qa[NACC], qb[NACC];
     if constexpr (POOL) {  // this lane's affine of the pass's channels (4 distinct addresses per wave)
       const float* kq = Kp + (size_t)((lane & 3) * 2 * g.C + ph.c_off + o0);
@@ -406,11 +463,11 @@ __device__ __forceinline__ void hb_unit(const uint32_t* __restrict__ Wt, const f
   }
 }
 
-template <int CWC, bool MULTI, int K, int CWCN, int MODE>
+template <int CWC, bool MULTI, int K, int CWCN, int MODE, int DSW = 0>
 __device__ __forceinline__ void hb_phase(const uint32_t* __restrict__ Wt, const float* __restrict__ Kc,
                                          const float* __restrict__ Kp, const float* __restrict__ res,
-                                         float* __restrict__ out, const HbGeo& g, unsigned char* smem, int n0, int kk,
-                                         int y0, int rows, int lane) {
+                                         float* __restrict__ out, const HbDs& ds, const HbGeo& g, unsigned char* smem, int n0,
+                                         int kk, int y0, int rows, int lane) {
   constexpr bool POOL = MODE == HB_POOL;
   const HbPhase& ph = g.ph[K];
   const HbDom d = hb_domain<POOL>(g, K, kk, y0, rows);
@@ -427,17 +484,18 @@ __device__ __forceinline__ void hb_phase(const uint32_t* __restrict__ Wt, const 
       const HbDom dp = hb_domain<POOL>(g, K - 1, kk, y0, rows);
       hb_wait_inputs<POOL>(g, K, d, dp, pg, kk, K == 1 ? done0 : done, lane);
     }
-    hb_unit<CWC, MULTI, K, CWCN, MODE>(Wt, Kc, Kp, res, out, g, smem, d, done, pg, p0, min(ph.ppu, ph.npass - p0), n0, kk,
-                                       y0, rows, lane);
+    hb_unit<CWC, MULTI, K, CWCN, MODE, DSW>(Wt, Kc, Kp, res, out, ds, g, smem, d, done, pg, p0, min(ph.ppu, ph.npass - p0),
+                                            n0, kk, y0, rows, lane);
   }
 }
 
-template <int CWC1, bool M1, int CWC2, bool M2, int CWC3, bool M3, int MODE>
+template <int CWC1, bool M1, int CWC2, bool M2, int CWC3, bool M3, int MODE, int DSW = 0>
 __global__ __launch_bounds__(1024, HB_MINW) void hblock_kernel(const uint64_t* __restrict__ inP, const uint32_t* __restrict__ Wt,
                                                       const float* __restrict__ Kc, const float* __restrict__ res,
                                                       float* __restrict__ out, uint64_t* __restrict__ outP,
                                                       const HbGeo g, const float* __restrict__ Kp,
-                                                      uint64_t* __restrict__ outP2, uint64_t* __restrict__ outM2) {
+                                                      uint64_t* __restrict__ outP2, uint64_t* __restrict__ outM2,
+                                                      const HbDs ds) {
   constexpr bool NEXT = MODE == HB_NEXT;
   unsigned char* smem = hb_smem;
   const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
@@ -485,11 +543,11 @@ __global__ __launch_bounds__(1024, HB_MINW) void hblock_kernel(const uint64_t* _
   // counters (hb_wait_inputs).  A unit only waits for units of the previous convolution, all of which are in the hands
   // of running waves by then.
   [[maybe_unused]] const unsigned long long t_p0 = HB_NOW();
-  hb_phase<CWC1, M1, 0, CWC2, MODE>(Wt, Kc, Kp, res, out, g, smem, n0, kk, y0, rows, lane);
+  hb_phase<CWC1, M1, 0, CWC2, MODE, DSW>(Wt, Kc, Kp, res, out, ds, g, smem, n0, kk, y0, rows, lane);
   [[maybe_unused]] const unsigned long long t_c1 = HB_NOW();
-  hb_phase<CWC2, M2, 1, CWC3, MODE>(Wt, Kc, Kp, res, out, g, smem, n0, kk, y0, rows, lane);
+  hb_phase<CWC2, M2, 1, CWC3, MODE, DSW>(Wt, Kc, Kp, res, out, ds, g, smem, n0, kk, y0, rows, lane);
   [[maybe_unused]] const unsigned long long t_c2 = HB_NOW();
-  hb_phase<CWC3, M3, 2, 1, MODE>(Wt, Kc, Kp, res, out, g, smem, n0, kk, y0, rows, lane);
+  hb_phase<CWC3, M3, 2, 1, MODE, DSW>(Wt, Kc, Kp, res, out, ds, g, smem, n0, kk, y0, rows, lane);
   [[maybe_unused]] const unsigned long long t_c3 = HB_NOW();
   if constexpr (NEXT) {
     __syncthreads();
@@ -644,12 +702,12 @@ long long hb_lds(const HbShape& s, int W, int planes, int G, int BR, int mode, H
 template <class K>
 int hb_launch(K kernel, const HbGeo& g, int nblocks, int waves, const uint64_t* inP, const uint32_t* W, const float* Kc,
               const float* res, float* out, uint64_t* outP, hipStream_t s, const float* Kp = nullptr,
-              uint64_t* outP2 = nullptr, uint64_t* outM2 = nullptr) {
+              uint64_t* outP2 = nullptr, uint64_t* outM2 = nullptr, HbDs ds = HbDs{nullptr, nullptr, nullptr, nullptr}) {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           kMaxDynamicLds) != hipSuccess)
     return BNN_HIP_ERR_LAUNCH;
   hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3((unsigned)waves * kWave), (size_t)g.lds16 * 16, s, inP, W, Kc,
-                     res, out, outP, g, Kp, outP2, outM2);
+                     res, out, outP, g, Kp, outP2, outM2, ds);
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
@@ -709,10 +767,18 @@ int hblock_plan(const bnn_hip_hblock_desc* d, int* G_out, int* BR_out, int* wave
 }
 
 namespace {
-template <int C1, bool M1, int C2, bool M2, int C3, bool M3, bool POOLED>
+template <int C1, bool M1, int C2, bool M2, int C3, bool M3, bool POOLED, int DSW>
 int hb_dispatch(int mode, const HbGeo& g, int nblocks, int waves, const uint64_t* inP, const uint32_t* W, const float* Kc,
                 const float* Kp, const float* res, float* out, uint64_t* outP, uint64_t* outP2, uint64_t* outM2,
-                hipStream_t stream) {
+                hipStream_t stream, const HbDs* ds) {
+  if (ds != nullptr) {   // the shortcut convolution inside the launch: the widths that OPEN a stage, a next block behind them
+    if constexpr (DSW > 0) {
+      if (mode == HB_NEXT && g.cw_in == DSW)
+        return hb_launch(hblock_kernel<C1, M1, C2, M2, C3, M3, HB_NEXT, DSW>, g, nblocks, waves, inP, W, Kc, res, out, outP,
+                         stream, nullptr, nullptr, nullptr, *ds);
+    }
+    return BNN_HIP_ERR_UNSUPPORTED;
+  }
   if constexpr (POOLED) {
     if (mode == HB_POOL)
       return hb_launch(hblock_kernel<C1, M1, C2, M2, C3, M3, HB_POOL>, g, nblocks, waves, inP, W, Kc, res, out, outP, stream,
@@ -726,7 +792,8 @@ int hb_dispatch(int mode, const HbGeo& g, int nblocks, int waves, const uint64_t
 }
 
 int hb_run(const bnn_hip_hblock_desc* d, int mode, const uint64_t* inP, const uint32_t* W, const float* Kc, const float* Kp,
-           const float* res, float* out, uint64_t* outP, uint64_t* outP2, uint64_t* outM2, hipStream_t stream) {
+           const float* res, float* out, uint64_t* outP, uint64_t* outP2, uint64_t* outM2, hipStream_t stream,
+           const HbDs* ds = nullptr) {
   HbShape s;
   bnn_hip_hblock_layout L;
   if (!hb_shape(d->C_in, d->planes, s) || hblock_layout(d->C_in, d->planes, &L) != BNN_HIP_OK) return BNN_HIP_ERR_UNSUPPORTED;
@@ -777,18 +844,19 @@ int hb_run(const bnn_hip_hblock_desc* d, int mode, const uint64_t* inP, const ui
   g.f32_bytes = (unsigned)((long long)d->N * d->planes * d->H * d->W * 4);
   const int nblocks = ((d->N + G - 1) / G) * g.nbi;
 
-#define HB_PICK(C1, M1_, C2, M2_, C3, M3_, POOLED)                                                                       \
+#define HB_PICK(C1, M1_, C2, M2_, C3, M3_, POOLED, DSW)                                                                  \
   if (s.cwc[0] == C1 && (s.nchunk[0] > 1) == M1_ && s.cwc[1] == C2 && (s.nchunk[1] > 1) == M2_ && s.cwc[2] == C3 &&    \
       (s.nchunk[2] > 1) == M3_)                                                                                         \
-    return hb_dispatch<C1, M1_, C2, M2_, C3, M3_, POOLED>(mode, g, nblocks, waves, inP, W, Kc, Kp, res, out, outP,      \
-                                                          outP2, outM2, stream);
+    return hb_dispatch<C1, M1_, C2, M2_, C3, M3_, POOLED, DSW>(mode, g, nblocks, waves, inP, W, Kc, Kp, res, out, outP, \
+                                                               outP2, outM2, stream, ds);
   // (the pooled form: the widths that END a stage of the [64, 128, 256, 512] networks)
-  HB_PICK(2, false, 1, false, 1, false, true)    // 64 -> 64:   64 -> 32 -> 16 -> 16
-  HB_PICK(2, false, 2, false, 1, false, false)   // 64 -> 128:  64 -> 64 -> 32 -> 32
-  HB_PICK(4, false, 2, false, 1, false, true)    // 128 -> 128
-  HB_PICK(4, false, 4, false, 2, false, false)   // 128 -> 256
-  HB_PICK(4, true, 4, false, 2, false, true)     // 256 -> 256
-  HB_PICK(4, true, 4, true, 4, false, false)     // 256 -> 512 and 512 -> 512
+  // (... and the form with the shortcut convolution inside: the widths that OPEN one, with the words of its input plane)
+  HB_PICK(2, false, 1, false, 1, false, true, 0)    // 64 -> 64:   64 -> 32 -> 16 -> 16
+  HB_PICK(2, false, 2, false, 1, false, false, 2)   // 64 -> 128:  64 -> 64 -> 32 -> 32
+  HB_PICK(4, false, 2, false, 1, false, true, 0)    // 128 -> 128
+  HB_PICK(4, false, 4, false, 2, false, false, 4)   // 128 -> 256
+  HB_PICK(4, true, 4, false, 2, false, true, 0)     // 256 -> 256
+  HB_PICK(4, true, 4, true, 4, false, false, 0)     // 256 -> 512 and 512 -> 512
 #undef HB_PICK
   return BNN_HIP_ERR_UNSUPPORTED;
 }
@@ -804,6 +872,38 @@ int launch_hblock_pool(const bnn_hip_hblock_desc* d, const uint64_t* inP, const 
                        const float* Kp, const float* res, uint64_t* outP1, uint64_t* outP2, uint64_t* outM2,
                        hipStream_t stream) {
   return hb_run(d, HB_POOL, inP, W, Kc, Kp, res, nullptr, outP1, outP2, outM2, stream);
+}
+
+// The first block of a stage with its shortcut convolution inside (HbDs at the top of the file).
+int launch_hblock_ds(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc,
+                     const uint64_t* dsP, const uint64_t* dsM, const uint32_t* dsW, const float* dsA, float* out,
+                     uint64_t* outP, hipStream_t stream) {
+  const HbDs ds{dsP, dsM, dsW, dsA};
+  return hb_run(d, HB_NEXT, inP, W, Kc, nullptr, nullptr, out, outP, nullptr, nullptr, stream, &ds);
+}
+
+bool hblock_ds_supported(const bnn_hip_hblock_desc* d) {
+  HbShape s;
+  if (!hb_shape(d->C_in, d->planes, s) || d->planes != 2 * d->C_in || !hblock_supported(d)) return false;
+  const bool m0 = s.nchunk[0] > 1;
+  return (s.cwc[0] == 2 && !m0 && s.cwc[1] == 2 && s.cwc[2] == 1) || (s.cwc[0] == 4 && !m0 && s.cwc[1] == 4 && s.cwc[2] == 2);
+}
+
+// standard packed weights of the 1 x 1 shortcut convolution (wbits[ob][chunk][j][cwc], 64-channel granularity) -> [o][cw]
+__global__ __launch_bounds__(256) void hblock_ds_pack_weight_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                                    int O, int cw, int cwc_s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= O * cw) return;
+  const int cwi = i % cw, o = i / cw;
+  const int ob = o >> 5, j = o & 31, nchunk_s = cw / cwc_s;
+  dst[i] = src[((size_t)(ob * nchunk_s + cwi / cwc_s) * 32 + j) * cwc_s + cwi % cwc_s];
+}
+
+int launch_hblock_ds_pack_weights(int C_in, int planes, const uint32_t* w, uint32_t* dst, hipStream_t s) {
+  if (C_in <= 0 || C_in % 64 != 0 || C_in > 4096 || planes <= 0 || planes > 4096) return BNN_HIP_ERR_UNSUPPORTED;
+  const int cw = C_in / 32, cwc_s = choose_cwc(cw, 1, 1), n = planes * cw;
+  hipLaunchKernelGGL(hblock_ds_pack_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, dst, planes, cw, cwc_s);
+  return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
 bool hblock_pool_supported(const bnn_hip_hblock_desc* d) {

@@ -551,6 +551,21 @@ int bnn_hip_hblock_pool_forward(const bnn_hip_hblock_desc* d, const uint64_t* in
                                 const float* consts, const float* pool_consts, const float* residual, uint64_t* out_P1,
                                 uint64_t* out_P2, uint64_t* out_M2, void* stream);
 
+/* The FIRST block of a stage with its shortcut convolution inside the launch (ABI 15; hierarchical_block.py:30-36: the
+ * shortcut of a block that changes width is BatchNorm -> sign -> binary conv1x1 of the block's input).  Instead of a residual
+ * tensor the launch takes the two sign planes of that binarisation (sc_P / sc_M: [N, C_in / 64, H, W], what
+ * bnn_hip_hblock_pool_forward or bnn_hip_avgpool2_bn_pack2_f32 wrote), the 1 x 1 weights as [planes][C_in / 32] words
+ * (bnn_hip_hblock_pack_shortcut_weights of the standard pack; no zero weights, no bias) and their alpha [planes], and
+ * computes  shortcut = fmaf(alpha[c], dot, 0)  per pass — the integer and the one rounding of bnn_hip_bconv2d — so the
+ * shortcut launch and its fp32 tensor disappear.  planes == 2 * C_in, C_in in {64, 128}; out_P is required (a next block in
+ * the stage); same bits as bnn_hip_bconv2d + bnn_hip_hblock_forward.  */
+int bnn_hip_hblock_shortcut_supported(const bnn_hip_hblock_desc* d);
+int bnn_hip_hblock_pack_shortcut_weights(int C_in, int planes, const uint32_t* wbits, uint32_t* weights, void* stream);
+int bnn_hip_hblock_shortcut_forward(const bnn_hip_hblock_desc* d, const uint64_t* in_P, const uint32_t* weights,
+                                    const float* consts, const uint64_t* sc_P, const uint64_t* sc_M,
+                                    const uint32_t* sc_weights, const float* sc_alpha, float* out, uint64_t* out_P,
+                                    void* stream);
+
 /* fp32 NCHW in -> fp32 NCHW out.  ONE launch (bnn_hip_bconv2d_direct) wherever that path applies:
  * bnn_hip_conv_workspace_bytes(d) is then 0 and `workspace` may be NULL.  For the remaining geometries (see above)
  * it is pack_act + conv through `workspace` (bnn_hip_conv_workspace_bytes(d) bytes, 16-byte aligned).          */

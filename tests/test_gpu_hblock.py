@@ -208,3 +208,60 @@ def test_pool_form_argument_checks():
         hipops.hblock_pool_forward(p_in, pack, res[:, :, :7], kp)
     with pytest.raises(native.NativeError):
         hipops.hblock_pool_forward(p_in, pack, res, kp, rows_per_band=3)
+
+
+SC_SHAPES = [(64, 3, 28, 28), (128, 5, 14, 14), (64, 2, 9, 13), (128, 2, 5, 5), (64, 130, 28, 28)]   # C_in (planes = 2 C_in), N, H, W
+
+
+@pytest.mark.parametrize("shape", SC_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_first_block_of_a_stage_with_its_shortcut_convolution_inside(shape):
+    """bnn_hip_hblock_shortcut_forward: the block whose shortcut is BatchNorm -> sign -> binary conv1x1 of its input
+    (hierarchical_block.py:30-36) computes that convolution per pass from the two sign planes — bit for bit
+    bnn_hip_bconv2d (the 1x1 launch, fp32 out) + bnn_hip_hblock_forward on its output, fp32 tensor and next planes alike."""
+    c_in, N, H, W = shape
+    planes = 2 * c_in
+    x, res, ws, bn1, bn2, bn3, nbn = _block(hash(shape) % 1000, c_in, planes, N, H, W)
+    g = torch.Generator().manual_seed(11)
+    ds_bn = ((torch.rand(c_in, generator=g) + 0.5).to(DEV) * torch.where(torch.arange(c_in) % 3 == 0, -1.0, 1.0).to(DEV),
+             (torch.randn(c_in, generator=g) * 0.3).to(DEV))
+    w_sc = (torch.randn(planes, c_in, 1, 1, generator=g) * 0.05).to(DEV)
+    x[:, :, 0, 0] = -ds_bn[1] / ds_bn[0]                       # some exact zeros of the shortcut's BatchNorm: sign() == 0
+    p_in = hipops.bn_act_pack(x, bn1[0], bn1[1], relu=True)
+    p_sc = hipops.bn_act_pack(x, ds_bn[0], ds_bn[1], relu=False)
+    assert bool(p_sc.M.any()) and bool(p_sc.P.any())
+    pw_sc = hipops.pack_weight(w_sc)
+    idn = hipops.bconv2d(p_sc, pw_sc)
+    pack = hipops.hblock_pack(*[hipops.pack_weight(w) for w in ws], bn2, bn3, nbn)
+    want_y, want_p = hipops.hblock_forward(p_in, pack, idn)
+    sc_pack = hipops.hblock_shortcut_pack(pw_sc)
+    ran = 0
+    for plan in PLANS:
+        if plan.get("rows_per_band", 0) > H or plan.get("images_per_band", 0) > N:
+            continue
+        if not hipops.hblock_shortcut_supported(N, c_in, H, W, planes, **plan):
+            assert plan.get("images_per_band", 0) > 1 and H * W > 1000
+            continue
+        y, p = hipops.hblock_shortcut_forward(p_in, pack, p_sc, sc_pack, **plan)
+        assert torch.equal(y, want_y), plan
+        assert torch.equal(p.P, want_p.P) and p.nonneg, plan
+        ran += 1
+    assert ran >= 4
+
+
+def test_shortcut_form_argument_checks():
+    from bnn_amd import native
+    assert not hipops.hblock_shortcut_supported(2, 64, 28, 28, 64)           # not a width-changing block
+    assert not hipops.hblock_shortcut_supported(2, 256, 14, 14, 512)         # no instance
+    x, res, ws, bn1, bn2, bn3, nbn = _block(5, 64, 128, 2, 8, 8)
+    p_in = hipops.bn_act_pack(x, bn1[0], bn1[1], relu=True)
+    p_sc = hipops.bn_act_pack(x, bn1[0], bn1[1], relu=False)
+    pws = [hipops.pack_weight(w) for w in ws]
+    sc_pack = hipops.hblock_shortcut_pack(hipops.pack_weight(torch.randn(128, 64, 1, 1, device=DEV)))
+    with pytest.raises(native.NativeError):                                  # a pack without the next block's BatchNorm
+        hipops.hblock_shortcut_forward(p_in, hipops.hblock_pack(*pws, bn2, bn3, None), p_sc, sc_pack)
+    with pytest.raises(native.NativeError):
+        hipops.hblock_shortcut_pack(pws[0])                                  # a 3x3 pack
+    wz = torch.randn(128, 64, 1, 1, device=DEV)
+    wz[3, 5] = 0.0
+    with pytest.raises(native.NativeError):
+        hipops.hblock_shortcut_pack(hipops.pack_weight(wz))                  # zero weights take the separate launch

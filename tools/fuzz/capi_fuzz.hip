@@ -125,6 +125,21 @@ int hblock_layout(int C_in, int planes, bnn_hip_hblock_layout* L) {
   L->const_floats = 4LL * planes;
   return BNN_HIP_OK;
 }
+bool hblock_ds_supported(const bnn_hip_hblock_desc* d) {
+  return d->planes == 2 * d->C_in && (d->C_in == 64 || d->C_in == 128) && (long long)d->H * d->W <= 4096;
+}
+int launch_hblock_ds(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc, const uint64_t* p,
+                     const uint64_t* m, const uint32_t* w, const float* a, float* out, uint64_t* outP, hipStream_t) {
+  ++g_reached;
+  REQUIRE(d && inP && W && Kc && p && m && w && a && out && outP && al(w, 32) && al(a, 32) && al(outP, 8) && al(p, 8) && al(m, 8));
+  REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->planes == 2 * d->C_in);
+  return BNN_HIP_OK;
+}
+int launch_hblock_ds_pack_weights(int C_in, int planes, const uint32_t* w, uint32_t* dst, hipStream_t) {
+  ++g_reached;
+  REQUIRE(w && dst && C_in > 0 && planes > 0 && al(dst, 32));
+  return (C_in % 64 || C_in > 4096 || planes > 4096) ? BNN_HIP_ERR_UNSUPPORTED : BNN_HIP_OK;
+}
 bool hblock_pool_supported(const bnn_hip_hblock_desc* d) {
   return d->C_in == d->planes && (d->planes == 64 || d->planes == 128 || d->planes == 256) && d->H % 2 == 0 && d->W % 2 == 0 &&
          d->rows_per_band % 2 == 0 && (long long)d->H * d->W <= 4096;
@@ -366,7 +381,7 @@ int main(int argc, char** argv) {
   for (long it = 0; it < iters; ++it) {
     ++g_calls;
     int st = 0;
-    switch (rnd() % 42) {
+    switch (rnd() % 44) {
       case 0: { bnn_hip_conv_desc d = pick_desc();
         st = bnn_hip_bconv2d(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(),
                              pick_ptr<uint32_t>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), pick_ptr<float>(), stream);
@@ -509,6 +524,16 @@ int main(int argc, char** argv) {
                                          pick_ptr<float>(), pick_ptr<float>(), pick_ptr<uint64_t>(), pick_ptr<uint64_t>(),
                                          pick_ptr<uint64_t>(), stream);
         break; }
+      case 41: { bnn_hip_hblock_desc d; int* f = reinterpret_cast<int*>(&d);
+        for (size_t i = 0; i < sizeof(d) / sizeof(int); ++i) f[i] = pick_int();
+        if (rnd() % 2) { d.C_in = 64 << (rnd() % 2); d.planes = 2 * d.C_in; d.flags = (int)(rnd() % 2) * 64; d.H = d.W = 1 + (int)(rnd() % 56);
+                         d.rows_per_band = d.images_per_band = d.waves = 0; }
+        (void)bnn_hip_hblock_shortcut_supported(rnd() % 16 ? &d : nullptr);
+        st = bnn_hip_hblock_shortcut_forward(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint32_t>(), pick_ptr<float>(),
+                                             pick_ptr<uint64_t>(), pick_ptr<uint64_t>(), pick_ptr<uint32_t>(), pick_ptr<float>(),
+                                             pick_ptr<float>(), pick_ptr<uint64_t>(), stream);
+        break; }
+      case 42: st = bnn_hip_hblock_pack_shortcut_weights(pick_int(), pick_int(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(), stream); break;
       case 37: st = bnn_hip_hblock_pack_weights(pick_int(), pick_int(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(), pick_ptr<uint32_t>(),
                                                 pick_ptr<uint32_t>(), stream); break;
       case 33: st = bnn_hip_xnor_grad_pack_weight_f32(pick_ptr<float>(), pick_int(), pick_int(), pick_int(), pick_int(), pick_int(),
