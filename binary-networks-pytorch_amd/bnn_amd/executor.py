@@ -620,14 +620,15 @@ class FusedResNet(nn.Module):
                 N, _, H, W = sp.shape
                 key = ("sc", N, H, W)
                 ok = b["hgeo"].get(key)
-                if ok is None:     # (the small-image form has no such variant: where it is the faster block, the 1x1 launch stays)
+                if ok is None:     # (in the form of the block that _hblock_ok chose for this geometry)
                     ok = b["hgeo"][key] = (self._hblock_ok(b, N, H, W) and
-                                           (not b["hcl"][(N, H, W)] or os.environ.get("BNN_AMD_HBLOCK_SHORTCUT_OVER_CL") == "1") and
-                                           hipops.hblock_shortcut_supported(N, hp.c_in, H, W, hp.planes, self.throughput_mode))
+                                           hipops.hblock_shortcut_supported(N, hp.c_in, H, W, hp.planes, self.throughput_mode,
+                                                                            channel_lanes=b["hcl"][(N, H, W)]))
                 if ok:
                     if not mine:
                         packed = hipops.bn_act_pack(t, *b["bn"][0], relu=True)
-                    y, pk = hipops.hblock_shortcut_forward(packed, hp, sp, b["hsc"], throughput=self.throughput_mode)
+                    y, pk = hipops.hblock_shortcut_forward(packed, hp, sp, b["hsc"], throughput=self.throughput_mode,
+                                                           channel_lanes=b["hcl"][(N, H, W)])
                     pk._h_for = nxt
                     return y, pk
             idn, _ = conv.run(sp, out_f32=True, out_packed=False)

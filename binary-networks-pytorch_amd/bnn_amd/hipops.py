@@ -784,10 +784,10 @@ def hblock_forward(a: PackedAct, pack: HBlockPack, residual: torch.Tensor, out_p
 
 
 def hblock_shortcut_supported(N: int, c_in: int, H: int, W: int, planes: int, throughput: bool = False, rows_per_band: int = 0,
-                              images_per_band: int = 0, waves: int = 0) -> bool:
+                              images_per_band: int = 0, waves: int = 0, channel_lanes: bool = False) -> bool:
     """Whether ``hblock_shortcut_forward`` covers this geometry (with this plan) on the current device."""
     lib = native.require()
-    d = _hblock_desc(N, c_in, H, W, planes, throughput, rows_per_band, images_per_band, waves)
+    d = _hblock_desc(N, c_in, H, W, planes, throughput, rows_per_band, images_per_band, waves, channel_lanes)
     return bool(lib.bnn_hip_hblock_shortcut_supported(ctypes.byref(d)))
 
 
@@ -808,7 +808,7 @@ def hblock_shortcut_pack(w: PackedWeight):
 
 
 def hblock_shortcut_forward(a: PackedAct, pack: HBlockPack, sc: PackedAct, sc_pack, throughput: bool = False,
-                            rows_per_band: int = 0, images_per_band: int = 0, waves: int = 0):
+                            rows_per_band: int = 0, images_per_band: int = 0, waves: int = 0, channel_lanes: bool = False):
     """The first hierarchical block of a stage with its shortcut (``BatchNorm -> sign -> conv1x1``,
     hierarchical_block.py:30-36) computed inside the launch from the sign planes ``sc`` of that binarisation:
     no shortcut launch, no fp32 shortcut tensor.  Returns ``(y, PackedAct of the next block's input)``."""
@@ -828,8 +828,9 @@ def hblock_shortcut_forward(a: PackedAct, pack: HBlockPack, sc: PackedAct, sc_pa
                        nonneg=True)
         if N == 0:
             return y, pk
-        d = _hblock_desc(N, c_in, H, W, pack.planes, throughput, rows_per_band, images_per_band, waves)
-        native.check(lib.bnn_hip_hblock_shortcut_forward(ctypes.byref(d), a.P.data_ptr(), pack.weights.data_ptr(),
+        d = _hblock_desc(N, c_in, H, W, pack.planes, throughput, rows_per_band, images_per_band, waves, channel_lanes)
+        wbuf = pack.channel_lane_weights() if channel_lanes else pack.weights
+        native.check(lib.bnn_hip_hblock_shortcut_forward(ctypes.byref(d), a.P.data_ptr(), wbuf.data_ptr(),
                                                          pack.consts.data_ptr(), sc.P.data_ptr(), sc.M.data_ptr(),
                                                          wsc.data_ptr(), asc.data_ptr(), y.data_ptr(), pk.P.data_ptr(),
                                                          _stream(dev)), "bnn_hip_hblock_shortcut_forward")

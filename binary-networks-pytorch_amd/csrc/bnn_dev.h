@@ -189,6 +189,10 @@ bool hblock_cl_supported(const bnn_hip_hblock_desc* d);
 int launch_hblock_cl_pack_weights(int C_in, int planes, const uint32_t* const w[3], uint32_t* dst, hipStream_t s);
 int launch_hblock_cl(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc, const float* res,
                      float* out, uint64_t* outP, hipStream_t stream);
+bool hblock_cl_ds_supported(const bnn_hip_hblock_desc* d);
+int launch_hblock_cl_ds(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc,
+                        const uint64_t* dsP, const uint64_t* dsM, const uint32_t* dsW, const float* dsA, float* out,
+                        uint64_t* outP, hipStream_t stream);
 // xnor_train.hip: XNORWeightBinarizer under autograd, value and backward
 int launch_xnor_grad_pack(const float* w, int O, int C, int ks, int center, int compute_alpha, void* packed, float* alpha,
                           hipStream_t s);

@@ -913,7 +913,8 @@ int bnn_hip_hblock_pool_forward(const bnn_hip_hblock_desc* d, const uint64_t* in
 }
 
 int bnn_hip_hblock_shortcut_supported(const bnn_hip_hblock_desc* d) {
-  if (check_hblock(d) != BNN_HIP_OK || (d->flags & BNN_HIP_HBLOCK_CHANNEL_LANES)) return 0;
+  if (check_hblock(d) != BNN_HIP_OK) return 0;
+  if (d->flags & BNN_HIP_HBLOCK_CHANNEL_LANES) return bnn::hblock_cl_ds_supported(d) ? 1 : 0;
   return bnn::hblock_ds_supported(d) ? 1 : 0;
 }
 
@@ -931,11 +932,17 @@ int bnn_hip_hblock_shortcut_forward(const bnn_hip_hblock_desc* d, const uint64_t
                                     void* stream) {
   const int st = check_hblock(d);
   if (st != BNN_HIP_OK) return st;
-  if (d->flags & BNN_HIP_HBLOCK_CHANNEL_LANES) return BNN_HIP_ERR_INVALID_ARG;
   if (!in_P || !weights || !consts || !sc_P || !sc_M || !sc_weights || !sc_alpha || !out || !out_P) return BNN_HIP_ERR_INVALID_ARG;
   if (!aligned(in_P, 8) || !aligned(weights, 64) || !aligned(consts, 8) || !aligned(sc_P, 8) || !aligned(sc_M, 8) ||
       !aligned(sc_weights, 32) || !aligned(sc_alpha, 32) || !aligned(out, 4) || !aligned(out_P, 8))
     return BNN_HIP_ERR_INVALID_ARG;
+  if (d->flags & BNN_HIP_HBLOCK_CHANNEL_LANES) {   // (weights: those of bnn_hip_hblock_pack_weights_cl)
+    if (!bnn::hblock_cl_ds_supported(d)) return BNN_HIP_ERR_UNSUPPORTED;
+    g_launches.fetch_add(1, std::memory_order_relaxed);
+    Range range("bnn_hip_hblock_shortcut_forward(channel lanes)");
+    return bnn::launch_hblock_cl_ds(d, in_P, weights, consts, sc_P, sc_M, sc_weights, sc_alpha, out, out_P,
+                                    static_cast<hipStream_t>(stream));
+  }
   if (!bnn::hblock_ds_supported(d)) return BNN_HIP_ERR_UNSUPPORTED;
   g_launches.fetch_add(1, std::memory_order_relaxed);
   BNN_RANGE();

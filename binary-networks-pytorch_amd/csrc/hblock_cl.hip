@@ -39,6 +39,17 @@ struct ClGeo {
   unsigned lds16;
   unsigned na_off, nb_off;
   unsigned f32_bytes;
+  unsigned lds_sc;    // DSW > 0: the shortcut's sign planes [H * W pixels][P: DSW words | M: DSW words], then int32 [H * W]:
+  unsigned lds_scnz;  //          non-zero inputs of every pixel
+};
+
+// DSW > 0 (csrc/hblock.hip: HbDs): the block's shortcut convolution — binary 1 x 1 over another binarisation of the block's
+// input — computed here instead of read as a residual tensor.
+struct ClDs {
+  const uint64_t* P;
+  const uint64_t* M;
+  const uint32_t* W;   // [C][DSW]
+  const float* A;      // [C]
 };
 
 namespace {
@@ -131,9 +142,9 @@ struct ClVec<2> { using type = uint2; };
 
 // One unit: 64 output channels (group cg) x the R image rows from r0 on, of convolution K of the block.
 //   W: image width (= height: 14 or 7);  R: rows of the tile;  KW: words per K-step
-template <int W, int R, int KW, int K, bool NEXT>
+template <int W, int R, int KW, int K, bool NEXT, int DSW = 0>
 __device__ __forceinline__ void cl_unit(const uint32_t* __restrict__ Wt, const float* __restrict__ Kc,
-                                        const float* __restrict__ res, float* __restrict__ out, const ClGeo& g,
+                                        const float* __restrict__ res, float* __restrict__ out, const ClDs& ds, const ClGeo& g,
                                         unsigned char* smem, int n, int cg, int r0, int lane,
                                         typename ClVec<KW>::type (&wnext)[9], int cg_following) {
   constexpr int H = W, T = R * W, HW = H * W;
@@ -160,7 +171,26 @@ __device__ __forceinline__ void cl_unit(const uint32_t* __restrict__ Wt, const f
   // stores — half the instructions and of the partial-line writes L2 has to merge; 7 x 7 images: 196-byte planes, dwords)
   constexpr bool VEC2 = W == 14;
   float resv[T];
-  if constexpr (VEC2) {
+  [[maybe_unused]] uint32_t wsc[DSW > 0 ? DSW : 1];
+  [[maybe_unused]] float asc = 0.0f;
+  // DSW > 0: the shortcut value of (pixel, this lane's channel) is computed in the epilogue, where the K-step's weight
+  // registers are free; this lane's 1 x 1 weights travel under the popcount loop where the registers allow it (W = 14: 142
+  // of 168; the 7 x 7 form is at 168 without them and fetches them in front of the epilogue)
+  constexpr bool SC_EARLY = DSW > 0 && W == 14;
+  auto load_sc = [&]() {
+    if constexpr (DSW > 0) {
+      const uint4* wp = reinterpret_cast<const uint4*>(ds.W + (size_t)co * DSW);
+#pragma unroll
+      for (int q = 0; q < DSW / 4; ++q) {
+        const uint4 v = wp[q];
+        wsc[4 * q] = v.x; wsc[4 * q + 1] = v.y; wsc[4 * q + 2] = v.z; wsc[4 * q + 3] = v.w;
+      }
+      asc = ds.A[co];
+    }
+  };
+  if constexpr (DSW > 0) {
+    if constexpr (SC_EARLY) load_sc();
+  } else if constexpr (VEC2) {
 #pragma unroll
     for (int p = 0; p < T; p += 2) {
       const float2 v2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(res) + voff + (unsigned)(p * 4));
@@ -239,6 +269,7 @@ __device__ __forceinline__ void cl_unit(const uint32_t* __restrict__ Wt, const f
       });
     });
   }
+  if constexpr (DSW > 0 && !SC_EARLY) load_sc();
   // epilogue, pixel by pixel (lane = channel): the float operations of csrc/hblock.hip
   uint32_t ilo = 0u, ihi = 0u, nlo = 0u, nhi = 0u;   // lane p: the 64 sign bits of pixel p (internal / next block)
   const unsigned ovoff = voff;
@@ -257,6 +288,23 @@ __device__ __forceinline__ void cl_unit(const uint32_t* __restrict__ Wt, const f
       const unsigned long long m = __builtin_amdgcn_ballot_w64(is_pos(v));
       cl_writelane2<p>(ilo, ihi, m);
 #endif
+    }
+    if constexpr (DSW > 0) {
+      // dot = 2 * (agreeing non-zero inputs) - (non-zero inputs) over the pixel's two plane words (wave-uniform: broadcast
+      // reads), value = fmaf(alpha, dot, 0) as bnn_hip_bconv2d rounds it
+      const uint32_t* scp = reinterpret_cast<const uint32_t*>(smem + g.lds_sc) + (size_t)(r0 * W + p) * (2 * DSW);
+      int agree = 0;
+#pragma unroll
+      for (int q = 0; q < DSW / 4; ++q) {
+        const uint4 pv = *reinterpret_cast<const uint4*>(scp + 4 * q);
+        const uint4 mv = *reinterpret_cast<const uint4*>(scp + DSW + 4 * q);
+        agree += __builtin_popcount((pv.x & wsc[4 * q]) | (mv.x & ~wsc[4 * q]));
+        agree += __builtin_popcount((pv.y & wsc[4 * q + 1]) | (mv.y & ~wsc[4 * q + 1]));
+        agree += __builtin_popcount((pv.z & wsc[4 * q + 2]) | (mv.z & ~wsc[4 * q + 2]));
+        agree += __builtin_popcount((pv.w & wsc[4 * q + 3]) | (mv.w & ~wsc[4 * q + 3]));
+      }
+      const int scnz = reinterpret_cast<const int*>(smem + g.lds_scnz)[r0 * W + p];
+      resv[p] = __builtin_fmaf(asc, (float)(2 * agree - scnz), 0.0f);
     }
     const float y = ov + resv[p];
     if constexpr (VEC2) {
@@ -308,24 +356,24 @@ struct ClTiles<7> {
   static constexpr int N = 4;
 };
 
-template <int W, int KW, int K, bool NEXT>
+template <int W, int KW, int K, bool NEXT, int DSW>
 __device__ __forceinline__ void cl_unit_of_tile(const uint32_t* __restrict__ Wt, const float* __restrict__ Kc,
-                                                const float* __restrict__ res, float* __restrict__ out, const ClGeo& g,
-                                                unsigned char* smem, int n, int cg, int tile, int lane,
+                                                const float* __restrict__ res, float* __restrict__ out, const ClDs& ds,
+                                                const ClGeo& g, unsigned char* smem, int n, int cg, int tile, int lane,
                                                 typename ClVec<KW>::type (&wnext)[9], int cg_following) {
   if constexpr (W == 14) {
-    cl_unit<14, 1, KW, K, NEXT>(Wt, Kc, res, out, g, smem, n, cg, tile, lane, wnext, cg_following);
+    cl_unit<14, 1, KW, K, NEXT, DSW>(Wt, Kc, res, out, ds, g, smem, n, cg, tile, lane, wnext, cg_following);
   } else {
-    if (tile < 3) cl_unit<7, 2, KW, K, NEXT>(Wt, Kc, res, out, g, smem, n, cg, 2 * tile, lane, wnext, cg_following);
-    else cl_unit<7, 1, KW, K, NEXT>(Wt, Kc, res, out, g, smem, n, cg, 6, lane, wnext, cg_following);
+    if (tile < 3) cl_unit<7, 2, KW, K, NEXT, DSW>(Wt, Kc, res, out, ds, g, smem, n, cg, 2 * tile, lane, wnext, cg_following);
+    else cl_unit<7, 1, KW, K, NEXT, DSW>(Wt, Kc, res, out, ds, g, smem, n, cg, 6, lane, wnext, cg_following);
   }
 }
 
 // Convolution K: units (tile, channel group) from a ticket counter; a unit waits for the tiles of convolution K - 1 that
 // hold the rows under its windows (all their channel groups) — no barrier between the convolutions (csrc/hblock.hip).
-template <int W, int KW, int K, bool NEXT>
+template <int W, int KW, int K, bool NEXT, int DSW>
 __device__ __forceinline__ void cl_phase(const uint32_t* __restrict__ Wt, const float* __restrict__ Kc,
-                                         const float* __restrict__ res, float* __restrict__ out, const ClGeo& g,
+                                         const float* __restrict__ res, float* __restrict__ out, const ClDs& ds, const ClGeo& g,
                                          unsigned char* smem, int n, int lane) {
   constexpr int NT = ClTiles<W>::N;
   const ClPhase& ph = g.ph[K];
@@ -369,7 +417,7 @@ __device__ __forceinline__ void cl_phase(const uint32_t* __restrict__ Wt, const 
 #endif
     }
 #if !defined(CL_DBG_STAGE) || CL_DBG_STAGE != 4
-    cl_unit_of_tile<W, KW, K, NEXT>(Wt, Kc, res, out, g, smem, n, cg, tile, lane, wnext, cg_following);
+    cl_unit_of_tile<W, KW, K, NEXT, DSW>(Wt, Kc, res, out, ds, g, smem, n, cg, tile, lane, wnext, cg_following);
 #endif
 #if defined(CL_DBG_STAGE) && CL_DBG_STAGE == 3
     break;
@@ -381,11 +429,11 @@ __device__ __forceinline__ void cl_phase(const uint32_t* __restrict__ Wt, const 
 }
 
 // One workgroup = one image.  KW3: words per K-step of conv3 (2 when its input has 64 channels).
-template <int W, int KW3, bool NEXT>
+template <int W, int KW3, bool NEXT, int DSW = 0>
 __global__ __launch_bounds__(CL_MAX_WAVES * 64) void hblock_cl_kernel(const uint64_t* __restrict__ inP, const uint32_t* __restrict__ Wt,
                                                         const float* __restrict__ Kc, const float* __restrict__ res,
                                                         float* __restrict__ out, uint64_t* __restrict__ outP,
-                                                        const ClGeo g) {
+                                                        const ClGeo g, const ClDs ds) {
   constexpr int H = W, HW = H * W;
   unsigned char* smem = cl_smem;
   const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
@@ -411,19 +459,30 @@ __global__ __launch_bounds__(CL_MAX_WAVES * 64) void hblock_cl_kernel(const uint
         __hip_atomic_fetch_add(q + (t / 3) * (W + 2) + t % 3, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
+  if constexpr (DSW > 0) {   // the shortcut's planes, pixel-major, and the non-zero inputs of every pixel
+    uint32_t* sp = reinterpret_cast<uint32_t*>(smem + g.lds_sc);
+    int* snz = reinterpret_cast<int*>(smem + g.lds_scnz);
+    for (int i = tid; i < (DSW / 2) * HW; i += nthr) {
+      const int gq = i / HW, r = i - gq * HW;
+      const uint64_t pv = ds.P[((size_t)n * (DSW / 2) + gq) * HW + r], mv = ds.M[((size_t)n * (DSW / 2) + gq) * HW + r];
+      *reinterpret_cast<uint2*>(sp + (size_t)r * (2 * DSW) + 2 * gq) = uint2{(uint32_t)pv, (uint32_t)(pv >> 32)};
+      *reinterpret_cast<uint2*>(sp + (size_t)r * (2 * DSW) + DSW + 2 * gq) = uint2{(uint32_t)mv, (uint32_t)(mv >> 32)};
+      __hip_atomic_fetch_add(snz + r, __builtin_popcountll(pv | mv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
   __syncthreads();
 #if defined(CL_DBG_STAGE) && CL_DBG_STAGE == 0
   return;
 #endif
-  cl_phase<W, 4, 0, NEXT>(Wt, Kc, res, out, g, smem, n, lane);
+  cl_phase<W, 4, 0, NEXT, DSW>(Wt, Kc, res, out, ds, g, smem, n, lane);
 #if defined(CL_DBG_STAGE) && (CL_DBG_STAGE == 1 || CL_DBG_STAGE == 3 || CL_DBG_STAGE == 4)
   return;
 #endif
-  cl_phase<W, 4, 1, NEXT>(Wt, Kc, res, out, g, smem, n, lane);
+  cl_phase<W, 4, 1, NEXT, DSW>(Wt, Kc, res, out, ds, g, smem, n, lane);
 #if defined(CL_DBG_STAGE) && CL_DBG_STAGE == 2
   return;
 #endif
-  cl_phase<W, KW3, 2, NEXT>(Wt, Kc, res, out, g, smem, n, lane);
+  cl_phase<W, KW3, 2, NEXT, DSW>(Wt, Kc, res, out, ds, g, smem, n, lane);
   if constexpr (NEXT) {
     __syncthreads();
     const int ngo = g.C >> 6;
@@ -466,7 +525,7 @@ bool cl_shape(int C_in, int planes, ClShape& s) {
   return true;   // (every convolution has a multiple of 64 output channels: planes % 256 == 0)
 }
 
-long long cl_lds(const ClShape& s, int W, int planes, bool next, ClGeo* g) {
+long long cl_lds(const ClShape& s, int W, int planes, bool next, ClGeo* g, int dsw = 0) {
   const int H = W;
   long long off = 16;
   const int nt = W == 14 ? 14 : 4;
@@ -480,6 +539,12 @@ long long cl_lds(const ClShape& s, int W, int planes, bool next, ClGeo* g) {
   }
   if (g) g->lds_out = (unsigned)off;
   if (next) off += ((long long)H * W * (planes / 32) * 4 + 15) / 16 * 16;
+  if (dsw > 0) {
+    if (g) g->lds_sc = (unsigned)off;
+    off += ((long long)H * W * 2 * dsw * 4 + 15) / 16 * 16;
+    if (g) g->lds_scnz = (unsigned)off;
+    off += ((long long)H * W * 4 + 15) / 16 * 16;
+  }
   return off;
 }
 
@@ -518,8 +583,36 @@ int launch_hblock_cl_pack_weights(int C_in, int planes, const uint32_t* const w[
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
 
+namespace {
+int cl_dsw(const bnn_hip_hblock_desc* d) { return d->C_in / 32; }
+int cl_run(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc, const float* res,
+           float* out, uint64_t* outP, hipStream_t stream, const ClDs* dsp);
+}  // namespace
+
+bool hblock_cl_ds_supported(const bnn_hip_hblock_desc* d) {
+  ClShape s;
+  if (!hblock_cl_supported(d) || !cl_shape(d->C_in, d->planes, s) || d->planes != 2 * d->C_in) return false;
+  if (d->C_in != 128 && d->C_in != 256) return false;
+  return cl_lds(s, d->W, d->planes, true, nullptr, cl_dsw(d)) <= 64 * 1024;
+}
+
 int launch_hblock_cl(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc,
                      const float* res, float* out, uint64_t* outP, hipStream_t stream) {
+  return cl_run(d, inP, W, Kc, res, out, outP, stream, nullptr);
+}
+
+// ... with the shortcut convolution inside (csrc/hblock.hip: launch_hblock_ds)
+int launch_hblock_cl_ds(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc,
+                        const uint64_t* dsP, const uint64_t* dsM, const uint32_t* dsW, const float* dsA, float* out,
+                        uint64_t* outP, hipStream_t stream) {
+  if (!hblock_cl_ds_supported(d) || outP == nullptr) return BNN_HIP_ERR_UNSUPPORTED;
+  const ClDs ds{dsP, dsM, dsW, dsA};
+  return cl_run(d, inP, W, Kc, nullptr, out, outP, stream, &ds);
+}
+
+namespace {
+int cl_run(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc, const float* res,
+           float* out, uint64_t* outP, hipStream_t stream, const ClDs* dsp) {
   ClShape s;
   bnn_hip_hblock_layout L;
   long long woff[3];
@@ -532,7 +625,8 @@ int launch_hblock_cl(const bnn_hip_hblock_desc* d, const uint64_t* inP, const ui
   g.C = d->planes;
   g.ng_in = d->C_in / 64;
   const bool next = outP != nullptr;
-  g.lds16 = (unsigned)((cl_lds(s, d->W, d->planes, next, &g) + 15) / 16);
+  const int dsw = dsp ? cl_dsw(d) : 0;
+  g.lds16 = (unsigned)((cl_lds(s, d->W, d->planes, next, &g, dsw) + 15) / 16);
   int c_off = 0;
   for (int k = 0; k < 3; ++k) {
     ClPhase& p = g.ph[k];
@@ -552,9 +646,19 @@ int launch_hblock_cl(const bnn_hip_hblock_desc* d, const uint64_t* inP, const ui
   g.f32_bytes = (unsigned)((long long)d->N * d->planes * d->H * d->W * 4);
   const int waves = d->waves > 0 ? std::min(d->waves, CL_MAX_WAVES) : CL_MAX_WAVES;
   const size_t lds = (size_t)g.lds16 * 16;
+  const ClDs none{nullptr, nullptr, nullptr, nullptr};
+#define CL_LAUNCH_DS(W_, KW3_, DSW_)                                                                                    \
+  hipLaunchKernelGGL((hblock_cl_kernel<W_, KW3_, true, DSW_>), dim3((unsigned)d->N), dim3((unsigned)waves * kWave), lds,    \
+                     stream, inP, W, Kc, res, out, outP, g, *dsp)
+  if (dsp != nullptr) {   // planes == 2 * C_in: 128 -> 256 (conv3 reads 64 channels: KW3 = 2), 256 -> 512 (KW3 = 4)
+    if (d->W == 14) { if (dsw == 4) CL_LAUNCH_DS(14, 2, 4); else CL_LAUNCH_DS(14, 4, 8); }
+    else { if (dsw == 4) CL_LAUNCH_DS(7, 2, 4); else CL_LAUNCH_DS(7, 4, 8); }
+    return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
+  }
+#undef CL_LAUNCH_DS
 #define CL_LAUNCH(W_, KW3_, NEXT_)                                                                                      \
   hipLaunchKernelGGL((hblock_cl_kernel<W_, KW3_, NEXT_>), dim3((unsigned)d->N), dim3((unsigned)waves * kWave), lds, stream, \
-                     inP, W, Kc, res, out, outP, g)
+                     inP, W, Kc, res, out, outP, g, none)
   if (d->W == 14) {
     if (s.kw[2] == 2) { if (next) CL_LAUNCH(14, 2, true); else CL_LAUNCH(14, 2, false); }
     else { if (next) CL_LAUNCH(14, 4, true); else CL_LAUNCH(14, 4, false); }
@@ -565,5 +669,6 @@ int launch_hblock_cl(const bnn_hip_hblock_desc* d, const uint64_t* inP, const ui
 #undef CL_LAUNCH
   return hipGetLastError() == hipSuccess ? BNN_HIP_OK : BNN_HIP_ERR_LAUNCH;
 }
+}  // namespace
 
 }  // namespace bnn

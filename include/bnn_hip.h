@@ -557,8 +557,9 @@ int bnn_hip_hblock_pool_forward(const bnn_hip_hblock_desc* d, const uint64_t* in
  * bnn_hip_hblock_pool_forward or bnn_hip_avgpool2_bn_pack2_f32 wrote), the 1 x 1 weights as [planes][C_in / 32] words
  * (bnn_hip_hblock_pack_shortcut_weights of the standard pack; no zero weights, no bias) and their alpha [planes], and
  * computes  shortcut = fmaf(alpha[c], dot, 0)  per pass — the integer and the one rounding of bnn_hip_bconv2d — so the
- * shortcut launch and its fp32 tensor disappear.  planes == 2 * C_in, C_in in {64, 128}; out_P is required (a next block in
- * the stage); same bits as bnn_hip_bconv2d + bnn_hip_hblock_forward.  */
+ * shortcut launch and its fp32 tensor disappear.  planes == 2 * C_in, C_in in {64, 128} — with
+ * BNN_HIP_HBLOCK_CHANNEL_LANES (14 x 14 / 7 x 7 images, weights of bnn_hip_hblock_pack_weights_cl) C_in in {128, 256};
+ * out_P is required (a next block in the stage); same bits as bnn_hip_bconv2d + bnn_hip_hblock_forward.  */
 int bnn_hip_hblock_shortcut_supported(const bnn_hip_hblock_desc* d);
 int bnn_hip_hblock_pack_shortcut_weights(int C_in, int planes, const uint32_t* wbits, uint32_t* weights, void* stream);
 int bnn_hip_hblock_shortcut_forward(const bnn_hip_hblock_desc* d, const uint64_t* in_P, const uint32_t* weights,

@@ -210,7 +210,8 @@ def test_pool_form_argument_checks():
         hipops.hblock_pool_forward(p_in, pack, res, kp, rows_per_band=3)
 
 
-SC_SHAPES = [(64, 3, 28, 28), (128, 5, 14, 14), (64, 2, 9, 13), (128, 2, 5, 5), (64, 130, 28, 28)]   # C_in (planes = 2 C_in), N, H, W
+SC_SHAPES = [(64, 3, 28, 28), (128, 5, 14, 14), (64, 2, 9, 13), (128, 2, 5, 5), (64, 130, 28, 28), (256, 9, 7, 7), (128, 3, 7, 7),
+             (256, 3, 14, 14)]   # C_in (planes = 2 C_in), N, H, W
 
 
 @pytest.mark.parametrize("shape", SC_SHAPES, ids=lambda s: "x".join(map(str, s)))
@@ -235,7 +236,9 @@ def test_first_block_of_a_stage_with_its_shortcut_convolution_inside(shape):
     want_y, want_p = hipops.hblock_forward(p_in, pack, idn)
     sc_pack = hipops.hblock_shortcut_pack(pw_sc)
     ran = 0
-    for plan in PLANS:
+    pixel_lanes = hipops.hblock_shortcut_supported(N, c_in, H, W, planes)
+    assert pixel_lanes == (c_in in (64, 128))              # (256 -> 512: the small-image form only)
+    for plan in PLANS if pixel_lanes else ():
         if plan.get("rows_per_band", 0) > H or plan.get("images_per_band", 0) > N:
             continue
         if not hipops.hblock_shortcut_supported(N, c_in, H, W, planes, **plan):
@@ -245,7 +248,14 @@ def test_first_block_of_a_stage_with_its_shortcut_convolution_inside(shape):
         assert torch.equal(y, want_y), plan
         assert torch.equal(p.P, want_p.P) and p.nonneg, plan
         ran += 1
-    assert ran >= 4
+    assert ran >= 4 or not pixel_lanes
+    # the small-image form (lanes = output channels) has the same variant from 128 input channels on
+    cl = hipops.hblock_shortcut_supported(N, c_in, H, W, planes, channel_lanes=True)
+    assert cl == ((H, W) in ((14, 14), (7, 7)) and c_in in (128, 256))
+    if cl:
+        for waves in (0, 4, 3):
+            y, p = hipops.hblock_shortcut_forward(p_in, pack, p_sc, sc_pack, channel_lanes=True, waves=waves)
+            assert torch.equal(y, want_y) and torch.equal(p.P, want_p.P), waves
 
 
 def test_shortcut_form_argument_checks():

@@ -125,6 +125,16 @@ int hblock_layout(int C_in, int planes, bnn_hip_hblock_layout* L) {
   L->const_floats = 4LL * planes;
   return BNN_HIP_OK;
 }
+bool hblock_cl_ds_supported(const bnn_hip_hblock_desc* d) {
+  return d->planes == 2 * d->C_in && (d->C_in == 128 || d->C_in == 256) && d->H == d->W && (d->H == 7 || d->H == 14);
+}
+int launch_hblock_cl_ds(const bnn_hip_hblock_desc* d, const uint64_t* inP, const uint32_t* W, const float* Kc, const uint64_t* p,
+                        const uint64_t* m, const uint32_t* w, const float* a, float* out, uint64_t* outP, hipStream_t) {
+  ++g_reached;
+  REQUIRE(d && inP && W && Kc && p && m && w && a && out && outP && al(w, 32) && al(a, 32) && al(outP, 8));
+  REQUIRE(d->N > 0 && d->planes == 2 * d->C_in && d->H == d->W);
+  return BNN_HIP_OK;
+}
 bool hblock_ds_supported(const bnn_hip_hblock_desc* d) {
   return d->planes == 2 * d->C_in && (d->C_in == 64 || d->C_in == 128) && (long long)d->H * d->W <= 4096;
 }
@@ -526,7 +536,7 @@ int main(int argc, char** argv) {
         break; }
       case 41: { bnn_hip_hblock_desc d; int* f = reinterpret_cast<int*>(&d);
         for (size_t i = 0; i < sizeof(d) / sizeof(int); ++i) f[i] = pick_int();
-        if (rnd() % 2) { d.C_in = 64 << (rnd() % 2); d.planes = 2 * d.C_in; d.flags = (int)(rnd() % 2) * 64; d.H = d.W = 1 + (int)(rnd() % 56);
+        if (rnd() % 2) { d.C_in = 64 << (rnd() % 3); d.planes = 2 * d.C_in; d.flags = (int)(rnd() % 2) * 64 + (int)(rnd() % 2) * 128; d.H = d.W = (rnd() % 2) ? (rnd() % 2 ? 7 : 14) : 1 + (int)(rnd() % 56);
                          d.rows_per_band = d.images_per_band = d.waves = 0; }
         (void)bnn_hip_hblock_shortcut_supported(rnd() % 16 ? &d : nullptr);
         st = bnn_hip_hblock_shortcut_forward(rnd() % 16 ? &d : nullptr, pick_ptr<uint64_t>(), pick_ptr<uint32_t>(), pick_ptr<float>(),
