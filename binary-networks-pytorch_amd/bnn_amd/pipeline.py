@@ -179,7 +179,9 @@ class TwoHalves:
     # side by side (a stem fills the register files): the half that starts second finishes ~one stem later, and nothing
     # of the NEXT call may start before both are done (the caller's tensors are ordered on the caller's stream).  The
     # side half therefore gets fewer images: 136 + 120 of 256 measured best (k images/s, 20 steps / sustained: 128 + 128
-    # 224.6 / 240.2, 136 + 120 239.3 / 248.2, 144 + 112 221.9 / 232.3; BNN_AMD_SPLIT_SHARE overrides).
+    # 224.6 / 240.2, 136 + 120 239.3 / 248.2, 144 + 112 221.9 / 232.3; BNN_AMD_SPLIT_SHARE overrides).  Three or four parts on
+    # three / four streams: 230.4 / 235.8 and 230.8 / 236.6 against 243.1 / 247.5 — smaller batches per launch cost more
+    # than the shorter first stem gives back.
     SHARE_CUR = float(os.environ.get("BNN_AMD_SPLIT_SHARE", "0.53"))
 
     def _split(self, n: int) -> int:
