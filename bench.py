@@ -957,7 +957,8 @@ def bench_net(args, world, rank, device, info, timed):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps": head_spin,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": DTYPE if not c5 else DTYPE.replace("fp32 operands split into fp16 hi+lo", "plain fp16 operands (BNN_HIP_STEM_FP16)"),
+        "dtype": DTYPE if not c5 else DTYPE.replace("fp32 operands split into fp16 hi+lo", "plain fp16 operands (BNN_HIP_STEM_FP16)")
+                                         .replace("19 binary convs", "51 binary convs").replace("3e-7 relative", "5e-4 relative"),
         "data": "synthetic",
         "config": {"workload": f"{name} 224x224 full forward, batch {B} per GPU",
                    "engine": args.engine, "engine_note": ENGINE_NOTES[args.engine], "batches_in_flight": n_streams,
