@@ -40,7 +40,7 @@ for extra in ("c2", "c5"):
     if os.path.exists(fn) and open(fn).read().strip():
         ln = open(fn).read().strip().splitlines()[-1]
         cmd = {"c2": "python bench.py --config c2 --steps 20 --warmup 5",
-               "c5": "python bench.py --config c5 --steps 200 --warmup 20 --no-cpu-baseline --no-roofline"}[extra]
+               "c5": "python bench.py --config c5 --no-cpu-baseline --no-roofline"}[extra]
         open(os.path.join(dst, f"{tag}_bench_{extra}.json"), "w").write(stamped(ln, cmd) + "\n")
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if stats:

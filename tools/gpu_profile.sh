@@ -7,7 +7,7 @@ timeout 900 python "$R/bench.py" --steps 20 --warmup 5 2>/dev/null | tail -1 > "
 # full-size parity records (gpurun_out/c3_b256_parity_*.json) of the same build
 ( cd "$R" && timeout 600 python -m pytest tests/test_gpu_c3_full.py -q --timeout 300 2>&1 | tail -2 > "$OUT/c3_full.txt" )
 timeout 300 python "$R/bench.py" --config c2 --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/bench_c2.json"
-timeout 600 python "$R/bench.py" --config c5 --steps 200 --warmup 20 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > "$OUT/bench_c5.json"
+timeout 600 python "$R/bench.py" --config c5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > "$OUT/bench_c5.json"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python "$R/bench.py" --steps 20 --warmup 5 --sustain 0 --no-extras --no-cpu-baseline > "$OUT/stats.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats1" -o bench1 -- python "$R/bench.py" --steps 20 --warmup 5 --spinup 200 --sustain 0 --streams 1 --no-extras --no-cpu-baseline --no-roofline > "$OUT/stats1.log" 2>&1   # (200 spin-up steps: the TRACE of this run is what tools/kernel_roofline.py reads, and traces above 8 MB are deleted below)
 if [ "${QUICK:-0}" = "1" ]; then   # bench lines, kernel-trace stats and the c2 one-stream CSV only (no PMC, training, stem A/B)
